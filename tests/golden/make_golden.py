@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures FROM THE UNMODIFIED REFERENCE (oracle/_ref/libcorto_ref.so,
+built by oracle/Makefile from /root/reference).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Every fixture is DATA: a .crt blob produced by the reference crt::Encoder plus the arrays the reference
+crt::Decoder returned for it (or their SHA-256 when large), plus Tunstall known-answer tables from
+crt::Tunstall::createDecodingTables2.  The reference has no tests/golden vectors of its own
+(SURVEY.md §4), so these outputs of the reference itself are what pins the oracle and the HIP path.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from corto_amd import synth            # noqa: E402
+from oracle import refcodec as rc      # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def cases():
+    S = synth
+    two_groups = S.bumpy_sphere(32, 16, seed=11)
+    two_groups.groups = [400, two_groups.nface]
+    multi = S.merge([S.closed_sphere(20, 10, seed=1), S.torus(16, 8, seed=2), S.holey_disc(14, seed=3, color_components=4)])
+    radius = S.bumpy_sphere(24, 12, seed=21)
+    radius.radius = (0.25 + np.arange(radius.nvert, dtype=np.float32) % 17).reshape(-1, 1)
+    return [
+        # name, mesh, encode kwargs
+        ("pos_only", S.bumpy_sphere(64, 32, seed=1), dict(with_normal=False, with_color=False, with_uv=False)),
+        ("nrm_diff", S.bumpy_sphere(64, 32, seed=2), dict(normal_prediction=rc.DIFF, with_color=False)),
+        ("nrm_estimated_rgb", S.bumpy_sphere(64, 32, seed=3, color_components=3), dict(normal_prediction=rc.ESTIMATED)),
+        ("c4_unit", S.bumpy_sphere(64, 32, seed=0), dict(normal_prediction=rc.BORDER)),
+        ("two_groups", two_groups, dict(normal_prediction=rc.BORDER)),
+        ("holey_disc", S.shuffled(S.holey_disc(40, seed=5), seed=3), dict(normal_prediction=rc.BORDER)),
+        ("multi_component", multi, dict(normal_prediction=rc.ESTIMATED)),
+        ("torus", S.torus(48, 24, seed=4), dict(normal_prediction=rc.BORDER)),
+        ("closed_sphere", S.closed_sphere(32, 16, seed=6), dict(normal_prediction=rc.DIFF)),
+        ("radius_attr", radius, dict(normal_prediction=rc.BORDER, exif={"mtllib": "a.mtl", "note": "x"})),
+        ("entropy_none", S.bumpy_sphere(32, 16, seed=9), dict(normal_prediction=rc.BORDER, entropy=0)),
+        ("cloud_diff", S.point_cloud(96, 64, seed=7), dict(normal_prediction=rc.DIFF)),
+        ("cloud_border", S.point_cloud(40, 20, seed=8), dict(normal_prediction=rc.BORDER)),
+    ]
+
+
+def main():
+    index = []
+    for name, mesh, kw in cases():
+        blob = rc.encode(mesh, **kw)
+        cc = mesh.color.shape[1] if mesh.color is not None and kw.get("with_color", True) else 4
+        ref = rc.decode_trace(blob, color_components=cc)
+        ref16 = rc.decode(blob, normal_format=rc.INT16, color_components=cc, index16=ref["nvert"] < 65536)
+        d = {"crt": np.asarray(blob).copy()}
+        for k, v in ref.items():
+            if isinstance(v, np.ndarray):
+                d[k] = v
+        d["_max_front"] = np.array(ref["_max_front"])
+        if "normal" in ref16:
+            d["normal_i16"] = ref16["normal"]
+        if "index" in ref16 and ref16["index"].dtype == np.uint16:
+            d["index_u16_sha256"] = np.frombuffer(sha(ref16["index"]).encode(), dtype=np.uint8)
+        d["color_components"] = np.array(cc)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        index.append((name, len(blob), ref["nvert"], ref["nface"]))
+        print("%-20s crt %7d B  nvert %6d nface %6d" % index[-1])
+
+    # mid-size mesh (C1-class, 34 060 verts / 67 600 tris): blob + digests only
+    m = synth.bumpy_sphere(260, 130, seed=34)
+    blob = rc.encode(m, normal_prediction=rc.BORDER)
+    ref = rc.decode(blob)
+    d = {"crt": np.asarray(blob).copy()}
+    for k, v in ref.items():
+        if isinstance(v, np.ndarray):
+            d[k + "_sha256"] = np.frombuffer(sha(v).encode(), dtype=np.uint8)
+    d["nvert"] = np.array(ref["nvert"]); d["nface"] = np.array(ref["nface"])
+    np.savez_compressed(os.path.join(OUT, "mid34k_digest.npz"), **d)
+    print("mid34k_digest        crt %7d B  nvert %6d nface %6d" % (len(blob), ref["nvert"], ref["nface"]))
+
+    # 16 distinct C4-unit blobs (seeds 0..15) for bench / batch tests: blobs + per-array digests
+    d = {}
+    for seed in range(16):
+        m = synth.bumpy_sphere(64, 32, seed=seed)
+        blob = rc.encode(m, normal_prediction=rc.BORDER)
+        ref = rc.decode(blob)
+        d["crt_%02d" % seed] = np.asarray(blob).copy()
+        for k in ("position", "normal", "color", "uv", "index"):
+            d["%s_sha256_%02d" % (k, seed)] = np.frombuffer(sha(ref[k]).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "c4_blobs16.npz"), **d)
+    print("c4_blobs16           %d blobs" % 16)
+
+    # Tunstall known-answer tables (createDecodingTables2) incl. the low-entropy branch, ties, zero tails
+    rng = np.random.default_rng(20250926)
+    kats = {}
+    plist = [np.array([[65, 254], [66, 0]]), np.array([[0, 255], [1, 0]]), np.array([[3, 128], [9, 127]]),
+             np.array([[1, 85], [2, 85], [3, 85]]), np.array([[7, 250], [8, 2], [9, 2], [1, 1]]),
+             np.array([[i, 1] for i in range(255)]), np.array([[i, 255 // 40] for i in range(40)])]
+    for t in range(57):
+        n = int(rng.integers(2, 41))
+        kind = t % 4
+        if kind == 0:
+            p = np.sort(rng.integers(0, 256, n))[::-1]
+        elif kind == 1:
+            p = np.sort((255 * rng.dirichlet(np.ones(n) * 0.3)).astype(int))[::-1]
+        elif kind == 2:
+            p = np.array([250 - n] + list(np.sort(rng.integers(0, 4, n - 1))[::-1]))
+        else:
+            p = np.sort((255 * rng.dirichlet(np.ones(n) * 4)).astype(int))[::-1]
+        plist.append(np.stack([rng.permutation(256)[:n], np.clip(p, 0, 255)], 1))
+    for i, pr in enumerate(plist):
+        pr = pr.astype(np.uint8)
+        idx, ln, tab = rc.tunstall_tables(pr)
+        kats["probs_%02d" % i] = pr
+        kats["index_%02d" % i] = idx.astype(np.uint16)
+        kats["length_%02d" % i] = ln.astype(np.uint16)
+        kats["table_%02d" % i] = tab
+    kats["count"] = np.array(len(plist))
+    # Tunstall stream KATs: symbols -> block (reference compressor) -> symbols (reference decompressor)
+    for i in range(8):
+        n = [1, 2, 7, 300, 5000, 5000, 20000, 3][i]
+        if i == 5:
+            sym = (rng.random(n) < 0.004).astype(np.uint8) * 3       # very low entropy -> count>=16 branch
+        elif i == 6:
+            sym = np.minimum(rng.geometric(0.35, n), 14).astype(np.uint8)
+        elif i == 7:
+            sym = np.array([5, 5, 5], dtype=np.uint8)                 # single symbol: memset path
+        else:
+            sym = rng.integers(0, 6, n).astype(np.uint8)
+        blk = rc.tunstall_compress_block(sym)
+        ns = int(blk[0]); size = int.from_bytes(blk[1 + 2 * ns:5 + 2 * ns].tobytes(), "little")
+        cs = int.from_bytes(blk[5 + 2 * ns:9 + 2 * ns].tobytes(), "little")
+        back = rc.tunstall_decompress(blk[1:1 + 2 * ns], blk[9 + 2 * ns:9 + 2 * ns + cs], size)
+        assert np.array_equal(back, sym), i
+        kats["stream_block_%d" % i] = blk
+        kats["stream_symbols_%d" % i] = sym
+    np.savez_compressed(os.path.join(OUT, "tunstall_kat.npz"), **kats)
+    print("tunstall_kat         %d tables, 8 streams" % len(plist))
+
+
+if __name__ == "__main__":
+    main()
