@@ -1,0 +1,413 @@
+"""corto_amd — MI355X-native decode path of corto (.crt meshes / point clouds).
+
+Python host mirror of the C ABI in include/corto_hip.h (ctypes over corto_amd/lib/libcorto_hip.so).
+PyTorch is used only as plumbing for device memory; the product is the HIP library.
+
+The reference interface this mirrors is crt::Decoder (include/corto/decoder.h:38-73 upstream):
+    Decoder(len, input) -> nvert / nface / attributes     here: probe(blob) / Decoder(blob)
+    setPositions / setNormals / setColors / setUvs / setAttribute / setIndex
+    decode()
+plus the batch form that has no upstream equivalent (Batch): many independent blobs, one set of launches.
+
+There is no CPU fallback: if the HIP library or a GPU is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcorto_hip.so")
+
+FMT_UINT32, FMT_INT32, FMT_UINT16, FMT_INT16, FMT_UINT8, FMT_INT8, FMT_FLOAT, FMT_DOUBLE = range(8)
+CODEC_GENERIC, CODEC_NORMAL, CODEC_COLOR = 1, 2, 3
+MAX_ATTRS, NAME_MAX, MAX_KERNELS = 16, 64, 32
+
+
+class CortoError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class AttrInfo(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_MAX), ("codec", C.c_uint32), ("q", C.c_float),
+                ("components", C.c_uint32), ("format", C.c_uint32), ("strategy", C.c_uint32)]
+
+
+class BlobInfo(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("entropy", C.c_uint32), ("nvert", C.c_uint32), ("nface", C.c_uint32),
+                ("nattr", C.c_uint32), ("attr", AttrInfo * MAX_ATTRS), ("nexif", C.c_uint32), ("body_offset", C.c_uint32)]
+
+    def attrs(self):
+        return [dict(name=self.attr[i].name.decode(), codec=self.attr[i].codec, q=self.attr[i].q,
+                     components=self.attr[i].components, format=self.attr[i].format, strategy=self.attr[i].strategy)
+                for i in range(self.nattr)]
+
+
+class AttrBinding(C.Structure):
+    _fields_ = [("buffer", C.c_void_p), ("format", C.c_uint32), ("out_components", C.c_uint32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("arena_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("tunstall_in", C.c_uint64),
+                ("tunstall_out", C.c_uint64), ("tunstall_tables", C.c_uint64), ("tunstall_streams", C.c_uint32),
+                ("total_nvert", C.c_uint64), ("total_nface", C.c_uint64), ("scratch_bytes", C.c_uint64)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("name", C.c_char_p * MAX_KERNELS), ("ms", C.c_float * MAX_KERNELS),
+                ("launches", C.c_uint32 * MAX_KERNELS)]
+
+    def as_dict(self):
+        return {self.name[i].decode(): dict(ms=float(self.ms[i]), launches=int(self.launches[i])) for i in range(self.count)}
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Fails loudly when it has not been built (python -m corto_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CortoError(-9, "corto_amd: %s is missing - build it with `python -m corto_amd.build` "
+                                 "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # torch (when present) bundles its own libamdhip64.so.7; it must be loaded FIRST so that this library
+        # binds to the same HIP runtime - two HIP runtimes in one process cannot both own the GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.crthip_last_error.restype = C.c_char_p
+        L.crthip_strerror.restype = C.c_char_p
+        L.crthip_abi_version.restype = C.c_uint32
+        L.crthip_probe_exif.restype = C.c_int64
+        L.crthip_probe_groups.restype = C.c_int64
+        L.crthip_arena_layout.restype = C.c_uint64
+        L.crthip_batch_size.restype = C.c_uint32
+        L.crthip_batch_debug_read.restype = C.c_int64
+        L.crthip_probe.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(BlobInfo)]
+        L.crthip_probe_exif.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.crthip_probe_groups.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.crthip_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.crthip_ctx_destroy.argtypes = [C.c_void_p]
+        L.crthip_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.crthip_ctx_sync.argtypes = [C.c_void_p]
+        L.crthip_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.crthip_batch_destroy.argtypes = [C.c_void_p]
+        L.crthip_batch_size.argtypes = [C.c_void_p]
+        L.crthip_batch_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(BlobInfo)]
+        L.crthip_batch_bind.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.crthip_batch_bind_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.crthip_batch_decode.argtypes = [C.c_void_p]
+        L.crthip_batch_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.crthip_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
+        L.crthip_batch_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTimes)]
+        L.crthip_batch_debug_read.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_size_t]
+        L.crthip_decode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.crthip_arena_layout.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.crthip_tunstall_decode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.POINTER(KernelTimes)]
+        _lib = L
+    return _lib
+
+
+def _check(code: int):
+    if code != 0:
+        raise CortoError(code, lib().crthip_last_error().decode())
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def aligned_blob(b, align: int = 16) -> np.ndarray:
+    """uint8 copy of b whose base address is `align`-aligned (the decoder needs 4: src/decoder.cpp:43-44)."""
+    b = np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b
+    raw = np.zeros(len(b) + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    v = raw[off:off + len(b)]
+    v[:] = b
+    return v
+
+
+def probe(blob: np.ndarray) -> BlobInfo:
+    """Header facts of one blob (host only, no GPU needed)."""
+    info = BlobInfo()
+    _check(lib().crthip_probe(_np_ptr(blob), len(blob), C.byref(info)))
+    return info
+
+
+def probe_exif(blob: np.ndarray) -> Dict[str, str]:
+    n = lib().crthip_probe_exif(_np_ptr(blob), len(blob), None, 0)
+    if n < 0:
+        _check(int(n))
+    buf = C.create_string_buffer(int(n) + 1)
+    lib().crthip_probe_exif(_np_ptr(blob), len(blob), buf, n)
+    parts = buf.raw[:n].split(b"\0")[:-1]
+    return {parts[i].decode(): parts[i + 1].decode() for i in range(0, len(parts), 2)}
+
+
+def probe_groups(blob: np.ndarray) -> List[int]:
+    n = lib().crthip_probe_groups(_np_ptr(blob), len(blob), None, 0)
+    if n < 0:
+        _check(int(n))
+    g = np.zeros(max(int(n), 1), dtype=np.uint32)
+    lib().crthip_probe_groups(_np_ptr(blob), len(blob), _np_ptr(g), int(n))
+    return [int(x) for x in g[:n]]
+
+
+def arena_layout(lens: Sequence[int]):
+    lens_a = np.asarray(lens, dtype=np.uint32)
+    offs = np.zeros(len(lens_a), dtype=np.uint64)
+    total = lib().crthip_arena_layout(len(lens_a), _np_ptr(lens_a), _np_ptr(offs))
+    return offs, int(total)
+
+
+class Context:
+    """One per GPU: owns the HIP stream and the scratch pool (crthip_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.handle = C.c_void_p()
+        _check(lib().crthip_ctx_create(device, C.byref(self.handle)))
+        self.device = device
+
+    def set_profiling(self, on: bool):
+        _check(lib().crthip_ctx_set_profiling(self.handle, int(on)))
+
+    def sync(self):
+        _check(lib().crthip_ctx_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().crthip_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DT = {"f32": np.float32, "i16": np.int16, "u8": np.uint8, "u32": np.uint32, "u16": np.uint16}
+
+
+class Batch:
+    """A planned batch of independent .crt blobs (crthip_batch)."""
+
+    def __init__(self, ctx: Context, blobs: Sequence[np.ndarray], device_arena=None):
+        self.ctx = ctx
+        self.blobs = list(blobs)
+        n = len(self.blobs)
+        self._ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in self.blobs])
+        self._lens = np.array([len(b) for b in self.blobs], dtype=np.uint32)
+        self.handle = C.c_void_p()
+        self._arena = device_arena
+        arena_ptr = C.c_void_p(device_arena.data_ptr()) if device_arena is not None else None
+        _check(lib().crthip_batch_create(ctx.handle, n, self._ptrs, _np_ptr(self._lens), arena_ptr, C.byref(self.handle)))
+        self.infos = []
+        for i in range(n):
+            info = BlobInfo()
+            _check(lib().crthip_batch_info(self.handle, i, C.byref(info)))
+            self.infos.append(info)
+        self.outputs: List[Dict[str, object]] = []
+        self._keep = None
+
+    def __len__(self):
+        return len(self.blobs)
+
+    # -- outputs -----------------------------------------------------------------------------------
+    def allocate_outputs(self, normal_format=FMT_FLOAT, color_components: Optional[int] = None, index16=False,
+                         only: Optional[set] = None, fill: Optional[int] = None):
+        """Allocate every output of every blob inside ONE device buffer (torch.uint8) and bind them.
+        Returns a list (per blob) of dicts name -> torch tensor view."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        plan = []   # (blob, name, offset, nbytes, dtype, shape, binding_slot)
+        off = 0
+
+        def take(nbytes):
+            nonlocal off
+            off = (off + 255) & ~255
+            r = off
+            off += nbytes
+            return r
+        for i, info in enumerate(self.infos):
+            nv, nf = info.nvert, info.nface
+            for k, a in enumerate(info.attrs()):
+                if only is not None and a["name"] not in only:
+                    continue
+                if a["codec"] == CODEC_NORMAL:
+                    dt = "f32" if normal_format == FMT_FLOAT else "i16"
+                    plan.append((i, a["name"], take(nv * 3 * np.dtype(_DT[dt]).itemsize), dt, (nv, 3), k, normal_format, 0))
+                elif a["codec"] == CODEC_COLOR:
+                    oc = color_components or a["components"]
+                    plan.append((i, a["name"], take(nv * oc), "u8", (nv, oc), k, FMT_UINT8, oc))
+                else:
+                    plan.append((i, a["name"], take(nv * a["components"] * 4), "f32", (nv, a["components"]), k, FMT_FLOAT, 0))
+            if nf and (only is None or "index" in only):
+                dt = "u16" if index16 else "u32"
+                plan.append((i, "index", take(nf * 3 * np.dtype(_DT[dt]).itemsize), dt, (nf, 3), -1, FMT_UINT16 if index16 else FMT_UINT32, 0))
+        total = max(off, 256)
+        buf = torch.empty(total, dtype=torch.uint8, device=dev) if fill is None else torch.full((total,), fill, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        nattr_total = sum(info.nattr for info in self.infos)
+        binds = (AttrBinding * max(nattr_total, 1))()
+        first = np.cumsum([0] + [info.nattr for info in self.infos])
+        index_ptrs = (C.c_void_p * max(len(self), 1))()
+        index_fmt = np.full(max(len(self), 1), FMT_UINT32, dtype=np.uint32)
+        outs = [dict() for _ in self.infos]
+        tdt = {"f32": torch.float32, "i16": torch.int16, "u8": torch.uint8, "u32": torch.int32, "u16": torch.int16}
+        for (i, name, o, dt, shape, slot, fmt, oc) in plan:
+            nbytes = int(np.prod(shape)) * np.dtype(_DT[dt]).itemsize
+            view = buf[o:o + nbytes].view(tdt[dt]).view(*shape) if nbytes else torch.empty(shape, dtype=tdt[dt], device=dev)
+            outs[i][name] = (view, dt)
+            if slot >= 0:
+                bd = binds[int(first[i]) + slot]
+                bd.buffer = base + o; bd.format = fmt; bd.out_components = oc
+            else:
+                index_ptrs[i] = base + o; index_fmt[i] = fmt
+        self._keep = (buf, binds, index_ptrs, index_fmt)
+        self.outputs = outs
+        self.rebind()
+        return outs
+
+    def rebind(self):
+        """(Re)apply the bindings prepared by allocate_outputs: one C call for the whole batch."""
+        buf, binds, index_ptrs, index_fmt = self._keep
+        _check(lib().crthip_batch_bind_all(self.handle, binds, index_ptrs, _np_ptr(index_fmt)))
+
+    def bind(self, i: int, bindings: Sequence[AttrBinding], index_ptr: Optional[int] = None, index_format=FMT_UINT32):
+        arr = (AttrBinding * max(len(bindings), 1))(*bindings)
+        _check(lib().crthip_batch_bind(self.handle, i, arr, C.c_void_p(index_ptr) if index_ptr else None, index_format))
+
+    def host_outputs(self, i: int) -> Dict[str, np.ndarray]:
+        """Copy blob i's outputs to the host as numpy arrays with the reference's dtypes."""
+        res = {}
+        for name, (t, dt) in self.outputs[i].items():
+            a = t.cpu().numpy()
+            res[name] = a.view(_DT[dt]) if a.dtype != _DT[dt] else a
+        res["nvert"], res["nface"] = self.infos[i].nvert, self.infos[i].nface
+        return res
+
+    # -- run ---------------------------------------------------------------------------------------
+    def decode(self):
+        _check(lib().crthip_batch_decode(self.handle))
+
+    def sync(self, raise_on_error=True) -> np.ndarray:
+        st = np.zeros(max(len(self), 1), dtype=np.int32)
+        code = lib().crthip_batch_sync(self.handle, _np_ptr(st))
+        if code != 0 and raise_on_error:
+            _check(code)
+        return st[:len(self)]
+
+    def stats(self) -> BatchStats:
+        s = BatchStats()
+        _check(lib().crthip_batch_get_stats(self.handle, C.byref(s)))
+        return s
+
+    def kernel_times(self) -> Dict[str, dict]:
+        t = KernelTimes()
+        _check(lib().crthip_batch_kernel_times(self.handle, C.byref(t)))
+        return t.as_dict()
+
+    def debug_read(self, i: int, what: str, nbytes: int) -> np.ndarray:
+        out = np.zeros(max(nbytes, 1), dtype=np.uint8)
+        n = lib().crthip_batch_debug_read(self.handle, i, what.encode(), _np_ptr(out), nbytes)
+        if n < 0:
+            _check(int(n))
+        return out[:n]
+
+    def close(self):
+        if self.handle:
+            lib().crthip_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def upload_arena(blobs: Sequence[np.ndarray], device: int = 0):
+    """Stage blobs back to back (16-byte aligned starts) into one device tensor: the 'inputs resident in
+    HBM' form that Batch(device_arena=...) consumes."""
+    import torch
+    offs, total = arena_layout([len(b) for b in blobs])
+    host = np.zeros(max(total, 16), dtype=np.uint8)
+    for b, o in zip(blobs, offs):
+        host[int(o):int(o) + len(b)] = b
+    return torch.from_numpy(host).to(torch.device("cuda", device))
+
+
+class Decoder:
+    """Mirror of crt::Decoder for one blob with HOST (numpy) output buffers; decode() runs on the GPU through
+    crthip_decode_host.  Same member names as upstream (include/corto/decoder.h:38-73)."""
+
+    _default_ctx: Dict[int, Context] = {}
+
+    def __init__(self, blob: np.ndarray, device: int = 0):
+        self.blob = blob
+        self.info = probe(blob)
+        self.nvert, self.nface = self.info.nvert, self.info.nface
+        self.exif = probe_exif(blob)
+        self.data = {a["name"]: a for a in self.info.attrs()}
+        self._bind = {}
+        self._index = None
+        self._index_format = FMT_UINT32
+        self.device = device
+
+    def hasAttr(self, name: str) -> bool:
+        return name in self.data
+
+    def setAttribute(self, name: str, buffer: np.ndarray, fmt: int, out_components: int = 0) -> bool:
+        if name not in self.data:
+            return False
+        self._bind[name] = (buffer, fmt, out_components)
+        return True
+
+    def setPositions(self, buffer: np.ndarray) -> bool:
+        return self.setAttribute("position", buffer, FMT_FLOAT)
+
+    def setNormals(self, buffer: np.ndarray) -> bool:
+        return self.setAttribute("normal", buffer, FMT_INT16 if buffer.dtype == np.int16 else FMT_FLOAT)
+
+    def setUvs(self, buffer: np.ndarray) -> bool:
+        return self.setAttribute("uv", buffer, FMT_FLOAT)
+
+    def setColors(self, buffer: np.ndarray, components: int = 4) -> bool:
+        return self.setAttribute("color", buffer, FMT_UINT8, components)
+
+    def setIndex(self, buffer: np.ndarray):
+        self._index = buffer
+        self._index_format = FMT_UINT16 if buffer.dtype == np.uint16 else FMT_UINT32
+
+    def decode(self):
+        ctx = Decoder._default_ctx.get(self.device)
+        if ctx is None:
+            ctx = Decoder._default_ctx[self.device] = Context(self.device)
+        attrs = self.info.attrs()
+        binds = (AttrBinding * max(len(attrs), 1))()
+        for k, a in enumerate(attrs):
+            if a["name"] in self._bind:
+                buf, fmt, oc = self._bind[a["name"]]
+                binds[k].buffer = buf.ctypes.data; binds[k].format = fmt; binds[k].out_components = oc
+        idx = C.c_void_p(self._index.ctypes.data) if self._index is not None else None
+        _check(lib().crthip_decode_host(ctx.handle, _np_ptr(self.blob), len(self.blob), binds, idx, self._index_format))
+
+
+def tunstall_decode_blocks(ctx: Context, host_blocks: np.ndarray, device_blocks, block_offsets, device_out, out_offsets):
+    """Stand-alone Tunstall decode of device-resident blocks (HBM-roofline run). Returns per-kernel ms."""
+    bo = np.ascontiguousarray(block_offsets, dtype=np.uint64)
+    oo = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+    t = KernelTimes()
+    _check(lib().crthip_tunstall_decode_blocks(ctx.handle, len(bo), _np_ptr(host_blocks), C.c_void_p(device_blocks.data_ptr()),
+                                               _np_ptr(bo), C.c_void_p(device_out.data_ptr()), _np_ptr(oo), C.byref(t)))
+    return t.as_dict()

@@ -1,0 +1,65 @@
+"""Build libcorto_hip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m corto_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: an FMA contraction changes the
+bits of the reference's BORDER normals; IEEE divide/sqrt are hipcc's default
+(-fhip-fp32-correctly-rounded-divide-sqrt).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcorto_hip.so")
+SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_normal.hip", "batch.cpp", "crt_format.cpp", "decoder_facade.cpp"]
+HEADERS = ["kernels_common.h", "kernels.h", "device_plan.h", "crt_format.h",
+           os.path.join("..", "..", "include", "corto_hip.h"), os.path.join("..", "..", "include", "corto", "decoder.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+         "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

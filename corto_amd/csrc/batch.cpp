@@ -1,0 +1,936 @@
+// batch.cpp — host side of the MI355X decode path: context (stream, scratch pool), batch planner
+// (walk -> job descriptors -> one H2D upload) and the kernel schedule.  Compiled by hipcc.
+//
+// The schedule restates the stage order of crt::Decoder::decodeMesh / decodePointCloud
+// (src/decoder.cpp:133-196) for a whole batch of blobs at once:
+//   decode-all (Tunstall + bit-unpack) -> topology -> delta-all -> postDelta (normals) -> dequantize-all.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/corto_hip.h"
+#include "crt_format.h"
+#include "device_plan.h"
+#include "kernels.h"
+
+using namespace corto_hip;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+static int fail(int code, const std::string &msg) { g_error = msg; return code; }
+
+extern "C" const char *crthip_strerror(int code) {
+	switch(code) {
+	case CRTHIP_OK: return "ok";
+	case CRTHIP_E_ALIGN: return "Memory must be alignegned on 4 bytes.";
+	case CRTHIP_E_MAGIC: return "Not a crt file.";
+	case CRTHIP_E_TRUNCATED: return "Truncated or inconsistent crt stream.";
+	case CRTHIP_E_ENTROPY: return "Unknown entropy";
+	case CRTHIP_E_TOPOLOGY: return "Decoding topology failed";
+	case CRTHIP_E_NORMAL_NEEDS_POSITION: return "No position attribute found. Use DIFF normal strategy instead.";
+	case CRTHIP_E_FORMAT: return "Format not supported for this attribute on the device path";
+	case CRTHIP_E_ARGUMENT: return "Invalid argument";
+	case CRTHIP_E_DEVICE: return "No usable HIP device (the MI355X path has no CPU fallback)";
+	case CRTHIP_E_NOMEM: return "Out of memory";
+	case CRTHIP_E_LIMIT: return "Too many attributes or components for this build";
+	}
+	return "unknown error";
+}
+static int fail(int code) { return fail(code, crthip_strerror(code)); }
+extern "C" const char *crthip_last_error(void) { return g_error.c_str(); }
+extern "C" uint32_t crthip_abi_version(void) { return CRTHIP_ABI_VERSION; }
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return fail(CRTHIP_E_DEVICE, std::string(#expr ": ") + hipGetErrorString(e_)); } while(0)
+
+// ------------------------------------------------------------------------------------------------
+// host-only probes
+static void fill_info(const BlobHeader &h, crthip_blob_info *info) {
+	memset(info, 0, sizeof(*info));
+	info->version = h.version; info->entropy = h.entropy; info->nvert = h.nvert; info->nface = h.nface;
+	info->nattr = (uint32_t)h.attrs.size(); info->nexif = (uint32_t)h.exif.size(); info->body_offset = h.body_offset;
+	for(size_t i = 0; i < h.attrs.size(); i++) {
+		crthip_attr_info &a = info->attr[i];
+		strncpy(a.name, h.attrs[i].name.c_str(), CRTHIP_NAME_MAX - 1);
+		a.codec = h.attrs[i].codec; a.q = h.attrs[i].q; a.components = h.attrs[i].N;
+		a.format = h.attrs[i].format; a.strategy = h.attrs[i].strategy;
+	}
+}
+
+extern "C" int crthip_probe(const uint8_t *blob, size_t len, crthip_blob_info *info) {
+	if(!blob || !info) return fail(CRTHIP_E_ARGUMENT);
+	BlobHeader h;
+	int err = parse_header(blob, len, h);
+	if(err) return fail(err);
+	fill_info(h, info);
+	return CRTHIP_OK;
+}
+
+extern "C" int64_t crthip_probe_exif(const uint8_t *blob, size_t len, char *out, size_t cap) {
+	BlobHeader h;
+	int err = parse_header(blob, len, h);
+	if(err) return fail(err);
+	std::string flat;
+	for(auto &kv : h.exif) { flat += kv.first; flat.push_back('\0'); flat += kv.second; flat.push_back('\0'); }
+	if(out && cap >= flat.size()) memcpy(out, flat.data(), flat.size());
+	return (int64_t)flat.size();
+}
+
+extern "C" int64_t crthip_probe_groups(const uint8_t *blob, size_t len, uint32_t *group_end, size_t cap) {
+	BlobLayout L;
+	int err = walk_blob(blob, len, L);
+	if(err) return fail(err);
+	for(size_t i = 0; i < L.group_end.size() && i < cap; i++) group_end[i] = L.group_end[i];
+	return (int64_t)L.group_end.size();
+}
+
+extern "C" uint64_t crthip_arena_layout(uint32_t nblobs, const uint32_t *lens, uint64_t *offsets) {
+	uint64_t off = 0;
+	for(uint32_t i = 0; i < nblobs; i++) {
+		if(offsets) offsets[i] = off;
+		off += ((uint64_t)lens[i] + 15) & ~15ull;
+	}
+	return off;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DeviceBuf {
+	void *p = nullptr; size_t cap = 0;
+	int reserve(size_t n) {
+		if(n <= cap) return CRTHIP_OK;
+		if(p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = std::max(n + n/4, (size_t)1 << 20);
+		if(hipMalloc(&p, want) != hipSuccess) { p = nullptr; return CRTHIP_E_NOMEM; }
+		cap = want;
+		return CRTHIP_OK;
+	}
+	void release() { if(p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinnedBuf {
+	void *p = nullptr; size_t cap = 0;
+	int reserve(size_t n) {
+		if(n <= cap) return CRTHIP_OK;
+		if(p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+		size_t want = std::max(n + n/4, (size_t)1 << 16);
+		if(hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return CRTHIP_E_NOMEM; }
+		cap = want;
+		return CRTHIP_OK;
+	}
+	void release() { if(p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct KernelTimer {
+	std::vector<hipEvent_t> pool;
+	struct Rec { const char *name; size_t e0, e1; };
+	std::vector<Rec> recs;
+	size_t used = 0;
+	hipEvent_t get() {
+		if(used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+		return pool[used++];
+	}
+	void reset() { used = 0; recs.clear(); }
+	void release() { for(auto e : pool) (void)hipEventDestroy(e); pool.clear(); reset(); }
+};
+
+struct crthip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
+	PinnedBuf staging;        // host image of the job arrays
+	PinnedBuf status_host;
+	bool profiling = false;
+	KernelTimer timer;
+	crthip_batch *in_flight = nullptr;
+};
+
+struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4; };
+
+struct BlobPlan {
+	BlobLayout L;
+	uint64_t arena_off = 0;
+	uint32_t len = 0;
+	std::vector<Binding> bind;
+	void *index = nullptr; uint32_t index_u16 = 0;
+	int32_t host_status = 0;   // set by the planner (e.g. unsupported format), overrides device status
+	// debug handles (scratch offsets valid after decode)
+	uint64_t dbg_clers = ~0ull, dbg_pred = ~0ull; uint32_t dbg_nclers = 0;
+	bool clers_in_arena = false;
+};
+
+struct crthip_batch {
+	crthip_ctx *ctx = nullptr;
+	std::vector<BlobPlan> blobs;
+	const uint8_t *d_arena = nullptr;
+	DeviceBuf own_arena;
+	uint64_t arena_bytes = 0;
+	bool dirty = true;
+	crthip_batch_stats stats{};
+	std::vector<int32_t> status;
+	bool decoded = false;
+};
+
+extern "C" int crthip_device_count(void) {
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
+	if(!out) return fail(CRTHIP_E_ARGUMENT);
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return fail(CRTHIP_E_DEVICE);
+	HIP_TRY(hipSetDevice(device));
+	crthip_ctx *c = new crthip_ctx();
+	c->device = device;
+	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	*out = c;
+	return CRTHIP_OK;
+}
+
+extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
+	if(!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	c->timer.release();
+	c->scratch.release(); c->staging.release(); c->status_host.release();
+	(void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int crthip_ctx_set_profiling(crthip_ctx *c, int enable) {
+	if(!c) return fail(CRTHIP_E_ARGUMENT);
+	c->profiling = enable != 0;
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_ctx_sync(crthip_ctx *c) {
+	if(!c) return fail(CRTHIP_E_ARGUMENT);
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return CRTHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens,
+                                   const void *device_arena, crthip_batch **out) {
+	if(!ctx || !out || (nblobs && (!blobs || !lens))) return fail(CRTHIP_E_ARGUMENT);
+	HIP_TRY(hipSetDevice(ctx->device));
+	crthip_batch *b = new crthip_batch();
+	b->ctx = ctx;
+	b->blobs.resize(nblobs);
+	uint64_t off = 0;
+	for(uint32_t i = 0; i < nblobs; i++) {
+		BlobPlan &P = b->blobs[i];
+		int err = walk_blob(blobs[i], lens[i], P.L);
+		if(err) { delete b; return fail(err, std::string(crthip_strerror(err)) + " (blob " + std::to_string(i) + ")"); }
+		P.arena_off = off; P.len = lens[i];
+		P.bind.resize(P.L.h.attrs.size());
+		off += ((uint64_t)lens[i] + 15) & ~15ull;
+		b->stats.total_nvert += P.L.h.nvert; b->stats.total_nface += P.L.h.nface;
+	}
+	b->arena_bytes = off;
+	b->stats.arena_bytes = off;
+	if(device_arena) b->d_arena = (const uint8_t *)device_arena;
+	else if(off) {
+		if(b->own_arena.reserve(off) != CRTHIP_OK) { delete b; return fail(CRTHIP_E_NOMEM); }
+		if(ctx->in_flight) { (void)hipStreamSynchronize(ctx->stream); ctx->in_flight = nullptr; }
+		if(ctx->staging.reserve(off) != CRTHIP_OK) { delete b; return fail(CRTHIP_E_NOMEM); }
+		uint8_t *h = (uint8_t *)ctx->staging.p;
+		for(uint32_t i = 0; i < nblobs; i++) memcpy(h + b->blobs[i].arena_off, blobs[i], lens[i]);
+		if(hipMemcpyAsync(b->own_arena.p, h, off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+		   hipStreamSynchronize(ctx->stream) != hipSuccess) { delete b; return fail(CRTHIP_E_DEVICE); }
+		b->d_arena = (const uint8_t *)b->own_arena.p;
+	}
+	b->status.assign(nblobs, 0);
+	*out = b;
+	return CRTHIP_OK;
+}
+
+extern "C" void crthip_batch_destroy(crthip_batch *b) {
+	if(!b) return;
+	if(b->ctx) {
+		(void)hipSetDevice(b->ctx->device);
+		if(b->ctx->in_flight == b) { (void)hipStreamSynchronize(b->ctx->stream); b->ctx->in_flight = nullptr; }
+	}
+	b->own_arena.release();
+	delete b;
+}
+
+extern "C" uint32_t crthip_batch_size(const crthip_batch *b) { return b ? (uint32_t)b->blobs.size() : 0; }
+
+extern "C" int crthip_batch_info(const crthip_batch *b, uint32_t i, crthip_blob_info *info) {
+	if(!b || !info || i >= b->blobs.size()) return fail(CRTHIP_E_ARGUMENT);
+	fill_info(b->blobs[i].L.h, info);
+	return CRTHIP_OK;
+}
+
+static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
+	if(!bd.buffer) return CRTHIP_OK;
+	if(a.codec == CRTHIP_CODEC_NORMAL) return (bd.format == CRTHIP_FMT_FLOAT || bd.format == CRTHIP_FMT_INT16) ? CRTHIP_OK : CRTHIP_E_FORMAT;
+	if(a.codec == CRTHIP_CODEC_COLOR) {
+		if(bd.format != CRTHIP_FMT_UINT8) return CRTHIP_E_FORMAT;        // FLOAT colour output is broken upstream (color_attribute.cpp:96-110)
+		uint32_t oc = bd.out_components ? bd.out_components : 4;
+		if(a.N < 1 || a.N > 4 || oc > 4 || oc < a.N) return CRTHIP_E_FORMAT;
+		return CRTHIP_OK;
+	}
+	if(a.N < 1) return CRTHIP_E_FORMAT;
+	return bd.format == CRTHIP_FMT_FLOAT ? CRTHIP_OK : CRTHIP_E_FORMAT;   // integer output formats: SURVEY a17, not on the device path
+}
+
+extern "C" int crthip_batch_bind(crthip_batch *b, uint32_t i, const crthip_attr_binding *attrs, void *index, uint32_t index_format) {
+	if(!b || i >= b->blobs.size()) return fail(CRTHIP_E_ARGUMENT);
+	BlobPlan &P = b->blobs[i];
+	if(P.bind.size() && !attrs) return fail(CRTHIP_E_ARGUMENT);
+	if(index && index_format != CRTHIP_FMT_UINT32 && index_format != CRTHIP_FMT_UINT16) return fail(CRTHIP_E_FORMAT);
+	for(size_t k = 0; k < P.bind.size(); k++) {
+		int err = check_binding(P.L.h.attrs[k], attrs[k]);
+		if(err) return fail(err, std::string(crthip_strerror(err)) + " (attribute '" + P.L.h.attrs[k].name + "')");
+	}
+	for(size_t k = 0; k < P.bind.size(); k++) {
+		P.bind[k].buffer = attrs[k].buffer; P.bind[k].format = attrs[k].format;
+		P.bind[k].out_components = attrs[k].out_components ? attrs[k].out_components : 4;
+	}
+	P.index = index; P.index_u16 = index && index_format == CRTHIP_FMT_UINT16;
+	b->dirty = true;
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_batch_bind_all(crthip_batch *b, const crthip_attr_binding *attrs, void *const *index, const uint32_t *index_format) {
+	if(!b) return fail(CRTHIP_E_ARGUMENT);
+	size_t k = 0;
+	for(uint32_t i = 0; i < b->blobs.size(); i++) {
+		int err = crthip_batch_bind(b, i, attrs ? attrs + k : nullptr, index ? index[i] : nullptr, index_format ? index_format[i] : CRTHIP_FMT_UINT32);
+		if(err) return err;
+		k += b->blobs[i].bind.size();
+	}
+	return CRTHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// planner: everything below turns the walked layouts + bindings into job arrays inside one scratch block
+namespace {
+
+struct Carver {                         // bump allocator over the scratch block (offsets only)
+	uint64_t off = 0;
+	uint64_t take(uint64_t bytes, uint64_t align = 256) { off = (off + align - 1) & ~(align - 1); uint64_t r = off; off += bytes; return r; }
+};
+
+template <typename T> struct HostArr {  // host image of a device array + where it goes
+	std::vector<T> v; uint64_t dev_off = 0;
+};
+
+static int32_t f2i_x86_host(float x) {
+	if(!(x > -2147483904.0f && x < 2147483648.0f)) return (int32_t)0x80000000;
+	return (int32_t)x;
+}
+
+struct Plan {
+	// job arrays
+	HostArr<TunStream> tun; HostArr<uint32_t> tun_chunk_stream;
+	HostArr<FillJob> fill;
+	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
+	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
+	HostArr<DeltaJob> delta;
+	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
+	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first;
+	HostArr<DequantJob> dequant; HostArr<uint32_t> dequant_block_job;
+	// scratch regions (offsets)
+	uint64_t zero_begin = 0, zero_end = 0;
+	uint64_t status_off = 0, tables_off = 0, tun_partial_off = 0, unpack_partial_off = 0, cloud_partial_off = 0;
+	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
+	uint64_t jobs_begin = 0, jobs_bytes = 0;
+	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
+	uint32_t delta_lds = 0;
+	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
+	uint64_t total = 0;
+};
+
+} // namespace
+
+static const uint32_t DELTA_LDS_MAX = 64*1024;
+
+struct Launch {
+	crthip_ctx *ctx;
+	void begin(const char *name) {
+		if(!ctx->profiling) return;
+		hipEvent_t e = ctx->timer.get();
+		(void)hipEventRecord(e, ctx->stream);
+		ctx->timer.recs.push_back({name, ctx->timer.used - 1, 0});
+	}
+	void end() {
+		if(!ctx->profiling) return;
+		hipEvent_t e = ctx->timer.get();
+		(void)hipEventRecord(e, ctx->stream);
+		ctx->timer.recs.back().e1 = ctx->timer.used - 1;
+	}
+};
+
+static int build_and_launch(crthip_batch *b) {
+	crthip_ctx *ctx = b->ctx;
+	Plan pl;
+	Carver cv;
+	const uint32_t nblobs = (uint32_t)b->blobs.size();
+	const uint8_t *arena = b->d_arena;
+
+	// ---- pass 1: sizes & offsets (device addresses are scratch_base + offset, resolved in pass 2) ----
+	// We first carve all scratch, then reserve the block, then fill job structs with real pointers.
+	struct AttrScratch { uint64_t color = ~0ull, diffs = ~0ull; std::vector<uint64_t> sym; };
+	struct BlobScratch {
+		uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
+		uint32_t front_cap = 0, aux_groups = 0;
+		std::vector<AttrScratch> attr;
+	};
+	std::vector<BlobScratch> bs(nblobs);
+
+	// zeroed region: status, predictions (vertices the automaton never reaches keep (0,0,0)), and the
+	// counters of the ESTIMATED/BORDER normal pipeline
+	uint64_t est_v = 0, est_f = 0;
+	for(uint32_t i = 0; i < nblobs; i++) {
+		const BlobPlan &P = b->blobs[i];
+		const BlobLayout &L = P.L;
+		if(L.h.nface == 0) continue;
+		for(size_t k = 0; k < L.attrs.size(); k++)
+			if(L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && L.attrs[k].normal_prediction != 0) { est_v += L.h.nvert; est_f += L.h.nface; }
+	}
+	pl.zero_begin = cv.take(0);
+	pl.status_off = cv.take((uint64_t)nblobs*4);
+	for(uint32_t i = 0; i < nblobs; i++) {
+		const BlobLayout &L = b->blobs[i].L;
+		if(L.h.nface > 0) bs[i].pred = cv.take((uint64_t)L.h.nvert*12, 16);
+	}
+	pl.est_nvert = (uint32_t)est_v; pl.est_nface = (uint32_t)est_f;
+	if(est_v) {
+		pl.cnt_off = cv.take(est_v*4 + 16); pl.cursor_off = cv.take(est_v*4 + 16); pl.bnd_off = cv.take(est_v*4 + 16);
+	}
+	pl.zero_end = cv.take(0);
+	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0;
+
+	auto need_stream = [&](const StreamRef &s, uint64_t &sym_off) {
+		sym_off = ~0ull;
+		if(s.mode == STREAM_TUNSTALL || s.mode == STREAM_FILL) sym_off = cv.take((uint64_t)s.size + 16, 16);
+		if(s.mode == STREAM_TUNSTALL) { n_tun++; stat_tin += s.csize; stat_tout += s.size; stat_tt += 9 + 2*(uint64_t)s.nsym; }
+	};
+
+	for(uint32_t i = 0; i < nblobs; i++) {
+		BlobPlan &P = b->blobs[i];
+		const BlobLayout &L = P.L;
+		BlobScratch &S = bs[i];
+		P.host_status = 0;
+		S.attr.resize(L.attrs.size());
+		const bool mesh = L.h.nface > 0;
+		if(mesh) {
+			need_stream(L.clers, S.clers);
+			uint32_t maxg = 0, prev = 0;
+			for(uint32_t ge : L.group_end) { if(ge > prev) maxg = std::max(maxg, ge - prev); prev = std::max(prev, ge); }
+			uint64_t cap = std::min<uint64_t>(L.max_front, (uint64_t)3*maxg);
+			S.front_cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFF0u);
+			S.front_a = cv.take((uint64_t)(S.front_cap + 4)*16);
+			S.front_b = cv.take((uint64_t)(S.front_cap + 4)*8);
+			S.order = cv.take((uint64_t)(S.front_cap + 4)*4);
+			S.delayed = cv.take((uint64_t)(S.front_cap + 4)*4);
+			if(!P.index) S.faces = cv.take((uint64_t)L.h.nface*12);
+		}
+		for(size_t k = 0; k < L.attrs.size(); k++) {
+			const AttrHeader &a = L.h.attrs[k];
+			const Binding &bd = P.bind[k];
+			if(!bd.buffer) continue;                           // unbound: streams skipped (cstream.h:302,331)
+			AttrScratch &A = S.attr[k];
+			A.sym.resize(L.attrs[k].logs.size());
+			for(size_t j = 0; j < A.sym.size(); j++) need_stream(L.attrs[k].logs[j], A.sym[j]);
+			if(a.codec == CRTHIP_CODEC_COLOR) A.color = cv.take((uint64_t)L.h.nvert*a.N + 16, 16);
+			if(a.codec == CRTHIP_CODEC_NORMAL) {
+				A.diffs = cv.take((uint64_t)L.h.nvert*8 + 16, 16);
+			}
+		}
+	}
+	if(est_v) {
+		pl.start_off = cv.take(est_v*4 + 16); pl.flag_off = cv.take(est_v*4 + 16); pl.slot_off = cv.take(est_v*4 + 16);
+		pl.adj_off = cv.take(est_f*12 + 16); pl.facen_off = cv.take(est_f*12 + 16);
+		pl.nscan_partial_off = cv.take(((est_v + CHUNK - 1)/CHUNK + 1)*8);
+	}
+	pl.tables_off = cv.take(n_tun*sizeof(TunTable));
+
+	// ---- pass 2: job structs with offsets stored in pointer fields (rebased after the block is reserved) ----
+	// To keep one pass, pointers are built as (uint8_t*)offset and fixed up by adding the scratch base.
+	auto SP = [](uint64_t off) { return (uint8_t *)(uintptr_t)off; };   // scratch-relative pseudo pointer
+
+	uint32_t tun_chunks = 0, unpack_chunks = 0, cloud_chunks = 0;
+	auto add_stream = [&](const StreamRef &s, uint64_t sym_off, uint64_t blob_off) -> const uint8_t * {
+		// returns the (pseudo or real) device pointer where the decoded symbols will be; real pointers have bit 63 set
+		if(s.mode == STREAM_RAW) return (const uint8_t *)((uintptr_t)(arena + blob_off + s.payload_off) | (1ull << 63));
+		if(s.mode == STREAM_EMPTY) return SP(0);
+		if(s.mode == STREAM_FILL) { pl.fill.v.push_back(FillJob{SP(sym_off), s.size, s.fill}); return SP(sym_off); }
+		TunStream t{};
+		t.src = arena + blob_off + s.payload_off; t.dst = SP(sym_off); t.probs = arena + blob_off + s.probs_off;
+		t.csize = s.csize; t.size = s.size; t.nsym = s.nsym; t.table = (uint32_t)pl.tun.v.size();
+		t.chunk0 = tun_chunks; t.nchunks = (s.csize + TUN_CHUNK_CODES - 1)/TUN_CHUNK_CODES;
+		if(t.nchunks > 1) pl.tun_multi_chunk = true;
+		for(uint32_t c = 0; c < t.nchunks; c++) pl.tun_chunk_stream.v.push_back((uint32_t)pl.tun.v.size());
+		tun_chunks += t.nchunks;
+		pl.tun.v.push_back(t);
+		return SP(sym_off);
+	};
+
+	uint32_t est_vbase = 0, est_fbase = 0;
+	for(uint32_t i = 0; i < nblobs; i++) {
+		BlobPlan &P = b->blobs[i];
+		const BlobLayout &L = P.L;
+		BlobScratch &S = bs[i];
+		const bool mesh = L.h.nface > 0;
+		const uint32_t nvert = L.h.nvert, nface = L.h.nface;
+		const uint64_t bo = P.arena_off;
+		const uint8_t *clers_ptr = nullptr;
+		if(mesh) {
+			clers_ptr = add_stream(L.clers, S.clers, bo);
+			P.clers_in_arena = L.clers.mode == STREAM_RAW;
+			P.dbg_clers = L.clers.mode == STREAM_RAW ? bo + L.clers.payload_off : S.clers;
+			P.dbg_nclers = L.clers.size; P.dbg_pred = S.pred;
+			TopoJob t{};
+			t.clers = clers_ptr;
+			t.split_words = (const uint32_t *)(arena + bo + L.split.words_off);
+			t.group_end = (const uint32_t *)SP(pl.aux_u32.v.size()*4);   // index into aux, rebased later
+			for(uint32_t ge : L.group_end) pl.aux_u32.v.push_back(ge);
+			t.faces = P.index ? P.index : (void *)SP(S.faces);
+			t.pred = (uint32_t *)SP(S.pred);
+			t.front_a = (uint4 *)SP(S.front_a); t.front_b = (uint2 *)SP(S.front_b);
+			t.order = (uint32_t *)SP(S.order); t.delayed = (uint32_t *)SP(S.delayed);
+			t.status = (int32_t *)SP(pl.status_off + (uint64_t)i*4);
+			t.nclers = L.clers.size; t.split_nwords = L.split.nwords; t.ngroups = (uint32_t)L.group_end.size();
+			t.nvert = nvert; t.nface = nface; t.front_cap = S.front_cap; t.faces_u16 = P.index ? P.index_u16 : 0;
+			t.pad = P.index ? 1u : 0u;                                   // pad = 1: faces is a real pointer
+			pl.topo.v.push_back(t);
+		}
+		// position attribute (needed by ESTIMATED/BORDER normals)
+		int pos_k = -1;
+		for(size_t k = 0; k < L.attrs.size(); k++) if(L.h.attrs[k].name == "position") pos_k = (int)k;
+
+		for(size_t k = 0; k < L.attrs.size(); k++) {
+			const AttrHeader &a = L.h.attrs[k];
+			const AttrStreams &as = L.attrs[k];
+			const Binding &bd = P.bind[k];
+			if(!bd.buffer) continue;
+			AttrScratch &A = S.attr[k];
+			const uint32_t *words = (const uint32_t *)(arena + bo + as.bits.words_off);
+			const uint32_t chain0 = unpack_chunks;
+			auto push_unpack = [&](const StreamRef &s, const uint8_t *logs, void *out, bool out_real, uint8_t mode, uint16_t fields, uint16_t stride, uint16_t comp, uint8_t u8) {
+				if(s.size == 0) return;
+				UnpackJob u{};
+				u.logs = logs; u.words = words; u.out = out; u.count = s.size; u.nwords = as.bits.nwords; u.out_limit = nvert;
+				u.chunk0 = unpack_chunks; u.chain_chunk0 = chain0; u.fields = fields; u.stride = stride; u.comp = comp; u.mode = mode;
+				u.out_u8 = (uint8_t)(u8 | (out_real ? 0x80 : 0));           // bit7: out is a real pointer (cleared at fixup)
+				const uint32_t nc = (s.size + CHUNK - 1)/CHUNK;
+				for(uint32_t c = 0; c < nc; c++) pl.unpack_chunk_job.v.push_back((uint32_t)pl.unpack.v.size());
+				unpack_chunks += nc;
+				pl.unpack.v.push_back(u);
+			};
+			std::vector<const uint8_t *> logs(as.logs.size());
+			for(size_t j = 0; j < as.logs.size(); j++) logs[j] = add_stream(as.logs[j], A.sym[j], bo);
+
+			void *values = nullptr; bool values_real = false; uint8_t is_u8 = 0; uint32_t N = a.N; bool para = false; bool do_delta = true;
+			if(a.codec == CRTHIP_CODEC_NORMAL) {
+				push_unpack(as.logs[0], logs[0], SP(A.diffs), false, 0, 2, 2, 0, 0);
+				values = SP(A.diffs); N = 2; para = false;
+				do_delta = as.normal_prediction == 0;                     // DIFF only (normal_attribute.cpp:190-191)
+			} else if(a.codec == CRTHIP_CODEC_COLOR) {
+				for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], SP(A.color), false, 1, 1, (uint16_t)a.N, (uint16_t)c, 1);
+				values = SP(A.color); is_u8 = 1; para = (a.strategy & CRTHIP_PARALLEL) != 0;
+			} else {
+				if(a.strategy & CRTHIP_CORRELATED) push_unpack(as.logs[0], logs[0], bd.buffer, true, 0, (uint16_t)a.N, (uint16_t)a.N, 0, 0);
+				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], bd.buffer, true, 1, 1, (uint16_t)a.N, (uint16_t)c, 0);
+				values = bd.buffer; values_real = true; para = (a.strategy & CRTHIP_PARALLEL) != 0;
+			}
+			if(do_delta && nvert > 1) {
+				if(mesh) {
+					DeltaJob d{};
+					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
+					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real;
+					const uint64_t bytes = (uint64_t)nvert*N*(is_u8 ? 1 : 4);
+					if(bytes <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((bytes + 15) & ~15ull));
+					pl.delta.v.push_back(d);
+				} else {
+					CloudJob c{};
+					c.values = values; c.nvert = nvert; c.N = N; c.chunk0 = cloud_chunks; c.is_u8 = is_u8; c.pad[0] = values_real;
+					const uint32_t nc = N*((nvert + CHUNK - 1)/CHUNK);
+					for(uint32_t q = 0; q < nc; q++) pl.cloud_chunk_job.v.push_back((uint32_t)pl.cloud.v.size());
+					cloud_chunks += nc;
+					pl.cloud.v.push_back(c);
+				}
+			}
+			if(a.codec == CRTHIP_CODEC_NORMAL) {
+				const uint32_t pr = as.normal_prediction;
+				if(pr == 0 || (mesh && (pr == 1 || pr == 2))) {       // clouds: postDelta never runs (decoder.cpp:142-143)
+					NormalJob n{};
+					n.diffs = (int32_t *)SP(A.diffs); n.out = bd.buffer; n.nvert = nvert; n.nface = nface;
+					n.ndiffs = std::min(as.logs[0].size, nvert); n.unit = f2i_x86_host(a.q);
+					n.prediction = (uint8_t)pr; n.out_i16 = bd.format == CRTHIP_FMT_INT16;
+					n.status = (int32_t *)SP(pl.status_off + (uint64_t)i*4);
+					if(pr != 0) {
+						const bool pos_ok = pos_k >= 0 && L.h.attrs[pos_k].codec == CRTHIP_CODEC_GENERIC && L.h.attrs[pos_k].N == 3 && P.bind[pos_k].buffer;
+						if(!pos_ok) { P.host_status = CRTHIP_E_NORMAL_NEEDS_POSITION; continue; }
+						n.position = (const int32_t *)P.bind[pos_k].buffer;
+						n.faces = P.index ? P.index : (void *)SP(S.faces); n.faces_u16 = P.index ? P.index_u16 : 0; n.pad = P.index ? 1 : 0;
+						n.vbase = est_vbase; n.fbase = est_fbase; est_vbase += nvert; est_fbase += nface;
+						pl.any_est_normal = true;
+					} else pl.any_diff_normal = true;
+					pl.normal.v.push_back(n);
+				}
+			} else {
+				DequantJob q{};
+				q.buffer = bd.buffer; q.q = a.q; q.nvert = nvert; q.N = a.N; q.out_components = bd.out_components;
+				for(int c = 0; c < 4; c++) q.qc[c] = as.qc[c];
+				q.block0 = (uint32_t)pl.dequant_block_job.v.size();
+				q.is_color = a.codec == CRTHIP_CODEC_COLOR;
+				if(q.is_color) q.color_src = SP(A.color);
+				const uint64_t elems = q.is_color ? nvert : (uint64_t)nvert*a.N;
+				const uint32_t nb = (uint32_t)((elems + CHUNK - 1)/CHUNK);
+				for(uint32_t c = 0; c < nb; c++) pl.dequant_block_job.v.push_back((uint32_t)pl.dequant.v.size());
+				pl.dequant.v.push_back(q);
+			}
+		}
+	}
+	// block maps of the normal jobs (per vertex / per face, 256 per block)
+	for(uint32_t j = 0; j < pl.normal.v.size(); j++) {
+		const NormalJob &n = pl.normal.v[j];
+		pl.nv_block_first.v.push_back((uint32_t)pl.nv_block_job.v.size());
+		for(uint32_t c = 0; c < (n.nvert + 255)/256; c++) pl.nv_block_job.v.push_back(j);
+		pl.nf_block_first.v.push_back((uint32_t)pl.nf_block_job.v.size());
+		if(n.prediction != 0) for(uint32_t c = 0; c < (n.nface + 255)/256; c++) pl.nf_block_job.v.push_back(j);
+	}
+
+	pl.tun_partial_off = cv.take(((uint64_t)tun_chunks + 1)*8);
+	pl.unpack_partial_off = cv.take(((uint64_t)unpack_chunks + 1)*8);
+	pl.cloud_partial_off = cv.take(((uint64_t)cloud_chunks + 1)*8);
+
+	// job arrays region
+	pl.jobs_begin = cv.take(0);
+	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
+	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.unpack); place(pl.unpack_chunk_job);
+	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
+	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.dequant); place(pl.dequant_block_job);
+	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
+	pl.total = cv.take(0);
+
+	// ---- reserve device + pinned memory; one batch in flight per context ----
+	if(ctx->in_flight && ctx->in_flight != b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
+	if(ctx->in_flight == b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+	if(ctx->scratch.reserve(pl.total + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	if(ctx->staging.reserve(pl.jobs_bytes + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	uint8_t *base = (uint8_t *)ctx->scratch.p;
+	auto R = [&](const void *pseudo) -> uint8_t * {          // rebase a scratch-relative pseudo pointer
+		uintptr_t v = (uintptr_t)pseudo;
+		if(v >> 63) return (uint8_t *)(v & ~(1ull << 63));     // already real (arena)
+		return base + v;
+	};
+	for(auto &t : pl.tun.v) t.dst = R(t.dst);
+	for(auto &f : pl.fill.v) f.dst = R(f.dst);
+	for(auto &t : pl.topo.v) {
+		t.clers = R(t.clers);
+		t.group_end = (const uint32_t *)(base + pl.aux_u32.dev_off + (uintptr_t)t.group_end);
+		if(!t.pad) t.faces = R(t.faces);
+		t.pad = 0;
+		t.pred = (uint32_t *)R(t.pred); t.front_a = (uint4 *)R(t.front_a); t.front_b = (uint2 *)R(t.front_b);
+		t.order = (uint32_t *)R(t.order); t.delayed = (uint32_t *)R(t.delayed); t.status = (int32_t *)R(t.status);
+	}
+	for(auto &u : pl.unpack.v) {
+		u.logs = R(u.logs);
+		if(!(u.out_u8 & 0x80)) u.out = R(u.out);
+		u.out_u8 &= 0x7F;
+	}
+	for(auto &d : pl.delta.v) { if(!d.pad[0]) d.values = R(d.values); d.pad[0] = 0; d.pred = (const uint32_t *)R(d.pred); }
+	for(auto &c : pl.cloud.v) { if(!c.pad[0]) c.values = R(c.values); c.pad[0] = 0; }
+	for(auto &n : pl.normal.v) {
+		n.diffs = (int32_t *)R(n.diffs); n.status = (int32_t *)R(n.status);
+		if(n.prediction != 0 && !n.pad) n.faces = R(n.faces);
+		n.pad = 0;
+	}
+	for(auto &q : pl.dequant.v) if(q.is_color) q.color_src = R(q.color_src);
+	for(auto &P : b->blobs) { (void)P; }
+
+	// host image -> device (one copy)
+	uint8_t *stage = (uint8_t *)ctx->staging.p;
+	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
+	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.unpack); put(pl.unpack_chunk_job);
+	put(pl.delta); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
+	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.dequant); put(pl.dequant_block_job);
+
+	hipStream_t st = ctx->stream;
+	ctx->timer.reset();
+	Launch LT{ctx};
+	if(pl.jobs_bytes) HIP_TRY(hipMemcpyAsync(base + pl.jobs_begin, stage, pl.jobs_bytes, hipMemcpyHostToDevice, st));
+	if(pl.zero_end > pl.zero_begin) HIP_TRY(hipMemsetAsync(base + pl.zero_begin, 0, pl.zero_end - pl.zero_begin, st));
+
+	auto D = [&](auto &arr) { return (decltype(arr.v.data()))(base + arr.dev_off); };
+	TunTable *tables = (TunTable *)(base + pl.tables_off);
+	uint64_t *tun_partial = (uint64_t *)(base + pl.tun_partial_off);
+	uint64_t *unpack_partial = (uint64_t *)(base + pl.unpack_partial_off);
+	uint64_t *cloud_partial = (uint64_t *)(base + pl.cloud_partial_off);
+
+	const uint32_t ntun = (uint32_t)pl.tun.v.size();
+	if(ntun) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables); LT.end();
+		if(pl.tun_multi_chunk) {
+			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial); LT.end();
+			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks); LT.end();
+		}
+		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial); LT.end();
+	}
+	if(!pl.fill.v.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)pl.fill.v.size()), dim3(256), 0, st, D(pl.fill), (uint32_t)pl.fill.v.size()); LT.end(); }
+	if(!pl.topo.v.empty()) { LT.begin("topology"); hipLaunchKernelGGL(k_topology, dim3((uint32_t)pl.topo.v.size()), dim3(64), 0, st, D(pl.topo), (uint32_t)pl.topo.v.size()); LT.end(); }
+	if(unpack_chunks) {
+		LT.begin("unpack_sums"); hipLaunchKernelGGL(k_unpack_sums, dim3(unpack_chunks), dim3(256), 0, st, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
+		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, unpack_partial, unpack_chunks); LT.end();
+		LT.begin("unpack_extract"); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, st, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
+	}
+	if(!pl.delta.v.empty()) {
+		LT.begin("delta_mesh");
+		hipLaunchKernelGGL(k_delta_mesh, dim3((uint32_t)pl.delta.v.size()), dim3(64), pl.delta_lds, st, D(pl.delta), (uint32_t)pl.delta.v.size(), pl.delta_lds);
+		LT.end();
+	}
+	if(cloud_chunks) {
+		LT.begin("cloud_sums"); hipLaunchKernelGGL(k_cloud_sums, dim3(cloud_chunks), dim3(256), 0, st, D(pl.cloud), D(pl.cloud_chunk_job), cloud_chunks, cloud_partial); LT.end();
+		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, cloud_partial, cloud_chunks); LT.end();
+		LT.begin("cloud_apply"); hipLaunchKernelGGL(k_cloud_apply, dim3(cloud_chunks), dim3(256), 0, st, D(pl.cloud), D(pl.cloud_chunk_job), cloud_chunks, cloud_partial); LT.end();
+	}
+	const uint32_t nvb = (uint32_t)pl.nv_block_job.v.size(), nfb = (uint32_t)pl.nf_block_job.v.size();
+	if(pl.any_est_normal) {
+		float *facen = (float *)(base + pl.facen_off);
+		uint32_t *cnt = (uint32_t *)(base + pl.cnt_off), *cursor = (uint32_t *)(base + pl.cursor_off), *bnd = (uint32_t *)(base + pl.bnd_off);
+		uint32_t *start = (uint32_t *)(base + pl.start_off), *flag = (uint32_t *)(base + pl.flag_off), *slot = (uint32_t *)(base + pl.slot_off);
+		uint32_t *adj = (uint32_t *)(base + pl.adj_off);
+		uint64_t *npart = (uint64_t *)(base + pl.nscan_partial_off);
+		const uint32_t nv = pl.est_nvert, nch = (nv + CHUNK - 1)/CHUNK;
+		LT.begin("normal_faces"); hipLaunchKernelGGL(k_normal_faces, dim3(nfb), dim3(256), 0, st, D(pl.normal), D(pl.nf_block_job), D(pl.nf_block_first), nfb, facen, cnt, bnd); LT.end();
+		LT.begin("normal_scan");
+		hipLaunchKernelGGL(k_u32_chunk_sums, dim3(nch), dim3(256), 0, st, cnt, nv, npart);
+		hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, npart, nch);
+		hipLaunchKernelGGL(k_u32_chunk_apply, dim3(nch), dim3(256), 0, st, cnt, start, nv, npart);
+		LT.end();
+		LT.begin("normal_fill"); hipLaunchKernelGGL(k_normal_fill, dim3(nfb), dim3(256), 0, st, D(pl.normal), D(pl.nf_block_job), D(pl.nf_block_first), nfb, start, cursor, adj); LT.end();
+		LT.begin("normal_flags"); hipLaunchKernelGGL(k_normal_flags, dim3(nvb), dim3(256), 0, st, D(pl.normal), D(pl.nv_block_job), D(pl.nv_block_first), nvb, bnd, flag); LT.end();
+		LT.begin("normal_scan");
+		hipLaunchKernelGGL(k_u32_chunk_sums, dim3(nch), dim3(256), 0, st, flag, nv, npart);
+		hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, npart, nch);
+		hipLaunchKernelGGL(k_u32_chunk_apply, dim3(nch), dim3(256), 0, st, flag, slot, nv, npart);
+		LT.end();
+		LT.begin("normal_vertex"); hipLaunchKernelGGL(k_normal_vertex, dim3(nvb), dim3(256), 0, st, D(pl.normal), D(pl.nv_block_job), D(pl.nv_block_first), nvb, facen, start, cnt, adj, flag, slot); LT.end();
+	}
+	if(pl.any_diff_normal) { LT.begin("normal_diff"); hipLaunchKernelGGL(k_normal_diff, dim3(nvb), dim3(256), 0, st, D(pl.normal), D(pl.nv_block_job), D(pl.nv_block_first), nvb); LT.end(); }
+	const uint32_t ndq = (uint32_t)pl.dequant_block_job.v.size();
+	if(ndq) { LT.begin("dequantize"); hipLaunchKernelGGL(k_dequant, dim3(ndq), dim3(256), 0, st, D(pl.dequant), D(pl.dequant_block_job), ndq); LT.end(); }
+
+	// status back to the host
+	if(ctx->status_host.reserve((size_t)nblobs*4 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	if(nblobs) HIP_TRY(hipMemcpyAsync(ctx->status_host.p, base + pl.status_off, (size_t)nblobs*4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipGetLastError());
+
+	// stats
+	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun;
+	b->stats.scratch_bytes = pl.total;
+	uint64_t ob = 0;
+	for(auto &P : b->blobs) {
+		const BlobLayout &L = P.L;
+		if(P.index) ob += (uint64_t)L.h.nface*3*(P.index_u16 ? 2 : 4);
+		for(size_t k = 0; k < P.bind.size(); k++) {
+			if(!P.bind[k].buffer) continue;
+			const AttrHeader &a = L.h.attrs[k];
+			if(a.codec == CRTHIP_CODEC_NORMAL) ob += (uint64_t)L.h.nvert*3*(P.bind[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
+			else if(a.codec == CRTHIP_CODEC_COLOR) ob += (uint64_t)L.h.nvert*P.bind[k].out_components;
+			else ob += (uint64_t)L.h.nvert*a.N*4;
+		}
+	}
+	b->stats.output_bytes = ob;
+	ctx->in_flight = b;
+	b->decoded = true;
+	b->dirty = false;
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_batch_decode(crthip_batch *b) {
+	if(!b || !b->ctx) return fail(CRTHIP_E_ARGUMENT);
+	HIP_TRY(hipSetDevice(b->ctx->device));
+	return build_and_launch(b);
+}
+
+extern "C" int crthip_batch_sync(crthip_batch *b, int32_t *status) {
+	if(!b || !b->ctx) return fail(CRTHIP_E_ARGUMENT);
+	crthip_ctx *ctx = b->ctx;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	int first = CRTHIP_OK;
+	if(ctx->in_flight == b) {
+		const int32_t *hs = (const int32_t *)ctx->status_host.p;
+		for(size_t i = 0; i < b->blobs.size(); i++) {
+			int32_t s = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
+			b->status[i] = s;
+		}
+		ctx->in_flight = nullptr;
+	}
+	for(size_t i = 0; i < b->blobs.size(); i++) {
+		if(status) status[i] = b->status[i];
+		if(b->status[i] && !first) { first = b->status[i]; fail(first, std::string(crthip_strerror(first)) + " (blob " + std::to_string(i) + ")"); }
+	}
+	return first;
+}
+
+extern "C" int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s) {
+	if(!b || !s) return fail(CRTHIP_E_ARGUMENT);
+	*s = b->stats;
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_batch_kernel_times(crthip_batch *b, crthip_kernel_times *t) {
+	if(!b || !t) return fail(CRTHIP_E_ARGUMENT);
+	crthip_ctx *ctx = b->ctx;
+	memset(t, 0, sizeof(*t));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	for(auto &r : ctx->timer.recs) {
+		float ms = 0;
+		if(hipEventElapsedTime(&ms, ctx->timer.pool[r.e0], ctx->timer.pool[r.e1]) != hipSuccess) continue;
+		uint32_t k = 0;
+		for(; k < t->count; k++) if(strcmp(t->name[k], r.name) == 0) break;
+		if(k == t->count) { if(t->count == CRTHIP_MAX_KERNELS) continue; t->name[k] = r.name; t->count++; }
+		t->ms[k] += ms; t->launches[k]++;
+	}
+	return CRTHIP_OK;
+}
+
+extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const char *what, void *host_out, size_t cap) {
+	if(!b || i >= b->blobs.size() || !what || !host_out || !b->decoded) return fail(CRTHIP_E_ARGUMENT);
+	crthip_ctx *ctx = b->ctx;
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	BlobPlan &P = b->blobs[i];
+	const uint8_t *src = nullptr; size_t n = 0;
+	if(!strcmp(what, "clers")) {
+		if(P.dbg_clers == ~0ull) return 0;
+		src = P.clers_in_arena ? b->d_arena + P.dbg_clers : (const uint8_t *)ctx->scratch.p + P.dbg_clers; n = P.dbg_nclers;
+	} else if(!strcmp(what, "prediction")) {
+		if(P.dbg_pred == ~0ull) return 0;
+		src = (const uint8_t *)ctx->scratch.p + P.dbg_pred; n = (size_t)P.L.h.nvert*12;
+	} else return fail(CRTHIP_E_ARGUMENT);
+	n = std::min(n, cap);
+	HIP_TRY(hipMemcpy(host_out, src, n, hipMemcpyDeviceToHost));
+	return (int64_t)n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one blob, host buffers: the crt::Decoder facade's decode()
+extern "C" int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
+                                  void *index, uint32_t index_format) {
+	if(!ctx || !blob) return fail(CRTHIP_E_ARGUMENT);
+	HIP_TRY(hipSetDevice(ctx->device));
+	crthip_batch *b = nullptr;
+	uint32_t l32 = (uint32_t)len;
+	int err = crthip_batch_create(ctx, 1, &blob, &l32, nullptr, &b);
+	if(err) return err;
+	const BlobLayout &L = b->blobs[0].L;
+	const uint32_t nvert = L.h.nvert, nface = L.h.nface;
+	std::vector<crthip_attr_binding> dev(L.h.attrs.size());
+	std::vector<size_t> bytes(L.h.attrs.size(), 0);
+	std::vector<void *> allocs;
+	auto cleanup = [&]() { for(void *p : allocs) (void)hipFree(p); crthip_batch_destroy(b); };
+	for(size_t k = 0; k < L.h.attrs.size(); k++) {
+		dev[k] = attrs ? attrs[k] : crthip_attr_binding{nullptr, 0, 0};
+		if(!dev[k].buffer) continue;
+		const AttrHeader &a = L.h.attrs[k];
+		size_t nb;
+		if(a.codec == CRTHIP_CODEC_NORMAL) nb = (size_t)nvert*3*(dev[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
+		else if(a.codec == CRTHIP_CODEC_COLOR) nb = (size_t)nvert*(dev[k].out_components ? dev[k].out_components : 4);
+		else nb = (size_t)nvert*a.N*4;
+		bytes[k] = nb;
+		void *d = nullptr;
+		if(hipMalloc(&d, nb + 16) != hipSuccess) { cleanup(); return fail(CRTHIP_E_NOMEM); }
+		allocs.push_back(d);
+		dev[k].buffer = d;
+	}
+	void *dindex = nullptr; size_t ibytes = 0;
+	if(index && nface) {
+		ibytes = (size_t)nface*3*(index_format == CRTHIP_FMT_UINT16 ? 2 : 4);
+		if(hipMalloc(&dindex, ibytes + 16) != hipSuccess) { cleanup(); return fail(CRTHIP_E_NOMEM); }
+		allocs.push_back(dindex);
+	}
+	err = crthip_batch_bind(b, 0, dev.data(), dindex, index_format);
+	if(!err) err = crthip_batch_decode(b);
+	if(!err) err = crthip_batch_sync(b, nullptr);
+	if(!err) {
+		for(size_t k = 0; k < dev.size() && !err; k++)
+			if(dev[k].buffer && hipMemcpy(attrs[k].buffer, dev[k].buffer, bytes[k], hipMemcpyDeviceToHost) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
+		if(dindex && !err && hipMemcpy(index, dindex, ibytes, hipMemcpyDeviceToHost) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
+	}
+	std::string keep = g_error;
+	cleanup();
+	g_error = keep;
+	return err;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone Tunstall run over device-resident blocks (roofline measurement of K-TAB/K-TUN)
+extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const uint8_t *host_blocks, const void *device_blocks,
+                                             const uint64_t *block_offset, void *device_out, const uint64_t *out_offset,
+                                             crthip_kernel_times *times) {
+	if(!ctx || !host_blocks || !device_blocks || !block_offset || !device_out || !out_offset) return fail(CRTHIP_E_ARGUMENT);
+	HIP_TRY(hipSetDevice(ctx->device));
+	if(ctx->in_flight) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
+	std::vector<TunStream> tun; std::vector<uint32_t> chunk_stream; std::vector<FillJob> fills;
+	uint32_t chunks = 0; bool multi = false;
+	for(uint32_t i = 0; i < n; i++) {
+		const uint8_t *p = host_blocks + block_offset[i];
+		const uint32_t ns = p[0];
+		auto rd = [&](const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+		const uint32_t size = rd(p + 1 + 2*ns), csize = rd(p + 5 + 2*ns);
+		const uint8_t *dblk = (const uint8_t *)device_blocks + block_offset[i];
+		uint8_t *dst = (uint8_t *)device_out + out_offset[i];
+		if(size == 0) continue;
+		if(ns == 1) { fills.push_back(FillJob{dst, size, p[1]}); continue; }
+		if(ns == 0 || csize == 0) return fail(CRTHIP_E_TRUNCATED);
+		TunStream t{};
+		t.src = dblk + 9 + 2*ns; t.dst = dst; t.probs = dblk + 1; t.csize = csize; t.size = size; t.nsym = ns; t.table = (uint32_t)tun.size();
+		t.chunk0 = chunks; t.nchunks = (csize + TUN_CHUNK_CODES - 1)/TUN_CHUNK_CODES;
+		if(t.nchunks > 1) multi = true;
+		for(uint32_t c = 0; c < t.nchunks; c++) chunk_stream.push_back((uint32_t)tun.size());
+		chunks += t.nchunks;
+		tun.push_back(t);
+	}
+	Carver cv;
+	const uint64_t o_tab = cv.take(tun.size()*sizeof(TunTable)), o_part = cv.take(((uint64_t)chunks + 1)*8);
+	const uint64_t o_jobs = cv.take(0);
+	const uint64_t o_tun = cv.take(tun.size()*sizeof(TunStream) + 16, 16), o_cs = cv.take(chunk_stream.size()*4 + 16, 16), o_fill = cv.take(fills.size()*sizeof(FillJob) + 16, 16);
+	const uint64_t total = cv.take(0);
+	if(ctx->scratch.reserve(total + 256) != CRTHIP_OK || ctx->staging.reserve(total - o_jobs + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	uint8_t *base = (uint8_t *)ctx->scratch.p, *stage = (uint8_t *)ctx->staging.p;
+	if(!tun.empty()) memcpy(stage + (o_tun - o_jobs), tun.data(), tun.size()*sizeof(TunStream));
+	if(!chunk_stream.empty()) memcpy(stage + (o_cs - o_jobs), chunk_stream.data(), chunk_stream.size()*4);
+	if(!fills.empty()) memcpy(stage + (o_fill - o_jobs), fills.data(), fills.size()*sizeof(FillJob));
+	hipStream_t st = ctx->stream;
+	HIP_TRY(hipMemcpyAsync(base + o_jobs, stage, total - o_jobs, hipMemcpyHostToDevice, st));
+	ctx->timer.reset();
+	Launch LT{ctx};
+	TunStream *dt = (TunStream *)(base + o_tun); uint32_t *dcs = (uint32_t *)(base + o_cs);
+	TunTable *tables = (TunTable *)(base + o_tab); uint64_t *part = (uint64_t *)(base + o_part);
+	const uint32_t ntun = (uint32_t)tun.size();
+	if(ntun) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables); LT.end();
+		if(multi) {
+			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part); LT.end();
+			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks); LT.end();
+		}
+		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part); LT.end();
+	}
+	if(!fills.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)fills.size()), dim3(256), 0, st, (FillJob *)(base + o_fill), (uint32_t)fills.size()); LT.end(); }
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	if(times) {
+		memset(times, 0, sizeof(*times));
+		for(auto &r : ctx->timer.recs) {
+			float ms = 0;
+			if(hipEventElapsedTime(&ms, ctx->timer.pool[r.e0], ctx->timer.pool[r.e1]) != hipSuccess) continue;
+			uint32_t k = 0;
+			for(; k < times->count; k++) if(strcmp(times->name[k], r.name) == 0) break;
+			if(k == times->count) { if(times->count == CRTHIP_MAX_KERNELS) continue; times->name[k] = r.name; times->count++; }
+			times->ms[k] += ms; times->launches[k]++;
+		}
+	}
+	return CRTHIP_OK;
+}

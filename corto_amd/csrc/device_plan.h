@@ -1,0 +1,107 @@
+// device_plan.h — POD descriptors shared by the host planner (batch.cpp) and the HIP kernels.
+// All pointers are DEVICE addresses.  One array of each job type per batch, uploaded in one H2D copy.
+#pragma once
+#include <cstdint>
+
+namespace corto_hip {
+
+constexpr uint32_t TUN_TABLE_BYTES = 8192 + 512;   // reference buffer is 8192 B (src/tunstall.cpp:137)
+constexpr uint32_t TUN_ENTRY_CAP = 768;            // creation-order entries; the reference reaches <= 510
+constexpr uint32_t CHUNK = 1024;                   // elements per scan chunk (256 threads x 4)
+
+// Decode table of one Tunstall stream as the decode kernel wants it (K-TAB output)
+struct TunTable {
+	uint16_t off[256];             // word start in bytes[]            (Tunstall::index)
+	uint8_t len[256];              // word length                      (Tunstall::lengths)
+	uint32_t used;                 // bytes of bytes[] any word reaches
+	uint32_t pad[3];
+	uint8_t bytes[TUN_TABLE_BYTES];
+};
+
+struct TunStream {
+	const uint8_t *src;            // codewords
+	uint8_t *dst;                  // decoded symbols
+	const uint8_t *probs;          // nsym x (symbol, probability)
+	uint32_t csize, size, nsym;
+	uint32_t table;                // TunTable slot
+	uint32_t chunk0;               // first entry of this stream in the chunk arrays (long streams)
+	uint32_t nchunks;
+};
+
+struct FillJob { uint8_t *dst; uint32_t size; uint32_t value; };
+
+// CLERS automaton input/output of one mesh blob (src/decoder.cpp:204-358)
+struct TopoJob {
+	const uint8_t *clers;
+	const uint32_t *split_words;
+	const uint32_t *group_end;
+	void *faces;                   // nface*3 u32 or u16
+	uint32_t *pred;                // nvert*3
+	uint4 *front_a;                // (v0, v1, v2, deleted)
+	uint2 *front_b;                // (prev, next)
+	uint32_t *order;               // FIFO of edge ids
+	uint32_t *delayed;             // LIFO of edge ids
+	int32_t *status;
+	uint32_t nclers, split_nwords, ngroups;
+	uint32_t nvert, nface, front_cap, faces_u16;
+	uint32_t pad;
+};
+
+// one log stream to turn into values (include/corto/cstream.h:294-360)
+struct UnpackJob {
+	const uint8_t *logs;
+	const uint32_t *words;
+	void *out;                     // int32* or uint8*
+	uint32_t count;                // logs in the stream
+	uint32_t nwords;
+	uint32_t out_limit;            // never write element index >= out_limit (nvert)
+	uint32_t chunk0;               // first chunk of this job in the chunk arrays
+	uint32_t chain_chunk0;         // first chunk of the bit block this job shares (component-major chaining)
+	uint16_t fields;               // ARRAY: N fields per log; VALUES: 1
+	uint16_t stride;               // output elements per vertex
+	uint16_t comp;                 // VALUES: component
+	uint8_t mode;                  // 0 ARRAY, 1 VALUES
+	uint8_t out_u8;
+};
+
+// parallelogram / first-neighbour delta over a mesh (include/corto/vertex_attribute.h:160-176,
+// src/normal_attribute.cpp:193-201)
+struct DeltaJob {
+	void *values;                  // int32* or uint8*, stride N
+	const uint32_t *pred;
+	uint32_t nvert, N;
+	uint8_t parallelogram, is_u8, pad[2];
+	uint32_t pad2;
+};
+
+// point-cloud running sum, one job per (blob, attribute) (vertex_attribute.h:177-181, normal_attribute.cpp:202-207)
+struct CloudJob {
+	void *values;
+	uint32_t nvert, N;
+	uint32_t chunk0;               // N * ceil(nvert/CHUNK) chunks: component-major
+	uint8_t is_u8, pad[3];
+};
+
+struct NormalJob {
+	int32_t *diffs;                // 2 ints per (corrected) vertex
+	void *out;                     // nvert*3 f32 or i16
+	const int32_t *position;       // delta-decoded integer positions (3 per vertex), ESTIMATED/BORDER only
+	const void *faces;
+	uint32_t nvert, nface, ndiffs;
+	uint32_t vbase, fbase;         // offsets into the batch-wide per-vertex / per-face scratch arrays
+	int32_t unit;                  // (int)q
+	uint8_t prediction, out_i16, faces_u16, pad;
+	int32_t *status;
+};
+
+struct DequantJob {
+	void *buffer;                  // generic: in-place int32 -> float; colour: destination
+	const uint8_t *color_src;      // colour: delta-decoded N-component bytes
+	float q;
+	uint32_t nvert, N, out_components;
+	uint32_t qc[4];
+	uint32_t block0;               // first block of this job in the block->job map
+	uint8_t is_color, pad[3];
+};
+
+} // namespace corto_hip

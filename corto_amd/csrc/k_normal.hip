@@ -1,0 +1,189 @@
+// k_normal.hip — normal reconstruction for gfx950.
+//   DIFF      : octahedral ints -> unit vectors                    src/normal_attribute.cpp:257-279, include/corto/normal_attribute.h:104-122
+//   ESTIMATED / BORDER (NormalAttr::postDelta, src/normal_attribute.cpp:210-255):
+//     estimateNormals :40-59   per-face float cross products of the INTEGER positions, accumulated per vertex
+//                              in face order (float addition order is part of the result)
+//     markBoundary    :24-37   XOR of neighbour ids (order-free -> atomicXor)
+//     computeNormals  :281-325 toOcta(est) + diff[slot] -> toSphere, or est/|est|
+//
+// Ordered accumulation without a serial pass over faces: build a CSR of incident faces per vertex with
+// atomics (arbitrary order), then each vertex walks its own short list in ascending face id.  All float
+// code is compiled with -ffp-contract=off: an FMA changes the reference's bits.
+#include "kernels_common.h"
+
+namespace corto_hip {
+
+// include/corto/point.h:111 — (float)sqrt((double)((x*x + y*y) + z*z))
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+	float s = x*x + y*y;
+	s = s + z*z;
+	return (float)sqrt((double)s);
+}
+
+// include/corto/normal_attribute.h:75-85
+__device__ __forceinline__ void to_octa(float vx, float vy, float vz, int32_t unit, int32_t &ox, int32_t &oy) {
+	float s = fabsf(vx) + fabsf(vy);
+	s = s + fabsf(vz);
+	float px = vx/s, py = vy/s;
+	if(vz < 0) {
+		const float qx = 1.0f - fabsf(py), qy = 1.0f - fabsf(px);
+		px = qx; py = qy;
+		if(vx < 0) px = -px;
+		if(vy < 0) py = -py;
+	}
+	ox = f2i_x86(px*(float)unit);
+	oy = f2i_x86(py*(float)unit);
+}
+
+// include/corto/normal_attribute.h:104-112 (x, y already narrowed to the caller's integer type)
+__device__ __forceinline__ void to_sphere(int32_t x, int32_t y, int32_t unit, float &nx, float &ny, float &nz) {
+	const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x, ay = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
+	const int32_t z = (int32_t)((uint32_t)unit - ax - ay);
+	nx = (float)x; ny = (float)y; nz = (float)z;
+	if(nz < 0) {
+		nx = (float)(int32_t)((x > 0 ? 1u : 0xFFFFFFFFu)*((uint32_t)unit - ay));
+		ny = (float)(int32_t)((y > 0 ? 1u : 0xFFFFFFFFu)*((uint32_t)unit - ax));
+	}
+	const float l = norm3(nx, ny, nz);
+	nx /= l; ny /= l; nz /= l;
+}
+
+__device__ __forceinline__ void store_normal(const NormalJob &J, uint32_t i, float nx, float ny, float nz) {
+	if(J.out_i16) {                                     // Point3s(n*32767) (normal_attribute.h:121)
+		int16_t *o = (int16_t *)J.out + (size_t)i*3;
+		o[0] = f2s_x86(nx*32767); o[1] = f2s_x86(ny*32767); o[2] = f2s_x86(nz*32767);
+	} else {
+		float *o = (float *)J.out + (size_t)i*3;
+		o[0] = nx; o[1] = ny; o[2] = nz;
+	}
+}
+
+__device__ __forceinline__ void load_face(const NormalJob &J, uint32_t f, uint32_t &a, uint32_t &b, uint32_t &c) {
+	if(J.faces_u16) { const uint16_t *p = (const uint16_t *)J.faces + (size_t)f*3; a = p[0]; b = p[1]; c = p[2]; }
+	else { const uint32_t *p = (const uint32_t *)J.faces + (size_t)f*3; a = p[0]; b = p[1]; c = p[2]; }
+}
+
+// ---- DIFF: dequantize (normal_attribute.cpp:257-279). block -> job; thread = vertex ----
+__global__ __launch_bounds__(256) void k_normal_diff(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ block_job,
+                                                     const uint32_t *__restrict__ block_first, uint32_t nblocks) {
+	if(blockIdx.x >= nblocks) return;
+	const NormalJob J = jobs[block_job[blockIdx.x]];
+	if(J.prediction != 0) return;
+	const uint32_t i = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
+	if(i >= J.nvert) return;
+	int32_t x = J.diffs[2*(size_t)i], y = J.diffs[2*(size_t)i + 1];
+	if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }   // Point2s(diffs...) :269
+	float nx, ny, nz;
+	to_sphere(x, y, J.unit, nx, ny, nz);
+	store_normal(J, i, nx, ny, nz);
+}
+
+// ---- ESTIMATED/BORDER step 1: per face: cross product, incidence counts, boundary XOR ----
+__global__ __launch_bounds__(256) void k_normal_faces(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ block_job,
+                                                      const uint32_t *__restrict__ block_first, uint32_t nblocks,
+                                                      float *__restrict__ facen, uint32_t *__restrict__ cnt, uint32_t *__restrict__ bnd) {
+	if(blockIdx.x >= nblocks) return;
+	const NormalJob J = jobs[block_job[blockIdx.x]];
+	const uint32_t f = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
+	if(f >= J.nface) return;
+	uint32_t a, b, c;
+	load_face(J, f, a, b, c);
+	float *n = facen + ((size_t)J.fbase + f)*3;
+	if(a >= J.nvert || b >= J.nvert || c >= J.nvert) { n[0] = n[1] = n[2] = 0.f; *J.status = -5; return; }
+	const int32_t *p0 = J.position + (size_t)a*3, *p1 = J.position + (size_t)b*3, *p2 = J.position + (size_t)c*3;
+	const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
+	const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
+	const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;
+	n[0] = ay*bz - az*by;                               // point.h:113-115
+	n[1] = az*bx - ax*bz;
+	n[2] = ax*by - ay*bx;
+	atomicAdd(&cnt[J.vbase + a], 1u); atomicAdd(&cnt[J.vbase + b], 1u); atomicAdd(&cnt[J.vbase + c], 1u);
+	if(J.prediction == 2) {                             // markBoundary
+		atomicXor(&bnd[J.vbase + a], b ^ c); atomicXor(&bnd[J.vbase + b], c ^ a); atomicXor(&bnd[J.vbase + c], a ^ b);
+	}
+}
+
+// ---- step 2 (after scanning cnt -> start): scatter face ids into each vertex' slot range ----
+__global__ __launch_bounds__(256) void k_normal_fill(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ block_job,
+                                                     const uint32_t *__restrict__ block_first, uint32_t nblocks,
+                                                     const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ adj) {
+	if(blockIdx.x >= nblocks) return;
+	const NormalJob J = jobs[block_job[blockIdx.x]];
+	const uint32_t f = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
+	if(f >= J.nface) return;
+	uint32_t v[3];
+	load_face(J, f, v[0], v[1], v[2]);
+	if(v[0] >= J.nvert || v[1] >= J.nvert || v[2] >= J.nvert) return;
+#pragma unroll
+	for(int k = 0; k < 3; k++) {
+		const uint32_t g = J.vbase + v[k];
+		adj[start[g] + atomicAdd(&cursor[g], 1u)] = f;
+	}
+}
+
+// ---- step 3: flag vertices that take a correction (ESTIMATED: all, BORDER: boundary != 0) ----
+__global__ __launch_bounds__(256) void k_normal_flags(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ block_job,
+                                                      const uint32_t *__restrict__ block_first, uint32_t nblocks,
+                                                      const uint32_t *__restrict__ bnd, uint32_t *__restrict__ flag) {
+	if(blockIdx.x >= nblocks) return;
+	const NormalJob J = jobs[block_job[blockIdx.x]];
+	const uint32_t i = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
+	if(i >= J.nvert) return;
+	flag[J.vbase + i] = (J.prediction == 1 || bnd[J.vbase + i] != 0) ? 1u : 0u;
+}
+
+// ---- step 4: per vertex ordered accumulation + computeNormals ----
+__global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ block_job,
+                                                       const uint32_t *__restrict__ block_first, uint32_t nblocks,
+                                                       const float *__restrict__ facen, const uint32_t *__restrict__ start,
+                                                       const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ adj,
+                                                       const uint32_t *__restrict__ flag, const uint32_t *__restrict__ slot) {
+	if(blockIdx.x >= nblocks) return;
+	const NormalJob J = jobs[block_job[blockIdx.x]];
+	if(J.prediction == 0) return;
+	const uint32_t i = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
+	if(i >= J.nvert) return;
+	const uint32_t g = J.vbase + i;
+	const uint32_t deg = cnt[g];
+	const uint32_t *__restrict__ list = adj + start[g];
+	float ex = 0.f, ey = 0.f, ez = 0.f;
+	// incident faces in ascending id (= the order estimateNormals visits them); a face listing this vertex
+	// twice adds twice, consecutively, as the reference's three += in a row do.
+	int64_t last = -1;
+	for(uint32_t done = 0; done < deg;) {
+		uint32_t best = 0xFFFFFFFFu, mult = 0;
+		for(uint32_t k = 0; k < deg; k++) {
+			const uint32_t f = list[k];
+			if((int64_t)f > last) { if(f < best) { best = f; mult = 1; } else if(f == best) mult++; }
+		}
+		const float *n = facen + ((size_t)J.fbase + best)*3;
+		const float nx = n[0], ny = n[1], nz = n[2];
+		for(uint32_t m = 0; m < mult; m++) { ex += nx; ey += ny; ez += nz; }
+		last = best; done += mult;
+	}
+	if(flag[g]) {                                       // normal_attribute.cpp:289-293 / 313-316
+		const uint32_t s = slot[g] - slot[J.vbase];
+		int32_t qx, qy;
+		to_octa(ex, ey, ez, J.unit, qx, qy);
+		int32_t dx = 0, dy = 0;
+		if(s < J.ndiffs) { dx = J.diffs[2*(size_t)s]; dy = J.diffs[2*(size_t)s + 1]; }
+		int32_t x = (int32_t)((uint32_t)qx + (uint32_t)dx), y = (int32_t)((uint32_t)qy + (uint32_t)dy);
+		if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }
+		float nx, ny, nz;
+		to_sphere(x, y, J.unit, nx, ny, nz);
+		store_normal(J, i, nx, ny, nz);
+	} else if(J.out_i16) {                              // normal_attribute.cpp:294-302
+		float len = norm3(ex, ey, ez);
+		if(!(len < 0.00001f)) {
+			len = 32767.0f/len;
+			int16_t *o = (int16_t *)J.out + (size_t)i*3;
+			o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
+		}
+	} else {                                            // normal_attribute.cpp:317-322
+		const float len = norm3(ex, ey, ez);
+		float *o = (float *)J.out + (size_t)i*3;
+		o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
+	}
+}
+
+} // namespace corto_hip

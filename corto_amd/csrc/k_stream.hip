@@ -1,0 +1,212 @@
+// k_stream.hip — the stream-level (scan + gather) stages for gfx950:
+//   device-wide exclusive scans of per-chunk partials,
+//   K-BIT  bit-unpack of log/field streams      include/corto/cstream.h:294-360, src/bitstream.cpp:103-121
+//   K-DELTA (point clouds) running sums         include/corto/vertex_attribute.h:177-181, src/normal_attribute.cpp:202-207
+//   K-DEQ  dequantisation                       include/corto/vertex_attribute.h:184-193, src/color_attribute.cpp:72-95
+//
+// Every stage is "scan + gather" over chunks of CHUNK elements; a chunk->job map built by the host
+// lets one launch cover every blob of the batch.
+#include "kernels_common.h"
+
+namespace corto_hip {
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of a[0..n) in place, one 1024-thread workgroup (n = number of chunks: small)
+__global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *__restrict__ a, uint32_t n) {
+	__shared__ uint64_t wsum[16];
+	__shared__ uint64_t carry_s;
+	if(threadIdx.x == 0) carry_s = 0;
+	__syncthreads();
+	const uint32_t lane = lane_id(), w = wave_id();
+	for(uint32_t base = 0; base < n; base += 1024) {
+		const uint32_t i = base + threadIdx.x;
+		const uint64_t v = i < n ? a[i] : 0;
+		uint64_t inc = wave_inclusive_scan(v);
+		if(lane == 63) wsum[w] = inc;
+		__syncthreads();
+		uint64_t wbase = 0, total = 0;
+#pragma unroll
+		for(uint32_t k = 0; k < 16; k++) { const uint64_t s = wsum[k]; if(k < w) wbase += s; total += s; }
+		const uint64_t carry = carry_s;
+		if(i < n) a[i] = carry + wbase + inc - v;
+		__syncthreads();
+		if(threadIdx.x == 0) carry_s = carry + total;
+		__syncthreads();
+	}
+}
+
+// u32 array scan in three phases (used for CSR offsets / boundary slots): per-chunk sums ...
+__global__ __launch_bounds__(256) void k_u32_chunk_sums(const uint32_t *__restrict__ a, uint32_t n, uint64_t *__restrict__ partial) {
+	const uint32_t c = blockIdx.x;
+	const uint32_t i0 = c*CHUNK + 4*threadIdx.x;
+	uint32_t s = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) if(i0 + k < n) s += a[i0 + k];
+#pragma unroll
+	for(int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+	__shared__ uint32_t red[4];
+	if(lane_id() == 0) red[wave_id()] = s;
+	__syncthreads();
+	if(threadIdx.x == 0) partial[c] = (uint64_t)red[0] + red[1] + red[2] + red[3];
+}
+// ... and the exclusive apply into out (may alias a; partial already scanned by k_scan_u64)
+__global__ __launch_bounds__(256) void k_u32_chunk_apply(const uint32_t *a, uint32_t *out, uint32_t n, const uint64_t *__restrict__ partial) {
+	const uint32_t c = blockIdx.x;
+	const uint32_t i0 = c*CHUNK + 4*threadIdx.x;
+	uint32_t v[4], s = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) { v[k] = i0 + k < n ? a[i0 + k] : 0u; s += v[k]; }
+	__shared__ uint32_t smem[4];
+	uint32_t total;
+	uint32_t o = (uint32_t)partial[c] + block256_exclusive_scan<uint32_t>(s, smem, &total);
+#pragma unroll
+	for(int k = 0; k < 4; k++) { if(i0 + k < n) out[i0 + k] = o; o += v[k]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-BIT.  chunk c -> job chunk_job[c]; the job's bit block may be shared by several jobs (one per
+// component, component-major: cstream.h:300-317), which is why offsets are taken relative to the first
+// chunk of the whole bit block (chain_chunk0) after ONE device-wide scan of all chunk sums.
+__device__ __forceinline__ uint32_t unpack_bits_of(const UnpackJob &J, uint32_t log) {
+	const uint32_t d = log > 32 ? 32u : log;          // >32 cannot be produced by the encoder (UB in the reference)
+	return d*J.fields;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_sums(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
+                                                     uint32_t nchunks, uint64_t *__restrict__ partial) {
+	const uint32_t c = blockIdx.x;
+	if(c >= nchunks) return;
+	const UnpackJob J = jobs[chunk_job[c]];
+	const uint32_t i0 = (c - J.chunk0)*CHUNK + 4*threadIdx.x;
+	uint32_t s = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) if(i0 + k < J.count) s += unpack_bits_of(J, J.logs[i0 + k]);
+#pragma unroll
+	for(int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+	__shared__ uint32_t red[4];
+	if(lane_id() == 0) red[wave_id()] = s;
+	__syncthreads();
+	if(threadIdx.x == 0) partial[c] = (uint64_t)red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
+                                                        uint32_t nchunks, const uint64_t *__restrict__ partial) {
+	const uint32_t c = blockIdx.x;
+	if(c >= nchunks) return;
+	const UnpackJob J = jobs[chunk_job[c]];
+	const uint32_t i0 = (c - J.chunk0)*CHUNK + 4*threadIdx.x;
+	uint32_t lg[4], s = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) {
+		lg[k] = i0 + k < J.count ? (uint32_t)J.logs[i0 + k] : 0u;
+		if(lg[k] > 32) lg[k] = 32;
+		s += lg[k]*J.fields;
+	}
+	__shared__ uint32_t smem[4];
+	uint32_t total;
+	uint64_t o = partial[c] - partial[J.chain_chunk0] + block256_exclusive_scan<uint32_t>(s, smem, &total);
+	const uint32_t *__restrict__ words = J.words;
+#pragma unroll
+	for(int k = 0; k < 4; k++) {
+		const uint32_t i = i0 + k;
+		if(i >= J.count) break;
+		const uint32_t d = lg[k];
+		const bool store = i < J.out_limit;
+		if(J.mode == 0) {                              // decodeArray: v = raw - 2^(d-1); d == 0 -> zeros (cstream.h:337-357)
+			int32_t *out = (int32_t *)J.out + (size_t)i*J.stride;
+			const uint32_t half = d ? (uint32_t)((1ull << d) >> 1) : 0u;
+			for(uint32_t f = 0; f < J.fields; f++) {
+				const int32_t v = d ? (int32_t)(bit_field(words, J.nwords, o, d) - half) : 0;
+				o += d;
+				if(store) out[f] = v;
+			}
+		} else {                                       // decodeValues: sign folding (cstream.h:304-316)
+			int32_t v = 0;
+			if(d) {
+				v = (int32_t)bit_field(words, J.nwords, o, d);
+				const int32_t mid = (int32_t)(1u << (d - 1));
+				if(v < mid) v = -v - mid;
+				o += d;
+			}
+			if(store) {
+				if(J.out_u8) ((uint8_t *)J.out)[(size_t)i*J.stride + J.comp] = (uint8_t)v;
+				else ((int32_t *)J.out)[(size_t)i*J.stride + J.comp] = v;
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// point-cloud delta: v[i] += v[i-N] over the flat array == per-component inclusive scan (wrap-around)
+__device__ __forceinline__ uint32_t cloud_load(const CloudJob &J, uint32_t i, uint32_t comp) {
+	return J.is_u8 ? (uint32_t)((const uint8_t *)J.values)[(size_t)i*J.N + comp] : ((const uint32_t *)J.values)[(size_t)i*J.N + comp];
+}
+
+__global__ __launch_bounds__(256) void k_cloud_sums(const CloudJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
+                                                    uint32_t nchunks, uint64_t *__restrict__ partial) {
+	const uint32_t c = blockIdx.x;
+	if(c >= nchunks) return;
+	const CloudJob J = jobs[chunk_job[c]];
+	const uint32_t cpc = (J.nvert + CHUNK - 1)/CHUNK, cj = c - J.chunk0;
+	const uint32_t comp = cj/cpc, i0 = (cj - comp*cpc)*CHUNK + 4*threadIdx.x;
+	uint32_t s = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) if(i0 + k < J.nvert) s += cloud_load(J, i0 + k, comp);
+#pragma unroll
+	for(int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+	__shared__ uint32_t red[4];
+	if(lane_id() == 0) red[wave_id()] = s;
+	__syncthreads();
+	if(threadIdx.x == 0) partial[c] = (uint64_t)(uint32_t)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_cloud_apply(const CloudJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
+                                                     uint32_t nchunks, const uint64_t *__restrict__ partial) {
+	const uint32_t c = blockIdx.x;
+	if(c >= nchunks) return;
+	const CloudJob J = jobs[chunk_job[c]];
+	const uint32_t cpc = (J.nvert + CHUNK - 1)/CHUNK, cj = c - J.chunk0;
+	const uint32_t comp = cj/cpc, i0 = (cj - comp*cpc)*CHUNK + 4*threadIdx.x;
+	uint32_t v[4], s = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) { v[k] = i0 + k < J.nvert ? cloud_load(J, i0 + k, comp) : 0u; s += v[k]; }
+	__shared__ uint32_t smem[4];
+	uint32_t total;
+	uint32_t o = (uint32_t)(partial[c] - partial[J.chunk0 + comp*cpc]) + block256_exclusive_scan<uint32_t>(s, smem, &total);
+#pragma unroll
+	for(int k = 0; k < 4; k++) {
+		if(i0 + k >= J.nvert) break;
+		o += v[k];
+		if(J.is_u8) ((uint8_t *)J.values)[(size_t)(i0 + k)*J.N + comp] = (uint8_t)o;
+		else ((uint32_t *)J.values)[(size_t)(i0 + k)*J.N + comp] = o;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-DEQ. block b -> job block_job[b]; 256 threads x 4 elements.
+__global__ __launch_bounds__(256) void k_dequant(const DequantJob *__restrict__ jobs, const uint32_t *__restrict__ block_job, uint32_t nblocks) {
+	const uint32_t b = blockIdx.x;
+	if(b >= nblocks) return;
+	const DequantJob J = jobs[block_job[b]];
+	const uint32_t e0 = (b - J.block0)*CHUNK + 4*threadIdx.x;
+	if(!J.is_color) {                                          // out = (float)v * q, in place (vertex_attribute.h:190-193)
+		const uint32_t n = J.nvert*J.N;
+		int32_t *vi = (int32_t *)J.buffer;
+		float *vf = (float *)J.buffer;
+#pragma unroll
+		for(int k = 0; k < 4; k++) if(e0 + k < n) { const float f = (float)vi[e0 + k]; vf[e0 + k] = f*J.q; }
+	} else {                                                   // YCC -> RGB, x qc, u8 wrap (color_attribute.cpp:76-95, point.h:214)
+#pragma unroll
+		for(int k = 0; k < 4; k++) {
+			const uint32_t i = e0 + k;
+			if(i >= J.nvert) break;
+			uint32_t col[4] = {0, 0, 0, 255};
+			for(uint32_t c = 0; c < J.N && c < 4; c++) col[c] = J.color_src[(size_t)i*J.N + c];
+			const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
+			uint8_t *out = (uint8_t *)J.buffer + (size_t)i*J.out_components;
+			for(uint32_t c = 0; c < J.out_components && c < 4; c++) out[c] = (uint8_t)(rgb[c]*J.qc[c]);
+		}
+	}
+}
+
+} // namespace corto_hip

@@ -1,0 +1,45 @@
+// kernels.h — declarations of the HIP kernels (k_tunstall.hip, k_stream.hip, k_mesh.hip, k_normal.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_plan.h"
+
+namespace corto_hip {
+
+// k_tunstall.hip
+__global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables);
+__global__ void k_tun_chunk_sums(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                                 uint32_t chunk_codes, uint64_t *chunk_out);
+__global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                             uint32_t chunk_codes, const uint64_t *chunk_out);
+__global__ void k_fill(const FillJob *jobs, uint32_t njobs);
+
+// k_stream.hip
+__global__ void k_scan_u64(uint64_t *a, uint32_t n);
+__global__ void k_u32_chunk_sums(const uint32_t *a, uint32_t n, uint64_t *partial);
+__global__ void k_u32_chunk_apply(const uint32_t *a, uint32_t *out, uint32_t n, const uint64_t *partial);
+__global__ void k_unpack_sums(const UnpackJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, uint64_t *partial);
+__global__ void k_unpack_extract(const UnpackJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, const uint64_t *partial);
+__global__ void k_cloud_sums(const CloudJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, uint64_t *partial);
+__global__ void k_cloud_apply(const CloudJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, const uint64_t *partial);
+__global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uint32_t nblocks);
+
+// k_mesh.hip
+__global__ void k_topology(const TopoJob *jobs, uint32_t njobs);
+__global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);
+
+// k_normal.hip
+__global__ void k_normal_diff(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks);
+__global__ void k_normal_faces(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks,
+                               float *facen, uint32_t *cnt, uint32_t *bnd);
+__global__ void k_normal_fill(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks,
+                              const uint32_t *start, uint32_t *cursor, uint32_t *adj);
+__global__ void k_normal_flags(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks,
+                               const uint32_t *bnd, uint32_t *flag);
+__global__ void k_normal_vertex(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks,
+                                const float *facen, const uint32_t *start, const uint32_t *cnt, const uint32_t *adj,
+                                const uint32_t *flag, const uint32_t *slot);
+
+constexpr uint32_t TUN_CHUNK_CODES = 16384;   // codewords per K-TUN workgroup
+
+} // namespace corto_hip

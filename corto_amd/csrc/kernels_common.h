@@ -1,0 +1,59 @@
+// kernels_common.h — device helpers shared by the HIP kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_plan.h"
+
+namespace corto_hip {
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+// inclusive scan across the 64 lanes of a wave
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+	const uint32_t lane = lane_id();
+#pragma unroll
+	for(int d = 1; d < 64; d <<= 1) {
+		T o = __shfl_up(v, d, 64);
+		if(lane >= (uint32_t)d) v += o;
+	}
+	return v;
+}
+
+// exclusive scan over a 256-thread block (4 waves); *total = block sum. smem: 4 entries of T.
+template <typename T>
+__device__ __forceinline__ T block256_exclusive_scan(T v, T *smem, T *total) {
+	T inc = wave_inclusive_scan(v);
+	const uint32_t lane = lane_id(), w = wave_id();
+	__syncthreads();                 // smem may still be read by a previous call
+	if(lane == 63) smem[w] = inc;
+	__syncthreads();
+	T s0 = smem[0], s1 = smem[1], s2 = smem[2], s3 = smem[3];
+	T base = w == 0 ? T(0) : w == 1 ? s0 : w == 2 ? T(s0 + s1) : T(s0 + s1 + s2);
+	*total = s0 + s1 + s2 + s3;
+	return base + inc - v;
+}
+
+// MSB-first bit field [o, o+n) of a u32 word stream (src/bitstream.cpp:103-121 as random access).
+// Words past nwords read as 0 (malformed streams cannot fault).
+__device__ __forceinline__ uint32_t bit_field(const uint32_t *__restrict__ w, uint32_t nwords, uint64_t o, uint32_t n) {
+	if(n == 0) return 0;
+	const uint64_t i = o >> 5;
+	const uint32_t sh = (uint32_t)(o & 31);
+	const uint32_t hi = i < nwords ? w[i] : 0u;
+	const uint32_t lo = (sh + n > 32 && i + 1 < nwords) ? w[i + 1] : 0u;
+	const uint64_t win = ((uint64_t)hi << 32) | lo;
+	return (uint32_t)((win << sh) >> (64 - n));
+}
+
+// x86 cvttss2si: out-of-range / NaN -> INT_MIN (what the reference's (int) casts do on its CPU)
+__device__ __forceinline__ int32_t f2i_x86(float x) {
+	if(!(x > -2147483904.0f && x < 2147483648.0f)) return (int32_t)0x80000000;
+	return (int32_t)x;
+}
+__device__ __forceinline__ int16_t f2s_x86(float x) { return (int16_t)(uint16_t)(uint32_t)f2i_x86(x); }
+
+} // namespace corto_hip

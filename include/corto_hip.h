@@ -1,0 +1,184 @@
+/* corto_hip.h — C ABI of the MI355X-native corto decode path (libcorto_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch/HIP types.
+ * Reference citations are relative to the upstream tree (cnr-isti-vclab/corto @ 2025-10-03).
+ *
+ * What it replaces
+ *   crt::Decoder::Decoder(len, input)           src/decoder.cpp:41-89        -> crthip_probe / crthip_batch_create
+ *   crt::Decoder::setPositions/Normals/Uvs/
+ *        setColors/setAttribute/setIndex         include/corto/decoder.h:50-61 -> crthip_batch_bind[_all]
+ *   crt::Decoder::decode()                       src/decoder.cpp:126-196      -> crthip_batch_decode (+ _sync)
+ *   the legacy one-blob veneers CreateDecoder/DecodeMesh (src/corto_codec.h:41-43) and the WASM glue
+ *   (html/js/emscripten/emcorto.cpp:14-89) map onto crthip_decode_host(), see INTEGRATION.md.
+ *
+ * Error behaviour: every entry point returns CRTHIP_OK (0) or a negative CRTHIP_E_* code and never
+ * throws; crthip_last_error() returns the message, which for the conditions the reference throws on
+ * is the reference's own string literal ("Not a crt file.", "Memory must be alignegned on 4 bytes.",
+ * "Decoding topology failed", "Unknown entropy", ...).
+ *
+ * There is NO CPU fallback behind this ABI: if no HIP device is usable the calls fail with
+ * CRTHIP_E_DEVICE.
+ */
+#ifndef CORTO_HIP_H
+#define CORTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRTHIP_ABI_VERSION 1
+
+/* VertexAttribute::Format, include/corto/vertex_attribute.h:32 */
+enum { CRTHIP_FMT_UINT32 = 0, CRTHIP_FMT_INT32 = 1, CRTHIP_FMT_UINT16 = 2, CRTHIP_FMT_INT16 = 3,
+       CRTHIP_FMT_UINT8 = 4, CRTHIP_FMT_INT8 = 5, CRTHIP_FMT_FLOAT = 6, CRTHIP_FMT_DOUBLE = 7 };
+/* VertexAttribute::CODEC, include/corto/vertex_attribute.h:34 */
+enum { CRTHIP_CODEC_GENERIC = 1, CRTHIP_CODEC_NORMAL = 2, CRTHIP_CODEC_COLOR = 3 };
+/* VertexAttribute::Strategy, include/corto/vertex_attribute.h:33 */
+enum { CRTHIP_PARALLEL = 1, CRTHIP_CORRELATED = 2 };
+/* Stream::Entropy, include/corto/cstream.h:35 */
+enum { CRTHIP_ENTROPY_NONE = 0, CRTHIP_ENTROPY_TUNSTALL = 1 };
+
+enum {
+	CRTHIP_OK = 0,
+	CRTHIP_E_ALIGN = -1,        /* "Memory must be alignegned on 4 bytes."  src/decoder.cpp:44 */
+	CRTHIP_E_MAGIC = -2,        /* "Not a crt file."                        src/decoder.cpp:51 */
+	CRTHIP_E_TRUNCATED = -3,    /* stream runs past len (the reference never checks) */
+	CRTHIP_E_ENTROPY = -4,      /* "Unknown entropy"                        src/cstream.cpp:82 */
+	CRTHIP_E_TOPOLOGY = -5,     /* "Decoding topology failed"               src/decoder.cpp:274 */
+	CRTHIP_E_NORMAL_NEEDS_POSITION = -6, /* src/normal_attribute.cpp:219-227 */
+	CRTHIP_E_FORMAT = -7,       /* output format not supported for that attribute */
+	CRTHIP_E_ARGUMENT = -8,
+	CRTHIP_E_DEVICE = -9,       /* no usable HIP device / HIP runtime error */
+	CRTHIP_E_NOMEM = -10,
+	CRTHIP_E_LIMIT = -11        /* more attributes / components than this build supports */
+};
+
+#define CRTHIP_MAX_ATTRS 16
+#define CRTHIP_NAME_MAX 64
+
+typedef struct {
+	char name[CRTHIP_NAME_MAX];  /* NUL-terminated */
+	uint32_t codec;              /* CRTHIP_CODEC_* (anything else is treated as GENERIC, src/decoder.cpp:77-79) */
+	float q;                     /* quantisation step as stored */
+	uint32_t components;         /* N as stored (normals always decode 2 octahedral ints -> 3 outputs) */
+	uint32_t format;             /* encoder-side format byte as stored (informational) */
+	uint32_t strategy;           /* CRTHIP_PARALLEL | CRTHIP_CORRELATED */
+} crthip_attr_info;
+
+typedef struct {
+	uint32_t version, entropy;
+	uint32_t nvert, nface;
+	uint32_t nattr;                              /* attributes in std::map order = sorted by name */
+	crthip_attr_info attr[CRTHIP_MAX_ATTRS];
+	uint32_t nexif;
+	uint32_t body_offset;                        /* first byte after the header */
+} crthip_blob_info;
+
+/* Per-attribute output binding (Decoder::setAttribute, src/decoder.cpp:96-123).
+ * buffer == NULL leaves the attribute unbound: its streams are skipped, like the reference does.
+ * Buffers are DEVICE pointers for the batch API (crthip_batch_*) and HOST pointers for crthip_decode_host.
+ *   generic (position, uv, radius, ...): FLOAT only; nvert*components*4 bytes (decoded in place as int32 first)
+ *   normal : FLOAT (nvert*3 f32) or INT16 (nvert*3 i16)
+ *   color  : UINT8, out_components = 3 or 4 (>= stored components); nvert*out_components bytes        */
+typedef struct {
+	void *buffer;
+	uint32_t format;
+	uint32_t out_components;
+} crthip_attr_binding;
+
+typedef struct crthip_ctx crthip_ctx;       /* one per device; owns streams + scratch pool */
+typedef struct crthip_batch crthip_batch;   /* a planned batch of independent .crt blobs */
+
+uint32_t crthip_abi_version(void);
+const char *crthip_last_error(void);         /* thread-local message of the last failing call */
+const char *crthip_strerror(int code);
+
+/* Header parse only; host-only, needs no GPU.  blob must be 4-byte aligned (src/decoder.cpp:43-44). */
+int crthip_probe(const uint8_t *blob, size_t len, crthip_blob_info *info);
+/* exif pairs / group table of one blob, host-only.  Strings are copied into out (NUL-separated
+ * key\0value\0...); returns bytes needed, or <0. */
+int64_t crthip_probe_exif(const uint8_t *blob, size_t len, char *out, size_t cap);
+/* groups: writes min(cap, ngroups) end-face markers, returns ngroups or <0 (include/corto/index_attribute.h:89-99) */
+int64_t crthip_probe_groups(const uint8_t *blob, size_t len, uint32_t *group_end, size_t cap);
+
+int crthip_ctx_create(int device, crthip_ctx **out);
+void crthip_ctx_destroy(crthip_ctx *ctx);
+int crthip_device_count(void);
+
+/* Plan a batch: parse every header, walk every body (validating all extents against lens[i]),
+ * stage the blobs into one 16-byte-aligned device arena and upload the stream descriptors.
+ * blobs[i] are HOST pointers (borrowed only for the duration of this call).
+ * device_arena: NULL -> the library uploads the blobs itself;
+ *               else  -> DEVICE pointer to the blobs already resident in HBM, laid out back to back with each
+ *                        blob starting at the next 16-byte multiple (offsets via crthip_arena_layout). */
+int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens,
+                        const void *device_arena, crthip_batch **out);
+/* offsets[i] = arena byte offset of blob i under the rule above; returns total arena bytes */
+uint64_t crthip_arena_layout(uint32_t nblobs, const uint32_t *lens, uint64_t *offsets);
+void crthip_batch_destroy(crthip_batch *b);
+
+uint32_t crthip_batch_size(const crthip_batch *b);
+int crthip_batch_info(const crthip_batch *b, uint32_t i, crthip_blob_info *info);
+
+/* Bind outputs of blob i. attrs has info.nattr entries in info.attr order. index: DEVICE pointer to
+ * nface*3 entries of index_format (CRTHIP_FMT_UINT32 or CRTHIP_FMT_UINT16), NULL for point clouds. */
+int crthip_batch_bind(crthip_batch *b, uint32_t i, const crthip_attr_binding *attrs, void *index, uint32_t index_format);
+/* Bind every blob in one call: attrs holds sum(nattr) entries blob after blob; index/index_format have nblobs entries. */
+int crthip_batch_bind_all(crthip_batch *b, const crthip_attr_binding *attrs, void *const *index, const uint32_t *index_format);
+
+/* Enqueue the whole decode of the batch on the context's stream (asynchronous). */
+int crthip_batch_decode(crthip_batch *b);
+/* Wait for completion and collect per-blob status: status[i] = CRTHIP_OK or CRTHIP_E_* (may be NULL).
+ * Returns CRTHIP_OK if every blob decoded, else the first failing blob's code. */
+int crthip_batch_sync(crthip_batch *b, int32_t *status);
+
+/* One-blob convenience with HOST output buffers: probe + plan + device decode + copy back.
+ * This is what the crt::Decoder facade (include/corto/decoder.h of this repo) calls. */
+int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
+                       void *index, uint32_t index_format);
+
+/* ---- measurement / test hooks (not needed by integrators) ---- */
+typedef struct {
+	uint64_t arena_bytes;       /* compressed input resident in HBM */
+	uint64_t output_bytes;      /* bytes of all bound outputs */
+	uint64_t tunstall_in;       /* compressed bytes through the Tunstall kernel */
+	uint64_t tunstall_out;      /* decoded symbol bytes out of it */
+	uint64_t tunstall_tables;   /* probability-table header bytes (1 + 2*nsym + 8 per stream) */
+	uint32_t tunstall_streams;
+	uint64_t total_nvert, total_nface;
+	uint64_t scratch_bytes;
+} crthip_batch_stats;
+int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
+
+/* Per-kernel device time of the LAST crthip_batch_decode of this batch, measured with HIP events on the
+ * context's stream.  Enable before decode with crthip_ctx_set_profiling(ctx, 1).  names[i] static strings. */
+#define CRTHIP_MAX_KERNELS 32
+typedef struct {
+	uint32_t count;
+	const char *name[CRTHIP_MAX_KERNELS];
+	float ms[CRTHIP_MAX_KERNELS];
+	uint32_t launches[CRTHIP_MAX_KERNELS];
+} crthip_kernel_times;
+int crthip_ctx_set_profiling(crthip_ctx *ctx, int enable);
+int crthip_batch_kernel_times(crthip_batch *b, crthip_kernel_times *t);
+
+/* Copy an internal intermediate of blob i to a HOST buffer (tests compare these with the oracle):
+ * what = "clers" (u8 symbols), "prediction" (nvert*3 u32). Returns bytes written or <0. */
+int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const char *what, void *host_out, size_t cap);
+
+/* Stand-alone Tunstall run on DEVICE-resident blocks, used for the HBM-roofline measurement of the
+ * Tunstall kernels: n blocks, each "u8 nsym | nsym*(sym,prob) | u32 size | u32 csize | payload"
+ * exactly as in the .crt stream (src/cstream.cpp:89-109), block_offset[i] bytes into device_blocks;
+ * out_offset[i] bytes into device_out.  host_blocks is the same memory on the host (for framing). */
+int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const uint8_t *host_blocks, const void *device_blocks,
+                                  const uint64_t *block_offset, void *device_out, const uint64_t *out_offset,
+                                  crthip_kernel_times *times);
+int crthip_ctx_sync(crthip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORTO_HIP_H */

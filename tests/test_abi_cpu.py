@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads, exports every symbol include/corto_hip.h declares, and its host-only entry
+points (header probe, arena layout, error strings) behave like the reference's constructor.  No kernel runs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import corto_amd as ca
+from conftest import ALL_CASES, ROOT, aligned, load_golden
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(ca.LIB_PATH):
+        from corto_amd import build
+        build.build()
+    return ca.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "corto_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(crthip_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(L, n), n
+    assert L.crthip_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_probe_matches_golden(L, name):
+    g = load_golden(name)
+    info = ca.probe(g["crt"])
+    nv = g["position"].shape[0]
+    assert info.nvert == nv
+    assert info.nface == (g["index"].shape[0] if "index" in g else 0)
+    names = [a["name"] for a in info.attrs()]
+    assert names == sorted(names)
+    for k in ("position", "normal", "color", "uv", "radius"):
+        assert (k in names) == (k in g)
+
+
+def test_probe_errors_use_reference_messages(L):
+    g = load_golden("c4_unit")
+    bad = g["crt"].copy(); bad[1] ^= 0x55
+    with pytest.raises(ca.CortoError, match="Not a crt file."):
+        ca.probe(aligned(bad))
+    raw = np.zeros(len(g["crt"]) + 32, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 16 + 2
+    mis = raw[off:off + len(g["crt"])]; mis[:] = g["crt"]
+    with pytest.raises(ca.CortoError, match="alignegned"):
+        ca.probe(mis)
+    with pytest.raises(ca.CortoError):
+        ca.probe(aligned(g["crt"][:40]))            # truncated header
+
+
+def test_exif_and_groups(L):
+    g = load_golden("radius_attr")
+    assert ca.probe_exif(g["crt"]) == {"mtllib": "a.mtl", "note": "x"}
+    g2 = load_golden("two_groups")
+    assert ca.probe_groups(g2["crt"]) == [400, 1024]
+    assert ca.probe_groups(load_golden("cloud_diff")["crt"]) == []
+
+
+def test_truncated_bodies_are_rejected_on_the_host(L):
+    g = load_golden("holey_disc")
+    blob = g["crt"]
+    for cut in (len(blob) - 1, len(blob) // 2, 130):
+        n = L.crthip_probe_groups(aligned(blob[:cut]).ctypes.data_as(C.c_void_p), cut, None, 0)
+        assert n == -3, cut                          # CRTHIP_E_TRUNCATED: the walk validates every extent
+
+
+def test_arena_layout():
+    offs, total = ca.arena_layout([5, 16, 17, 0, 3])
+    assert list(offs) == [0, 16, 32, 64, 64] and total == 80
+
+
+def test_no_gpu_means_loud_failure(L):
+    if L.crthip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ca.CortoError, match="no CPU fallback"):
+        ca.Context(0)

@@ -1,0 +1,295 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (a) the golden outputs the reference produced,
+(b) the C oracle on the same inputs, (c) size-independent properties at BASELINE.json's full sizes.
+Bit-exact everywhere (integer/byte/index work; floats are compared as raw bytes - tolerance 0)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import corto_amd as ca
+from conftest import ALL_CASES, CLOUD_CASES, MESH_CASES, GOLDEN, aligned, load_golden
+from oracle import oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ca.Context(0)
+    yield c
+    c.close()
+
+
+def run_batch(ctx, blobs, **kw):
+    b = ca.Batch(ctx, blobs)
+    b.allocate_outputs(**kw)
+    b.decode()
+    st = b.sync()
+    assert (st == 0).all(), st
+    return b
+
+
+def assert_same(got, exp, keys, tag=""):
+    for k in keys:
+        if k in exp:
+            assert k in got, (tag, k)
+            a, e = got[k], exp[k]
+            assert a.dtype == e.dtype and a.shape == e.shape, (tag, k, a.dtype, e.dtype, a.shape, e.shape)
+            if a.tobytes() != e.tobytes():
+                bad = np.argwhere(a.reshape(len(a), -1) != e.reshape(len(e), -1))
+                raise AssertionError("%s %s: %d mismatching entries, first %s got %s expected %s" % (
+                    tag, k, len(bad), bad[0], a.reshape(len(a), -1)[bad[0][0]], e.reshape(len(e), -1)[bad[0][0]]))
+
+
+KEYS = ("position", "normal", "color", "uv", "radius", "index")
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_golden_single_blob(ctx, name):
+    g = load_golden(name)
+    cc = int(g["color_components"])
+    b = run_batch(ctx, [g["crt"]], color_components=cc if "color" in g else None)
+    got = b.host_outputs(0)
+    if "index" in g:                                   # stage-level: CLERS symbols + prediction triples
+        cl = b.debug_read(0, "clers", len(g["_clers"]) + 16)
+        assert np.array_equal(cl, g["_clers"])
+        pr = b.debug_read(0, "prediction", g["_prediction"].size * 4).view(np.uint32).reshape(-1, 3)
+        assert np.array_equal(pr[1:], g["_prediction"][1:])
+    assert_same(got, g, KEYS, name)
+    o = oc.decode(g["crt"], color_components=cc)
+    assert_same(got, o, KEYS, name + "/oracle")
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_golden_int16_normals_u16_index(ctx, name):
+    g = load_golden(name)
+    cc = int(g["color_components"])
+    b = run_batch(ctx, [g["crt"]], normal_format=ca.FMT_INT16, index16=True, color_components=cc if "color" in g else None, fill=0)
+    got = b.host_outputs(0)
+    if "normal_i16" in g:
+        assert got["normal"].tobytes() == g["normal_i16"].tobytes()
+    if "index_u16_sha256" in g:
+        assert sha(got["index"]) == g["index_u16_sha256"].tobytes().decode()
+
+
+def test_heterogeneous_batch(ctx):
+    """all fixtures (meshes, clouds, entropy NONE, 3/4-component colours) in ONE batch / one set of launches"""
+    gs = [load_golden(n) for n in ALL_CASES]
+    b = run_batch(ctx, [g["crt"] for g in gs])
+    for i, g in enumerate(gs):
+        assert_same(b.host_outputs(i), g, KEYS, ALL_CASES[i])
+
+
+def test_rgb_expands_to_rgba(ctx):
+    g = load_golden("nrm_estimated_rgb")
+    b = run_batch(ctx, [g["crt"]], color_components=4)
+    got = b.host_outputs(0)
+    o = oc.decode(g["crt"], color_components=4)
+    assert_same(got, o, KEYS, "rgb->rgba")
+    assert (got["color"][:, 3] == 248).all()           # (uchar)(255*8), SURVEY a14
+
+
+def test_unbound_attributes_are_skipped(ctx):
+    g = load_golden("c4_unit")
+    b = run_batch(ctx, [g["crt"]], only={"position", "index"})
+    got = b.host_outputs(0)
+    assert set(k for k in got if k not in ("nvert", "nface")) == {"position", "index"}
+    assert_same(got, g, ("position", "index"), "only position")
+
+
+def test_c4_blobs_digests_and_replicated_batch(ctx):
+    z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
+    blobs = [aligned(z["crt_%02d" % s]) for s in range(16)]
+    b = run_batch(ctx, blobs * 4)                       # 64 blobs, one launch set
+    for i in range(64):
+        got = b.host_outputs(i)
+        for k in ("position", "normal", "color", "uv", "index"):
+            assert sha(got[k]) == z["%s_sha256_%02d" % (k, i % 16)].tobytes().decode(), (i, k)
+
+
+def test_mid_mesh_digests(ctx):
+    g = load_golden("mid34k_digest")
+    b = run_batch(ctx, [g["crt"]])
+    got = b.host_outputs(0)
+    for k in ("position", "normal", "color", "uv", "index"):
+        assert sha(got[k]) == g[k + "_sha256"].tobytes().decode(), k
+
+
+def test_resident_arena_and_redecode(ctx):
+    """inputs already resident in HBM (device_arena) + decoding the same batch twice gives the same bytes"""
+    gs = [load_golden(n) for n in ("c4_unit", "cloud_diff", "torus")]
+    blobs = [g["crt"] for g in gs]
+    arena = ca.upload_arena(blobs)
+    b = ca.Batch(ctx, blobs, device_arena=arena)
+    b.allocate_outputs(fill=0xAB)
+    for _ in range(2):
+        b.decode(); assert (b.sync() == 0).all()
+        for i, g in enumerate(gs):
+            assert_same(b.host_outputs(i), g, KEYS, "arena")
+
+
+def test_decoder_facade_host_buffers(ctx):
+    """crt::Decoder-shaped one-blob API with host buffers (crthip_decode_host)"""
+    g = load_golden("c4_unit")
+    d = ca.Decoder(g["crt"])
+    assert d.nvert == 2112 and d.nface == 4096 and d.hasAttr("uv") and not d.hasAttr("radius")
+    pos = np.zeros((d.nvert, 3), np.float32); nrm = np.zeros((d.nvert, 3), np.float32)
+    col = np.zeros((d.nvert, 4), np.uint8); uv = np.zeros((d.nvert, 2), np.float32); idx = np.zeros((d.nface, 3), np.uint32)
+    assert d.setPositions(pos) and d.setNormals(nrm) and d.setColors(col, 4) and d.setUvs(uv)
+    assert not d.setAttribute("radius", pos, ca.FMT_FLOAT)
+    d.setIndex(idx)
+    d.decode()
+    assert_same(dict(position=pos, normal=nrm, color=col, uv=uv, index=idx), g, KEYS, "facade")
+
+
+def test_topology_failure_is_reported_per_blob(ctx):
+    g = load_golden("holey_disc"); ok = load_golden("torus")
+    bad = g["crt"].copy()
+    h = oc.parse_header(bad)
+    # corrupt the split/vertex-id bit block region heavily: flip bytes in the CLERS payload
+    start = h["body_offset"] + 40
+    bad[start:start + 200] ^= 0x5A
+    b = ca.Batch(ctx, [aligned(bad), ok["crt"]])
+    b.allocate_outputs()
+    b.decode()
+    st = b.sync(raise_on_error=False)
+    assert st[1] == 0
+    assert_same(b.host_outputs(1), ok, KEYS, "good blob next to a corrupt one")
+    # the corrupt blob either fails topology or decodes garbage without faulting; it must not take the batch down
+    assert st[0] in (0, -5)
+
+
+def test_unsupported_format_fails_loudly(ctx):
+    g = load_golden("c4_unit")
+    b = ca.Batch(ctx, [g["crt"]])
+    info = b.infos[0].attrs()
+    binds = [ca.AttrBinding() for _ in info]
+    k = [a["name"] for a in info].index("position")
+    binds[k].buffer = 4096; binds[k].format = ca.FMT_INT16
+    with pytest.raises(ca.CortoError, match="Format not supported"):
+        b.bind(0, binds)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Tunstall stage in isolation
+def _kat():
+    z = np.load(os.path.join(GOLDEN, "tunstall_kat.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _run_blocks(ctx, blocks, sizes):
+    import torch
+    offs, total = [], 0
+    for b in blocks:
+        offs.append(total); total += (len(b) + 15) & ~15
+    host = np.zeros(total + 16, dtype=np.uint8)
+    for b, o in zip(blocks, offs):
+        host[o:o + len(b)] = b
+    oo, ot = [], 0
+    for s in sizes:
+        oo.append(ot); ot += (s + 15) & ~15
+    dblk = torch.from_numpy(host).cuda()
+    dout = torch.full((ot + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+    times = ca.tunstall_decode_blocks(ctx, host, dblk, offs, dout, oo)
+    out = dout.cpu().numpy()
+    return [out[o:o + s] for o, s in zip(oo, sizes)], times
+
+
+def test_tunstall_tables_kat_on_device(ctx):
+    """every dictionary of the reference KAT: decode the payload 0,1,...,255 -> concatenation of all 256 words"""
+    k = _kat()
+    blocks, sizes, expect = [], [], []
+    for i in range(int(k["count"])):
+        pr, idx, ln, tab = k["probs_%02d" % i], k["index_%02d" % i].astype(int), k["length_%02d" % i].astype(int), k["table_%02d" % i]
+        words = np.concatenate([tab[idx[c]:idx[c] + ln[c]] for c in range(256)])
+        hdr = bytes([len(pr)]) + pr.tobytes() + int(len(words)).to_bytes(4, "little") + (256).to_bytes(4, "little")
+        blocks.append(np.frombuffer(hdr + bytes(range(256)), dtype=np.uint8)); sizes.append(len(words)); expect.append(words)
+    outs, _ = _run_blocks(ctx, blocks, sizes)
+    for i, (o, e) in enumerate(zip(outs, expect)):
+        assert np.array_equal(o, e), i
+
+
+def test_tunstall_streams_kat_on_device(ctx):
+    k = _kat()
+    blocks = [k["stream_block_%d" % i] for i in range(8)]
+    syms = [k["stream_symbols_%d" % i] for i in range(8)]
+    outs, _ = _run_blocks(ctx, blocks, [len(s) for s in syms])
+    for i, (o, e) in enumerate(zip(outs, syms)):
+        assert np.array_equal(o, e), i
+
+
+def test_tunstall_long_streams_multi_chunk(ctx):
+    """streams far longer than one workgroup's chunk: any byte string is a valid codeword stream, so random
+    payloads + the oracle's dictionary give the expected output without needing an encoder"""
+    rng = np.random.default_rng(5)
+    k = _kat()
+    blocks, sizes, expect = [], [], []
+    for i, ncode in ((3, 100_000), (20, 300_001), (0, 70_000), (40, 16_385)):
+        pr = k["probs_%02d" % i]
+        idx, ln, tab = oc.tunstall_tables(pr)
+        payload = rng.integers(0, 256, ncode).astype(np.uint8)
+        size = int(ln[payload].sum())
+        if i == 20:
+            size -= 1                                   # clip the last word by one byte
+        hdr = bytes([len(pr)]) + pr.tobytes() + size.to_bytes(4, "little") + ncode.to_bytes(4, "little")
+        blocks.append(np.frombuffer(hdr + payload.tobytes(), dtype=np.uint8)); sizes.append(size)
+        expect.append(oc.tunstall_decompress(pr, payload, size))
+    outs, times = _run_blocks(ctx, blocks, sizes)
+    for i, (o, e) in enumerate(zip(outs, expect)):
+        assert np.array_equal(o, e), i
+    assert "tunstall_chunk_sums" in times or not times  # multi-chunk path taken when profiling is on
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes, inputs made on the box by the reference encoder when oracle/_ref travelled
+def _ref():
+    from oracle import refcodec as rc
+    if not rc.available():
+        pytest.skip("oracle/_ref not present on this box")
+    return rc
+
+
+@pytest.mark.parametrize("pred", [0, 1, 2])
+def test_config2_128k_mesh(ctx, pred):
+    rc = _ref()
+    from corto_amd import synth
+    m = synth.bumpy_sphere(512, 250, seed=2)           # 128 512 verts / 256 000 tris
+    blob = rc.encode(m, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=pred)
+    b = run_batch(ctx, [blob])
+    got = b.host_outputs(0)
+    assert got["nvert"] == 128512 and got["nface"] == 256000
+    o = oc.decode(blob)
+    assert_same(got, o, KEYS, "C2 pred %d" % pred)
+    # properties: every index valid, every triangle non-degenerate, normals unit length
+    idx = got["index"].astype(np.int64)
+    assert idx.max() == got["nvert"] - 1 and (idx[:, 0] != idx[:, 1]).all() and (idx[:, 1] != idx[:, 2]).all()
+    assert np.abs(np.linalg.norm(got["normal"].astype(np.float64), axis=1) - 1).max() < 1e-5
+
+
+def test_config3_167k_point_cloud(ctx):
+    rc = _ref()
+    from corto_amd import synth
+    m = synth.point_cloud(578, 289, seed=3)            # 167 042 points
+    blob = rc.encode(m, position_bits=14, normal_bits=10, normal_prediction=0)
+    b = run_batch(ctx, [blob])
+    got = b.host_outputs(0)
+    assert got["nvert"] == 167042 and got["nface"] == 0
+    assert_same(got, oc.decode(blob), KEYS, "C3")
+
+
+def test_config4_256_blob_batch_roundtrip(ctx):
+    """256 x 4K-tri blobs in one batch; encode -> decode round trip equals the oracle for every blob, and the
+    decoded positions equal the quantised input positions (permuted by the encoder's vertex order)"""
+    z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
+    blobs = [aligned(z["crt_%02d" % (s % 16)]) for s in range(256)]
+    b = run_batch(ctx, blobs)
+    st = b.stats()
+    assert st.total_nface == 256 * 4096 and st.total_nvert == 256 * 2112
+    for i in (0, 17, 100, 255):
+        got = b.host_outputs(i)
+        assert_same(got, oc.decode(blobs[i]), KEYS, "C4 blob %d" % i)
