@@ -332,6 +332,7 @@ struct Plan {
 	HostArr<TunStream> tun; HostArr<uint32_t> tun_chunk_stream;
 	HostArr<FillJob> fill;
 	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
+	HostArr<uint32_t> topo_lds_ids, topo_glob_ids; uint32_t topo_lds = 0;
 	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
 	HostArr<DeltaJob> delta;
 	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
@@ -501,6 +502,11 @@ static int build_and_launch(crthip_batch *b) {
 			t.nclers = L.clers.size; t.split_nwords = L.split.nwords; t.ngroups = (uint32_t)L.group_end.size();
 			t.nvert = nvert; t.nface = nface; t.front_cap = S.front_cap; t.faces_u16 = P.index ? P.index_u16 : 0;
 			t.pad = P.index ? 1u : 0u;                                   // pad = 1: faces is a real pointer
+			{
+				const uint32_t need = topo_lds_bytes(S.front_cap, L.clers.size);
+				if(nvert <= 65535 && S.front_cap <= 65530 && need <= TOPO_LDS_MAX) { pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need); }
+				else pl.topo_glob_ids.v.push_back((uint32_t)pl.topo.v.size());
+			}
 			pl.topo.v.push_back(t);
 		}
 		// position attribute (needed by ESTIMATED/BORDER normals)
@@ -607,7 +613,7 @@ static int build_and_launch(crthip_batch *b) {
 	// job arrays region
 	pl.jobs_begin = cv.take(0);
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
-	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.unpack); place(pl.unpack_chunk_job);
+	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
 	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.dequant); place(pl.dequant_block_job);
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
@@ -652,7 +658,7 @@ static int build_and_launch(crthip_batch *b) {
 	// host image -> device (one copy)
 	uint8_t *stage = (uint8_t *)ctx->staging.p;
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
-	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.unpack); put(pl.unpack_chunk_job);
+	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
 	put(pl.delta); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.dequant); put(pl.dequant_block_job);
 
@@ -678,7 +684,16 @@ static int build_and_launch(crthip_batch *b) {
 		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial); LT.end();
 	}
 	if(!pl.fill.v.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)pl.fill.v.size()), dim3(256), 0, st, D(pl.fill), (uint32_t)pl.fill.v.size()); LT.end(); }
-	if(!pl.topo.v.empty()) { LT.begin("topology"); hipLaunchKernelGGL(k_topology, dim3((uint32_t)pl.topo.v.size()), dim3(64), 0, st, D(pl.topo), (uint32_t)pl.topo.v.size()); LT.end(); }
+	if(!pl.topo_lds_ids.v.empty()) {
+		static uint32_t lds_attr = 0;                      // raise the dynamic-LDS limit once per size class
+		if(pl.topo_lds > lds_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX)); lds_attr = TOPO_LDS_MAX; }
+		const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size();
+		LT.begin("topology_lds"); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); LT.end();
+	}
+	if(!pl.topo_glob_ids.v.empty()) {
+		const uint32_t nj = (uint32_t)pl.topo_glob_ids.v.size();
+		LT.begin("topology"); hipLaunchKernelGGL(k_topology, dim3(nj), dim3(64), 0, st, D(pl.topo), D(pl.topo_glob_ids), nj); LT.end();
+	}
 	if(unpack_chunks) {
 		LT.begin("unpack_sums"); hipLaunchKernelGGL(k_unpack_sums, dim3(unpack_chunks), dim3(256), 0, st, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
 		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, unpack_partial, unpack_chunks); LT.end();

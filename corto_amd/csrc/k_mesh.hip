@@ -12,30 +12,93 @@ enum : uint32_t { C_VERTEX = 0, C_LEFT = 1, C_RIGHT = 2, C_END = 3, C_BOUNDARY =
 constexpr int32_t ERR_TOPOLOGY = -5;   // CRTHIP_E_TOPOLOGY
 
 // ------------------------------------------------------------------------------------------------
-// K-TOPO, general path: front / queues in global scratch sized by the stream's max_front.
+// K-TOPO.  The automaton is written once against a "front store" policy:
+//   GlobalFront : front / queues in HBM scratch sized by the stream's max_front (any mesh size)
+//   LdsFront    : the same state in the CU's LDS, 12 bytes per edge (u16 vertex ids and links), for
+//                 blobs whose whole front fits: every dependent read is an LDS round trip (~100 cycles)
+//                 instead of an L2/HBM one (~500-2000).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct GlobalFront {
+	CRT_GLOBAL u32x4 *fa;            // (v0, v1, v2, deleted)
+	CRT_GLOBAL u32x2 *fb;            // (prev, next)
+	CRT_GLOBAL uint32_t *order;
+	CRT_GLOBAL uint32_t *delayed;
+	__device__ void core(uint32_t e, uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &dead) const { const u32x4 t = fa[e]; v0 = t.x; v1 = t.y; v2 = t.z; dead = t.w; }
+	__device__ void links(uint32_t e, uint32_t &p, uint32_t &n) const { const u32x2 t = fb[e]; p = t.x; n = t.y; }
+	__device__ uint32_t prev(uint32_t e) const { return ((CRT_GLOBAL uint32_t *)fb)[2*(size_t)e]; }
+	__device__ uint32_t next(uint32_t e) const { return ((CRT_GLOBAL uint32_t *)fb)[2*(size_t)e + 1]; }
+	__device__ uint32_t v0(uint32_t e) const { return ((CRT_GLOBAL uint32_t *)fa)[4*(size_t)e]; }
+	__device__ uint32_t v1(uint32_t e) const { return ((CRT_GLOBAL uint32_t *)fa)[4*(size_t)e + 1]; }
+	__device__ void set_prev(uint32_t e, uint32_t x) { ((CRT_GLOBAL uint32_t *)fb)[2*(size_t)e] = x; }
+	__device__ void set_next(uint32_t e, uint32_t x) { ((CRT_GLOBAL uint32_t *)fb)[2*(size_t)e + 1] = x; }
+	__device__ void kill(uint32_t e) { ((CRT_GLOBAL uint32_t *)fa)[4*(size_t)e + 3] = 1; }
+	__device__ void put(uint32_t e, uint32_t a, uint32_t b, uint32_t c, uint32_t p, uint32_t n) {
+		u32x4 t; t.x = a; t.y = b; t.z = c; t.w = 0; fa[e] = t;
+		u32x2 l; l.x = p; l.y = n; fb[e] = l;
+	}
+	__device__ void order_put(uint32_t i, uint32_t e) { order[i] = e; }
+	__device__ uint32_t order_get(uint32_t i) const { return order[i]; }
+	__device__ void delayed_put(uint32_t i, uint32_t e) { delayed[i] = e; }
+	__device__ uint32_t delayed_get(uint32_t i) const { return delayed[i]; }
+};
+
+struct LdsFront {
+	CRT_LDS uint32_t *va;            // v0 | v1 << 16
+	CRT_LDS uint32_t *vb;            // v2 | deleted << 16
+	CRT_LDS uint32_t *lk;            // prev | next << 16
+	CRT_LDS uint16_t *order;
+	CRT_LDS uint16_t *delayed;
+	__device__ void core(uint32_t e, uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &dead) const {
+		const uint32_t a = va[e], b = vb[e];
+		v0 = a & 0xFFFFu; v1 = a >> 16; v2 = b & 0xFFFFu; dead = b >> 16;
+	}
+	__device__ void links(uint32_t e, uint32_t &p, uint32_t &n) const { const uint32_t t = lk[e]; p = t & 0xFFFFu; n = t >> 16; }
+	__device__ uint32_t prev(uint32_t e) const { return lk[e] & 0xFFFFu; }
+	__device__ uint32_t next(uint32_t e) const { return lk[e] >> 16; }
+	__device__ uint32_t v0(uint32_t e) const { return va[e] & 0xFFFFu; }
+	__device__ uint32_t v1(uint32_t e) const { return va[e] >> 16; }
+	__device__ void set_prev(uint32_t e, uint32_t x) { ((CRT_LDS uint16_t *)lk)[2*e] = (uint16_t)x; }
+	__device__ void set_next(uint32_t e, uint32_t x) { ((CRT_LDS uint16_t *)lk)[2*e + 1] = (uint16_t)x; }
+	__device__ void kill(uint32_t e) { ((CRT_LDS uint16_t *)vb)[2*e + 1] = 1; }
+	__device__ void put(uint32_t e, uint32_t a, uint32_t b, uint32_t c, uint32_t p, uint32_t n) { va[e] = a | (b << 16); vb[e] = c; lk[e] = p | (n << 16); }
+	__device__ void order_put(uint32_t i, uint32_t e) { order[i] = (uint16_t)e; }
+	__device__ uint32_t order_get(uint32_t i) const { return order[i]; }
+	__device__ void delayed_put(uint32_t i, uint32_t e) { delayed[i] = (uint16_t)e; }
+	__device__ uint32_t delayed_get(uint32_t i) const { return delayed[i]; }
+};
+
+template <class ClersPtr>
 struct TopoState {
 	const TopoJob &J;
+	ClersPtr clers;                  // global, or the LDS copy
+	CRT_GLOBAL const uint32_t *split;
+	CRT_GLOBAL uint32_t *pred;
+	CRT_GLOBAL uint32_t *f32;
+	CRT_GLOBAL uint16_t *f16;
 	uint32_t cler, vertex_count;
 	uint64_t bit;
 	int32_t err;
 	__device__ uint32_t bits(uint32_t n) {
 		if(bit + n > (uint64_t)J.split_nwords*32) { err = ERR_TOPOLOGY; return 0; }
-		const uint32_t v = bit_field(J.split_words, J.split_nwords, bit, n);
+		const uint32_t v = bit_field(split, J.split_nwords, bit, n);
 		bit += n;
 		return v;
 	}
 	__device__ void face(uint32_t at, uint32_t a, uint32_t b, uint32_t c) {
-		if(J.faces_u16) { uint16_t *f = (uint16_t *)J.faces + at; f[0] = (uint16_t)a; f[1] = (uint16_t)b; f[2] = (uint16_t)c; }
-		else { uint32_t *f = (uint32_t *)J.faces + at; f[0] = a; f[1] = b; f[2] = c; }
+		if(f16) { f16[at] = (uint16_t)a; f16[at + 1] = (uint16_t)b; f16[at + 2] = (uint16_t)c; }
+		else { f32[at] = a; f32[at + 1] = b; f32[at + 2] = c; }
+	}
+	__device__ void predict(uint32_t v, uint32_t a, uint32_t b, uint32_t c) {
+		CRT_GLOBAL uint32_t *p = pred + (size_t)v*3;
+		p[0] = a; p[1] = b; p[2] = c;
 	}
 };
 
-__device__ void topo_group(TopoState &S, uint32_t start, uint32_t end) {
+template <class Front, class ClersPtr>
+__device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uint32_t end) {
 	const TopoJob &J = S.J;
-	uint4 *__restrict__ fa = J.front_a;
-	uint2 *__restrict__ fb = J.front_b;
-	uint32_t *__restrict__ order = J.order;
-	uint32_t *__restrict__ delayed = J.delayed;
 	const uint32_t cap = J.front_cap;
 	uint32_t nfront = 0, norder = 0, iorder = 0, ndelayed = 0;
 	int64_t new_edge = -1;
@@ -46,15 +109,14 @@ __device__ void topo_group(TopoState &S, uint32_t start, uint32_t end) {
 		if(new_edge == -1 && iorder >= norder && ndelayed == 0) {      // seed face (decoder.cpp:224-259)
 			if(S.cler >= J.nclers) FAIL();
 			uint32_t last = S.vertex_count - 1, vi[3], split = 0;
-			const uint32_t c = J.clers[S.cler++];
+			const uint32_t c = S.clers[S.cler++];
 			if(c == C_SPLIT) split = S.bits(3);
 			for(int k = 0; k < 3; k++) {
 				uint32_t v;
 				if(split & (1u << k)) v = S.bits(splitbits);
 				else {
 					if(S.vertex_count >= J.nvert) FAIL();
-					uint32_t *p = J.pred + (size_t)S.vertex_count*3;
-					p[0] = last; p[1] = last; p[2] = last;
+					S.predict(S.vertex_count, last, last, last);
 					last = v = S.vertex_count++;
 				}
 				vi[k] = v;
@@ -63,25 +125,26 @@ __device__ void topo_group(TopoState &S, uint32_t start, uint32_t end) {
 			S.face(start, vi[0], vi[1], vi[2]); start += 3;
 			const uint32_t e = nfront;
 			if(e + 3 > cap) FAIL();
-			order[norder++] = e; order[norder++] = e + 1; order[norder++] = e + 2;
-			fa[e] = make_uint4(vi[1], vi[2], vi[0], 0);     fb[e] = make_uint2(e + 2, e + 1);
-			fa[e + 1] = make_uint4(vi[2], vi[0], vi[1], 0); fb[e + 1] = make_uint2(e, e + 2);
-			fa[e + 2] = make_uint4(vi[0], vi[1], vi[2], 0); fb[e + 2] = make_uint2(e + 1, e);
+			F.order_put(norder++, e); F.order_put(norder++, e + 1); F.order_put(norder++, e + 2);
+			F.put(e, vi[1], vi[2], vi[0], e + 2, e + 1);
+			F.put(e + 1, vi[2], vi[0], vi[1], e, e + 2);
+			F.put(e + 2, vi[0], vi[1], vi[2], e + 1, e);
 			nfront += 3;
 			continue;
 		}
 		uint32_t f;
 		if(new_edge != -1) { f = (uint32_t)new_edge; new_edge = -1; }
-		else if(iorder < norder) f = order[iorder++];
-		else f = delayed[--ndelayed];
+		else if(iorder < norder) f = F.order_get(iorder++);
+		else f = F.delayed_get(--ndelayed);
 		if(f >= nfront) FAIL();
-		const uint4 ea = fa[f];
-		if(ea.w) continue;                                             // deleted: no symbol consumed (decoder.cpp:278-279)
+		uint32_t v0, v1, v2, dead;
+		F.core(f, v0, v1, v2, dead);
+		if(dead) continue;                                             // deleted: no symbol consumed (decoder.cpp:278-279)
 		if(S.cler >= J.nclers) FAIL();
-		const uint32_t c = J.clers[S.cler++];
+		const uint32_t c = S.clers[S.cler++];
 		if(c == C_BOUNDARY) continue;
-		const uint2 eb = fb[f];
-		const uint32_t v0 = ea.x, v1 = ea.y, ep = eb.x, en = eb.y;
+		uint32_t ep, en;
+		F.links(f, ep, en);
 		if(ep >= nfront || en >= nfront) FAIL();
 		const uint32_t ne = nfront;
 		uint32_t opp;
@@ -90,47 +153,46 @@ __device__ void topo_group(TopoState &S, uint32_t start, uint32_t end) {
 			if(c == C_SPLIT) { opp = S.bits(splitbits); if(S.err) return; }
 			else {
 				if(S.vertex_count >= J.nvert) FAIL();
-				uint32_t *p = J.pred + (size_t)S.vertex_count*3;
-				p[0] = v1; p[1] = v0; p[2] = ea.z;
+				S.predict(S.vertex_count, v1, v0, v2);
 				opp = S.vertex_count++;
 			}
 			if(ne + 2 > cap) FAIL();
-			fb[ep].y = ne;
-			fb[en].x = ne + 1;
-			fa[ne] = make_uint4(v0, opp, v1, 0);     fb[ne] = make_uint2(ep, ne + 1);
-			order[norder++] = ne + 1;
-			fa[ne + 1] = make_uint4(opp, v1, v0, 0); fb[ne + 1] = make_uint2(ne, en);
+			F.set_next(ep, ne);
+			F.set_prev(en, ne + 1);
+			F.put(ne, v0, opp, v1, ep, ne + 1);
+			F.order_put(norder++, ne + 1);
+			F.put(ne + 1, opp, v1, v0, ne, en);
 			nfront += 2;
 		} else if(c == C_LEFT) {                                       // decoder.cpp:311-317
-			const uint32_t pp = fb[ep].x;
+			const uint32_t pp = F.prev(ep);
 			if(pp >= nfront || ne + 1 > cap) FAIL();
-			opp = fa[ep].x;
-			fa[ep].w = 1;
-			fb[pp].y = ne;
-			fb[en].x = ne;
-			fa[ne] = make_uint4(opp, v1, v0, 0); fb[ne] = make_uint2(pp, en);
+			opp = F.v0(ep);
+			F.kill(ep);
+			F.set_next(pp, ne);
+			F.set_prev(en, ne);
+			F.put(ne, opp, v1, v0, pp, en);
 			nfront += 1;
 		} else if(c == C_RIGHT) {                                      // decoder.cpp:319-325
-			const uint32_t nn = fb[en].y;
+			const uint32_t nn = F.next(en);
 			if(nn >= nfront || ne + 1 > cap) FAIL();
-			opp = fa[en].y;
-			fa[en].w = 1;
-			fb[nn].x = ne;
-			fb[ep].y = ne;
-			fa[ne] = make_uint4(v0, opp, v1, 0); fb[ne] = make_uint2(ep, nn);
+			opp = F.v1(en);
+			F.kill(en);
+			F.set_prev(nn, ne);
+			F.set_next(ep, ne);
+			F.put(ne, v0, opp, v1, ep, nn);
 			nfront += 1;
 		} else if(c == C_DELAY) {                                      // decoder.cpp:327-331
 			if(ndelayed >= cap) FAIL();
-			delayed[ndelayed++] = f;
+			F.delayed_put(ndelayed++, f);
 			new_edge = -1;
 			continue;
 		} else if(c == C_END) {                                        // decoder.cpp:333-339
-			const uint32_t pp = fb[ep].x, nn = fb[en].y;
+			const uint32_t pp = F.prev(ep), nn = F.next(en);
 			if(pp >= nfront || nn >= nfront) FAIL();
-			opp = fa[ep].x;
-			fa[ep].w = 1; fa[en].w = 1;
-			fb[pp].y = nn;
-			fb[nn].x = pp;
+			opp = F.v0(ep);
+			F.kill(ep); F.kill(en);
+			F.set_next(pp, nn);
+			F.set_prev(nn, pp);
 			new_edge = -1;
 		} else FAIL();
 		S.face(start, v1, v0, opp); start += 3;                        // decoder.cpp:348-356
@@ -138,18 +200,189 @@ __device__ void topo_group(TopoState &S, uint32_t start, uint32_t end) {
 #undef FAIL
 }
 
-__global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ jobs, uint32_t njobs) {
-	if(blockIdx.x >= njobs || threadIdx.x != 0) return;
-	const TopoJob J = jobs[blockIdx.x];
-	TopoState S{J, 0, 0, 0, 0};
+template <class Front, class ClersPtr>
+__device__ void topo_run(const TopoJob &J, ClersPtr clers, Front &F) {
+	TopoState<ClersPtr> S{J, clers, as_global(J.split_words), as_global(J.pred),
+	                      J.faces_u16 ? nullptr : as_global((uint32_t *)J.faces), J.faces_u16 ? as_global((uint16_t *)J.faces) : nullptr, 0, 0, 0, 0};
+	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
 	uint32_t start = 0;
 	for(uint32_t g = 0; g < J.ngroups && !S.err; g++) {                // decoder.cpp:173-178
-		uint32_t ge = J.group_end[g];
+		const uint32_t ge = group_end[g];
 		if(ge > J.nface || ge < start) { S.err = ERR_TOPOLOGY; break; }
-		topo_group(S, start*3, ge*3);
+		topo_group(S, F, start*3, ge*3);
 		start = ge;
 	}
-	if(S.err) *J.status = S.err;
+	if(S.err) *as_global(J.status) = S.err;
+}
+
+// general path: any size, state in HBM scratch
+__global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+	if(blockIdx.x >= njobs || threadIdx.x != 0) return;
+	const TopoJob J = jobs[job_ids[blockIdx.x]];
+	GlobalFront F{(CRT_GLOBAL u32x4 *)as_global(J.front_a), (CRT_GLOBAL u32x2 *)as_global(J.front_b), as_global(J.order), as_global(J.delayed)};
+	topo_run(J, as_global(J.clers), F);
+}
+
+// small-blob path: front, queues and the CLERS symbols in LDS, hand-tightened: this single-lane loop is
+// issue-bound (one instruction per ~4 cycles for a lone wave), so every instruction per symbol counts.
+//   * 16-byte edge records {v0|v1<<16, v2|dead<<16, prev|next<<16, -}: one ds_read_b128 / ds_write_b128 each
+//   * the edge about to be processed is the one just created -> kept in registers, never re-read
+//   * RIGHT right after VERTEX closes against the second edge that VERTEX just created -> its (next, v1) are cached
+//   * all links stored in the front are produced by this loop, hence always in range: only values that come
+//     from the stream (symbols, queue pops are ours too) are validated; the symbol array is padded with an
+//     invalid symbol so running off its end fails without a per-step bounds test
+// Layout (dynamic LDS): rec[cap+4] (16 B) | order[cap+4] (u16) | delayed[cap+4] (u16) | clers[nclers+64] (u8)
+__global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const TopoJob J = jobs[job_ids[blockIdx.x]];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const uint32_t cap4 = J.front_cap + 4, qbytes = ((cap4*2 + 15) & ~15u);
+	CRT_LDS u32x4 *rec = (CRT_LDS u32x4 *)as_lds(lds);
+	CRT_LDS uint16_t *rec16 = (CRT_LDS uint16_t *)rec;
+	CRT_LDS uint16_t *order = (CRT_LDS uint16_t *)(rec + cap4);
+	CRT_LDS uint16_t *delayed = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)order + qbytes);
+	CRT_LDS uint8_t *cl = (CRT_LDS uint8_t *)delayed + qbytes;
+	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
+	for(uint32_t i = threadIdx.x; i < J.nclers + 64; i += 64) cl[i] = i < J.nclers ? gcl[i] : (uint8_t)0xFF;
+	__syncthreads();
+	if(threadIdx.x != 0) return;
+
+	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
+	CRT_GLOBAL uint32_t *pred = as_global(J.pred);
+	CRT_GLOBAL uint32_t *f32 = J.faces_u16 ? nullptr : as_global((uint32_t *)J.faces);
+	CRT_GLOBAL uint16_t *f16 = J.faces_u16 ? as_global((uint16_t *)J.faces) : nullptr;
+	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
+	const uint32_t cap = J.front_cap, nvert = J.nvert;
+	const uint32_t splitbits = 32 - __clz(nvert | 1u);
+	uint32_t cler = 0, vc = 0, err = 0;
+	uint64_t bit = 0;
+	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
+
+#define TOPO_BITS(dst, n) do { if(bit + (n) > bit_end) { err = 1; dst = 0; } else { dst = bit_field(split, J.split_nwords, bit, (n)); bit += (n); } } while(0)
+#define TOPO_FACE(a, b, c) do { if(f16) { f16[start] = (uint16_t)(a); f16[start + 1] = (uint16_t)(b); f16[start + 2] = (uint16_t)(c); } \
+	else { f32[start] = (a); f32[start + 1] = (b); f32[start + 2] = (c); } start += 3; } while(0)
+#define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a) | ((b) << 16); t_.y = (c); t_.z = (p) | ((n) << 16); t_.w = 0; rec[e] = t_; } while(0)
+
+	uint32_t start = 0;
+	for(uint32_t g = 0; g < J.ngroups && !err; g++) {                   // decoder.cpp:173-178
+		const uint32_t ge = group_end[g];
+		if(ge > J.nface || ge*3 < start) { err = 1; break; }
+		const uint32_t end = ge*3;
+		uint32_t nfront = 0, norder = 0, iorder = 0, ndelayed = 0;
+		bool have = false;                                             // current edge valid (== reference's new_edge != -1)
+		uint32_t f = 0, v0 = 0, v1 = 0, v2 = 0, ep = 0, en = 0;        // current edge, in registers
+		uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;             // cached (next, v1) of edge nc
+		while(start < end) {
+			if(!have) {
+				nc = 0xFFFFFFFFu;                                      // the (next, v1) cache only survives VERTEX -> RIGHT back to back
+				if(iorder < norder) f = order[iorder++];
+				else if(ndelayed) f = delayed[--ndelayed];
+				else {                                                 // seed face (decoder.cpp:224-259)
+					const uint32_t c = cl[cler++];
+					uint32_t last = vc - 1, vi[3], mask = 0;
+					if(c == C_SPLIT) TOPO_BITS(mask, 3);
+					else if(c != C_VERTEX) { err = 1; break; }
+					for(int k = 0; k < 3; k++) {
+						uint32_t v;
+						if(mask & (1u << k)) { TOPO_BITS(v, splitbits); v &= 0xFFFFu; }
+						else {
+							if(vc >= nvert) { err = 1; break; }
+							CRT_GLOBAL uint32_t *p = pred + (size_t)vc*3;
+							p[0] = last; p[1] = last; p[2] = last;
+							last = v = vc++;
+						}
+						vi[k] = v;
+					}
+					if(err || nfront + 3 > cap) { err = 1; break; }
+					TOPO_FACE(vi[0], vi[1], vi[2]);
+					const uint32_t e = nfront;
+					order[norder] = (uint16_t)e; order[norder + 1] = (uint16_t)(e + 1); order[norder + 2] = (uint16_t)(e + 2); norder += 3;
+					TOPO_PUT(e, vi[1], vi[2], vi[0], e + 2, e + 1);
+					TOPO_PUT(e + 1, vi[2], vi[0], vi[1], e, e + 2);
+					TOPO_PUT(e + 2, vi[0], vi[1], vi[2], e + 1, e);
+					nfront += 3;
+					continue;
+				}
+				if(f >= nfront) { err = 1; break; }                    // cannot happen: queue entries are ours
+				const u32x4 t = rec[f];
+				if(t.y >> 16) continue;                                // deleted: no symbol consumed (decoder.cpp:278-279)
+				v0 = t.x & 0xFFFFu; v1 = t.x >> 16; v2 = t.y & 0xFFFFu; ep = t.z & 0xFFFFu; en = t.z >> 16;
+			}
+			have = false;
+			const uint32_t c = cl[cler++];
+			const uint32_t ne = nfront;
+			if(c == C_VERTEX) {                                        // decoder.cpp:294-309
+				if(vc >= nvert || ne + 2 > cap) { err = 1; break; }
+				const uint32_t opp = vc++;
+				CRT_GLOBAL uint32_t *p = pred + (size_t)opp*3;
+				p[0] = v1; p[1] = v0; p[2] = v2;
+				TOPO_FACE(v1, v0, opp);
+				rec16[ep*8 + 5] = (uint16_t)ne;                        // front[e.prev].next = new_edge
+				rec16[en*8 + 4] = (uint16_t)(ne + 1);                  // front[e.next].prev = new_edge + 1
+				TOPO_PUT(ne, v0, opp, v1, ep, ne + 1);
+				order[norder++] = (uint16_t)(ne + 1);
+				TOPO_PUT(ne + 1, opp, v1, v0, ne, en);
+				nfront = ne + 2;
+				nc = ne + 1; nc_next = en; nc_v1 = v1;                 // what a following RIGHT will ask about edge ne+1
+				f = ne; v2 = v1; v1 = opp; en = ne + 1; have = true;   // next: edge ne = (v0, opp, old v1, ep, ne+1); ne+1 is queued
+			} else if(c == C_LEFT) {                                   // decoder.cpp:311-317
+				if(ne + 1 > cap) { err = 1; break; }
+				const u32x4 t = rec[ep];
+				const uint32_t pp = t.z & 0xFFFFu, opp = t.x & 0xFFFFu;
+				rec16[ep*8 + 3] = 1;                                   // front[e.prev].deleted = true
+				rec16[pp*8 + 5] = (uint16_t)ne;
+				rec16[en*8 + 4] = (uint16_t)ne;
+				TOPO_PUT(ne, opp, v1, v0, pp, en);
+				TOPO_FACE(v1, v0, opp);
+				nfront = ne + 1;
+				nc = 0xFFFFFFFFu;
+				f = ne; v2 = v0; v0 = opp; ep = pp; have = true;       // next: edge ne = (opp, v1, old v0, pp, en)
+			} else if(c == C_RIGHT) {                                  // decoder.cpp:319-325
+				if(ne + 1 > cap) { err = 1; break; }
+				uint32_t nn, opp;
+				if(en == nc) { nn = nc_next; opp = nc_v1; }
+				else { const u32x4 t = rec[en]; nn = t.z >> 16; opp = t.x >> 16; }
+				rec16[en*8 + 3] = 1;
+				rec16[nn*8 + 4] = (uint16_t)ne;
+				rec16[ep*8 + 5] = (uint16_t)ne;
+				TOPO_PUT(ne, v0, opp, v1, ep, nn);
+				TOPO_FACE(v1, v0, opp);
+				nfront = ne + 1;
+				nc = 0xFFFFFFFFu;
+				f = ne; v2 = v1; v1 = opp; en = nn; have = true;       // next: edge ne = (v0, opp, old v1, ep, nn)
+			} else if(c == C_BOUNDARY) {
+				continue;
+			} else if(c == C_SPLIT) {
+				if(ne + 2 > cap) { err = 1; break; }
+				uint32_t opp; TOPO_BITS(opp, splitbits);
+				if(err) break;
+				const uint32_t o16 = opp & 0xFFFFu;
+				TOPO_FACE(v1, v0, opp);
+				rec16[ep*8 + 5] = (uint16_t)ne;
+				rec16[en*8 + 4] = (uint16_t)(ne + 1);
+				TOPO_PUT(ne, v0, o16, v1, ep, ne + 1);
+				order[norder++] = (uint16_t)(ne + 1);
+				TOPO_PUT(ne + 1, o16, v1, v0, ne, en);
+				nfront = ne + 2;
+				nc = ne + 1; nc_next = en; nc_v1 = v1;
+				f = ne; v2 = v1; v1 = o16; en = ne + 1; have = true;
+			} else if(c == C_DELAY) {                                  // decoder.cpp:327-331
+				if(ndelayed >= cap) { err = 1; break; }
+				delayed[ndelayed++] = (uint16_t)f;
+			} else if(c == C_END) {                                    // decoder.cpp:333-339
+				const u32x4 tp = rec[ep], tn = rec[en];
+				const uint32_t pp = tp.z & 0xFFFFu, nn = tn.z >> 16, opp = tp.x & 0xFFFFu;
+				rec16[ep*8 + 3] = 1; rec16[en*8 + 3] = 1;
+				rec16[pp*8 + 5] = (uint16_t)nn;
+				rec16[nn*8 + 4] = (uint16_t)pp;
+				TOPO_FACE(v1, v0, opp);
+			} else { err = 1; break; }                                 // invalid symbol, or ran past the end (0xFF padding)
+		}
+	}
+#undef TOPO_BITS
+#undef TOPO_FACE
+#undef TOPO_PUT
+	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,8 +390,8 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 // (or += v[a]) for i = 1..nvert-1 in index order.  When the attribute fits the LDS budget the whole
 // array is staged there (dependent-read latency ~1/4 of an L2 round trip); otherwise in place in HBM.
 // Prediction triples are fetched 64 vertices at a time (one per lane) and broadcast with readlane.
-template <typename T>
-__device__ void delta_chain(T *v, const uint32_t *__restrict__ pred, uint32_t nvert, uint32_t N, bool para) {
+template <typename T, typename VPtr>
+__device__ void delta_chain(VPtr v, CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t N, bool para) {
 	const uint32_t lane = lane_id();
 	for(uint32_t c0 = 0; c0 < N; c0 += 64) {
 		const uint32_t comp = c0 + lane;
@@ -187,18 +420,18 @@ __global__ __launch_bounds__(64) void k_delta_mesh(const DeltaJob *__restrict__ 
 	const size_t bytes = (size_t)J.nvert*J.N*(J.is_u8 ? 1 : 4);
 	const uint32_t lane = lane_id();
 	if(bytes <= lds_bytes && (bytes & 3) == 0 && (((uintptr_t)J.values) & 3) == 0) {
-		uint32_t *l32 = (uint32_t *)lds;
-		uint32_t *g32 = (uint32_t *)J.values;
+		CRT_LDS uint32_t *l32 = (CRT_LDS uint32_t *)as_lds(lds);
+		CRT_GLOBAL uint32_t *g32 = as_global((uint32_t *)J.values);
 		const uint32_t ndw = (uint32_t)(bytes >> 2);
 		for(uint32_t i = lane; i < ndw; i += 64) l32[i] = g32[i];
 		__syncthreads();
-		if(J.is_u8) delta_chain<uint8_t>((uint8_t *)lds, J.pred, J.nvert, J.N, J.parallelogram);
-		else delta_chain<uint32_t>((uint32_t *)lds, J.pred, J.nvert, J.N, J.parallelogram);
+		if(J.is_u8) delta_chain<uint8_t>((CRT_LDS uint8_t *)l32, as_global(J.pred), J.nvert, J.N, J.parallelogram);
+		else delta_chain<uint32_t>(l32, as_global(J.pred), J.nvert, J.N, J.parallelogram);
 		__syncthreads();
 		for(uint32_t i = lane; i < ndw; i += 64) g32[i] = l32[i];
 	} else {
-		if(J.is_u8) delta_chain<uint8_t>((uint8_t *)J.values, J.pred, J.nvert, J.N, J.parallelogram);
-		else delta_chain<uint32_t>((uint32_t *)J.values, J.pred, J.nvert, J.N, J.parallelogram);
+		if(J.is_u8) delta_chain<uint8_t>(as_global((uint8_t *)J.values), as_global(J.pred), J.nvert, J.N, J.parallelogram);
+		else delta_chain<uint32_t>(as_global((uint32_t *)J.values), as_global(J.pred), J.nvert, J.N, J.parallelogram);
 	}
 }
 

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_normal_flags(const NormalJob *__restric
                                                       const uint32_t *__restrict__ bnd, uint32_t *__restrict__ flag) {
 	if(blockIdx.x >= nblocks) return;
 	const NormalJob J = jobs[block_job[blockIdx.x]];
+	if(J.prediction == 0) return;                       // DIFF jobs own no slice of the per-vertex scratch
 	const uint32_t i = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
 	if(i >= J.nvert) return;
 	flag[J.vbase + i] = (J.prediction == 1 || bnd[J.vbase + i] != 0) ? 1u : 0u;

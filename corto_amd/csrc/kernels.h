@@ -25,7 +25,11 @@ __global__ void k_cloud_apply(const CloudJob *jobs, const uint32_t *chunk_job, u
 __global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uint32_t nblocks);
 
 // k_mesh.hip
-__global__ void k_topology(const TopoJob *jobs, uint32_t njobs);
+__global__ void k_topology(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
+__global__ void k_topology_lds(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
+// dynamic LDS bytes k_topology_lds needs for a front of `cap` edges and `nclers` symbols
+inline uint32_t topo_lds_bytes(uint32_t cap, uint32_t nclers) { return (cap + 4)*16 + ((((cap + 4)*2 + 15) & ~15u))*2 + ((nclers + 64 + 15) & ~15u); }
+constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);
 
 // k_normal.hip

@@ -8,6 +8,15 @@
 
 namespace corto_hip {
 
+// Pointers that come out of job structs in memory are "generic" to the compiler, which then emits FLAT loads and
+// stores.  A FLAT store bumps lgkmcnt as well as vmcnt, so the next LDS read stalls until the store has been
+// acknowledged by the memory system (~1-2 us) - fatal for the serial per-blob chains.  These casts pin the
+// address space so that global_load/global_store (vmcnt only) and ds_* (lgkmcnt only) are emitted.
+#define CRT_GLOBAL __attribute__((address_space(1)))
+#define CRT_LDS __attribute__((address_space(3)))
+template <typename T> __device__ __forceinline__ CRT_GLOBAL T *as_global(T *p) { return (CRT_GLOBAL T *)p; }
+template <typename T> __device__ __forceinline__ CRT_LDS T *as_lds(T *p) { return (CRT_LDS T *)p; }
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
 
@@ -39,7 +48,8 @@ __device__ __forceinline__ T block256_exclusive_scan(T v, T *smem, T *total) {
 
 // MSB-first bit field [o, o+n) of a u32 word stream (src/bitstream.cpp:103-121 as random access).
 // Words past nwords read as 0 (malformed streams cannot fault).
-__device__ __forceinline__ uint32_t bit_field(const uint32_t *__restrict__ w, uint32_t nwords, uint64_t o, uint32_t n) {
+template <typename WordPtr>
+__device__ __forceinline__ uint32_t bit_field(WordPtr w, uint32_t nwords, uint64_t o, uint32_t n) {
 	if(n == 0) return 0;
 	const uint64_t i = o >> 5;
 	const uint32_t sh = (uint32_t)(o & 31);
