@@ -223,14 +223,18 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 	topo_run(J, as_global(J.clers), F);
 }
 
-// small-blob path: front, queues and the CLERS symbols in LDS, hand-tightened: this single-lane loop is
-// issue-bound (one instruction per ~4 cycles for a lone wave), so every instruction per symbol counts.
+// small-blob path: front, queues and the CLERS symbols in LDS, hand-tightened.  A lone wave issues one
+// instruction every ~4 cycles, so this single-lane loop is issue-bound: every instruction per symbol counts.
 //   * 16-byte edge records {v0|v1<<16, v2|dead<<16, prev|next<<16, -}: one ds_read_b128 / ds_write_b128 each
-//   * the edge about to be processed is the one just created -> kept in registers, never re-read
-//   * RIGHT right after VERTEX closes against the second edge that VERTEX just created -> its (next, v1) are cached
-//   * all links stored in the front are produced by this loop, hence always in range: only values that come
-//     from the stream (symbols, queue pops are ours too) are validated; the symbol array is padded with an
-//     invalid symbol so running off its end fails without a per-step bounds test
+//   * LAZY current edge: the edge created by VERTEX/LEFT/RIGHT is the next one processed (decoder.cpp:261-264),
+//     and when it is consumed right away by another VERTEX/LEFT/RIGHT/END nobody ever reads its record, and the
+//     links its neighbours hold to it are overwritten by that step.  So it lives in registers only, and its record
+//     plus the two neighbour links are written ("materialised") only if it survives (BOUNDARY / DELAY).
+//     Edge ids are internal to the decoder (outputs carry vertex ids only), so this is unobservable.
+//   * RIGHT right after VERTEX closes against the second edge VERTEX just created -> its (next, v1) are cached
+//   * links stored in the front are produced by this loop, hence always in range; only values that come from the
+//     stream are validated; the symbol array is padded with an invalid symbol so running off its end fails
+//     without a per-step bounds test.  Symbols are fetched four at a time.
 // Layout (dynamic LDS): rec[cap+4] (16 B) | order[cap+4] (u16) | delayed[cap+4] (u16) | clers[nclers+64] (u8)
 __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 	CRT_LDS uint16_t *order = (CRT_LDS uint16_t *)(rec + cap4);
 	CRT_LDS uint16_t *delayed = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)order + qbytes);
 	CRT_LDS uint8_t *cl = (CRT_LDS uint8_t *)delayed + qbytes;
+	CRT_LDS const uint32_t *cl32 = (CRT_LDS const uint32_t *)cl;
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	for(uint32_t i = threadIdx.x; i < J.nclers + 64; i += 64) cl[i] = i < J.nclers ? gcl[i] : (uint8_t)0xFF;
 	__syncthreads();
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 	const uint32_t cap = J.front_cap, nvert = J.nvert;
 	const uint32_t splitbits = 32 - __clz(nvert | 1u);
 	uint32_t cler = 0, vc = 0, err = 0;
+	uint32_t sw = cl32[0], swn = cl32[1];                                // symbol words: current (shifted) and next
 	uint64_t bit = 0;
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
 
@@ -262,6 +268,8 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 #define TOPO_FACE(a, b, c) do { if(f16) { f16[start] = (uint16_t)(a); f16[start + 1] = (uint16_t)(b); f16[start + 2] = (uint16_t)(c); } \
 	else { f32[start] = (a); f32[start + 1] = (b); f32[start + 2] = (c); } start += 3; } while(0)
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a) | ((b) << 16); t_.y = (c); t_.z = (p) | ((n) << 16); t_.w = 0; rec[e] = t_; } while(0)
+#define TOPO_SYMBOL(c) do { c = sw & 0xFFu; sw >>= 8; cler++; if((cler & 3u) == 0) { sw = swn; swn = cl32[(cler >> 2) + 1]; } } while(0)
+#define TOPO_MATERIALISE() do { if(lazy) { TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
 
 	uint32_t start = 0;
 	for(uint32_t g = 0; g < J.ngroups && !err; g++) {                   // decoder.cpp:173-178
@@ -269,119 +277,122 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 		if(ge > J.nface || ge*3 < start) { err = 1; break; }
 		const uint32_t end = ge*3;
 		uint32_t nfront = 0, norder = 0, iorder = 0, ndelayed = 0;
-		bool have = false;                                             // current edge valid (== reference's new_edge != -1)
-		uint32_t f = 0, v0 = 0, v1 = 0, v2 = 0, ep = 0, en = 0;        // current edge, in registers
-		uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;             // cached (next, v1) of edge nc
-		while(start < end) {
-			if(!have) {
-				nc = 0xFFFFFFFFu;                                      // the (next, v1) cache only survives VERTEX -> RIGHT back to back
-				if(iorder < norder) f = order[iorder++];
-				else if(ndelayed) f = delayed[--ndelayed];
-				else {                                                 // seed face (decoder.cpp:224-259)
-					const uint32_t c = cl[cler++];
-					uint32_t last = vc - 1, vi[3], mask = 0;
-					if(c == C_SPLIT) TOPO_BITS(mask, 3);
-					else if(c != C_VERTEX) { err = 1; break; }
-					for(int k = 0; k < 3; k++) {
-						uint32_t v;
-						if(mask & (1u << k)) { TOPO_BITS(v, splitbits); v &= 0xFFFFu; }
-						else {
-							if(vc >= nvert) { err = 1; break; }
-							CRT_GLOBAL uint32_t *p = pred + (size_t)vc*3;
-							p[0] = last; p[1] = last; p[2] = last;
-							last = v = vc++;
-						}
-						vi[k] = v;
+		while(start < end && !err) {
+			// ---- cold: fetch the next edge to process: queue, delayed stack, or a new seed face ----
+			uint32_t f;
+			if(iorder < norder) f = order[iorder++];
+			else if(ndelayed) f = delayed[--ndelayed];
+			else {                                                     // seed face (decoder.cpp:224-259)
+				uint32_t c; TOPO_SYMBOL(c);
+				uint32_t last = vc - 1, vi[3], mask = 0;
+				if(c == C_SPLIT) TOPO_BITS(mask, 3);
+				else if(c != C_VERTEX) { err = 1; break; }
+				for(int k = 0; k < 3; k++) {
+					uint32_t v;
+					if(mask & (1u << k)) { TOPO_BITS(v, splitbits); v &= 0xFFFFu; }
+					else {
+						if(vc >= nvert) { err = 1; break; }
+						CRT_GLOBAL uint32_t *p = pred + (size_t)vc*3;
+						p[0] = last; p[1] = last; p[2] = last;
+						last = v = vc++;
 					}
-					if(err || nfront + 3 > cap) { err = 1; break; }
-					TOPO_FACE(vi[0], vi[1], vi[2]);
-					const uint32_t e = nfront;
-					order[norder] = (uint16_t)e; order[norder + 1] = (uint16_t)(e + 1); order[norder + 2] = (uint16_t)(e + 2); norder += 3;
-					TOPO_PUT(e, vi[1], vi[2], vi[0], e + 2, e + 1);
-					TOPO_PUT(e + 1, vi[2], vi[0], vi[1], e, e + 2);
-					TOPO_PUT(e + 2, vi[0], vi[1], vi[2], e + 1, e);
-					nfront += 3;
-					continue;
+					vi[k] = v;
 				}
-				if(f >= nfront) { err = 1; break; }                    // cannot happen: queue entries are ours
-				const u32x4 t = rec[f];
-				if(t.y >> 16) continue;                                // deleted: no symbol consumed (decoder.cpp:278-279)
-				v0 = t.x & 0xFFFFu; v1 = t.x >> 16; v2 = t.y & 0xFFFFu; ep = t.z & 0xFFFFu; en = t.z >> 16;
-			}
-			have = false;
-			const uint32_t c = cl[cler++];
-			const uint32_t ne = nfront;
-			if(c == C_VERTEX) {                                        // decoder.cpp:294-309
-				if(vc >= nvert || ne + 2 > cap) { err = 1; break; }
-				const uint32_t opp = vc++;
-				CRT_GLOBAL uint32_t *p = pred + (size_t)opp*3;
-				p[0] = v1; p[1] = v0; p[2] = v2;
-				TOPO_FACE(v1, v0, opp);
-				rec16[ep*8 + 5] = (uint16_t)ne;                        // front[e.prev].next = new_edge
-				rec16[en*8 + 4] = (uint16_t)(ne + 1);                  // front[e.next].prev = new_edge + 1
-				TOPO_PUT(ne, v0, opp, v1, ep, ne + 1);
-				order[norder++] = (uint16_t)(ne + 1);
-				TOPO_PUT(ne + 1, opp, v1, v0, ne, en);
-				nfront = ne + 2;
-				nc = ne + 1; nc_next = en; nc_v1 = v1;                 // what a following RIGHT will ask about edge ne+1
-				f = ne; v2 = v1; v1 = opp; en = ne + 1; have = true;   // next: edge ne = (v0, opp, old v1, ep, ne+1); ne+1 is queued
-			} else if(c == C_LEFT) {                                   // decoder.cpp:311-317
-				if(ne + 1 > cap) { err = 1; break; }
-				const u32x4 t = rec[ep];
-				const uint32_t pp = t.z & 0xFFFFu, opp = t.x & 0xFFFFu;
-				rec16[ep*8 + 3] = 1;                                   // front[e.prev].deleted = true
-				rec16[pp*8 + 5] = (uint16_t)ne;
-				rec16[en*8 + 4] = (uint16_t)ne;
-				TOPO_PUT(ne, opp, v1, v0, pp, en);
-				TOPO_FACE(v1, v0, opp);
-				nfront = ne + 1;
-				nc = 0xFFFFFFFFu;
-				f = ne; v2 = v0; v0 = opp; ep = pp; have = true;       // next: edge ne = (opp, v1, old v0, pp, en)
-			} else if(c == C_RIGHT) {                                  // decoder.cpp:319-325
-				if(ne + 1 > cap) { err = 1; break; }
-				uint32_t nn, opp;
-				if(en == nc) { nn = nc_next; opp = nc_v1; }
-				else { const u32x4 t = rec[en]; nn = t.z >> 16; opp = t.x >> 16; }
-				rec16[en*8 + 3] = 1;
-				rec16[nn*8 + 4] = (uint16_t)ne;
-				rec16[ep*8 + 5] = (uint16_t)ne;
-				TOPO_PUT(ne, v0, opp, v1, ep, nn);
-				TOPO_FACE(v1, v0, opp);
-				nfront = ne + 1;
-				nc = 0xFFFFFFFFu;
-				f = ne; v2 = v1; v1 = opp; en = nn; have = true;       // next: edge ne = (v0, opp, old v1, ep, nn)
-			} else if(c == C_BOUNDARY) {
+				if(err || nfront + 3 > cap) { err = 1; break; }
+				TOPO_FACE(vi[0], vi[1], vi[2]);
+				const uint32_t e = nfront;
+				order[norder] = (uint16_t)e; order[norder + 1] = (uint16_t)(e + 1); order[norder + 2] = (uint16_t)(e + 2); norder += 3;
+				TOPO_PUT(e, vi[1], vi[2], vi[0], e + 2, e + 1);
+				TOPO_PUT(e + 1, vi[2], vi[0], vi[1], e, e + 2);
+				TOPO_PUT(e + 2, vi[0], vi[1], vi[2], e + 1, e);
+				nfront += 3;
 				continue;
-			} else if(c == C_SPLIT) {
-				if(ne + 2 > cap) { err = 1; break; }
-				uint32_t opp; TOPO_BITS(opp, splitbits);
-				if(err) break;
-				const uint32_t o16 = opp & 0xFFFFu;
-				TOPO_FACE(v1, v0, opp);
-				rec16[ep*8 + 5] = (uint16_t)ne;
-				rec16[en*8 + 4] = (uint16_t)(ne + 1);
-				TOPO_PUT(ne, v0, o16, v1, ep, ne + 1);
-				order[norder++] = (uint16_t)(ne + 1);
-				TOPO_PUT(ne + 1, o16, v1, v0, ne, en);
-				nfront = ne + 2;
-				nc = ne + 1; nc_next = en; nc_v1 = v1;
-				f = ne; v2 = v1; v1 = o16; en = ne + 1; have = true;
-			} else if(c == C_DELAY) {                                  // decoder.cpp:327-331
-				if(ndelayed >= cap) { err = 1; break; }
-				delayed[ndelayed++] = (uint16_t)f;
-			} else if(c == C_END) {                                    // decoder.cpp:333-339
-				const u32x4 tp = rec[ep], tn = rec[en];
-				const uint32_t pp = tp.z & 0xFFFFu, nn = tn.z >> 16, opp = tp.x & 0xFFFFu;
-				rec16[ep*8 + 3] = 1; rec16[en*8 + 3] = 1;
-				rec16[pp*8 + 5] = (uint16_t)nn;
-				rec16[nn*8 + 4] = (uint16_t)pp;
-				TOPO_FACE(v1, v0, opp);
-			} else { err = 1; break; }                                 // invalid symbol, or ran past the end (0xFF padding)
+			}
+			if(f >= nfront) { err = 1; break; }                        // cannot happen: queue entries are ours
+			const u32x4 t0 = rec[f];
+			if(t0.y >> 16) continue;                                   // deleted: no symbol consumed (decoder.cpp:278-279)
+			uint32_t v0 = t0.x & 0xFFFFu, v1 = t0.x >> 16, v2 = t0.y & 0xFFFFu, ep = t0.z & 0xFFFFu, en = t0.z >> 16;
+			bool lazy = false;                                         // current edge's record not written yet
+			uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;         // cached (next, v1) of edge nc
+
+			// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
+			for(;;) {
+				uint32_t c; TOPO_SYMBOL(c);
+				const uint32_t ne = nfront;
+				if(c == C_VERTEX) {                                    // decoder.cpp:294-309
+					if(vc >= nvert || ne + 2 > cap) { err = 1; break; }
+					const uint32_t opp = vc++;
+					CRT_GLOBAL uint32_t *p = pred + (size_t)opp*3;
+					p[0] = v1; p[1] = v0; p[2] = v2;
+					TOPO_FACE(v1, v0, opp);
+					rec16[en*8 + 4] = (uint16_t)(ne + 1);              // front[e.next].prev = new_edge + 1
+					order[norder++] = (uint16_t)(ne + 1);
+					TOPO_PUT(ne + 1, opp, v1, v0, ne, en);             // second new edge: queued, so it must exist
+					nfront = ne + 2;
+					nc = ne + 1; nc_next = en; nc_v1 = v1;
+					f = ne; v2 = v1; v1 = opp; en = ne + 1;            // first new edge (v0, opp, old v1, ep, ne+1): next, lazily
+					lazy = true;
+				} else if(c == C_LEFT) {                               // decoder.cpp:311-317
+					if(ne + 1 > cap) { err = 1; break; }
+					const u32x4 t = rec[ep];
+					const uint32_t pp = t.z & 0xFFFFu, opp = t.x & 0xFFFFu;
+					rec16[ep*8 + 3] = 1;                               // front[e.prev].deleted = true
+					TOPO_FACE(v1, v0, opp);
+					nfront = ne + 1;
+					nc = 0xFFFFFFFFu;
+					f = ne; v2 = v0; v0 = opp; ep = pp;                // new edge (opp, v1, old v0, pp, en): next, lazily
+					lazy = true;
+				} else if(c == C_RIGHT) {                              // decoder.cpp:319-325
+					if(ne + 1 > cap) { err = 1; break; }
+					uint32_t nn, opp;
+					if(en == nc) { nn = nc_next; opp = nc_v1; }
+					else { const u32x4 t = rec[en]; nn = t.z >> 16; opp = t.x >> 16; }
+					rec16[en*8 + 3] = 1;
+					TOPO_FACE(v1, v0, opp);
+					nfront = ne + 1;
+					nc = 0xFFFFFFFFu;
+					f = ne; v2 = v1; v1 = opp; en = nn;                // new edge (v0, opp, old v1, ep, nn): next, lazily
+					lazy = true;
+				} else {                                               // ---- cold symbols end the chain ----
+					if(c == C_BOUNDARY) {
+						TOPO_MATERIALISE();
+					} else if(c == C_SPLIT) {
+						if(ne + 2 > cap) { err = 1; break; }
+						uint32_t opp; TOPO_BITS(opp, splitbits);
+						if(err) break;
+						const uint32_t o16 = opp & 0xFFFFu;
+						TOPO_FACE(v1, v0, opp);
+						rec16[en*8 + 4] = (uint16_t)(ne + 1);
+						order[norder++] = (uint16_t)(ne + 1);
+						TOPO_PUT(ne + 1, o16, v1, v0, ne, en);
+						nfront = ne + 2;
+						nc = ne + 1; nc_next = en; nc_v1 = v1;
+						f = ne; v2 = v1; v1 = o16; en = ne + 1;
+						lazy = true;
+						if(start < end) continue;                      // SPLIT continues the chain like VERTEX
+					} else if(c == C_DELAY) {                          // decoder.cpp:327-331
+						if(ndelayed >= cap) { err = 1; break; }
+						TOPO_MATERIALISE();
+						delayed[ndelayed++] = (uint16_t)f;
+					} else if(c == C_END) {                            // decoder.cpp:333-339
+						const u32x4 tp = rec[ep], tn = rec[en];
+						const uint32_t pp = tp.z & 0xFFFFu, nn = tn.z >> 16, opp = tp.x & 0xFFFFu;
+						rec16[ep*8 + 3] = 1; rec16[en*8 + 3] = 1;
+						rec16[pp*8 + 5] = (uint16_t)nn;
+						rec16[nn*8 + 4] = (uint16_t)pp;
+						TOPO_FACE(v1, v0, opp);
+					} else err = 1;                                    // invalid symbol, or ran past the end (0xFF padding)
+					break;
+				}
+				if(start >= end) break;
+			}
 		}
 	}
 #undef TOPO_BITS
 #undef TOPO_FACE
 #undef TOPO_PUT
+#undef TOPO_SYMBOL
+#undef TOPO_MATERIALISE
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
 }
 
