@@ -127,7 +127,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    blobs, z = load_blobs()                      # every rank decodes its own 256-blob shard (no data-path collective)
+    from corto_amd import shard
+    blobs, z = load_blobs()
+    # C5 = world x 256 blobs cut into contiguous work-balanced ranges; this rank decodes only its own (no collective)
+    lo, hi = shard.my_range([4096 + 2112] * (NBLOBS * world), world, rank)
+    assert hi - lo == NBLOBS
     ctx = ca.Context(local_rank)
     arena = ca.upload_arena(blobs, local_rank)   # compressed inputs resident in HBM before the timed region
     # outputs are allocated and bound once (like a caller that reuses its vertex/index buffers)
@@ -152,12 +156,12 @@ def main():
         ca._check(L.crthip_batch_sync(h, status.ctypes.data_as(C.c_void_p)))
         return h
 
-    def barrier():
+    def device_sync():
         torch.cuda.synchronize()
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+
+    def barrier():
+        shard.barrier(dist, device_sync)
 
     ctx.set_profiling(True)                      # HIP events around every kernel, on the stream the kernels run on
     for _ in range(args.warmup):
@@ -175,10 +179,7 @@ def main():
         L.crthip_batch_destroy(h)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, torch.device("cuda", local_rank))
     assert (status == 0).all(), status
 
     # untimed bit-exactness check of this rank's outputs against the golden digests made by the reference

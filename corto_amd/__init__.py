@@ -88,6 +88,8 @@ def lib():
         L.crthip_abi_version.restype = C.c_uint32
         L.crthip_probe_exif.restype = C.c_int64
         L.crthip_probe_groups.restype = C.c_int64
+        L.crthip_probe_group_props.restype = C.c_int64
+        L.crthip_probe_group_props.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]
         L.crthip_arena_layout.restype = C.c_uint64
         L.crthip_batch_size.restype = C.c_uint32
         L.crthip_batch_debug_read.restype = C.c_int64

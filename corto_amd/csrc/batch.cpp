@@ -87,6 +87,17 @@ extern "C" int64_t crthip_probe_groups(const uint8_t *blob, size_t len, uint32_t
 	return (int64_t)L.group_end.size();
 }
 
+extern "C" int64_t crthip_probe_group_props(const uint8_t *blob, size_t len, uint32_t g, char *out, size_t cap) {
+	BlobLayout L;
+	int err = walk_blob(blob, len, L);
+	if(err) return fail(err);
+	if(g >= L.group_props.size()) return fail(CRTHIP_E_ARGUMENT);
+	std::string flat;
+	for(auto &kv : L.group_props[g]) { flat += kv.first; flat.push_back('\0'); flat += kv.second; flat.push_back('\0'); }
+	if(out && cap >= flat.size()) memcpy(out, flat.data(), flat.size());
+	return (int64_t)flat.size();
+}
+
 extern "C" uint64_t crthip_arena_layout(uint32_t nblobs, const uint32_t *lens, uint64_t *offsets) {
 	uint64_t off = 0;
 	for(uint32_t i = 0; i < nblobs; i++) {

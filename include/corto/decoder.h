@@ -1,0 +1,97 @@
+// include/corto/decoder.h — drop-in crt::Decoder for the MI355X path.
+//
+// Same class name, public members and method signatures as upstream's include/corto/decoder.h:38-73,
+// so code written against libcorto's decoder compiles unchanged against this header and links with
+// libcorto_hip.so instead of libcorto.  decode() runs on the GPU through the C ABI (corto_hip.h);
+// output buffers are the caller's HOST buffers exactly as upstream (ownership rules: SURVEY.md §8b).
+//
+// Differences, all deliberate and loud:
+//   * there is no CPU path: without a usable HIP device decode() throws;
+//   * VertexAttribute here is a plain descriptor, not upstream's codec base class: custom codec objects
+//     (setAttribute(name, buffer, VertexAttribute*)) cannot run on the device and are rejected;
+//   * generic attributes decode to FLOAT only, colours to UINT8, normals to FLOAT or INT16 (the formats
+//     upstream's own callers use; SURVEY.md a17 lists the rest as never executed by Decoder).
+// Errors are thrown as `const char *` with upstream's own messages (src/decoder.cpp:44,51,274 ...).
+#ifndef CRT_HIP_DECODER_H
+#define CRT_HIP_DECODER_H
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+typedef unsigned char uchar;
+
+namespace crt {
+
+// upstream include/corto/vertex_attribute.h:30-45 (data members only)
+class VertexAttribute {
+public:
+	enum Format { UINT32 = 0, INT32, UINT16, INT16, UINT8, INT8, FLOAT, DOUBLE };
+	enum Strategy { PARALLEL = 0x1, CORRELATED = 0x2 };
+	enum CODEC { GENERIC_CODEC = 1, NORMAL_CODEC = 2, COLOR_CODEC = 3, CUSTOM_CODEC = 100 };
+
+	char *buffer = nullptr;     // output buffer (host), set by the set* calls
+	int N = 0;                  // number of components as stored
+	float q = 0.0f;             // quantisation step
+	int strategy = 0;
+	Format format = INT32;      // output format
+	uint32_t size = 0;
+	int bits = 0;
+	int codec_id = GENERIC_CODEC;
+	int out_components = 4;     // colours only (upstream ColorAttr::out_components)
+	int codec() const { return codec_id; }
+};
+
+// upstream include/corto/index_attribute.h:40-60 (what callers touch)
+struct Group {
+	uint32_t end = 0;           // 1 + last face
+	std::map<std::string, std::string> properties;
+};
+
+class IndexAttribute {
+public:
+	uint32_t *faces32 = nullptr;
+	uint16_t *faces16 = nullptr;
+	std::vector<Group> groups;
+	uint32_t max_front = 0;
+};
+
+class Decoder {
+public:
+	uint32_t nvert, nface;
+	std::map<std::string, std::string> exif;
+	std::map<std::string, VertexAttribute *> data;
+	IndexAttribute index;
+
+	Decoder(int len, const uchar *input);                // src/decoder.cpp:41-89
+	~Decoder();
+	Decoder(const Decoder &) = delete;
+	Decoder &operator=(const Decoder &) = delete;
+
+	bool hasAttr(const char *name) { return data.count(name) != 0; }
+
+	bool setPositions(float *buffer) { return setAttribute("position", (char *)buffer, VertexAttribute::FLOAT); }
+	bool setNormals(float *buffer) { return setAttribute("normal", (char *)buffer, VertexAttribute::FLOAT); }
+	bool setNormals(int16_t *buffer) { return setAttribute("normal", (char *)buffer, VertexAttribute::INT16); }
+	bool setUvs(float *buffer) { return setAttribute("uv", (char *)buffer, VertexAttribute::FLOAT); }
+	bool setColors(uchar *buffer, int components = 4);
+
+	bool setAttribute(const char *name, char *buffer, VertexAttribute::Format format);
+	bool setAttribute(const char *name, char *buffer, VertexAttribute *attr);   // custom codecs: rejected (throws)
+
+	void setIndex(uint32_t *buffer) { index.faces32 = buffer; }
+	void setIndex(uint16_t *buffer) { index.faces16 = buffer; }
+
+	void decode();                                       // src/decoder.cpp:126-196, on the GPU
+
+	// which HIP device the process-wide context of this facade uses (default 0, or $CORTO_HIP_DEVICE)
+	static void setDevice(int device);
+
+private:
+	const uchar *input_;
+	int len_;
+};
+
+} // namespace crt
+#endif // CRT_HIP_DECODER_H

@@ -103,6 +103,8 @@ int crthip_probe(const uint8_t *blob, size_t len, crthip_blob_info *info);
 int64_t crthip_probe_exif(const uint8_t *blob, size_t len, char *out, size_t cap);
 /* groups: writes min(cap, ngroups) end-face markers, returns ngroups or <0 (include/corto/index_attribute.h:89-99) */
 int64_t crthip_probe_groups(const uint8_t *blob, size_t len, uint32_t *group_end, size_t cap);
+/* properties of group g as key\0value\0... (Group::properties); returns bytes needed, or <0 */
+int64_t crthip_probe_group_props(const uint8_t *blob, size_t len, uint32_t g, char *out, size_t cap);
 
 int crthip_ctx_create(int device, crthip_ctx **out);
 void crthip_ctx_destroy(crthip_ctx *ctx);

@@ -148,6 +148,30 @@ def test_decoder_facade_host_buffers(ctx):
     assert_same(dict(position=pos, normal=nrm, color=col, uv=uv, index=idx), g, KEYS, "facade")
 
 
+def test_cpp_decoder_dropin(ctx, tmp_path):
+    """the C++ crt::Decoder facade, compiled against include/corto/decoder.h exactly as a libcorto user would"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "facade_decode")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_decode.cpp"),
+                           "-L", os.path.dirname(ca.LIB_PATH), "-lcorto_hip", "-Wl,-rpath," + os.path.dirname(ca.LIB_PATH), "-o", exe])
+    for name in ("c4_unit", "two_groups", "radius_attr"):
+        g = load_golden(name)
+        src, dst = str(tmp_path / (name + ".crt")), str(tmp_path / (name + ".bin"))
+        g["crt"].tofile(src)
+        out = subprocess.run([exe, src, dst], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        cc = int(g["color_components"])
+        exp = oc.decode(g["crt"], color_components=4)
+        blob = np.fromfile(dst, dtype=np.uint8)
+        want = np.concatenate([exp[k].reshape(-1).view(np.uint8) for k in ("position", "normal", "color", "uv", "index")])
+        assert blob.tobytes() == want.tobytes(), name
+    bad = str(tmp_path / "bad.crt")
+    np.zeros(64, dtype=np.uint8).tofile(bad)
+    out = subprocess.run([exe, bad, str(tmp_path / "x")], capture_output=True, text=True)
+    assert out.returncode == 1 and "Not a crt file." in out.stderr
+
+
 def test_topology_failure_is_reported_per_blob(ctx):
     g = load_golden("holey_disc"); ok = load_golden("torus")
     bad = g["crt"].copy()
