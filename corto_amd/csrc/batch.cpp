@@ -362,6 +362,7 @@ struct Plan {
 
 } // namespace
 
+
 static const uint32_t DELTA_LDS_MAX = 64*1024;
 
 struct Launch {
@@ -389,7 +390,7 @@ static int build_and_launch(crthip_batch *b) {
 
 	// ---- pass 1: sizes & offsets (device addresses are scratch_base + offset, resolved in pass 2) ----
 	// We first carve all scratch, then reserve the block, then fill job structs with real pointers.
-	struct AttrScratch { uint64_t color = ~0ull, diffs = ~0ull; std::vector<uint64_t> sym; };
+	struct AttrScratch { uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull; std::vector<uint64_t> sym; };
 	struct BlobScratch {
 		uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
 		uint32_t front_cap = 0, aux_groups = 0;
@@ -416,6 +417,18 @@ static int build_and_launch(crthip_batch *b) {
 	pl.est_nvert = (uint32_t)est_v; pl.est_nface = (uint32_t)est_f;
 	if(est_v) {
 		pl.cnt_off = cv.take(est_v*4 + 16); pl.cursor_off = cv.take(est_v*4 + 16); pl.bnd_off = cv.take(est_v*4 + 16);
+	}
+	for(uint32_t i = 0; i < nblobs; i++) {                           // "fired" flags of delta jobs too large for LDS
+		const BlobPlan &P = b->blobs[i];
+		const BlobLayout &L = P.L;
+		bs[i].attr.resize(L.attrs.size());
+		if(L.h.nface == 0) continue;
+		for(size_t k = 0; k < L.attrs.size(); k++) {
+			if(!P.bind[k].buffer) continue;
+			const AttrHeader &a = L.h.attrs[k];
+			const uint64_t per = a.codec == CRTHIP_CODEC_NORMAL ? 8 : a.codec == CRTHIP_CODEC_COLOR ? a.N : (uint64_t)a.N*4;
+			if(((L.h.nvert*per + 15) & ~15ull) + L.h.nvert > DELTA_LDS_MAX) bs[i].attr[k].fired = cv.take((uint64_t)L.h.nvert + 16, 16);
+		}
 	}
 	pl.zero_end = cv.take(0);
 	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0;
@@ -564,8 +577,9 @@ static int build_and_launch(crthip_batch *b) {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real;
-					const uint64_t bytes = (uint64_t)nvert*N*(is_u8 ? 1 : 4);
-					if(bytes <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((bytes + 15) & ~15ull));
+					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
+					const uint64_t need = (((uint64_t)nvert*N*(is_u8 ? 1 : 4) + 15) & ~15ull) + nvert;
+					if(need <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((need + 15) & ~15ull));
 					pl.delta.v.push_back(d);
 				} else {
 					CloudJob c{};
@@ -656,7 +670,7 @@ static int build_and_launch(crthip_batch *b) {
 		if(!(u.out_u8 & 0x80)) u.out = R(u.out);
 		u.out_u8 &= 0x7F;
 	}
-	for(auto &d : pl.delta.v) { if(!d.pad[0]) d.values = R(d.values); d.pad[0] = 0; d.pred = (const uint32_t *)R(d.pred); }
+	for(auto &d : pl.delta.v) { if(!d.pad[0]) d.values = R(d.values); d.pad[0] = 0; d.pred = (const uint32_t *)R(d.pred); if(d.fired) d.fired = R(d.fired); }
 	for(auto &c : pl.cloud.v) { if(!c.pad[0]) c.values = R(c.values); c.pad[0] = 0; }
 	for(auto &n : pl.normal.v) {
 		n.diffs = (int32_t *)R(n.diffs); n.status = (int32_t *)R(n.status);
@@ -712,7 +726,7 @@ static int build_and_launch(crthip_batch *b) {
 	}
 	if(!pl.delta.v.empty()) {
 		LT.begin("delta_mesh");
-		hipLaunchKernelGGL(k_delta_mesh, dim3((uint32_t)pl.delta.v.size()), dim3(64), pl.delta_lds, st, D(pl.delta), (uint32_t)pl.delta.v.size(), pl.delta_lds);
+		hipLaunchKernelGGL(k_delta_mesh, dim3((uint32_t)pl.delta.v.size()), dim3(1024), pl.delta_lds, st, D(pl.delta), (uint32_t)pl.delta.v.size(), pl.delta_lds);
 		LT.end();
 	}
 	if(cloud_chunks) {

@@ -69,6 +69,7 @@ struct UnpackJob {
 struct DeltaJob {
 	void *values;                  // int32* or uint8*, stride N
 	const uint32_t *pred;
+	uint8_t *fired;                // nvert zeroed flags in HBM, used only when values + flags do not fit LDS
 	uint32_t nvert, N;
 	uint8_t parallelogram, is_u8, pad[2];
 	uint32_t pad2;

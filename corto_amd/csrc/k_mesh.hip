@@ -397,52 +397,86 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-DELTA (mesh).  One wave per (blob, attribute); lane = component.  v[i] += v[a] + v[b] - v[c]
-// (or += v[a]) for i = 1..nvert-1 in index order.  When the attribute fits the LDS budget the whole
-// array is staged there (dependent-read latency ~1/4 of an L2 round trip); otherwise in place in HBM.
-// Prediction triples are fetched 64 vertices at a time (one per lane) and broadcast with readlane.
-template <typename T, typename VPtr>
-__device__ void delta_chain(VPtr v, CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t N, bool para) {
-	const uint32_t lane = lane_id();
-	for(uint32_t c0 = 0; c0 < N; c0 += 64) {
-		const uint32_t comp = c0 + lane;
-		const bool on = comp < N;
-		for(uint32_t i0 = 0; i0 < nvert; i0 += 64) {
-			const uint32_t mine = i0 + lane;
-			uint32_t pa = 0, pb = 0, pc = 0;
-			if(mine < nvert) { pa = pred[(size_t)mine*3]; pb = pred[(size_t)mine*3 + 1]; pc = pred[(size_t)mine*3 + 2]; }
-			const uint32_t kend = min(64u, nvert - i0);
-			for(uint32_t k = (i0 == 0 ? 1u : 0u); k < kend; k++) {
-				const uint32_t a = __shfl(pa, k, 64), b = __shfl(pb, k, 64), c = __shfl(pc, k, 64);
-				const uint32_t i = i0 + k;
-				if(on && a < nvert && b < nvert && c < nvert) {
-					if(para) v[(size_t)i*N + comp] = (T)(v[(size_t)i*N + comp] + v[(size_t)a*N + comp] + v[(size_t)b*N + comp] - v[(size_t)c*N + comp]);
-					else v[(size_t)i*N + comp] = (T)(v[(size_t)i*N + comp] + v[(size_t)a*N + comp]);
-				}
+// K-DELTA (mesh): v[i] += v[a] + v[b] - v[c] (or += v[a]) for i = 1..nvert-1 in index order
+// (vertex_attribute.h:165-176).  a, b, c < i, so the recurrence is a DAG whose depth is only ~3.5*sqrt(n)
+// (158 levels for the 2 112-vertex C4 unit).  Barrier-free dataflow inside one DELTA_THREADS-wide
+// workgroup per (blob, attribute): thread t owns vertices t, t+DELTA_THREADS, ...; it spins on the "fired" flags of the
+// three vertices its current vertex is predicted from, fires (updates all N components), publishes its own flag
+// and moves to its next vertex.  The lowest unfired vertex is always ready, so the sweep cannot stall, and the
+// critical path is ~depth x (two LDS round trips) instead of nvert serial steps.  Values and flags live in LDS
+// when they fit (dynamic LDS = values | flags), else in HBM (workgroup-scope release/acquire; one CU's waves
+// share its L1).
+constexpr uint32_t DELTA_THREADS = 1024;
+
+template <typename T, typename VPtr, typename FPtr>
+__device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t N, bool para) {
+	uint32_t i = threadIdx.x == 0 ? DELTA_THREADS : threadIdx.x;
+	// prediction triples are fetched ONE VERTEX AHEAD: a fetch in the fire path would park the whole wave on an
+	// HBM/L2 round trip while its other lanes are ready to fire.
+	uint32_t na = 0, nb = 0, nc = 0;
+	auto prefetch = [&](uint32_t j) {
+		if(j < nvert) { na = pred[(size_t)j*3]; nb = na; nc = na; if(para) { nb = pred[(size_t)j*3 + 1]; nc = pred[(size_t)j*3 + 2]; } }
+	};
+	prefetch(i);
+	uint32_t a = na, b = nb, c = nc;
+	prefetch(i + DELTA_THREADS);
+	bool valid = a < i && b < i && c < i;                            // well-formed streams always predict from earlier vertices
+	if(!valid) a = b = c = 0;                                        // vertex 0 is fired from the start
+	// ONE loop, test-and-fire in the same iteration: a lane that spun in an inner wait loop would keep the lanes it is
+	// waiting for (same wave) parked at the reconvergence point - the classic SIMT spin deadlock.
+	while(i < nvert) {
+		const uint32_t ready = __hip_atomic_load(&fired[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
+		                       __hip_atomic_load(&fired[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
+		                       __hip_atomic_load(&fired[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if(ready) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			if(valid) {
+				if(para) for(uint32_t k = 0; k < N; k++) v[(size_t)i*N + k] = (T)(v[(size_t)i*N + k] + v[(size_t)a*N + k] + v[(size_t)b*N + k] - v[(size_t)c*N + k]);
+				else for(uint32_t k = 0; k < N; k++) v[(size_t)i*N + k] = (T)(v[(size_t)i*N + k] + v[(size_t)a*N + k]);
 			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__hip_atomic_store(&fired[i], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			i += DELTA_THREADS;
+			a = na; b = nb; c = nc;
+			valid = a < i && b < i && c < i;
+			if(!valid) a = b = c = 0;
+			prefetch(i + DELTA_THREADS);
 		}
+		if(!__any(ready)) __builtin_amdgcn_s_sleep(4);                 // nothing to do in this wave: leave the issue slots to the waves that fire
 	}
 }
 
-__global__ __launch_bounds__(64) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs, uint32_t lds_bytes) {
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs, uint32_t lds_bytes) {
 	if(blockIdx.x >= njobs) return;
 	const DeltaJob J = jobs[blockIdx.x];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const size_t bytes = (size_t)J.nvert*J.N*(J.is_u8 ? 1 : 4);
-	const uint32_t lane = lane_id();
-	if(bytes <= lds_bytes && (bytes & 3) == 0 && (((uintptr_t)J.values) & 3) == 0) {
+	const size_t vbytes = (bytes + 15) & ~(size_t)15;
+	const bool in_lds = vbytes + J.nvert <= lds_bytes;                // the host plans with the same rule (batch.cpp)
+	CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
+	if(in_lds) {
 		CRT_LDS uint32_t *l32 = (CRT_LDS uint32_t *)as_lds(lds);
+		CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)l32;
+		CRT_LDS uint8_t *fired = l8 + vbytes;
 		CRT_GLOBAL uint32_t *g32 = as_global((uint32_t *)J.values);
-		const uint32_t ndw = (uint32_t)(bytes >> 2);
-		for(uint32_t i = lane; i < ndw; i += 64) l32[i] = g32[i];
+		CRT_GLOBAL uint8_t *g8 = as_global((uint8_t *)J.values);
+		const bool al = (((uintptr_t)J.values) & 3) == 0;
+		const uint32_t ndw = al ? (uint32_t)(bytes >> 2) : 0u;            // dword body + byte tail (3-component colours: odd sizes)
+		for(uint32_t i = threadIdx.x; i < ndw; i += DELTA_THREADS) l32[i] = g32[i];
+		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += DELTA_THREADS) l8[i] = g8[i];
+		for(uint32_t i = threadIdx.x; i < J.nvert; i += DELTA_THREADS) fired[i] = i == 0;
 		__syncthreads();
-		if(J.is_u8) delta_chain<uint8_t>((CRT_LDS uint8_t *)l32, as_global(J.pred), J.nvert, J.N, J.parallelogram);
-		else delta_chain<uint32_t>(l32, as_global(J.pred), J.nvert, J.N, J.parallelogram);
+		if(J.is_u8) delta_dataflow<uint8_t>(l8, fired, pred, J.nvert, J.N, J.parallelogram);
+		else delta_dataflow<uint32_t>(l32, fired, pred, J.nvert, J.N, J.parallelogram);
 		__syncthreads();
-		for(uint32_t i = lane; i < ndw; i += 64) g32[i] = l32[i];
+		for(uint32_t i = threadIdx.x; i < ndw; i += DELTA_THREADS) g32[i] = l32[i];
+		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += DELTA_THREADS) g8[i] = l8[i];
 	} else {
-		if(J.is_u8) delta_chain<uint8_t>(as_global((uint8_t *)J.values), as_global(J.pred), J.nvert, J.N, J.parallelogram);
-		else delta_chain<uint32_t>(as_global((uint32_t *)J.values), as_global(J.pred), J.nvert, J.N, J.parallelogram);
+		CRT_GLOBAL uint8_t *fired = as_global(J.fired);                // zero-filled by the host
+		if(threadIdx.x == 0) __hip_atomic_store(&fired[0], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__syncthreads();
+		if(J.is_u8) delta_dataflow<uint8_t>(as_global((uint8_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram);
+		else delta_dataflow<uint32_t>(as_global((uint32_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram);
 	}
 }
 
