@@ -236,9 +236,10 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 //     stream are validated; the symbol array is padded with an invalid symbol so running off its end fails
 //     without a per-step bounds test.  Symbols are fetched four at a time.
 // Layout (dynamic LDS): rec[cap+4] (16 B) | order[cap+4] (u16) | delayed[cap+4] (u16) | clers[nclers+64] (u8)
-__global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;
-	const TopoJob J = jobs[job_ids[blockIdx.x]];
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+template <bool U16>
+__device__ __forceinline__ void topo_lds_body(const TopoJob &J) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const uint32_t cap4 = J.front_cap + 4, qbytes = ((cap4*2 + 15) & ~15u);
 	CRT_LDS u32x4 *rec = (CRT_LDS u32x4 *)as_lds(lds);
@@ -253,9 +254,8 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 	if(threadIdx.x != 0) return;
 
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
-	CRT_GLOBAL uint32_t *pred = as_global(J.pred);
-	CRT_GLOBAL uint32_t *f32 = J.faces_u16 ? nullptr : as_global((uint32_t *)J.faces);
-	CRT_GLOBAL uint16_t *f16 = J.faces_u16 ? as_global((uint16_t *)J.faces) : nullptr;
+	CRT_GLOBAL uint32_t *predp = as_global(J.pred);                    // bumped by 3 per new vertex (vertices are numbered in creation order)
+	CRT_GLOBAL uint8_t *facep = as_global((uint8_t *)J.faces);          // bumped by 3 indices per face
 	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
 	const uint32_t cap = J.front_cap, nvert = J.nvert;
 	const uint32_t splitbits = 32 - __clz(nvert | 1u);
@@ -265,8 +265,9 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
 
 #define TOPO_BITS(dst, n) do { if(bit + (n) > bit_end) { err = 1; dst = 0; } else { dst = bit_field(split, J.split_nwords, bit, (n)); bit += (n); } } while(0)
-#define TOPO_FACE(a, b, c) do { if(f16) { f16[start] = (uint16_t)(a); f16[start + 1] = (uint16_t)(b); f16[start + 2] = (uint16_t)(c); } \
-	else { f32[start] = (a); f32[start + 1] = (b); f32[start + 2] = (c); } start += 3; } while(0)
+#define TOPO_FACE(a, b, c) do { if(U16) { CRT_GLOBAL uint16_t *h_ = (CRT_GLOBAL uint16_t *)facep; h_[0] = (uint16_t)(a); h_[1] = (uint16_t)(b); h_[2] = (uint16_t)(c); facep += 6; } \
+	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)facep = f_; facep += 12; } start += 3; } while(0)
+#define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)predp = p_; predp += 3; } while(0)
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a) | ((b) << 16); t_.y = (c); t_.z = (p) | ((n) << 16); t_.w = 0; rec[e] = t_; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFFu; sw >>= 8; cler++; if((cler & 3u) == 0) { sw = swn; swn = cl32[(cler >> 2) + 1]; } } while(0)
 #define TOPO_MATERIALISE() do { if(lazy) { TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
@@ -292,8 +293,7 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 					if(mask & (1u << k)) { TOPO_BITS(v, splitbits); v &= 0xFFFFu; }
 					else {
 						if(vc >= nvert) { err = 1; break; }
-						CRT_GLOBAL uint32_t *p = pred + (size_t)vc*3;
-						p[0] = last; p[1] = last; p[2] = last;
+						TOPO_PRED(last, last, last);
 						last = v = vc++;
 					}
 					vi[k] = v;
@@ -322,8 +322,7 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 				if(c == C_VERTEX) {                                    // decoder.cpp:294-309
 					if(vc >= nvert || ne + 2 > cap) { err = 1; break; }
 					const uint32_t opp = vc++;
-					CRT_GLOBAL uint32_t *p = pred + (size_t)opp*3;
-					p[0] = v1; p[1] = v0; p[2] = v2;
+					TOPO_PRED(v1, v0, v2);
 					TOPO_FACE(v1, v0, opp);
 					rec16[en*8 + 4] = (uint16_t)(ne + 1);              // front[e.next].prev = new_edge + 1
 					order[norder++] = (uint16_t)(ne + 1);
@@ -390,10 +389,17 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 	}
 #undef TOPO_BITS
 #undef TOPO_FACE
+#undef TOPO_PRED
 #undef TOPO_PUT
 #undef TOPO_SYMBOL
 #undef TOPO_MATERIALISE
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
+}
+
+__global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const TopoJob J = jobs[job_ids[blockIdx.x]];
+	if(J.faces_u16) topo_lds_body<true>(J); else topo_lds_body<false>(J);
 }
 
 // ------------------------------------------------------------------------------------------------
