@@ -149,6 +149,8 @@ struct KernelTimer {
 struct crthip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr;  // attribute streams (Tunstall + bit-unpack) run here while the main stream does topology
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
 	PinnedBuf staging;        // host image of the job arrays
 	PinnedBuf status_host;
@@ -196,7 +198,10 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	HIP_TRY(hipSetDevice(device));
 	crthip_ctx *c = new crthip_ctx();
 	c->device = device;
-	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+	   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+	   hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
 	*out = c;
 	return CRTHIP_OK;
 }
@@ -207,6 +212,9 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	(void)hipStreamSynchronize(c->stream);
 	c->timer.release();
 	c->scratch.release(); c->staging.release(); c->status_host.release();
+	(void)hipStreamSynchronize(c->stream2);
+	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
+	(void)hipStreamDestroy(c->stream2);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -367,16 +375,18 @@ static const uint32_t DELTA_LDS_MAX = 64*1024;
 
 struct Launch {
 	crthip_ctx *ctx;
-	void begin(const char *name) {
+	hipStream_t cur = nullptr;
+	void begin(const char *name, hipStream_t s = nullptr) {
+		cur = s ? s : ctx->stream;
 		if(!ctx->profiling) return;
 		hipEvent_t e = ctx->timer.get();
-		(void)hipEventRecord(e, ctx->stream);
+		(void)hipEventRecord(e, cur);
 		ctx->timer.recs.push_back({name, ctx->timer.used - 1, 0});
 	}
 	void end() {
 		if(!ctx->profiling) return;
 		hipEvent_t e = ctx->timer.get();
-		(void)hipEventRecord(e, ctx->stream);
+		(void)hipEventRecord(e, cur);
 		ctx->timer.recs.back().e1 = ctx->timer.used - 1;
 	}
 };
@@ -499,6 +509,15 @@ static int build_and_launch(crthip_batch *b) {
 		return SP(sym_off);
 	};
 
+	// the CLERS streams come first in every stream/chunk/fill array: they are what the topology kernel waits for, the
+	// attribute streams are decoded on the second HIP stream while topology runs
+	std::vector<const uint8_t *> clers_ptrs(nblobs, nullptr);
+	for(uint32_t i = 0; i < nblobs; i++) {
+		const BlobLayout &L = b->blobs[i].L;
+		if(L.h.nface > 0) clers_ptrs[i] = add_stream(L.clers, bs[i].clers, b->blobs[i].arena_off);
+	}
+	const uint32_t clers_tun = (uint32_t)pl.tun.v.size(), clers_chunks = tun_chunks, clers_fill = (uint32_t)pl.fill.v.size();
+
 	uint32_t est_vbase = 0, est_fbase = 0;
 	for(uint32_t i = 0; i < nblobs; i++) {
 		BlobPlan &P = b->blobs[i];
@@ -509,7 +528,7 @@ static int build_and_launch(crthip_batch *b) {
 		const uint64_t bo = P.arena_off;
 		const uint8_t *clers_ptr = nullptr;
 		if(mesh) {
-			clers_ptr = add_stream(L.clers, S.clers, bo);
+			clers_ptr = clers_ptrs[i];
 			P.clers_in_arena = L.clers.mode == STREAM_RAW;
 			P.dbg_clers = L.clers.mode == STREAM_RAW ? bo + L.clers.payload_off : S.clers;
 			P.dbg_nclers = L.clers.size; P.dbg_pred = S.pred;
@@ -700,29 +719,57 @@ static int build_and_launch(crthip_batch *b) {
 	uint64_t *cloud_partial = (uint64_t *)(base + pl.cloud_partial_off);
 
 	const uint32_t ntun = (uint32_t)pl.tun.v.size();
-	if(ntun) {
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables); LT.end();
-		if(pl.tun_multi_chunk) {
-			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial); LT.end();
-			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks); LT.end();
+	const uint32_t nfill = (uint32_t)pl.fill.v.size();
+	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
+		if(t1 > t0) {
+			LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables); LT.end();
+			LT.begin("tunstall_decode", s); hipLaunchKernelGGL(k_tun_decode, dim3(c1 - c0), dim3(256), 0, s, D(pl.tun), D(pl.tun_chunk_stream), c1 - c0, tables, TUN_CHUNK_CODES, tun_partial, c0); LT.end();
 		}
-		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial); LT.end();
-	}
-	if(!pl.fill.v.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)pl.fill.v.size()), dim3(256), 0, st, D(pl.fill), (uint32_t)pl.fill.v.size()); LT.end(); }
-	if(!pl.topo_lds_ids.v.empty()) {
-		static uint32_t lds_attr = 0;                      // raise the dynamic-LDS limit once per size class
-		if(pl.topo_lds > lds_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX)); lds_attr = TOPO_LDS_MAX; }
-		const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size();
-		LT.begin("topology_lds"); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); LT.end();
-	}
-	if(!pl.topo_glob_ids.v.empty()) {
-		const uint32_t nj = (uint32_t)pl.topo_glob_ids.v.size();
-		LT.begin("topology"); hipLaunchKernelGGL(k_topology, dim3(nj), dim3(64), 0, st, D(pl.topo), D(pl.topo_glob_ids), nj); LT.end();
-	}
-	if(unpack_chunks) {
-		LT.begin("unpack_sums"); hipLaunchKernelGGL(k_unpack_sums, dim3(unpack_chunks), dim3(256), 0, st, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
-		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, unpack_partial, unpack_chunks); LT.end();
-		LT.begin("unpack_extract"); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, st, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
+		if(f1 > f0) { LT.begin("fill", s); hipLaunchKernelGGL(k_fill, dim3(f1 - f0), dim3(256), 0, s, D(pl.fill) + f0, f1 - f0); LT.end(); }
+	};
+	auto unpack = [&](hipStream_t s) {
+		if(!unpack_chunks) return;
+		LT.begin("unpack_sums", s); hipLaunchKernelGGL(k_unpack_sums, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
+		LT.begin("scan", s); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, unpack_partial, unpack_chunks); LT.end();
+		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
+	};
+	auto topology = [&]() -> int {
+		if(!pl.topo_lds_ids.v.empty()) {
+			static uint32_t lds_attr = 0;                      // raise the dynamic-LDS limit once
+			if(pl.topo_lds > lds_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX)); lds_attr = TOPO_LDS_MAX; }
+			const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size();
+			LT.begin("topology_lds"); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); LT.end();
+		}
+		if(!pl.topo_glob_ids.v.empty()) {
+			const uint32_t nj = (uint32_t)pl.topo_glob_ids.v.size();
+			LT.begin("topology"); hipLaunchKernelGGL(k_topology, dim3(nj), dim3(64), 0, st, D(pl.topo), D(pl.topo_glob_ids), nj); LT.end();
+		}
+		return CRTHIP_OK;
+	};
+	if(pl.tun_multi_chunk) {
+		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables); LT.end();
+		LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial, 0u); LT.end();
+		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks); LT.end();
+		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial, 0u); LT.end();
+		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
+		{ int e_ = topology(); if(e_) return e_; }
+		unpack(st);
+	} else if(!pl.topo.v.empty() && (ntun > clers_tun || nfill > clers_fill || unpack_chunks)) {
+		// fork: attribute streams on stream2, CLERS + topology on the main stream
+		hipStream_t s2 = ctx->stream2;
+		HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+		tunstall(st, 0, clers_tun, 0, clers_chunks, 0, clers_fill);
+		{ int e_ = topology(); if(e_) return e_; }
+		tunstall(s2, clers_tun, ntun, clers_chunks, tun_chunks, clers_fill, nfill);
+		unpack(s2);
+		HIP_TRY(hipEventRecord(ctx->ev_join, s2));
+		HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+	} else {
+		tunstall(st, 0, ntun, 0, tun_chunks, 0, nfill);
+		{ int e_ = topology(); if(e_) return e_; }
+		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
 		LT.begin("delta_mesh");
@@ -953,10 +1000,10 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	if(ntun) {
 		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables); LT.end();
 		if(multi) {
-			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part); LT.end();
+			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u); LT.end();
 			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks); LT.end();
 		}
-		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part); LT.end();
+		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u); LT.end();
 	}
 	if(!fills.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)fills.size()), dim3(256), 0, st, (FillJob *)(base + o_fill), (uint32_t)fills.size()); LT.end(); }
 	HIP_TRY(hipGetLastError());

@@ -168,9 +168,9 @@ __device__ __forceinline__ void tun_load_table(TunLds &L, const TunTable &T, uin
 // pass A: per-chunk decoded byte count
 __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                         uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                        uint32_t chunk_codes, uint64_t *__restrict__ chunk_out) {
-	const uint32_t c = blockIdx.x;
-	if(c >= nchunks) return;
+                                                        uint32_t chunk_codes, uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+	const uint32_t c = blockIdx.x + chunk_base;
+	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
 	const TunTable &T = tables[st.table];
 	__shared__ uint8_t len[256];
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restr
 // pass B: decode one chunk.  chunk_out[c] (after the scan) - chunk_out[st.chunk0] = output offset.
 __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                     uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                    uint32_t chunk_codes, const uint64_t *__restrict__ chunk_out) {
-	const uint32_t c = blockIdx.x;
-	if(c >= nchunks) return;
+                                                    uint32_t chunk_codes, const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+	const uint32_t c = blockIdx.x + chunk_base;
+	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
 	const TunTable &T = tables[st.table];
 	__shared__ TunLds L;
