@@ -5,7 +5,7 @@
 
 namespace corto_hip {
 
-constexpr uint32_t TUN_TABLE_BYTES = 8192 + 512;   // reference buffer is 8192 B (src/tunstall.cpp:137)
+constexpr uint32_t TUN_TABLE_BYTES = 8192 + 1024;  // reference buffer is 8192 B (src/tunstall.cpp:137); +3 B padding per word
 constexpr uint32_t TUN_ENTRY_CAP = 768;            // creation-order entries; the reference reaches <= 510
 constexpr uint32_t CHUNK = 1024;                   // elements per scan chunk (256 threads x 4)
 

@@ -12,9 +12,13 @@
 // K-TUN: decode = exclusive scan of word lengths + gather.  Every workgroup stages the stream's
 //        table in LDS (<= 9 KiB), reads codewords coalesced, scans lengths wave/block-wide and
 //        emits the words.
+#include <type_traits>
+
 #include "kernels_common.h"
 
 namespace corto_hip {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // K-TAB
@@ -188,7 +192,77 @@ __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restr
 	if(threadIdx.x == 0) chunk_out[c] = (uint64_t)red[0] + red[1] + red[2] + red[3];
 }
 
-// pass B: decode one chunk.  chunk_out[c] (after the scan) - chunk_out[st.chunk0] = output offset.
+// Emit one thread's run (its up-to-4 words back to back) at byte pointer d.  Table words are read as ALIGNED dwords
+// (v_alignbyte shifts out the word's byte phase) into a 64-bit byte FIFO; the run is written as <=3 head bytes (up to the next 4-aligned destination address),
+// aligned dwords, and <=3 tail bytes: no unaligned accesses (on gfx950 those stall the LDS pipeline ~70 % of the time, PMC
+// SQ_LDS_UNALIGNED_STALL) and no overlap with the neighbouring threads' runs.
+template <typename DPtr>
+__device__ __forceinline__ void tun_emit_run(DPtr d, uint32_t daddr, CRT_LDS const uint32_t *tab32, const uint32_t (&wo)[4], const uint32_t (&nb)[4]) {
+	typedef typename std::conditional<std::is_same<DPtr, CRT_LDS uint8_t *>::value, CRT_LDS uint32_t, CRT_GLOBAL uint32_t>::type dword_t;
+	// The FIFO starts at the 4-aligned address at or below d with m = d & 3 placeholder bytes (they belong to the previous
+	// thread's run), so that every dword leaves on an aligned address; the first dword is then written byte-wise without
+	// its m placeholder bytes, and the last partial dword byte-wise too.
+	const uint32_t m = daddr & 3u;
+	d -= m;
+	uint32_t lo = 0, na = m;                                   // lo holds na (< 4) pending bytes
+	bool first = m != 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) {
+		if(nb[k] == 0) continue;
+		CRT_LDS const uint32_t *src = tab32 + (wo[k] >> 2);
+		const uint32_t sh = wo[k] & 3u;                        // words keep the reference's shared-suffix layout: any byte offset
+		uint32_t prev = *src++;
+		for(uint32_t i = 0; i < nb[k]; i += 4) {
+			const uint32_t next = *src++;
+			uint32_t dw = __builtin_amdgcn_alignbyte(next, prev, sh);
+			prev = next;
+			const uint32_t vb = min(4u, nb[k] - i);
+			if(vb < 4) dw &= (1u << (8*vb)) - 1u;
+			const uint32_t full = lo | (dw << (8*na));          // na < 4
+			if(na + vb >= 4) {
+				if(first) { for(uint32_t b = m; b < 4; b++) d[b] = (uint8_t)(full >> (8*b)); first = false; }
+				else *(dword_t *)d = full;
+				d += 4;
+				lo = na ? dw >> (32 - 8*na) : 0u;
+				na = na + vb - 4;
+			} else { lo = full; na += vb; }
+		}
+	}
+	for(uint32_t b = first ? m : 0u; b < na; b++) d[b] = (uint8_t)(lo >> (8*b));
+}
+
+// shared front half of a tile: codes -> lengths -> block scan -> clipped byte counts
+struct TunTile { uint32_t wo[4], nb[4], l[4]; uint32_t total; uint64_t o; };
+
+__device__ __forceinline__ void tun_tile_prepare(TunTile &t, const TunStream &st, CRT_GLOBAL const uint8_t *src, uint32_t tile, uint32_t last,
+                                                 uint64_t base, CRT_LDS const uint8_t *len8, CRT_LDS const uint16_t *off16, uint32_t *scan) {
+	const uint32_t j0 = tile + 4*threadIdx.x;
+	uint32_t code[4], sum = 0;
+#pragma unroll
+	for(int k = 0; k < 4; k++) {
+		const bool ok = j0 + k < last;
+		code[k] = ok ? (uint32_t)src[j0 + k] : 0u;
+		t.l[k] = ok ? (uint32_t)len8[code[k]] : 0u;
+		sum += t.l[k];
+	}
+	t.o = base + block256_exclusive_scan<uint32_t>(sum, scan, &t.total);
+	const uint64_t size = st.size;
+	uint64_t oo = t.o;
+#pragma unroll
+	for(int k = 0; k < 4; k++) {                       // every word whole; the stream's last codeword emits what is left (tunstall.cpp:447-451)
+		uint32_t nb = t.l[k];
+		t.wo[k] = off16[code[k]];
+		if(j0 + k < last) {
+			if(j0 + k + 1 == st.csize) nb = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - t.wo[k]), size - oo) : 0u;
+			else if(oo + nb > size) nb = oo < size ? (uint32_t)(size - oo) : 0u;
+		} else nb = 0;
+		t.nb[k] = nb;
+		oo += t.l[k];
+	}
+}
+
+// pass B, short streams (the .crt case: one chunk, a few KiB): small LDS footprint so that it can run next to the
+// LDS-hungry topology kernel; runs are written straight to HBM.
 __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                     uint32_t nchunks, const TunTable *__restrict__ tables,
                                                     uint32_t chunk_codes, const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
@@ -199,39 +273,71 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 	__shared__ TunLds L;
 	tun_load_table(L, T, T.used);
 	__syncthreads();
+	const uint32_t first = (c - st.chunk0)*chunk_codes;
+	const uint32_t last = min(first + chunk_codes, st.csize);
+	uint64_t base = st.nchunks > 1 ? chunk_out[c] - chunk_out[st.chunk0] : 0;
+	CRT_GLOBAL const uint8_t *src = as_global(st.src);
+	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
+	for(uint32_t tile = first; tile < last; tile += TUN_TILE) {
+		TunTile t;
+		tun_tile_prepare(t, st, src, tile, last, base, as_lds(L.len), as_lds(L.off), L.scan);
+		CRT_GLOBAL uint8_t *d = gdst + t.o;
+		tun_emit_run(d, (uint32_t)(uintptr_t)d, (CRT_LDS const uint32_t *)as_lds(L.bytes), t.wo, t.nb);
+		base += t.total;
+	}
+}
 
+// pass B, long streams: each tile's bytes are staged in LDS at the destination's 16-byte phase and flushed with coalesced
+// 16-byte stores (full cache lines to HBM instead of 64 scattered partial lines per store instruction).
+constexpr uint32_t TUN_OUTBUF = 16*1024;
+
+__global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
+                                                           uint32_t nchunks, const TunTable *__restrict__ tables,
+                                                           uint32_t chunk_codes, const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+	const uint32_t c = blockIdx.x + chunk_base;
+	if(blockIdx.x >= nchunks) return;
+	const TunStream st = streams[chunk_stream[c]];
+	const TunTable &T = tables[st.table];
+	__shared__ TunLds L;
+	__shared__ __attribute__((aligned(16))) uint8_t outbuf[TUN_OUTBUF + 32];
+	tun_load_table(L, T, T.used);
+	__syncthreads();
 	const uint32_t first = (c - st.chunk0)*chunk_codes;
 	const uint32_t last = min(first + chunk_codes, st.csize);
 	uint64_t base = st.nchunks > 1 ? chunk_out[c] - chunk_out[st.chunk0] : 0;
 	const uint64_t size = st.size;
-	const uint8_t *__restrict__ src = st.src;
-	uint8_t *__restrict__ dst = st.dst;
-
+	CRT_GLOBAL const uint8_t *src = as_global(st.src);
+	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
+	const uint32_t tid = threadIdx.x;
 	for(uint32_t tile = first; tile < last; tile += TUN_TILE) {
-		const uint32_t j0 = tile + 4*threadIdx.x;
-		uint32_t code[4], l[4], sum = 0;
-#pragma unroll
-		for(int k = 0; k < 4; k++) {
-			const bool ok = j0 + k < last;
-			code[k] = ok ? src[j0 + k] : 0u;
-			l[k] = ok ? L.len[code[k]] : 0u;
-			sum += l[k];
+		TunTile t;
+		tun_tile_prepare(t, st, src, tile, last, base, as_lds(L.len), as_lds(L.off), L.scan);
+		// bytes this tile really writes (clipped at the stream's declared size / extended by its last codeword)
+		const bool has_last = tile + TUN_TILE >= st.csize;
+		const uint64_t endo = has_last ? size : min(size, base + t.total);
+		const uint64_t tb64 = endo > base ? endo - base : 0;
+		if(tb64 <= TUN_OUTBUF) {
+			const uint32_t n = (uint32_t)tb64;
+			CRT_GLOBAL uint8_t *g0 = gdst + base;
+			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
+			CRT_LDS uint8_t *out = as_lds(outbuf) + phase;
+			CRT_LDS uint8_t *d = out + (uint32_t)(t.o - base);
+			tun_emit_run(d, (uint32_t)(uintptr_t)d, (CRT_LDS const uint32_t *)as_lds(L.bytes), t.wo, t.nb);
+			__syncthreads();
+			const uint32_t head = min((16u - phase) & 15u, n);
+			if(tid < head) g0[tid] = out[tid];
+			const uint32_t nvec = (n - head) >> 4;
+			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 + head);
+			CRT_LDS const u32x4_t *lv = (CRT_LDS const u32x4_t *)(out + head);
+			for(uint32_t i = tid; i < nvec; i += 256) gv[i] = lv[i];
+			const uint32_t tail0 = head + (nvec << 4);
+			if(tail0 + tid < n) g0[tail0 + tid] = out[tail0 + tid];
+			__syncthreads();
+		} else {                                         // very long words (low-entropy streams): straight to HBM
+			CRT_GLOBAL uint8_t *d = gdst + t.o;
+			tun_emit_run(d, (uint32_t)(uintptr_t)d, (CRT_LDS const uint32_t *)as_lds(L.bytes), t.wo, t.nb);
 		}
-		uint32_t total;
-		uint64_t o = base + block256_exclusive_scan<uint32_t>(sum, L.scan, &total);
-#pragma unroll
-		for(int k = 0; k < 4; k++) {
-			if(j0 + k < last) {
-				// every word is copied whole; the stream's last codeword emits whatever is left (tunstall.cpp:447-451)
-				uint32_t nb = l[k];
-				const uint32_t wo = L.off[code[k]];
-				if(j0 + k + 1 == st.csize) nb = o < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo), size - o) : 0u;
-				else if(o + nb > size) nb = o < size ? (uint32_t)(size - o) : 0u;
-				for(uint32_t b = 0; b < nb; b++) dst[o + b] = L.bytes[wo + b];
-				o += l[k];
-			}
-		}
-		base += total;
+		base += t.total;
 	}
 }
 

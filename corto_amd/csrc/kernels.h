@@ -12,6 +12,8 @@ __global__ void k_tun_chunk_sums(const TunStream *streams, const uint32_t *chunk
                                  uint32_t chunk_codes, uint64_t *chunk_out, uint32_t chunk_base);
 __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                              uint32_t chunk_codes, const uint64_t *chunk_out, uint32_t chunk_base);
+__global__ void k_tun_decode_staged(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                                    uint32_t chunk_codes, const uint64_t *chunk_out, uint32_t chunk_base);
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
 
 // k_stream.hip
