@@ -355,7 +355,8 @@ struct Plan {
 	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
 	HostArr<DeltaJob> delta;
 	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
-	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first;
+	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first, normal_fused_ids;
+	uint32_t normal_fused_lds = 0;
 	HostArr<DequantJob> dequant; HostArr<uint32_t> dequant_block_job;
 	// scratch regions (offsets)
 	uint64_t zero_begin = 0, zero_end = 0;
@@ -372,6 +373,7 @@ struct Plan {
 
 
 static const uint32_t DELTA_LDS_MAX = 64*1024;
+static bool normal_fused(uint32_t nvert, uint32_t nface) { return nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
 struct Launch {
 	crthip_ctx *ctx;
@@ -416,7 +418,7 @@ static int build_and_launch(crthip_batch *b) {
 		const BlobLayout &L = P.L;
 		if(L.h.nface == 0) continue;
 		for(size_t k = 0; k < L.attrs.size(); k++)
-			if(L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && L.attrs[k].normal_prediction != 0) { est_v += L.h.nvert; est_f += L.h.nface; }
+			if(L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && L.attrs[k].normal_prediction != 0 && !normal_fused(L.h.nvert, L.h.nface)) { est_v += L.h.nvert; est_f += L.h.nface; }
 	}
 	pl.zero_begin = cv.take(0);
 	pl.status_off = cv.take((uint64_t)nblobs*4);
@@ -621,9 +623,15 @@ static int build_and_launch(crthip_batch *b) {
 						const bool pos_ok = pos_k >= 0 && L.h.attrs[pos_k].codec == CRTHIP_CODEC_GENERIC && L.h.attrs[pos_k].N == 3 && P.bind[pos_k].buffer;
 						if(!pos_ok) { P.host_status = CRTHIP_E_NORMAL_NEEDS_POSITION; continue; }
 						n.position = (const int32_t *)P.bind[pos_k].buffer;
-						n.faces = P.index ? P.index : (void *)SP(S.faces); n.faces_u16 = P.index ? P.index_u16 : 0; n.pad = P.index ? 1 : 0;
-						n.vbase = est_vbase; n.fbase = est_fbase; est_vbase += nvert; est_fbase += nface;
-						pl.any_est_normal = true;
+						n.faces = P.index ? P.index : (void *)SP(S.faces); n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0));   // bit7: faces is a real pointer (cleared at fixup)
+						if(normal_fused(nvert, nface)) {
+							n.fused = 1;
+							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
+							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds(nvert, nface));
+						} else {
+							n.vbase = est_vbase; n.fbase = est_fbase; est_vbase += nvert; est_fbase += nface;
+							pl.any_est_normal = true;
+						}
 					} else pl.any_diff_normal = true;
 					pl.normal.v.push_back(n);
 				}
@@ -647,7 +655,7 @@ static int build_and_launch(crthip_batch *b) {
 		pl.nv_block_first.v.push_back((uint32_t)pl.nv_block_job.v.size());
 		for(uint32_t c = 0; c < (n.nvert + 255)/256; c++) pl.nv_block_job.v.push_back(j);
 		pl.nf_block_first.v.push_back((uint32_t)pl.nf_block_job.v.size());
-		if(n.prediction != 0) for(uint32_t c = 0; c < (n.nface + 255)/256; c++) pl.nf_block_job.v.push_back(j);
+		if(n.prediction != 0 && !n.fused) for(uint32_t c = 0; c < (n.nface + 255)/256; c++) pl.nf_block_job.v.push_back(j);
 	}
 
 	pl.tun_partial_off = cv.take(((uint64_t)tun_chunks + 1)*8);
@@ -659,7 +667,7 @@ static int build_and_launch(crthip_batch *b) {
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
 	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
-	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.dequant); place(pl.dequant_block_job);
+	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.normal_fused_ids); place(pl.dequant); place(pl.dequant_block_job);
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
 	pl.total = cv.take(0);
 
@@ -693,8 +701,8 @@ static int build_and_launch(crthip_batch *b) {
 	for(auto &c : pl.cloud.v) { if(!c.pad[0]) c.values = R(c.values); c.pad[0] = 0; }
 	for(auto &n : pl.normal.v) {
 		n.diffs = (int32_t *)R(n.diffs); n.status = (int32_t *)R(n.status);
-		if(n.prediction != 0 && !n.pad) n.faces = R(n.faces);
-		n.pad = 0;
+		if(n.prediction != 0 && !(n.faces_u16 & 0x80)) n.faces = R(n.faces);
+		n.faces_u16 &= 0x7F;
 	}
 	for(auto &q : pl.dequant.v) if(q.is_color) q.color_src = R(q.color_src);
 	for(auto &P : b->blobs) { (void)P; }
@@ -704,7 +712,7 @@ static int build_and_launch(crthip_batch *b) {
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
 	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
 	put(pl.delta); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
-	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.dequant); put(pl.dequant_block_job);
+	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
 	hipStream_t st = ctx->stream;
 	ctx->timer.reset();
@@ -782,6 +790,12 @@ static int build_and_launch(crthip_batch *b) {
 		LT.begin("cloud_apply"); hipLaunchKernelGGL(k_cloud_apply, dim3(cloud_chunks), dim3(256), 0, st, D(pl.cloud), D(pl.cloud_chunk_job), cloud_chunks, cloud_partial); LT.end();
 	}
 	const uint32_t nvb = (uint32_t)pl.nv_block_job.v.size(), nfb = (uint32_t)pl.nf_block_job.v.size();
+	if(!pl.normal_fused_ids.v.empty()) {
+		static uint32_t nl_attr = 0;
+		if(pl.normal_fused_lds > nl_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_normal_blob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NORMAL_LDS_MAX)); nl_attr = NORMAL_LDS_MAX; }
+		const uint32_t nj = (uint32_t)pl.normal_fused_ids.v.size();
+		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), pl.normal_fused_lds, st, D(pl.normal), D(pl.normal_fused_ids), nj); LT.end();
+	}
 	if(pl.any_est_normal) {
 		float *facen = (float *)(base + pl.facen_off);
 		uint32_t *cnt = (uint32_t *)(base + pl.cnt_off), *cursor = (uint32_t *)(base + pl.cursor_off), *bnd = (uint32_t *)(base + pl.bnd_off);

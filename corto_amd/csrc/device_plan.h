@@ -91,7 +91,7 @@ struct NormalJob {
 	uint32_t nvert, nface, ndiffs;
 	uint32_t vbase, fbase;         // offsets into the batch-wide per-vertex / per-face scratch arrays
 	int32_t unit;                  // (int)q
-	uint8_t prediction, out_i16, faces_u16, pad;
+	uint8_t prediction, out_i16, faces_u16, fused;   // fused: handled by k_normal_blob (whole pipeline in one workgroup)
 	int32_t *status;
 };
 

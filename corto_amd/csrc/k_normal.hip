@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_normal_flags(const NormalJob *__restric
                                                       const uint32_t *__restrict__ bnd, uint32_t *__restrict__ flag) {
 	if(blockIdx.x >= nblocks) return;
 	const NormalJob J = jobs[block_job[blockIdx.x]];
-	if(J.prediction == 0) return;                       // DIFF jobs own no slice of the per-vertex scratch
+	if(J.prediction == 0 || J.fused) return;            // DIFF / fused jobs own no slice of the per-vertex scratch
 	const uint32_t i = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
 	if(i >= J.nvert) return;
 	flag[J.vbase + i] = (J.prediction == 1 || bnd[J.vbase + i] != 0) ? 1u : 0u;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
                                                        const uint32_t *__restrict__ flag, const uint32_t *__restrict__ slot) {
 	if(blockIdx.x >= nblocks) return;
 	const NormalJob J = jobs[block_job[blockIdx.x]];
-	if(J.prediction == 0) return;
+	if(J.prediction == 0 || J.fused) return;
 	const uint32_t i = (blockIdx.x - block_first[block_job[blockIdx.x]])*256 + threadIdx.x;
 	if(i >= J.nvert) return;
 	const uint32_t g = J.vbase + i;
@@ -184,6 +184,117 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
 		const float len = norm3(ex, ey, ez);
 		float *o = (float *)J.out + (size_t)i*3;
 		o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-blob path: the whole ESTIMATED/BORDER pipeline of one blob in ONE workgroup with every intermediate in LDS
+// (integer positions, incidence counts -> CSR offsets, boundary XORs, adjacency, correction slots), replacing nine
+// batch-wide launches.  Same arithmetic and the same ascending-face-id accumulation order as the kernels above.
+// Dynamic LDS layout: pos[3*nvert] i32 | cnt[nvert+1] | start[nvert+1] | bnd[nvert] | slot[nvert+1] u32 | adj[3*nface] u16
+__host__ __device__ inline uint32_t normal_blob_lds_bytes(uint32_t nvert, uint32_t nface) {
+	return (3*nvert + 4*(nvert + 1))*4 + ((3*nface*2 + 15) & ~15u) + 64;
+}
+
+__global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const NormalJob J = jobs[job_ids[blockIdx.x]];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+	const uint32_t nv = J.nvert, nf = J.nface, tid = threadIdx.x;
+	CRT_LDS int32_t *pos = (CRT_LDS int32_t *)as_lds(lds_raw);
+	CRT_LDS uint32_t *cnt = (CRT_LDS uint32_t *)(pos + 3*nv);
+	CRT_LDS uint32_t *start = cnt + nv + 1;
+	CRT_LDS uint32_t *bnd = start + nv + 1;
+	CRT_LDS uint32_t *slot = bnd + nv;
+	CRT_LDS uint16_t *adj = (CRT_LDS uint16_t *)(slot + nv + 1);
+	__shared__ uint32_t scan_s[4];
+	__shared__ uint32_t carry_s;
+	CRT_GLOBAL const int32_t *gpos = as_global(J.position);
+	CRT_GLOBAL const uint32_t *f32 = J.faces_u16 ? nullptr : as_global((const uint32_t *)J.faces);
+	CRT_GLOBAL const uint16_t *f16 = J.faces_u16 ? as_global((const uint16_t *)J.faces) : nullptr;
+	auto face = [&](uint32_t f, uint32_t &a, uint32_t &b, uint32_t &c) {
+		if(f16) { a = f16[3*(size_t)f]; b = f16[3*(size_t)f + 1]; c = f16[3*(size_t)f + 2]; }
+		else { a = f32[3*(size_t)f]; b = f32[3*(size_t)f + 1]; c = f32[3*(size_t)f + 2]; }
+	};
+	for(uint32_t i = tid; i < 3*nv; i += 256) pos[i] = gpos[i];
+	for(uint32_t i = tid; i <= nv; i += 256) { cnt[i] = 0; if(i < nv) bnd[i] = 0; }
+	__syncthreads();
+	// incidence counts + boundary XOR (markBoundary, normal_attribute.cpp:24-37)
+	bool bad = false;
+	for(uint32_t f = tid; f < nf; f += 256) {
+		uint32_t a, b, c; face(f, a, b, c);
+		if(a >= nv || b >= nv || c >= nv) { bad = true; continue; }
+		atomicAdd((uint32_t *)&cnt[a], 1u); atomicAdd((uint32_t *)&cnt[b], 1u); atomicAdd((uint32_t *)&cnt[c], 1u);
+		if(J.prediction == 2) { atomicXor((uint32_t *)&bnd[a], b ^ c); atomicXor((uint32_t *)&bnd[b], c ^ a); atomicXor((uint32_t *)&bnd[c], a ^ b); }
+	}
+	if(bad) *as_global(J.status) = -5;
+	__syncthreads();
+	// two block-wide exclusive scans over the vertices: CSR offsets of cnt, and correction slots of the flags
+	const uint32_t per = (nv + 255)/256;
+	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint32_t *out, bool flags) {
+		const uint32_t i0 = tid*per;
+		uint32_t s = 0;
+		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; }
+		uint32_t total;
+		uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
+		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { out[i] = o; o += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; } }
+		if(tid == 0) out[nv] = total;
+	};
+	block_scan(cnt, start, false);
+	block_scan(bnd, slot, true);
+	__syncthreads();
+	for(uint32_t i = tid; i < nv; i += 256) cnt[i] = start[i];           // cnt becomes the fill cursor
+	__syncthreads();
+	for(uint32_t f = tid; f < nf; f += 256) {
+		uint32_t v[3]; face(f, v[0], v[1], v[2]);
+		if(v[0] >= nv || v[1] >= nv || v[2] >= nv) continue;
+#pragma unroll
+		for(int k = 0; k < 3; k++) adj[atomicAdd((uint32_t *)&cnt[v[k]], 1u)] = (uint16_t)f;
+	}
+	__syncthreads();
+	// per vertex: ordered accumulation (estimateNormals :40-59) + computeNormals (:281-325)
+	for(uint32_t i = tid; i < nv; i += 256) {
+		const uint32_t s0 = start[i], deg = start[i + 1] - s0;
+		float ex = 0.f, ey = 0.f, ez = 0.f;
+		int32_t last = -1;
+		for(uint32_t done = 0; done < deg;) {
+			uint32_t best = 0xFFFFFFFFu, mult = 0;
+			for(uint32_t k = 0; k < deg; k++) {
+				const uint32_t f = adj[s0 + k];
+				if((int32_t)f > last) { if(f < best) { best = f; mult = 1; } else if(f == best) mult++; }
+			}
+			uint32_t a, b, c; face(best, a, b, c);
+			const CRT_LDS int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
+			const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
+			const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
+			const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;
+			const float nx = ay*bz - az*by, ny = az*bx - ax*bz, nz = ax*by - ay*bx;   // point.h:113-115
+			for(uint32_t m = 0; m < mult; m++) { ex += nx; ey += ny; ez += nz; }
+			last = (int32_t)best; done += mult;
+		}
+		if(J.prediction == 1 || bnd[i] != 0) {
+			const uint32_t sl = slot[i];
+			int32_t qx, qy;
+			to_octa(ex, ey, ez, J.unit, qx, qy);
+			int32_t dx = 0, dy = 0;
+			if(sl < J.ndiffs) { dx = J.diffs[2*(size_t)sl]; dy = J.diffs[2*(size_t)sl + 1]; }
+			int32_t x = (int32_t)((uint32_t)qx + (uint32_t)dx), y = (int32_t)((uint32_t)qy + (uint32_t)dy);
+			if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }
+			float nx, ny, nz;
+			to_sphere(x, y, J.unit, nx, ny, nz);
+			store_normal(J, i, nx, ny, nz);
+		} else if(J.out_i16) {
+			float len = norm3(ex, ey, ez);
+			if(!(len < 0.00001f)) {
+				len = 32767.0f/len;
+				int16_t *o = (int16_t *)J.out + (size_t)i*3;
+				o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
+			}
+		} else {
+			const float len = norm3(ex, ey, ez);
+			float *o = (float *)J.out + (size_t)i*3;
+			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
+		}
 	}
 }
 

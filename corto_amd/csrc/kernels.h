@@ -46,6 +46,10 @@ __global__ void k_normal_vertex(const NormalJob *jobs, const uint32_t *block_job
                                 const float *facen, const uint32_t *start, const uint32_t *cnt, const uint32_t *adj,
                                 const uint32_t *flag, const uint32_t *slot);
 
+__global__ void k_normal_blob(const NormalJob *jobs, const uint32_t *job_ids, uint32_t njobs);
+inline uint32_t normal_blob_lds(uint32_t nvert, uint32_t nface) { return (3*nvert + 4*(nvert + 1))*4 + ((3*nface*2 + 15) & ~15u) + 64; }
+constexpr uint32_t NORMAL_LDS_MAX = 150*1024;
+
 constexpr uint32_t TUN_CHUNK_CODES = 16384;   // codewords per K-TUN workgroup
 
 } // namespace corto_hip
