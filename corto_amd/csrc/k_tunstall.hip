@@ -86,7 +86,49 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	}
 	__syncthreads();
 
-	while(nwords < 256) {                       // tunstall.cpp:207-241
+	if(n <= 64) {
+		// Fast path (n <= 64 symbols, i.e. every stream the encoder really produces): lane r keeps row r's FIFO head
+		// (index, probability, offset, length) in registers, so picking the likeliest head is a register-only wave
+		// reduction and an expansion touches LDS only to append the children.             tunstall.cpp:207-241
+		uint32_t h = lane < n ? head[lane] : 0xFFFFu, hp = 0, ho = 0, hl = 0;
+		if(lane < n && h < TUN_ENTRY_CAP) { hp = eprob[h]; ho = eoff[h]; hl = elen[h]; }
+		const uint32_t mysym = lane < n ? sym[lane] : 0u, myP = lane < n ? P[lane] : 0u;
+		while(nwords < 256) {
+			// likeliest head, first row wins ties, all-zero -> row 0: one DPP wave reduction + readlane broadcasts
+			// (ds_bpermute-based shuffles cost ~60 cycles each and there would be ten of them per expansion)
+			const uint32_t key = wave_max_u32(hp ? ((hp << 16) | (0xFFFFu - lane)) : 0u);
+			const uint32_t best = (key >> 16) ? 0xFFFFu - (key & 0xFFFFu) : 0u;
+			const uint32_t parent = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)best);
+			if(parent >= TUN_ENTRY_CAP) break;                                    // malformed probabilities
+			const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)hp, (int)best), po = (uint32_t)__builtin_amdgcn_readlane((int)ho, (int)best),
+			               pl = (uint32_t)__builtin_amdgcn_readlane((int)hl, (int)best);
+			const bool full = nwords + n > 255;                                   // dictionary fills up during this expansion: parent stays
+			const uint32_t m = full ? 256 - nwords : n;
+			const uint32_t tot = m*(pl + 1);
+			if(end + m > TUN_ENTRY_CAP || pos + tot > TUN_TABLE_BYTES) break;
+			// child r = parent bytes + sym[r]; lanes hold the parent's bytes, one write per child
+			for(uint32_t j0 = 0; j0 < pl; j0 += 64) {
+				const uint32_t j = j0 + lane;
+				const uint8_t pb = j < pl ? buf[po + j] : (uint8_t)0;
+				for(uint32_t r = 0; r < m; r++) if(j < pl) buf[pos + r*(pl + 1) + j] = pb;
+			}
+			if(lane < m) {
+				const uint32_t e = end + lane, cp = (pp*myP) >> 16, co = pos + lane*(pl + 1);
+				buf[co + pl] = (uint8_t)mysym;
+				eprob[e] = cp; eoff[e] = (uint16_t)co; elen[e] = (uint16_t)(pl + 1);
+				if(h == e) { hp = cp; ho = co; hl = pl + 1; }                  // the row's FIFO was empty: the child is its new head
+			}
+			__syncthreads();
+			if(!full && lane == best) {                                            // parent fully expanded: pop it
+				h = parent + n;
+				if(h < end + m && h < TUN_ENTRY_CAP) { hp = eprob[h]; ho = eoff[h]; hl = elen[h]; } else { hp = 0; ho = 0; hl = 0; }
+			}
+			end += m; pos += tot; nwords += n - 1;
+		}
+		if(lane < n) head[lane] = (uint16_t)min(h, 0xFFFFu);
+		__syncthreads();
+	} else
+	while(nwords < 256) {                       // tunstall.cpp:207-241 (general path, n > 64)
 		// likeliest FIFO head; first row wins ties; all-zero -> row 0.  key = prob:16 | (0xFFFF - row)
 		uint32_t key = 0;
 		for(uint32_t r = lane; r < n; r += 64) {

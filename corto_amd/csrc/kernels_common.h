@@ -20,6 +20,20 @@ template <typename T> __device__ __forceinline__ CRT_LDS T *as_lds(T *p) { retur
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
 
+// max over the 64 lanes of a wave, result uniform (SGPR).  DPP row operations + row broadcasts (gfx9) instead of
+// ds_bpermute shuffles: ~12 VALU instructions with no LDS round trip.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define CRT_DPP_MAX(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v = o_ > v ? o_ : v; }
+	CRT_DPP_MAX(0xB1, 0xf)      // quad_perm [1,0,3,2]
+	CRT_DPP_MAX(0x4E, 0xf)      // quad_perm [2,3,0,1]
+	CRT_DPP_MAX(0x141, 0xf)     // row_half_mirror
+	CRT_DPP_MAX(0x140, 0xf)     // row_mirror: every lane of a 16-lane row holds the row max
+	CRT_DPP_MAX(0x142, 0xa)     // row_bcast:15 into rows 1 and 3
+	CRT_DPP_MAX(0x143, 0xc)     // row_bcast:31 into rows 2 and 3: lane 63 holds the wave max
+#undef CRT_DPP_MAX
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // inclusive scan across the 64 lanes of a wave
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v) {
