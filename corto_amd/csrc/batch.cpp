@@ -393,8 +393,11 @@ struct Launch {
 	}
 };
 
+#include <chrono>
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int build_and_launch(crthip_batch *b) {
 	crthip_ctx *ctx = b->ctx;
+	const bool TT = getenv("CRTHIP_HOST_TIMING") != nullptr; double t0 = now_us(), t1 = 0, t2 = 0, t3 = 0;
 	Plan pl;
 	Carver cv;
 	const uint32_t nblobs = (uint32_t)b->blobs.size();
@@ -671,6 +674,7 @@ static int build_and_launch(crthip_batch *b) {
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
 	pl.total = cv.take(0);
 
+	t1 = now_us();
 	// ---- reserve device + pinned memory; one batch in flight per context ----
 	if(ctx->in_flight && ctx->in_flight != b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
 	if(ctx->in_flight == b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); }
@@ -714,6 +718,7 @@ static int build_and_launch(crthip_batch *b) {
 	put(pl.delta); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
+	t2 = now_us();
 	hipStream_t st = ctx->stream;
 	ctx->timer.reset();
 	Launch LT{ctx};
@@ -846,6 +851,8 @@ static int build_and_launch(crthip_batch *b) {
 	ctx->in_flight = b;
 	b->decoded = true;
 	b->dirty = false;
+	t3 = now_us();
+	if(TT) fprintf(stderr, "plan %.1f us, fixup+stage %.1f us, launches %.1f us\n", t1 - t0, t2 - t1, t3 - t2);
 	return CRTHIP_OK;
 }
 

@@ -329,9 +329,20 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 	}
 }
 
-// pass B, long streams: each tile's bytes are staged in LDS at the destination's 16-byte phase and flushed with coalesced
-// 16-byte stores (full cache lines to HBM instead of 64 scattered partial lines per store instruction).
-constexpr uint32_t TUN_OUTBUF = 16*1024;
+// pass B, long streams.  Per tile of 2048 codewords (8 per thread) the decoded bytes are composed in an LDS window laid
+// out at the destination's 16-byte phase and flushed with coalesced 16-byte stores (full lines to HBM).
+//   phase A, branch-free: every word has a zero-padded 16-byte copy (T16).  A thread reads it with one ds_read_b128, moves
+//            it to the word's byte phase with five v_perm_b32 and ORs the five dwords into the zeroed window with LDS
+//            atomics: neighbouring words touch disjoint bytes of a shared dword, so OR composes them with no ordering.
+//   phase B: the bytes beyond 16 of long words go through a small work list (position, table offset, count) that the whole
+//            workgroup drains, 16 bytes per thread per step - long words are rare in high-entropy streams but carry many
+//            bytes each in low-entropy ones, and this keeps phase A free of data-dependent loops.
+// The kernel is instruction-issue bound (PMC: SIMDs ~80 % busy), not bandwidth bound, hence the effort on instruction
+// count: barriers drain lgkmcnt only (lds_barrier) so stores stay in flight, and codewords are fetched one tile ahead.
+// A stream's clipped last tile, and tiles whose bytes exceed the window, take the general byte-FIFO path.
+constexpr uint32_t TUN_OUTBUF = 24*1024;
+constexpr uint32_t TUN_TILE8 = 2048;
+constexpr uint32_t TUN_LONG_CAP = 1024;
 
 __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                            uint32_t nchunks, const TunTable *__restrict__ tables,
@@ -341,8 +352,22 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const TunStream st = streams[chunk_stream[c]];
 	const TunTable &T = tables[st.table];
 	__shared__ TunLds L;
-	__shared__ __attribute__((aligned(16))) uint8_t outbuf[TUN_OUTBUF + 32];
+	__shared__ __attribute__((aligned(16))) u32x4_t t16[256];
+	__shared__ __attribute__((aligned(16))) uint32_t outbuf[(TUN_OUTBUF + 64)/4];
+	__shared__ uint32_t longq[TUN_LONG_CAP];                   // (window byte position << 8 | bytes) , table offset in longo
+	__shared__ uint16_t longo[TUN_LONG_CAP];
+	__shared__ uint32_t nlong_s;
+	const uint32_t tid = threadIdx.x;
 	tun_load_table(L, T, T.used);
+	for(uint32_t i = tid; i < (TUN_OUTBUF + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(outbuf))[i] = u32x4_t{0, 0, 0, 0};
+	if(tid == 0) nlong_s = 0;
+	__syncthreads();
+	{	// zero-padded 16-byte copy of every word
+		const uint32_t wo = L.off[tid], wl = min((uint32_t)L.len[tid], 16u);
+		uint32_t d[4] = {0, 0, 0, 0};
+		for(uint32_t b = 0; b < wl; b++) d[b >> 2] |= (uint32_t)L.bytes[wo + b] << (8*(b & 3));
+		t16[tid] = u32x4_t{d[0], d[1], d[2], d[3]};
+	}
 	__syncthreads();
 	const uint32_t first = (c - st.chunk0)*chunk_codes;
 	const uint32_t last = min(first + chunk_codes, st.csize);
@@ -350,36 +375,129 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const uint64_t size = st.size;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
-	const uint32_t tid = threadIdx.x;
-	for(uint32_t tile = first; tile < last; tile += TUN_TILE) {
-		TunTile t;
-		tun_tile_prepare(t, st, src, tile, last, base, as_lds(L.len), as_lds(L.off), L.scan);
-		// bytes this tile really writes (clipped at the stream's declared size / extended by its last codeword)
-		const bool has_last = tile + TUN_TILE >= st.csize;
-		const uint64_t endo = has_last ? size : min(size, base + t.total);
-		const uint64_t tb64 = endo > base ? endo - base : 0;
-		if(tb64 <= TUN_OUTBUF) {
-			const uint32_t n = (uint32_t)tb64;
+	CRT_LDS uint32_t *out32 = as_lds(outbuf);
+	CRT_LDS const u32x4_t *t16l = (CRT_LDS const u32x4_t *)as_lds(t16);
+	CRT_LDS const uint8_t *len8 = as_lds(L.len);
+	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(L.bytes);
+
+	// codewords are fetched one tile ahead, 8 per thread as two (unaligned) dwords
+	auto fetch = [&](uint32_t j, uint32_t &lo, uint32_t &hi) {
+		lo = 0; hi = 0;
+		if(j + 8 <= last) { lo = *(CRT_GLOBAL const uint32_t *)(src + j); hi = *(CRT_GLOBAL const uint32_t *)(src + j + 4); }
+		else for(uint32_t k = 0; k < 8 && j + k < last; k++) { const uint32_t v = src[j + k]; if(k < 4) lo |= v << (8*k); else hi |= v << (8*(k - 4)); }
+	};
+	uint32_t nlo, nhi;
+	fetch(first + 8*tid, nlo, nhi);
+	for(uint32_t tile = first; tile < last; tile += TUN_TILE8) {
+		const uint32_t j0 = tile + 8*tid;
+		const uint32_t clo = nlo, chi = nhi;
+		fetch(j0 + TUN_TILE8, nlo, nhi);
+		uint32_t code[8], l[8], sum = 0, lmax = 0;
+#pragma unroll
+		for(int k = 0; k < 8; k++) {
+			code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
+			l[k] = j0 + k < last ? (uint32_t)len8[code[k]] : 0u;
+			sum += l[k]; lmax = max(lmax, l[k]);
+		}
+		uint32_t total;
+		const uint32_t orel = block256_exclusive_scan<uint32_t, true>(sum, L.scan, &total);
+		const bool fast = total + 32 <= TUN_OUTBUF && tile + TUN_TILE8 < st.csize && base + total <= size;
+		if(fast) {
 			CRT_GLOBAL uint8_t *g0 = gdst + base;
 			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
-			CRT_LDS uint8_t *out = as_lds(outbuf) + phase;
-			CRT_LDS uint8_t *d = out + (uint32_t)(t.o - base);
-			tun_emit_run(d, (uint32_t)(uintptr_t)d, (CRT_LDS const uint32_t *)as_lds(L.bytes), t.wo, t.nb);
-			__syncthreads();
+			uint32_t p = phase + orel;
+			// ---- phase A ----
+#pragma unroll
+			for(int k = 0; k < 8; k++) {
+				u32x4_t w = t16l[code[k]];
+				if(l[k] == 0) w = u32x4_t{0, 0, 0, 0};                       // past the end of the chunk
+				const uint32_t sel = 0x07060504u - 0x01010101u*(p & 3u);      // v_perm selector: bytes (4-s .. 7-s) of {hi, lo}
+				CRT_LDS uint32_t *o = out32 + (p >> 2);
+				atomicOr((uint32_t *)(o + 0), __builtin_amdgcn_perm(w.x, 0u, sel));
+				atomicOr((uint32_t *)(o + 1), __builtin_amdgcn_perm(w.y, w.x, sel));
+				atomicOr((uint32_t *)(o + 2), __builtin_amdgcn_perm(w.z, w.y, sel));
+				atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(w.w, w.z, sel));
+				atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, w.w, sel));
+				p += l[k];
+			}
+			// ---- phase B: the tails of long words, through a work list drained by the whole workgroup ----
+			auto or_tail = [&](uint32_t q, uint32_t so, uint32_t rem) {       // rem <= 16 bytes from table offset so to window position q
+				CRT_LDS const uint32_t *s32 = tab32 + (so >> 2);
+				const uint32_t a = so & 3u;
+				const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
+				uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
+				                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
+#pragma unroll
+				for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
+				const uint32_t sel = 0x07060504u - 0x01010101u*(q & 3u);
+				CRT_LDS uint32_t *o = out32 + (q >> 2);
+				atomicOr((uint32_t *)(o + 0), __builtin_amdgcn_perm(d[0], 0u, sel));
+				atomicOr((uint32_t *)(o + 1), __builtin_amdgcn_perm(d[1], d[0], sel));
+				atomicOr((uint32_t *)(o + 2), __builtin_amdgcn_perm(d[2], d[1], sel));
+				atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(d[3], d[2], sel));
+				atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, d[3], sel));
+			};
+			if(lmax > 16) {
+				uint32_t q = phase + orel;
+#pragma unroll
+				for(int k = 0; k < 8; k++) {
+					if(l[k] > 16) {
+						const uint32_t np = (l[k] - 1) >> 4;                       // pieces beyond the first 16 bytes
+						const uint32_t at = atomicAdd(&nlong_s, np);
+						const uint32_t wo = L.off[code[k]];
+						for(uint32_t i = 0; i < np; i++) {
+							const uint32_t b0 = 16u*(i + 1), rem = min(l[k] - b0, 16u);
+							if(at + i < TUN_LONG_CAP) { longq[at + i] = ((q + b0) << 8) | rem; longo[at + i] = (uint16_t)(wo + b0); }
+							else or_tail(q + b0, wo + b0, rem);                      // list full: do it here
+						}
+					}
+					q += l[k];
+				}
+			}
+			lds_barrier();
+			const uint32_t nlong = min(nlong_s, TUN_LONG_CAP);
+			for(uint32_t i = tid; i < nlong; i += 256) { const uint32_t e = longq[i]; or_tail(e >> 8, longo[i], e & 255u); }
+			if(nlong) lds_barrier();
+			// ---- flush [0, total) and re-zero the window ----
+			CRT_LDS uint8_t *out = (CRT_LDS uint8_t *)out32 + phase;
+			const uint32_t n = total;
 			const uint32_t head = min((16u - phase) & 15u, n);
 			if(tid < head) g0[tid] = out[tid];
 			const uint32_t nvec = (n - head) >> 4;
 			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 + head);
-			CRT_LDS const u32x4_t *lv = (CRT_LDS const u32x4_t *)(out + head);
-			for(uint32_t i = tid; i < nvec; i += 256) gv[i] = lv[i];
+			CRT_LDS u32x4_t *lv = (CRT_LDS u32x4_t *)(out + head);
+			for(uint32_t i = tid; i < nvec; i += 256) { gv[i] = lv[i]; lv[i] = u32x4_t{0, 0, 0, 0}; }
 			const uint32_t tail0 = head + (nvec << 4);
 			if(tail0 + tid < n) g0[tail0 + tid] = out[tail0 + tid];
-			__syncthreads();
-		} else {                                         // very long words (low-entropy streams): straight to HBM
-			CRT_GLOBAL uint8_t *d = gdst + t.o;
-			tun_emit_run(d, (uint32_t)(uintptr_t)d, (CRT_LDS const uint32_t *)as_lds(L.bytes), t.wo, t.nb);
+			lds_barrier();
+			if(tid < 4) out32[tid] = 0;                                        // head / tail dwords of the window
+			if(tid < 8) out32[((phase + tail0) >> 2) + tid] = 0;
+			if(tid == 0) nlong_s = 0;
+			lds_barrier();
+		} else {
+			// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
+			uint64_t oo = base + orel;
+#pragma unroll
+			for(int h = 0; h < 2; h++) {
+				uint32_t wo[4], nb[4];
+				const uint64_t o_run = oo;
+#pragma unroll
+				for(int k = 0; k < 4; k++) {
+					const int kk = 4*h + k;
+					uint32_t n_ = l[kk];
+					wo[k] = L.off[code[kk]];
+					if(j0 + kk < last) {
+						if(j0 + kk + 1 == st.csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
+						else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
+					} else n_ = 0;
+					nb[k] = n_;
+					oo += l[kk];
+				}
+				CRT_GLOBAL uint8_t *d = gdst + o_run;
+				tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
+			}
 		}
-		base += t.total;
+		base += total;
 	}
 }
 

@@ -46,14 +46,21 @@ __device__ __forceinline__ T wave_inclusive_scan(T v) {
 	return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits until every global
+// store of the wave has been acknowledged by the memory system (microseconds under load) - fatal in streaming loops that
+// flush to HBM and then reuse an LDS buffer.  Here only lgkmcnt is drained; global loads/stores stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // exclusive scan over a 256-thread block (4 waves); *total = block sum. smem: 4 entries of T.
-template <typename T>
+template <typename T, bool LDS_ONLY = false>
 __device__ __forceinline__ T block256_exclusive_scan(T v, T *smem, T *total) {
 	T inc = wave_inclusive_scan(v);
 	const uint32_t lane = lane_id(), w = wave_id();
-	__syncthreads();                 // smem may still be read by a previous call
+	if(LDS_ONLY) lds_barrier(); else __syncthreads();                 // smem may still be read by a previous call
 	if(lane == 63) smem[w] = inc;
-	__syncthreads();
+	if(LDS_ONLY) lds_barrier(); else __syncthreads();
 	T s0 = smem[0], s1 = smem[1], s2 = smem[2], s3 = smem[3];
 	T base = w == 0 ? T(0) : w == 1 ? s0 : w == 2 ? T(s0 + s1) : T(s0 + s1 + s2);
 	*total = s0 + s1 + s2 + s3;
