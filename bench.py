@@ -25,13 +25,16 @@ sys.path.insert(0, ROOT)
 NBLOBS = 256
 
 
-def load_blobs():
-    """16 distinct reference-encoded C4-unit blobs (tests/golden/c4_blobs16.npz, made by the reference
-    encoder from corto_amd.synth.bumpy_sphere(64, 32, seed)), replicated 16x to 256 at distinct addresses."""
+def load_blobs(first_seed=0):
+    """256 distinct C4-unit blobs: corto_amd.synth.bumpy_sphere(64, 32, seed) (2 112 verts / 4 096 tris) encoded
+    by the repo's own .crt writer (csrc/encoder.cpp, byte-identical to the reference encoder; tests/test_encoder_cpu.py).
+    Host-side input synthesis, outside the timed region."""
     import corto_amd as ca
+    from corto_amd import synth
+    blobs = [ca.encode(synth.bumpy_sphere(64, 32, seed=first_seed + i), position_bits=14, uv_bits=12, normal_bits=10,
+                       normal_prediction=ca.BORDER) for i in range(NBLOBS)]
     z = np.load(os.path.join(ROOT, "tests", "golden", "c4_blobs16.npz"))
-    uniq = [ca.aligned_blob(z["crt_%02d" % s]) for s in range(16)]
-    return [uniq[i % 16] for i in range(NBLOBS)], z
+    return blobs, z
 
 
 def cpu_baseline(blobs, budget_s=12.0):
@@ -63,6 +66,21 @@ def cpu_baseline(blobs, budget_s=12.0):
     return {"value": round(tris / best / 1e6, 3), "unit": "Mtri/s", "mverts_per_s": round(verts / best / 1e6, 3), "cores": 1, "kind": kind,
             "sample": "16 distinct C4-unit blobs (65 536 tris) decoded back to back, best of %d passes in %.0f s; ctor+set*+decode per blob" % (n, budget_s),
             "host_cpus": os.cpu_count()}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/, separate
+    --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None when no profile is committed."""
+    import glob
+    name = {"topology_lds": "corto_hip::k_topology_lds", "topology": "corto_hip::k_topology", "delta_mesh": "corto_hip::k_delta_mesh",
+            "tunstall_tables": "corto_hip::k_tun_tables", "tunstall_decode": "corto_hip::k_tun_decode"}.get(kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_per_dispatch.json")))
+    if not name or not files:
+        return None
+    d = json.load(open(files[-1])).get(name, {})
+    if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+        return None
+    return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
 
 
 def tunstall_scaled(ctx, ca, z):
@@ -128,7 +146,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from corto_amd import shard
-    blobs, z = load_blobs()
+    blobs, z = load_blobs(first_seed=NBLOBS * rank)   # C5: rank r decodes seeds 256r .. 256r+255
     # C5 = world x 256 blobs cut into contiguous work-balanced ranges; this rank decodes only its own (no collective)
     lo, hi = shard.my_range([4096 + 2112] * (NBLOBS * world), world, rank)
     assert hi - lo == NBLOBS
@@ -184,11 +202,17 @@ def main():
 
     # untimed bit-exactness check of this rank's outputs against the golden digests made by the reference
     import hashlib
-    for i in (0, 5, 31, 255):
-        got = b0.host_outputs(i)
+    from oracle import oracle as oc
+    for i in range(0, NBLOBS, 17):                # every 17th blob against the CPU oracle ...
+        got, ref = b0.host_outputs(i), oc.decode(blobs[i])
         for k in ("position", "normal", "color", "uv", "index"):
-            d = hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest()
-            assert d == z["%s_sha256_%02d" % (k, i % 16)].tobytes().decode(), ("bit-exact check failed", i, k)
+            assert got[k].tobytes() == ref[k].tobytes(), ("bit-exact check failed", i, k)
+    if rank == 0:
+        for i in range(16):                       # ... and seeds 0-15 against the digests of the reference decoder's own output
+            got = b0.host_outputs(i)
+            for k in ("position", "normal", "color", "uv", "index"):
+                d = hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest()
+                assert d == z["%s_sha256_%02d" % (k, i)].tobytes().decode(), ("bit-exact check failed (golden)", i, k)
 
     if rank == 0:
         ntri, nvert = int(stats0.total_nface), int(stats0.total_nvert)
@@ -196,11 +220,11 @@ def main():
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps} for k, v in kt_acc.items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         # algorithmic bytes of the dominant kernel per launch
+        topo_bytes = int(stats0.clers_symbols + stats0.split_bytes + ntri * 12 + nvert * 12)
         alg = {
-            # CLERS symbols + split words read; index (12 B/tri) + prediction triples (12 B/vert) written
-            "topology": NBLOBS * (4318 + 13 * 4) + ntri * 12 + nvert * 12,
-            "delta_mesh": None, "tunstall_decode": int(stats0.tunstall_in + stats0.tunstall_out),
-            "tunstall_tables": int(stats0.tunstall_tables),
+            # CLERS symbols + split words read; index (12 B/tri) + prediction triples (12 B/vert) written (DESIGN.md §3)
+            "topology_lds": topo_bytes, "topology": topo_bytes,
+            "tunstall_decode": int(stats0.tunstall_in + stats0.tunstall_out), "tunstall_tables": int(stats0.tunstall_tables),
         }
         whole_path_bytes = int(stats0.arena_bytes + stats0.output_bytes)
         dom_bytes = alg.get(dom) or whole_path_bytes
@@ -212,14 +236,14 @@ def main():
             "mverts_per_s": round(world * nvert / (elapsed / args.steps) / 1e6, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 integer + f32 normals",
-            "data": "synthetic: 16 distinct reference-encoded bumpy-sphere blobs (seeds 0-15) replicated 16x at distinct HBM addresses",
+            "data": "synthetic: 256 distinct bumpy-sphere meshes per GPU (seeds 256*rank ..), encoded by the repo's byte-identical .crt writer",
             "config": {"workload": "C4: 256 x (2112 verts / 4096 tris), pos14+uv12+normal10(BORDER)+rgba, per GPU; C5 when n_gpus=8",
                        "blobs_per_gpu": NBLOBS, "tris_per_gpu": ntri, "verts_per_gpu": nvert,
                        "timed_region": "plan(host walk)+bind+kernels+sync, compressed inputs resident in HBM, outputs left in HBM",
                        "parallelism": "blob-sharded x%d, no collective" % world},
             "bit_exact": True,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(ach / 8000.0, 6), "traffic": None,
+                         "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
             "whole_path": {"algorithmic_bytes": whole_path_bytes, "GBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9, 2),
                            "frac_of_8TBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9 / 8000.0, 6)},

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorto_hip.so")
-SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_normal.hip", "batch.cpp", "crt_format.cpp", "decoder_facade.cpp"]
+SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_normal.hip", "batch.cpp", "crt_format.cpp", "decoder_facade.cpp", "encoder.cpp"]
 HEADERS = ["kernels_common.h", "kernels.h", "device_plan.h", "crt_format.h",
            os.path.join("..", "..", "include", "corto_hip.h"), os.path.join("..", "..", "include", "corto", "decoder.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fgpu-rdc" if False else "-fno-gpu-rdc",

@@ -249,6 +249,7 @@ extern "C" int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8
 		P.bind.resize(P.L.h.attrs.size());
 		off += ((uint64_t)lens[i] + 15) & ~15ull;
 		b->stats.total_nvert += P.L.h.nvert; b->stats.total_nface += P.L.h.nface;
+		if(P.L.h.nface) { b->stats.clers_symbols += P.L.clers.size; b->stats.split_bytes += (uint64_t)P.L.split.nwords*4; }
 	}
 	b->arena_bytes = off;
 	b->stats.arena_bytes = off;

@@ -1,0 +1,624 @@
+// encoder.cpp — host-side .crt writer: lets tests and bench.py synthesise inputs on the GPU
+// box without the reference library.  Byte-identical to upstream's crt::Encoder for the attribute set the decoder path
+// covers (positions, normals in all three prediction modes, rgb/rgba colours, uvs, one generic "radius" attribute,
+// groups, exif, entropy NONE/TUNSTALL, meshes and point clouds); tests/test_encoder_cpu.py pins that against the
+// reference-made golden blobs and, where oracle/_ref exists, against the reference on a random corpus.
+//
+// What it restates (upstream file:line):
+//   container + stage order   src/encoder.cpp:207-296 (encode, encodePointCloud), :311-381 (encodeMesh)
+//   quantisation              src/encoder.cpp:49-100, include/corto/vertex_attribute.h:79-128, src/normal_attribute.cpp:61-111,
+//                             src/color_attribute.cpp:23-70
+//   value coding              include/corto/cstream.h:105-204 (needed, encodeValues, encodeArray), src/bitstream.cpp:86-101,123-129
+//   Tunstall                  src/tunstall.cpp:83-115 (getProbabilities), :125-256 (dictionary), :335-428 (encoding trie, compress),
+//                             src/cstream.cpp:89-109 (block framing)
+//   topology                  src/encoder.cpp:383-504 (buildTopology), :522-722 (encodeFaces)
+//   normals                   src/normal_attribute.cpp:113-176 (preDelta, deltaEncode, encode)
+// Where the reference's output depends on std::sort's handling of ties (probability order, edge buckets, Morton order)
+// the same std::sort call on the same element sequence is made, which reproduces it exactly.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/corto_hip.h"
+
+namespace {
+
+int ilog2u(uint64_t p) { int k = 0; while(p >>= 1) ++k; return k; }                  // src/cstream.cpp:31-35
+
+int32_t f2i(float x) {                                                                 // x86 cvttss2si
+	if(!(x > -2147483904.0f && x < 2147483648.0f)) return INT_MIN;
+	return (int32_t)x;
+}
+
+// ---- byte sink (OutStream, include/corto/cstream.h:42-105) ----
+struct Sink {
+	std::vector<uint8_t> b;
+	void u8(uint32_t v) { b.push_back((uint8_t)v); }
+	void u16(uint32_t v) { u8(v); u8(v >> 8); }
+	void u32(uint32_t v) { u8(v); u8(v >> 8); u8(v >> 16); u8(v >> 24); }
+	void f32(float f) { uint32_t u; memcpy(&u, &f, 4); u32(u); }
+	void str(const std::string &s) { u16((uint32_t)s.size() + 1); b.insert(b.end(), s.begin(), s.end()); u8(0); }
+	void raw(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+};
+
+// ---- MSB-first bit writer over u32 words (src/bitstream.cpp:86-101, 123-129) ----
+struct BitWriter {
+	std::vector<uint32_t> words;
+	uint32_t buff = 0;
+	int bits = 32;                      // free bits in buff
+	void write(uint32_t value, int n) {
+		if(n >= bits) {
+			buff = (bits == 32 ? 0u : (buff << bits)) | (value >> (n - bits));
+			words.push_back(buff);
+			const int rest = n - bits;
+			value &= rest >= 32 ? 0xFFFFFFFFu : ((1u << rest) - 1u);
+			n = rest; bits = 32; buff = 0;
+		}
+		if(n > 0) { buff = (buff << n) | value; bits -= n; }
+	}
+	void flush() { if(bits != 32) { words.push_back(buff << bits); buff = 0; bits = 32; } }
+	void emit(Sink &s) {                // OutStream::write(BitStream&), cstream.h:79-89
+		flush();
+		s.u32((uint32_t)words.size());
+		while(s.b.size() & 3) s.u8(0);
+		for(uint32_t w : words) s.u32(w);
+	}
+};
+
+// ---- Tunstall encoder ----
+struct Sym { uint8_t symbol, probability; };
+
+struct Tunstall {
+	std::vector<Sym> probs;
+	std::vector<int> index, lengths;    // 256 words after build()
+	std::vector<uint8_t> table;
+	std::vector<int> offsets;           // 2-symbol-step trie (createEncodingTables)
+	std::vector<uint8_t> remap;
+
+	void probabilities(const uint8_t *data, int size) {                               // tunstall.cpp:83-115
+		std::vector<int> cnt(256, 0);
+		for(int i = 0; i < size; i++) cnt[data[i]]++;
+		probs.clear();
+		for(int i = 0; i < 256; i++) if(cnt[i] > 0) probs.push_back(Sym{(uint8_t)i, (uint8_t)(cnt[i]*255/size)});
+		std::sort(probs.begin(), probs.end(), [](const Sym &a, const Sym &b) -> bool { return a.probability > b.probability; });
+	}
+
+	void build() {                                                                     // tunstall.cpp:125-256
+		const uint32_t n = (uint32_t)probs.size();
+		if(n <= 1) return;
+		std::vector<uint32_t> q(1024, 0), head(n);
+		index.assign(1024, 0); lengths.assign(1024, 0);
+		table.assign(8192 + 1024, 0);
+		std::vector<uint32_t> P(n);
+		for(uint32_t i = 0; i < n; i++) P[i] = (uint32_t)probs[i].probability << 8;
+		uint32_t count = 2, run = (P[0]*P[0]) >> 16, max_count = 255/(n - 1), pos = 0, end = 0, nwords = 0;
+		while(run > P[1] && count < max_count) { run = (run*P[0]) >> 16; count++; }
+		if(count >= 16) {
+			table[pos++] = probs[0].symbol;
+			for(uint32_t k = 1; k < n; k++) { for(uint32_t i = 0; i + 1 < count; i++) table[pos++] = probs[0].symbol; table[pos++] = probs[k].symbol; }
+			head[0] = (count - 1)*n;
+			for(uint32_t k = 1; k < n; k++) head[k] = k;
+			uint32_t pw = 0;
+			for(uint32_t col = 0; col < count; col++) {
+				for(uint32_t row = 1; row < n; row++) {
+					const uint32_t e = row + col*n;
+					q[e] = col == 0 ? P[row] : (pw*P[row]) >> 16;
+					index[e] = (int)(row*count - col); lengths[e] = (int)(col + 1);
+				}
+				pw = col == 0 ? P[0] : (pw*P[0]) >> 16;
+			}
+			const uint32_t first = (count - 1)*n;
+			q[first] = pw; index[first] = 0; lengths[first] = (int)count;
+			nwords = 1 + count*(n - 1); end = count*n;
+		} else {
+			for(uint32_t i = 0; i < n; i++) { head[i] = i; q[end] = P[i]; index[end] = (int)pos; lengths[end] = 1; end++; table[pos++] = probs[i].symbol; }
+			nwords = n;
+		}
+		while(nwords < 256) {
+			uint32_t best = 0, maxp = 0;
+			for(uint32_t i = 0; i < n; i++) { const uint32_t p = head[i] < q.size() ? q[head[i]] : 0; if(p > maxp) { best = i; maxp = p; } }
+			const uint32_t parent = head[best], pp = q[parent], po = (uint32_t)index[parent], pl = (uint32_t)lengths[parent];
+			uint32_t r = 0;
+			for(; r < n; r++) {
+				q[end] = (pp*P[r]) >> 16; index[end] = (int)pos; lengths[end] = (int)pl + 1; end++;
+				memmove(&table[pos], &table[po], pl); pos += pl;
+				table[pos++] = probs[r].symbol;
+				if(nwords + r == 255) break;
+			}
+			if(r == n) head[best] += n;
+			nwords += n - 1;
+		}
+		size_t w = 0;
+		for(size_t e = 0; e < end && w < 256; e++) { if(head[e % n] > e) continue; index[w] = index[e]; lengths[w] = lengths[e]; w++; }
+		index.resize(256); lengths.resize(256);
+	}
+
+	void code(const uint8_t *w, int length, int &low, int &high) const {              // wordCode, tunstall.h:117-132 (lookup_size 2)
+		const int n = (int)probs.size();
+		int c = 0;
+		for(int i = 0; i < length && i < 2; i++) c = c*n + remap[w[i]];
+		low = c; high = c + 1;
+		for(int i = length; i < 2; i++) { low *= n; high *= n; }
+	}
+
+	void trie() {                                                                      // createEncodingTables, tunstall.cpp:335-382
+		const int n = (int)probs.size();
+		if(n <= 1) return;
+		const int span = n*n;
+		remap.assign(256, 0);
+		for(int i = 0; i < n; i++) remap[probs[i].symbol] = (uint8_t)i;
+		offsets.assign(span, 0xffffff);
+		for(size_t i = 0; i < index.size(); i++) {
+			int low, high, off = 0, toff = 0;
+			for(;;) {
+				code(&table[index[i] + off], lengths[i] - off, low, high);
+				if(lengths[i] - off <= 2) { for(int k = low; k < high; k++) offsets[toff + k] = (int)i; break; }
+				const int w = offsets[toff + low];
+				if(w >= 0) { offsets[toff + low] = -(int)offsets.size(); offsets.resize(offsets.size() + span, w); }
+				toff = -offsets[toff + low];
+				off += 2;
+			}
+		}
+	}
+
+	std::vector<uint8_t> compress(const uint8_t *data, int size) const {               // tunstall.cpp:384-428
+		std::vector<uint8_t> out;
+		if(probs.size() == 1) return out;
+		int in = 0, woff = 0, off = 0;
+		while(in < size) {
+			const int d = std::min(size - in, 2);
+			int low, high;
+			code(data + in, d, low, high);
+			off = offsets[-off + low];
+			if(off >= 0) { out.push_back((uint8_t)off); in += lengths[off] - woff; off = 0; woff = 0; }
+			else { woff += 2; in += 2; }
+		}
+		if(off < 0) { while(off < 0) off = offsets[-off]; out.push_back((uint8_t)off); }
+		return out;
+	}
+};
+
+// entropy-coded byte array (OutStream::compress / tunstall_compress, cstream.cpp:43-64, 89-109)
+void put_symbols(Sink &s, uint32_t entropy, const uint8_t *data, uint32_t size) {
+	if(entropy == CRTHIP_ENTROPY_NONE) { s.u32(size); s.raw(data, size); return; }
+	Tunstall t;
+	t.probabilities(data, (int)size);
+	t.build();
+	t.trie();
+	const std::vector<uint8_t> c = t.compress(data, (int)size);
+	s.u8((uint32_t)t.probs.size());
+	for(const Sym &p : t.probs) { s.u8(p.symbol); s.u8(p.probability); }
+	s.u32(size);
+	s.u32((uint32_t)c.size());
+	s.raw(c.data(), c.size());
+}
+
+int needed(int a) {                                                                    // cstream.h:105-112
+	if(a == 0) return 0;
+	if(a == -1) return 1;
+	if(a < 0) a = -a - 1;
+	int n = 2;
+	while(a >>= 1) n++;
+	return n;
+}
+
+// encodeValues (cstream.h:115-141): component-major logs, sign folding
+template <class T> void put_values(Sink &s, uint32_t entropy, uint32_t size, const T *values, int N) {
+	BitWriter bw;
+	std::vector<std::vector<uint8_t>> logs((size_t)N, std::vector<uint8_t>(size));
+	for(int c = 0; c < N; c++) for(uint32_t i = 0; i < size; i++) {
+		int val = values[(size_t)i*N + c];
+		if(val == 0) { logs[c][i] = 0; continue; }
+		const int ret = ilog2u((uint64_t)std::abs(val)) + 1;
+		logs[c][i] = (uint8_t)ret;
+		const int middle = (1 << ret) >> 1;
+		if(val < 0) val = -val - middle;
+		bw.write((uint32_t)val, ret);
+	}
+	bw.emit(s);
+	for(int c = 0; c < N; c++) put_symbols(s, entropy, logs[c].data(), size);
+}
+
+// encodeArray (cstream.h:143-164): one log per element
+void put_array(Sink &s, uint32_t entropy, uint32_t size, const int32_t *values, int N) {
+	BitWriter bw;
+	std::vector<uint8_t> logs(size);
+	for(uint32_t i = 0; i < size; i++) {
+		const int32_t *p = values + (size_t)i*N;
+		int diff = needed(p[0]);
+		for(int c = 1; c < N; c++) diff = std::max(diff, needed(p[c]));
+		logs[i] = (uint8_t)diff;
+		if(diff == 0) continue;
+		const int mx = 1 << (diff - 1);
+		for(int c = 0; c < N; c++) bw.write((uint32_t)(p[c] + mx), diff);
+	}
+	bw.emit(s);
+	put_symbols(s, entropy, logs.data(), size);
+}
+
+struct Quad { uint32_t t, a, b, c; };
+
+// normals: octahedral map (include/corto/normal_attribute.h:75-85)
+void to_octa(const float v[3], int unit, int32_t o[2]) {
+	float s = std::fabs(v[0]) + std::fabs(v[1]); s = s + std::fabs(v[2]);
+	float px = v[0]/s, py = v[1]/s;
+	if(v[2] < 0) {
+		const float qx = 1.0f - std::fabs(py), qy = 1.0f - std::fabs(px);
+		px = qx; py = qy;
+		if(v[0] < 0) px = -px;
+		if(v[1] < 0) py = -py;
+	}
+	o[0] = f2i(px*(float)unit); o[1] = f2i(py*(float)unit);
+}
+
+struct Attr {
+	std::string name;
+	int codec = CRTHIP_CODEC_GENERIC, N = 0, format = CRTHIP_FMT_FLOAT, strategy = 0;
+	float q = 0;
+	std::vector<int32_t> values, diffs;        // generic + normal (normal: 2 per vertex)
+	std::vector<uint8_t> cvalues, cdiffs;      // colour
+	int qc[4] = {4, 4, 4, 8};
+	int prediction = 0;                        // normals
+	std::vector<int32_t> boundary;
+};
+
+// ---- topology (src/encoder.cpp:383-504) ----
+struct McFace { uint32_t f[3], t[3], i[3]; };
+struct McEdge {
+	uint32_t face, side, v0, v1; bool inverted;
+	McEdge() {}
+	McEdge(uint32_t f, uint32_t s, uint32_t a, uint32_t b): face(f), side(s), inverted(false) { if(a < b) { v0 = a; v1 = b; } else { v1 = a; v0 = b; inverted = true; } }
+	bool operator<(const McEdge &e) const { if(v0 < e.v0) return true; if(v0 > e.v0) return false; return v1 < e.v1; }
+	bool match(const McEdge &e) const { if(inverted == e.inverted) return false; return v0 == e.v0 && v1 == e.v1; }
+};
+
+void build_topology(std::vector<McFace> &faces, uint32_t nvert) {
+	std::vector<uint32_t> count(nvert, 0);
+	for(McFace &f : faces) { count[std::min(f.f[0], f.f[1])]++; count[std::min(f.f[1], f.f[2])]++; count[std::min(f.f[2], f.f[0])]++; }
+	uint32_t partial = 0;
+	for(uint32_t &c : count) { const uint32_t tmp = c; c = partial; partial += tmp; }
+	std::vector<McEdge> edges(faces.size()*3);
+	for(size_t i = 0; i < faces.size(); i++) {
+		McFace &f = faces[i];
+		edges[count[std::min(f.f[1], f.f[2])]++] = McEdge((uint32_t)i, 0, f.f[1], f.f[2]);
+		edges[count[std::min(f.f[2], f.f[0])]++] = McEdge((uint32_t)i, 1, f.f[2], f.f[0]);
+		edges[count[std::min(f.f[0], f.f[1])]++] = McEdge((uint32_t)i, 2, f.f[0], f.f[1]);
+	}
+	if(!count.empty()) {
+		std::sort(edges.begin(), edges.begin() + count[0]);
+		for(uint32_t i = 0; i + 1 < count.size(); i++) { if(count[i] == 0) continue; std::sort(edges.begin() + count[i], edges.begin() + count[i + 1]); }
+	}
+	McEdge prev(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff);
+	for(const McEdge &e : edges) {
+		if(e.match(prev)) {
+			uint32_t &a = faces[e.face].t[e.side], &b = faces[prev.face].t[prev.side];
+			if(a == 0xffffffff && b == 0xffffffff) { a = prev.face; faces[e.face].i[e.side] = prev.side; b = e.face; faces[prev.face].i[prev.side] = e.side; }
+		} else prev = e;
+	}
+}
+
+struct CEdge { uint32_t face, side, prev, next; bool deleted; };
+enum { VERTEX = 0, LEFT = 1, RIGHT = 2, END = 3, BOUNDARY = 4, DELAY = 5, SPLIT = 6 };
+
+struct Encoder {
+	uint32_t nvert, nface, entropy;
+	std::vector<uint32_t> faces;                 // original indexing, degenerate faces removed in encode_mesh
+	std::vector<uint32_t> group_end;
+	std::map<std::string, std::string> exif;
+	std::map<std::string, Attr> data;            // std::map: alphabetical like upstream
+	std::vector<uint8_t> clers;
+	BitWriter split;
+	uint32_t max_front = 0, current_vertex = 0, last_index = 0;
+	std::vector<int> encoded;
+	std::vector<Quad> prediction;
+	Sink s;
+
+	void encode_faces(int start, int end) {                                            // src/encoder.cpp:522-722
+		std::vector<McFace> mf((size_t)(end - start));
+		for(int i = start; i < end; i++) { McFace &f = mf[(size_t)(i - start)]; for(int k = 0; k < 3; k++) { f.f[k] = faces[(size_t)i*3 + k]; f.t[k] = 0xffffffff; f.i[k] = 0; } }
+		build_topology(mf, nvert);
+		uint32_t current = 0, order = 0;
+		std::vector<int> delayed, faceorder;
+		std::vector<CEdge> front;
+		std::vector<bool> visited(mf.size(), false);
+		uint32_t totfaces = (uint32_t)mf.size();
+		std::vector<bool> referenced(nvert, false);
+		for(uint32_t v : faces) referenced[v] = true;
+		uint32_t nref = 0; for(bool r : referenced) if(r) nref++;
+		const int splitbits = ilog2u(nref) + 1;
+		int new_edge = -1;
+		auto nxt = [](int t) { return t == 2 ? 0 : t + 1; };
+		while(totfaces > 0) {
+			if(new_edge == -1 && order >= faceorder.size() && delayed.empty()) {
+				while(current != mf.size() && visited[current]) current++;
+				if(current == mf.size()) break;
+				const uint32_t ce = (uint32_t)front.size();
+				McFace &face = mf[current];
+				int mask = 0;
+				for(int k = 0; k < 3; k++) if(encoded[face.f[k]] != -1) mask |= 1 << k;
+				if(mask) { clers.push_back(SPLIT); split.write((uint32_t)mask, 3); } else clers.push_back(VERTEX);
+				for(int k = 0; k < 3; k++) {
+					const uint32_t v = face.f[k];
+					int &enc = encoded[v];
+					if(enc != -1) split.write((uint32_t)enc, splitbits);
+					else { prediction[current_vertex] = Quad{v, last_index, last_index, last_index}; enc = (int)current_vertex++; last_index = v; }
+				}
+				faceorder.push_back((int)front.size()); front.push_back(CEdge{current, 0, ce + 2, ce + 1, false});
+				faceorder.push_back((int)front.size()); front.push_back(CEdge{current, 1, ce + 0, ce + 2, false});
+				faceorder.push_back((int)front.size()); front.push_back(CEdge{current, 2, ce + 1, ce + 0, false});
+				visited[current] = true; current++; totfaces--;
+				continue;
+			}
+			int c;
+			if(new_edge != -1) { c = new_edge; new_edge = -1; }
+			else if(order < faceorder.size()) c = faceorder[order++];
+			else { c = delayed.back(); delayed.pop_back(); }
+			CEdge e = front[(size_t)c];
+			if(e.deleted) continue;
+			const uint32_t of = mf[e.face].t[e.side];
+			const int os = (int)mf[e.face].i[e.side];
+			if(of == 0xffffffff || visited[of]) { clers.push_back(BOUNDARY); continue; }
+			McFace &face = mf[of];
+			const int k2 = os, k0 = nxt(k2), k1 = nxt(k0);
+			const int eprev = (int)e.prev, enext = (int)e.next;
+			const CEdge pe = front[(size_t)eprev], ne = front[(size_t)enext];
+			const bool close_left = mf[pe.face].t[pe.side] == of, close_right = mf[ne.face].t[ne.side] == of;
+			new_edge = (int)front.size();
+			if(close_left && close_right) {
+				clers.push_back(END);
+				front[(size_t)eprev].deleted = true; front[(size_t)enext].deleted = true;
+				front[pe.prev].next = ne.next; front[ne.next].prev = pe.prev;
+				new_edge = -1;
+			} else if(close_left) {
+				clers.push_back(LEFT);
+				front[(size_t)eprev].deleted = true;
+				front[pe.prev].next = (uint32_t)new_edge; front[(size_t)enext].prev = (uint32_t)new_edge;
+				front.push_back(CEdge{of, (uint32_t)k1, pe.prev, (uint32_t)enext, false});
+			} else if(close_right) {
+				clers.push_back(RIGHT);
+				front[(size_t)enext].deleted = true;
+				front[ne.next].prev = (uint32_t)new_edge; front[(size_t)eprev].next = (uint32_t)new_edge;
+				front.push_back(CEdge{of, (uint32_t)k0, (uint32_t)eprev, ne.next, false});
+			} else {
+				const uint32_t v0 = face.f[k0], v1 = face.f[k1], opp = face.f[k2];
+				if(encoded[opp] != -1 && order < faceorder.size()) { delayed.push_back(c); clers.push_back(DELAY); new_edge = -1; continue; }
+				if(encoded[opp] != -1) { clers.push_back(SPLIT); split.write((uint32_t)encoded[opp], splitbits); }
+				else {
+					clers.push_back(VERTEX);
+					const uint32_t v2 = mf[e.face].f[e.side];
+					prediction[current_vertex] = Quad{opp, v0, v1, v2};
+					encoded[opp] = (int)current_vertex++;
+					last_index = opp;
+				}
+				front[(size_t)eprev].next = (uint32_t)new_edge; front[(size_t)enext].prev = (uint32_t)new_edge + 1;
+				front.push_back(CEdge{of, (uint32_t)k0, (uint32_t)eprev, (uint32_t)new_edge + 1, false});
+				faceorder.push_back((int)front.size());
+				front.push_back(CEdge{of, (uint32_t)k1, (uint32_t)new_edge, (uint32_t)enext, false});
+			}
+			visited[of] = true; totfaces--;
+		}
+		max_front = std::max(max_front, (uint32_t)front.size());
+	}
+
+	// NormalAttr::preDelta (normal_attribute.cpp:113-143): uses ORIGINAL vertex ids and quantised positions
+	void normal_predelta(Attr &a) {
+		if(a.prediction == 0) return;
+		auto it = data.find("position");
+		const std::vector<int32_t> &coords = it->second.values;
+		std::vector<float> est((size_t)nvert*3, 0.f);
+		a.boundary.assign(nvert, 0);
+		for(uint32_t f = 0; f < nface; f++) {
+			const uint32_t i0 = faces[(size_t)f*3], i1 = faces[(size_t)f*3 + 1], i2 = faces[(size_t)f*3 + 2];
+			const int32_t *p0 = &coords[(size_t)i0*3], *p1 = &coords[(size_t)i1*3], *p2 = &coords[(size_t)i2*3];
+			const float ax = (float)p1[0] - (float)p0[0], ay = (float)p1[1] - (float)p0[1], az = (float)p1[2] - (float)p0[2];
+			const float bx = (float)p2[0] - (float)p0[0], by = (float)p2[1] - (float)p0[1], bz = (float)p2[2] - (float)p0[2];
+			const float n[3] = {ay*bz - az*by, az*bx - ax*bz, ax*by - ay*bx};
+			for(int k = 0; k < 3; k++) est[(size_t)i0*3 + k] += n[k];
+			for(int k = 0; k < 3; k++) est[(size_t)i1*3 + k] += n[k];
+			for(int k = 0; k < 3; k++) est[(size_t)i2*3 + k] += n[k];
+			if(a.prediction == 2) {
+				a.boundary[i0] ^= (int32_t)i1; a.boundary[i0] ^= (int32_t)i2; a.boundary[i1] ^= (int32_t)i2;
+				a.boundary[i1] ^= (int32_t)i0; a.boundary[i2] ^= (int32_t)i0; a.boundary[i2] ^= (int32_t)i1;
+			}
+		}
+		const int unit = f2i(a.q);
+		for(uint32_t i = 0; i < nvert; i++) {
+			int32_t o[2]; to_octa(&est[(size_t)i*3], unit, o);
+			a.values[(size_t)i*2] = (int32_t)((uint32_t)a.values[(size_t)i*2] - (uint32_t)o[0]);
+			a.values[(size_t)i*2 + 1] = (int32_t)((uint32_t)a.values[(size_t)i*2 + 1] - (uint32_t)o[1]);
+		}
+	}
+
+	void delta_encode(Attr &a) {
+		const std::vector<Quad> &ctx = prediction;
+		if(a.codec == CRTHIP_CODEC_NORMAL) {                                            // normal_attribute.cpp:145-176
+			if(a.prediction == 0) {
+				a.diffs.assign(ctx.size()*2, 0);
+				if(ctx.empty()) return;
+				a.diffs[0] = a.values[(size_t)ctx[0].t*2]; a.diffs[1] = a.values[(size_t)ctx[0].t*2 + 1];
+				for(size_t i = 1; i < ctx.size(); i++) for(int c = 0; c < 2; c++)
+					a.diffs[i*2 + c] = (int32_t)((uint32_t)a.values[(size_t)ctx[i].t*2 + c] - (uint32_t)a.values[(size_t)ctx[i].a*2 + c]);
+			} else {
+				a.diffs.clear();
+				for(const Quad &q : ctx) if(a.prediction != 2 || a.boundary[q.t] != 0) { a.diffs.push_back(a.values[(size_t)q.t*2]); a.diffs.push_back(a.values[(size_t)q.t*2 + 1]); }
+			}
+			return;
+		}
+		const int N = a.N;
+		if(a.codec == CRTHIP_CODEC_COLOR) {                                             // GenericAttr<uchar>::deltaEncode, strategy 0
+			a.cdiffs.assign(ctx.size()*(size_t)N, 0);
+			if(ctx.empty()) return;
+			for(int c = 0; c < N; c++) a.cdiffs[c] = a.cvalues[(size_t)ctx[0].t*N + c];
+			for(size_t i = 1; i < ctx.size(); i++) {
+				const Quad &q = ctx[i];
+				for(int c = 0; c < N; c++) {
+					if(q.a != q.b && (a.strategy & CRTHIP_PARALLEL)) a.cdiffs[i*N + c] = (uint8_t)(a.cvalues[(size_t)q.t*N + c] - (a.cvalues[(size_t)q.a*N + c] + a.cvalues[(size_t)q.b*N + c] - a.cvalues[(size_t)q.c*N + c]));
+					else a.cdiffs[i*N + c] = (uint8_t)(a.cvalues[(size_t)q.t*N + c] - a.cvalues[(size_t)q.a*N + c]);
+				}
+			}
+			return;
+		}
+		a.diffs.assign(ctx.size()*(size_t)N, 0);                                        // vertex_attribute.h:130-144
+		if(ctx.empty()) return;
+		for(int c = 0; c < N; c++) a.diffs[c] = a.values[(size_t)ctx[0].t*N + c];
+		for(size_t i = 1; i < ctx.size(); i++) {
+			const Quad &q = ctx[i];
+			for(int c = 0; c < N; c++) {
+				const uint32_t t = (uint32_t)a.values[(size_t)q.t*N + c], va = (uint32_t)a.values[(size_t)q.a*N + c];
+				if(q.a != q.b && (a.strategy & CRTHIP_PARALLEL)) a.diffs[i*N + c] = (int32_t)(t - (va + (uint32_t)a.values[(size_t)q.b*N + c] - (uint32_t)a.values[(size_t)q.c*N + c]));
+				else a.diffs[i*N + c] = (int32_t)(t - va);
+			}
+		}
+	}
+
+	void attr_encode(Attr &a) {
+		if(a.codec == CRTHIP_CODEC_NORMAL) { s.u8((uint32_t)a.prediction); put_array(s, entropy, (uint32_t)(a.diffs.size()/2), a.diffs.data(), 2); return; }
+		if(a.codec == CRTHIP_CODEC_COLOR) {
+			for(int c = 0; c < a.N; c++) s.u8((uint32_t)a.qc[c]);
+			put_values<int8_t>(s, entropy, nvert, (const int8_t *)a.cdiffs.data(), a.N);
+			return;
+		}
+		if(a.strategy & CRTHIP_CORRELATED) put_array(s, entropy, nvert, a.diffs.data(), a.N);
+		else put_values<int32_t>(s, entropy, nvert, a.diffs.data(), a.N);
+	}
+
+	void header() {                                                                    // src/encoder.cpp:207-229
+		s.u32(0x787A6300); s.u32(1); s.u8(entropy);
+		s.u32((uint32_t)exif.size());
+		for(auto &kv : exif) { s.str(kv.first); s.str(kv.second); }
+		s.u32((uint32_t)data.size());
+		for(auto &kv : data) { const Attr &a = kv.second; s.str(kv.first); s.u32((uint32_t)a.codec); s.f32(a.q); s.u8((uint32_t)a.N); s.u8((uint32_t)a.format); s.u8((uint32_t)a.strategy); }
+	}
+
+	void groups() { s.u32((uint32_t)group_end.size()); for(uint32_t g : group_end) { s.u32(g); s.u8(0); } }
+
+	void encode_mesh() {                                                               // src/encoder.cpp:311-381
+		encoded.assign(nvert, -1);
+		if(group_end.empty()) group_end.push_back(nface);
+		uint32_t start = 0, count = 0;
+		for(uint32_t &g : group_end) {
+			for(uint32_t i = start; i < g; i++) {
+				const uint32_t *f = &faces[(size_t)i*3];
+				if(f[0] == f[1] || f[0] == f[2] || f[1] == f[2]) continue;
+				if(count != i) { faces[(size_t)count*3] = f[0]; faces[(size_t)count*3 + 1] = f[1]; faces[(size_t)count*3 + 2] = f[2]; }
+				count++;
+			}
+			start = g; g = count;
+		}
+		faces.resize((size_t)count*3);
+		nface = count;
+		prediction.assign(nvert, Quad{0, 0, 0, 0});
+		start = 0;
+		for(uint32_t g : group_end) { encode_faces((int)start, (int)g); start = g; }
+		for(auto &kv : data) if(kv.second.codec == CRTHIP_CODEC_NORMAL) normal_predelta(kv.second);
+		nvert = current_vertex;
+		prediction.resize(nvert);
+		for(auto &kv : data) delta_encode(kv.second);
+		s.u32(nvert); s.u32(nface);
+		groups();
+		s.u32(max_front);
+		put_symbols(s, entropy, clers.data(), (uint32_t)clers.size());
+		split.emit(s);
+		for(auto &kv : data) attr_encode(kv.second);
+	}
+
+	struct ZPoint { uint64_t bits; uint32_t pos; bool operator<(const ZPoint &z) const { return bits > z.bits; } };
+
+	void encode_cloud() {                                                              // src/encoder.cpp:238-296
+		const std::vector<int32_t> &coords = data.find("position")->second.values;
+		int32_t mn[3] = {0, 0, 0};
+		for(uint32_t i = 0; i < nvert; i++) for(int k = 0; k < 3; k++) mn[k] = std::min(mn[k], coords[(size_t)i*3 + k]);
+		std::vector<ZPoint> z(nvert);
+		for(uint32_t i = 0; i < nvert; i++) {
+			const uint64_t x = (uint64_t)(int64_t)(coords[(size_t)i*3] - mn[0]), y = (uint64_t)(int64_t)(coords[(size_t)i*3 + 1] - mn[1]), w = (uint64_t)(int64_t)(coords[(size_t)i*3 + 2] - mn[2]);
+			uint64_t bits = 0; const uint64_t l = 1;
+			for(int k = 0; k < 21; k++) bits |= (x & l << k) << (2*k) | (y & l << k) << (2*k + 1) | (w & l << k) << (2*k + 2);   // include/corto/zpoint.h:34-38
+			z[i] = ZPoint{bits, i};
+		}
+		std::sort(z.rbegin(), z.rend());
+		s.u32(nvert); s.u32(0);
+		groups();
+		prediction.resize(nvert);
+		if(nvert) prediction[0] = Quad{z[0].pos, 0xffffffff, 0xffffffff, 0xffffffff};
+		for(uint32_t i = 1; i < nvert; i++) prediction[i] = Quad{z[i].pos, z[i - 1].pos, z[i - 1].pos, z[i - 1].pos};
+		for(auto &kv : data) if(kv.second.codec == CRTHIP_CODEC_NORMAL) normal_predelta(kv.second);
+		for(auto &kv : data) delta_encode(kv.second);
+		for(auto &kv : data) attr_encode(kv.second);
+	}
+};
+
+} // namespace
+
+extern "C" {
+
+
+// Encode a mesh / point cloud into a .crt blob (host only).  Returns the blob size (also when out == NULL or cap is too
+// small: call twice), or <0.  out_nvert/out_nface = counts after unreferenced vertices / degenerate faces are dropped.
+int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface) {
+	if(!m || !m->position) return CRTHIP_E_ARGUMENT;
+	Encoder E;
+	E.nvert = m->nvert; E.nface = m->index ? m->nface : 0; E.entropy = (uint32_t)m->entropy;
+	const char *p = m->exif;
+	for(uint32_t i = 0; i < m->nexif; i++) { std::string k(p); p += k.size() + 1; std::string v(p); p += v.size() + 1; E.exif[k] = v; }
+	for(uint32_t g = 0; g < m->ngroups; g++) E.group_end.push_back(m->group_end[g]);
+	if(E.nface) E.faces.assign(m->index, m->index + (size_t)E.nface*3);
+	const uint32_t nv = m->nvert;
+	{	// positions (src/encoder.cpp:49-100, vertex_attribute.h:79-128)
+		float q = m->position_q;
+		if(m->position_bits > 0) {
+			float mn[3] = {m->position[0], m->position[1], m->position[2]}, mx[3] = {mn[0], mn[1], mn[2]};
+			for(uint32_t i = 0; i < nv; i++) for(int k = 0; k < 3; k++) { const float v = m->position[(size_t)i*3 + k]; if(v < mn[k]) mn[k] = v; if(v > mx[k]) mx[k] = v; }
+			const float intervals = powf(2.0f, (float)m->position_bits);
+			float e[3]; for(int k = 0; k < 3; k++) { e[k] = mx[k] - mn[k]; e[k] /= intervals; }
+			q = std::max(std::max(e[0], e[1]), e[2]);
+		}
+		Attr &a = E.data["position"];
+		a.name = "position"; a.N = 3; a.q = q; a.format = CRTHIP_FMT_FLOAT;
+		a.strategy = CRTHIP_CORRELATED | (E.nface > 0 ? CRTHIP_PARALLEL : 0);
+		a.values.resize((size_t)nv*3);
+		for(size_t i = 0; i < (size_t)nv*3; i++) a.values[i] = f2i((m->position[i] - 0.0f)/q);
+	}
+	if(m->normal) {
+		Attr &a = E.data["normal"];
+		a.name = "normal"; a.codec = CRTHIP_CODEC_NORMAL; a.N = 3; a.q = powf(2.0f, (float)(m->normal_bits - 1));
+		a.format = CRTHIP_FMT_FLOAT; a.strategy = CRTHIP_CORRELATED; a.prediction = m->normal_prediction;
+		a.values.resize((size_t)nv*2);
+		const int unit = f2i(a.q);
+		for(uint32_t i = 0; i < nv; i++) to_octa(m->normal + (size_t)i*3, unit, &a.values[(size_t)i*2]);
+	}
+	if(m->color) {
+		Attr &a = E.data["color"];
+		a.name = "color"; a.codec = CRTHIP_CODEC_COLOR; a.N = m->color_components; a.format = CRTHIP_FMT_UINT8; a.strategy = 0; a.q = 0;
+		for(int k = 0; k < 3; k++) a.qc[k] = 1 << (8 - m->color_bits[k]);
+		a.qc[3] = m->color_components == 3 ? 1 : 1 << (8 - m->color_bits[3]);           // addColors3: setQ(r, g, b, 8)
+		a.cvalues.resize((size_t)nv*a.N);
+		for(uint32_t i = 0; i < nv; i++) {                                              // color_attribute.cpp:30-44, point.h:213
+			uint8_t y[4] = {0, 0, 0, 0};
+			for(int k = 0; k < a.N; k++) y[k] = (uint8_t)(m->color[(size_t)i*a.N + k]/a.qc[k]);
+			const uint8_t ycc[4] = {y[1], (uint8_t)(y[2] - y[1]), (uint8_t)(y[0] - y[1]), y[3]};
+			for(int k = 0; k < a.N; k++) a.cvalues[(size_t)i*a.N + k] = ycc[k];
+		}
+	}
+	auto generic = [&](const char *name, const float *buf, int N, float q) {
+		Attr &a = E.data[name];
+		a.name = name; a.N = N; a.q = q; a.format = CRTHIP_FMT_FLOAT; a.strategy = 0;
+		a.values.resize((size_t)nv*N);
+		for(size_t i = 0; i < (size_t)nv*N; i++) a.values[i] = f2i(buf[i]/q);
+	};
+	if(m->uv) generic("uv", m->uv, 2, m->uv_q);
+	if(m->radius) generic("radius", m->radius, 1, m->radius_q);
+	E.header();
+	if(E.nface > 0) E.encode_mesh(); else E.encode_cloud();
+	if(out_nvert) *out_nvert = E.nvert;
+	if(out_nface) *out_nface = E.nface;
+	if(out && cap >= E.s.b.size()) memcpy(out, E.s.b.data(), E.s.b.size());
+	return (int64_t)E.s.b.size();
+}
+
+} // extern "C"

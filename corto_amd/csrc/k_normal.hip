@@ -208,7 +208,6 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	CRT_LDS uint32_t *slot = bnd + nv;
 	CRT_LDS uint16_t *adj = (CRT_LDS uint16_t *)(slot + nv + 1);
 	__shared__ uint32_t scan_s[4];
-	__shared__ uint32_t carry_s;
 	CRT_GLOBAL const int32_t *gpos = as_global(J.position);
 	CRT_GLOBAL const uint32_t *f32 = J.faces_u16 ? nullptr : as_global((const uint32_t *)J.faces);
 	CRT_GLOBAL const uint16_t *f16 = J.faces_u16 ? as_global((const uint16_t *)J.faces) : nullptr;

@@ -142,6 +142,35 @@ int crthip_batch_sync(crthip_batch *b, int32_t *status);
 int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
                        void *index, uint32_t index_format);
 
+/* ---- .crt writer (host only) -------------------------------------------------------------
+ * Byte-identical to upstream's crt::Encoder (src/encoder.cpp:207-722) for positions, normals (all three predictions),
+ * rgb/rgba colours, uvs, one generic "radius" attribute, groups, exif, entropy NONE/TUNSTALL, meshes and point clouds.
+ * Lets tests and bench.py synthesise inputs without the reference library. */
+typedef struct {
+	uint32_t nvert, nface;
+	const float *position;        /* nvert*3, required */
+	const uint32_t *index;        /* nface*3, NULL for point clouds */
+	int32_t position_bits;        /* >0: step = max extent / 2^bits (Encoder::addPositionsBits); else position_q */
+	float position_q;
+	const float *normal;          /* nvert*3 or NULL */
+	int32_t normal_bits;
+	int32_t normal_prediction;    /* 0 DIFF, 1 ESTIMATED, 2 BORDER */
+	const uint8_t *color;         /* nvert*color_components or NULL */
+	int32_t color_components;     /* 3 or 4 */
+	int32_t color_bits[4];
+	const float *uv;              /* nvert*2 or NULL */
+	float uv_q;
+	const float *radius;          /* nvert or NULL */
+	float radius_q;
+	const uint32_t *group_end;    /* ngroups end-face markers or NULL */
+	uint32_t ngroups;
+	int32_t entropy;              /* CRTHIP_ENTROPY_* */
+	const char *exif;             /* "k\0v\0..." nexif pairs or NULL */
+	uint32_t nexif;
+} crthip_mesh;
+/* returns the blob size (also when out == NULL or cap is too small), or <0 */
+int64_t crthip_encode(const crthip_mesh *mesh, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface);
+
 /* ---- measurement / test hooks (not needed by integrators) ---- */
 typedef struct {
 	uint64_t arena_bytes;       /* compressed input resident in HBM */
@@ -152,6 +181,8 @@ typedef struct {
 	uint32_t tunstall_streams;
 	uint64_t total_nvert, total_nface;
 	uint64_t scratch_bytes;
+	uint64_t clers_symbols;     /* decoded CLERS symbols over all mesh blobs */
+	uint64_t split_bytes;       /* bytes of the split / vertex-id bit blocks */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

@@ -27,29 +27,8 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def cases():
-    S = synth
-    two_groups = S.bumpy_sphere(32, 16, seed=11)
-    two_groups.groups = [400, two_groups.nface]
-    multi = S.merge([S.closed_sphere(20, 10, seed=1), S.torus(16, 8, seed=2), S.holey_disc(14, seed=3, color_components=4)])
-    radius = S.bumpy_sphere(24, 12, seed=21)
-    radius.radius = (0.25 + np.arange(radius.nvert, dtype=np.float32) % 17).reshape(-1, 1)
-    return [
-        # name, mesh, encode kwargs
-        ("pos_only", S.bumpy_sphere(64, 32, seed=1), dict(with_normal=False, with_color=False, with_uv=False)),
-        ("nrm_diff", S.bumpy_sphere(64, 32, seed=2), dict(normal_prediction=rc.DIFF, with_color=False)),
-        ("nrm_estimated_rgb", S.bumpy_sphere(64, 32, seed=3, color_components=3), dict(normal_prediction=rc.ESTIMATED)),
-        ("c4_unit", S.bumpy_sphere(64, 32, seed=0), dict(normal_prediction=rc.BORDER)),
-        ("two_groups", two_groups, dict(normal_prediction=rc.BORDER)),
-        ("holey_disc", S.shuffled(S.holey_disc(40, seed=5), seed=3), dict(normal_prediction=rc.BORDER)),
-        ("multi_component", multi, dict(normal_prediction=rc.ESTIMATED)),
-        ("torus", S.torus(48, 24, seed=4), dict(normal_prediction=rc.BORDER)),
-        ("closed_sphere", S.closed_sphere(32, 16, seed=6), dict(normal_prediction=rc.DIFF)),
-        ("radius_attr", radius, dict(normal_prediction=rc.BORDER, exif={"mtllib": "a.mtl", "note": "x"})),
-        ("entropy_none", S.bumpy_sphere(32, 16, seed=9), dict(normal_prediction=rc.BORDER, entropy=0)),
-        ("cloud_diff", S.point_cloud(96, 64, seed=7), dict(normal_prediction=rc.DIFF)),
-        ("cloud_border", S.point_cloud(40, 20, seed=8), dict(normal_prediction=rc.BORDER)),
-    ]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cases import cases  # noqa: E402
 
 
 def main():

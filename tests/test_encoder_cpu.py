@@ -1,0 +1,77 @@
+"""CPU: the repo's own .crt writer (corto_amd/csrc/encoder.cpp, C ABI crthip_encode) is byte-identical to the REFERENCE
+encoder: against the golden blobs the reference produced (always), and against the reference itself on a random corpus
+(only where oracle/_ref exists)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import corto_amd as ca
+from conftest import GOLDEN, ROOT, load_golden
+from corto_amd import synth
+
+sys.path.insert(0, GOLDEN)
+from cases import cases  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(ca.LIB_PATH):
+        from corto_amd import build
+        build.build()
+
+
+def test_byte_identical_to_reference_made_fixtures():
+    for name, mesh, kw in cases():
+        g = load_golden(name)
+        mine = ca.encode(mesh, **kw)
+        assert len(mine) == len(g["crt"]) and mine.tobytes() == g["crt"].tobytes(), name
+
+
+def test_c4_units_and_mid_mesh():
+    z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
+    for seed in range(16):
+        mine = ca.encode(synth.bumpy_sphere(64, 32, seed=seed), normal_prediction=ca.BORDER)
+        assert mine.tobytes() == z["crt_%02d" % seed].tobytes(), seed
+    g = load_golden("mid34k_digest")
+    mine = ca.encode(synth.bumpy_sphere(260, 130, seed=34), normal_prediction=ca.BORDER)
+    assert mine.tobytes() == g["crt"].tobytes()
+
+
+def test_roundtrip_through_the_oracle_decoder():
+    """encode (ours) -> decode (C oracle): positions come back as the quantised inputs, in the encoder's vertex order"""
+    from oracle import oracle as oc
+    m = synth.torus(20, 10, seed=3)
+    blob = ca.encode(m, normal_prediction=ca.DIFF)
+    out = oc.decode(blob)
+    info = ca.probe(blob)
+    q = [a["q"] for a in info.attrs() if a["name"] == "position"][0]
+    want = np.sort((np.trunc(m.position / np.float32(q)).astype(np.int64)).view([("", np.int64)] * 3), axis=0)
+    got = np.sort(np.rint(out["position"] / np.float32(q)).astype(np.int64).view([("", np.int64)] * 3), axis=0)
+    assert np.array_equal(want, got)
+    assert out["index"].shape == (m.nface, 3)
+
+
+def test_random_corpus_against_reference():
+    from oracle import refcodec as rc
+    if not rc.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    S = synth
+    rng = np.random.default_rng(5)
+    meshes = []
+    for seed in range(5):
+        meshes += [S.bumpy_sphere(6 + 9 * seed, 3 + 6 * seed, seed), S.shuffled(S.holey_disc(5 + 7 * seed, seed, hole_frac=0.04 + 0.06 * seed), seed),
+                   S.torus(5 + 6 * seed, 4 + 3 * seed, seed, color_components=3), S.closed_sphere(4 + 5 * seed, 3 + 3 * seed, seed),
+                   S.point_cloud(5 + 20 * seed, 3 + 11 * seed, seed)]
+    meshes.append(S.merge([S.closed_sphere(9, 5, 1), S.closed_sphere(7, 4, 2), S.torus(8, 5, 3), S.holey_disc(9, 4, color_components=4)]))
+    for i, m in enumerate(meshes):
+        for pred in (0, 1, 2):
+            kw = dict(position_bits=int(rng.integers(8, 20)), normal_bits=int(rng.integers(6, 14)), uv_bits=int(rng.integers(8, 14)),
+                      normal_prediction=pred, entropy=int(i % 4 != 3))
+            a, b = ca.encode(m, **kw), rc.encode(m, **kw)
+            assert a.tobytes() == b.tobytes(), (i, pred, kw)
+    # explicit quantisation step instead of bits, groups, exif
+    m = S.bumpy_sphere(20, 10, 3); m.groups = [100, 250, m.nface]
+    kw = dict(position_bits=0, position_q=0.0137, exif={"a": "b"})
+    assert ca.encode(m, **kw).tobytes() == rc.encode(m, **kw).tobytes()
