@@ -662,7 +662,7 @@ static int build_and_launch(crthip_batch *b) {
 		if(n.prediction != 0 && !n.fused) for(uint32_t c = 0; c < (n.nface + 255)/256; c++) pl.nf_block_job.v.push_back(j);
 	}
 
-	pl.tun_partial_off = cv.take(((uint64_t)tun_chunks + 1)*8);
+	pl.tun_partial_off = cv.take(((uint64_t)tun_chunks*4 + 4)*8);
 	pl.unpack_partial_off = cv.take(((uint64_t)unpack_chunks + 1)*8);
 	pl.cloud_partial_off = cv.take(((uint64_t)cloud_chunks + 1)*8);
 
@@ -764,7 +764,7 @@ static int build_and_launch(crthip_batch *b) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
 		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables); LT.end();
 		LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial, 0u); LT.end();
-		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks); LT.end();
+		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end();
 		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode_staged, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial, 0u); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
@@ -1003,7 +1003,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		tun.push_back(t);
 	}
 	Carver cv;
-	const uint64_t o_tab = cv.take(tun.size()*sizeof(TunTable)), o_part = cv.take(((uint64_t)chunks + 1)*8);
+	const uint64_t o_tab = cv.take(tun.size()*sizeof(TunTable)), o_part = cv.take(((uint64_t)chunks*4 + 4)*8);
 	const uint64_t o_jobs = cv.take(0);
 	const uint64_t o_tun = cv.take(tun.size()*sizeof(TunStream) + 16, 16), o_cs = cv.take(chunk_stream.size()*4 + 16, 16), o_fill = cv.take(fills.size()*sizeof(FillJob) + 16, 16);
 	const uint64_t total = cv.take(0);
@@ -1023,7 +1023,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables); LT.end();
 		if(multi) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u); LT.end();
-			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks); LT.end();
+			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end();
 		}
 		LT.begin("tunstall_decode");
 		if(multi) hipLaunchKernelGGL(k_tun_decode_staged, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u);

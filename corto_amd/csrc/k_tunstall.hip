@@ -211,7 +211,7 @@ __device__ __forceinline__ void tun_load_table(TunLds &L, const TunTable &T, uin
 	for(uint32_t i = t; i < ndw; i += 256) dst32[i] = src32[i];
 }
 
-// pass A: per-chunk decoded byte count
+// pass A: decoded byte count of every quarter chunk (one wave's share of a chunk in pass B): chunk_out[4*c + w]
 __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                         uint32_t nchunks, const TunTable *__restrict__ tables,
                                                         uint32_t chunk_codes, uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
@@ -220,18 +220,25 @@ __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restr
 	const TunStream st = streams[chunk_stream[c]];
 	const TunTable &T = tables[st.table];
 	__shared__ uint8_t len[256];
-	__shared__ uint32_t red[4];
 	len[threadIdx.x] = T.len[threadIdx.x];
 	__syncthreads();
-	const uint32_t first = (c - st.chunk0)*chunk_codes;
-	const uint32_t last = min(first + chunk_codes, st.csize);
+	const uint32_t quarter = chunk_codes/4, w = wave_id(), lane = lane_id();
+	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
+	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
+	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	uint32_t sum = 0;
-	for(uint32_t j = first + threadIdx.x; j < last; j += 256) sum += len[st.src[j]];
-#pragma unroll
-	for(int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-	if(lane_id() == 0) red[wave_id()] = sum;
-	__syncthreads();
-	if(threadIdx.x == 0) chunk_out[c] = (uint64_t)red[0] + red[1] + red[2] + red[3];
+	const uint32_t head = min((uint32_t)((0u - (uint32_t)(uintptr_t)(st.src + first)) & 3u), last - first);   // aligned dword body, byte head/tail
+	if(lane < head) sum += len[src[first + lane]];
+	const uint32_t body0 = first + head, ndw = (last - body0) >> 2;
+	CRT_GLOBAL const uint32_t *src32 = (CRT_GLOBAL const uint32_t *)(src + body0);
+	for(uint32_t i = lane; i < ndw; i += 64) {
+		const uint32_t x = src32[i];
+		sum += (uint32_t)len[x & 255u] + len[(x >> 8) & 255u] + len[(x >> 16) & 255u] + len[x >> 24];
+	}
+	const uint32_t tail0 = body0 + ndw*4;
+	if(tail0 + lane < last) sum += len[src[tail0 + lane]];
+	sum = wave_inclusive_scan_u32(sum);
+	if(lane == 63) chunk_out[(size_t)c*4 + w] = sum;
 }
 
 // Emit one thread's run (its up-to-4 words back to back) at byte pointer d.  Table words are read as ALIGNED dwords
@@ -329,20 +336,19 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 	}
 }
 
-// pass B, long streams.  Per tile of 2048 codewords (8 per thread) the decoded bytes are composed in an LDS window laid
-// out at the destination's 16-byte phase and flushed with coalesced 16-byte stores (full lines to HBM).
-//   phase A, branch-free: every word has a zero-padded 16-byte copy (T16).  A thread reads it with one ds_read_b128, moves
-//            it to the word's byte phase with five v_perm_b32 and ORs the five dwords into the zeroed window with LDS
-//            atomics: neighbouring words touch disjoint bytes of a shared dword, so OR composes them with no ordering.
-//   phase B: the bytes beyond 16 of long words go through a small work list (position, table offset, count) that the whole
-//            workgroup drains, 16 bytes per thread per step - long words are rare in high-entropy streams but carry many
-//            bytes each in low-entropy ones, and this keeps phase A free of data-dependent loops.
-// The kernel is instruction-issue bound (PMC: SIMDs ~80 % busy), not bandwidth bound, hence the effort on instruction
-// count: barriers drain lgkmcnt only (lds_barrier) so stores stay in flight, and codewords are fetched one tile ahead.
-// A stream's clipped last tile, and tiles whose bytes exceed the window, take the general byte-FIFO path.
-constexpr uint32_t TUN_OUTBUF = 24*1024;
-constexpr uint32_t TUN_TILE8 = 2048;
-constexpr uint32_t TUN_LONG_CAP = 1024;
+// pass B, long streams.  WAVE-AUTONOMOUS: a workgroup shares the stream's table in LDS, but each of its four waves decodes
+// its own quarter of the chunk (output offset from pass A's per-quarter sums) with no workgroup barrier in the loop - in
+// a first version two block-wide scans per tile (barriers) were half of the kernel time.  Per sub-tile of 512 codewords
+// (8 per lane): lengths -> DPP wave scan -> compose the bytes in the wave's own LDS window, laid out at the destination's
+// 16-byte phase -> flush with 16-byte stores, one kilobyte per instruction.
+//   compose, branch-free: every word has a zero-padded 16-byte copy (T16); a lane reads it with one ds_read_b128, moves it
+//            to the word's byte phase with five v_perm_b32 and ORs the five dwords into the zeroed window with LDS atomics -
+//            neighbouring words touch disjoint bytes of a shared dword, so OR composes them with no ordering at all.
+//   long words (> 16 bytes): their further 16-byte pieces are ORed in by the owning lane in a compact loop.
+// LDS ordering inside one wave is program order, so the window needs no barrier, only the s_waitcnt the compiler places.
+// A stream's clipped last sub-tile, and sub-tiles whose bytes exceed the window, take the general byte-FIFO path.
+constexpr uint32_t TUN_WIN = 6*1024;             // per-wave window
+constexpr uint32_t TUN_SUB = 512;                // codewords per wave per step
 
 __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                            uint32_t nchunks, const TunTable *__restrict__ tables,
@@ -353,14 +359,10 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const TunTable &T = tables[st.table];
 	__shared__ TunLds L;
 	__shared__ __attribute__((aligned(16))) u32x4_t t16[256];
-	__shared__ __attribute__((aligned(16))) uint32_t outbuf[(TUN_OUTBUF + 64)/4];
-	__shared__ uint32_t longq[TUN_LONG_CAP];                   // (window byte position << 8 | bytes) , table offset in longo
-	__shared__ uint16_t longo[TUN_LONG_CAP];
-	__shared__ uint32_t nlong_s;
-	const uint32_t tid = threadIdx.x;
+	__shared__ __attribute__((aligned(16))) uint32_t winbuf[4][(TUN_WIN + 64)/4];
+	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	tun_load_table(L, T, T.used);
-	for(uint32_t i = tid; i < (TUN_OUTBUF + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(outbuf))[i] = u32x4_t{0, 0, 0, 0};
-	if(tid == 0) nlong_s = 0;
+	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(&winbuf[0][0]))[i] = u32x4_t{0, 0, 0, 0};
 	__syncthreads();
 	{	// zero-padded 16-byte copy of every word
 		const uint32_t wo = L.off[tid], wl = min((uint32_t)L.len[tid], 16u);
@@ -369,111 +371,85 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		t16[tid] = u32x4_t{d[0], d[1], d[2], d[3]};
 	}
 	__syncthreads();
-	const uint32_t first = (c - st.chunk0)*chunk_codes;
-	const uint32_t last = min(first + chunk_codes, st.csize);
-	uint64_t base = st.nchunks > 1 ? chunk_out[c] - chunk_out[st.chunk0] : 0;
+	const uint32_t quarter = chunk_codes/4;
+	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
+	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
+	uint64_t base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];
 	const uint64_t size = st.size;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
-	CRT_LDS uint32_t *out32 = as_lds(outbuf);
+	CRT_LDS uint32_t *out32 = as_lds(&winbuf[w][0]);
 	CRT_LDS const u32x4_t *t16l = (CRT_LDS const u32x4_t *)as_lds(t16);
 	CRT_LDS const uint8_t *len8 = as_lds(L.len);
 	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(L.bytes);
 
-	// codewords are fetched one tile ahead, 8 per thread as two (unaligned) dwords
-	auto fetch = [&](uint32_t j, uint32_t &lo, uint32_t &hi) {
+	auto fetch = [&](uint32_t j, uint32_t &lo, uint32_t &hi) {           // 8 codewords per lane as two (unaligned) dwords
 		lo = 0; hi = 0;
 		if(j + 8 <= last) { lo = *(CRT_GLOBAL const uint32_t *)(src + j); hi = *(CRT_GLOBAL const uint32_t *)(src + j + 4); }
 		else for(uint32_t k = 0; k < 8 && j + k < last; k++) { const uint32_t v = src[j + k]; if(k < 4) lo |= v << (8*k); else hi |= v << (8*(k - 4)); }
 	};
+	auto or16 = [&](uint32_t q, uint32_t x, uint32_t y, uint32_t z, uint32_t v) {   // OR 16 bytes into the window at byte q
+		const uint32_t sel = 0x07060504u - 0x01010101u*(q & 3u);           // v_perm selector: bytes (4-s .. 7-s) of {hi, lo}
+		CRT_LDS uint32_t *o = out32 + (q >> 2);
+		atomicOr((uint32_t *)(o + 0), __builtin_amdgcn_perm(x, 0u, sel));
+		atomicOr((uint32_t *)(o + 1), __builtin_amdgcn_perm(y, x, sel));
+		atomicOr((uint32_t *)(o + 2), __builtin_amdgcn_perm(z, y, sel));
+		atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(v, z, sel));
+		atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, v, sel));
+	};
 	uint32_t nlo, nhi;
-	fetch(first + 8*tid, nlo, nhi);
-	for(uint32_t tile = first; tile < last; tile += TUN_TILE8) {
-		const uint32_t j0 = tile + 8*tid;
+	fetch(first + 8*lane, nlo, nhi);                                    // codewords are fetched one step ahead
+	for(uint32_t tile = first; tile < last; tile += TUN_SUB) {
+		const uint32_t j0 = tile + 8*lane;
 		const uint32_t clo = nlo, chi = nhi;
-		fetch(j0 + TUN_TILE8, nlo, nhi);
-		uint32_t code[8], l[8], sum = 0, lmax = 0;
+		fetch(j0 + TUN_SUB, nlo, nhi);
+		uint32_t code[8], l[8], sum = 0;
 #pragma unroll
 		for(int k = 0; k < 8; k++) {
 			code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
 			l[k] = j0 + k < last ? (uint32_t)len8[code[k]] : 0u;
-			sum += l[k]; lmax = max(lmax, l[k]);
+			sum += l[k];
 		}
-		uint32_t total;
-		const uint32_t orel = block256_exclusive_scan<uint32_t, true>(sum, L.scan, &total);
-		const bool fast = total + 32 <= TUN_OUTBUF && tile + TUN_TILE8 < st.csize && base + total <= size;
+		const uint32_t inc = wave_inclusive_scan_u32(sum);
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), orel = inc - sum;
+		const bool fast = total + 32 <= TUN_WIN && tile + TUN_SUB < st.csize && base + total <= size;
 		if(fast) {
 			CRT_GLOBAL uint8_t *g0 = gdst + base;
 			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
 			uint32_t p = phase + orel;
-			// ---- phase A ----
 #pragma unroll
 			for(int k = 0; k < 8; k++) {
-				u32x4_t w = t16l[code[k]];
-				if(l[k] == 0) w = u32x4_t{0, 0, 0, 0};                       // past the end of the chunk
-				const uint32_t sel = 0x07060504u - 0x01010101u*(p & 3u);      // v_perm selector: bytes (4-s .. 7-s) of {hi, lo}
-				CRT_LDS uint32_t *o = out32 + (p >> 2);
-				atomicOr((uint32_t *)(o + 0), __builtin_amdgcn_perm(w.x, 0u, sel));
-				atomicOr((uint32_t *)(o + 1), __builtin_amdgcn_perm(w.y, w.x, sel));
-				atomicOr((uint32_t *)(o + 2), __builtin_amdgcn_perm(w.z, w.y, sel));
-				atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(w.w, w.z, sel));
-				atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, w.w, sel));
+				u32x4_t x = t16l[code[k]];
+				if(l[k] == 0) x = u32x4_t{0, 0, 0, 0};                        // past the end of the quarter
+				or16(p, x.x, x.y, x.z, x.w);
+				if(l[k] > 16) {                                                  // rare: the rest of a long word, 16 bytes at a time
+					const uint32_t wo = L.off[code[k]];
+					for(uint32_t b0 = 16; b0 < l[k]; b0 += 16) {
+						CRT_LDS const uint32_t *s32 = tab32 + ((wo + b0) >> 2);
+						const uint32_t a = (wo + b0) & 3u, rem = min(l[k] - b0, 16u);
+						const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
+						uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
+						                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
+#pragma unroll
+						for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
+						or16(p + b0, d[0], d[1], d[2], d[3]);
+					}
+				}
 				p += l[k];
 			}
-			// ---- phase B: the tails of long words, through a work list drained by the whole workgroup ----
-			auto or_tail = [&](uint32_t q, uint32_t so, uint32_t rem) {       // rem <= 16 bytes from table offset so to window position q
-				CRT_LDS const uint32_t *s32 = tab32 + (so >> 2);
-				const uint32_t a = so & 3u;
-				const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
-				uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
-				                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
-#pragma unroll
-				for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
-				const uint32_t sel = 0x07060504u - 0x01010101u*(q & 3u);
-				CRT_LDS uint32_t *o = out32 + (q >> 2);
-				atomicOr((uint32_t *)(o + 0), __builtin_amdgcn_perm(d[0], 0u, sel));
-				atomicOr((uint32_t *)(o + 1), __builtin_amdgcn_perm(d[1], d[0], sel));
-				atomicOr((uint32_t *)(o + 2), __builtin_amdgcn_perm(d[2], d[1], sel));
-				atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(d[3], d[2], sel));
-				atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, d[3], sel));
-			};
-			if(lmax > 16) {
-				uint32_t q = phase + orel;
-#pragma unroll
-				for(int k = 0; k < 8; k++) {
-					if(l[k] > 16) {
-						const uint32_t np = (l[k] - 1) >> 4;                       // pieces beyond the first 16 bytes
-						const uint32_t at = atomicAdd(&nlong_s, np);
-						const uint32_t wo = L.off[code[k]];
-						for(uint32_t i = 0; i < np; i++) {
-							const uint32_t b0 = 16u*(i + 1), rem = min(l[k] - b0, 16u);
-							if(at + i < TUN_LONG_CAP) { longq[at + i] = ((q + b0) << 8) | rem; longo[at + i] = (uint16_t)(wo + b0); }
-							else or_tail(q + b0, wo + b0, rem);                      // list full: do it here
-						}
-					}
-					q += l[k];
-				}
-			}
-			lds_barrier();
-			const uint32_t nlong = min(nlong_s, TUN_LONG_CAP);
-			for(uint32_t i = tid; i < nlong; i += 256) { const uint32_t e = longq[i]; or_tail(e >> 8, longo[i], e & 255u); }
-			if(nlong) lds_barrier();
-			// ---- flush [0, total) and re-zero the window ----
+			// flush [0, total) and re-zero the window (same wave: LDS program order, no barrier)
 			CRT_LDS uint8_t *out = (CRT_LDS uint8_t *)out32 + phase;
 			const uint32_t n = total;
 			const uint32_t head = min((16u - phase) & 15u, n);
-			if(tid < head) g0[tid] = out[tid];
+			if(lane < head) g0[lane] = out[lane];
 			const uint32_t nvec = (n - head) >> 4;
 			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 + head);
 			CRT_LDS u32x4_t *lv = (CRT_LDS u32x4_t *)(out + head);
-			for(uint32_t i = tid; i < nvec; i += 256) { gv[i] = lv[i]; lv[i] = u32x4_t{0, 0, 0, 0}; }
+			for(uint32_t i = lane; i < nvec; i += 64) { gv[i] = lv[i]; lv[i] = u32x4_t{0, 0, 0, 0}; }
 			const uint32_t tail0 = head + (nvec << 4);
-			if(tail0 + tid < n) g0[tail0 + tid] = out[tail0 + tid];
-			lds_barrier();
-			if(tid < 4) out32[tid] = 0;                                        // head / tail dwords of the window
-			if(tid < 8) out32[((phase + tail0) >> 2) + tid] = 0;
-			if(tid == 0) nlong_s = 0;
-			lds_barrier();
+			if(tail0 + lane < n) g0[tail0 + lane] = out[tail0 + lane];
+			if(lane < 4) out32[lane] = 0;                                       // head / tail dwords of the window
+			if(lane < 8) out32[((phase + tail0) >> 2) + lane] = 0;
 		} else {
 			// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
 			uint64_t oo = base + orel;

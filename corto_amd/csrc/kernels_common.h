@@ -34,7 +34,22 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive +scan of a u32 across the 64 lanes of a wave with DPP row shifts / row broadcasts (gfx9): six v_add_u32 with a
+// DPP modifier.  The generic __shfl_up version below goes through ds_bpermute (an LDS-pipe round trip per step) and was half
+// of the Tunstall decode kernel's time.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+#define CRT_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false);
+	CRT_DPP_ADD(0x111, 0xf)     // row_shr:1
+	CRT_DPP_ADD(0x112, 0xf)     // row_shr:2
+	CRT_DPP_ADD(0x114, 0xf)     // row_shr:4
+	CRT_DPP_ADD(0x118, 0xf)     // row_shr:8   -> inclusive scan inside every 16-lane row
+	CRT_DPP_ADD(0x142, 0xa)     // row_bcast:15 into rows 1 and 3
+	CRT_DPP_ADD(0x143, 0xc)     // row_bcast:31 into rows 2 and 3
+#undef CRT_DPP_ADD
+	return v;
+}
+
+// inclusive scan across the 64 lanes of a wave (any additive type)
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v) {
 	const uint32_t lane = lane_id();
@@ -54,9 +69,12 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // exclusive scan over a 256-thread block (4 waves); *total = block sum. smem: 4 entries of T.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_any(uint32_t v) { return wave_inclusive_scan_u32(v); }
+template <typename T> __device__ __forceinline__ T wave_inclusive_scan_any(T v) { return wave_inclusive_scan(v); }
+
 template <typename T, bool LDS_ONLY = false>
 __device__ __forceinline__ T block256_exclusive_scan(T v, T *smem, T *total) {
-	T inc = wave_inclusive_scan(v);
+	T inc = wave_inclusive_scan_any(v);
 	const uint32_t lane = lane_id(), w = wave_id();
 	if(LDS_ONLY) lds_barrier(); else __syncthreads();                 // smem may still be read by a previous call
 	if(lane == 63) smem[w] = inc;
