@@ -83,7 +83,7 @@ def pmc_traffic(kernel):
     return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
 
 
-def tunstall_scaled(ctx, ca, z):
+def tunstall_scaled(ctx, ca, z, table_ids=None):
     """The Tunstall kernels on a run large enough to leave the launch-latency regime:
     64 streams x 4 Mi codewords with the dictionaries of real log streams, random codeword payloads."""
     import torch
@@ -93,7 +93,7 @@ def tunstall_scaled(ctx, ca, z):
     nstream, ncode = 64, 4 << 20
     blocks, sizes = [], []
     for i in range(nstream):
-        pr = kat["probs_%02d" % (7 + (i % 50))]
+        pr = kat["probs_%02d" % (table_ids[i % len(table_ids)] if table_ids else 7 + (i % 50))]
         _, ln, _ = oc.tunstall_tables(pr)
         payload = rng.integers(0, 256, ncode, dtype=np.uint8)
         size = int(ln[payload].sum(dtype=np.int64))

@@ -507,7 +507,7 @@ static int build_and_launch(crthip_batch *b) {
 		TunStream t{};
 		t.src = arena + blob_off + s.payload_off; t.dst = SP(sym_off); t.probs = arena + blob_off + s.probs_off;
 		t.csize = s.csize; t.size = s.size; t.nsym = s.nsym; t.table = (uint32_t)pl.tun.v.size();
-		t.chunk0 = tun_chunks; t.nchunks = (s.csize + TUN_CHUNK_CODES - 1)/TUN_CHUNK_CODES;
+		t.chunk0 = tun_chunks; tun_pick_geometry(t);
 		if(t.nchunks > 1) pl.tun_multi_chunk = true;
 		for(uint32_t c = 0; c < t.nchunks; c++) pl.tun_chunk_stream.v.push_back((uint32_t)pl.tun.v.size());
 		tun_chunks += t.nchunks;
@@ -737,7 +737,7 @@ static int build_and_launch(crthip_batch *b) {
 	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
 		if(t1 > t0) {
 			LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables); LT.end();
-			LT.begin("tunstall_decode", s); hipLaunchKernelGGL(k_tun_decode, dim3(c1 - c0), dim3(256), 0, s, D(pl.tun), D(pl.tun_chunk_stream), c1 - c0, tables, TUN_CHUNK_CODES, tun_partial, c0); LT.end();
+			LT.begin("tunstall_decode", s); hipLaunchKernelGGL(k_tun_decode, dim3(c1 - c0), dim3(256), 0, s, D(pl.tun), D(pl.tun_chunk_stream), c1 - c0, tables, tun_partial, c0); LT.end();
 		}
 		if(f1 > f0) { LT.begin("fill", s); hipLaunchKernelGGL(k_fill, dim3(f1 - f0), dim3(256), 0, s, D(pl.fill) + f0, f1 - f0); LT.end(); }
 	};
@@ -763,9 +763,9 @@ static int build_and_launch(crthip_batch *b) {
 	if(pl.tun_multi_chunk) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
 		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables); LT.end();
-		LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial, 0u); LT.end();
+		LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
 		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end();
-		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode_staged, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, TUN_CHUNK_CODES, tun_partial, 0u); LT.end();
+		LT.begin("tunstall_decode"); hipLaunchKernelGGL(k_tun_decode_staged, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
@@ -996,7 +996,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		if(ns == 0 || csize == 0) return fail(CRTHIP_E_TRUNCATED);
 		TunStream t{};
 		t.src = dblk + 9 + 2*ns; t.dst = dst; t.probs = dblk + 1; t.csize = csize; t.size = size; t.nsym = ns; t.table = (uint32_t)tun.size();
-		t.chunk0 = chunks; t.nchunks = (csize + TUN_CHUNK_CODES - 1)/TUN_CHUNK_CODES;
+		t.chunk0 = chunks; tun_pick_geometry(t);
 		if(t.nchunks > 1) multi = true;
 		for(uint32_t c = 0; c < t.nchunks; c++) chunk_stream.push_back((uint32_t)tun.size());
 		chunks += t.nchunks;
@@ -1022,12 +1022,12 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	if(ntun) {
 		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables); LT.end();
 		if(multi) {
-			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u); LT.end();
+			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
 			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end();
 		}
 		LT.begin("tunstall_decode");
-		if(multi) hipLaunchKernelGGL(k_tun_decode_staged, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u);
-		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, TUN_CHUNK_CODES, part, 0u);
+		if(multi) hipLaunchKernelGGL(k_tun_decode_staged, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
+		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
 		LT.end();
 	}
 	if(!fills.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)fills.size()), dim3(256), 0, st, (FillJob *)(base + o_fill), (uint32_t)fills.size()); LT.end(); }

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "kernels_common.h"
+#include "kernels.h"
 
 namespace corto_hip {
 
@@ -214,7 +215,7 @@ __device__ __forceinline__ void tun_load_table(TunLds &L, const TunTable &T, uin
 // pass A: decoded byte count of every quarter chunk (one wave's share of a chunk in pass B): chunk_out[4*c + w]
 __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                         uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                        uint32_t chunk_codes, uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+                                                        uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
 	const uint32_t c = blockIdx.x + chunk_base;
 	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void k_tun_chunk_sums(const TunStream *__restr
 	__shared__ uint8_t len[256];
 	len[threadIdx.x] = T.len[threadIdx.x];
 	__syncthreads();
-	const uint32_t quarter = chunk_codes/4, w = wave_id(), lane = lane_id();
+	const uint32_t chunk_codes = st.chunk_codes, quarter = chunk_codes/4, w = wave_id(), lane = lane_id();
 	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
 	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
@@ -314,7 +315,7 @@ __device__ __forceinline__ void tun_tile_prepare(TunTile &t, const TunStream &st
 // LDS-hungry topology kernel; runs are written straight to HBM.
 __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                     uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                    uint32_t chunk_codes, const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+                                                    const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
 	const uint32_t c = blockIdx.x + chunk_base;
 	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 	__shared__ TunLds L;
 	tun_load_table(L, T, T.used);
 	__syncthreads();
-	const uint32_t first = (c - st.chunk0)*chunk_codes;
-	const uint32_t last = min(first + chunk_codes, st.csize);
+	const uint32_t first = (c - st.chunk0)*st.chunk_codes;
+	const uint32_t last = min(first + st.chunk_codes, st.csize);
 	uint64_t base = st.nchunks > 1 ? chunk_out[c] - chunk_out[st.chunk0] : 0;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
@@ -349,10 +350,12 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 // A stream's clipped last sub-tile, and sub-tiles whose bytes exceed the window, take the general byte-FIFO path.
 constexpr uint32_t TUN_WIN = 6*1024;             // per-wave window
 constexpr uint32_t TUN_SUB = 512;                // codewords per wave per step
+constexpr uint32_t TUN_LONGQ = 64;               // per-wave queue of long words
+static_assert(2048 % (4*TUN_SUB) == 0 && TUN_CHUNK_CODES % 2048 == 0, "a wave's quarter chunk is whole steps (tun_pick_geometry)");
 
 __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                            uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                           uint32_t chunk_codes, const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+                                                           const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
 	const uint32_t c = blockIdx.x + chunk_base;
 	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	__shared__ TunLds L;
 	__shared__ __attribute__((aligned(16))) u32x4_t t16[256];
 	__shared__ __attribute__((aligned(16))) uint32_t winbuf[4][(TUN_WIN + 64)/4];
+	__shared__ uint32_t longbuf[4][TUN_LONGQ];
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	tun_load_table(L, T, T.used);
 	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(&winbuf[0][0]))[i] = u32x4_t{0, 0, 0, 0};
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		t16[tid] = u32x4_t{d[0], d[1], d[2], d[3]};
 	}
 	__syncthreads();
-	const uint32_t quarter = chunk_codes/4;
+	const uint32_t chunk_codes = st.chunk_codes, quarter = chunk_codes/4;
 	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
 	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
 	uint64_t base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];
@@ -397,46 +401,65 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(v, z, sel));
 		atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, v, sel));
 	};
-	uint32_t nlo, nhi;
-	fetch(first + 8*lane, nlo, nhi);                                    // codewords are fetched one step ahead
-	for(uint32_t tile = first; tile < last; tile += TUN_SUB) {
-		const uint32_t j0 = tile + 8*lane;
-		const uint32_t clo = nlo, chi = nhi;
-		fetch(j0 + TUN_SUB, nlo, nhi);
-		uint32_t code[8], l[8], sum = 0;
+	// long words (> 16 bytes): queued per wave as (window position | code << 16), their further 16-byte pieces ORed in by
+	// up to 64 lanes at once - inline in the loop above, one long word in any lane would make the whole wave walk this path
+	CRT_LDS uint32_t *longq = as_lds(&longbuf[w][0]);
+	auto drain_long = [&](uint32_t n) {
+		if(lane < n) {
+			const uint32_t e = longq[lane], q = e & 0xffffu, cd = e >> 16;
+			const uint32_t wo = L.off[cd], ln = len8[cd];
+			for(uint32_t b0 = 16; b0 < ln; b0 += 16) {
+				CRT_LDS const uint32_t *s32 = tab32 + ((wo + b0) >> 2);
+				const uint32_t a = (wo + b0) & 3u, rem = min(ln - b0, 16u);
+				const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
+				uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
+				                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
 #pragma unroll
-		for(int k = 0; k < 8; k++) {
-			code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
-			l[k] = j0 + k < last ? (uint32_t)len8[code[k]] : 0u;
-			sum += l[k];
+				for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
+				or16(q + b0, d[0], d[1], d[2], d[3]);
+			}
+		}
+	};
+	const uint32_t cpl = st.cpl, sub = 64*cpl;                          // codewords per lane / per wave in one step
+	uint32_t nlo, nhi;
+	fetch(first + cpl*lane, nlo, nhi);                                  // codewords are fetched one step ahead
+	for(uint32_t tile = first; tile < last; tile += sub) {
+		const uint32_t j0 = tile + cpl*lane;
+		const uint32_t clo = nlo, chi = nhi;
+		fetch(j0 + sub, nlo, nhi);
+		uint32_t code[8], l[8], sum = 0;
+		const bool full = tile + sub <= last;                              // wave-uniform; false only on a stream's last step
+#pragma unroll
+		for(int k = 0; k < 8; k++) code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
+		if(full) {
+#pragma unroll
+			for(int k = 0; k < 8; k++) { l[k] = (uint32_t)k < cpl ? (uint32_t)len8[code[k]] : 0u; sum += l[k]; }
+		} else {
+#pragma unroll
+			for(int k = 0; k < 8; k++) { l[k] = (uint32_t)k < cpl && j0 + k < last ? (uint32_t)len8[code[k]] : 0u; sum += l[k]; }
 		}
 		const uint32_t inc = wave_inclusive_scan_u32(sum);
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), orel = inc - sum;
-		const bool fast = total + 32 <= TUN_WIN && tile + TUN_SUB < st.csize && base + total <= size;
+		const bool fast = full && total + 32 <= TUN_WIN && tile + sub < st.csize && base + total <= size;
 		if(fast) {
 			CRT_GLOBAL uint8_t *g0 = gdst + base;
 			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
-			uint32_t p = phase + orel;
+			uint32_t p = phase + orel, nlong = 0;
 #pragma unroll
 			for(int k = 0; k < 8; k++) {
-				u32x4_t x = t16l[code[k]];
-				if(l[k] == 0) x = u32x4_t{0, 0, 0, 0};                        // past the end of the quarter
+				if((uint32_t)k >= cpl) break;
+				const u32x4_t x = t16l[code[k]];
 				or16(p, x.x, x.y, x.z, x.w);
-				if(l[k] > 16) {                                                  // rare: the rest of a long word, 16 bytes at a time
-					const uint32_t wo = L.off[code[k]];
-					for(uint32_t b0 = 16; b0 < l[k]; b0 += 16) {
-						CRT_LDS const uint32_t *s32 = tab32 + ((wo + b0) >> 2);
-						const uint32_t a = (wo + b0) & 3u, rem = min(l[k] - b0, 16u);
-						const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
-						uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
-						                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
-#pragma unroll
-						for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
-						or16(p + b0, d[0], d[1], d[2], d[3]);
-					}
+				const bool lg = l[k] > 16;                                       // queue the rest of a long word
+				const uint64_t m = __ballot(lg);
+				if(m) {
+					if(nlong + (uint32_t)__popcll(m) > TUN_LONGQ) { drain_long(nlong); nlong = 0; }
+					if(lg) longq[nlong + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = p | code[k] << 16;
+					nlong += (uint32_t)__popcll(m);
 				}
 				p += l[k];
 			}
+			if(nlong) drain_long(nlong);
 			// flush [0, total) and re-zero the window (same wave: LDS program order, no barrier)
 			CRT_LDS uint8_t *out = (CRT_LDS uint8_t *)out32 + phase;
 			const uint32_t n = total;
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 					const int kk = 4*h + k;
 					uint32_t n_ = l[kk];
 					wo[k] = L.off[code[kk]];
-					if(j0 + kk < last) {
+					if((uint32_t)kk < cpl && j0 + kk < last) {
 						if(j0 + kk + 1 == st.csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
 						else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
 					} else n_ = 0;

@@ -9,11 +9,11 @@ namespace corto_hip {
 // k_tunstall.hip
 __global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables);
 __global__ void k_tun_chunk_sums(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                                 uint32_t chunk_codes, uint64_t *chunk_out, uint32_t chunk_base);
+                                 uint64_t *chunk_out, uint32_t chunk_base);
 __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                             uint32_t chunk_codes, const uint64_t *chunk_out, uint32_t chunk_base);
+                             const uint64_t *chunk_out, uint32_t chunk_base);
 __global__ void k_tun_decode_staged(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                                    uint32_t chunk_codes, const uint64_t *chunk_out, uint32_t chunk_base);
+                                    const uint64_t *chunk_out, uint32_t chunk_base);
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
 
 // k_stream.hip
@@ -50,6 +50,5 @@ __global__ void k_normal_blob(const NormalJob *jobs, const uint32_t *job_ids, ui
 inline uint32_t normal_blob_lds(uint32_t nvert, uint32_t nface) { return (3*nvert + 4*(nvert + 1))*4 + ((3*nface*2 + 15) & ~15u) + 64; }
 constexpr uint32_t NORMAL_LDS_MAX = 150*1024;
 
-constexpr uint32_t TUN_CHUNK_CODES = 16384;   // codewords per K-TUN workgroup
 
 } // namespace corto_hip

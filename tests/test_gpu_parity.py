@@ -270,6 +270,28 @@ def test_tunstall_long_streams_multi_chunk(ctx):
     assert "tunstall_chunk_sums" in times or not times  # multi-chunk path taken when profiling is on
 
 
+def test_tunstall_long_streams_every_step_geometry(ctx):
+    """the staged decode sizes a wave's step (8/4/2/1 codewords per lane) and the chunk from the stream's mean word
+    length: low-entropy dictionaries (two symbols, words up to 255 bytes) down to flat ones, multi-chunk, clipped ends"""
+    rng = np.random.default_rng(11)
+    k = _kat()
+    dicts = [k["probs_09"], k["probs_25"], k["probs_37"], k["probs_13"], k["probs_08"],
+             np.array([[0, 235], [1, 20]], dtype=np.uint8), np.array([[0, 240], [1, 15]], dtype=np.uint8),
+             np.array([[7, 250], [9, 5]], dtype=np.uint8), np.array([[3, 254], [200, 1]], dtype=np.uint8)]
+    blocks, sizes, expect = [], [], []
+    for i, pr in enumerate(dicts):
+        idx, ln, tab = oc.tunstall_tables(pr)
+        ncode = 20_000 + 4_099*i
+        payload = rng.integers(0, 256, ncode).astype(np.uint8)
+        size = int(np.asarray(ln)[payload].sum()) - (i % 3)           # clip the last word by 0..2 bytes
+        hdr = bytes([len(pr)]) + pr.tobytes() + size.to_bytes(4, "little") + ncode.to_bytes(4, "little")
+        blocks.append(np.frombuffer(hdr + payload.tobytes(), dtype=np.uint8)); sizes.append(size)
+        expect.append(oc.tunstall_decompress(pr, payload, size))
+    outs, _ = _run_blocks(ctx, blocks, sizes)
+    for i, (o, e) in enumerate(zip(outs, expect)):
+        assert np.array_equal(o, e), (i, int(np.argmax(o != e[:len(o)])) if len(o) == len(e) else (len(o), len(e)))
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: inputs synthesised on the box by the repo's own encoder (byte-identical to the reference's,
 # tests/test_encoder_cpu.py), outputs checked against the C oracle and, when oracle/_ref travelled, the reference itself.

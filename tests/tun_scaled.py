@@ -7,4 +7,7 @@ import corto_amd as ca
 import bench
 ctx = ca.Context(0)
 ctx.set_profiling(True)
-print(json.dumps(bench.tunstall_scaled(ctx, ca, None)))
+for m in [int(x) for x in os.environ.get("ABL", "0").split(",")]:
+    tid = [int(x) for x in os.environ["TABLES"].split(",")] if os.environ.get("TABLES") else None
+    r = bench.tunstall_scaled(ctx, ca, None, tid)
+    print(m, r["decode_kernel_ms"], r["decode_kernel_GBps"], r["bytes_written"])
