@@ -20,6 +20,7 @@
 namespace corto_hip {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // K-TAB
@@ -339,19 +340,89 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 
 // pass B, long streams.  WAVE-AUTONOMOUS: a workgroup shares the stream's table in LDS, but each of its four waves decodes
 // its own quarter of the chunk (output offset from pass A's per-quarter sums) with no workgroup barrier in the loop - in
-// a first version two block-wide scans per tile (barriers) were half of the kernel time.  Per sub-tile of 512 codewords
-// (8 per lane): lengths -> DPP wave scan -> compose the bytes in the wave's own LDS window, laid out at the destination's
-// 16-byte phase -> flush with 16-byte stores, one kilobyte per instruction.
-//   compose, branch-free: every word has a zero-padded 16-byte copy (T16); a lane reads it with one ds_read_b128, moves it
-//            to the word's byte phase with five v_perm_b32 and ORs the five dwords into the zeroed window with LDS atomics -
-//            neighbouring words touch disjoint bytes of a shared dword, so OR composes them with no ordering at all.
-//   long words (> 16 bytes): their further 16-byte pieces are ORed in by the owning lane in a compact loop.
+// a first version two block-wide scans per tile (barriers) were half of the kernel time.  Per step of 64*cpl codewords
+// (cpl per lane, from the stream's mean word length): lengths -> DPP wave scan -> compose the bytes in the wave's own
+// LDS window, laid out at the destination's 16-byte phase -> flush with 16-byte stores, one kilobyte per instruction.
+//   compose, branch-free: every word has a zero-padded 16-byte copy (T16); a lane reads W = 1, 2 or 4 dwords of it (W from
+//            the dictionary's longest word), moves them to the word's byte phase with W+1 v_alignbyte_b32 and ORs the
+//            W+1 dwords into the zeroed window with LDS atomics - neighbouring words touch disjoint bytes of a shared
+//            dword, so OR composes them with no ordering at all.
+//   long words (> 16 bytes): queued per wave; their further 16-byte pieces are ORed in by up to 64 lanes at once (inline
+//            in the compose loop, one long word in any lane would make the whole wave walk that path).
+//   flush:   whole 16-byte vectors only; the bytes after the last whole vector stay in the window and become the head of
+//            the next step's window, so only a wave's first and last vector are written bytewise.
 // LDS ordering inside one wave is program order, so the window needs no barrier, only the s_waitcnt the compiler places.
-// A stream's clipped last sub-tile, and sub-tiles whose bytes exceed the window, take the general byte-FIFO path.
+// A stream's clipped last step, and steps whose bytes exceed the window, take the general byte-FIFO path.
 constexpr uint32_t TUN_WIN = 6*1024;             // per-wave window
-constexpr uint32_t TUN_SUB = 512;                // codewords per wave per step
+constexpr uint32_t TUN_SUB = 512;                // most codewords per wave per step
 constexpr uint32_t TUN_LONGQ = 64;               // per-wave queue of long words
 static_assert(2048 % (4*TUN_SUB) == 0 && TUN_CHUNK_CODES % 2048 == 0, "a wave's quarter chunk is whole steps (tun_pick_geometry)");
+
+// OR the W dwords x[] into the window so that their first byte lands on window byte p.  P = p + 15 is the running byte
+// offset from the window buffer's start (the window proper starts 16 bytes in), N = ~P: the dwords are moved up by p & 3
+// bytes as {x[i], x[i-1]} >> 8*((-p) & 3) - v_alignbyte_b32 takes the shift from the low two bits of N - which for
+// p & 3 == 0 yields them one dword late; addressing from (p - 1) & ~3 instead of p & ~3 absorbs exactly that.
+template <int W> __device__ __forceinline__ void tun_or(CRT_LDS uint8_t *wb, uint32_t P, uint32_t N, const uint32_t *x) {
+	CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(wb + (P & ~3u));
+	uint32_t prev = 0;
+#pragma unroll
+	for(int i = 0; i < W; i++) { atomicOr((uint32_t *)(o + i), __builtin_amdgcn_alignbyte(x[i], prev, N)); prev = x[i]; }
+	atomicOr((uint32_t *)(o + W), __builtin_amdgcn_alignbyte(0u, prev, N));
+}
+
+struct TunStep { uint32_t code[8], l[8]; };
+
+// pieces 16.. of the queued long words
+__device__ __forceinline__ void tun_drain_long(CRT_LDS uint8_t *wb, CRT_LDS const uint32_t *longq, uint32_t n, CRT_LDS const uint16_t *off16,
+                                               CRT_LDS const uint8_t *len8, CRT_LDS const uint32_t *tab32) {
+	if(lane_id() < n) {
+		const uint32_t e = longq[lane_id()], q = e & 0xffffu, cd = e >> 16;
+		const uint32_t wo = off16[cd], ln = len8[cd];
+		for(uint32_t b0 = 16; b0 < ln; b0 += 16) {
+			CRT_LDS const uint32_t *s32 = tab32 + ((wo + b0) >> 2);
+			const uint32_t a = (wo + b0) & 3u, rem = min(ln - b0, 16u);
+			const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
+			uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
+			                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
+#pragma unroll
+			for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
+			const uint32_t P = q + b0 + 15u;
+			tun_or<4>(wb, P, ~P, d);
+		}
+	}
+}
+
+// compose one step: all table reads first (their latency overlaps), then the ORs
+template <int W> __device__ __forceinline__ void tun_compose(CRT_LDS uint8_t *wb, CRT_LDS const uint32_t *t16, const TunStep &S, uint32_t cpl, uint32_t p0,
+                                                             CRT_LDS uint32_t *longq, CRT_LDS const uint16_t *off16, CRT_LDS const uint8_t *len8,
+                                                             CRT_LDS const uint32_t *tab32) {
+	uint32_t x[8][W];
+#pragma unroll
+	for(int k = 0; k < 8; k++) {
+		if((uint32_t)k >= cpl) break;
+		CRT_LDS const uint32_t *e = t16 + 4*S.code[k];
+		if constexpr(W == 1) x[k][0] = e[0];
+		else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
+		else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
+	}
+	uint32_t P = p0 + 15u, N = ~P, nlong = 0;
+#pragma unroll
+	for(int k = 0; k < 8; k++) {
+		if((uint32_t)k >= cpl) break;
+		tun_or<W>(wb, P, N, x[k]);
+		if constexpr(W == 4) {
+			const bool lg = S.l[k] > 16;                                         // queue the rest of a long word
+			const uint64_t m = __ballot(lg);
+			if(m) {
+				if(nlong + (uint32_t)__popcll(m) > TUN_LONGQ) { tun_drain_long(wb, longq, nlong, off16, len8, tab32); nlong = 0; }
+				if(lg) longq[nlong + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (P - 15u) | S.code[k] << 16;
+				nlong += (uint32_t)__popcll(m);
+			}
+		}
+		P += S.l[k]; N -= S.l[k];
+	}
+	if constexpr(W == 4) if(nlong) tun_drain_long(wb, longq, nlong, off16, len8, tab32);
+}
 
 __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                            uint32_t nchunks, const TunTable *__restrict__ tables,
@@ -362,19 +433,20 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const TunTable &T = tables[st.table];
 	__shared__ TunLds L;
 	__shared__ __attribute__((aligned(16))) u32x4_t t16[256];
-	__shared__ __attribute__((aligned(16))) uint32_t winbuf[4][(TUN_WIN + 64)/4];
+	__shared__ __attribute__((aligned(16))) uint32_t winbuf[4][(TUN_WIN + 64)/4];      // 16 bytes of slack in front, 48 behind
 	__shared__ uint32_t longbuf[4][TUN_LONGQ];
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	tun_load_table(L, T, T.used);
 	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(&winbuf[0][0]))[i] = u32x4_t{0, 0, 0, 0};
 	__syncthreads();
+	const uint32_t mylen = L.len[tid];
 	{	// zero-padded 16-byte copy of every word
-		const uint32_t wo = L.off[tid], wl = min((uint32_t)L.len[tid], 16u);
+		const uint32_t wo = L.off[tid], wl = min(mylen, 16u);
 		uint32_t d[4] = {0, 0, 0, 0};
 		for(uint32_t b = 0; b < wl; b++) d[b >> 2] |= (uint32_t)L.bytes[wo + b] << (8*(b & 3));
 		t16[tid] = u32x4_t{d[0], d[1], d[2], d[3]};
 	}
-	__syncthreads();
+	const uint32_t width = __syncthreads_or(mylen > 8) ? 4u : __syncthreads_or(mylen > 4) ? 2u : 1u;   // dwords of T16 a word needs
 	const uint32_t chunk_codes = st.chunk_codes, quarter = chunk_codes/4;
 	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
 	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
@@ -382,9 +454,12 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const uint64_t size = st.size;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
-	CRT_LDS uint32_t *out32 = as_lds(&winbuf[w][0]);
-	CRT_LDS const u32x4_t *t16l = (CRT_LDS const u32x4_t *)as_lds(t16);
+	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(&winbuf[w][0]);     // window byte i lives at wb[16 + i]
+	CRT_LDS u32x4_t *win = (CRT_LDS u32x4_t *)(wb + 16);
+	CRT_LDS uint32_t *longq = as_lds(&longbuf[w][0]);
+	CRT_LDS const uint32_t *t16l = (CRT_LDS const uint32_t *)as_lds(t16);
 	CRT_LDS const uint8_t *len8 = as_lds(L.len);
+	CRT_LDS const uint16_t *off16 = as_lds(L.off);
 	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(L.bytes);
 
 	auto fetch = [&](uint32_t j, uint32_t &lo, uint32_t &hi) {           // 8 codewords per lane as two (unaligned) dwords
@@ -392,33 +467,17 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		if(j + 8 <= last) { lo = *(CRT_GLOBAL const uint32_t *)(src + j); hi = *(CRT_GLOBAL const uint32_t *)(src + j + 4); }
 		else for(uint32_t k = 0; k < 8 && j + k < last; k++) { const uint32_t v = src[j + k]; if(k < 4) lo |= v << (8*k); else hi |= v << (8*(k - 4)); }
 	};
-	auto or16 = [&](uint32_t q, uint32_t x, uint32_t y, uint32_t z, uint32_t v) {   // OR 16 bytes into the window at byte q
-		const uint32_t sel = 0x07060504u - 0x01010101u*(q & 3u);           // v_perm selector: bytes (4-s .. 7-s) of {hi, lo}
-		CRT_LDS uint32_t *o = out32 + (q >> 2);
-		atomicOr((uint32_t *)(o + 0), __builtin_amdgcn_perm(x, 0u, sel));
-		atomicOr((uint32_t *)(o + 1), __builtin_amdgcn_perm(y, x, sel));
-		atomicOr((uint32_t *)(o + 2), __builtin_amdgcn_perm(z, y, sel));
-		atomicOr((uint32_t *)(o + 3), __builtin_amdgcn_perm(v, z, sel));
-		atomicOr((uint32_t *)(o + 4), __builtin_amdgcn_perm(0u, v, sel));
-	};
-	// long words (> 16 bytes): queued per wave as (window position | code << 16), their further 16-byte pieces ORed in by
-	// up to 64 lanes at once - inline in the loop above, one long word in any lane would make the whole wave walk this path
-	CRT_LDS uint32_t *longq = as_lds(&longbuf[w][0]);
-	auto drain_long = [&](uint32_t n) {
-		if(lane < n) {
-			const uint32_t e = longq[lane], q = e & 0xffffu, cd = e >> 16;
-			const uint32_t wo = L.off[cd], ln = len8[cd];
-			for(uint32_t b0 = 16; b0 < ln; b0 += 16) {
-				CRT_LDS const uint32_t *s32 = tab32 + ((wo + b0) >> 2);
-				const uint32_t a = (wo + b0) & 3u, rem = min(ln - b0, 16u);
-				const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
-				uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
-				                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
-#pragma unroll
-				for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
-				or16(q + b0, d[0], d[1], d[2], d[3]);
-			}
-		}
+	// Window state between steps: window byte 0 is the 16-byte aligned destination address below base; of the `phase`
+	// bytes in front of base, the first `foreign` are not this wave's to write (another wave's, or already written by the
+	// general path), the rest are composed and pending.
+	uint32_t foreign = (uint32_t)(uintptr_t)(gdst + base) & 15u;
+	bool pending = false;
+	auto write_pending = [&]() {                                        // bytes [foreign, phase) of window vector 0 -> HBM, bytewise
+		const uint32_t phase = (uint32_t)(uintptr_t)(gdst + base) & 15u;
+		CRT_GLOBAL uint8_t *a0 = gdst + base - phase;
+		if(lane >= foreign && lane < phase) a0[lane] = wb[16 + lane];
+		if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
+		pending = false; foreign = phase;
 	};
 	const uint32_t cpl = st.cpl, sub = 64*cpl;                          // codewords per lane / per wave in one step
 	uint32_t nlo, nhi;
@@ -427,16 +486,17 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		const uint32_t j0 = tile + cpl*lane;
 		const uint32_t clo = nlo, chi = nhi;
 		fetch(j0 + sub, nlo, nhi);
-		uint32_t code[8], l[8], sum = 0;
+		TunStep S;
+		uint32_t sum = 0;
 		const bool full = tile + sub <= last;                              // wave-uniform; false only on a stream's last step
 #pragma unroll
-		for(int k = 0; k < 8; k++) code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
+		for(int k = 0; k < 8; k++) S.code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
 		if(full) {
 #pragma unroll
-			for(int k = 0; k < 8; k++) { l[k] = (uint32_t)k < cpl ? (uint32_t)len8[code[k]] : 0u; sum += l[k]; }
+			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl ? (uint32_t)len8[S.code[k]] : 0u; sum += S.l[k]; }
 		} else {
 #pragma unroll
-			for(int k = 0; k < 8; k++) { l[k] = (uint32_t)k < cpl && j0 + k < last ? (uint32_t)len8[code[k]] : 0u; sum += l[k]; }
+			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl && j0 + k < last ? (uint32_t)len8[S.code[k]] : 0u; sum += S.l[k]; }
 		}
 		const uint32_t inc = wave_inclusive_scan_u32(sum);
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), orel = inc - sum;
@@ -444,37 +504,27 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		if(fast) {
 			CRT_GLOBAL uint8_t *g0 = gdst + base;
 			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
-			uint32_t p = phase + orel, nlong = 0;
-#pragma unroll
-			for(int k = 0; k < 8; k++) {
-				if((uint32_t)k >= cpl) break;
-				const u32x4_t x = t16l[code[k]];
-				or16(p, x.x, x.y, x.z, x.w);
-				const bool lg = l[k] > 16;                                       // queue the rest of a long word
-				const uint64_t m = __ballot(lg);
-				if(m) {
-					if(nlong + (uint32_t)__popcll(m) > TUN_LONGQ) { drain_long(nlong); nlong = 0; }
-					if(lg) longq[nlong + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = p | code[k] << 16;
-					nlong += (uint32_t)__popcll(m);
-				}
-				p += l[k];
+			if(width == 1) tun_compose<1>(wb, t16l, S, cpl, phase + orel, longq, off16, len8, tab32);
+			else if(width == 2) tun_compose<2>(wb, t16l, S, cpl, phase + orel, longq, off16, len8, tab32);
+			else tun_compose<4>(wb, t16l, S, cpl, phase + orel, longq, off16, len8, tab32);
+			// flush the whole vectors of [0, phase + total) and re-zero them (same wave: LDS program order, no barrier)
+			const uint32_t end = phase + total, nvec = end >> 4;
+			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 - phase);
+			uint32_t i0 = 0;
+			if(foreign && nvec) {                                             // vector 0 holds bytes that are not ours
+				if(lane >= foreign && lane < 16) ((CRT_GLOBAL uint8_t *)gv)[lane] = wb[16 + lane];
+				if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
+				i0 = 1;
 			}
-			if(nlong) drain_long(nlong);
-			// flush [0, total) and re-zero the window (same wave: LDS program order, no barrier)
-			CRT_LDS uint8_t *out = (CRT_LDS uint8_t *)out32 + phase;
-			const uint32_t n = total;
-			const uint32_t head = min((16u - phase) & 15u, n);
-			if(lane < head) g0[lane] = out[lane];
-			const uint32_t nvec = (n - head) >> 4;
-			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 + head);
-			CRT_LDS u32x4_t *lv = (CRT_LDS u32x4_t *)(out + head);
-			for(uint32_t i = lane; i < nvec; i += 64) { gv[i] = lv[i]; lv[i] = u32x4_t{0, 0, 0, 0}; }
-			const uint32_t tail0 = head + (nvec << 4);
-			if(tail0 + lane < n) g0[tail0 + lane] = out[tail0 + lane];
-			if(lane < 4) out32[lane] = 0;                                       // head / tail dwords of the window
-			if(lane < 8) out32[((phase + tail0) >> 2) + lane] = 0;
+			for(uint32_t i = i0 + lane; i < nvec; i += 64) { gv[i] = win[i]; win[i] = u32x4_t{0, 0, 0, 0}; }
+			if(nvec) {
+				foreign = 0;
+				if((end & 15u) && lane == 0) { const u32x4_t t = win[nvec]; win[nvec] = u32x4_t{0, 0, 0, 0}; win[0] = t; }   // carry the tail
+			}
+			pending = (end & 15u) > foreign;
 		} else {
 			// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
+			if(pending) write_pending();
 			uint64_t oo = base + orel;
 #pragma unroll
 			for(int h = 0; h < 2; h++) {
@@ -483,21 +533,23 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 #pragma unroll
 				for(int k = 0; k < 4; k++) {
 					const int kk = 4*h + k;
-					uint32_t n_ = l[kk];
-					wo[k] = L.off[code[kk]];
+					uint32_t n_ = S.l[kk];
+					wo[k] = L.off[S.code[kk]];
 					if((uint32_t)kk < cpl && j0 + kk < last) {
 						if(j0 + kk + 1 == st.csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
 						else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
 					} else n_ = 0;
 					nb[k] = n_;
-					oo += l[kk];
+					oo += S.l[kk];
 				}
 				CRT_GLOBAL uint8_t *d = gdst + o_run;
 				tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
 			}
+			foreign = (uint32_t)(uintptr_t)(gdst + base + total) & 15u;      // everything below the next base is written now
 		}
 		base += total;
 	}
+	if(pending) write_pending();
 }
 
 // memset path: single-symbol streams (tunstall.cpp:433-436)
