@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 //            the next step's window, so only a wave's first and last vector are written bytewise.
 // LDS ordering inside one wave is program order, so the window needs no barrier, only the s_waitcnt the compiler places.
 // A stream's clipped last step, and steps whose bytes exceed the window, take the general byte-FIFO path.
-constexpr uint32_t TUN_WIN = 6*1024;             // per-wave window
+constexpr uint32_t TUN_WIN = 6*1024 - 64;        // per-wave window
 constexpr uint32_t TUN_SUB = 512;                // most codewords per wave per step
 constexpr uint32_t TUN_LONGQ = 64;               // per-wave queue of long words
 static_assert(2048 % (4*TUN_SUB) == 0 && TUN_CHUNK_CODES % 2048 == 0, "a wave's quarter chunk is whole steps (tun_pick_geometry)");
@@ -393,14 +393,14 @@ __device__ __forceinline__ void tun_drain_long(CRT_LDS uint8_t *wb, CRT_LDS cons
 }
 
 // compose one step: all table reads first (their latency overlaps), then the ORs
-template <int W> __device__ __forceinline__ void tun_compose(CRT_LDS uint8_t *wb, CRT_LDS const uint32_t *t16, const TunStep &S, uint32_t cpl, uint32_t p0,
+template <int W> __device__ __forceinline__ void tun_compose(CRT_LDS uint8_t *wb, CRT_LDS const uint32_t *t16, const TunStep &S, uint32_t cpl, uint32_t p0, uint32_t p1,
                                                              CRT_LDS uint32_t *longq, CRT_LDS const uint16_t *off16, CRT_LDS const uint8_t *len8,
                                                              CRT_LDS const uint32_t *tab32) {
 	uint32_t x[8][W];
 #pragma unroll
 	for(int k = 0; k < 8; k++) {
 		if((uint32_t)k >= cpl) break;
-		CRT_LDS const uint32_t *e = t16 + 4*S.code[k];
+		CRT_LDS const uint32_t *e = t16 + W*S.code[k];
 		if constexpr(W == 1) x[k][0] = e[0];
 		else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
 		else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
@@ -409,6 +409,7 @@ template <int W> __device__ __forceinline__ void tun_compose(CRT_LDS uint8_t *wb
 #pragma unroll
 	for(int k = 0; k < 8; k++) {
 		if((uint32_t)k >= cpl) break;
+		if(k == 4) { P = p1 + 15u; N = ~P; }                                  // second group of four
 		tun_or<W>(wb, P, N, x[k]);
 		if constexpr(W == 4) {
 			const bool lg = S.l[k] > 16;                                         // queue the rest of a long word
@@ -440,13 +441,17 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(&winbuf[0][0]))[i] = u32x4_t{0, 0, 0, 0};
 	__syncthreads();
 	const uint32_t mylen = L.len[tid];
-	{	// zero-padded 16-byte copy of every word
+	const uint32_t width = __syncthreads_or(mylen > 8) ? 4u : __syncthreads_or(mylen > 4) ? 2u : 1u;   // dwords of a word's padded copy
+	{	// zero-padded copy of every word, `width` dwords per entry (a compact table spreads over more LDS banks)
 		const uint32_t wo = L.off[tid], wl = min(mylen, 16u);
 		uint32_t d[4] = {0, 0, 0, 0};
 		for(uint32_t b = 0; b < wl; b++) d[b >> 2] |= (uint32_t)L.bytes[wo + b] << (8*(b & 3));
-		t16[tid] = u32x4_t{d[0], d[1], d[2], d[3]};
+		CRT_LDS uint32_t *e = (CRT_LDS uint32_t *)as_lds(t16) + width*tid;
+		if(width == 4) *(CRT_LDS u32x4_t *)e = u32x4_t{d[0], d[1], d[2], d[3]};
+		else if(width == 2) *(CRT_LDS u32x2_t *)e = u32x2_t{d[0], d[1]};
+		else e[0] = d[0];
 	}
-	const uint32_t width = __syncthreads_or(mylen > 8) ? 4u : __syncthreads_or(mylen > 4) ? 2u : 1u;   // dwords of T16 a word needs
+	__syncthreads();
 	const uint32_t chunk_codes = st.chunk_codes, quarter = chunk_codes/4;
 	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
 	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
@@ -462,10 +467,11 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	CRT_LDS const uint16_t *off16 = as_lds(L.off);
 	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(L.bytes);
 
-	auto fetch = [&](uint32_t j, uint32_t &lo, uint32_t &hi) {           // 8 codewords per lane as two (unaligned) dwords
-		lo = 0; hi = 0;
-		if(j + 8 <= last) { lo = *(CRT_GLOBAL const uint32_t *)(src + j); hi = *(CRT_GLOBAL const uint32_t *)(src + j + 4); }
-		else for(uint32_t k = 0; k < 8 && j + k < last; k++) { const uint32_t v = src[j + k]; if(k < 4) lo |= v << (8*k); else hi |= v << (8*(k - 4)); }
+	auto fetch4 = [&](uint32_t j) -> uint32_t {                         // four codewords as one (unaligned) dword
+		if(j + 4 <= last) return *(CRT_GLOBAL const uint32_t *)(src + j);
+		uint32_t v = 0;
+		for(uint32_t k = 0; k < 4 && j + k < last; k++) v |= (uint32_t)src[j + k] << (8*k);
+		return v;
 	};
 	// Window state between steps: window byte 0 is the 16-byte aligned destination address below base; of the `phase`
 	// bytes in front of base, the first `foreign` are not this wave's to write (another wave's, or already written by the
@@ -479,34 +485,39 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
 		pending = false; foreign = phase;
 	};
-	const uint32_t cpl = st.cpl, sub = 64*cpl;                          // codewords per lane / per wave in one step
+	// A lane takes the step's codewords in groups of four consecutive ones (one dword of the coalesced fetch): with
+	// cpl = 8 the codewords 4*lane.. and 256 + 4*lane.. - the closer neighbouring lanes' words are in the window, the
+	// fewer LDS bank conflicts the ORs have.
+	const uint32_t cpl = st.cpl, sub = 64*cpl, grp = min(cpl, 4u);
+	auto fetch2 = [&](uint32_t j, uint32_t &lo, uint32_t &hi) { lo = fetch4(j); hi = cpl == 8 ? fetch4(j + 256) : 0u; };
 	uint32_t nlo, nhi;
-	fetch(first + cpl*lane, nlo, nhi);                                  // codewords are fetched one step ahead
+	fetch2(first + grp*lane, nlo, nhi);                                 // codewords are fetched one step ahead
 	for(uint32_t tile = first; tile < last; tile += sub) {
-		const uint32_t j0 = tile + cpl*lane;
+		const uint32_t j0 = tile + grp*lane;
 		const uint32_t clo = nlo, chi = nhi;
-		fetch(j0 + sub, nlo, nhi);
+		fetch2(j0 + sub, nlo, nhi);
 		TunStep S;
-		uint32_t sum = 0;
+		uint32_t sum0 = 0, sum1 = 0;
 		const bool full = tile + sub <= last;                              // wave-uniform; false only on a stream's last step
 #pragma unroll
 		for(int k = 0; k < 8; k++) S.code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
 		if(full) {
 #pragma unroll
-			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl ? (uint32_t)len8[S.code[k]] : 0u; sum += S.l[k]; }
+			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl ? (uint32_t)len8[S.code[k]] : 0u; (k < 4 ? sum0 : sum1) += S.l[k]; }
 		} else {
 #pragma unroll
-			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl && j0 + k < last ? (uint32_t)len8[S.code[k]] : 0u; sum += S.l[k]; }
+			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl && j0 + (k < 4 ? k : 252 + k) < last ? (uint32_t)len8[S.code[k]] : 0u; (k < 4 ? sum0 : sum1) += S.l[k]; }
 		}
-		const uint32_t inc = wave_inclusive_scan_u32(sum);
-		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), orel = inc - sum;
+		const uint32_t inc = wave_inclusive_scan_u32(sum0 | sum1 << 16);      // both groups in one scan: a group's bytes < 2^16
+		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), total0 = tot & 0xffffu, total = total0 + (tot >> 16);
+		const uint32_t orel0 = (inc & 0xffffu) - sum0, orel1 = total0 + (inc >> 16) - sum1;
 		const bool fast = full && total + 32 <= TUN_WIN && tile + sub < st.csize && base + total <= size;
 		if(fast) {
 			CRT_GLOBAL uint8_t *g0 = gdst + base;
 			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
-			if(width == 1) tun_compose<1>(wb, t16l, S, cpl, phase + orel, longq, off16, len8, tab32);
-			else if(width == 2) tun_compose<2>(wb, t16l, S, cpl, phase + orel, longq, off16, len8, tab32);
-			else tun_compose<4>(wb, t16l, S, cpl, phase + orel, longq, off16, len8, tab32);
+			if(width == 1) tun_compose<1>(wb, t16l, S, cpl, phase + orel0, phase + orel1, longq, off16, len8, tab32);
+			else if(width == 2) tun_compose<2>(wb, t16l, S, cpl, phase + orel0, phase + orel1, longq, off16, len8, tab32);
+			else tun_compose<4>(wb, t16l, S, cpl, phase + orel0, phase + orel1, longq, off16, len8, tab32);
 			// flush the whole vectors of [0, phase + total) and re-zero them (same wave: LDS program order, no barrier)
 			const uint32_t end = phase + total, nvec = end >> 4;
 			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 - phase);
@@ -525,18 +536,19 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		} else {
 			// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
 			if(pending) write_pending();
-			uint64_t oo = base + orel;
 #pragma unroll
 			for(int h = 0; h < 2; h++) {
 				uint32_t wo[4], nb[4];
+				uint64_t oo = base + (h ? orel1 : orel0);
 				const uint64_t o_run = oo;
 #pragma unroll
 				for(int k = 0; k < 4; k++) {
 					const int kk = 4*h + k;
 					uint32_t n_ = S.l[kk];
 					wo[k] = L.off[S.code[kk]];
-					if((uint32_t)kk < cpl && j0 + kk < last) {
-						if(j0 + kk + 1 == st.csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
+					const uint32_t j = j0 + (h ? 252 + kk : kk);
+					if((uint32_t)kk < cpl && j < last) {
+						if(j + 1 == st.csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
 						else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
 					} else n_ = 0;
 					nb[k] = n_;
