@@ -358,71 +358,49 @@ constexpr uint32_t TUN_SUB = 512;                // most codewords per wave per 
 constexpr uint32_t TUN_LONGQ = 64;               // per-wave queue of long words
 static_assert(2048 % (4*TUN_SUB) == 0 && TUN_CHUNK_CODES % 2048 == 0, "a wave's quarter chunk is whole steps (tun_pick_geometry)");
 
-// OR the W dwords x[] into the window so that their first byte lands on window byte p.  P = p + 15 is the running byte
-// offset from the window buffer's start (the window proper starts 16 bytes in), N = ~P: the dwords are moved up by p & 3
-// bytes as {x[i], x[i-1]} >> 8*((-p) & 3) - v_alignbyte_b32 takes the shift from the low two bits of N - which for
-// p & 3 == 0 yields them one dword late; addressing from (p - 1) & ~3 instead of p & ~3 absorbs exactly that.
-template <int W> __device__ __forceinline__ void tun_or(CRT_LDS uint8_t *wb, uint32_t P, uint32_t N, const uint32_t *x) {
-	CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(wb + (P & ~3u));
+// OR the W dwords x[] into the window so that their first byte lands on window byte p.  P is the LDS byte address of
+// window byte p - 1 (the window buffer is 16-byte aligned), N = ~P: the dwords are moved up by p & 3 bytes as
+// {x[i], x[i-1]} >> 8*((-p) & 3) - v_alignbyte_b32 takes the shift from the low two bits of N - which for p & 3 == 0
+// yields them one dword late; addressing from (p - 1) & ~3 instead of p & ~3 absorbs exactly that.
+template <int W> __device__ __forceinline__ void tun_or(uint32_t P, uint32_t N, const uint32_t *x) {
+	CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(P & ~3u);
 	uint32_t prev = 0;
 #pragma unroll
 	for(int i = 0; i < W; i++) { atomicOr((uint32_t *)(o + i), __builtin_amdgcn_alignbyte(x[i], prev, N)); prev = x[i]; }
 	atomicOr((uint32_t *)(o + W), __builtin_amdgcn_alignbyte(0u, prev, N));
 }
 
-struct TunStep { uint32_t code[8], l[8]; };
-
-// pieces 16.. of the queued long words
-__device__ __forceinline__ void tun_drain_long(CRT_LDS uint8_t *wb, CRT_LDS const uint32_t *longq, uint32_t n, CRT_LDS const uint16_t *off16,
+// Bytes 16.. of the queued long words (entry = window position of the word | code << 16): the owning lane streams the
+// table's dwords to the window's dwords, {T[i+1], T[i]} >> 8*shift, three instructions per dword.  The dword the stream
+// starts in is shared with the word's own bytes 12..15, already there - ORing them again changes nothing, so only the
+// last dword needs a mask (the table bytes behind a word belong to other words).
+__device__ __forceinline__ void tun_drain_long(uint32_t win0, CRT_LDS const uint32_t *longq, uint32_t n, CRT_LDS const uint16_t *off16,
                                                CRT_LDS const uint8_t *len8, CRT_LDS const uint32_t *tab32) {
 	if(lane_id() < n) {
-		const uint32_t e = longq[lane_id()], q = e & 0xffffu, cd = e >> 16;
-		const uint32_t wo = off16[cd], ln = len8[cd];
-		for(uint32_t b0 = 16; b0 < ln; b0 += 16) {
-			CRT_LDS const uint32_t *s32 = tab32 + ((wo + b0) >> 2);
-			const uint32_t a = (wo + b0) & 3u, rem = min(ln - b0, 16u);
-			const uint32_t r0 = s32[0], r1 = s32[1], r2 = s32[2], r3 = s32[3], r4 = s32[4];
-			uint32_t d[4] = {__builtin_amdgcn_alignbyte(r1, r0, a), __builtin_amdgcn_alignbyte(r2, r1, a),
-			                 __builtin_amdgcn_alignbyte(r3, r2, a), __builtin_amdgcn_alignbyte(r4, r3, a)};
-#pragma unroll
-			for(int j = 0; j < 4; j++) { const uint32_t lo = 4u*j; d[j] = rem >= lo + 4 ? d[j] : rem > lo ? d[j] & ((1u << (8*(rem - lo))) - 1u) : 0u; }
-			const uint32_t P = q + b0 + 15u;
-			tun_or<4>(wb, P, ~P, d);
+		const uint32_t e = longq[lane_id()], cd = e >> 16;
+		const uint32_t d0 = (e & 0xffffu) + 16u;                             // window byte position of the word's byte 16
+		const uint32_t sp = (uint32_t)off16[cd] + 16u - (d0 & 3u);           // table byte that lands on the first dword's byte 0
+		const uint32_t nbytes = (uint32_t)len8[cd] - 16u + (d0 & 3u);        // bytes from there to the word's end
+		CRT_LDS const uint32_t *t = tab32 + (sp >> 2);
+		CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(win0 + (d0 & ~3u));
+		const uint32_t nd = (nbytes + 3u) >> 2;                               // dwords to OR; the last one masked
+		uint32_t lo = t[0], i = 0;
+		for(; i + 4 < nd; i += 4) {
+			const uint32_t t1 = t[i + 1], t2 = t[i + 2], t3 = t[i + 3], t4 = t[i + 4];
+			atomicOr((uint32_t *)(o + i), __builtin_amdgcn_alignbyte(t1, lo, sp));
+			atomicOr((uint32_t *)(o + i + 1), __builtin_amdgcn_alignbyte(t2, t1, sp));
+			atomicOr((uint32_t *)(o + i + 2), __builtin_amdgcn_alignbyte(t3, t2, sp));
+			atomicOr((uint32_t *)(o + i + 3), __builtin_amdgcn_alignbyte(t4, t3, sp));
+			lo = t4;
+		}
+		for(; i < nd; i++) {
+			const uint32_t hi = t[i + 1];
+			uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sp);
+			if(i + 1 == nd && (nbytes & 3u)) v &= (1u << (8*(nbytes & 3u))) - 1u;
+			atomicOr((uint32_t *)(o + i), v);
+			lo = hi;
 		}
 	}
-}
-
-// compose one step: all table reads first (their latency overlaps), then the ORs
-template <int W> __device__ __forceinline__ void tun_compose(CRT_LDS uint8_t *wb, CRT_LDS const uint32_t *t16, const TunStep &S, uint32_t cpl, uint32_t p0, uint32_t p1,
-                                                             CRT_LDS uint32_t *longq, CRT_LDS const uint16_t *off16, CRT_LDS const uint8_t *len8,
-                                                             CRT_LDS const uint32_t *tab32) {
-	uint32_t x[8][W];
-#pragma unroll
-	for(int k = 0; k < 8; k++) {
-		if((uint32_t)k >= cpl) break;
-		CRT_LDS const uint32_t *e = t16 + W*S.code[k];
-		if constexpr(W == 1) x[k][0] = e[0];
-		else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
-		else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
-	}
-	uint32_t P = p0 + 15u, N = ~P, nlong = 0;
-#pragma unroll
-	for(int k = 0; k < 8; k++) {
-		if((uint32_t)k >= cpl) break;
-		if(k == 4) { P = p1 + 15u; N = ~P; }                                  // second group of four
-		tun_or<W>(wb, P, N, x[k]);
-		if constexpr(W == 4) {
-			const bool lg = S.l[k] > 16;                                         // queue the rest of a long word
-			const uint64_t m = __ballot(lg);
-			if(m) {
-				if(nlong + (uint32_t)__popcll(m) > TUN_LONGQ) { tun_drain_long(wb, longq, nlong, off16, len8, tab32); nlong = 0; }
-				if(lg) longq[nlong + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (P - 15u) | S.code[k] << 16;
-				nlong += (uint32_t)__popcll(m);
-			}
-		}
-		P += S.l[k]; N -= S.l[k];
-	}
-	if constexpr(W == 4) if(nlong) tun_drain_long(wb, longq, nlong, off16, len8, tab32);
 }
 
 __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
@@ -441,7 +419,8 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(&winbuf[0][0]))[i] = u32x4_t{0, 0, 0, 0};
 	__syncthreads();
 	const uint32_t mylen = L.len[tid];
-	const uint32_t width = __syncthreads_or(mylen > 8) ? 4u : __syncthreads_or(mylen > 4) ? 2u : 1u;   // dwords of a word's padded copy
+	// dwords of a word's padded copy: by the dictionary's longest word; steps of fewer than 8 codewords per lane are only compiled for 4
+	const uint32_t width = st.cpl < 8 || __syncthreads_or(mylen > 8) ? 4u : __syncthreads_or(mylen > 4) ? 2u : 1u;
 	{	// zero-padded copy of every word, `width` dwords per entry (a compact table spreads over more LDS banks)
 		const uint32_t wo = L.off[tid], wl = min(mylen, 16u);
 		uint32_t d[4] = {0, 0, 0, 0};
@@ -457,10 +436,12 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
 	uint64_t base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];
 	const uint64_t size = st.size;
+	const uint32_t csize = st.csize;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
 	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(&winbuf[w][0]);     // window byte i lives at wb[16 + i]
 	CRT_LDS u32x4_t *win = (CRT_LDS u32x4_t *)(wb + 16);
+	const uint32_t win0 = (uint32_t)(uintptr_t)win;                      // LDS byte address of window byte 0
 	CRT_LDS uint32_t *longq = as_lds(&longbuf[w][0]);
 	CRT_LDS const uint32_t *t16l = (CRT_LDS const uint32_t *)as_lds(t16);
 	CRT_LDS const uint8_t *len8 = as_lds(L.len);
@@ -485,82 +466,122 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 		if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
 		pending = false; foreign = phase;
 	};
-	// A lane takes the step's codewords in groups of four consecutive ones (one dword of the coalesced fetch): with
-	// cpl = 8 the codewords 4*lane.. and 256 + 4*lane.. - the closer neighbouring lanes' words are in the window, the
-	// fewer LDS bank conflicts the ORs have.
-	const uint32_t cpl = st.cpl, sub = 64*cpl, grp = min(cpl, 4u);
-	auto fetch2 = [&](uint32_t j, uint32_t &lo, uint32_t &hi) { lo = fetch4(j); hi = cpl == 8 ? fetch4(j + 256) : 0u; };
-	uint32_t nlo, nhi;
-	fetch2(first + grp*lane, nlo, nhi);                                 // codewords are fetched one step ahead
-	for(uint32_t tile = first; tile < last; tile += sub) {
-		const uint32_t j0 = tile + grp*lane;
-		const uint32_t clo = nlo, chi = nhi;
-		fetch2(j0 + sub, nlo, nhi);
-		TunStep S;
-		uint32_t sum0 = 0, sum1 = 0;
-		const bool full = tile + sub <= last;                              // wave-uniform; false only on a stream's last step
+
+	// The loop over a wave's quarter chunk, compiled for each (table width W, codewords per lane CPL) that occurs.  A lane
+	// takes the step's codewords in groups of four consecutive ones (one dword of the coalesced fetch): with CPL = 8 the
+	// codewords 4*lane.. and 256 + 4*lane.. - the closer neighbouring lanes' words are in the window, the fewer LDS bank
+	// conflicts the ORs have.
+	auto run = [&](auto Wc, auto Cc) {
+		constexpr int W = decltype(Wc)::value, CPL = decltype(Cc)::value, GRP = CPL < 4 ? CPL : 4;
+		constexpr uint32_t sub = 64*CPL;
+		uint32_t nlo = fetch4(first + GRP*lane), nhi = CPL == 8 ? fetch4(first + GRP*lane + 256) : 0u;   // fetched one step ahead
+		for(uint32_t tile = first; tile < last; tile += sub) {
+			const uint32_t j0 = tile + GRP*lane;
+			const uint32_t clo = nlo, chi = nhi;
+			nlo = fetch4(j0 + sub);
+			if(CPL == 8) nhi = fetch4(j0 + sub + 256);
+			uint32_t code[CPL], l[CPL], sum0 = 0, sum1 = 0;
+			const bool full = tile + sub <= last;                             // wave-uniform; false only on a stream's last step
 #pragma unroll
-		for(int k = 0; k < 8; k++) S.code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
-		if(full) {
+			for(int k = 0; k < CPL; k++) code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
+			if(full) {
 #pragma unroll
-			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl ? (uint32_t)len8[S.code[k]] : 0u; (k < 4 ? sum0 : sum1) += S.l[k]; }
-		} else {
+				for(int k = 0; k < CPL; k++) { l[k] = len8[code[k]]; (k < 4 ? sum0 : sum1) += l[k]; }
+			} else {
 #pragma unroll
-			for(int k = 0; k < 8; k++) { S.l[k] = (uint32_t)k < cpl && j0 + (k < 4 ? k : 252 + k) < last ? (uint32_t)len8[S.code[k]] : 0u; (k < 4 ? sum0 : sum1) += S.l[k]; }
-		}
-		const uint32_t inc = wave_inclusive_scan_u32(sum0 | sum1 << 16);      // both groups in one scan: a group's bytes < 2^16
-		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), total0 = tot & 0xffffu, total = total0 + (tot >> 16);
-		const uint32_t orel0 = (inc & 0xffffu) - sum0, orel1 = total0 + (inc >> 16) - sum1;
-		const bool fast = full && total + 32 <= TUN_WIN && tile + sub < st.csize && base + total <= size;
-		if(fast) {
-			CRT_GLOBAL uint8_t *g0 = gdst + base;
-			const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
-			if(width == 1) tun_compose<1>(wb, t16l, S, cpl, phase + orel0, phase + orel1, longq, off16, len8, tab32);
-			else if(width == 2) tun_compose<2>(wb, t16l, S, cpl, phase + orel0, phase + orel1, longq, off16, len8, tab32);
-			else tun_compose<4>(wb, t16l, S, cpl, phase + orel0, phase + orel1, longq, off16, len8, tab32);
-			// flush the whole vectors of [0, phase + total) and re-zero them (same wave: LDS program order, no barrier)
-			const uint32_t end = phase + total, nvec = end >> 4;
-			CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 - phase);
-			uint32_t i0 = 0;
-			if(foreign && nvec) {                                             // vector 0 holds bytes that are not ours
-				if(lane >= foreign && lane < 16) ((CRT_GLOBAL uint8_t *)gv)[lane] = wb[16 + lane];
-				if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
-				i0 = 1;
+				for(int k = 0; k < CPL; k++) { l[k] = j0 + (k < 4 ? k : 252 + k) < last ? (uint32_t)len8[code[k]] : 0u; (k < 4 ? sum0 : sum1) += l[k]; }
 			}
-			for(uint32_t i = i0 + lane; i < nvec; i += 64) { gv[i] = win[i]; win[i] = u32x4_t{0, 0, 0, 0}; }
-			if(nvec) {
-				foreign = 0;
-				if((end & 15u) && lane == 0) { const u32x4_t t = win[nvec]; win[nvec] = u32x4_t{0, 0, 0, 0}; win[0] = t; }   // carry the tail
-			}
-			pending = (end & 15u) > foreign;
-		} else {
-			// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
-			if(pending) write_pending();
+			const uint32_t inc = wave_inclusive_scan_u32(sum0 | sum1 << 16);   // both groups in one scan: a group's bytes < 2^16
+			const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), total0 = tot & 0xffffu, total = total0 + (tot >> 16);
+			const uint32_t orel0 = (inc & 0xffffu) - sum0, orel1 = total0 + (inc >> 16) - sum1;
+			const bool fast = full && total + 32 <= TUN_WIN && tile + sub < csize && base + total <= size;
+			if(fast) {
+				CRT_GLOBAL uint8_t *g0 = gdst + base;
+				const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
+				{	// compose: all table reads first (their latency overlaps), then the ORs
+					uint32_t x[CPL][W];
 #pragma unroll
-			for(int h = 0; h < 2; h++) {
-				uint32_t wo[4], nb[4];
-				uint64_t oo = base + (h ? orel1 : orel0);
-				const uint64_t o_run = oo;
+					for(int k = 0; k < CPL; k++) {
+						CRT_LDS const uint32_t *e = t16l + W*code[k];
+						if constexpr(W == 1) x[k][0] = e[0];
+						else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
+						else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
+					}
+					uint32_t P = win0 + phase + orel0 - 1u, N = ~P, nlong = 0;
 #pragma unroll
-				for(int k = 0; k < 4; k++) {
-					const int kk = 4*h + k;
-					uint32_t n_ = S.l[kk];
-					wo[k] = L.off[S.code[kk]];
-					const uint32_t j = j0 + (h ? 252 + kk : kk);
-					if((uint32_t)kk < cpl && j < last) {
-						if(j + 1 == st.csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
-						else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
-					} else n_ = 0;
-					nb[k] = n_;
-					oo += S.l[kk];
+					for(int k = 0; k < CPL; k++) {
+						if(k == 4) { P = win0 + phase + orel1 - 1u; N = ~P; }        // second group of four
+						tun_or<W>(P, N, x[k]);
+						if constexpr(W == 4) {
+							const bool lg = l[k] > 16;                                  // queue the rest of a long word
+							const uint64_t m = __ballot(lg);
+							if(m) {
+								if(nlong + (uint32_t)__popcll(m) > TUN_LONGQ) { tun_drain_long(win0, longq, nlong, off16, len8, tab32); nlong = 0; }
+								if(lg) longq[nlong + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (P + 1u - win0) | code[k] << 16;
+								nlong += (uint32_t)__popcll(m);
+							}
+						}
+						P += l[k]; N -= l[k];
+					}
+					if constexpr(W == 4) if(nlong) tun_drain_long(win0, longq, nlong, off16, len8, tab32);
 				}
-				CRT_GLOBAL uint8_t *d = gdst + o_run;
-				tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
+				// flush the whole vectors of [0, phase + total) and re-zero them (same wave: LDS program order, no barrier)
+				const uint32_t end = phase + total, nvec = end >> 4;
+				CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 - phase);
+				uint32_t i0 = 0;
+				if(foreign && nvec) {                                            // vector 0 holds bytes that are not ours
+					if(lane >= foreign && lane < 16) ((CRT_GLOBAL uint8_t *)gv)[lane] = wb[16 + lane];
+					if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
+					i0 = 1;
+				}
+				for(uint32_t i = i0 + lane; i < nvec; i += 64) { gv[i] = win[i]; win[i] = u32x4_t{0, 0, 0, 0}; }
+				if(nvec) {
+					foreign = 0;
+					if((end & 15u) && lane == 0) { const u32x4_t t = win[nvec]; win[nvec] = u32x4_t{0, 0, 0, 0}; win[0] = t; }   // carry the tail
+				}
+				pending = (end & 15u) > foreign;
+			} else {
+				// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
+				if(pending) write_pending();
+#pragma unroll
+				for(int h = 0; h < (CPL == 8 ? 2 : 1); h++) {
+					uint32_t wo[4], nb[4];
+					uint64_t oo = base + (h ? orel1 : orel0);
+					const uint64_t o_run = oo;
+#pragma unroll
+					for(int k = 0; k < 4; k++) {
+						const int kk = 4*h + k;
+						uint32_t n_ = 0;
+						wo[k] = 0;
+						if(kk < CPL) {
+							const uint32_t j = j0 + (h ? 252 + kk : kk);
+							n_ = l[kk < CPL ? kk : 0];
+							wo[k] = L.off[code[kk < CPL ? kk : 0]];
+							if(j < last) {
+								if(j + 1 == csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
+								else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
+							} else n_ = 0;
+							oo += l[kk < CPL ? kk : 0];
+						}
+						nb[k] = n_;
+					}
+					CRT_GLOBAL uint8_t *d = gdst + o_run;
+					tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
+				}
+				foreign = (uint32_t)(uintptr_t)(gdst + base + total) & 15u;     // everything below the next base is written now
 			}
-			foreign = (uint32_t)(uintptr_t)(gdst + base + total) & 15u;      // everything below the next base is written now
+			base += total;
 		}
-		base += total;
-	}
+	};
+	using std::integral_constant;
+	const uint32_t cpl = st.cpl;                                        // tun_pick_geometry: 8, 4, 2 or 1 by mean word length
+	if(cpl == 8) {
+		if(width == 1) run(integral_constant<int, 1>{}, integral_constant<int, 8>{});
+		else if(width == 2) run(integral_constant<int, 2>{}, integral_constant<int, 8>{});
+		else run(integral_constant<int, 4>{}, integral_constant<int, 8>{});
+	} else if(cpl == 4) run(integral_constant<int, 4>{}, integral_constant<int, 4>{});
+	else if(cpl == 2) run(integral_constant<int, 4>{}, integral_constant<int, 2>{});
+	else run(integral_constant<int, 4>{}, integral_constant<int, 1>{});
 	if(pending) write_pending();
 }
 
