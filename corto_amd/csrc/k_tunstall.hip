@@ -474,16 +474,31 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	auto run = [&](auto Wc, auto Cc) {
 		constexpr int W = decltype(Wc)::value, CPL = decltype(Cc)::value, GRP = CPL < 4 ? CPL : 4;
 		constexpr uint32_t sub = 64*CPL;
-		uint32_t nlo = fetch4(first + GRP*lane), nhi = CPL == 8 ? fetch4(first + GRP*lane + 256) : 0u;   // fetched one step ahead
+		// Codewords are fetched two steps ahead and taken out of the fetched dwords BEFORE the step's stores are issued:
+		// loads and stores share one in-order counter (vmcnt), so a load waited for behind this step's flush would
+		// cost the flush's whole HBM write latency, every step.
+		uint32_t code[CPL], l[CPL];
+		auto extract = [&](uint32_t lo, uint32_t hi, uint32_t (&cd)[CPL]) {
+#pragma unroll
+			for(int k = 0; k < CPL; k++) cd[k] = ((k < 4 ? lo : hi) >> (8*(k & 3))) & 255u;
+		};
+		{
+			const uint32_t lo = fetch4(first + GRP*lane), hi = CPL == 8 ? fetch4(first + GRP*lane + 256) : 0u;
+			extract(lo, hi, code);
+		}
+		uint32_t nlo = fetch4(first + sub + GRP*lane), nhi = CPL == 8 ? fetch4(first + sub + GRP*lane + 256) : 0u;
 		for(uint32_t tile = first; tile < last; tile += sub) {
 			const uint32_t j0 = tile + GRP*lane;
-			const uint32_t clo = nlo, chi = nhi;
-			nlo = fetch4(j0 + sub);
-			if(CPL == 8) nhi = fetch4(j0 + sub + 256);
-			uint32_t code[CPL], l[CPL], sum0 = 0, sum1 = 0;
+			uint32_t sum0 = 0, sum1 = 0;
 			const bool full = tile + sub <= last;                             // wave-uniform; false only on a stream's last step
+			uint32_t x[CPL][W];                                                // the words' padded copies: read now, their latency
 #pragma unroll
-			for(int k = 0; k < CPL; k++) code[k] = ((k < 4 ? clo : chi) >> (8*(k & 3))) & 255u;
+			for(int k = 0; k < CPL; k++) {                                     // overlaps the length reads and the scan
+				CRT_LDS const uint32_t *e = t16l + W*code[k];
+				if constexpr(W == 1) x[k][0] = e[0];
+				else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
+				else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
+			}
 			if(full) {
 #pragma unroll
 				for(int k = 0; k < CPL; k++) { l[k] = len8[code[k]]; (k < 4 ? sum0 : sum1) += l[k]; }
@@ -495,18 +510,15 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 			const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), total0 = tot & 0xffffu, total = total0 + (tot >> 16);
 			const uint32_t orel0 = (inc & 0xffffu) - sum0, orel1 = total0 + (inc >> 16) - sum1;
 			const bool fast = full && total + 32 <= TUN_WIN && tile + sub < csize && base + total <= size;
+			auto next_codes = [&]() {                                          // the next step's codewords out, the one after's in flight
+				extract(nlo, nhi, code);
+				nlo = fetch4(j0 + 2*sub);
+				if(CPL == 8) nhi = fetch4(j0 + 2*sub + 256);
+			};
 			if(fast) {
 				CRT_GLOBAL uint8_t *g0 = gdst + base;
 				const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
-				{	// compose: all table reads first (their latency overlaps), then the ORs
-					uint32_t x[CPL][W];
-#pragma unroll
-					for(int k = 0; k < CPL; k++) {
-						CRT_LDS const uint32_t *e = t16l + W*code[k];
-						if constexpr(W == 1) x[k][0] = e[0];
-						else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
-						else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
-					}
+				{	// compose
 					uint32_t P = win0 + phase + orel0 - 1u, N = ~P, nlong = 0;
 #pragma unroll
 					for(int k = 0; k < CPL; k++) {
@@ -525,6 +537,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 					}
 					if constexpr(W == 4) if(nlong) tun_drain_long(win0, longq, nlong, off16, len8, tab32);
 				}
+				next_codes();
 				// flush the whole vectors of [0, phase + total) and re-zero them (same wave: LDS program order, no barrier)
 				const uint32_t end = phase + total, nvec = end >> 4;
 				CRT_GLOBAL u32x4_t *gv = (CRT_GLOBAL u32x4_t *)(g0 - phase);
@@ -542,6 +555,10 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 				pending = (end & 15u) > foreign;
 			} else {
 				// general path: byte FIFO straight to HBM, with the clipping rules of the stream's end (tunstall.cpp:447-451)
+				uint32_t ccode[CPL];
+#pragma unroll
+				for(int k = 0; k < CPL; k++) ccode[k] = code[k];
+				next_codes();
 				if(pending) write_pending();
 #pragma unroll
 				for(int h = 0; h < (CPL == 8 ? 2 : 1); h++) {
@@ -556,7 +573,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 						if(kk < CPL) {
 							const uint32_t j = j0 + (h ? 252 + kk : kk);
 							n_ = l[kk < CPL ? kk : 0];
-							wo[k] = L.off[code[kk < CPL ? kk : 0]];
+							wo[k] = L.off[ccode[kk < CPL ? kk : 0]];
 							if(j < last) {
 								if(j + 1 == csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
 								else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
