@@ -385,13 +385,16 @@ __device__ __forceinline__ void tun_drain_long(uint32_t win0, CRT_LDS const uint
 		CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(win0 + (d0 & ~3u));
 		const uint32_t nd = (nbytes + 3u) >> 2;                               // dwords to OR; the last one masked
 		uint32_t lo = t[0], i = 0;
-		for(; i + 4 < nd; i += 4) {
-			const uint32_t t1 = t[i + 1], t2 = t[i + 2], t3 = t[i + 3], t4 = t[i + 4];
-			atomicOr((uint32_t *)(o + i), __builtin_amdgcn_alignbyte(t1, lo, sp));
-			atomicOr((uint32_t *)(o + i + 1), __builtin_amdgcn_alignbyte(t2, t1, sp));
-			atomicOr((uint32_t *)(o + i + 2), __builtin_amdgcn_alignbyte(t3, t2, sp));
-			atomicOr((uint32_t *)(o + i + 3), __builtin_amdgcn_alignbyte(t4, t3, sp));
-			lo = t4;
+		if(nd > 4) {                                                           // reads of the next four dwords go out before this four's ORs
+			uint32_t t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
+			for(; i + 4 < nd; i += 4) {
+				const uint32_t a0 = __builtin_amdgcn_alignbyte(t1, lo, sp), a1 = __builtin_amdgcn_alignbyte(t2, t1, sp);
+				const uint32_t a2 = __builtin_amdgcn_alignbyte(t3, t2, sp), a3 = __builtin_amdgcn_alignbyte(t4, t3, sp);
+				lo = t4;
+				if(i + 8 < nd) { t1 = t[i + 5]; t2 = t[i + 6]; t3 = t[i + 7]; t4 = t[i + 8]; }
+				atomicOr((uint32_t *)(o + i), a0); atomicOr((uint32_t *)(o + i + 1), a1);
+				atomicOr((uint32_t *)(o + i + 2), a2); atomicOr((uint32_t *)(o + i + 3), a3);
+			}
 		}
 		for(; i < nd; i++) {
 			const uint32_t hi = t[i + 1];
