@@ -26,19 +26,19 @@ struct TunStream {
 	uint32_t table;                // TunTable slot
 	uint32_t chunk0;               // first entry of this stream in the chunk arrays (long streams)
 	uint32_t nchunks;
-	uint32_t chunk_codes;          // codewords per chunk (= per K-TUN workgroup), a multiple of 2048
+	uint32_t chunk_codes;          // codewords per chunk (= per K-TUN workgroup), a multiple of 256*cpl
 	uint32_t cpl;                  // staged decode: codewords per lane per step (8, 4, 2 or 1)
 };
 
 // Chunk geometry of one stream, from its mean word length size/csize (both are in the stream header): workgroups are
 // balanced by OUTPUT bytes (a two-symbol dictionary expands 60x, a flat one 2x), and a wave's step of 64*cpl codewords
 // is sized so that its decoded bytes fit the wave's LDS window (k_tunstall.hip).
-constexpr uint32_t TUN_CHUNK_CODES = 16384;   // largest chunk
+constexpr uint32_t TUN_CHUNK_CODES = 32768;   // largest chunk
 inline void tun_pick_geometry(TunStream &t) {
 	const uint32_t avg = t.csize ? (uint32_t)(((uint64_t)t.size + t.csize - 1)/t.csize) : 1;
 	t.cpl = avg <= 8 ? 8 : avg <= 16 ? 4 : avg <= 32 ? 2 : 1;
 	uint32_t codes = TUN_CHUNK_CODES;
-	while(codes > 2048 && (uint64_t)codes*avg > 96*1024) codes >>= 1;
+	while(codes > 256*t.cpl && (uint64_t)codes*avg > 256*1024) codes >>= 1;   // a wave's quarter chunk stays whole steps of 64*cpl
 	t.chunk_codes = codes;
 	t.nchunks = (t.csize + codes - 1)/codes;
 }

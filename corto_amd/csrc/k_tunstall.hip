@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 constexpr uint32_t TUN_WIN = 6*1024 - 64;        // per-wave window
 constexpr uint32_t TUN_SUB = 512;                // most codewords per wave per step
 constexpr uint32_t TUN_LONGQ = 64;               // per-wave queue of long words
-static_assert(2048 % (4*TUN_SUB) == 0 && TUN_CHUNK_CODES % 2048 == 0, "a wave's quarter chunk is whole steps (tun_pick_geometry)");
+static_assert(TUN_SUB == 64*8 && TUN_CHUNK_CODES % (4*TUN_SUB) == 0, "a wave's quarter chunk is whole steps of 64*cpl codewords (tun_pick_geometry)");
 
 // OR the W dwords x[] into the window so that their first byte lands on window byte p.  P is the LDS byte address of
 // window byte p - 1 (the window buffer is 16-byte aligned), N = ~P: the dwords are moved up by p & 3 bytes as
