@@ -56,7 +56,7 @@ class BatchStats(C.Structure):
     _fields_ = [("arena_bytes", C.c_uint64), ("output_bytes", C.c_uint64), ("tunstall_in", C.c_uint64),
                 ("tunstall_out", C.c_uint64), ("tunstall_tables", C.c_uint64), ("tunstall_streams", C.c_uint32),
                 ("total_nvert", C.c_uint64), ("total_nface", C.c_uint64), ("scratch_bytes", C.c_uint64),
-                ("clers_symbols", C.c_uint64), ("split_bytes", C.c_uint64)]
+                ("clers_symbols", C.c_uint64), ("split_bytes", C.c_uint64), ("topology_fallbacks", C.c_uint64)]
 
 
 class MeshDesc(C.Structure):

@@ -374,7 +374,7 @@ struct Plan {
 
 
 static const uint32_t DELTA_LDS_MAX = 64*1024;
-static bool normal_fused(uint32_t nvert, uint32_t nface) { return nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
+static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 65535 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
 struct Launch {
 	crthip_ctx *ctx;
@@ -425,7 +425,7 @@ static int build_and_launch(crthip_batch *b) {
 			if(L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && L.attrs[k].normal_prediction != 0 && !normal_fused(L.h.nvert, L.h.nface)) { est_v += L.h.nvert; est_f += L.h.nface; }
 	}
 	pl.zero_begin = cv.take(0);
-	pl.status_off = cv.take((uint64_t)nblobs*4);
+	pl.status_off = cv.take((uint64_t)nblobs*8);                        // per blob: status, then flags (TopoJob::flags)
 	for(uint32_t i = 0; i < nblobs; i++) {
 		const BlobLayout &L = b->blobs[i].L;
 		if(L.h.nface > 0) bs[i].pred = cv.take((uint64_t)L.h.nvert*12, 16);
@@ -548,12 +548,17 @@ static int build_and_launch(crthip_batch *b) {
 			t.front_a = (uint4 *)SP(S.front_a); t.front_b = (uint2 *)SP(S.front_b);
 			t.order = (uint32_t *)SP(S.order); t.delayed = (uint32_t *)SP(S.delayed);
 			t.status = (int32_t *)SP(pl.status_off + (uint64_t)i*4);
+			t.flags = (int32_t *)SP(pl.status_off + (uint64_t)(nblobs + i)*4);
 			t.nclers = L.clers.size; t.split_nwords = L.split.nwords; t.ngroups = (uint32_t)L.group_end.size();
 			t.nvert = nvert; t.nface = nface; t.front_cap = S.front_cap; t.faces_u16 = P.index ? P.index_u16 : 0;
 			t.pad = P.index ? 1u : 0u;                                   // pad = 1: faces is a real pointer
 			{
-				const uint32_t need = topo_lds_bytes(S.front_cap, L.clers.size);
-				if(nvert <= 65535 && S.front_cap <= 65530 && need <= TOPO_LDS_MAX) { pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need); }
+				const uint32_t slots = topo_lds_slots(S.front_cap, nvert), dslots = std::min(slots, TOPO_LDS_DELAYED);
+				const uint32_t need = topo_lds_bytes(slots, dslots, L.clers.size);
+				if(nvert <= 65535 && slots <= 65530 && need <= TOPO_LDS_MAX) {
+					t.lds_cap = slots; t.lds_delayed_cap = dslots;
+					pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need);
+				}
 				else pl.topo_glob_ids.v.push_back((uint32_t)pl.topo.v.size());
 			}
 			pl.topo.v.push_back(t);
@@ -695,7 +700,7 @@ static int build_and_launch(crthip_batch *b) {
 		if(!t.pad) t.faces = R(t.faces);
 		t.pad = 0;
 		t.pred = (uint32_t *)R(t.pred); t.front_a = (uint4 *)R(t.front_a); t.front_b = (uint2 *)R(t.front_b);
-		t.order = (uint32_t *)R(t.order); t.delayed = (uint32_t *)R(t.delayed); t.status = (int32_t *)R(t.status);
+		t.order = (uint32_t *)R(t.order); t.delayed = (uint32_t *)R(t.delayed); t.status = (int32_t *)R(t.status); t.flags = (int32_t *)R(t.flags);
 	}
 	for(auto &u : pl.unpack.v) {
 		u.logs = R(u.logs);
@@ -829,8 +834,8 @@ static int build_and_launch(crthip_batch *b) {
 	if(ndq) { LT.begin("dequantize"); hipLaunchKernelGGL(k_dequant, dim3(ndq), dim3(256), 0, st, D(pl.dequant), D(pl.dequant_block_job), ndq); LT.end(); }
 
 	// status back to the host
-	if(ctx->status_host.reserve((size_t)nblobs*4 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-	if(nblobs) HIP_TRY(hipMemcpyAsync(ctx->status_host.p, base + pl.status_off, (size_t)nblobs*4, hipMemcpyDeviceToHost, st));
+	if(ctx->status_host.reserve((size_t)nblobs*8 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	if(nblobs) HIP_TRY(hipMemcpyAsync(ctx->status_host.p, base + pl.status_off, (size_t)nblobs*8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipGetLastError());
 
 	// stats
@@ -875,6 +880,8 @@ extern "C" int crthip_batch_sync(crthip_batch *b, int32_t *status) {
 			int32_t s = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
 			b->status[i] = s;
 		}
+		b->stats.topology_fallbacks = 0;
+		for(size_t i = 0; i < b->blobs.size(); i++) b->stats.topology_fallbacks += (uint64_t)(hs[b->blobs.size() + i] & 1);
 		ctx->in_flight = nullptr;
 	}
 	for(size_t i = 0; i < b->blobs.size(); i++) {

@@ -57,9 +57,11 @@ struct TopoJob {
 	uint32_t *order;               // FIFO of edge ids
 	uint32_t *delayed;             // LIFO of edge ids
 	int32_t *status;
+	int32_t *flags;                // bit 0: the LDS path ran out of edge slots and the blob was redone on the HBM front
 	uint32_t nclers, split_nwords, ngroups;
 	uint32_t nvert, nface, front_cap, faces_u16;
 	uint32_t pad;
+	uint32_t lds_cap, lds_delayed_cap;   // LDS path: edge-record slots / DELAY stack entries (0: not eligible)
 };
 
 // one log stream to turn into values (include/corto/cstream.h:294-360)

@@ -228,38 +228,43 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 //   * 16-byte edge records {v0|v1<<16, v2|dead<<16, prev|next<<16, -}: one ds_read_b128 / ds_write_b128 each
 //   * LAZY current edge: the edge created by VERTEX/LEFT/RIGHT is the next one processed (decoder.cpp:261-264),
 //     and when it is consumed right away by another VERTEX/LEFT/RIGHT/END nobody ever reads its record, and the
-//     links its neighbours hold to it are overwritten by that step.  So it lives in registers only, and its record
-//     plus the two neighbour links are written ("materialised") only if it survives (BOUNDARY / DELAY).
-//     Edge ids are internal to the decoder (outputs carry vertex ids only), so this is unobservable.
+//     links its neighbours hold to it are overwritten by that step.  So it lives in registers only; it gets a record
+//     SLOT, its record and the two neighbour links ("materialised") only if it survives (BOUNDARY / DELAY).
+//     Edge ids are internal to the decoder (outputs carry vertex ids only), so this is unobservable - and it means
+//     slots are spent only on queued edges (one per VERTEX / SPLIT, three per seed) and chain ends, about nvert of the
+//     reference's max_front ~ 3*nvert: the front of a 4K-triangle blob takes 39 KB of LDS instead of 100 KB, so three
+//     blobs' automata share a CU (kernels.h: topo_lds_slots).  A blob that runs out of slots is redone on the HBM front.
 //   * RIGHT right after VERTEX closes against the second edge VERTEX just created -> its (next, v1) are cached
 //   * links stored in the front are produced by this loop, hence always in range; only values that come from the
 //     stream are validated; the symbol array is padded with an invalid symbol so running off its end fails
 //     without a per-step bounds test.  Symbols are fetched four at a time.
-// Layout (dynamic LDS): rec[cap+4] (16 B) | order[cap+4] (u16) | delayed[cap+4] (u16) | clers[nclers+64] (u8)
+// Layout (dynamic LDS): rec[cap+4] (16 B) | order[cap+4] (u16) | delayed[dcap+4] (u16) | clers[nclers+64] (u8)
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 template <bool U16>
-__device__ __forceinline__ void topo_lds_body(const TopoJob &J) {
+__device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const uint32_t cap4 = J.front_cap + 4, qbytes = ((cap4*2 + 15) & ~15u);
+	const uint32_t cap = J.lds_cap, dcap = J.lds_delayed_cap;
+	const uint32_t cap4 = cap + 4, qbytes = ((cap4*2 + 15) & ~15u), dbytes = (((dcap + 4)*2 + 15) & ~15u);
 	CRT_LDS u32x4 *rec = (CRT_LDS u32x4 *)as_lds(lds);
 	CRT_LDS uint16_t *rec16 = (CRT_LDS uint16_t *)rec;
 	CRT_LDS uint16_t *order = (CRT_LDS uint16_t *)(rec + cap4);
 	CRT_LDS uint16_t *delayed = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)order + qbytes);
-	CRT_LDS uint8_t *cl = (CRT_LDS uint8_t *)delayed + qbytes;
+	CRT_LDS uint8_t *cl = (CRT_LDS uint8_t *)delayed + dbytes;
 	CRT_LDS const uint32_t *cl32 = (CRT_LDS const uint32_t *)cl;
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	for(uint32_t i = threadIdx.x; i < J.nclers + 64; i += 64) cl[i] = i < J.nclers ? gcl[i] : (uint8_t)0xFF;
 	__syncthreads();
-	if(threadIdx.x != 0) return;
+	if(threadIdx.x != 0) return true;
+	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
 
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
 	CRT_GLOBAL uint32_t *predp = as_global(J.pred);                    // bumped by 3 per new vertex (vertices are numbered in creation order)
 	CRT_GLOBAL uint8_t *facep = as_global((uint8_t *)J.faces);          // bumped by 3 indices per face
 	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
-	const uint32_t cap = J.front_cap, nvert = J.nvert;
+	const uint32_t nvert = J.nvert;
 	const uint32_t splitbits = 32 - __clz(nvert | 1u);
-	uint32_t cler = 0, vc = 0, err = 0;
+	uint32_t cler = 0, vc = 0, err = 0;                                  // err: 1 = bad stream, 2 = out of slots
 	uint32_t sw = cl32[0], swn = cl32[1];                                // symbol words: current (shifted) and next
 	uint64_t bit = 0;
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
@@ -270,7 +275,8 @@ __device__ __forceinline__ void topo_lds_body(const TopoJob &J) {
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)predp = p_; predp += 3; } while(0)
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a) | ((b) << 16); t_.y = (c); t_.z = (p) | ((n) << 16); t_.w = 0; rec[e] = t_; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFFu; sw >>= 8; cler++; if((cler & 3u) == 0) { sw = swn; swn = cl32[(cler >> 2) + 1]; } } while(0)
-#define TOPO_MATERIALISE() do { if(lazy) { TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
+	// give the surviving current edge a slot, its record, and its neighbours their links to it
+#define TOPO_MATERIALISE() do { if(lazy) { if(nfront >= cap) { err = 2; break; } f = nfront++; TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
 
 	uint32_t start = 0;
 	for(uint32_t g = 0; g < J.ngroups && !err; g++) {                   // decoder.cpp:173-178
@@ -298,7 +304,8 @@ __device__ __forceinline__ void topo_lds_body(const TopoJob &J) {
 					}
 					vi[k] = v;
 				}
-				if(err || nfront + 3 > cap) { err = 1; break; }
+				if(err) break;
+				if(nfront + 3 > cap) { err = 2; break; }
 				TOPO_FACE(vi[0], vi[1], vi[2]);
 				const uint32_t e = nfront;
 				order[norder] = (uint16_t)e; order[norder + 1] = (uint16_t)(e + 1); order[norder + 2] = (uint16_t)(e + 2); norder += 3;
@@ -312,65 +319,63 @@ __device__ __forceinline__ void topo_lds_body(const TopoJob &J) {
 			const u32x4 t0 = rec[f];
 			if(t0.y >> 16) continue;                                   // deleted: no symbol consumed (decoder.cpp:278-279)
 			uint32_t v0 = t0.x & 0xFFFFu, v1 = t0.x >> 16, v2 = t0.y & 0xFFFFu, ep = t0.z & 0xFFFFu, en = t0.z >> 16;
-			bool lazy = false;                                         // current edge's record not written yet
+			bool lazy = false;                                         // current edge has no slot / record yet
 			uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;         // cached (next, v1) of edge nc
 
 			// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
 			for(;;) {
 				uint32_t c; TOPO_SYMBOL(c);
-				const uint32_t ne = nfront;
 				if(c == C_VERTEX) {                                    // decoder.cpp:294-309
-					if(vc >= nvert || ne + 2 > cap) { err = 1; break; }
+					const uint32_t s = nfront;                         // slot of the second new edge
+					if(vc >= nvert) { err = 1; break; }
+					if(s >= cap) { err = 2; break; }
 					const uint32_t opp = vc++;
 					TOPO_PRED(v1, v0, v2);
 					TOPO_FACE(v1, v0, opp);
-					rec16[en*8 + 4] = (uint16_t)(ne + 1);              // front[e.next].prev = new_edge + 1
-					order[norder++] = (uint16_t)(ne + 1);
-					TOPO_PUT(ne + 1, opp, v1, v0, ne, en);             // second new edge: queued, so it must exist
-					nfront = ne + 2;
-					nc = ne + 1; nc_next = en; nc_v1 = v1;
-					f = ne; v2 = v1; v1 = opp; en = ne + 1;            // first new edge (v0, opp, old v1, ep, ne+1): next, lazily
+					rec16[en*8 + 4] = (uint16_t)s;                     // front[e.next].prev = new_edge + 1
+					order[norder++] = (uint16_t)s;
+					TOPO_PUT(s, opp, v1, v0, 0xFFFFu, en);             // second new edge: queued, so it must exist; its prev is the lazy edge
+					nfront = s + 1;
+					nc = s; nc_next = en; nc_v1 = v1;
+					v2 = v1; v1 = opp; en = s;                         // first new edge (v0, opp, old v1, ep, s): next, lazily
 					lazy = true;
 				} else if(c == C_LEFT) {                               // decoder.cpp:311-317
-					if(ne + 1 > cap) { err = 1; break; }
 					const u32x4 t = rec[ep];
 					const uint32_t pp = t.z & 0xFFFFu, opp = t.x & 0xFFFFu;
 					rec16[ep*8 + 3] = 1;                               // front[e.prev].deleted = true
 					TOPO_FACE(v1, v0, opp);
-					nfront = ne + 1;
 					nc = 0xFFFFFFFFu;
-					f = ne; v2 = v0; v0 = opp; ep = pp;                // new edge (opp, v1, old v0, pp, en): next, lazily
+					v2 = v0; v0 = opp; ep = pp;                        // new edge (opp, v1, old v0, pp, en): next, lazily
 					lazy = true;
 				} else if(c == C_RIGHT) {                              // decoder.cpp:319-325
-					if(ne + 1 > cap) { err = 1; break; }
 					uint32_t nn, opp;
 					if(en == nc) { nn = nc_next; opp = nc_v1; }
 					else { const u32x4 t = rec[en]; nn = t.z >> 16; opp = t.x >> 16; }
 					rec16[en*8 + 3] = 1;
 					TOPO_FACE(v1, v0, opp);
-					nfront = ne + 1;
 					nc = 0xFFFFFFFFu;
-					f = ne; v2 = v1; v1 = opp; en = nn;                // new edge (v0, opp, old v1, ep, nn): next, lazily
+					v2 = v1; v1 = opp; en = nn;                        // new edge (v0, opp, old v1, ep, nn): next, lazily
 					lazy = true;
 				} else {                                               // ---- cold symbols end the chain ----
 					if(c == C_BOUNDARY) {
 						TOPO_MATERIALISE();
 					} else if(c == C_SPLIT) {
-						if(ne + 2 > cap) { err = 1; break; }
+						const uint32_t s = nfront;
+						if(s >= cap) { err = 2; break; }
 						uint32_t opp; TOPO_BITS(opp, splitbits);
 						if(err) break;
 						const uint32_t o16 = opp & 0xFFFFu;
 						TOPO_FACE(v1, v0, opp);
-						rec16[en*8 + 4] = (uint16_t)(ne + 1);
-						order[norder++] = (uint16_t)(ne + 1);
-						TOPO_PUT(ne + 1, o16, v1, v0, ne, en);
-						nfront = ne + 2;
-						nc = ne + 1; nc_next = en; nc_v1 = v1;
-						f = ne; v2 = v1; v1 = o16; en = ne + 1;
+						rec16[en*8 + 4] = (uint16_t)s;
+						order[norder++] = (uint16_t)s;
+						TOPO_PUT(s, o16, v1, v0, 0xFFFFu, en);
+						nfront = s + 1;
+						nc = s; nc_next = en; nc_v1 = v1;
+						v2 = v1; v1 = o16; en = s;
 						lazy = true;
 						if(start < end) continue;                      // SPLIT continues the chain like VERTEX
 					} else if(c == C_DELAY) {                          // decoder.cpp:327-331
-						if(ndelayed >= cap) { err = 1; break; }
+						if(ndelayed >= dcap) { err = 2; break; }
 						TOPO_MATERIALISE();
 						delayed[ndelayed++] = (uint16_t)f;
 					} else if(c == C_END) {                            // decoder.cpp:333-339
@@ -393,13 +398,20 @@ __device__ __forceinline__ void topo_lds_body(const TopoJob &J) {
 #undef TOPO_PUT
 #undef TOPO_SYMBOL
 #undef TOPO_MATERIALISE
+	if(err == 2) return false;
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
+	return true;
 }
 
 __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
 	const TopoJob J = jobs[job_ids[blockIdx.x]];
-	if(J.faces_u16) topo_lds_body<true>(J); else topo_lds_body<false>(J);
+	const bool done = J.faces_u16 ? topo_lds_body<true>(J) : topo_lds_body<false>(J);
+	if(!done) {                                                          // thread 0 only: redo the blob with the front in HBM
+		*as_global(J.flags) = 1;
+		GlobalFront F{(CRT_GLOBAL u32x4 *)as_global(J.front_a), (CRT_GLOBAL u32x2 *)as_global(J.front_b), as_global(J.order), as_global(J.delayed)};
+		topo_run(J, as_global(J.clers), F);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

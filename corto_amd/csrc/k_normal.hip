@@ -188,34 +188,31 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small-blob path: the whole ESTIMATED/BORDER pipeline of one blob in ONE workgroup with every intermediate in LDS
-// (integer positions, incidence counts -> CSR offsets, boundary XORs, adjacency, correction slots), replacing nine
-// batch-wide launches.  Same arithmetic and the same ascending-face-id accumulation order as the kernels above.
-// Dynamic LDS layout: pos[3*nvert] i32 | cnt[nvert+1] | start[nvert+1] | bnd[nvert] | slot[nvert+1] u32 | adj[3*nface] u16
-__host__ __device__ inline uint32_t normal_blob_lds_bytes(uint32_t nvert, uint32_t nface) {
-	return (3*nvert + 4*(nvert + 1))*4 + ((3*nface*2 + 15) & ~15u) + 64;
-}
-
+// Small-blob path: the whole ESTIMATED/BORDER pipeline of one blob in ONE workgroup with its intermediates in LDS
+// (incidence counts -> CSR offsets, boundary XORs, adjacency, correction slots), replacing nine batch-wide launches.
+// Same arithmetic and the same ascending-face-id accumulation order as the kernels above.  The integer positions are
+// read from HBM/L2 (25 KB for a 2K-vertex blob: it stays in the CU's L1) rather than staged, and offsets are 16-bit
+// (3*nface <= 65535), so that the workgroup's LDS (50 KB for the 4K-triangle blob) fits beside the CLERS automata of
+// the batches behind it in a pipelined decode (k_mesh.hip: three 49 KB fronts per CU leave little).
+// Dynamic LDS layout: cnt[nvert+1] u32 | bnd[nvert] u32 | start[nvert+1] u16 | slot[nvert+1] u16 | adj[3*nface] u16
 __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
 	const NormalJob J = jobs[job_ids[blockIdx.x]];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 	const uint32_t nv = J.nvert, nf = J.nface, tid = threadIdx.x;
-	CRT_LDS int32_t *pos = (CRT_LDS int32_t *)as_lds(lds_raw);
-	CRT_LDS uint32_t *cnt = (CRT_LDS uint32_t *)(pos + 3*nv);
-	CRT_LDS uint32_t *start = cnt + nv + 1;
-	CRT_LDS uint32_t *bnd = start + nv + 1;
-	CRT_LDS uint32_t *slot = bnd + nv;
-	CRT_LDS uint16_t *adj = (CRT_LDS uint16_t *)(slot + nv + 1);
+	CRT_LDS uint32_t *cnt = (CRT_LDS uint32_t *)as_lds(lds_raw);
+	CRT_LDS uint32_t *bnd = cnt + nv + 1;
+	CRT_LDS uint16_t *start = (CRT_LDS uint16_t *)(bnd + nv);
+	CRT_LDS uint16_t *slot = start + ((nv + 2) & ~1u);
+	CRT_LDS uint16_t *adj = slot + ((nv + 2) & ~1u);
 	__shared__ uint32_t scan_s[4];
-	CRT_GLOBAL const int32_t *gpos = as_global(J.position);
+	CRT_GLOBAL const int32_t *pos = as_global(J.position);
 	CRT_GLOBAL const uint32_t *f32 = J.faces_u16 ? nullptr : as_global((const uint32_t *)J.faces);
 	CRT_GLOBAL const uint16_t *f16 = J.faces_u16 ? as_global((const uint16_t *)J.faces) : nullptr;
 	auto face = [&](uint32_t f, uint32_t &a, uint32_t &b, uint32_t &c) {
 		if(f16) { a = f16[3*(size_t)f]; b = f16[3*(size_t)f + 1]; c = f16[3*(size_t)f + 2]; }
 		else { a = f32[3*(size_t)f]; b = f32[3*(size_t)f + 1]; c = f32[3*(size_t)f + 2]; }
 	};
-	for(uint32_t i = tid; i < 3*nv; i += 256) pos[i] = gpos[i];
 	for(uint32_t i = tid; i <= nv; i += 256) { cnt[i] = 0; if(i < nv) bnd[i] = 0; }
 	__syncthreads();
 	// incidence counts + boundary XOR (markBoundary, normal_attribute.cpp:24-37)
@@ -230,14 +227,14 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	__syncthreads();
 	// two block-wide exclusive scans over the vertices: CSR offsets of cnt, and correction slots of the flags
 	const uint32_t per = (nv + 255)/256;
-	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint32_t *out, bool flags) {
+	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint16_t *out, bool flags) {
 		const uint32_t i0 = tid*per;
 		uint32_t s = 0;
 		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; }
 		uint32_t total;
 		uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
-		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { out[i] = o; o += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; } }
-		if(tid == 0) out[nv] = total;
+		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { out[i] = (uint16_t)o; o += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; } }
+		if(tid == 0) out[nv] = (uint16_t)total;
 	};
 	block_scan(cnt, start, false);
 	block_scan(bnd, slot, true);
@@ -253,7 +250,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	__syncthreads();
 	// per vertex: ordered accumulation (estimateNormals :40-59) + computeNormals (:281-325)
 	for(uint32_t i = tid; i < nv; i += 256) {
-		const uint32_t s0 = start[i], deg = start[i + 1] - s0;
+		const uint32_t s0 = start[i], deg = (uint32_t)start[i + 1] - s0;
 		float ex = 0.f, ey = 0.f, ez = 0.f;
 		int32_t last = -1;
 		for(uint32_t done = 0; done < deg;) {
@@ -263,7 +260,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 				if((int32_t)f > last) { if(f < best) { best = f; mult = 1; } else if(f == best) mult++; }
 			}
 			uint32_t a, b, c; face(best, a, b, c);
-			const CRT_LDS int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
+			CRT_GLOBAL const int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
 			const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
 			const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
 			const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;

@@ -186,6 +186,22 @@ def holey_disc(n=40, seed=0, hole_frac=0.12, color_components=3):
     return Mesh(pos, tris, nrm, col, uv)
 
 
+def strip(n=400, seed=0, color_components=4):
+    """A 2 x n ribbon: every edge but the rungs is a boundary edge, so nearly every CLERS chain ends on the boundary
+    after one triangle (the automaton's worst case for edge records per vertex)."""
+    j = np.arange(2 * n, dtype=np.float32)
+    col_i, row_i = np.floor(j / 2), j % 2
+    ang = col_i * np.float32(0.05)
+    s, c = _sincos(ang)
+    r = np.float32(1.0) + row_i * np.float32(0.2)
+    px, py, pz = r * c, r * s, col_i * np.float32(0.01) + _lcg_fast(seed, 2 * n) * np.float32(0.002)
+    nrm, uv, col = _grid_attrs(2, n, px.reshape(n, 2), py.reshape(n, 2), pz.reshape(n, 2), seed, color_components)
+    pos = np.stack([px, py, pz], axis=1)
+    k = np.arange(n - 1, dtype=np.uint32) * 2
+    tris = np.concatenate([np.stack([k, k + 2, k + 1], axis=1), np.stack([k + 1, k + 2, k + 3], axis=1)])
+    return Mesh(pos, tris, nrm, col, uv)
+
+
 def merge(meshes):
     """Concatenate meshes into one multi-component mesh."""
     off = 0

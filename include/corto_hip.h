@@ -183,6 +183,8 @@ typedef struct {
 	uint64_t scratch_bytes;
 	uint64_t clers_symbols;     /* decoded CLERS symbols over all mesh blobs */
 	uint64_t split_bytes;       /* bytes of the split / vertex-id bit blocks */
+	uint64_t topology_fallbacks;/* after crthip_batch_sync: mesh blobs whose CLERS automaton outgrew its LDS edge slots and was
+	                               redone with the front in HBM (same results, slower) */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

@@ -331,6 +331,22 @@ def test_config3_167k_point_cloud(ctx):
         assert_same(got, r, KEYS, "C3 vs reference")
 
 
+def test_topology_lds_slot_overflow_redone_on_hbm_front(ctx):
+    """the LDS automaton budgets ~1.125 edge records per vertex; a ribbon needs ~2 (every chain ends on the boundary), so it
+    runs out of slots and is redone on the HBM front - same results, and reported in the stats; in a batch with blobs that fit"""
+    from corto_amd import synth
+    meshes = [synth.strip(400, seed=3), synth.bumpy_sphere(24, 12, seed=5), synth.strip(90, seed=4), synth.holey_disc(40, seed=2, color_components=4)]
+    blobs = [ca.encode(m, normal_prediction=ca.BORDER) for m in meshes]
+    for u16 in (False, True):
+        b = run_batch(ctx, blobs, index16=u16)
+        for i in range(len(blobs)):
+            exp = oc.decode(blobs[i])
+            if u16:
+                exp["index"] = exp["index"].astype(np.uint16)
+            assert_same(b.host_outputs(i), exp, KEYS, "blob %d u16=%s" % (i, u16))
+        assert b.stats().topology_fallbacks == 3, b.stats().topology_fallbacks   # both ribbons and the holey disc
+
+
 def test_config4_256_distinct_blobs(ctx):
     """256 distinct 4K-tri blobs in one batch: every blob equals the oracle; decoded positions equal the quantised inputs"""
     from corto_amd import synth
@@ -339,6 +355,7 @@ def test_config4_256_distinct_blobs(ctx):
     b = run_batch(ctx, blobs)
     st = b.stats()
     assert st.total_nface == 256 * 4096 and st.total_nvert == 256 * 2112
+    assert st.topology_fallbacks == 0
     for i in range(0, 256, 5):
         got = b.host_outputs(i)
         assert_same(got, oc.decode(blobs[i]), KEYS, "C4 blob %d" % i)
