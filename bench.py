@@ -9,6 +9,11 @@ Workload (config C4 of BASELINE.json): a batch of 256 independent ~4K-triangle .
 = 1 048 576 triangles / 540 672 vertices PER GPU (weak scaling: config C5 = 8 GPUs x 256 blobs).
 A "step" = one pass of the hot path over that batch with the compressed blobs already resident in HBM:
 plan (host walk of every blob + descriptor upload) + bind + all kernels + sync; outputs stay in HBM.
+Steps are PIPELINED --depth deep (default 4): step i runs on context i % depth (own HIP streams, scratch and output
+buffers), so the host's planning of one batch and the short data-parallel kernels of another overlap the 1.6 ms
+serial CLERS kernel of a third (three 49 KB automata fit one CU).  Every one of the K steps is launched AND
+completed inside the timed region; value = K batches / elapsed.  `single_batch` reports the unpipelined latency of
+one step and the per-kernel HIP-event times come from that unpipelined phase (no co-running kernels).
 One JSON line on stdout (rank 0).
 """
 import argparse
@@ -19,6 +24,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one HW queue per HIP stream of the pipelined contexts (the ROCm default of 4
+                                                   # makes streams share queues, and a shared queue serialises its kernels)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -108,6 +115,7 @@ def tunstall_scaled(ctx, ca, z, table_ids=None):
     oo, ot = [], 0
     for s in sizes:
         oo.append(ot); ot += (s + 15) & ~15
+    ctx.set_profiling(True)                      # per-kernel HIP events (crthip_kernel_times)
     dblk = torch.from_numpy(host).cuda()
     dout = torch.empty(ot + 16, dtype=torch.uint8, device="cuda")
     best = None
@@ -129,6 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=4, help="batches in flight (contexts); 1 = unpipelined")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")
     args = ap.parse_args()
@@ -150,12 +159,17 @@ def main():
     # C5 = world x 256 blobs cut into contiguous work-balanced ranges; this rank decodes only its own (no collective)
     lo, hi = shard.my_range([4096 + 2112] * (NBLOBS * world), world, rank)
     assert hi - lo == NBLOBS
-    ctx = ca.Context(local_rank)
+    depth = max(1, args.depth)
+    ctxs = [ca.Context(local_rank) for _ in range(depth)]
+    ctx = ctxs[0]
     arena = ca.upload_arena(blobs, local_rank)   # compressed inputs resident in HBM before the timed region
-    # outputs are allocated and bound once (like a caller that reuses its vertex/index buffers)
-    b0 = ca.Batch(ctx, blobs, device_arena=arena)
-    b0.allocate_outputs()
-    keep = b0._keep
+    # outputs are allocated and bound once per context (like a caller that reuses its vertex/index buffers)
+    slots = []
+    for c in ctxs:
+        bk = ca.Batch(c, blobs, device_arena=arena)
+        bk.allocate_outputs()
+        slots.append(bk)
+    b0 = slots[0]
     stats0 = None
     # one step = plan + bind + decode + sync, through the C ABI only
     import ctypes as C
@@ -163,48 +177,75 @@ def main():
     n = len(blobs)
     ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in blobs])
     lens = np.array([len(x) for x in blobs], dtype=np.uint32)
-    buf, binds, index_ptrs, index_fmt = keep
     status = np.zeros(n, dtype=np.int32)
 
-    def one_step():
+    def launch(k):
         h = C.c_void_p()
-        ca._check(L.crthip_batch_create(ctx.handle, n, ptrs, lens.ctypes.data_as(C.c_void_p), C.c_void_p(arena.data_ptr()), C.byref(h)))
+        buf, binds, index_ptrs, index_fmt = slots[k]._keep
+        ca._check(L.crthip_batch_create(ctxs[k].handle, n, ptrs, lens.ctypes.data_as(C.c_void_p), C.c_void_p(arena.data_ptr()), C.byref(h)))
         ca._check(L.crthip_batch_bind_all(h, binds, index_ptrs, index_fmt.ctypes.data_as(C.c_void_p)))
         ca._check(L.crthip_batch_decode(h))
-        ca._check(L.crthip_batch_sync(h, status.ctypes.data_as(C.c_void_p)))
         return h
+
+    def finish(h, destroy=True):
+        ca._check(L.crthip_batch_sync(h, status.ctypes.data_as(C.c_void_p)))
+        assert (status == 0).all(), status
+        if destroy:
+            L.crthip_batch_destroy(h)
+
+    def run_pipelined(steps):
+        pend = [None] * depth
+        for i in range(steps):
+            k = i % depth
+            if pend[k] is not None:
+                finish(pend[k])
+            pend[k] = launch(k)
+        for h in pend:
+            if h is not None:
+                finish(h)
 
     def device_sync():
         torch.cuda.synchronize()
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
 
     def barrier():
         shard.barrier(dist, device_sync)
 
-    ctx.set_profiling(True)                      # HIP events around every kernel, on the stream the kernels run on
-    for _ in range(args.warmup):
-        L.crthip_batch_destroy(one_step())
-    barrier()
+    # ---- unpipelined phase: latency of one batch, and per-kernel device times (HIP events around every kernel, on the
+    # stream the kernels run on) with nothing else on the GPU - the numbers the rocprofv3 summary in profiles/ agrees with
+    ctx.set_profiling(True)
     kt_acc = {}
+    solo_steps = max(3, min(10, args.steps))
+    finish(launch(0))
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h = one_step()
+    for _ in range(solo_steps):
+        h = launch(0)
+        finish(h, destroy=False)
         kt = ca.KernelTimes()
         L.crthip_batch_kernel_times(h, C.byref(kt))
         for k, v in kt.as_dict().items():
             a = kt_acc.setdefault(k, [0.0, 0]); a[0] += v["ms"]; a[1] += v["launches"]
         st = ca.BatchStats(); L.crthip_batch_get_stats(h, C.byref(st)); stats0 = st
         L.crthip_batch_destroy(h)
+    solo_ms = (time.perf_counter() - t0) / solo_steps * 1e3
+    ctx.set_profiling(False)
+
+    # ---- the timed region: W warm-up steps, then exactly K steps, pipelined `depth` deep
+    run_pipelined(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_pipelined(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, torch.device("cuda", local_rank))
-    assert (status == 0).all(), status
 
     # untimed bit-exactness check of this rank's outputs against the golden digests made by the reference
     import hashlib
     from oracle import oracle as oc
-    for i in range(0, NBLOBS, 17):                # every 17th blob against the CPU oracle ...
-        got, ref = b0.host_outputs(i), oc.decode(blobs[i])
+    for i in range(0, NBLOBS, 17):                # every 17th blob against the CPU oracle (each context's buffers in turn) ...
+        got, ref = slots[(i // 17) % depth].host_outputs(i), oc.decode(blobs[i])
         for k in ("position", "normal", "color", "uv", "index"):
             assert got[k].tobytes() == ref[k].tobytes(), ("bit-exact check failed", i, k)
     if rank == 0:
@@ -217,7 +258,7 @@ def main():
     if rank == 0:
         ntri, nvert = int(stats0.total_nface), int(stats0.total_nvert)
         ms_step = elapsed / args.steps * 1e3
-        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps} for k, v in kt_acc.items()}
+        kernels = {k: {"ms_per_step": round(v[0] / solo_steps, 4), "launches_per_step": v[1] // solo_steps} for k, v in kt_acc.items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         # algorithmic bytes of the dominant kernel per launch
         topo_bytes = int(stats0.clers_symbols + stats0.split_bytes + ntri * 12 + nvert * 12)
@@ -239,9 +280,12 @@ def main():
             "data": "synthetic: 256 distinct bumpy-sphere meshes per GPU (seeds 256*rank ..), encoded by the repo's byte-identical .crt writer",
             "config": {"workload": "C4: 256 x (2112 verts / 4096 tris), pos14+uv12+normal10(BORDER)+rgba, per GPU; C5 when n_gpus=8",
                        "blobs_per_gpu": NBLOBS, "tris_per_gpu": ntri, "verts_per_gpu": nvert,
-                       "timed_region": "plan(host walk)+bind+kernels+sync, compressed inputs resident in HBM, outputs left in HBM",
-                       "parallelism": "blob-sharded x%d, no collective" % world},
-            "bit_exact": True,
+                       "timed_region": "K x [plan(host walk)+bind+kernels+sync], compressed inputs resident in HBM, outputs left in HBM",
+                       "pipeline_depth": depth,
+                       "parallelism": "blob-sharded x%d, no collective; %d batches in flight per GPU" % (world, depth)},
+            "bit_exact": True, "topology_fallbacks": int(stats0.topology_fallbacks),
+            "single_batch": {"ms": round(solo_ms, 4), "mtri_per_s": round(ntri / solo_ms / 1e3, 2), "steps": solo_steps,
+                             "note": "one batch at a time on one context (latency); `kernels` and `roofline` are measured in this phase"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},

@@ -12,7 +12,7 @@ ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in blobs])
 lens = np.array([len(x) for x in blobs], dtype=np.uint32)
 arena = ca.upload_arena(blobs, 0)
 ntri = 256 * 4096
-for depth in (1, 2, 3, 4):
+for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
     ctxs = [ca.Context(0) for _ in range(depth)]
     keeps = []
     for c in ctxs:

@@ -4,16 +4,26 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pipe
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
 GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tests/pipe_probe.py > $OUT/log.txt 2>&1
 python - <<PY
-import csv, glob
+import csv, glob, collections
 f = glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-t0 = int(rows[0]["Start_Timestamp"])
-# last 400 kernels = depth 4 phase
-tail = rows[-330:]
-b = int(tail[0]["Start_Timestamp"])
-for r in tail[:110]:
-    n = r["Kernel_Name"].split("(")[0].replace("corto_hip::", "")
-    print("%-22s q%-3s start %9.1f dur %8.1f us" % (n, r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - b) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+topo = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_topology_lds" in r["Kernel_Name"]]
+# depth-4 phase = last 46 topology launches
+ph = topo[-40:]
+t0, t1 = ph[0][0], ph[-1][1]
+print("depth-4 phase: %d topology launches in %.2f ms -> %.3f ms/step" % (len(ph), (t1 - t0) / 1e6, (t1 - t0) / 1e6 / len(ph)))
+ev = sorted([(s, 1) for s, e in ph] + [(e, -1) for s, e in ph])
+cur = 0; last = t0; hist = collections.Counter()
+for t, d in ev:
+    hist[cur] += t - last; last = t; cur += d
+print("time share by number of concurrent topology kernels:", {k: round(v / (t1 - t0), 3) for k, v in sorted(hist.items())})
+print("topology duration avg %.0f us" % (sum(e - s for s, e in ph) / len(ph) / 1e3))
+acc = collections.defaultdict(list)
+for r in rows:
+    s = int(r["Start_Timestamp"])
+    if t0 <= s <= t1: acc[r["Kernel_Name"].split("(")[0].replace("corto_hip::", "")].append((int(r["End_Timestamp"]) - s) / 1e3)
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    print("%-28s n=%4d avg %8.1f us max %8.1f" % (k, len(v), sum(v) / len(v), max(v)))
 PY
-tail -4 $OUT/log.txt
+tail -4 $OUT/log.txt | head -4
