@@ -231,6 +231,16 @@ def main():
         L.crthip_batch_destroy(h)
     solo_ms = (time.perf_counter() - t0) / solo_steps * 1e3
     ctx.set_profiling(False)
+    # PCIe-inclusive variant of the same unpipelined step: the blobs start in host memory and crthip_batch_create uploads them
+    t0 = time.perf_counter()
+    for _ in range(solo_steps):
+        h = C.c_void_p()
+        buf, binds, index_ptrs, index_fmt = slots[0]._keep
+        ca._check(L.crthip_batch_create(ctx.handle, n, ptrs, lens.ctypes.data_as(C.c_void_p), None, C.byref(h)))
+        ca._check(L.crthip_batch_bind_all(h, binds, index_ptrs, index_fmt.ctypes.data_as(C.c_void_p)))
+        ca._check(L.crthip_batch_decode(h))
+        finish(h)
+    h2d_ms = (time.perf_counter() - t0) / solo_steps * 1e3
 
     # ---- the timed region: W warm-up steps, then exactly K steps, pipelined `depth` deep
     run_pipelined(args.warmup)
@@ -285,7 +295,11 @@ def main():
                        "parallelism": "blob-sharded x%d, no collective; %d batches in flight per GPU" % (world, depth)},
             "bit_exact": True, "topology_fallbacks": int(stats0.topology_fallbacks),
             "single_batch": {"ms": round(solo_ms, 4), "mtri_per_s": round(ntri / solo_ms / 1e3, 2), "steps": solo_steps,
-                             "note": "one batch at a time on one context (latency); `kernels` and `roofline` are measured in this phase"},
+                             "note": "one batch at a time on one context (latency); `kernels` and `roofline` are measured in this phase",
+                             "host_us": {"create_walk": round(stats0.host_create_us, 1), "plan": round(stats0.host_plan_us, 1),
+                                         "stage": round(stats0.host_stage_us, 1), "launch": round(stats0.host_launch_us, 1)},
+                             "from_host_memory": {"ms": round(h2d_ms, 4), "mtri_per_s": round(ntri / h2d_ms / 1e3, 2),
+                                                  "note": "same step with the %.1f MB of compressed blobs uploaded over PCIe inside it" % (stats0.arena_bytes / 1e6)}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},

@@ -4,6 +4,7 @@
 // The schedule restates the stage order of crt::Decoder::decodeMesh / decodePointCloud
 // (src/decoder.cpp:133-196) for a whole batch of blobs at once:
 //   decode-all (Tunstall + bit-unpack) -> topology -> delta-all -> postDelta (normals) -> dequantize-all.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -233,9 +234,12 @@ extern "C" int crthip_ctx_sync(crthip_ctx *c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 extern "C" int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens,
                                    const void *device_arena, crthip_batch **out) {
 	if(!ctx || !out || (nblobs && (!blobs || !lens))) return fail(CRTHIP_E_ARGUMENT);
+	const double t_create = now_us();
 	HIP_TRY(hipSetDevice(ctx->device));
 	crthip_batch *b = new crthip_batch();
 	b->ctx = ctx;
@@ -265,6 +269,7 @@ extern "C" int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8
 		b->d_arena = (const uint8_t *)b->own_arena.p;
 	}
 	b->status.assign(nblobs, 0);
+	b->stats.host_create_us = (float)(now_us() - t_create);
 	*out = b;
 	return CRTHIP_OK;
 }
@@ -394,11 +399,9 @@ struct Launch {
 	}
 };
 
-#include <chrono>
-static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int build_and_launch(crthip_batch *b) {
 	crthip_ctx *ctx = b->ctx;
-	const bool TT = getenv("CRTHIP_HOST_TIMING") != nullptr; double t0 = now_us(), t1 = 0, t2 = 0, t3 = 0;
+	const double t0 = now_us(); double t1 = 0, t2 = 0, t3 = 0;        // host-side cost of a decode call (crthip_batch_stats::host_*_us)
 	Plan pl;
 	Carver cv;
 	const uint32_t nblobs = (uint32_t)b->blobs.size();
@@ -858,7 +861,7 @@ static int build_and_launch(crthip_batch *b) {
 	b->decoded = true;
 	b->dirty = false;
 	t3 = now_us();
-	if(TT) fprintf(stderr, "plan %.1f us, fixup+stage %.1f us, launches %.1f us\n", t1 - t0, t2 - t1, t3 - t2);
+	b->stats.host_plan_us = (float)(t1 - t0); b->stats.host_stage_us = (float)(t2 - t1); b->stats.host_launch_us = (float)(t3 - t2);
 	return CRTHIP_OK;
 }
 

@@ -185,6 +185,10 @@ typedef struct {
 	uint64_t split_bytes;       /* bytes of the split / vertex-id bit blocks */
 	uint64_t topology_fallbacks;/* after crthip_batch_sync: mesh blobs whose CLERS automaton outgrew its LDS edge slots and was
 	                               redone with the front in HBM (same results, slower) */
+	float host_plan_us;         /* host time of the last crthip_batch_decode: job planning (descriptor build) ... */
+	float host_stage_us;        /* ... pointer fix-up + staging of the descriptors ... */
+	float host_launch_us;       /* ... and issuing the copies / kernel launches (asynchronous; no device wait) */
+	float host_create_us;       /* host time of crthip_batch_create: header parse + bounds-checked walk of every blob */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

@@ -1,7 +1,7 @@
 """Ad-hoc GPU bring-up script (not a test): decode each golden fixture, print the first mismatch per array."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import corto_amd as ca
 from conftest import ALL_CASES, load_golden

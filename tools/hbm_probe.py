@@ -1,3 +1,5 @@
+"""Calibration: what torch's own fill / copy kernels reach on this GPU (achievable HBM bandwidth beside the 8 TB/s spec).
+Measured on the MI355X box in round 1: fill 6.7 TB/s, copy 4.8 TB/s (read+write)."""
 import torch, time
 x = torch.empty(1 << 30, dtype=torch.int32, device="cuda")   # 4 GiB
 y = torch.empty_like(x)

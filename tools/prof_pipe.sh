@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pipe
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tests/pipe_probe.py > $OUT/log.txt 2>&1
+GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tools/pipe_probe.py > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True)[0]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): bash tests/prof_run.sh <tag>
+# usage (on the GPU box, via gpurun): bash tools/prof_run.sh <tag>
 # writes rocprofv3 summaries under gpurun_out/prof_<tag>; the ones to be judged are copied into profiles/.
 TAG=${1:-r01}
 export TMPDIR=/tmp
