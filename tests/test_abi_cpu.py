@@ -82,3 +82,35 @@ def test_no_gpu_means_loud_failure(L):
         pytest.skip("a GPU is present")
     with pytest.raises(ca.CortoError, match="no CPU fallback"):
         ca.Context(0)
+
+
+def _veneer():
+    from corto_amd import build
+    if not os.path.exists(build.VENEER):
+        build.build()
+    V = C.CDLL(build.VENEER)
+    V.CreateDecoder.restype = C.c_void_p
+    V.CreateDecoder.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    V.DestroyDecoder.argtypes = [C.c_void_p]
+    V.DecodeMesh.restype = C.c_int
+    V.DecodeMesh.argtypes = [C.c_void_p] * 6
+    return V
+
+
+def test_unity_veneer_exports_and_parses_on_the_host(L):
+    """the legacy C ABI of upstream's cortocodec_unity (src/corto_codec.h:41-43): same three symbols; CreateDecoder is the
+    host-side header parse (info = (nface, nvert), src/corto_codec.cpp:11-13) and needs no GPU"""
+    V = _veneer()
+    for name in ("c4_unit", "cloud_border"):
+        g = load_golden(name)
+        blob = aligned(g["crt"])
+        info = np.zeros(2, dtype=np.float32)
+        d = V.CreateDecoder(len(blob), blob.ctypes.data, info.ctypes.data)
+        assert d, name
+        nface = len(g["index"]) if "index" in g else 0
+        assert info[0] == nface and info[1] == len(g["position"])
+        if nface == 0:                       # point cloud: refused before anything touches the device
+            assert V.DecodeMesh(d, None, None, None, None, None) == -1
+        V.DestroyDecoder(d)
+    junk = aligned(np.zeros(64, dtype=np.uint8))
+    assert not V.CreateDecoder(len(junk), junk.ctypes.data, None)      # "Not a crt file." does not cross the C boundary

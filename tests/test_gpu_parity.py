@@ -172,6 +172,35 @@ def test_cpp_decoder_dropin(ctx, tmp_path):
     assert out.returncode == 1 and "Not a crt file." in out.stderr
 
 
+def test_unity_veneer_decode_mesh(ctx):
+    """CreateDecoder / DecodeMesh / DestroyDecoder (include/corto/corto_codec.h = upstream src/corto_codec.h:41-43) driven the
+    way unity/CortoMeshLoader.cs does: arrays sized from info, one DecodeMesh call"""
+    import ctypes as C
+    from corto_amd import build
+    V = C.CDLL(build.VENEER)
+    V.CreateDecoder.restype = C.c_void_p
+    V.CreateDecoder.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    V.DestroyDecoder.argtypes = [C.c_void_p]
+    V.DecodeMesh.restype = C.c_int
+    V.DecodeMesh.argtypes = [C.c_void_p] * 6
+    for name in ("c4_unit", "torus", "two_groups"):
+        g = load_golden(name)
+        blob = aligned(g["crt"])
+        info = np.zeros(2, dtype=np.float32)
+        d = V.CreateDecoder(len(blob), blob.ctypes.data, info.ctypes.data)
+        assert d
+        nface, nvert = int(info[0]), int(info[1])
+        pos = np.zeros((nvert, 3), np.float32); nrm = np.zeros((nvert, 3), np.float32); uv = np.zeros((nvert, 2), np.float32)
+        col = np.zeros((nvert, 4), np.float32); idx = np.zeros((nface, 3), np.int32)
+        assert V.DecodeMesh(d, pos.ctypes.data, idx.ctypes.data, nrm.ctypes.data, col.ctypes.data, uv.ctypes.data) == nface
+        V.DestroyDecoder(d)
+        exp = oc.decode(g["crt"], color_components=4)
+        assert pos.tobytes() == exp["position"].tobytes() and idx.tobytes() == exp["index"].tobytes(), name
+        if "normal" in exp: assert nrm.tobytes() == exp["normal"].tobytes(), name
+        if "uv" in exp: assert uv.tobytes() == exp["uv"].tobytes(), name
+        if "color" in exp: assert col.tobytes() == (exp["color"].astype(np.float32) / np.float32(255.0)).tobytes(), name
+
+
 def test_topology_failure_is_reported_per_blob(ctx):
     g = load_golden("holey_disc"); ok = load_golden("torus")
     bad = g["crt"].copy()
