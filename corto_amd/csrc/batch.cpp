@@ -379,7 +379,7 @@ struct Plan {
 
 
 static const uint32_t DELTA_LDS_MAX = 64*1024;
-static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 65535 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
+static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 32767 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
 struct Launch {
 	crthip_ctx *ctx;
@@ -795,7 +795,7 @@ static int build_and_launch(crthip_batch *b) {
 	}
 	if(!pl.delta.v.empty()) {
 		LT.begin("delta_mesh");
-		hipLaunchKernelGGL(k_delta_mesh, dim3((uint32_t)pl.delta.v.size()), dim3(1024), pl.delta_lds, st, D(pl.delta), (uint32_t)pl.delta.v.size(), pl.delta_lds);
+		hipLaunchKernelGGL(k_delta_mesh, dim3((uint32_t)pl.delta.v.size()), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), (uint32_t)pl.delta.v.size(), pl.delta_lds);
 		LT.end();
 	}
 	if(cloud_chunks) {

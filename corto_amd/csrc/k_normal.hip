@@ -194,17 +194,18 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
 // read from HBM/L2 (25 KB for a 2K-vertex blob: it stays in the CU's L1) rather than staged, and offsets are 16-bit
 // (3*nface <= 65535), so that the workgroup's LDS (50 KB for the 4K-triangle blob) fits beside the CLERS automata of
 // the batches behind it in a pipelined decode (k_mesh.hip: three 49 KB fronts per CU leave little).
-// Dynamic LDS layout: cnt[nvert+1] u32 | bnd[nvert] u32 | start[nvert+1] u16 | slot[nvert+1] u16 | adj[3*nface] u16
+// Dynamic LDS layout: cnt[nvert+1] u32 | start[nvert+1] u16 | slot[nvert+1] u16 | bnd[nvert] u32, later adj[3*nface] u16
+// (the boundary flag moves into slot's top bit - nvert <= 32767 - once the slots are scanned, and the adjacency takes bnd's place)
 __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
 	const NormalJob J = jobs[job_ids[blockIdx.x]];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 	const uint32_t nv = J.nvert, nf = J.nface, tid = threadIdx.x;
 	CRT_LDS uint32_t *cnt = (CRT_LDS uint32_t *)as_lds(lds_raw);
-	CRT_LDS uint32_t *bnd = cnt + nv + 1;
-	CRT_LDS uint16_t *start = (CRT_LDS uint16_t *)(bnd + nv);
+	CRT_LDS uint16_t *start = (CRT_LDS uint16_t *)(cnt + nv + 1);
 	CRT_LDS uint16_t *slot = start + ((nv + 2) & ~1u);
-	CRT_LDS uint16_t *adj = slot + ((nv + 2) & ~1u);
+	CRT_LDS uint32_t *bnd = (CRT_LDS uint32_t *)(slot + ((nv + 2) & ~1u));
+	CRT_LDS uint16_t *adj = (CRT_LDS uint16_t *)bnd;
 	__shared__ uint32_t scan_s[4];
 	CRT_GLOBAL const int32_t *pos = as_global(J.position);
 	CRT_GLOBAL const uint32_t *f32 = J.faces_u16 ? nullptr : as_global((const uint32_t *)J.faces);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; }
 		uint32_t total;
 		uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
-		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { out[i] = (uint16_t)o; o += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; } }
+		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { const uint32_t x = flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; out[i] = (uint16_t)(flags ? o | x << 15 : o); o += x; } }
 		if(tid == 0) out[nv] = (uint16_t)total;
 	};
 	block_scan(cnt, start, false);
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			for(uint32_t m = 0; m < mult; m++) { ex += nx; ey += ny; ez += nz; }
 			last = (int32_t)best; done += mult;
 		}
-		if(J.prediction == 1 || bnd[i] != 0) {
-			const uint32_t sl = slot[i];
+		if(slot[i] & 0x8000u) {                                          // ESTIMATED: every vertex; BORDER: boundary vertices
+			const uint32_t sl = slot[i] & 0x7FFFu;
 			int32_t qx, qy;
 			to_octa(ex, ey, ez, J.unit, qx, qy);
 			int32_t dx = 0, dy = 0;

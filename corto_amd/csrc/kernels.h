@@ -30,12 +30,13 @@ __global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uin
 __global__ void k_topology(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 __global__ void k_topology_lds(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 // dynamic LDS bytes k_topology_lds needs for a front of `cap` edges and `nclers` symbols
-inline uint32_t topo_lds_bytes(uint32_t cap, uint32_t dcap, uint32_t nclers) { return (cap + 4)*16 + (((cap + 4)*2 + 15) & ~15u) + (((dcap + 4)*2 + 15) & ~15u) + ((nclers + 64 + 15) & ~15u); }
+inline uint32_t topo_lds_bytes(uint32_t cap, uint32_t dcap, uint32_t nclers) { return (cap + 4)*16 + (((dcap + 4)*2 + 15) & ~15u) + (((nclers + 64 + 7)/8*4 + 15) & ~15u); }
 // Edge-record slots the LDS path gets: records exist only for edges that wait in the queue (one per VERTEX / SPLIT, three
 // per seed face) or end a chain on the boundary, about one per vertex; a blob that needs more is redone on the HBM front.
-inline uint32_t topo_lds_slots(uint32_t front_cap, uint32_t nvert) { const uint32_t want = nvert + nvert/8 + 64; return want < front_cap ? want : front_cap; }
+inline uint32_t topo_lds_slots(uint32_t front_cap, uint32_t nvert) { const uint32_t want = nvert + nvert/16 + 64; return want < front_cap ? want : front_cap; }
 constexpr uint32_t TOPO_LDS_DELAYED = 256;
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
+constexpr uint32_t DELTA_THREADS = 256;       // threads of the dataflow workgroup of one (blob, attribute)
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);
 
 // k_normal.hip
@@ -51,7 +52,7 @@ __global__ void k_normal_vertex(const NormalJob *jobs, const uint32_t *block_job
                                 const uint32_t *flag, const uint32_t *slot);
 
 __global__ void k_normal_blob(const NormalJob *jobs, const uint32_t *job_ids, uint32_t njobs);
-inline uint32_t normal_blob_lds(uint32_t nvert, uint32_t nface) { return (2*nvert + 1)*4 + 2*((nvert + 2) & ~1u)*2 + ((3*nface*2 + 15) & ~15u) + 64; }
+inline uint32_t normal_blob_lds(uint32_t nvert, uint32_t nface) { const uint32_t adj = (3*nface*2 + 15) & ~15u, bnd = nvert*4; return (nvert + 1)*4 + 2*((nvert + 2) & ~1u)*2 + (adj > bnd ? adj : bnd) + 64; }
 constexpr uint32_t NORMAL_LDS_MAX = 150*1024;
 
 

@@ -16,7 +16,7 @@ for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
     ctxs = [ca.Context(0) for _ in range(depth)]
     keeps = []
     for c in ctxs:
-        b = ca.Batch(c, blobs, device_arena=arena); b.allocate_outputs(); keeps.append((b, b._keep))
+        b = ca.Batch(c, blobs, device_arena=arena); b.allocate_outputs(only=set(os.environ['ONLY'].split(',')) if os.environ.get('ONLY') else None); keeps.append((b, b._keep))
     status = np.zeros(n, dtype=np.int32)
     def launch(k):
         h = C.c_void_p()
