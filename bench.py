@@ -9,9 +9,10 @@ Workload (config C4 of BASELINE.json): a batch of 256 independent ~4K-triangle .
 = 1 048 576 triangles / 540 672 vertices PER GPU (weak scaling: config C5 = 8 GPUs x 256 blobs).
 A "step" = one pass of the hot path over that batch with the compressed blobs already resident in HBM:
 plan (host walk of every blob + descriptor upload) + bind + all kernels + sync; outputs stay in HBM.
-Steps are PIPELINED --depth deep (default 4): step i runs on context i % depth (own HIP streams, scratch and output
-buffers), so the host's planning of one batch and the short data-parallel kernels of another overlap the 1.6 ms
-serial CLERS kernel of a third (three 49 KB automata fit one CU).  Every one of the K steps is launched AND
+Steps are PIPELINED: --host-threads (default 2) host threads each keep --depth (default 3) batches in flight, every
+batch on its own context (own HIP streams, scratch and output buffers), so the host's planning of one batch and the
+short data-parallel kernels of another overlap the 1.6 ms serial CLERS kernel of a third (three 40 KB automata fit
+one CU).  Every one of the K steps is launched AND
 completed inside the timed region; value = K batches / elapsed.  `single_batch` reports the unpipelined latency of
 one step and the per-kernel HIP-event times come from that unpipelined phase (no co-running kernels).
 One JSON line on stdout (rank 0).
@@ -135,9 +136,10 @@ def tunstall_scaled(ctx, ca, z, table_ids=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=4, help="batches in flight (contexts); 1 = unpipelined")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (contexts) per host thread; 1 = unpipelined")
+    ap.add_argument("--host-threads", type=int, default=2, help="host threads feeding the GPU (the C ABI releases the GIL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")
     args = ap.parse_args()
@@ -147,20 +149,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import corto_amd as ca
+    # test hook (tools/): BENCH_SHARE_GPU=1 lets several ranks share one GPU, with gloo for the barrier (RCCL refuses
+    # duplicate devices) - exercises the N>1 code path on a 1-GPU box; never set by the driver
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world); red_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=red_dev)
 
     from corto_amd import shard
     blobs, z = load_blobs(first_seed=NBLOBS * rank)   # C5: rank r decodes seeds 256r .. 256r+255
     # C5 = world x 256 blobs cut into contiguous work-balanced ranges; this rank decodes only its own (no collective)
     lo, hi = shard.my_range([4096 + 2112] * (NBLOBS * world), world, rank)
     assert hi - lo == NBLOBS
-    depth = max(1, args.depth)
-    ctxs = [ca.Context(local_rank) for _ in range(depth)]
+    depth, nthreads = max(1, args.depth), max(1, args.host_threads)
+    ctxs = [ca.Context(local_rank) for _ in range(depth * nthreads)]
     ctx = ctxs[0]
     arena = ca.upload_arena(blobs, local_rank)   # compressed inputs resident in HBM before the timed region
     # outputs are allocated and bound once per context (like a caller that reuses its vertex/index buffers)
@@ -187,22 +198,39 @@ def main():
         ca._check(L.crthip_batch_decode(h))
         return h
 
-    def finish(h, destroy=True):
-        ca._check(L.crthip_batch_sync(h, status.ctypes.data_as(C.c_void_p)))
-        assert (status == 0).all(), status
+    def finish(h, destroy=True, st=status):
+        ca._check(L.crthip_batch_sync(h, st.ctypes.data_as(C.c_void_p)))
+        assert (st == 0).all(), st
         if destroy:
             L.crthip_batch_destroy(h)
 
+    def worker(t, steps, errors):
+        # host thread t owns contexts [t*depth, (t+1)*depth): step i of its share runs on context t*depth + i % depth
+        try:
+            st = np.zeros(n, dtype=np.int32)
+            pend = [None] * depth
+            for i in range(steps):
+                k = i % depth
+                if pend[k] is not None:
+                    finish(pend[k], st=st)
+                pend[k] = launch(t * depth + k)
+            for h in pend:
+                if h is not None:
+                    finish(h, st=st)
+        except BaseException as e:       # surfaced by run_pipelined
+            errors.append(e)
+
     def run_pipelined(steps):
-        pend = [None] * depth
-        for i in range(steps):
-            k = i % depth
-            if pend[k] is not None:
-                finish(pend[k])
-            pend[k] = launch(k)
-        for h in pend:
-            if h is not None:
-                finish(h)
+        import threading
+        share = [steps // nthreads + (1 if t < steps % nthreads else 0) for t in range(nthreads)]
+        errors = []
+        ths = [threading.Thread(target=worker, args=(t, share[t], errors)) for t in range(nthreads)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errors:
+            raise errors[0]
 
     def device_sync():
         torch.cuda.synchronize()
@@ -242,20 +270,22 @@ def main():
         finish(h)
     h2d_ms = (time.perf_counter() - t0) / solo_steps * 1e3
 
-    # ---- the timed region: W warm-up steps, then exactly K steps, pipelined `depth` deep
+    # ---- the timed region: W warm-up steps, then exactly K steps, pipelined.  Every context is first used once (its scratch
+    # pool is allocated on first use), whatever W is.
+    run_pipelined(depth * nthreads)
     run_pipelined(args.warmup)
     barrier()
     t0 = time.perf_counter()
     run_pipelined(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dist, torch.device("cuda", local_rank))
+    elapsed = shard.max_over_ranks(elapsed, dist, red_dev)
 
     # untimed bit-exactness check of this rank's outputs against the golden digests made by the reference
     import hashlib
     from oracle import oracle as oc
     for i in range(0, NBLOBS, 17):                # every 17th blob against the CPU oracle (each context's buffers in turn) ...
-        got, ref = slots[(i // 17) % depth].host_outputs(i), oc.decode(blobs[i])
+        got, ref = slots[(i // 17) % len(slots)].host_outputs(i), oc.decode(blobs[i])
         for k in ("position", "normal", "color", "uv", "index"):
             assert got[k].tobytes() == ref[k].tobytes(), ("bit-exact check failed", i, k)
     if rank == 0:
@@ -291,8 +321,8 @@ def main():
             "config": {"workload": "C4: 256 x (2112 verts / 4096 tris), pos14+uv12+normal10(BORDER)+rgba, per GPU; C5 when n_gpus=8",
                        "blobs_per_gpu": NBLOBS, "tris_per_gpu": ntri, "verts_per_gpu": nvert,
                        "timed_region": "K x [plan(host walk)+bind+kernels+sync], compressed inputs resident in HBM, outputs left in HBM",
-                       "pipeline_depth": depth,
-                       "parallelism": "blob-sharded x%d, no collective; %d batches in flight per GPU" % (world, depth)},
+                       "pipeline_depth": depth, "host_threads": nthreads,
+                       "parallelism": "blob-sharded x%d, no collective; %d host threads x %d batches in flight per GPU" % (world, nthreads, depth)},
             "bit_exact": True, "topology_fallbacks": int(stats0.topology_fallbacks),
             "single_batch": {"ms": round(solo_ms, 4), "mtri_per_s": round(ntri / solo_ms / 1e3, 2), "steps": solo_steps,
                              "note": "one batch at a time on one context (latency); `kernels` and `roofline` are measured in this phase",
