@@ -239,9 +239,10 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 //   * links stored in the front are produced by this loop, hence always in range; only values that come from the
 //     stream are validated; the symbol array is padded with an invalid symbol so running off its end fails
 //     without a per-step bounds test.  Symbols are fetched four at a time.
-//   * the FIFO of queued edges is threaded through the records' fourth dword (a pop's record read also yields the next
-//     entry), and the symbols sit in LDS as nibbles, eight per dword: 40 KB per 4K-triangle blob in all.
-// Layout (dynamic LDS): rec[cap+4] (16 B; rec[cap+1] is the FIFO's dummy tail) | delayed[dcap+4] (u16) | clers nibbles
+//   * the FIFO of queued edges needs no storage: queued edges take slots upwards from 0 in the order they are queued,
+//     so the queue is a cursor over the slots (surviving chain ends take slots downwards from the top); the symbols
+//     sit in LDS as nibbles, eight per dword: 40 KB per 4K-triangle blob in all.
+// Layout (dynamic LDS): rec[cap+4] (16 B) | delayed[dcap+4] (u16) | clers nibbles
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 template <bool U16>
@@ -251,7 +252,6 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	const uint32_t cap4 = cap + 4, dbytes = (((dcap + 4)*2 + 15) & ~15u);
 	CRT_LDS u32x4 *rec = (CRT_LDS u32x4 *)as_lds(lds);
 	CRT_LDS uint16_t *rec16 = (CRT_LDS uint16_t *)rec;
-	CRT_LDS uint32_t *rec32 = (CRT_LDS uint32_t *)rec;
 	CRT_LDS uint16_t *delayed = (CRT_LDS uint16_t *)(rec + cap4);
 	CRT_LDS uint32_t *cl32 = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)delayed + dbytes);
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
@@ -282,23 +282,19 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)predp = p_; predp += 3; } while(0)
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a) | ((b) << 16); t_.y = (c); t_.z = (p) | ((n) << 16); t_.w = 0; rec[e] = t_; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = cl32[(cler >> 3) + 1]; } } while(0)
-	// FIFO push: link from the current tail (the dummy record while the queue is empty), remember the head if there was none
-#define TOPO_PUSH(s_) do { rec32[qtail*4 + 3] = (s_); qhead = qhead == QNONE ? (s_) : qhead; qtail = (s_); } while(0)
 	// give the surviving current edge a slot, its record, and its neighbours their links to it
-#define TOPO_MATERIALISE() do { if(lazy) { if(nfront >= cap) { err = 2; break; } f = nfront++; TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
+#define TOPO_MATERIALISE() do { if(lazy) { if(nq >= mtop) { err = 2; break; } f = --mtop; TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
 
 	uint32_t start = 0;
 	for(uint32_t g = 0; g < J.ngroups && !err; g++) {                   // decoder.cpp:173-178
 		const uint32_t ge = group_end[g];
 		if(ge > J.nface || ge*3 < start) { err = 1; break; }
 		const uint32_t end = ge*3;
-		const uint32_t QNONE = 0xFFFFFFFFu, QDUMMY = cap + 1;
-		uint32_t nfront = 0, ndelayed = 0, qhead = QNONE, qtail = QDUMMY;
+		uint32_t nq = 0, qpos = 0, mtop = cap, ndelayed = 0;                 // queued slots [0, nq), popped up to qpos; survivors [mtop, cap)
 		while(start < end && !err) {
 			// ---- cold: fetch the next edge to process: queue, delayed stack, or a new seed face ----
 			uint32_t f;
-			bool from_queue = false;
-			if(qhead != QNONE) { f = qhead; from_queue = true; }
+			if(qpos < nq) f = qpos++;
 			else if(ndelayed) f = delayed[--ndelayed];
 			else {                                                     // seed face (decoder.cpp:224-259)
 				uint32_t c; TOPO_SYMBOL(c);
@@ -316,19 +312,16 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 					vi[k] = v;
 				}
 				if(err) break;
-				if(nfront + 3 > cap) { err = 2; break; }
+				if(nq + 3 > mtop) { err = 2; break; }
 				TOPO_FACE(vi[0], vi[1], vi[2]);
-				const uint32_t e = nfront;
+				const uint32_t e = nq;
 				TOPO_PUT(e, vi[1], vi[2], vi[0], e + 2, e + 1);
 				TOPO_PUT(e + 1, vi[2], vi[0], vi[1], e, e + 2);
 				TOPO_PUT(e + 2, vi[0], vi[1], vi[2], e + 1, e);
-				TOPO_PUSH(e); TOPO_PUSH(e + 1); TOPO_PUSH(e + 2);
-				nfront += 3;
+				nq += 3;                                                   // all three wait in the queue
 				continue;
 			}
-			if(f >= nfront) { err = 1; break; }                        // cannot happen: queue entries are ours
 			const u32x4 t0 = rec[f];
-			if(from_queue) { if(f == qtail) { qhead = QNONE; qtail = QDUMMY; } else qhead = t0.w; }   // the record carries the next queue entry
 			if(t0.y >> 16) continue;                                   // deleted: no symbol consumed (decoder.cpp:278-279)
 			uint32_t v0 = t0.x & 0xFFFFu, v1 = t0.x >> 16, v2 = t0.y & 0xFFFFu, ep = t0.z & 0xFFFFu, en = t0.z >> 16;
 			bool lazy = false;                                         // current edge has no slot / record yet
@@ -338,16 +331,15 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 			for(;;) {
 				uint32_t c; TOPO_SYMBOL(c);
 				if(c == C_VERTEX) {                                    // decoder.cpp:294-309
-					const uint32_t s = nfront;                         // slot of the second new edge
+					const uint32_t s = nq;                             // slot of the second new edge = its place in the queue
 					if(vc >= nvert) { err = 1; break; }
-					if(s >= cap) { err = 2; break; }
+					if(s >= mtop) { err = 2; break; }
 					const uint32_t opp = vc++;
 					TOPO_PRED(v1, v0, v2);
 					TOPO_FACE(v1, v0, opp);
 					rec16[en*8 + 4] = (uint16_t)s;                     // front[e.next].prev = new_edge + 1
 					TOPO_PUT(s, opp, v1, v0, 0xFFFFu, en);             // second new edge: queued, so it must exist; its prev is the lazy edge
-					TOPO_PUSH(s);
-					nfront = s + 1;
+					nq = s + 1;
 					nc = s; nc_next = en; nc_v1 = v1;
 					v2 = v1; v1 = opp; en = s;                         // first new edge (v0, opp, old v1, ep, s): next, lazily
 					lazy = true;
@@ -372,16 +364,15 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 					if(c == C_BOUNDARY) {
 						TOPO_MATERIALISE();
 					} else if(c == C_SPLIT) {
-						const uint32_t s = nfront;
-						if(s >= cap) { err = 2; break; }
+						const uint32_t s = nq;
+						if(s >= mtop) { err = 2; break; }
 						uint32_t opp; TOPO_BITS(opp, splitbits);
 						if(err) break;
 						const uint32_t o16 = opp & 0xFFFFu;
 						TOPO_FACE(v1, v0, opp);
 						rec16[en*8 + 4] = (uint16_t)s;
 						TOPO_PUT(s, o16, v1, v0, 0xFFFFu, en);
-						TOPO_PUSH(s);
-						nfront = s + 1;
+						nq = s + 1;
 						nc = s; nc_next = en; nc_v1 = v1;
 						v2 = v1; v1 = o16; en = s;
 						lazy = true;
@@ -409,7 +400,6 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #undef TOPO_PRED
 #undef TOPO_PUT
 #undef TOPO_SYMBOL
-#undef TOPO_PUSH
 #undef TOPO_MATERIALISE
 	if(err == 2) return false;
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
