@@ -71,9 +71,18 @@ def cpu_baseline(blobs, budget_s=12.0):
     while time.perf_counter() - t_start < budget_s:
         best = min(best, run()); n += 1
     verts = 2112 * len(sample)
-    return {"value": round(tris / best / 1e6, 3), "unit": "Mtri/s", "mverts_per_s": round(verts / best / 1e6, 3), "cores": 1, "kind": kind,
-            "sample": "16 distinct C4-unit blobs (65 536 tris) decoded back to back, best of %d passes in %.0f s; ctor+set*+decode per blob" % (n, budget_s),
-            "host_cpus": os.cpu_count()}
+    out = {"value": round(tris / best / 1e6, 3), "unit": "Mtri/s", "mverts_per_s": round(verts / best / 1e6, 3), "cores": 1, "kind": kind,
+           "sample": "16 distinct C4-unit blobs (65 536 tris) decoded back to back, best of %d passes in %.0f s; ctor+set*+decode per blob" % (n, budget_s),
+           "host_cpus": os.cpu_count()}
+    if rc.available():
+        # context: the same decoder on every host core at once, one blob per thread (the C call releases the GIL)
+        nthr = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ndone = rc.decode_mt(sample, nthr, 4.0)
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(ndone * 4096 / wall / 1e6, 1), "unit": "Mtri/s", "threads": nthr,
+                            "note": "reference decoder on %d C++ threads, one blob per thread, for %.1f s (context, not the baseline)" % (nthr, wall)}
+    return out
 
 
 def pmc_traffic(kernel):
@@ -269,6 +278,14 @@ def main():
         ca._check(L.crthip_batch_decode(h))
         finish(h)
     h2d_ms = (time.perf_counter() - t0) / solo_steps * 1e3
+    # ... and with the decoded outputs copied back to (pinned) host memory as well: what a host-side caller of crt::Decoder pays
+    dbuf = slots[0]._keep[0]
+    hbuf = torch.empty(dbuf.shape, dtype=dbuf.dtype, pin_memory=True)
+    t0 = time.perf_counter()
+    for _ in range(solo_steps):
+        finish(launch(0))
+        hbuf.copy_(dbuf, non_blocking=True); torch.cuda.synchronize()
+    d2h_ms = (time.perf_counter() - t0) / solo_steps * 1e3
 
     # ---- the timed region: W warm-up steps, then exactly K steps, pipelined.  Every context is first used once (its scratch
     # pool is allocated on first use), whatever W is.
@@ -329,7 +346,9 @@ def main():
                              "host_us": {"create_walk": round(stats0.host_create_us, 1), "plan": round(stats0.host_plan_us, 1),
                                          "stage": round(stats0.host_stage_us, 1), "launch": round(stats0.host_launch_us, 1)},
                              "from_host_memory": {"ms": round(h2d_ms, 4), "mtri_per_s": round(ntri / h2d_ms / 1e3, 2),
-                                                  "note": "same step with the %.1f MB of compressed blobs uploaded over PCIe inside it" % (stats0.arena_bytes / 1e6)}},
+                                                  "note": "same step with the %.1f MB of compressed blobs uploaded over PCIe inside it" % (stats0.arena_bytes / 1e6)},
+                             "to_host_memory": {"ms": round(d2h_ms, 4), "mtri_per_s": round(ntri / d2h_ms / 1e3, 2),
+                                                "note": "same step plus the %.1f MB of decoded outputs copied to pinned host memory" % (stats0.output_bytes / 1e6)}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},

@@ -8,6 +8,7 @@
 //
 // Used by: tests/ (golden-vector generation + parity checks) and bench.py's cpu_baseline leg
 // (cpu_baseline.kind == "reference").
+#include <thread>
 #include <stdint.h>
 #include <string.h>
 #include <chrono>
@@ -188,6 +189,41 @@ int ref_decode_timed(const uint8_t *blob, int len, const ref_out_t *o, int iters
 		g_err = e;
 		return -1;
 	}
+}
+
+// The same timed region on `nthreads` host threads at once, thread t decoding blob t % nblobs over and over for
+// `seconds` (all blobs take outputs of the shape `o` describes; every thread has its own copy of the buffers).
+// Returns the number of completed decodes (context figure for bench.py: all host cores vs one GPU).
+int64_t ref_decode_mt(const uint8_t *const *blobs, const int *lens, int nblobs, const ref_out_t *o, uint32_t nvert, uint32_t nface,
+                      int nthreads, double seconds) {
+	std::vector<int64_t> done(nthreads, 0);
+	std::vector<std::thread> th;
+	auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+	for(int t = 0; t < nthreads; t++) th.emplace_back([&, t]() {
+		ref_out_t mine = *o;                                // private output buffers of the largest shape (nvert, nface)
+		std::vector<std::vector<uint8_t>> bufs;
+		auto own = [&](size_t bytes) { bufs.emplace_back(bytes + 64); return (void *)bufs.back().data(); };
+		if(o->position) mine.position = (float *)own((size_t)nvert*12);
+		if(o->normal) mine.normal = own((size_t)nvert*12);
+		if(o->color) mine.color = (uint8_t *)own((size_t)nvert*4);
+		if(o->uv) mine.uv = (float *)own((size_t)nvert*8);
+		if(o->radius) mine.radius = (float *)own((size_t)nvert*4);
+		if(o->index32) mine.index32 = (uint32_t *)own((size_t)nface*12);
+		if(o->index16) mine.index16 = (uint16_t *)own((size_t)nface*6);
+		const int b = t % nblobs;
+		try {
+			while(std::chrono::steady_clock::now() < t_end) {
+				Decoder dec(lens[b], blobs[b]);
+				bind(dec, &mine);
+				dec.decode();
+				done[t]++;
+			}
+		} catch(const char *) {}
+	});
+	for(auto &x : th) x.join();
+	int64_t n = 0;
+	for(auto d : done) n += d;
+	return n;
 }
 
 // Stage hooks ------------------------------------------------------------------------------

@@ -188,6 +188,18 @@ def decode_timed(blob: np.ndarray, iters=20, normal_format=FLOAT, color_componen
     return ns, info
 
 
+def decode_mt(blobs, nthreads: int, seconds: float, normal_format=FLOAT, color_components=4) -> int:
+    """all blobs must have the attribute set of blobs[0]; returns completed decodes over `nthreads` C++ threads"""
+    infos = [probe(b) for b in blobs]
+    outs, o = _alloc_outputs(infos[0], normal_format, color_components)
+    ptrs = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+    lens = (C.c_int * len(blobs))(*[len(b) for b in blobs])
+    f = lib().ref_decode_mt
+    f.restype = C.c_int64
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_double]
+    return int(f(ptrs, lens, len(blobs), C.byref(o), max(i["nvert"] for i in infos), max(i["nface"] for i in infos), nthreads, seconds))
+
+
 def tunstall_tables(probs: np.ndarray):
     probs = np.ascontiguousarray(probs, dtype=np.uint8).reshape(-1, 2)
     idx = np.zeros(256, dtype=np.int32); ln = np.zeros(256, dtype=np.int32)
