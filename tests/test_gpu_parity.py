@@ -218,6 +218,51 @@ def test_topology_failure_is_reported_per_blob(ctx):
     assert st[0] in (0, -5)
 
 
+@pytest.mark.timeout(180)
+def test_corrupt_blobs_never_fault_or_disturb_neighbours(ctx):
+    """byte-flipped, burst-corrupted, garbage-tailed and zero-windowed copies of every fixture, decoded in ONE batch next to
+    intact blobs: whatever the host walk cannot reject either fails per blob (CRTHIP_E_TOPOLOGY) or decodes garbage - no
+    fault, no hang, and the intact neighbours stay bit-exact (the reference itself reads out of bounds on such input)"""
+    rng = np.random.default_rng(7)
+    names = list(MESH_CASES) + list(CLOUD_CASES)
+    good = load_golden("c4_unit")
+    blobs, intact = [], []
+    for i in range(96):
+        g = load_golden(names[i % len(names)])
+        b = g["crt"].copy()
+        body = oc.parse_header(b)["body_offset"]
+        mode = i % 4
+        if mode == 0:
+            for p in rng.integers(body, len(b), 6):
+                b[p] ^= rng.integers(1, 256)
+        elif mode == 1:
+            p = int(rng.integers(body, max(body + 1, len(b) - 64))); b[p:p + 48] ^= 0xA5
+        elif mode == 2:
+            p = int(rng.integers(body, len(b))); b[p:] = rng.integers(0, 256, len(b) - p, dtype=np.uint8)
+        else:
+            p = int(rng.integers(body, max(body + 1, len(b) - 200))); b[p:p + 160] = 0
+        blobs.append(aligned(b)); intact.append(False)
+        if i % 8 == 7:
+            blobs.append(aligned(good["crt"])); intact.append(True)
+    keep = []
+    for i, b in enumerate(blobs):                     # what the bounds-checked host walk proves truncated never reaches the device
+        try:
+            ca.Batch(ctx, [b]).close(); keep.append(i)
+        except ca.CortoError:
+            assert not intact[i]
+    assert len(keep) > len(blobs) // 2
+    bt = ca.Batch(ctx, [blobs[i] for i in keep])
+    bt.allocate_outputs(fill=0)
+    bt.decode()
+    st = bt.sync(raise_on_error=False)
+    assert set(np.unique(st)) <= {0, -5}
+    ref = oc.decode(good["crt"])
+    for j, i in enumerate(keep):
+        if intact[i]:
+            assert st[j] == 0
+            assert_same(bt.host_outputs(j), ref, KEYS, "intact blob %d among corrupt ones" % j)
+
+
 def test_unsupported_format_fails_loudly(ctx):
     g = load_golden("c4_unit")
     b = ca.Batch(ctx, [g["crt"]])
