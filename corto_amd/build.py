@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorto_hip.so")
-VENEER = os.path.join(LIBDIR, "libcortocodec_hip.so")   # legacy Unity C ABI (include/corto/corto_codec.h) over the facade
+VENEER = os.path.join(LIBDIR, "libcortocodec_hip.so")
+CLI = os.path.join(LIBDIR, "corto_hip")                   # the `corto` command line tool on this repo's encoder + GPU decoder (tools/corto_hip_cli.cpp)   # legacy Unity C ABI (include/corto/corto_codec.h) over the facade
 SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_normal.hip", "batch.cpp", "crt_format.cpp", "decoder_facade.cpp", "encoder.cpp"]
 HEADERS = ["kernels_common.h", "kernels.h", "device_plan.h", "crt_format.h",
            os.path.join("..", "..", "include", "corto_hip.h"), os.path.join("..", "..", "include", "corto", "decoder.h")]
@@ -64,6 +65,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(VENEER, [vsrc, LIB, os.path.join(inc, "corto", "corto_codec.h"), os.path.join(inc, "corto", "decoder.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", inc, vsrc, "-o", VENEER,
                "-L", LIBDIR, "-lcorto_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    csrc = os.path.join(HERE, "..", "tools", "corto_hip_cli.cpp")
+    if os.path.exists(csrc) and (force or _stale(CLI, [csrc, LIB, os.path.join(inc, "corto_hip.h"), os.path.join(inc, "corto", "decoder.h")])):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", inc, csrc, "-o", CLI, "-L", LIBDIR, "-lcorto_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -15,6 +15,7 @@
 //   normals                   src/normal_attribute.cpp:113-176 (preDelta, deltaEncode, encode)
 // Where the reference's output depends on std::sort's handling of ties (probability order, edge buckets, Morton order)
 // the same std::sort call on the same element sequence is made, which reproduces it exactly.
+#include <cfloat>
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -577,6 +578,19 @@ int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *
 			const float intervals = powf(2.0f, (float)m->position_bits);
 			float e[3]; for(int k = 0; k < 3; k++) { e[k] = mx[k] - mn[k]; e[k] /= intervals; }
 			q = std::max(std::max(e[0], e[1]), e[2]);
+		} else if(q == 0.0f && E.nface) {                       // a twentieth of the mean length of each face's first edge (src/encoder.cpp:105-110)
+			double average = 0;
+			for(uint32_t f = 0; f < E.nface; f++) {
+				const float *a = m->position + (size_t)m->index[(size_t)f*3]*3, *b = m->position + (size_t)m->index[(size_t)f*3 + 1]*3;
+				const float d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+				average += (float)sqrt((double)(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]));   // Point3f::norm, include/corto/point.h:111
+			}
+			q = (float)(average/E.nface)/20.0f;
+		} else if(q == 0.0f && nv) {                            // point cloud: from the bounding box volume (src/encoder.cpp:83-91)
+			float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+			for(uint32_t i = 0; i < nv; i++) for(int k = 0; k < 3; k++) { const float v = m->position[(size_t)i*3 + k] - 0.0f; if(v < mn[k]) mn[k] = v; if(v > mx[k]) mx[k] = v; }
+			for(int k = 0; k < 3; k++) mx[k] -= mn[k];
+			q = (float)(0.02*pow(mx[0]*mx[1]*mx[2], 2.0/3.0)/nv);
 		}
 		Attr &a = E.data["position"];
 		a.name = "position"; a.N = 3; a.q = q; a.format = CRTHIP_FMT_FLOAT;

@@ -201,6 +201,28 @@ def test_unity_veneer_decode_mesh(ctx):
         if "color" in exp: assert col.tobytes() == (exp["color"].astype(np.float32) / np.float32(255.0)).tobytes(), name
 
 
+def test_cli_round_trip_ply_identical_to_the_reference_cli(ctx, tmp_path):
+    """corto_hip in.ply -o out.crt -P out.ply (tools/corto_hip_cli.cpp: this repo's encoder, decode on the GPU through the
+    crt::Decoder facade) against the reference's own CLI (oracle/_ref/corto_ref_cli) on the same PLY and options: same .crt,
+    same decoded .ply, byte for byte"""
+    from cli_common import REF_CLI, our_cli, run, write_ply
+    from corto_amd import synth
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/corto_ref_cli did not travel")
+    cases = [(synth.bumpy_sphere(32, 16, seed=21), dict(), ["-v", "13"]),
+             (synth.torus(24, 12, seed=22), dict(binary=False), ["-N", "estimated"]),
+             (synth.holey_disc(20, seed=23, color_components=4), dict(uv_names=("s", "t")), ["-v", "12", "-N", "delta", "-n", "11"]),
+             (synth.bumpy_sphere(20, 10, seed=24), dict(faces=False), ["-v", "14", "-N", "delta"])]
+    for k, (m, kw, opts) in enumerate(cases):
+        d = tmp_path / ("case%d" % k)
+        d.mkdir()
+        write_ply(str(d / "in.ply"), m, **kw)
+        run(REF_CLI, ["in.ply", "-o", "ref.crt", "-P", "ref.ply"] + opts, str(d))
+        run(our_cli(), ["in.ply", "-o", "ours.crt", "-P", "ours.ply"] + opts, str(d))
+        assert (d / "ref.crt").read_bytes() == (d / "ours.crt").read_bytes(), k
+        assert (d / "ref.ply").read_bytes() == (d / "ours.ply").read_bytes(), k
+
+
 def test_topology_failure_is_reported_per_blob(ctx):
     g = load_golden("holey_disc"); ok = load_golden("torus")
     bad = g["crt"].copy()
