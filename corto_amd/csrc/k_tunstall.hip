@@ -363,7 +363,7 @@ static_assert(TUN_SUB == 64*8 && TUN_CHUNK_CODES % (4*TUN_SUB) == 0, "a wave's q
 // {x[i], x[i-1]} >> 8*((-p) & 3) - v_alignbyte_b32 takes the shift from the low two bits of N - which for p & 3 == 0
 // yields them one dword late; addressing from (p - 1) & ~3 instead of p & ~3 absorbs exactly that.
 template <int W> __device__ __forceinline__ void tun_or(uint32_t P, uint32_t N, const uint32_t *x) {
-	CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(P & ~3u);
+	CRT_LDS uint32_t *o = lds_at<uint32_t>(P & ~3u);
 	uint32_t prev = 0;
 #pragma unroll
 	for(int i = 0; i < W; i++) { atomicOr((uint32_t *)(o + i), __builtin_amdgcn_alignbyte(x[i], prev, N)); prev = x[i]; }
@@ -382,7 +382,7 @@ __device__ __forceinline__ void tun_drain_long(uint32_t win0, CRT_LDS const uint
 		const uint32_t sp = (uint32_t)off16[cd] + 16u - (d0 & 3u);           // table byte that lands on the first dword's byte 0
 		const uint32_t nbytes = (uint32_t)len8[cd] - 16u + (d0 & 3u);        // bytes from there to the word's end
 		CRT_LDS const uint32_t *t = tab32 + (sp >> 2);
-		CRT_LDS uint32_t *o = (CRT_LDS uint32_t *)(win0 + (d0 & ~3u));
+		CRT_LDS uint32_t *o = lds_at<uint32_t>(win0 + (d0 & ~3u));
 		const uint32_t nd = (nbytes + 3u) >> 2;                               // dwords to OR; the last one masked
 		uint32_t lo = t[0], i = 0;
 		if(nd > 4) {                                                           // reads of the next four dwords go out before this four's ORs

@@ -16,6 +16,11 @@ namespace corto_hip {
 #define CRT_LDS __attribute__((address_space(3)))
 template <typename T> __device__ __forceinline__ CRT_GLOBAL T *as_global(T *p) { return (CRT_GLOBAL T *)p; }
 template <typename T> __device__ __forceinline__ CRT_LDS T *as_lds(T *p) { return (CRT_LDS T *)p; }
+// LDS pointer from its 32-bit byte address (address arithmetic in integers keeps running offsets in one register)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+template <typename T> __device__ __forceinline__ CRT_LDS T *lds_at(uint32_t addr) { return (CRT_LDS T *)addr; }
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
