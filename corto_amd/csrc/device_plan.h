@@ -14,7 +14,8 @@ struct TunTable {
 	uint16_t off[256];             // word start in bytes[]            (Tunstall::index)
 	uint8_t len[256];              // word length                      (Tunstall::lengths)
 	uint32_t used;                 // bytes of bytes[] any word reaches
-	uint32_t pad[3];
+	uint32_t maxlen;               // longest word
+	uint32_t pad[2];
 	uint8_t bytes[TUN_TABLE_BYTES];
 };
 

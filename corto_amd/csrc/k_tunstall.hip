@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	}
 
 	// survivors in creation order -> codes 0..255 (tunstall.cpp:243-253)
-	uint32_t w = 0, used = 0;
+	uint32_t w = 0, used = 0, maxlen = 0;
 	for(uint32_t base = 0; base < end; base += 64) {
 		const uint32_t e = base + lane;
 		const bool alive = e < end && !(head[e % n] > e);
@@ -176,13 +176,13 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 			T.off[rank] = eoff[e]; T.len[rank] = (uint8_t)elen[e];
 			const uint32_t u = (uint32_t)eoff[e] + elen[e];
 			used = u > used ? u : used;
+			maxlen = elen[e] > maxlen ? (uint32_t)elen[e] : maxlen;
 		}
 		w += __popcll(mask);
 	}
-#pragma unroll
-	for(int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(used, d, 64); used = o > used ? o : used; }
+	used = wave_max_u32(used); maxlen = wave_max_u32(maxlen);
 	for(uint32_t c = w + lane; c < 256; c += 64) { T.off[c] = 0; T.len[c] = 0; }   // never on valid input
-	if(lane == 0) T.used = used;
+	if(lane == 0) { T.used = used; T.maxlen = maxlen; }
 	const uint32_t ndw = (used + 3) >> 2;
 	const uint32_t *src32 = (const uint32_t *)buf;
 	uint32_t *dst32 = (uint32_t *)T.bytes;
@@ -353,7 +353,6 @@ __global__ __launch_bounds__(256) void k_tun_decode(const TunStream *__restrict_
 //            the next step's window, so only a wave's first and last vector are written bytewise.
 // LDS ordering inside one wave is program order, so the window needs no barrier, only the s_waitcnt the compiler places.
 // A stream's clipped last step, and steps whose bytes exceed the window, take the general byte-FIFO path.
-constexpr uint32_t TUN_WIN = 6*1024 - 64;        // per-wave window
 constexpr uint32_t TUN_SUB = 512;                // most codewords per wave per step
 constexpr uint32_t TUN_LONGQ = 64;               // per-wave queue of long words
 static_assert(TUN_SUB == 64*8 && TUN_CHUNK_CODES % (4*TUN_SUB) == 0, "a wave's quarter chunk is whole steps of 64*cpl codewords (tun_pick_geometry)");
@@ -406,25 +405,20 @@ __device__ __forceinline__ void tun_drain_long(uint32_t win0, CRT_LDS const uint
 	}
 }
 
-__global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
-                                                           uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                           const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
-	const uint32_t c = blockIdx.x + chunk_base;
-	if(blockIdx.x >= nchunks) return;
-	const TunStream st = streams[chunk_stream[c]];
-	const TunTable &T = tables[st.table];
-	__shared__ TunLds L;
-	__shared__ __attribute__((aligned(16))) u32x4_t t16[256];
-	__shared__ __attribute__((aligned(16))) uint32_t winbuf[4][(TUN_WIN + 64)/4];      // 16 bytes of slack in front, 48 behind
-	__shared__ uint32_t longbuf[4][TUN_LONGQ];
+template <int W, int CPL> constexpr uint32_t tun_win_bytes() { return W == 1 ? 2048 + 64 : W == 2 ? 4096 + 64 : 6*1024 - 64; }
+constexpr uint32_t tun_staged_lds(uint32_t win) { return 4*(win + 64); }                // dynamic LDS: the four waves' windows
+
+template <int W, int CPL>
+__device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTable &T, uint32_t c, const uint64_t *__restrict__ chunk_out,
+                                                TunLds &L, uint32_t *t16, uint32_t (*longbuf)[TUN_LONGQ], uint32_t *winbuf) {
+	constexpr uint32_t TUN_WIN = tun_win_bytes<W, CPL>();
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	tun_load_table(L, T, T.used);
-	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(&winbuf[0][0]))[i] = u32x4_t{0, 0, 0, 0};
+	for(uint32_t i = tid; i < 4*(TUN_WIN + 64)/16; i += 256) ((CRT_LDS u32x4_t *)as_lds(winbuf))[i] = u32x4_t{0, 0, 0, 0};
 	__syncthreads();
 	const uint32_t mylen = L.len[tid];
-	// dwords of a word's padded copy: by the dictionary's longest word; steps of fewer than 8 codewords per lane are only compiled for 4
-	const uint32_t width = st.cpl < 8 || __syncthreads_or(mylen > 8) ? 4u : __syncthreads_or(mylen > 4) ? 2u : 1u;
-	{	// zero-padded copy of every word, `width` dwords per entry (a compact table spreads over more LDS banks)
+	constexpr uint32_t width = W;
+	{	// zero-padded copy of every word, W dwords per entry (a compact table spreads over more LDS banks)
 		const uint32_t wo = L.off[tid], wl = min(mylen, 16u);
 		uint32_t d[4] = {0, 0, 0, 0};
 		for(uint32_t b = 0; b < wl; b++) d[b >> 2] |= (uint32_t)L.bytes[wo + b] << (8*(b & 3));
@@ -442,10 +436,10 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const uint32_t csize = st.csize;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
-	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(&winbuf[w][0]);     // window byte i lives at wb[16 + i]
+	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(winbuf) + w*(TUN_WIN + 64);   // window byte i lives at wb[16 + i]
 	CRT_LDS u32x4_t *win = (CRT_LDS u32x4_t *)(wb + 16);
 	const uint32_t win0 = (uint32_t)(uintptr_t)win;                      // LDS byte address of window byte 0
-	CRT_LDS uint32_t *longq = as_lds(&longbuf[w][0]);
+	CRT_LDS uint32_t *longq = as_lds(&longbuf[W == 4 ? w : 0][0]);   // (never touched unless W == 4)
 	CRT_LDS const uint32_t *t16l = (CRT_LDS const uint32_t *)as_lds(t16);
 	CRT_LDS const uint8_t *len8 = as_lds(L.len);
 	CRT_LDS const uint16_t *off16 = as_lds(L.off);
@@ -474,8 +468,8 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	// takes the step's codewords in groups of four consecutive ones (one dword of the coalesced fetch): with CPL = 8 the
 	// codewords 4*lane.. and 256 + 4*lane.. - the closer neighbouring lanes' words are in the window, the fewer LDS bank
 	// conflicts the ORs have.
-	auto run = [&](auto Wc, auto Cc) {
-		constexpr int W = decltype(Wc)::value, CPL = decltype(Cc)::value, GRP = CPL < 4 ? CPL : 4;
+	{
+		constexpr int GRP = CPL < 4 ? CPL : 4;
 		constexpr uint32_t sub = 64*CPL;
 		// Codewords are fetched two steps ahead and taken out of the fetched dwords BEFORE the step's stores are issued:
 		// loads and stores share one in-order counter (vmcnt), so a load waited for behind this step's flush would
@@ -592,17 +586,42 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 			}
 			base += total;
 		}
-	};
-	using std::integral_constant;
-	const uint32_t cpl = st.cpl;                                        // tun_pick_geometry: 8, 4, 2 or 1 by mean word length
-	if(cpl == 8) {
-		if(width == 1) run(integral_constant<int, 1>{}, integral_constant<int, 8>{});
-		else if(width == 2) run(integral_constant<int, 2>{}, integral_constant<int, 8>{});
-		else run(integral_constant<int, 4>{}, integral_constant<int, 8>{});
-	} else if(cpl == 4) run(integral_constant<int, 4>{}, integral_constant<int, 4>{});
-	else if(cpl == 2) run(integral_constant<int, 4>{}, integral_constant<int, 2>{});
-	else run(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+	}
 	if(pending) write_pending();
+}
+
+// Three kernels, each launched over all chunks (a workgroup whose stream belongs to another kernel leaves at once): words of at
+// most 4 bytes, of at most 8, and the rest (which picks its step size by the stream).  Separate kernels, not branches of one,
+// because they want different resources: the 4-byte kernel (most log streams) needs a 2 KB window per wave and 67 VGPRs, so
+// eight of its workgroups fit a CU where the long-word kernel (6 KB windows, up to 128 VGPRs) fits four - and this kernel is
+// latency-bound, waves in flight are what it runs on.
+template <int W>
+__global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
+                                                           uint32_t nchunks, const TunTable *__restrict__ tables,
+                                                           const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
+	const uint32_t c = blockIdx.x + chunk_base;
+	if(blockIdx.x >= nchunks) return;
+	const TunStream st = streams[chunk_stream[c]];
+	const TunTable &T = tables[st.table];
+	if(tun_width(st.cpl, T.maxlen) != (uint32_t)W) return;
+	__shared__ TunLds L;
+	__shared__ __attribute__((aligned(16))) uint32_t t16[256*W];
+	__shared__ uint32_t longbuf[W == 4 ? 4 : 1][TUN_LONGQ];
+	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];                   // [4][(TUN_WIN + 64)/4]: 16 bytes of slack in front, 48 behind
+	if(W != 4 || st.cpl == 8) tun_staged_body<W, 8>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	else if(st.cpl == 4) tun_staged_body<W, 4>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	else if(st.cpl == 2) tun_staged_body<W, 2>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	else tun_staged_body<W, 1>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+}
+
+// host side: the three launches, short words first
+int launch_tun_decode_staged(hipStream_t st, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                             const uint64_t *chunk_out) {
+#define TUN_LAUNCH(W_) hipLaunchKernelGGL((k_tun_decode_staged<W_>), dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<W_, 8>()), st, \
+                                          streams, chunk_stream, nchunks, tables, chunk_out, 0u)
+	TUN_LAUNCH(1); TUN_LAUNCH(2); TUN_LAUNCH(4);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+#undef TUN_LAUNCH
 }
 
 // memset path: single-symbol streams (tunstall.cpp:433-436)
