@@ -422,10 +422,10 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 		const uint32_t wo = L.off[tid], wl = min(mylen, 16u);
 		uint32_t d[4] = {0, 0, 0, 0};
 		for(uint32_t b = 0; b < wl; b++) d[b >> 2] |= (uint32_t)L.bytes[wo + b] << (8*(b & 3));
-		CRT_LDS uint32_t *e = (CRT_LDS uint32_t *)as_lds(t16) + width*tid;
+		CRT_LDS uint32_t *e = (CRT_LDS uint32_t *)as_lds(t16) + (width == 1 ? 2u : width)*tid;
 		if(width == 4) *(CRT_LDS u32x4_t *)e = u32x4_t{d[0], d[1], d[2], d[3]};
 		else if(width == 2) *(CRT_LDS u32x2_t *)e = u32x2_t{d[0], d[1]};
-		else e[0] = d[0];
+		else *(CRT_LDS u32x2_t *)e = u32x2_t{d[0], mylen};                  // one-dword words carry their length: one 8-byte read serves both
 	}
 	__syncthreads();
 	const uint32_t chunk_codes = st.chunk_codes, quarter = chunk_codes/4;
@@ -465,61 +465,78 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 	};
 
 	// The loop over a wave's quarter chunk, compiled for each (table width W, codewords per lane CPL) that occurs.  A lane
-	// takes the step's codewords in groups of four consecutive ones (one dword of the coalesced fetch): with CPL = 8 the
-	// codewords 4*lane.. and 256 + 4*lane.. - the closer neighbouring lanes' words are in the window, the fewer LDS bank
-	// conflicts the ORs have.
+	// takes the step's codewords in NG groups of GS consecutive ones (group g = codewords g*64*GS + GS*lane ..): the closer
+	// neighbouring lanes' words are in the window, the fewer LDS bank conflicts the ORs have; a group is one dword of the fetch.
 	{
-		constexpr int GRP = CPL < 4 ? CPL : 4;
+		constexpr int GS = CPL < 4 ? CPL : 4, NG = CPL/GS;     // (GS = 2 for short words halves the conflicts but its four 2-byte fetches and second scan cost more)
 		constexpr uint32_t sub = 64*CPL;
-		// Codewords are fetched two steps ahead and taken out of the fetched dwords BEFORE the step's stores are issued:
+		auto fetchg = [&](uint32_t j) -> uint32_t {                        // a group's GS codewords (GS < 4: with CPL < 4, fetch4's spare bytes are ignored)
+			if constexpr(GS == 2 && CPL == 8) {
+				if(j + 2 <= last) return *(CRT_GLOBAL const uint16_t *)(src + j);
+				return j < last ? (uint32_t)src[j] : 0u;
+			} else return fetch4(j);
+		};
+		// Codewords are fetched two steps ahead and taken out of the fetched registers BEFORE the step's stores are issued:
 		// loads and stores share one in-order counter (vmcnt), so a load waited for behind this step's flush would
 		// cost the flush's whole HBM write latency, every step.
-		uint32_t code[CPL], l[CPL];
-		auto extract = [&](uint32_t lo, uint32_t hi, uint32_t (&cd)[CPL]) {
+		uint32_t code[CPL], l[CPL], raw[NG];
+		auto extract = [&]() {
 #pragma unroll
-			for(int k = 0; k < CPL; k++) cd[k] = ((k < 4 ? lo : hi) >> (8*(k & 3))) & 255u;
+			for(int k = 0; k < CPL; k++) code[k] = (raw[k/GS] >> (8*(k % GS))) & 255u;
 		};
-		{
-			const uint32_t lo = fetch4(first + GRP*lane), hi = CPL == 8 ? fetch4(first + GRP*lane + 256) : 0u;
-			extract(lo, hi, code);
-		}
-		uint32_t nlo = fetch4(first + sub + GRP*lane), nhi = CPL == 8 ? fetch4(first + sub + GRP*lane + 256) : 0u;
+		auto fetch_step = [&](uint32_t t) {
+#pragma unroll
+			for(int g = 0; g < NG; g++) raw[g] = fetchg(t + g*64*GS + GS*lane);
+		};
+		fetch_step(first);
+		extract();
+		fetch_step(first + sub);
 		for(uint32_t tile = first; tile < last; tile += sub) {
-			const uint32_t j0 = tile + GRP*lane;
-			uint32_t sum0 = 0, sum1 = 0;
+			const uint32_t j0 = tile + GS*lane;
+			uint32_t gsum[NG];
+#pragma unroll
+			for(int g = 0; g < NG; g++) gsum[g] = 0;
 			const bool full = tile + sub <= last;                             // wave-uniform; false only on a stream's last step
 			uint32_t x[CPL][W];                                                // the words' padded copies: read now, their latency
 #pragma unroll
 			for(int k = 0; k < CPL; k++) {                                     // overlaps the length reads and the scan
-				CRT_LDS const uint32_t *e = t16l + W*code[k];
-				if constexpr(W == 1) x[k][0] = e[0];
-				else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)e; x[k][0] = v.x; x[k][1] = v.y; }
-				else { const u32x4_t v = *(CRT_LDS const u32x4_t *)e; x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
+				if constexpr(W == 1) { const u32x2_t v = *(CRT_LDS const u32x2_t *)(t16l + 2*code[k]); x[k][0] = v.x; l[k] = v.y; }
+				else if constexpr(W == 2) { const u32x2_t v = *(CRT_LDS const u32x2_t *)(t16l + 2*code[k]); x[k][0] = v.x; x[k][1] = v.y; }
+				else { const u32x4_t v = *(CRT_LDS const u32x4_t *)(t16l + 4*code[k]); x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w; }
 			}
-			if(full) {
+			if constexpr(W != 1) {
 #pragma unroll
-				for(int k = 0; k < CPL; k++) { l[k] = len8[code[k]]; (k < 4 ? sum0 : sum1) += l[k]; }
-			} else {
-#pragma unroll
-				for(int k = 0; k < CPL; k++) { l[k] = j0 + (k < 4 ? k : 252 + k) < last ? (uint32_t)len8[code[k]] : 0u; (k < 4 ? sum0 : sum1) += l[k]; }
+				for(int k = 0; k < CPL; k++) l[k] = len8[code[k]];
 			}
-			const uint32_t inc = wave_inclusive_scan_u32(sum0 | sum1 << 16);   // both groups in one scan: a group's bytes < 2^16
-			const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), total0 = tot & 0xffffu, total = total0 + (tot >> 16);
-			const uint32_t orel0 = (inc & 0xffffu) - sum0, orel1 = total0 + (inc >> 16) - sum1;
+#pragma unroll
+			for(int k = 0; k < CPL; k++) {
+				if(!full && !(j0 + (k/GS)*64*GS + (k % GS) < last)) l[k] = 0;      // a stream's last step: codewords past its end
+				gsum[k/GS] += l[k];
+			}
+			// exclusive offsets of the lane's groups: groups are scanned two per register (a group's bytes stay below 2^16)
+			uint32_t orel[NG], total = 0;
+#pragma unroll
+			for(int g = 0; g < NG; g += 2) {
+				const uint32_t hi = g + 1 < NG ? gsum[g + 1 < NG ? g + 1 : g] : 0u;
+				const uint32_t inc = wave_inclusive_scan_u32(gsum[g] | hi << 16);
+				const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+				orel[g] = total + (inc & 0xffffu) - gsum[g];
+				total += tot & 0xffffu;
+				if(g + 1 < NG) { orel[g + 1 < NG ? g + 1 : g] = total + (inc >> 16) - hi; total += tot >> 16; }
+			}
 			const bool fast = full && total + 32 <= TUN_WIN && tile + sub < csize && base + total <= size;
 			auto next_codes = [&]() {                                          // the next step's codewords out, the one after's in flight
-				extract(nlo, nhi, code);
-				nlo = fetch4(j0 + 2*sub);
-				if(CPL == 8) nhi = fetch4(j0 + 2*sub + 256);
+				extract();
+				fetch_step(tile + 2*sub);
 			};
 			if(fast) {
 				CRT_GLOBAL uint8_t *g0 = gdst + base;
 				const uint32_t phase = (uint32_t)(uintptr_t)g0 & 15u;
 				{	// compose
-					uint32_t P = win0 + phase + orel0 - 1u, N = ~P, nlong = 0;
+					uint32_t P = 0, N = 0, nlong = 0;
 #pragma unroll
 					for(int k = 0; k < CPL; k++) {
-						if(k == 4) { P = win0 + phase + orel1 - 1u; N = ~P; }        // second group of four
+						if(k % GS == 0) { P = win0 + phase + orel[k/GS] - 1u; N = ~P; }   // next group
 						tun_or<W>(P, N, x[k]);
 						if constexpr(W == 4) {
 							const bool lg = l[k] > 16;                                  // queue the rest of a long word
@@ -558,26 +575,26 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 				next_codes();
 				if(pending) write_pending();
 #pragma unroll
-				for(int h = 0; h < (CPL == 8 ? 2 : 1); h++) {
+				for(int g = 0; g < NG; g++) {                                    // a group's words are one run of up to four
 					uint32_t wo[4], nb[4];
-					uint64_t oo = base + (h ? orel1 : orel0);
+					uint64_t oo = base + orel[g];
 					const uint64_t o_run = oo;
 #pragma unroll
-					for(int k = 0; k < 4; k++) {
-						const int kk = 4*h + k;
+					for(int r = 0; r < 4; r++) {
 						uint32_t n_ = 0;
-						wo[k] = 0;
-						if(kk < CPL) {
-							const uint32_t j = j0 + (h ? 252 + kk : kk);
-							n_ = l[kk < CPL ? kk : 0];
-							wo[k] = L.off[ccode[kk < CPL ? kk : 0]];
+						wo[r] = 0;
+						if(r < GS) {
+							const int kk = g*GS + (r < GS ? r : 0);
+							const uint32_t j = j0 + g*64*GS + r;
+							n_ = l[kk];
+							wo[r] = L.off[ccode[kk]];
 							if(j < last) {
-								if(j + 1 == csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
+								if(j + 1 == csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[r]), size - oo) : 0u;
 								else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
 							} else n_ = 0;
-							oo += l[kk < CPL ? kk : 0];
+							oo += l[kk];
 						}
-						nb[k] = n_;
+						nb[r] = n_;
 					}
 					CRT_GLOBAL uint8_t *d = gdst + o_run;
 					tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
@@ -605,13 +622,16 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	const TunTable &T = tables[st.table];
 	if(tun_width(st.cpl, T.maxlen) != (uint32_t)W) return;
 	__shared__ TunLds L;
-	__shared__ __attribute__((aligned(16))) uint32_t t16[256*W];
+	__shared__ __attribute__((aligned(16))) uint32_t t16[256*(W == 1 ? 2 : W)];
 	__shared__ uint32_t longbuf[W == 4 ? 4 : 1][TUN_LONGQ];
 	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];                   // [4][(TUN_WIN + 64)/4]: 16 bytes of slack in front, 48 behind
-	if(W != 4 || st.cpl == 8) tun_staged_body<W, 8>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
-	else if(st.cpl == 4) tun_staged_body<W, 4>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
-	else if(st.cpl == 2) tun_staged_body<W, 2>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
-	else tun_staged_body<W, 1>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	if constexpr(W != 4) tun_staged_body<W, 8>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	else {
+		if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+		else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+		else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+		else tun_staged_body<4, 1>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	}
 }
 
 // host side: the three launches, short words first
