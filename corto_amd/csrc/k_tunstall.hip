@@ -366,7 +366,8 @@ template <int W> __device__ __forceinline__ void tun_or(uint32_t P, uint32_t N, 
 	uint32_t prev = 0;
 #pragma unroll
 	for(int i = 0; i < W; i++) { atomicOr((uint32_t *)(o + i), __builtin_amdgcn_alignbyte(x[i], prev, N)); prev = x[i]; }
-	atomicOr((uint32_t *)(o + W), __builtin_amdgcn_alignbyte(0u, prev, N));
+	const uint32_t top = __builtin_amdgcn_alignbyte(0u, prev, N);          // what spills into the next dword: nothing for most short words,
+	if(W > 1 || top) atomicOr((uint32_t *)(o + W), top);                   // and the LDS is the busiest unit of the short-word kernel
 }
 
 // Bytes 16.. of the queued long words (entry = window position of the word | code << 16): the owning lane streams the
