@@ -142,6 +142,28 @@ def tunstall_scaled(ctx, ca, z, table_ids=None):
             "frac_of_8TBps": round((rd + wr) / dec_ms / 1e6 / 8000.0, 4)}
 
 
+def other_configs(ctx, ca):
+    """BASELINE.json's single-object configs, one decode each (parity cases in tests/; timed here for the record): they do not take
+    the small-blob path - a mesh whose front does not fit LDS runs its serial CLERS chain against HBM."""
+    from corto_amd import synth
+    out = {}
+    for key, mesh, kw in (("C2_mesh_128k_verts", synth.bumpy_sphere(512, 250, seed=1), dict(normal_prediction=ca.BORDER)),
+                          ("C3_cloud_167k_points", synth.point_cloud(578, 289, seed=2), dict(normal_prediction=ca.DIFF))):
+        blob = ca.encode(mesh, position_bits=14, uv_bits=12, normal_bits=10, **kw)
+        b = ca.Batch(ctx, [blob]); b.allocate_outputs()
+        b.decode(); b.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            b.decode(); b.sync()
+        dt = (time.perf_counter() - t0) / 3
+        out[key] = {"ms": round(dt * 1e3, 3), "mverts_per_s": round(mesh.nvert / dt / 1e6, 2)}
+        if mesh.nface:
+            out[key]["mtri_per_s"] = round(mesh.nface / dt / 1e6, 2)
+        b.close()
+    out["note"] = "one object per decode: no blob-level parallelism; the 128K-vertex mesh is latency-bound on its HBM-resident front (DESIGN.md 3.1)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -358,6 +380,7 @@ def main():
         }
         if not args.no_tunstall_scaled:
             out["tunstall_scaled"] = tunstall_scaled(ctx, ca, z)
+            out["other_configs"] = other_configs(ctx, ca)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(blobs)
             out["vs_cpu_1core"] = round(out["value"] / world / out["cpu_baseline"]["value"], 2)

@@ -556,10 +556,12 @@ static int build_and_launch(crthip_batch *b) {
 			t.nvert = nvert; t.nface = nface; t.front_cap = S.front_cap; t.faces_u16 = P.index ? P.index_u16 : 0;
 			t.pad = P.index ? 1u : 0u;                                   // pad = 1: faces is a real pointer
 			{
-				const uint32_t slots = topo_lds_slots(S.front_cap, nvert), dslots = std::min(slots, TOPO_LDS_DELAYED);
-				const uint32_t need = topo_lds_bytes(slots, dslots, L.clers.size);
-				if(nvert <= 65535 && slots <= 65530 && need <= TOPO_LDS_MAX) {
-					t.lds_cap = slots; t.lds_delayed_cap = dslots;
+				// every mesh takes the LDS path; a lone big mesh may use most of a CU's LDS, a batch keeps its blobs small
+				uint32_t ring, pool, symwin;
+				topo_lds_geometry(nface, L.clers.size, 4096, ring, pool, symwin);
+				const uint32_t need = topo_lds_bytes(ring, pool, pool, symwin);          // every delayed edge is a pool record: same capacity
+				if(need <= TOPO_LDS_MAX) {
+					t.lds_ring = ring; t.lds_pool = pool; t.lds_delayed_cap = pool; t.lds_symwin = symwin;
 					pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need);
 				}
 				else pl.topo_glob_ids.v.push_back((uint32_t)pl.topo.v.size());

@@ -62,7 +62,9 @@ struct TopoJob {
 	uint32_t nclers, split_nwords, ngroups;
 	uint32_t nvert, nface, front_cap, faces_u16;
 	uint32_t pad;
-	uint32_t lds_cap, lds_delayed_cap;   // LDS path: edge-record slots / DELAY stack entries (0: not eligible)
+	// LDS path (k_mesh.hip): ring of queued-edge records (a power of two; 0: not eligible), pool of surviving-edge records,
+	// DELAY stack entries, symbols in the LDS window (a multiple of 8)
+	uint32_t lds_ring, lds_pool, lds_delayed_cap, lds_symwin;
 };
 
 // one log stream to turn into values (include/corto/cstream.h:294-360)

@@ -224,183 +224,214 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 	topo_run(J, as_global(J.clers), F);
 }
 
-// small-blob path: front, queues and the CLERS symbols in LDS, hand-tightened.  A lone wave issues one
-// instruction every ~4 cycles, so this single-lane loop is issue-bound: every instruction per symbol counts.
-//   * 16-byte edge records {v0|v1<<16, v2|dead<<16, prev|next<<16, -}: one ds_read_b128 / ds_write_b128 each
-//   * LAZY current edge: the edge created by VERTEX/LEFT/RIGHT is the next one processed (decoder.cpp:261-264),
-//     and when it is consumed right away by another VERTEX/LEFT/RIGHT/END nobody ever reads its record, and the
-//     links its neighbours hold to it are overwritten by that step.  So it lives in registers only; it gets a record
-//     SLOT, its record and the two neighbour links ("materialised") only if it survives (BOUNDARY / DELAY).
-//     Edge ids are internal to the decoder (outputs carry vertex ids only), so this is unobservable - and it means
-//     slots are spent only on queued edges (one per VERTEX / SPLIT, three per seed) and chain ends, about nvert of the
-//     reference's max_front ~ 3*nvert: the front of a 4K-triangle blob takes 39 KB of LDS instead of 100 KB, so three
-//     blobs' automata share a CU (kernels.h: topo_lds_slots).  A blob that runs out of slots is redone on the HBM front.
-//   * RIGHT right after VERTEX closes against the second edge VERTEX just created -> its (next, v1) are cached
-//   * links stored in the front are produced by this loop, hence always in range; only values that come from the
-//     stream are validated; the symbol array is padded with an invalid symbol so running off its end fails
-//     without a per-step bounds test.  Symbols are fetched four at a time.
-//   * the FIFO of queued edges needs no storage: queued edges take slots upwards from 0 in the order they are queued,
-//     so the queue is a cursor over the slots (surviving chain ends take slots downwards from the top); the symbols
-//     sit in LDS as nibbles, eight per dword: 40 KB per 4K-triangle blob in all.
-// Layout (dynamic LDS): rec[cap+4] (16 B) | delayed[dcap+4] (u16) | clers nibbles
+// LDS path: the front of one blob in LDS, hand-tightened.  A lone wave issues one instruction every ~4 cycles, so this
+// single-lane loop is issue-bound: every instruction per symbol counts.
+//   * 16-byte edge records {v0, v1, v2 | flags, prev | next<<16}: one ds_read_b128 / ds_write_b128 each
+//   * LAZY current edge: the edge created by VERTEX/LEFT/RIGHT is the next one processed (decoder.cpp:261-264), and when
+//     it is consumed right away by another VERTEX/LEFT/RIGHT/END nobody ever reads its record, and the links its
+//     neighbours hold to it are overwritten by that step.  So the current edge lives in registers only; it gets a record
+//     slot, its record and the two neighbour links ("materialised") only if it survives (BOUNDARY / DELAY).  Edge ids are
+//     internal to the decoder (outputs carry vertex ids only), so this is unobservable.
+//   * RECORDS ARE RECYCLED, so the LDS holds the LIVE front, not every edge ever made (the reference's max_front ~ 3*nvert):
+//       - queued edges (one per VERTEX / SPLIT, three per seed face) take the slots of a RING in the order they are
+//         queued, so the reference's FIFO (`faceorder`) is just the ring's read cursor - no queue storage, no push, and a
+//         pop is the record read it needs anyway; a slot is free again the moment it is popped;
+//       - surviving chain ends take slots of a POOL with a free list, and give them back when LEFT / RIGHT / END delete
+//         them (or, if they sit in the DELAY stack, when they are popped from it).
+//     The live front of a mesh is ~3*sqrt(nface) queued edges (251 records for the 4K-triangle blob, 2 000 for a
+//     256K-triangle sphere), so a 4K-triangle blob needs 16 KB of LDS instead of 100 KB, ten blobs' automata fit a CU,
+//     and meshes of any size run from LDS.  A blob that outgrows its ring or pool (a torus' front is ten times a
+//     sphere's) is redone on the HBM front.
+//   * RIGHT right after VERTEX closes against the edge VERTEX just created -> its (next, v1) are cached in registers
+//   * links stored in the front are produced by this loop, hence always in range; only values that come from the stream
+//     are validated.  The symbols sit in LDS as nibbles, eight per dword, in a window the whole wave refills between
+//     chains (a blob of up to 8K symbols is loaded once); the padding behind the last symbol is an invalid symbol, so
+//     running off the end fails without a per-step bounds test.
+// Layout (dynamic LDS): rec[ring + pool] (16 B) | freelist[pool] (u16) | delayed[dcap] (u16) | symbol window (nibbles)
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMASK = 0x3FFFFFFFu;
 
 template <bool U16>
 __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const uint32_t cap = J.lds_cap, dcap = J.lds_delayed_cap;
-	const uint32_t cap4 = cap + 4, dbytes = (((dcap + 4)*2 + 15) & ~15u);
+	const uint32_t RING = J.lds_ring, MASK = RING - 1, POOL = J.lds_pool, dcap = J.lds_delayed_cap, SYMW = J.lds_symwin;
 	CRT_LDS u32x4 *rec = (CRT_LDS u32x4 *)as_lds(lds);
 	CRT_LDS uint16_t *rec16 = (CRT_LDS uint16_t *)rec;
-	CRT_LDS uint16_t *delayed = (CRT_LDS uint16_t *)(rec + cap4);
-	CRT_LDS uint32_t *cl32 = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)delayed + dbytes);
+	CRT_LDS uint16_t *freel = (CRT_LDS uint16_t *)(rec + RING + POOL);
+	CRT_LDS uint16_t *delayed = freel + ((POOL + 7) & ~7u);
+	CRT_LDS uint32_t *cl32 = (CRT_LDS uint32_t *)(delayed + ((dcap + 7) & ~7u));
+	CRT_LDS uint32_t *cold = cl32 + SYMW/8 + 2;                         // state only the cold paths touch lives here, not in loop-carried registers
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
-	// symbols as nibbles, eight per dword, padded with an invalid symbol (0xF) for 64 symbols past the end
-	for(uint32_t w = threadIdx.x; w < (J.nclers + 64 + 7)/8; w += 64) {
-		uint32_t v = 0;
-		for(uint32_t k = 0; k < 8; k++) { const uint32_t i = w*8 + k; const uint32_t b = i < J.nclers ? (uint32_t)gcl[i] : 15u; v |= (b < 7u ? b : 15u) << (4*k); }   // any invalid byte -> invalid nibble
-		cl32[w] = v;
-	}
-	__syncthreads();
-	if(threadIdx.x != 0) return true;
-	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
+	const uint32_t nclers = J.nclers, symwords = SYMW/8;
+	auto pack8 = [&](uint32_t s0) -> uint32_t {                         // symbols s0 .. s0+7 as nibbles; any invalid byte, and
+		uint32_t v = 0;                                                    // everything behind the stream, is the invalid nibble
+		for(uint32_t k = 0; k < 8; k++) { const uint32_t i = s0 + k, b = i < nclers ? (uint32_t)gcl[i] : 15u; v |= (b < 7u ? b : 15u) << (4*k); }
+		return v;
+	};
 
+	// automaton state, alive across window refills (uniform: only lane 0 ever changes it)
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
 	CRT_GLOBAL uint32_t *predp = as_global(J.pred);                    // bumped by 3 per new vertex (vertices are numbered in creation order)
 	CRT_GLOBAL uint8_t *facep = as_global((uint8_t *)J.faces);          // bumped by 3 indices per face
 	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
 	const uint32_t nvert = J.nvert;
 	const uint32_t splitbits = 32 - __clz(nvert | 1u);
-	uint32_t cler = 0, vc = 0, err = 0;                                  // err: 1 = bad stream, 2 = out of slots
-	uint32_t sw = cl32[0], swn = cl32[1];                                // symbol words: current (shifted) and next
-	uint64_t bit = 0;
+	uint32_t cler = 0, winbase = 0, vc = 0, err = 0;                     // err: 1 = bad stream, 2 = out of slots
+	uint32_t start = 0;
+	uint32_t nq = 0, qpos = 0;                                           // ring [qpos, nq)
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
+	enum { K_MBUMP = 0, K_NFREE = 1, K_NDELAYED = 2, K_BIT_LO = 3, K_BIT_HI = 4 };   // pool bump pointer, free list / DELAY stack fill, split-bit cursor
 
-#define TOPO_BITS(dst, n) do { if(bit + (n) > bit_end) { err = 1; dst = 0; } else { dst = bit_field(split, J.split_nwords, bit, (n)); bit += (n); } } while(0)
+	// the whole wave fills the symbol window once; from then on lane 0 is alone (and the compiler sees uniform code), and
+	// slides the window by itself between chains when a mesh has more symbols than the window (3 instructions per symbol)
+	// (two words behind the window: "window exhausted" nibbles - a chain that outruns the window ends in the HBM redo, so that the
+	// loop never loads symbols from HBM itself: a load's s_waitcnt would also wait for every face / prediction store in flight)
+	for(uint32_t w = threadIdx.x; w < symwords + 2; w += 64) cl32[w] = w < symwords ? pack8(8*w) : 0xEEEEEEEEu;
+	__syncthreads();
+	if(threadIdx.x != 0) return true;
+	cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0; cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
+	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
+	uint32_t sw = cl32[0], swn = cl32[1];
+	uint32_t wbias = 1, slide_at = SYMW < nclers ? SYMW - 2048u : 0xFFFFFFFFu;   // next symbol word = cl32[(cler >> 3) + wbias]; slide when cler gets here
+	{
+		{
+#define TOPO_BITS(dst, n) do { uint64_t bit_ = (uint64_t)cold[K_BIT_LO] | (uint64_t)cold[K_BIT_HI] << 32; if(bit_ + (n) > bit_end) { err = 1; dst = 0; } \
+	else { dst = bit_field(split, J.split_nwords, bit_, (n)); bit_ += (n); cold[K_BIT_LO] = (uint32_t)bit_; cold[K_BIT_HI] = (uint32_t)(bit_ >> 32); } } while(0)
 #define TOPO_FACE(a, b, c) do { if(U16) { CRT_GLOBAL uint16_t *h_ = (CRT_GLOBAL uint16_t *)facep; h_[0] = (uint16_t)(a); h_[1] = (uint16_t)(b); h_[2] = (uint16_t)(c); facep += 6; } \
 	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)facep = f_; facep += 12; } start += 3; } while(0)
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)predp = p_; predp += 3; } while(0)
-#define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a) | ((b) << 16); t_.y = (c); t_.z = (p) | ((n) << 16); t_.w = 0; rec[e] = t_; } while(0)
-#define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = cl32[(cler >> 3) + 1]; } } while(0)
-	// give the surviving current edge a slot, its record, and its neighbours their links to it
-#define TOPO_MATERIALISE() do { if(lazy) { if(nq >= mtop) { err = 2; break; } f = --mtop; TOPO_PUT(f, v0, v1, v2, ep, en); rec16[ep*8 + 5] = (uint16_t)f; rec16[en*8 + 4] = (uint16_t)f; } } while(0)
+#define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
+#define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = cl32[(cler >> 3) + wbias]; } } while(0)
+	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
+#define TOPO_RELEASE(id, z) do { if((id) > MASK && !((z) & TOPO_DELAYED)) { const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)(id); cold[K_NFREE] = n_ + 1; } } while(0)
+	// give the surviving current edge a pool slot, its record, and its neighbours their links to it
+#define TOPO_MATERIALISE(flags) do { const uint32_t nf_ = cold[K_NFREE], mb_ = cold[K_MBUMP]; \
+	if(nf_) { f = freel[nf_ - 1]; cold[K_NFREE] = nf_ - 1; } else if(mb_ < RING + POOL) { f = mb_; cold[K_MBUMP] = mb_ + 1; } else { err = 2; break; } \
+	TOPO_PUT(f, v0, v1, v2 | (flags), ep, en); rec16[ep*8 + 7] = (uint16_t)f; rec16[en*8 + 6] = (uint16_t)f; } while(0)
 
-	uint32_t start = 0;
-	for(uint32_t g = 0; g < J.ngroups && !err; g++) {                   // decoder.cpp:173-178
-		const uint32_t ge = group_end[g];
-		if(ge > J.nface || ge*3 < start) { err = 1; break; }
-		const uint32_t end = ge*3;
-		uint32_t nq = 0, qpos = 0, mtop = cap, ndelayed = 0;                 // queued slots [0, nq), popped up to qpos; survivors [mtop, cap)
-		while(start < end && !err) {
-			// ---- cold: fetch the next edge to process: queue, delayed stack, or a new seed face ----
-			uint32_t f;
-			if(qpos < nq) f = qpos++;
-			else if(ndelayed) f = delayed[--ndelayed];
-			else {                                                     // seed face (decoder.cpp:224-259)
-				uint32_t c; TOPO_SYMBOL(c);
-				uint32_t last = vc - 1, vi[3], mask = 0;
-				if(c == C_SPLIT) TOPO_BITS(mask, 3);
-				else if(c != C_VERTEX) { err = 1; break; }
-				for(int k = 0; k < 3; k++) {
-					uint32_t v;
-					if(mask & (1u << k)) { TOPO_BITS(v, splitbits); v &= 0xFFFFu; }
-					else {
-						if(vc >= nvert) { err = 1; break; }
-						TOPO_PRED(last, last, last);
-						last = v = vc++;
+			for(uint32_t g = 0; g < J.ngroups && !err; g++) {              // every group starts from an empty front (decoder.cpp:173-178)
+			const uint32_t ge = group_end[g];
+			if(ge > J.nface || ge*3 < start) { err = 1; break; }
+			const uint32_t end = ge*3;
+			nq = 0; qpos = 0; cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0;
+			while(start < end && !err) {
+				if(cler >= slide_at) {                                      // between chains: slide the window before it runs low
+					winbase = cler & ~7u;
+					for(uint32_t w = 0; w < symwords; w++) cl32[w] = pack8(winbase + 8*w);
+					sw = cl32[0] >> (4*(cler & 7u)); swn = cl32[1];
+					wbias = 1u - (winbase >> 3);
+					slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu;
+				}
+				// ---- cold: fetch the next edge to process: ring, DELAY stack, or a new seed face ----
+				uint32_t f;
+				u32x4 t0;
+				uint32_t nd_;
+				if(qpos != nq) { f = qpos & MASK; qpos++; t0 = rec[f]; }     // the slot is free from here on
+				else if((nd_ = cold[K_NDELAYED]) != 0) { f = delayed[nd_ - 1]; cold[K_NDELAYED] = nd_ - 1; t0 = rec[f]; const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)f; cold[K_NFREE] = n_ + 1; }
+				else {                                                     // seed face (decoder.cpp:224-259)
+					uint32_t c; TOPO_SYMBOL(c);
+					uint32_t last = vc - 1, vi[3], mask = 0;
+					if(c == C_SPLIT) TOPO_BITS(mask, 3);
+					else if(c != C_VERTEX) { err = c == 14u ? 2u : 1u; break; }
+					for(int k = 0; k < 3; k++) {
+						uint32_t v;
+						if(mask & (1u << k)) TOPO_BITS(v, splitbits);
+						else {
+							if(vc >= nvert) { err = 1; break; }
+							TOPO_PRED(last, last, last);
+							last = v = vc++;
+						}
+						vi[k] = v & TOPO_VMASK;
 					}
-					vi[k] = v;
+					if(err) break;
+					if(nq - qpos + 3 > RING) { err = 2; break; }
+					TOPO_FACE(vi[0], vi[1], vi[2]);
+					const uint32_t e0 = nq & MASK, e1 = (nq + 1) & MASK, e2 = (nq + 2) & MASK;
+					TOPO_PUT(e0, vi[1], vi[2], vi[0], e2, e1);
+					TOPO_PUT(e1, vi[2], vi[0], vi[1], e0, e2);
+					TOPO_PUT(e2, vi[0], vi[1], vi[2], e1, e0);
+					nq += 3;                                                   // all three wait in the queue
+					continue;
 				}
-				if(err) break;
-				if(nq + 3 > mtop) { err = 2; break; }
-				TOPO_FACE(vi[0], vi[1], vi[2]);
-				const uint32_t e = nq;
-				TOPO_PUT(e, vi[1], vi[2], vi[0], e + 2, e + 1);
-				TOPO_PUT(e + 1, vi[2], vi[0], vi[1], e, e + 2);
-				TOPO_PUT(e + 2, vi[0], vi[1], vi[2], e + 1, e);
-				nq += 3;                                                   // all three wait in the queue
-				continue;
-			}
-			const u32x4 t0 = rec[f];
-			if(t0.y >> 16) continue;                                   // deleted: no symbol consumed (decoder.cpp:278-279)
-			uint32_t v0 = t0.x & 0xFFFFu, v1 = t0.x >> 16, v2 = t0.y & 0xFFFFu, ep = t0.z & 0xFFFFu, en = t0.z >> 16;
-			bool lazy = false;                                         // current edge has no slot / record yet
-			uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;         // cached (next, v1) of edge nc
+				if(t0.z & TOPO_DEAD) continue;                             // deleted: no symbol consumed (decoder.cpp:278-279)
+				uint32_t v0 = t0.x, v1 = t0.y, v2 = t0.z & TOPO_VMASK, ep = t0.w & 0xFFFFu, en = t0.w >> 16;
+				uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;         // cached (next, v1) of edge nc
 
-			// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
-			for(;;) {
-				uint32_t c; TOPO_SYMBOL(c);
-				if(c == C_VERTEX) {                                    // decoder.cpp:294-309
-					const uint32_t s = nq;                             // slot of the second new edge = its place in the queue
-					if(vc >= nvert) { err = 1; break; }
-					if(s >= mtop) { err = 2; break; }
-					const uint32_t opp = vc++;
-					TOPO_PRED(v1, v0, v2);
-					TOPO_FACE(v1, v0, opp);
-					rec16[en*8 + 4] = (uint16_t)s;                     // front[e.next].prev = new_edge + 1
-					TOPO_PUT(s, opp, v1, v0, 0xFFFFu, en);             // second new edge: queued, so it must exist; its prev is the lazy edge
-					nq = s + 1;
-					nc = s; nc_next = en; nc_v1 = v1;
-					v2 = v1; v1 = opp; en = s;                         // first new edge (v0, opp, old v1, ep, s): next, lazily
-					lazy = true;
-				} else if(c == C_LEFT) {                               // decoder.cpp:311-317
-					const u32x4 t = rec[ep];
-					const uint32_t pp = t.z & 0xFFFFu, opp = t.x & 0xFFFFu;
-					rec16[ep*8 + 3] = 1;                               // front[e.prev].deleted = true
-					TOPO_FACE(v1, v0, opp);
-					nc = 0xFFFFFFFFu;
-					v2 = v0; v0 = opp; ep = pp;                        // new edge (opp, v1, old v0, pp, en): next, lazily
-					lazy = true;
-				} else if(c == C_RIGHT) {                              // decoder.cpp:319-325
-					uint32_t nn, opp;
-					if(en == nc) { nn = nc_next; opp = nc_v1; }
-					else { const u32x4 t = rec[en]; nn = t.z >> 16; opp = t.x >> 16; }
-					rec16[en*8 + 3] = 1;
-					TOPO_FACE(v1, v0, opp);
-					nc = 0xFFFFFFFFu;
-					v2 = v1; v1 = opp; en = nn;                        // new edge (v0, opp, old v1, ep, nn): next, lazily
-					lazy = true;
-				} else {                                               // ---- cold symbols end the chain ----
-					if(c == C_BOUNDARY) {
-						TOPO_MATERIALISE();
-					} else if(c == C_SPLIT) {
-						const uint32_t s = nq;
-						if(s >= mtop) { err = 2; break; }
-						uint32_t opp; TOPO_BITS(opp, splitbits);
-						if(err) break;
-						const uint32_t o16 = opp & 0xFFFFu;
+				// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
+				for(;;) {
+					uint32_t c; TOPO_SYMBOL(c);
+					if(c == C_VERTEX) {                                    // decoder.cpp:294-309
+						if(vc >= nvert) { err = 1; break; }
+						if(nq - qpos > MASK) { err = 2; break; }
+						const uint32_t s = nq & MASK;                      // slot of the second new edge = its place in the queue
+						nq++;
+						const uint32_t opp = vc++;
+						TOPO_PRED(v1, v0, v2);
 						TOPO_FACE(v1, v0, opp);
-						rec16[en*8 + 4] = (uint16_t)s;
-						TOPO_PUT(s, o16, v1, v0, 0xFFFFu, en);
-						nq = s + 1;
+						rec16[en*8 + 6] = (uint16_t)s;                     // front[e.next].prev = new_edge + 1
+						TOPO_PUT(s, opp, v1, v0, 0xFFFFu, en);             // second new edge: queued, so it must exist; its prev is the lazy edge
 						nc = s; nc_next = en; nc_v1 = v1;
-						v2 = v1; v1 = o16; en = s;
-						lazy = true;
-						if(start < end) continue;                      // SPLIT continues the chain like VERTEX
-					} else if(c == C_DELAY) {                          // decoder.cpp:327-331
-						if(ndelayed >= dcap) { err = 2; break; }
-						TOPO_MATERIALISE();
-						delayed[ndelayed++] = (uint16_t)f;
-					} else if(c == C_END) {                            // decoder.cpp:333-339
-						const u32x4 tp = rec[ep], tn = rec[en];
-						const uint32_t pp = tp.z & 0xFFFFu, nn = tn.z >> 16, opp = tp.x & 0xFFFFu;
-						rec16[ep*8 + 3] = 1; rec16[en*8 + 3] = 1;
-						rec16[pp*8 + 5] = (uint16_t)nn;
-						rec16[nn*8 + 4] = (uint16_t)pp;
+						v2 = v1; v1 = opp; en = s;                         // first new edge (v0, opp, old v1, ep, s): next, lazily
+					} else if(c == C_LEFT) {                               // decoder.cpp:311-317
+						const u32x4 t = rec[ep];
+						const uint32_t pp = t.w & 0xFFFFu, opp = t.x;
+						rec16[ep*8 + 5] = 0x8000u;                         // front[e.prev].deleted = true
+						TOPO_RELEASE(ep, t.z);
 						TOPO_FACE(v1, v0, opp);
-					} else err = 1;                                    // invalid symbol, or ran past the end (0xFF padding)
-					break;
+						v2 = v0; v0 = opp; ep = pp;                        // new edge (opp, v1, old v0, pp, en): next, lazily
+					} else if(c == C_RIGHT) {                              // decoder.cpp:319-325
+						uint32_t nn, opp;
+						if(en == nc) { nn = nc_next; opp = nc_v1; }        // (a ring slot: nothing to release)
+						else { const u32x4 t = rec[en]; nn = t.w >> 16; opp = t.y; TOPO_RELEASE(en, t.z); }
+						rec16[en*8 + 5] = 0x8000u;
+						TOPO_FACE(v1, v0, opp);
+						nc = 0xFFFFFFFFu;
+						v2 = v1; v1 = opp; en = nn;                        // new edge (v0, opp, old v1, ep, nn): next, lazily
+					} else {                                               // ---- cold symbols end the chain ----
+						if(c == C_BOUNDARY) {
+							TOPO_MATERIALISE(0u);
+						} else if(c == C_SPLIT) {
+							if(nq - qpos > MASK) { err = 2; break; }
+							uint32_t opp; TOPO_BITS(opp, splitbits);
+							if(err) break;
+							opp &= TOPO_VMASK;
+							const uint32_t s = nq & MASK;
+							nq++;
+							TOPO_FACE(v1, v0, opp);
+							rec16[en*8 + 6] = (uint16_t)s;
+							TOPO_PUT(s, opp, v1, v0, 0xFFFFu, en);
+							nc = s; nc_next = en; nc_v1 = v1;
+							v2 = v1; v1 = opp; en = s;
+							if(start < end) continue;                      // SPLIT continues the chain like VERTEX
+						} else if(c == C_DELAY) {                          // decoder.cpp:327-331
+							const uint32_t nd2_ = cold[K_NDELAYED];
+							if(nd2_ >= dcap) { err = 2; break; }
+							TOPO_MATERIALISE(TOPO_DELAYED);
+							if(!err) { delayed[nd2_] = (uint16_t)f; cold[K_NDELAYED] = nd2_ + 1; }
+						} else if(c == C_END) {                            // decoder.cpp:333-339
+							const u32x4 tp = rec[ep], tn = rec[en];
+							const uint32_t pp = tp.w & 0xFFFFu, nn = tn.w >> 16, opp = tp.x;
+							rec16[ep*8 + 5] = 0x8000u; rec16[en*8 + 5] = 0x8000u;
+							TOPO_RELEASE(ep, tp.z); TOPO_RELEASE(en, tn.z);
+							rec16[pp*8 + 7] = (uint16_t)nn;
+							rec16[nn*8 + 6] = (uint16_t)pp;
+							TOPO_FACE(v1, v0, opp);
+						} else err = c == 14u ? 2u : 1u;                   // window exhausted mid-chain (redo on the HBM front) / invalid symbol or past the end
+						break;
+					}
+					if(start >= end) break;
 				}
-				if(start >= end) break;
 			}
-		}
-	}
+			}
 #undef TOPO_BITS
 #undef TOPO_FACE
 #undef TOPO_PRED
 #undef TOPO_PUT
 #undef TOPO_SYMBOL
+#undef TOPO_RELEASE
 #undef TOPO_MATERIALISE
+		}
+	}
 	if(err == 2) return false;
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
 	return true;

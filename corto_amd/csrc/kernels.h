@@ -33,11 +33,22 @@ __global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uin
 __global__ void k_topology(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 __global__ void k_topology_lds(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 // dynamic LDS bytes k_topology_lds needs for a front of `cap` edges and `nclers` symbols
-inline uint32_t topo_lds_bytes(uint32_t cap, uint32_t dcap, uint32_t nclers) { return (cap + 4)*16 + (((dcap + 4)*2 + 15) & ~15u) + (((nclers + 64 + 7)/8*4 + 15) & ~15u); }
-// Edge-record slots the LDS path gets: records exist only for edges that wait in the queue (one per VERTEX / SPLIT, three
-// per seed face) or end a chain on the boundary, about one per vertex; a blob that needs more is redone on the HBM front.
-inline uint32_t topo_lds_slots(uint32_t front_cap, uint32_t nvert) { const uint32_t want = nvert + nvert/16 + 64; return want < front_cap ? want : front_cap; }
-constexpr uint32_t TOPO_LDS_DELAYED = 256;
+// LDS of one blob's CLERS automaton (k_mesh.hip): records of the LIVE front only - a ring for the queued edges, a pool for
+// surviving chain ends - plus the DELAY stack and a window of nibble-packed symbols.
+inline uint32_t topo_lds_bytes(uint32_t ring, uint32_t pool, uint32_t dcap, uint32_t symwin) {
+	return (ring + pool)*16 + ((pool + 7) & ~7u)*2 + ((dcap + 7) & ~7u)*2 + symwin/2 + 8 + 32 + 16;
+}
+constexpr uint32_t TOPO_SYMWIN_MAX = 8192;
+// The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the ring gets 8*sqrt(nface)
+// rounded up to a power of two (at least 256, at most `ring_max`), the pool as much again (it also holds every edge of the mesh's own
+// boundary for good).  What does not fit - a torus' queue is ten times a sphere's, a ribbon is all boundary - is redone on the HBM front.
+inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
+	uint32_t want = 256;
+	while((uint64_t)want*want < (uint64_t)64*nface && want < ring_max) want <<= 1;
+	ring = want; pool = want;
+	const uint32_t all = (nclers + 64 + 7) & ~7u;
+	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;
+}
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 256;       // threads of the dataflow workgroup of one (blob, attribute)
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);

@@ -428,10 +428,11 @@ def test_config3_167k_point_cloud(ctx):
 
 
 def test_topology_lds_slot_overflow_redone_on_hbm_front(ctx):
-    """the LDS automaton budgets ~1.125 edge records per vertex; a ribbon needs ~2 (every chain ends on the boundary), so it
-    runs out of slots and is redone on the HBM front - same results, and reported in the stats; in a batch with blobs that fit"""
+    """the LDS automaton holds the LIVE front: a ring of 8*sqrt(nface) queued edges and a pool as large for surviving ones.  A
+    torus' queue and a ribbon's boundary outgrow that; those blobs are redone on the HBM front - same results, reported in the
+    stats - in one batch with blobs that fit"""
     from corto_amd import synth
-    meshes = [synth.strip(400, seed=3), synth.bumpy_sphere(24, 12, seed=5), synth.strip(90, seed=4), synth.holey_disc(40, seed=2, color_components=4)]
+    meshes = [synth.strip(400, seed=3), synth.bumpy_sphere(24, 12, seed=5), synth.torus(100, 50, seed=4), synth.holey_disc(40, seed=2, color_components=4)]
     blobs = [ca.encode(m, normal_prediction=ca.BORDER) for m in meshes]
     for u16 in (False, True):
         b = run_batch(ctx, blobs, index16=u16)
@@ -440,7 +441,7 @@ def test_topology_lds_slot_overflow_redone_on_hbm_front(ctx):
             if u16:
                 exp["index"] = exp["index"].astype(np.uint16)
             assert_same(b.host_outputs(i), exp, KEYS, "blob %d u16=%s" % (i, u16))
-        assert b.stats().topology_fallbacks == 3, b.stats().topology_fallbacks   # both ribbons and the holey disc
+        assert b.stats().topology_fallbacks == 3, b.stats().topology_fallbacks   # the ribbon (800 boundary edges), the torus (queue of 3 800), the holey disc
 
 
 def test_config4_256_distinct_blobs(ctx):
