@@ -680,6 +680,8 @@ static int build_and_launch(crthip_batch *b) {
 	pl.jobs_begin = cv.take(0);
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
 	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
+	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return d.nvert > DELTA_SMALL_NVERT; });
 	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
 	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.normal_fused_ids); place(pl.dequant); place(pl.dequant_block_job);
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
@@ -796,8 +798,12 @@ static int build_and_launch(crthip_batch *b) {
 		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
+		uint32_t nlarge = 0;
+		for(auto &d : pl.delta.v) nlarge += d.nvert > DELTA_SMALL_NVERT;
+		const uint32_t nsmall = (uint32_t)pl.delta.v.size() - nlarge;
 		LT.begin("delta_mesh");
-		hipLaunchKernelGGL(k_delta_mesh, dim3((uint32_t)pl.delta.v.size()), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), (uint32_t)pl.delta.v.size(), pl.delta_lds);
+		if(nlarge) hipLaunchKernelGGL(k_delta_mesh, dim3(nlarge), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), nlarge, pl.delta_lds);
+		if(nsmall) hipLaunchKernelGGL(k_delta_mesh, dim3(nsmall), dim3(DELTA_THREADS/4), pl.delta_lds, st, D(pl.delta) + nlarge, nsmall, pl.delta_lds);
 		LT.end();
 	}
 	if(cloud_chunks) {

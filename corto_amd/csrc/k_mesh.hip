@@ -460,8 +460,8 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 // share its L1).
 
 template <typename T, typename VPtr, typename FPtr>
-__device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t N, bool para) {
-	uint32_t i = threadIdx.x == 0 ? DELTA_THREADS : threadIdx.x;
+__device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t N, bool para, uint32_t THREADS) {
+	uint32_t i = threadIdx.x == 0 ? THREADS : threadIdx.x;
 	// prediction triples are fetched ONE VERTEX AHEAD: a fetch in the fire path would park the whole wave on an
 	// HBM/L2 round trip while its other lanes are ready to fire.
 	uint32_t na = 0, nb = 0, nc = 0;
@@ -470,7 +470,7 @@ __device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pr
 	};
 	prefetch(i);
 	uint32_t a = na, b = nb, c = nc;
-	prefetch(i + DELTA_THREADS);
+	prefetch(i + THREADS);
 	bool valid = a < i && b < i && c < i;                            // well-formed streams always predict from earlier vertices
 	if(!valid) a = b = c = 0;                                        // vertex 0 is fired from the start
 	// ONE loop, test-and-fire in the same iteration: a lane that spun in an inner wait loop would keep the lanes it is
@@ -487,11 +487,11 @@ __device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pr
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__hip_atomic_store(&fired[i], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			i += DELTA_THREADS;
+			i += THREADS;
 			a = na; b = nb; c = nc;
 			valid = a < i && b < i && c < i;
 			if(!valid) a = b = c = 0;
-			prefetch(i + DELTA_THREADS);
+			prefetch(i + THREADS);
 		}
 		if(!__any(ready)) __builtin_amdgcn_s_sleep(4);                 // nothing to do in this wave: leave the issue slots to the waves that fire
 	}
@@ -500,6 +500,7 @@ __device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pr
 __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs, uint32_t lds_bytes) {
 	if(blockIdx.x >= njobs) return;
 	const DeltaJob J = jobs[blockIdx.x];
+	const uint32_t THREADS = blockDim.x;             // DELTA_THREADS for large attributes, a quarter for small ones (fewer waves to spin and to place)
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const size_t bytes = (size_t)J.nvert*J.N*(J.is_u8 ? 1 : 4);
 	const size_t vbytes = (bytes + 15) & ~(size_t)15;
@@ -513,21 +514,21 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 		CRT_GLOBAL uint8_t *g8 = as_global((uint8_t *)J.values);
 		const bool al = (((uintptr_t)J.values) & 3) == 0;
 		const uint32_t ndw = al ? (uint32_t)(bytes >> 2) : 0u;            // dword body + byte tail (3-component colours: odd sizes)
-		for(uint32_t i = threadIdx.x; i < ndw; i += DELTA_THREADS) l32[i] = g32[i];
-		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += DELTA_THREADS) l8[i] = g8[i];
-		for(uint32_t i = threadIdx.x; i < J.nvert; i += DELTA_THREADS) fired[i] = i == 0;
+		for(uint32_t i = threadIdx.x; i < ndw; i += THREADS) l32[i] = g32[i];
+		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += THREADS) l8[i] = g8[i];
+		for(uint32_t i = threadIdx.x; i < J.nvert; i += THREADS) fired[i] = i == 0;
 		__syncthreads();
-		if(J.is_u8) delta_dataflow<uint8_t>(l8, fired, pred, J.nvert, J.N, J.parallelogram);
-		else delta_dataflow<uint32_t>(l32, fired, pred, J.nvert, J.N, J.parallelogram);
+		if(J.is_u8) delta_dataflow<uint8_t>(l8, fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
+		else delta_dataflow<uint32_t>(l32, fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
 		__syncthreads();
-		for(uint32_t i = threadIdx.x; i < ndw; i += DELTA_THREADS) g32[i] = l32[i];
-		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += DELTA_THREADS) g8[i] = l8[i];
+		for(uint32_t i = threadIdx.x; i < ndw; i += THREADS) g32[i] = l32[i];
+		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += THREADS) g8[i] = l8[i];
 	} else {
 		CRT_GLOBAL uint8_t *fired = as_global(J.fired);                // zero-filled by the host
 		if(threadIdx.x == 0) __hip_atomic_store(&fired[0], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__syncthreads();
-		if(J.is_u8) delta_dataflow<uint8_t>(as_global((uint8_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram);
-		else delta_dataflow<uint32_t>(as_global((uint32_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram);
+		if(J.is_u8) delta_dataflow<uint8_t>(as_global((uint8_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
+		else delta_dataflow<uint32_t>(as_global((uint32_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
 	}
 }
 

@@ -50,7 +50,7 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;
 }
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
-constexpr uint32_t DELTA_THREADS = 256;       // threads of the dataflow workgroup of one (blob, attribute)
+constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of the dataflow workgroup of one (blob, attribute)
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);
 
 // k_normal.hip
