@@ -357,7 +357,7 @@ struct Plan {
 	HostArr<TunStream> tun; HostArr<uint32_t> tun_chunk_stream;
 	HostArr<FillJob> fill;
 	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
-	HostArr<uint32_t> topo_lds_ids, topo_glob_ids; uint32_t topo_lds = 0;
+	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
 	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
 	HostArr<DeltaJob> delta;
 	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
@@ -562,7 +562,8 @@ static int build_and_launch(crthip_batch *b) {
 				const uint32_t need = topo_lds_bytes(ring, pool, pool, symwin);          // every delayed edge is a pool record: same capacity
 				if(need <= TOPO_LDS_MAX) {
 					t.lds_ring = ring; t.lds_pool = pool; t.lds_delayed_cap = pool; t.lds_symwin = symwin;
-					pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need);
+					if(need <= 32*1024) { pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need); }
+					else { pl.topo_big_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_big_lds = std::max(pl.topo_big_lds, need); }   // (a big mesh does not cost the small ones their occupancy)
 				}
 				else pl.topo_glob_ids.v.push_back((uint32_t)pl.topo.v.size());
 			}
@@ -679,7 +680,7 @@ static int build_and_launch(crthip_batch *b) {
 	// job arrays region
 	pl.jobs_begin = cv.take(0);
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
-	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
+	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return d.nvert > DELTA_SMALL_NVERT; });
 	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
@@ -727,7 +728,7 @@ static int build_and_launch(crthip_batch *b) {
 	// host image -> device (one copy)
 	uint8_t *stage = (uint8_t *)ctx->staging.p;
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
-	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
+	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
 	put(pl.delta); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
@@ -760,11 +761,13 @@ static int build_and_launch(crthip_batch *b) {
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
 	};
 	auto topology = [&]() -> int {
-		if(!pl.topo_lds_ids.v.empty()) {
+		if(!pl.topo_lds_ids.v.empty() || !pl.topo_big_ids.v.empty()) {
 			static uint32_t lds_attr = 0;                      // raise the dynamic-LDS limit once
-			if(pl.topo_lds > lds_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX)); lds_attr = TOPO_LDS_MAX; }
-			const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size();
-			LT.begin("topology_lds"); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); LT.end();
+			if(std::max(pl.topo_lds, pl.topo_big_lds) > lds_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX)); lds_attr = TOPO_LDS_MAX; }
+			LT.begin("topology_lds");
+			if(!pl.topo_big_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_big_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_big_lds, st, D(pl.topo), D(pl.topo_big_ids), nj); }
+			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); }
+			LT.end();
 		}
 		if(!pl.topo_glob_ids.v.empty()) {
 			const uint32_t nj = (uint32_t)pl.topo_glob_ids.v.size();

@@ -444,6 +444,19 @@ def test_topology_lds_slot_overflow_redone_on_hbm_front(ctx):
         assert b.stats().topology_fallbacks == 3, b.stats().topology_fallbacks   # the ribbon (800 boundary edges), the torus (queue of 3 800), the holey disc
 
 
+def test_large_and_small_meshes_in_one_batch(ctx):
+    """a 66K-triangle mesh (its automaton gets a 64 KB front, launched apart from the small ones), a 15K-triangle one and 4K-triangle
+    blobs in one batch; the large one's symbol window (8K symbols) is slid ~8 times"""
+    from corto_amd import synth
+    meshes = [synth.bumpy_sphere(64, 32, seed=31), synth.bumpy_sphere(260, 128, seed=32), synth.torus(48, 24, seed=33),
+              synth.bumpy_sphere(124, 62, seed=34), synth.bumpy_sphere(64, 32, seed=35)]
+    blobs = [ca.encode(m, normal_prediction=p) for m, p in zip(meshes, (ca.BORDER, ca.ESTIMATED, ca.DIFF, ca.BORDER, ca.ESTIMATED))]
+    b = run_batch(ctx, blobs)
+    for i in range(len(blobs)):
+        assert_same(b.host_outputs(i), oc.decode(blobs[i]), KEYS, "blob %d" % i)
+    assert b.stats().topology_fallbacks == 0
+
+
 def test_config4_256_distinct_blobs(ctx):
     """256 distinct 4K-tri blobs in one batch: every blob equals the oracle; decoded positions equal the quantised inputs"""
     from corto_amd import synth
