@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=2, help="host threads feeding the GPU (the C ABI releases the GIL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the single-object C2 / C3 decodes (tools/prof_run.sh: keeps the rocprofv3 kernel averages about the C4 batch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -380,6 +381,7 @@ def main():
         }
         if not args.no_tunstall_scaled:
             out["tunstall_scaled"] = tunstall_scaled(ctx, ca, z)
+        if not args.no_other_configs and not args.no_tunstall_scaled:
             out["other_configs"] = other_configs(ctx, ca)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(blobs)
