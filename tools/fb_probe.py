@@ -1,3 +1,5 @@
+"""Probe: which synthetic meshes outgrow the LDS automaton's ring / pool and are redone on the HBM front (stats.topology_fallbacks),
+and that every one of them decodes bit-exact either way."""
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 import corto_amd as ca
