@@ -271,8 +271,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 
 	// automaton state, alive across window refills (uniform: only lane 0 ever changes it)
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
-	CRT_GLOBAL uint32_t *predp = as_global(J.pred);                    // bumped by 3 per new vertex (vertices are numbered in creation order)
-	CRT_GLOBAL uint8_t *facep = as_global((uint8_t *)J.faces);          // bumped by 3 indices per face
+	CRT_GLOBAL uint8_t *predb = (CRT_GLOBAL uint8_t *)as_global(J.pred);   // prediction triple of vertex vc at byte 12*vc (vertices are numbered in creation order)
+	CRT_GLOBAL uint8_t *faceb = as_global((uint8_t *)J.faces);          // index `start` at byte 4*start (2*start for u16 indices)
 	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
 	const uint32_t nvert = J.nvert;
 	const uint32_t splitbits = 32 - __clz(nvert | 1u);
@@ -297,9 +297,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 		{
 #define TOPO_BITS(dst, n) do { uint64_t bit_ = (uint64_t)cold[K_BIT_LO] | (uint64_t)cold[K_BIT_HI] << 32; if(bit_ + (n) > bit_end) { err = 1; dst = 0; } \
 	else { dst = bit_field(split, J.split_nwords, bit_, (n)); bit_ += (n); cold[K_BIT_LO] = (uint32_t)bit_; cold[K_BIT_HI] = (uint32_t)(bit_ >> 32); } } while(0)
-#define TOPO_FACE(a, b, c) do { if(U16) { CRT_GLOBAL uint16_t *h_ = (CRT_GLOBAL uint16_t *)facep; h_[0] = (uint16_t)(a); h_[1] = (uint16_t)(b); h_[2] = (uint16_t)(c); facep += 6; } \
-	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)facep = f_; facep += 12; } start += 3; } while(0)
-#define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)predp = p_; predp += 3; } while(0)
+#define TOPO_FACE(a, b, c) do { if(U16) { CRT_GLOBAL uint16_t *h_ = (CRT_GLOBAL uint16_t *)(faceb + start*2u); h_[0] = (uint16_t)(a); h_[1] = (uint16_t)(b); h_[2] = (uint16_t)(c); } \
+	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)(faceb + start*4u) = f_; } start += 3; } while(0)
+#define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)(predb + vc*12u) = p_; } while(0)   // always right before vc++
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = cl32[(cler >> 3) + wbias]; } } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
@@ -365,8 +365,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						if(nq - qpos > MASK) { err = 2; break; }
 						const uint32_t s = nq & MASK;                      // slot of the second new edge = its place in the queue
 						nq++;
-						const uint32_t opp = vc++;
 						TOPO_PRED(v1, v0, v2);
+						const uint32_t opp = vc++;
 						TOPO_FACE(v1, v0, opp);
 						rec16[en*8 + 6] = (uint16_t)s;                     // front[e.next].prev = new_edge + 1
 						TOPO_PUT(s, opp, v1, v0, 0xFFFFu, en);             // second new edge: queued, so it must exist; its prev is the lazy edge
