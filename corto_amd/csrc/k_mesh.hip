@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 //     running off the end fails without a per-step bounds test.
 // Layout (dynamic LDS): rec[ring + pool] (16 B) | freelist[pool] (u16) | delayed[dcap] (u16) | symbol window (nibbles)
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+#define TOPO_S(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMASK = 0x3FFFFFFFu;
 
 template <bool U16>
@@ -291,7 +292,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	if(threadIdx.x != 0) return true;
 	cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0; cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
 	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
-	uint32_t sw = cl32[0], swn = cl32[1];
+	uint32_t sw = TOPO_S(cl32[0]), swn = TOPO_S(cl32[1]);   // TOPO_S: a value lane 0 alone computes is uniform by construction; tell the compiler (SGPR)
 	uint32_t wbias = 1, slide_at = SYMW < nclers ? SYMW - 2048u : 0xFFFFFFFFu;   // next symbol word = cl32[(cler >> 3) + wbias]; slide when cler gets here
 	{
 		{
@@ -301,7 +302,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)(faceb + start*4u) = f_; } start += 3; } while(0)
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)(predb + vc*12u) = p_; } while(0)   // always right before vc++
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
-#define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = cl32[(cler >> 3) + wbias]; } } while(0)
+#define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = TOPO_S(cl32[(cler >> 3) + wbias]); } } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
 #define TOPO_RELEASE(id, z) do { if((id) > MASK && !((z) & TOPO_DELAYED)) { const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)(id); cold[K_NFREE] = n_ + 1; } } while(0)
 	// give the surviving current edge a pool slot, its record, and its neighbours their links to it
@@ -310,7 +311,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	TOPO_PUT(f, v0, v1, v2 | (flags), ep, en); rec16[ep*8 + 7] = (uint16_t)f; rec16[en*8 + 6] = (uint16_t)f; } while(0)
 
 			for(uint32_t g = 0; g < J.ngroups && !err; g++) {              // every group starts from an empty front (decoder.cpp:173-178)
-			const uint32_t ge = group_end[g];
+			const uint32_t ge = TOPO_S(group_end[g]);
 			if(ge > J.nface || ge*3 < start) { err = 1; break; }
 			const uint32_t end = ge*3;
 			nq = 0; qpos = 0; cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0;
@@ -318,7 +319,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 				if(cler >= slide_at) {                                      // between chains: slide the window before it runs low
 					winbase = cler & ~7u;
 					for(uint32_t w = 0; w < symwords; w++) cl32[w] = pack8(winbase + 8*w);
-					sw = cl32[0] >> (4*(cler & 7u)); swn = cl32[1];
+					sw = TOPO_S(cl32[0]) >> (4*(cler & 7u)); swn = TOPO_S(cl32[1]);
 					wbias = 1u - (winbase >> 3);
 					slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu;
 				}
@@ -354,11 +355,156 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 					continue;
 				}
 				if(t0.z & TOPO_DEAD) continue;                             // deleted: no symbol consumed (decoder.cpp:278-279)
-				uint32_t v0 = t0.x, v1 = t0.y, v2 = t0.z & TOPO_VMASK, ep = t0.w & 0xFFFFu, en = t0.w >> 16;
+				uint32_t v0 = TOPO_S(t0.x), v1 = TOPO_S(t0.y), v2 = TOPO_S(t0.z) & TOPO_VMASK, ep = TOPO_S(t0.w) & 0xFFFFu, en = TOPO_S(t0.w) >> 16;
 				uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;         // cached (next, v1) of edge nc
 
 				// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
 				for(;;) {
+					if constexpr(!U16) {
+						// The common steps in hand-scheduled gfx950 ISA: VERTEX, and LEFT / RIGHT against a ring-slot (queued)
+						// neighbour, ~40 instructions per symbol where the compiler's dispatch of the C++ below spends ~68
+						// (scalar copies at every join).  The block PEEKS at the next symbol and leaves with the state
+						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
+						// or ring running out, the group's last face - which the C++ below then handles.
+						uint32_t t0_, t1_, t2_, c_;
+						asm volatile(
+							"Ltop_%=:\n"
+							"  s_and_b32 %[c], %[sw], 15\n"
+							"  s_cmp_eq_u32 %[c], 0\n"
+							"  s_cbranch_scc1 Lvertex_%=\n"
+							"  s_cmp_eq_u32 %[c], 1\n"
+							"  s_cbranch_scc1 Lleft_%=\n"
+							"  s_cmp_eq_u32 %[c], 2\n"
+							"  s_cbranch_scc1 Lright_%=\n"
+							"  s_branch Lexit_%=\n"
+							// ---------------- VERTEX (decoder.cpp:294-309)
+							"Lvertex_%=:\n"
+							"  s_cmp_ge_u32 %[vc], %[nvert]\n"
+							"  s_cbranch_scc1 Lexit_%=\n"
+							"  s_sub_u32 %[t0], %[nq], %[qpos]\n"
+							"  s_cmp_gt_u32 %[t0], %[mask]\n"
+							"  s_cbranch_scc1 Lexit_%=\n"
+							"  s_and_b32 %[t1], %[nq], %[mask]\n"                 // s: slot of the second new edge
+							"  s_add_u32 %[nq], %[nq], 1\n"
+							"  s_mul_i32 %[t0], %[vc], 12\n"                      // prediction triple (v1, v0, v2) of the new vertex
+							"  v_mov_b32 v40, %[v1]\n"
+							"  v_mov_b32 v41, %[v0]\n"
+							"  v_mov_b32 v42, %[v2]\n"
+							"  v_mov_b32 v43, %[t0]\n"
+							"  global_store_dwordx3 v43, v[40:42], %[predb]\n"
+							"  s_lshl_b32 %[t0], %[start], 2\n"                   // face (v1, v0, opp = vc)
+							"  v_mov_b32 v44, %[v1]\n"
+							"  v_mov_b32 v45, %[v0]\n"
+							"  v_mov_b32 v46, %[vc]\n"
+							"  v_mov_b32 v47, %[t0]\n"
+							"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
+							"  s_add_u32 %[start], %[start], 3\n"
+							"  s_lshl_b32 %[t0], %[en], 4\n"                      // front[e.next].prev = s
+							"  v_mov_b32 v52, %[t0]\n"
+							"  v_mov_b32 v53, %[t1]\n"
+							"  ds_write_b16 v52, v53 offset:12\n"
+							"  s_lshl_b32 %[t2], %[en], 16\n"                     // rec[s] = {opp, v1, v0, 0xFFFF | en << 16}
+							"  s_or_b32 %[t2], %[t2], 0xffff\n"
+							"  v_mov_b32 v48, %[vc]\n"
+							"  v_mov_b32 v49, %[v1]\n"
+							"  v_mov_b32 v50, %[v0]\n"
+							"  v_mov_b32 v51, %[t2]\n"
+							"  s_lshl_b32 %[t0], %[t1], 4\n"
+							"  v_mov_b32 v54, %[t0]\n"
+							"  ds_write_b128 v54, v[48:51]\n"
+							"  s_mov_b32 %[nc], %[t1]\n"
+							"  s_mov_b32 %[ncnext], %[en]\n"
+							"  s_mov_b32 %[ncv1], %[v1]\n"
+							"  s_mov_b32 %[v2], %[v1]\n"
+							"  s_mov_b32 %[v1], %[vc]\n"
+							"  s_mov_b32 %[en], %[t1]\n"
+							"  s_add_u32 %[vc], %[vc], 1\n"
+							"  s_branch Lconsumed_%=\n"
+							// ---------------- LEFT (decoder.cpp:311-317), neighbour in the ring
+							"Lleft_%=:\n"
+							"  s_cmp_gt_u32 %[ep], %[mask]\n"
+							"  s_cbranch_scc1 Lexit_%=\n"
+							"  s_lshl_b32 %[t0], %[ep], 4\n"
+							"  v_mov_b32 v52, %[t0]\n"
+							"  ds_read_b128 v[56:59], v52\n"
+							"  v_mov_b32 v53, 0x8000\n"
+							"  s_lshl_b32 %[t2], %[start], 2\n"
+							"  v_mov_b32 v44, %[v1]\n"
+							"  v_mov_b32 v45, %[v0]\n"
+							"  v_mov_b32 v47, %[t2]\n"
+							"  s_waitcnt lgkmcnt(0)\n"
+							"  v_readfirstlane_b32 %[t1], v56\n"                  // opp = prev.v0
+							"  v_readfirstlane_b32 %[t2], v59\n"
+							"  s_and_b32 %[t2], %[t2], 0xffff\n"                  // pp = prev.prev
+							"  ds_write_b16 v52, v53 offset:10\n"                 // prev.deleted = true
+							"  v_mov_b32 v46, v56\n"
+							"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
+							"  s_add_u32 %[start], %[start], 3\n"
+							"  s_mov_b32 %[v2], %[v0]\n"
+							"  s_mov_b32 %[v0], %[t1]\n"
+							"  s_mov_b32 %[ep], %[t2]\n"
+							"  s_branch Lconsumed_%=\n"
+							// ---------------- RIGHT (decoder.cpp:319-325): against the edge VERTEX just made (cached), or a ring neighbour
+							"Lright_%=:\n"
+							"  s_lshl_b32 %[t0], %[en], 4\n"
+							"  v_mov_b32 v52, %[t0]\n"
+							"  s_cmp_eq_u32 %[en], %[nc]\n"
+							"  s_cbranch_scc1 Lrightc_%=\n"
+							"  s_cmp_gt_u32 %[en], %[mask]\n"
+							"  s_cbranch_scc1 Lexit_%=\n"
+							"  ds_read_b128 v[56:59], v52\n"
+							"  s_waitcnt lgkmcnt(0)\n"
+							"  v_readfirstlane_b32 %[t1], v57\n"                  // opp = next.v1
+							"  v_readfirstlane_b32 %[t2], v59\n"
+							"  s_lshr_b32 %[t2], %[t2], 16\n"                     // nn = next.next
+							"  s_branch Lrightd_%=\n"
+							"Lrightc_%=:\n"
+							"  s_mov_b32 %[t1], %[ncv1]\n"
+							"  s_mov_b32 %[t2], %[ncnext]\n"
+							"Lrightd_%=:\n"
+							"  v_mov_b32 v53, 0x8000\n"
+							"  ds_write_b16 v52, v53 offset:10\n"                 // next.deleted = true
+							"  s_lshl_b32 %[t0], %[start], 2\n"
+							"  v_mov_b32 v44, %[v1]\n"
+							"  v_mov_b32 v45, %[v0]\n"
+							"  v_mov_b32 v46, %[t1]\n"
+							"  v_mov_b32 v47, %[t0]\n"
+							"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
+							"  s_add_u32 %[start], %[start], 3\n"
+							"  s_mov_b32 %[nc], -1\n"
+							"  s_mov_b32 %[v2], %[v1]\n"
+							"  s_mov_b32 %[v1], %[t1]\n"
+							"  s_mov_b32 %[en], %[t2]\n"
+							// ---------------- the symbol is consumed; every eighth one pulls the next word of the window
+							"Lconsumed_%=:\n"
+							"  s_lshr_b32 %[sw], %[sw], 4\n"
+							"  s_add_u32 %[cler], %[cler], 1\n"
+							"  s_and_b32 %[t0], %[cler], 7\n"
+							"  s_cmp_eq_u32 %[t0], 0\n"
+							"  s_cbranch_scc0 Lnext_%=\n"
+							"  s_mov_b32 %[sw], %[swn]\n"
+							"  s_lshr_b32 %[t0], %[cler], 3\n"
+							"  s_add_u32 %[t0], %[t0], %[wbias]\n"
+							"  s_lshl_b32 %[t0], %[t0], 2\n"
+							"  s_add_u32 %[t0], %[t0], %[clbase]\n"
+							"  v_mov_b32 v55, %[t0]\n"
+							"  ds_read_b32 v55, v55\n"
+							"  s_waitcnt lgkmcnt(0)\n"
+							"  v_readfirstlane_b32 %[swn], v55\n"
+							"Lnext_%=:\n"
+							"  s_cmp_lt_u32 %[start], %[end]\n"
+							"  s_cbranch_scc1 Ltop_%=\n"
+							"Lexit_%=:\n"
+							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start),
+							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en),
+							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1),
+							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_)
+							: [nvert] "s"(nvert), [qpos] "s"(qpos), [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias),
+							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb)
+							: "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+						if(start >= end) break;
+					}
 					uint32_t c; TOPO_SYMBOL(c);
 					if(c == C_VERTEX) {                                    // decoder.cpp:294-309
 						if(vc >= nvert) { err = 1; break; }
@@ -374,7 +520,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						v2 = v1; v1 = opp; en = s;                         // first new edge (v0, opp, old v1, ep, s): next, lazily
 					} else if(c == C_LEFT) {                               // decoder.cpp:311-317
 						const u32x4 t = rec[ep];
-						const uint32_t pp = t.w & 0xFFFFu, opp = t.x;
+						const uint32_t pp = TOPO_S(t.w) & 0xFFFFu, opp = TOPO_S(t.x);
 						rec16[ep*8 + 5] = 0x8000u;                         // front[e.prev].deleted = true
 						TOPO_RELEASE(ep, t.z);
 						TOPO_FACE(v1, v0, opp);
@@ -382,7 +528,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 					} else if(c == C_RIGHT) {                              // decoder.cpp:319-325
 						uint32_t nn, opp;
 						if(en == nc) { nn = nc_next; opp = nc_v1; }        // (a ring slot: nothing to release)
-						else { const u32x4 t = rec[en]; nn = t.w >> 16; opp = t.y; TOPO_RELEASE(en, t.z); }
+						else { const u32x4 t = rec[en]; nn = TOPO_S(t.w) >> 16; opp = TOPO_S(t.y); TOPO_RELEASE(en, t.z); }
 						rec16[en*8 + 5] = 0x8000u;
 						TOPO_FACE(v1, v0, opp);
 						nc = 0xFFFFFFFFu;
@@ -394,7 +540,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							if(nq - qpos > MASK) { err = 2; break; }
 							uint32_t opp; TOPO_BITS(opp, splitbits);
 							if(err) break;
-							opp &= TOPO_VMASK;
+							opp = TOPO_S(opp) & TOPO_VMASK;
 							const uint32_t s = nq & MASK;
 							nq++;
 							TOPO_FACE(v1, v0, opp);
