@@ -327,7 +327,18 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 				uint32_t f;
 				u32x4 t0;
 				uint32_t nd_;
-				if(qpos != nq) { f = qpos & MASK; qpos++; t0 = rec[f]; }     // the slot is free from here on
+				if(qpos != nq) {
+					// most queued edges are dead by the time they are popped (closed by a neighbouring chain): look at four ring
+					// records per LDS round trip and skip the dead ones together; a popped slot is free from here on
+					const u32x4 r0 = rec[qpos & MASK], r1 = rec[(qpos + 1) & MASK], r2 = rec[(qpos + 2) & MASK], r3 = rec[(qpos + 3) & MASK];
+					const uint32_t avail = nq - qpos;
+					if(!(r0.z & TOPO_DEAD)) { t0 = r0; qpos += 1; }
+					else if(avail > 1 && !(r1.z & TOPO_DEAD)) { t0 = r1; qpos += 2; }
+					else if(avail > 2 && !(r2.z & TOPO_DEAD)) { t0 = r2; qpos += 3; }
+					else if(avail > 3 && !(r3.z & TOPO_DEAD)) { t0 = r3; qpos += 4; }
+					else { qpos += avail < 4 ? avail : 4u; continue; }         // all dead: no symbol consumed (decoder.cpp:278-279)
+					f = 0;
+				}
 				else if((nd_ = cold[K_NDELAYED]) != 0) { f = delayed[nd_ - 1]; cold[K_NDELAYED] = nd_ - 1; t0 = rec[f]; const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)f; cold[K_NFREE] = n_ + 1; }
 				else {                                                     // seed face (decoder.cpp:224-259)
 					uint32_t c; TOPO_SYMBOL(c);
