@@ -262,6 +262,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	CRT_LDS uint16_t *delayed = freel + ((POOL + 7) & ~7u);
 	CRT_LDS uint32_t *cl32 = (CRT_LDS uint32_t *)(delayed + ((dcap + 7) & ~7u));
 	CRT_LDS uint32_t *cold = cl32 + SYMW/8 + 2;                         // state only the cold paths touch lives here, not in loop-carried registers
+	CRT_LDS uint32_t *spl = cold + 8;                                   // the first TOPO_SPLIT_LDS words of the split / vertex-id bits: a SPLIT that loads them from HBM
+	const uint32_t nspl = J.split_nwords < TOPO_SPLIT_LDS ? J.split_nwords : TOPO_SPLIT_LDS;   // waits ~2 us (the load, and every store in flight before it)
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	const uint32_t nclers = J.nclers, symwords = SYMW/8;
 	auto pack8 = [&](uint32_t s0) -> uint32_t {                         // symbols s0 .. s0+7 as nibbles; any invalid byte, and
@@ -288,6 +290,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	// (two words behind the window: "window exhausted" nibbles - a chain that outruns the window ends in the HBM redo, so that the
 	// loop never loads symbols from HBM itself: a load's s_waitcnt would also wait for every face / prediction store in flight)
 	for(uint32_t w = threadIdx.x; w < symwords + 2; w += 64) cl32[w] = w < symwords ? pack8(8*w) : 0xEEEEEEEEu;
+	for(uint32_t w = threadIdx.x; w < nspl; w += 64) spl[w] = split[w];
 	__syncthreads();
 	if(threadIdx.x != 0) return true;
 	cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0; cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
@@ -297,7 +300,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	{
 		{
 #define TOPO_BITS(dst, n) do { uint64_t bit_ = (uint64_t)cold[K_BIT_LO] | (uint64_t)cold[K_BIT_HI] << 32; if(bit_ + (n) > bit_end) { err = 1; dst = 0; } \
-	else { dst = bit_field(split, J.split_nwords, bit_, (n)); bit_ += (n); cold[K_BIT_LO] = (uint32_t)bit_; cold[K_BIT_HI] = (uint32_t)(bit_ >> 32); } } while(0)
+	else { dst = (bit_ + (n) + 31)/32 <= nspl ? bit_field(spl, nspl, bit_, (n)) : bit_field(split, J.split_nwords, bit_, (n)); bit_ += (n); cold[K_BIT_LO] = (uint32_t)bit_; cold[K_BIT_HI] = (uint32_t)(bit_ >> 32); } } while(0)
 #define TOPO_FACE(a, b, c) do { if(U16) { CRT_GLOBAL uint16_t *h_ = (CRT_GLOBAL uint16_t *)(faceb + start*2u); h_[0] = (uint16_t)(a); h_[1] = (uint16_t)(b); h_[2] = (uint16_t)(c); } \
 	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)(faceb + start*4u) = f_; } start += 3; } while(0)
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)(predb + vc*12u) = p_; } while(0)   // always right before vc++

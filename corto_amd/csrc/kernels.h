@@ -33,10 +33,11 @@ __global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uin
 __global__ void k_topology(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 __global__ void k_topology_lds(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 // dynamic LDS bytes k_topology_lds needs for a front of `cap` edges and `nclers` symbols
+constexpr uint32_t TOPO_SPLIT_LDS = 256;          // words of the split / vertex-id bit block staged in LDS
 // LDS of one blob's CLERS automaton (k_mesh.hip): records of the LIVE front only - a ring for the queued edges, a pool for
 // surviving chain ends - plus the DELAY stack and a window of nibble-packed symbols.
 inline uint32_t topo_lds_bytes(uint32_t ring, uint32_t pool, uint32_t dcap, uint32_t symwin) {
-	return (ring + pool)*16 + ((pool + 7) & ~7u)*2 + ((dcap + 7) & ~7u)*2 + symwin/2 + 8 + 32 + 16;
+	return (ring + pool)*16 + ((pool + 7) & ~7u)*2 + ((dcap + 7) & ~7u)*2 + symwin/2 + 8 + 32 + TOPO_SPLIT_LDS*4 + 16;
 }
 constexpr uint32_t TOPO_SYMWIN_MAX = 8192;
 // The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the ring gets 8*sqrt(nface)
