@@ -381,11 +381,11 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
 						// or ring running out, the group's last face - which the C++ below then handles.
 						uint32_t t0_, t1_, t2_, c_;
+						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
 						asm volatile(
 							"Ltop_%=:\n"
-							"  s_and_b32 %[c], %[sw], 15\n"
-							"  s_cmp_eq_u32 %[c], 0\n"
-							"  s_cbranch_scc1 Lvertex_%=\n"
+							"  s_and_b32 %[c], %[sw], 15\n"                       // (SCC = result != 0)
+							"  s_cbranch_scc0 Lvertex_%=\n"
 							"  s_cmp_eq_u32 %[c], 1\n"
 							"  s_cbranch_scc1 Lleft_%=\n"
 							"  s_cmp_eq_u32 %[c], 2\n"
@@ -393,10 +393,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							"  s_branch Lexit_%=\n"
 							// ---------------- VERTEX (decoder.cpp:294-309)
 							"Lvertex_%=:\n"
-							"  s_cmp_ge_u32 %[vc], %[nvert]\n"
-							"  s_cbranch_scc1 Lexit_%=\n"
-							"  s_sub_u32 %[t0], %[nq], %[qpos]\n"
-							"  s_cmp_gt_u32 %[t0], %[mask]\n"
+							"  s_sub_u32 %[budget], %[budget], 1\n"               // vertex ids and ring slots left (SCC = borrow: none)
 							"  s_cbranch_scc1 Lexit_%=\n"
 							"  s_and_b32 %[t1], %[nq], %[mask]\n"                 // s: slot of the second new edge
 							"  s_add_u32 %[nq], %[nq], 1\n"
@@ -494,8 +491,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							"  s_lshr_b32 %[sw], %[sw], 4\n"
 							"  s_add_u32 %[cler], %[cler], 1\n"
 							"  s_and_b32 %[t0], %[cler], 7\n"
-							"  s_cmp_eq_u32 %[t0], 0\n"
-							"  s_cbranch_scc0 Lnext_%=\n"
+							"  s_cbranch_scc1 Lnext_%=\n"
 							"  s_mov_b32 %[sw], %[swn]\n"
 							"  s_lshr_b32 %[t0], %[cler], 3\n"
 							"  s_add_u32 %[t0], %[t0], %[wbias]\n"
@@ -512,8 +508,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start),
 							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en),
 							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1),
-							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_)
-							: [nvert] "s"(nvert), [qpos] "s"(qpos), [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias),
+							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [budget] "+s"(budget_)
+							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias),
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb)
 							: "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
 							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
