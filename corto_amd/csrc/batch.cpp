@@ -806,7 +806,7 @@ static int build_and_launch(crthip_batch *b) {
 		const uint32_t nsmall = (uint32_t)pl.delta.v.size() - nlarge;
 		LT.begin("delta_mesh");
 		if(nlarge) hipLaunchKernelGGL(k_delta_mesh, dim3(nlarge), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), nlarge, pl.delta_lds);
-		if(nsmall) hipLaunchKernelGGL(k_delta_mesh, dim3(nsmall), dim3(DELTA_THREADS/4), pl.delta_lds, st, D(pl.delta) + nlarge, nsmall, pl.delta_lds);
+		if(nsmall) hipLaunchKernelGGL(k_delta_mesh, dim3(nsmall), dim3(DELTA_THREADS/2), pl.delta_lds, st, D(pl.delta) + nlarge, nsmall, pl.delta_lds);
 		LT.end();
 	}
 	if(cloud_chunks) {
