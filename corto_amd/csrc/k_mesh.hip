@@ -252,6 +252,142 @@ typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 #define TOPO_S(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMASK = 0x3FFFFFFFu;
 
+// the face store of the ISA block below: three u32, or three u16 (a dword of v1 | v0 << 16, then opp)
+#define TOPO_ASM_FACE32(OPP) \
+	"  s_lshl_b32 %[t0], %[start], 2\n" \
+	"  v_mov_b32 v44, %[v1]\n" \
+	"  v_mov_b32 v45, %[v0]\n" \
+	"  v_mov_b32 v46, " OPP "\n" \
+	"  v_mov_b32 v47, %[t0]\n" \
+	"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
+#define TOPO_ASM_FACE16(OPP) \
+	"  s_lshl_b32 %[t0], %[start], 1\n" \
+	"  s_and_b32 %[t3], %[v1], 0xffff\n" \
+	"  s_lshl_b32 %[c], %[v0], 16\n" \
+	"  s_or_b32 %[t3], %[t3], %[c]\n" \
+	"  v_mov_b32 v44, %[t3]\n" \
+	"  v_mov_b32 v46, " OPP "\n" \
+	"  v_mov_b32 v47, %[t0]\n" \
+	"  global_store_dword v47, v44, %[faceb]\n" \
+	"  global_store_short v47, v46, %[faceb] offset:4\n"
+#define TOPO_FAST_PATH(FACE) \
+						asm volatile( \
+							"Ltop_%=:\n" \
+							"  s_and_b32 %[c], %[sw], 15\n"   /* (SCC = result != 0) */ \
+							"  s_cbranch_scc0 Lvertex_%=\n" \
+							"  s_cmp_eq_u32 %[c], 1\n" \
+							"  s_cbranch_scc1 Lleft_%=\n" \
+							"  s_cmp_eq_u32 %[c], 2\n" \
+							"  s_cbranch_scc1 Lright_%=\n" \
+							"  s_branch Lexit_%=\n" \
+   /* ---------------- VERTEX (decoder.cpp:294-309) */ \
+							"Lvertex_%=:\n" \
+							"  s_sub_u32 %[budget], %[budget], 1\n"   /* vertex ids and ring slots left (SCC = borrow: none) */ \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_and_b32 %[t1], %[nq], %[mask]\n"   /* s: slot of the second new edge */ \
+							"  s_add_u32 %[nq], %[nq], 1\n" \
+							"  s_mul_i32 %[t0], %[vc], 12\n"   /* prediction triple (v1, v0, v2) of the new vertex */ \
+							"  v_mov_b32 v40, %[v1]\n" \
+							"  v_mov_b32 v41, %[v0]\n" \
+							"  v_mov_b32 v42, %[v2]\n" \
+							"  v_mov_b32 v43, %[t0]\n" \
+							"  global_store_dwordx3 v43, v[40:42], %[predb]\n" \
+							FACE("%[vc]")                                           /* face (v1, v0, opp = vc) */ \
+							"  s_add_u32 %[start], %[start], 3\n" \
+							"  s_lshl_b32 %[t0], %[en], 4\n"   /* front[e.next].prev = s */ \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  v_mov_b32 v53, %[t1]\n" \
+							"  ds_write_b16 v52, v53 offset:12\n" \
+							"  s_lshl_b32 %[t2], %[en], 16\n"   /* rec[s] = {opp, v1, v0, 0xFFFF | en << 16} */ \
+							"  s_or_b32 %[t2], %[t2], 0xffff\n" \
+							"  v_mov_b32 v48, %[vc]\n" \
+							"  v_mov_b32 v49, %[v1]\n" \
+							"  v_mov_b32 v50, %[v0]\n" \
+							"  v_mov_b32 v51, %[t2]\n" \
+							"  s_lshl_b32 %[t0], %[t1], 4\n" \
+							"  v_mov_b32 v54, %[t0]\n" \
+							"  ds_write_b128 v54, v[48:51]\n" \
+							"  s_mov_b32 %[nc], %[t1]\n" \
+							"  s_mov_b32 %[ncnext], %[en]\n" \
+							"  s_mov_b32 %[ncv1], %[v1]\n" \
+							"  s_mov_b32 %[v2], %[v1]\n" \
+							"  s_mov_b32 %[v1], %[vc]\n" \
+							"  s_mov_b32 %[en], %[t1]\n" \
+							"  s_add_u32 %[vc], %[vc], 1\n" \
+							"  s_branch Lconsumed_%=\n" \
+   /* ---------------- LEFT (decoder.cpp:311-317), neighbour in the ring */ \
+							"Lleft_%=:\n" \
+							"  s_cmp_gt_u32 %[ep], %[mask]\n" \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_lshl_b32 %[t0], %[ep], 4\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_read_b128 v[56:59], v52\n" \
+							"  v_mov_b32 v53, 0x8000\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[t1], v56\n"   /* opp = prev.v0 */ \
+							"  v_readfirstlane_b32 %[t2], v59\n" \
+							"  s_and_b32 %[t2], %[t2], 0xffff\n"   /* pp = prev.prev */ \
+							"  ds_write_b16 v52, v53 offset:10\n"   /* prev.deleted = true */ \
+							FACE("%[t1]") \
+							"  s_add_u32 %[start], %[start], 3\n" \
+							"  s_mov_b32 %[v2], %[v0]\n" \
+							"  s_mov_b32 %[v0], %[t1]\n" \
+							"  s_mov_b32 %[ep], %[t2]\n" \
+							"  s_branch Lconsumed_%=\n" \
+   /* ---------------- RIGHT (decoder.cpp:319-325): against the edge VERTEX just made (cached), or a ring neighbour */ \
+							"Lright_%=:\n" \
+							"  s_lshl_b32 %[t0], %[en], 4\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  s_cmp_eq_u32 %[en], %[nc]\n" \
+							"  s_cbranch_scc1 Lrightc_%=\n" \
+							"  s_cmp_gt_u32 %[en], %[mask]\n" \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  ds_read_b128 v[56:59], v52\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[t1], v57\n"   /* opp = next.v1 */ \
+							"  v_readfirstlane_b32 %[t2], v59\n" \
+							"  s_lshr_b32 %[t2], %[t2], 16\n"   /* nn = next.next */ \
+							"  s_branch Lrightd_%=\n" \
+							"Lrightc_%=:\n" \
+							"  s_mov_b32 %[t1], %[ncv1]\n" \
+							"  s_mov_b32 %[t2], %[ncnext]\n" \
+							"Lrightd_%=:\n" \
+							"  v_mov_b32 v53, 0x8000\n" \
+							"  ds_write_b16 v52, v53 offset:10\n"   /* next.deleted = true */ \
+							FACE("%[t1]") \
+							"  s_add_u32 %[start], %[start], 3\n" \
+							"  s_mov_b32 %[nc], -1\n" \
+							"  s_mov_b32 %[v2], %[v1]\n" \
+							"  s_mov_b32 %[v1], %[t1]\n" \
+							"  s_mov_b32 %[en], %[t2]\n" \
+   /* ---------------- the symbol is consumed; every eighth one pulls the next word of the window */ \
+							"Lconsumed_%=:\n" \
+							"  s_lshr_b32 %[sw], %[sw], 4\n" \
+							"  s_add_u32 %[cler], %[cler], 1\n" \
+							"  s_and_b32 %[t0], %[cler], 7\n" \
+							"  s_cbranch_scc1 Lnext_%=\n" \
+							"  s_mov_b32 %[sw], %[swn]\n" \
+							"  s_lshr_b32 %[t0], %[cler], 3\n" \
+							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
+							"  s_lshl_b32 %[t0], %[t0], 2\n" \
+							"  s_add_u32 %[t0], %[t0], %[clbase]\n" \
+							"  v_mov_b32 v55, %[t0]\n" \
+							"  ds_read_b32 v55, v55\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[swn], v55\n" \
+							"Lnext_%=:\n" \
+							"  s_cmp_lt_u32 %[start], %[end]\n" \
+							"  s_cbranch_scc1 Ltop_%=\n" \
+							"Lexit_%=:\n" \
+							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start), \
+							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en), \
+							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1), \
+							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [t3] "=&s"(t3_), [budget] "+s"(budget_) \
+							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), \
+							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
+							: "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+
 template <bool U16>
 __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -374,145 +510,15 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 
 				// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
 				for(;;) {
-					if constexpr(!U16) {
+					{
 						// The common steps in hand-scheduled gfx950 ISA: VERTEX, and LEFT / RIGHT against a ring-slot (queued)
 						// neighbour, ~40 instructions per symbol where the compiler's dispatch of the C++ below spends ~68
 						// (scalar copies at every join).  The block PEEKS at the next symbol and leaves with the state
 						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
 						// or ring running out, the group's last face - which the C++ below then handles.
-						uint32_t t0_, t1_, t2_, c_;
+						uint32_t t0_, t1_, t2_, t3_, c_;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
-						asm volatile(
-							"Ltop_%=:\n"
-							"  s_and_b32 %[c], %[sw], 15\n"                       // (SCC = result != 0)
-							"  s_cbranch_scc0 Lvertex_%=\n"
-							"  s_cmp_eq_u32 %[c], 1\n"
-							"  s_cbranch_scc1 Lleft_%=\n"
-							"  s_cmp_eq_u32 %[c], 2\n"
-							"  s_cbranch_scc1 Lright_%=\n"
-							"  s_branch Lexit_%=\n"
-							// ---------------- VERTEX (decoder.cpp:294-309)
-							"Lvertex_%=:\n"
-							"  s_sub_u32 %[budget], %[budget], 1\n"               // vertex ids and ring slots left (SCC = borrow: none)
-							"  s_cbranch_scc1 Lexit_%=\n"
-							"  s_and_b32 %[t1], %[nq], %[mask]\n"                 // s: slot of the second new edge
-							"  s_add_u32 %[nq], %[nq], 1\n"
-							"  s_mul_i32 %[t0], %[vc], 12\n"                      // prediction triple (v1, v0, v2) of the new vertex
-							"  v_mov_b32 v40, %[v1]\n"
-							"  v_mov_b32 v41, %[v0]\n"
-							"  v_mov_b32 v42, %[v2]\n"
-							"  v_mov_b32 v43, %[t0]\n"
-							"  global_store_dwordx3 v43, v[40:42], %[predb]\n"
-							"  s_lshl_b32 %[t0], %[start], 2\n"                   // face (v1, v0, opp = vc)
-							"  v_mov_b32 v44, %[v1]\n"
-							"  v_mov_b32 v45, %[v0]\n"
-							"  v_mov_b32 v46, %[vc]\n"
-							"  v_mov_b32 v47, %[t0]\n"
-							"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
-							"  s_add_u32 %[start], %[start], 3\n"
-							"  s_lshl_b32 %[t0], %[en], 4\n"                      // front[e.next].prev = s
-							"  v_mov_b32 v52, %[t0]\n"
-							"  v_mov_b32 v53, %[t1]\n"
-							"  ds_write_b16 v52, v53 offset:12\n"
-							"  s_lshl_b32 %[t2], %[en], 16\n"                     // rec[s] = {opp, v1, v0, 0xFFFF | en << 16}
-							"  s_or_b32 %[t2], %[t2], 0xffff\n"
-							"  v_mov_b32 v48, %[vc]\n"
-							"  v_mov_b32 v49, %[v1]\n"
-							"  v_mov_b32 v50, %[v0]\n"
-							"  v_mov_b32 v51, %[t2]\n"
-							"  s_lshl_b32 %[t0], %[t1], 4\n"
-							"  v_mov_b32 v54, %[t0]\n"
-							"  ds_write_b128 v54, v[48:51]\n"
-							"  s_mov_b32 %[nc], %[t1]\n"
-							"  s_mov_b32 %[ncnext], %[en]\n"
-							"  s_mov_b32 %[ncv1], %[v1]\n"
-							"  s_mov_b32 %[v2], %[v1]\n"
-							"  s_mov_b32 %[v1], %[vc]\n"
-							"  s_mov_b32 %[en], %[t1]\n"
-							"  s_add_u32 %[vc], %[vc], 1\n"
-							"  s_branch Lconsumed_%=\n"
-							// ---------------- LEFT (decoder.cpp:311-317), neighbour in the ring
-							"Lleft_%=:\n"
-							"  s_cmp_gt_u32 %[ep], %[mask]\n"
-							"  s_cbranch_scc1 Lexit_%=\n"
-							"  s_lshl_b32 %[t0], %[ep], 4\n"
-							"  v_mov_b32 v52, %[t0]\n"
-							"  ds_read_b128 v[56:59], v52\n"
-							"  v_mov_b32 v53, 0x8000\n"
-							"  s_lshl_b32 %[t2], %[start], 2\n"
-							"  v_mov_b32 v44, %[v1]\n"
-							"  v_mov_b32 v45, %[v0]\n"
-							"  v_mov_b32 v47, %[t2]\n"
-							"  s_waitcnt lgkmcnt(0)\n"
-							"  v_readfirstlane_b32 %[t1], v56\n"                  // opp = prev.v0
-							"  v_readfirstlane_b32 %[t2], v59\n"
-							"  s_and_b32 %[t2], %[t2], 0xffff\n"                  // pp = prev.prev
-							"  ds_write_b16 v52, v53 offset:10\n"                 // prev.deleted = true
-							"  v_mov_b32 v46, v56\n"
-							"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
-							"  s_add_u32 %[start], %[start], 3\n"
-							"  s_mov_b32 %[v2], %[v0]\n"
-							"  s_mov_b32 %[v0], %[t1]\n"
-							"  s_mov_b32 %[ep], %[t2]\n"
-							"  s_branch Lconsumed_%=\n"
-							// ---------------- RIGHT (decoder.cpp:319-325): against the edge VERTEX just made (cached), or a ring neighbour
-							"Lright_%=:\n"
-							"  s_lshl_b32 %[t0], %[en], 4\n"
-							"  v_mov_b32 v52, %[t0]\n"
-							"  s_cmp_eq_u32 %[en], %[nc]\n"
-							"  s_cbranch_scc1 Lrightc_%=\n"
-							"  s_cmp_gt_u32 %[en], %[mask]\n"
-							"  s_cbranch_scc1 Lexit_%=\n"
-							"  ds_read_b128 v[56:59], v52\n"
-							"  s_waitcnt lgkmcnt(0)\n"
-							"  v_readfirstlane_b32 %[t1], v57\n"                  // opp = next.v1
-							"  v_readfirstlane_b32 %[t2], v59\n"
-							"  s_lshr_b32 %[t2], %[t2], 16\n"                     // nn = next.next
-							"  s_branch Lrightd_%=\n"
-							"Lrightc_%=:\n"
-							"  s_mov_b32 %[t1], %[ncv1]\n"
-							"  s_mov_b32 %[t2], %[ncnext]\n"
-							"Lrightd_%=:\n"
-							"  v_mov_b32 v53, 0x8000\n"
-							"  ds_write_b16 v52, v53 offset:10\n"                 // next.deleted = true
-							"  s_lshl_b32 %[t0], %[start], 2\n"
-							"  v_mov_b32 v44, %[v1]\n"
-							"  v_mov_b32 v45, %[v0]\n"
-							"  v_mov_b32 v46, %[t1]\n"
-							"  v_mov_b32 v47, %[t0]\n"
-							"  global_store_dwordx3 v47, v[44:46], %[faceb]\n"
-							"  s_add_u32 %[start], %[start], 3\n"
-							"  s_mov_b32 %[nc], -1\n"
-							"  s_mov_b32 %[v2], %[v1]\n"
-							"  s_mov_b32 %[v1], %[t1]\n"
-							"  s_mov_b32 %[en], %[t2]\n"
-							// ---------------- the symbol is consumed; every eighth one pulls the next word of the window
-							"Lconsumed_%=:\n"
-							"  s_lshr_b32 %[sw], %[sw], 4\n"
-							"  s_add_u32 %[cler], %[cler], 1\n"
-							"  s_and_b32 %[t0], %[cler], 7\n"
-							"  s_cbranch_scc1 Lnext_%=\n"
-							"  s_mov_b32 %[sw], %[swn]\n"
-							"  s_lshr_b32 %[t0], %[cler], 3\n"
-							"  s_add_u32 %[t0], %[t0], %[wbias]\n"
-							"  s_lshl_b32 %[t0], %[t0], 2\n"
-							"  s_add_u32 %[t0], %[t0], %[clbase]\n"
-							"  v_mov_b32 v55, %[t0]\n"
-							"  ds_read_b32 v55, v55\n"
-							"  s_waitcnt lgkmcnt(0)\n"
-							"  v_readfirstlane_b32 %[swn], v55\n"
-							"Lnext_%=:\n"
-							"  s_cmp_lt_u32 %[start], %[end]\n"
-							"  s_cbranch_scc1 Ltop_%=\n"
-							"Lexit_%=:\n"
-							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start),
-							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en),
-							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1),
-							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [budget] "+s"(budget_)
-							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias),
-							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb)
-							: "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32); }
 						if(start >= end) break;
 					}
 					uint32_t c; TOPO_SYMBOL(c);
