@@ -33,12 +33,12 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	const uint32_t n = st.nsym;                 // 2..255 (host guarantees)
 	const uint32_t lane = threadIdx.x;
 
-	__shared__ uint32_t eprob[TUN_ENTRY_CAP];   // entry e (creation order) lives in FIFO row e % n
+	__shared__ uint16_t eprob[TUN_ENTRY_CAP];   // entry e (creation order) lives in FIFO row e % n; probabilities are 16-bit ((a*b) >> 16 of 16-bit factors)
 	__shared__ uint16_t eoff[TUN_ENTRY_CAP];
 	__shared__ uint16_t elen[TUN_ENTRY_CAP];
 	__shared__ uint16_t head[256];              // oldest not-yet-expanded entry of each row
-	__shared__ uint32_t P[256];                 // probability << 8  (16.16-ish fixed point)
-	__shared__ uint32_t pw[256];                // P0^k (successive (a*b)>>16), low-entropy seed only
+	__shared__ uint16_t P[256];                 // probability << 8  (16.16-ish fixed point)
+	__shared__ uint16_t pw[256];                // P0^k (successive (a*b)>>16), low-entropy seed only
 	__shared__ uint8_t sym[256];
 	__shared__ __attribute__((aligned(16))) uint8_t buf[TUN_TABLE_BYTES];
 
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 		for(uint32_t e = lane; e < count*n; e += 64) {
 			const uint32_t col = e/n, row = e - col*n;
 			if(row == 0) continue;
-			eprob[e] = col == 0 ? P[row] : (pw[col]*P[row]) >> 16;
+			eprob[e] = (uint16_t)(col == 0 ? (uint32_t)P[row] : ((uint32_t)pw[col]*(uint32_t)P[row]) >> 16);
 			eoff[e] = (uint16_t)(row*count - col);
 			elen[e] = (uint16_t)(col + 1);
 		}
@@ -109,6 +109,15 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 			const uint32_t tot = m*(pl + 1);
 			if(end + m > TUN_ENTRY_CAP || pos + tot > TUN_TABLE_BYTES) break;
 			// child r = parent bytes + sym[r]; lanes hold the parent's bytes, one write per child
+			if(pl < m && pl <= 64) {
+				// short parent (the usual case): lane j holds parent byte j; one pass per byte position, lanes = children
+				const uint32_t pb = lane < pl ? (uint32_t)buf[po + lane] : 0u;
+				const uint32_t cbase = pos + lane*(pl + 1);
+				for(uint32_t j = 0; j < pl; j++) {
+					const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)pb, (int)j);
+					if(lane < m) buf[cbase + j] = (uint8_t)b;
+				}
+			} else
 			for(uint32_t j0 = 0; j0 < pl; j0 += 64) {
 				const uint32_t j = j0 + lane;
 				const uint8_t pb = j < pl ? buf[po + j] : (uint8_t)0;
