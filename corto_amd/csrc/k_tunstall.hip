@@ -176,9 +176,12 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 
 	// survivors in creation order -> codes 0..255 (tunstall.cpp:243-253)
 	uint32_t w = 0, used = 0, maxlen = 0;
+	uint32_t row = lane % n;                                              // e % n, carried along (an integer division per entry otherwise)
+	const uint32_t rstep = 64u % n;
 	for(uint32_t base = 0; base < end; base += 64) {
 		const uint32_t e = base + lane;
-		const bool alive = e < end && !(head[e % n] > e);
+		const bool alive = e < end && !(head[row] > e);
+		row += rstep; row -= row >= n ? n : 0u;
 		const uint64_t mask = __ballot(alive);
 		const uint32_t rank = w + __popcll(mask & ((1ull << lane) - 1ull));
 		if(alive && rank < 256) {
