@@ -265,14 +265,24 @@ class Batch:
 
     def __init__(self, ctx: Context, blobs: Sequence[np.ndarray], device_arena=None):
         self.ctx = ctx
+        self.handle = C.c_void_p()
+        self._plan(blobs, device_arena, create=True)
+
+    def reset(self, blobs: Sequence[np.ndarray], device_arena=None):
+        """crthip_batch_reset: re-plan this object for another list of blobs (bindings and outputs are dropped)."""
+        self._plan(blobs, device_arena, create=False)
+
+    def _plan(self, blobs, device_arena, create):
         self.blobs = list(blobs)
         n = len(self.blobs)
         self._ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in self.blobs])
         self._lens = np.array([len(b) for b in self.blobs], dtype=np.uint32)
-        self.handle = C.c_void_p()
         self._arena = device_arena
         arena_ptr = C.c_void_p(device_arena.data_ptr()) if device_arena is not None else None
-        _check(lib().crthip_batch_create(ctx.handle, n, self._ptrs, _np_ptr(self._lens), arena_ptr, C.byref(self.handle)))
+        if create:
+            _check(lib().crthip_batch_create(self.ctx.handle, n, self._ptrs, _np_ptr(self._lens), arena_ptr, C.byref(self.handle)))
+        else:
+            _check(lib().crthip_batch_reset(self.handle, n, self._ptrs, _np_ptr(self._lens), arena_ptr))
         self.infos = []
         for i in range(n):
             info = BlobInfo()

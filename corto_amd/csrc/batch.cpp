@@ -147,6 +147,59 @@ struct KernelTimer {
 	void release() { for(auto e : pool) (void)hipEventDestroy(e); pool.clear(); reset(); }
 };
 
+namespace {
+template <typename T> struct HostArr {  // host image of a device array + where it goes
+	std::vector<T> v; uint64_t dev_off = 0;
+};
+
+struct AttrScratch {
+	uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull; std::vector<uint64_t> sym;
+	void reset() { color = diffs = fired = ~0ull; sym.clear(); }
+};
+struct BlobScratch {
+	uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
+	uint32_t front_cap = 0, aux_groups = 0;
+	std::vector<AttrScratch> attr;
+	size_t nattr = 0;                                       // attr[0..nattr) are this decode's (the vector only grows)
+	void reset() { clers = pred = front_a = front_b = order = delayed = faces = ~0ull; front_cap = 0; aux_groups = 0; nattr = 0; }
+	void set_attrs(size_t n) { if(attr.size() < n) attr.resize(n); for(size_t k = nattr; k < n; k++) attr[k].reset(); if(n > nattr) nattr = n; }
+};
+
+struct Plan {
+	// job arrays
+	HostArr<TunStream> tun; HostArr<uint32_t> tun_chunk_stream;
+	HostArr<FillJob> fill;
+	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
+	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
+	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
+	HostArr<DeltaJob> delta;
+	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
+	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first, normal_fused_ids;
+	uint32_t normal_fused_lds = 0;
+	HostArr<DequantJob> dequant; HostArr<uint32_t> dequant_block_job;
+	// scratch regions (offsets)
+	uint64_t zero_begin = 0, zero_end = 0;
+	uint64_t status_off = 0, tables_off = 0, tun_partial_off = 0, unpack_partial_off = 0, cloud_partial_off = 0;
+	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
+	uint64_t jobs_begin = 0, jobs_bytes = 0;
+	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
+	uint32_t delta_lds = 0;
+	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
+	uint64_t total = 0;
+	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
+	void reset() {                                          // keep every vector's capacity
+		clr(tun); clr(tun_chunk_stream); clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
+		clr(unpack); clr(unpack_chunk_job); clr(delta); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
+		clr(nf_block_job); clr(nf_block_first); clr(normal_fused_ids); clr(dequant); clr(dequant_block_job);
+		topo_lds = topo_big_lds = normal_fused_lds = 0;
+		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
+		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
+		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_lds = 0;
+		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0;
+	}
+};
+} // namespace
+
 struct crthip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -158,6 +211,10 @@ struct crthip_ctx {
 	bool profiling = false;
 	KernelTimer timer;
 	crthip_batch *in_flight = nullptr;
+	// planner state reused from one decode call to the next (batch.cpp: build_and_launch)
+	Plan plan;
+	std::vector<BlobScratch> plan_scratch;
+	std::vector<const uint8_t *> plan_clers, plan_logs;
 };
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4; };
@@ -236,42 +293,63 @@ extern "C" int crthip_ctx_sync(crthip_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-extern "C" int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens,
-                                   const void *device_arena, crthip_batch **out) {
-	if(!ctx || !out || (nblobs && (!blobs || !lens))) return fail(CRTHIP_E_ARGUMENT);
+// (re)fill a batch object from a list of blobs: header parse + bounds-checked walk of each, arena layout, upload unless resident
+static int batch_fill(crthip_ctx *ctx, crthip_batch *b, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens, const void *device_arena) {
 	const double t_create = now_us();
-	HIP_TRY(hipSetDevice(ctx->device));
-	crthip_batch *b = new crthip_batch();
 	b->ctx = ctx;
 	b->blobs.resize(nblobs);
+	b->stats = crthip_batch_stats{};
+	b->dirty = true; b->decoded = false;
 	uint64_t off = 0;
 	for(uint32_t i = 0; i < nblobs; i++) {
 		BlobPlan &P = b->blobs[i];
+		reset_layout(P.L);
 		int err = walk_blob(blobs[i], lens[i], P.L);
-		if(err) { delete b; return fail(err, std::string(crthip_strerror(err)) + " (blob " + std::to_string(i) + ")"); }
+		if(err) return fail(err, std::string(crthip_strerror(err)) + " (blob " + std::to_string(i) + ")");
 		P.arena_off = off; P.len = lens[i];
-		P.bind.resize(P.L.h.attrs.size());
+		P.bind.assign(P.L.h.attrs.size(), Binding{});
+		P.index = nullptr; P.index_u16 = 0; P.host_status = 0;
+		P.dbg_clers = P.dbg_pred = ~0ull; P.dbg_nclers = 0; P.clers_in_arena = false;
 		off += ((uint64_t)lens[i] + 15) & ~15ull;
 		b->stats.total_nvert += P.L.h.nvert; b->stats.total_nface += P.L.h.nface;
 		if(P.L.h.nface) { b->stats.clers_symbols += P.L.clers.size; b->stats.split_bytes += (uint64_t)P.L.split.nwords*4; }
 	}
 	b->arena_bytes = off;
 	b->stats.arena_bytes = off;
+	b->d_arena = nullptr;
 	if(device_arena) b->d_arena = (const uint8_t *)device_arena;
 	else if(off) {
-		if(b->own_arena.reserve(off) != CRTHIP_OK) { delete b; return fail(CRTHIP_E_NOMEM); }
+		if(b->own_arena.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 		if(ctx->in_flight) { (void)hipStreamSynchronize(ctx->stream); ctx->in_flight = nullptr; }
-		if(ctx->staging.reserve(off) != CRTHIP_OK) { delete b; return fail(CRTHIP_E_NOMEM); }
+		if(ctx->staging.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 		uint8_t *h = (uint8_t *)ctx->staging.p;
 		for(uint32_t i = 0; i < nblobs; i++) memcpy(h + b->blobs[i].arena_off, blobs[i], lens[i]);
 		if(hipMemcpyAsync(b->own_arena.p, h, off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-		   hipStreamSynchronize(ctx->stream) != hipSuccess) { delete b; return fail(CRTHIP_E_DEVICE); }
+		   hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
 		b->d_arena = (const uint8_t *)b->own_arena.p;
 	}
 	b->status.assign(nblobs, 0);
 	b->stats.host_create_us = (float)(now_us() - t_create);
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens,
+                                   const void *device_arena, crthip_batch **out) {
+	if(!ctx || !out || (nblobs && (!blobs || !lens))) return fail(CRTHIP_E_ARGUMENT);
+	HIP_TRY(hipSetDevice(ctx->device));
+	crthip_batch *b = new crthip_batch();
+	const int err = batch_fill(ctx, b, nblobs, blobs, lens, device_arena);
+	if(err) { b->own_arena.release(); delete b; return err; }
 	*out = b;
 	return CRTHIP_OK;
+}
+
+extern "C" int crthip_batch_reset(crthip_batch *b, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens, const void *device_arena) {
+	if(!b || !b->ctx || (nblobs && (!blobs || !lens))) return fail(CRTHIP_E_ARGUMENT);
+	crthip_ctx *ctx = b->ctx;
+	HIP_TRY(hipSetDevice(ctx->device));
+	if(ctx->in_flight == b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
+	return batch_fill(ctx, b, nblobs, blobs, lens, device_arena);       // on failure the batch is left empty-handed: reset or destroy it
 }
 
 extern "C" void crthip_batch_destroy(crthip_batch *b) {
@@ -343,37 +421,12 @@ struct Carver {                         // bump allocator over the scratch block
 	uint64_t take(uint64_t bytes, uint64_t align = 256) { off = (off + align - 1) & ~(align - 1); uint64_t r = off; off += bytes; return r; }
 };
 
-template <typename T> struct HostArr {  // host image of a device array + where it goes
-	std::vector<T> v; uint64_t dev_off = 0;
-};
 
 static int32_t f2i_x86_host(float x) {
 	if(!(x > -2147483904.0f && x < 2147483648.0f)) return (int32_t)0x80000000;
 	return (int32_t)x;
 }
 
-struct Plan {
-	// job arrays
-	HostArr<TunStream> tun; HostArr<uint32_t> tun_chunk_stream;
-	HostArr<FillJob> fill;
-	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
-	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
-	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
-	HostArr<DeltaJob> delta;
-	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
-	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first, normal_fused_ids;
-	uint32_t normal_fused_lds = 0;
-	HostArr<DequantJob> dequant; HostArr<uint32_t> dequant_block_job;
-	// scratch regions (offsets)
-	uint64_t zero_begin = 0, zero_end = 0;
-	uint64_t status_off = 0, tables_off = 0, tun_partial_off = 0, unpack_partial_off = 0, cloud_partial_off = 0;
-	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
-	uint64_t jobs_begin = 0, jobs_bytes = 0;
-	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
-	uint32_t delta_lds = 0;
-	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
-	uint64_t total = 0;
-};
 
 } // namespace
 
@@ -402,20 +455,19 @@ struct Launch {
 static int build_and_launch(crthip_batch *b) {
 	crthip_ctx *ctx = b->ctx;
 	const double t0 = now_us(); double t1 = 0, t2 = 0, t3 = 0;        // host-side cost of a decode call (crthip_batch_stats::host_*_us)
-	Plan pl;
+	Plan &pl = ctx->plan;
+	pl.reset();
 	Carver cv;
 	const uint32_t nblobs = (uint32_t)b->blobs.size();
 	const uint8_t *arena = b->d_arena;
 
 	// ---- pass 1: sizes & offsets (device addresses are scratch_base + offset, resolved in pass 2) ----
 	// We first carve all scratch, then reserve the block, then fill job structs with real pointers.
-	struct AttrScratch { uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull; std::vector<uint64_t> sym; };
-	struct BlobScratch {
-		uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
-		uint32_t front_cap = 0, aux_groups = 0;
-		std::vector<AttrScratch> attr;
-	};
-	std::vector<BlobScratch> bs(nblobs);
+	// per-blob scratch offsets live in the context and are reset, not reallocated: a decode call used to spend a third of its host
+	// time in malloc/free of these small vectors
+	std::vector<BlobScratch> &bs = ctx->plan_scratch;
+	if(bs.size() < nblobs) bs.resize(nblobs);
+	for(uint32_t i = 0; i < nblobs; i++) bs[i].reset();
 
 	// zeroed region: status, predictions (vertices the automaton never reaches keep (0,0,0)), and the
 	// counters of the ESTIMATED/BORDER normal pipeline
@@ -440,7 +492,7 @@ static int build_and_launch(crthip_batch *b) {
 	for(uint32_t i = 0; i < nblobs; i++) {                           // "fired" flags of delta jobs too large for LDS
 		const BlobPlan &P = b->blobs[i];
 		const BlobLayout &L = P.L;
-		bs[i].attr.resize(L.attrs.size());
+		bs[i].set_attrs(L.attrs.size());
 		if(L.h.nface == 0) continue;
 		for(size_t k = 0; k < L.attrs.size(); k++) {
 			if(!P.bind[k].buffer) continue;
@@ -463,7 +515,7 @@ static int build_and_launch(crthip_batch *b) {
 		const BlobLayout &L = P.L;
 		BlobScratch &S = bs[i];
 		P.host_status = 0;
-		S.attr.resize(L.attrs.size());
+		S.set_attrs(L.attrs.size());
 		const bool mesh = L.h.nface > 0;
 		if(mesh) {
 			need_stream(L.clers, S.clers);
@@ -520,7 +572,8 @@ static int build_and_launch(crthip_batch *b) {
 
 	// the CLERS streams come first in every stream/chunk/fill array: they are what the topology kernel waits for, the
 	// attribute streams are decoded on the second HIP stream while topology runs
-	std::vector<const uint8_t *> clers_ptrs(nblobs, nullptr);
+	std::vector<const uint8_t *> &clers_ptrs = ctx->plan_clers;
+	clers_ptrs.assign(nblobs, nullptr);
 	for(uint32_t i = 0; i < nblobs; i++) {
 		const BlobLayout &L = b->blobs[i].L;
 		if(L.h.nface > 0) clers_ptrs[i] = add_stream(L.clers, bs[i].clers, b->blobs[i].arena_off);
@@ -592,7 +645,8 @@ static int build_and_launch(crthip_batch *b) {
 				unpack_chunks += nc;
 				pl.unpack.v.push_back(u);
 			};
-			std::vector<const uint8_t *> logs(as.logs.size());
+			std::vector<const uint8_t *> &logs = ctx->plan_logs;
+			logs.assign(as.logs.size(), nullptr);
 			for(size_t j = 0; j < as.logs.size(); j++) logs[j] = add_stream(as.logs[j], A.sym[j], bo);
 
 			void *values = nullptr; bool values_real = false; uint8_t is_u8 = 0; uint32_t N = a.N; bool para = false; bool do_delta = true;

@@ -108,6 +108,16 @@ int parse_header(const uint8_t *p, size_t len, BlobHeader &h) {
 	return header(c, h);
 }
 
+void reset_layout(BlobLayout &L) {
+	L.h.version = L.h.entropy = L.h.nvert = L.h.nface = L.h.body_offset = 0;
+	L.h.exif.clear(); L.h.attrs.clear();
+	L.group_end.clear();
+	for(auto &g : L.group_props) g.clear();
+	L.max_front = 0; L.clers = StreamRef(); L.split = BitsRef();
+	for(auto &a : L.attrs) { a.bits = BitsRef(); a.logs.clear(); a.normal_prediction = 0; a.qc[0] = 4; a.qc[1] = 4; a.qc[2] = 4; a.qc[3] = 8; }
+	L.end_offset = 0;
+}
+
 int walk_blob(const uint8_t *p, size_t len, BlobLayout &L) {
 	Cursor c{p, len};
 	int err = header(c, L.h);

@@ -69,6 +69,7 @@ struct BlobLayout {
 
 // error codes are the CRTHIP_E_* values of include/corto_hip.h
 int parse_header(const uint8_t *p, size_t len, BlobHeader &h);
-int walk_blob(const uint8_t *p, size_t len, BlobLayout &L);
+int walk_blob(const uint8_t *p, size_t len, BlobLayout &L);      // L must be fresh, or reset_layout()
+void reset_layout(BlobLayout &L);                                 // back to the default state, keeping every vector's capacity
 
 } // namespace corto_hip

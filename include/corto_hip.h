@@ -118,6 +118,9 @@ int crthip_device_count(void);
  *                        blob starting at the next 16-byte multiple (offsets via crthip_arena_layout). */
 int crthip_batch_create(crthip_ctx *ctx, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens,
                         const void *device_arena, crthip_batch **out);
+/* Re-plan an existing batch object for a new list of blobs (same meaning as destroy + create, bindings are cleared) reusing
+ * its allocations: what a serving loop that decodes batch after batch on one context calls instead of create / destroy. */
+int crthip_batch_reset(crthip_batch *b, uint32_t nblobs, const uint8_t *const *blobs, const uint32_t *lens, const void *device_arena);
 /* offsets[i] = arena byte offset of blob i under the rule above; returns total arena bytes */
 uint64_t crthip_arena_layout(uint32_t nblobs, const uint32_t *lens, uint64_t *offsets);
 void crthip_batch_destroy(crthip_batch *b);

@@ -457,6 +457,28 @@ def test_large_and_small_meshes_in_one_batch(ctx):
     assert b.stats().topology_fallbacks == 0
 
 
+def test_batch_reset_reuses_the_object_for_other_blobs(ctx):
+    """crthip_batch_reset = destroy + create on the same object (a serving loop's per-batch call): different blobs, different
+    count, attributes in a different order of presence, a point cloud after meshes - nothing of the previous plan may leak"""
+    sets = [["c4_unit", "torus", "two_groups"], ["cloud_border", "radius_attr"], ["entropy_none"], ["holey_disc", "c4_unit", "closed_sphere", "multi_component"]]
+    b = None
+    for names in sets + sets[:1]:
+        gs = [load_golden(nm) for nm in names]
+        blobs = [aligned(g["crt"]) for g in gs]
+        if b is None:
+            b = ca.Batch(ctx, blobs)
+        else:
+            b.reset(blobs)
+        b.allocate_outputs(fill=0, color_components=4)
+        b.decode()
+        st = b.sync()
+        assert (st == 0).all()
+        for i, g in enumerate(gs):
+            got = b.host_outputs(i)
+            exp = oc.decode(g["crt"], color_components=4)
+            assert_same(got, exp, KEYS, "%s after reset" % names[i])
+
+
 def test_config4_256_distinct_blobs(ctx):
     """256 distinct 4K-tri blobs in one batch: every blob equals the oracle; decoded positions equal the quantised inputs"""
     from corto_amd import synth
