@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorto_hip.so")
 VENEER = os.path.join(LIBDIR, "libcortocodec_hip.so")
+EMVENEER = os.path.join(LIBDIR, "libcorto_em_hip.so")    # upstream's wasm/JS C ABI (include/corto/emcorto.h) over the facade
 CLI = os.path.join(LIBDIR, "corto_hip")                   # the `corto` command line tool on this repo's encoder + GPU decoder (tools/corto_hip_cli.cpp)   # legacy Unity C ABI (include/corto/corto_codec.h) over the facade
 SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_normal.hip", "batch.cpp", "crt_format.cpp", "decoder_facade.cpp", "encoder.cpp"]
 HEADERS = ["kernels_common.h", "kernels.h", "device_plan.h", "crt_format.h",
@@ -64,6 +65,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     inc = os.path.join(HERE, "..", "include")
     if force or _stale(VENEER, [vsrc, LIB, os.path.join(inc, "corto", "corto_codec.h"), os.path.join(inc, "corto", "decoder.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", inc, vsrc, "-o", VENEER,
+               "-L", LIBDIR, "-lcorto_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    esrc = os.path.join(CSRC, "em_veneer.cpp")
+    if force or _stale(EMVENEER, [esrc, LIB, os.path.join(inc, "corto", "emcorto.h"), os.path.join(inc, "corto", "decoder.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", inc, esrc, "-o", EMVENEER,
                "-L", LIBDIR, "-lcorto_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -114,3 +114,57 @@ def test_unity_veneer_exports_and_parses_on_the_host(L):
         V.DestroyDecoder(d)
     junk = aligned(np.zeros(64, dtype=np.uint8))
     assert not V.CreateDecoder(len(junk), junk.ctypes.data, None)      # "Not a crt file." does not cross the C boundary
+
+
+EM_SYMBOLS = ("newDecoder ngroups groups nvert nface hasAttr hasNormal hasColor hasUv setPositions setNormals32 setNormals16 "
+              "setColors setUvs setIndex16 setIndex32 decode deleteDecoder").split()
+
+
+def em_veneer():
+    from corto_amd import build
+    if not os.path.exists(build.EMVENEER):
+        build.build()
+    E = C.CDLL(build.EMVENEER)
+    E.newDecoder.restype = C.c_void_p
+    E.newDecoder.argtypes = [C.c_int, C.c_void_p]
+    for nm in ("ngroups", "nvert", "nface"):
+        getattr(E, nm).restype = C.c_int
+        getattr(E, nm).argtypes = [C.c_void_p]
+    for nm in ("hasNormal", "hasColor", "hasUv"):
+        getattr(E, nm).restype = C.c_bool
+        getattr(E, nm).argtypes = [C.c_void_p]
+    E.hasAttr.restype = C.c_bool
+    E.hasAttr.argtypes = [C.c_void_p, C.c_char_p]
+    for nm in ("groups", "setPositions", "setNormals32", "setNormals16", "setUvs", "setIndex16", "setIndex32"):
+        getattr(E, nm).restype = None
+        getattr(E, nm).argtypes = [C.c_void_p, C.c_void_p]
+    E.setColors.restype = None
+    E.setColors.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    for nm in ("decode", "deleteDecoder"):
+        getattr(E, nm).restype = None
+        getattr(E, nm).argtypes = [C.c_void_p]
+    return E
+
+
+def test_js_veneer_exports_and_parses_on_the_host(L):
+    """the flat C ABI of upstream's wasm module (html/js/emscripten/emcorto.cpp:14-89): all eighteen symbols of
+    include/corto/emcorto.h; the header queries (nvert, nface, groups, has*) are host-side and need no GPU"""
+    hdr = open(os.path.join(ROOT, "include", "corto", "emcorto.h")).read()
+    E = em_veneer()
+    for nm in EM_SYMBOLS:
+        assert re.search(r"\b%s\(" % nm, hdr), nm
+        assert hasattr(E, nm), nm
+    for name in ("two_groups", "cloud_border", "nrm_estimated_rgb"):
+        g = load_golden(name)
+        blob = aligned(g["crt"])
+        d = E.newDecoder(len(blob), blob.ctypes.data)
+        assert d, name
+        assert E.nvert(d) == len(g["position"]) and E.nface(d) == (len(g["index"]) if "index" in g else 0)
+        assert E.hasNormal(d) == ("normal" in g) and E.hasColor(d) == ("color" in g) and E.hasUv(d) == ("uv" in g)
+        assert E.hasAttr(d, b"position") and not E.hasAttr(d, b"nope")
+        assert E.ngroups(d) == 0              # like upstream, groups are read by decode() (src/decoder.cpp:137,165)
+        E.deleteDecoder(d)
+    junk = aligned(np.zeros(64, dtype=np.uint8))
+    assert not E.newDecoder(len(junk), junk.ctypes.data)
+    assert E.nvert(None) == 0 and E.ngroups(None) == 0 and not E.hasUv(None)
+    E.decode(None); E.deleteDecoder(None)

@@ -457,6 +457,40 @@ def test_large_and_small_meshes_in_one_batch(ctx):
     assert b.stats().topology_fallbacks == 0
 
 
+def test_js_veneer_decode(ctx):
+    """newDecoder / set* / decode / deleteDecoder (include/corto/emcorto.h = upstream html/js/emscripten/emcorto.cpp:14-89)
+    driven the way corto.em.js does: sizes from nvert/nface, u16 index when nvert < 65536, int16 normals on request"""
+    from test_abi_cpu import em_veneer
+    E = em_veneer()
+    for name, n16, i16 in (("c4_unit", False, True), ("two_groups", True, False), ("cloud_diff", False, False), ("nrm_estimated_rgb", True, True)):
+        g = load_golden(name)
+        blob = aligned(g["crt"])
+        d = E.newDecoder(len(blob), blob.ctypes.data)
+        assert d
+        nv, nf = E.nvert(d), E.nface(d)
+        pos = np.zeros((nv, 3), np.float32); uv = np.zeros((nv, 2), np.float32); col = np.zeros((nv, 4), np.uint8)
+        nrm = np.zeros((nv, 3), np.int16 if n16 else np.float32)
+        idx = np.zeros((nf, 3), np.uint16 if i16 else np.uint32)
+        E.setPositions(d, pos.ctypes.data)
+        if E.hasNormal(d): (E.setNormals16 if n16 else E.setNormals32)(d, nrm.ctypes.data)
+        if E.hasColor(d): E.setColors(d, col.ctypes.data, 4)
+        if E.hasUv(d): E.setUvs(d, uv.ctypes.data)
+        if nf: (E.setIndex16 if i16 else E.setIndex32)(d, idx.ctypes.data)
+        E.decode(d)
+        ng = E.ngroups(d)
+        ends = np.zeros(max(ng, 1), dtype=np.int32)
+        E.groups(d, ends.ctypes.data)
+        assert ng == (2 if name == "two_groups" else 1 if nf else 0), (name, ng)
+        if ng: assert ends[ng - 1] == nf and (np.diff(ends[:ng]) > 0).all()
+        E.deleteDecoder(d)
+        exp = oc.decode(g["crt"], color_components=4, normal_format=ca.FMT_INT16 if n16 else ca.FMT_FLOAT, index16=i16)
+        assert pos.tobytes() == exp["position"].tobytes(), name
+        if nf: assert idx.tobytes() == exp["index"].tobytes(), name
+        if "normal" in exp: assert nrm.tobytes() == exp["normal"].tobytes(), name
+        if "uv" in exp: assert uv.tobytes() == exp["uv"].tobytes(), name
+        if "color" in exp: assert col.tobytes() == exp["color"].tobytes(), name
+
+
 def test_batch_reset_reuses_the_object_for_other_blobs(ctx):
     """crthip_batch_reset = destroy + create on the same object (a serving loop's per-batch call): different blobs, different
     count, attributes in a different order of presence, a point cloud after meshes - nothing of the previous plan may leak"""
