@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 			if(row == 0) continue;
 			eprob[e] = (uint16_t)(col == 0 ? (uint32_t)P[row] : ((uint32_t)pw[col]*(uint32_t)P[row]) >> 16);
 			eoff[e] = (uint16_t)(row*count - col);
-			elen[e] = (uint16_t)(col + 1);
+			elen[e] = (uint16_t)((col + 1) | (row << 8));     // high byte: row = last symbol (used by the n <= 64 path)
 		}
 		for(uint32_t k = lane; k < n; k += 64) head[k] = (uint16_t)(k == 0 ? (count - 1)*n : k);
 		__syncthreads();
@@ -82,57 +82,43 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 		pos = total;
 	} else {                                    // one-symbol words (tunstall.cpp:195-205)
 		for(uint32_t i = lane; i < n; i += 64) {
-			head[i] = (uint16_t)i; eprob[i] = P[i]; eoff[i] = (uint16_t)i; elen[i] = 1; buf[i] = sym[i];
+			head[i] = (uint16_t)i; eprob[i] = P[i]; eoff[i] = (uint16_t)i; elen[i] = (uint16_t)(1u | (i << 8)); buf[i] = sym[i];
 		}
 		nwords = n; end = n; pos = n;
 	}
 	__syncthreads();
 
-	if(n <= 64) {
-		// Fast path (n <= 64 symbols, i.e. every stream the encoder really produces): lane r keeps row r's FIFO head
-		// (index, probability, offset, length) in registers, so picking the likeliest head is a register-only wave
-		// reduction and an expansion touches LDS only to append the children.             tunstall.cpp:207-241
-		uint32_t h = lane < n ? head[lane] : 0xFFFFu, hp = 0, ho = 0, hl = 0;
-		if(lane < n && h < TUN_ENTRY_CAP) { hp = eprob[h]; ho = eoff[h]; hl = elen[h]; }
-		const uint32_t mysym = lane < n ? sym[lane] : 0u, myP = lane < n ? P[lane] : 0u;
+	const bool tree = n <= 64;
+	const uint32_t seed_end = end, seed_bytes = pos;
+	if(tree) {
+		// Fast path (n <= 64 symbols, i.e. every stream the encoder really produces).  Lane r keeps row r's FIFO head (index,
+		// probability, length) in registers, so picking the likeliest head is a register-only wave reduction.  A child is
+		// recorded as (parent entry, row) - no bytes are copied while the dictionary grows; the 256 surviving words are
+		// spelled out once at the end by walking up to the seed.  For the entries made here eoff[] holds the PARENT ENTRY and
+		// the high byte of elen[] the row (= index of the last symbol).                                  tunstall.cpp:207-241
+		uint32_t h = lane < n ? head[lane] : 0xFFFFu, hp = 0, hl = 0;
+		if(lane < n && h < TUN_ENTRY_CAP) { hp = eprob[h]; hl = elen[h] & 255u; }
+		const uint32_t myP = lane < n ? P[lane] : 0u;
 		while(nwords < 256) {
 			// likeliest head, first row wins ties, all-zero -> row 0: one DPP wave reduction + readlane broadcasts
-			// (ds_bpermute-based shuffles cost ~60 cycles each and there would be ten of them per expansion)
 			const uint32_t key = wave_max_u32(hp ? ((hp << 16) | (0xFFFFu - lane)) : 0u);
 			const uint32_t best = (key >> 16) ? 0xFFFFu - (key & 0xFFFFu) : 0u;
 			const uint32_t parent = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)best);
 			if(parent >= TUN_ENTRY_CAP) break;                                    // malformed probabilities
-			const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)hp, (int)best), po = (uint32_t)__builtin_amdgcn_readlane((int)ho, (int)best),
-			               pl = (uint32_t)__builtin_amdgcn_readlane((int)hl, (int)best);
+			const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)hp, (int)best), pl = (uint32_t)__builtin_amdgcn_readlane((int)hl, (int)best);
 			const bool full = nwords + n > 255;                                   // dictionary fills up during this expansion: parent stays
 			const uint32_t m = full ? 256 - nwords : n;
 			const uint32_t tot = m*(pl + 1);
-			if(end + m > TUN_ENTRY_CAP || pos + tot > TUN_TABLE_BYTES) break;
-			// child r = parent bytes + sym[r]; lanes hold the parent's bytes, one write per child
-			if(pl < m && pl <= 64) {
-				// short parent (the usual case): lane j holds parent byte j; one pass per byte position, lanes = children
-				const uint32_t pb = lane < pl ? (uint32_t)buf[po + lane] : 0u;
-				const uint32_t cbase = pos + lane*(pl + 1);
-				for(uint32_t j = 0; j < pl; j++) {
-					const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)pb, (int)j);
-					if(lane < m) buf[cbase + j] = (uint8_t)b;
-				}
-			} else
-			for(uint32_t j0 = 0; j0 < pl; j0 += 64) {
-				const uint32_t j = j0 + lane;
-				const uint8_t pb = j < pl ? buf[po + j] : (uint8_t)0;
-				for(uint32_t r = 0; r < m; r++) if(j < pl) buf[pos + r*(pl + 1) + j] = pb;
-			}
+			if(end + m > TUN_ENTRY_CAP || pos + tot > TUN_TABLE_BYTES) break;     // where the reference's buffers would overflow
 			if(lane < m) {
-				const uint32_t e = end + lane, cp = (pp*myP) >> 16, co = pos + lane*(pl + 1);
-				buf[co + pl] = (uint8_t)mysym;
-				eprob[e] = cp; eoff[e] = (uint16_t)co; elen[e] = (uint16_t)(pl + 1);
-				if(h == e) { hp = cp; ho = co; hl = pl + 1; }                  // the row's FIFO was empty: the child is its new head
+				const uint32_t e = end + lane, cp = (pp*myP) >> 16;
+				eprob[e] = (uint16_t)cp; eoff[e] = (uint16_t)parent; elen[e] = (uint16_t)((pl + 1) | (lane << 8));
+				if(h == e) { hp = cp; hl = pl + 1; }                              // the row's FIFO was empty: the child is its new head
 			}
-			__syncthreads();
+			asm volatile("" ::: "memory");                                        // one wave: LDS executes in program order
 			if(!full && lane == best) {                                            // parent fully expanded: pop it
 				h = parent + n;
-				if(h < end + m && h < TUN_ENTRY_CAP) { hp = eprob[h]; ho = eoff[h]; hl = elen[h]; } else { hp = 0; ho = 0; hl = 0; }
+				if(h < end + m && h < TUN_ENTRY_CAP) { hp = eprob[h]; hl = elen[h] & 255u; } else { hp = 0; hl = 0; }
 			}
 			end += m; pos += tot; nwords += n - 1;
 		}
@@ -174,27 +160,43 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 		__syncthreads();
 	}
 
-	// survivors in creation order -> codes 0..255 (tunstall.cpp:243-253)
-	uint32_t w = 0, used = 0, maxlen = 0;
+	// survivors in creation order -> codes 0..255 (tunstall.cpp:243-253).  Seed words keep their place in the seed bytes
+	// (they share suffixes); on the n <= 64 path every surviving word made by an expansion is spelled out behind them:
+	// its last symbols come from the rows on the way up to the seed entry, the rest is the seed word A^(k-1) sym[row].
+	uint32_t w = 0, used = tree ? seed_bytes : 0u, maxlen = 0, wpos = seed_bytes;
 	uint32_t row = lane % n;                                              // e % n, carried along (an integer division per entry otherwise)
 	const uint32_t rstep = 64u % n;
+	const uint8_t A = sym[0];
 	for(uint32_t base = 0; base < end; base += 64) {
 		const uint32_t e = base + lane;
 		const bool alive = e < end && !(head[row] > e);
 		row += rstep; row -= row >= n ? n : 0u;
 		const uint64_t mask = __ballot(alive);
 		const uint32_t rank = w + __popcll(mask & ((1ull << lane) - 1ull));
-		if(alive && rank < 256) {
-			T.off[rank] = eoff[e]; T.len[rank] = (uint8_t)elen[e];
-			const uint32_t u = (uint32_t)eoff[e] + elen[e];
-			used = u > used ? u : used;
-			maxlen = elen[e] > maxlen ? (uint32_t)elen[e] : maxlen;
+		const bool take = alive && rank < 256;
+		const uint32_t len = take ? (uint32_t)elen[e] & 255u : 0u;
+		const bool made = tree && take && e >= seed_end;                  // spelled out here
+		const uint32_t incl = wave_inclusive_scan_u32(made ? len : 0u);
+		const uint32_t off = made ? wpos + incl - len : take ? (uint32_t)eoff[e] : 0u;
+		wpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		if(take) {
+			T.off[rank] = (uint16_t)off; T.len[rank] = (uint8_t)len;
+			used = off + len > used ? off + len : used;
+			maxlen = len > maxlen ? len : maxlen;
+		}
+		if(made) {
+			uint32_t cur = e, j = off + len;
+			while(cur >= seed_end) { const uint32_t lr = elen[cur]; buf[--j] = sym[lr >> 8]; cur = eoff[cur]; }
+			const uint32_t lr = elen[cur];
+			buf[--j] = sym[lr >> 8];
+			while(j > off) buf[--j] = A;
 		}
 		w += __popcll(mask);
 	}
 	used = wave_max_u32(used); maxlen = wave_max_u32(maxlen);
 	for(uint32_t c = w + lane; c < 256; c += 64) { T.off[c] = 0; T.len[c] = 0; }   // never on valid input
 	if(lane == 0) { T.used = used; T.maxlen = maxlen; }
+	__syncthreads();
 	const uint32_t ndw = (used + 3) >> 2;
 	const uint32_t *src32 = (const uint32_t *)buf;
 	uint32_t *dst32 = (uint32_t *)T.bytes;
