@@ -183,7 +183,7 @@ struct Plan {
 	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
 	uint64_t jobs_begin = 0, jobs_bytes = 0;
 	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
-	uint32_t delta_lds = 0;
+	uint32_t delta_lds = 0, delta_wave_lds = 0;
 	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
 	uint64_t total = 0;
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
@@ -194,7 +194,7 @@ struct Plan {
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
 		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
-		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_lds = 0;
+		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_lds = 0; delta_wave_lds = 0;
 		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0;
 	}
 };
@@ -432,6 +432,9 @@ static int32_t f2i_x86_host(float x) {
 
 
 static const uint32_t DELTA_LDS_MAX = 64*1024;
+// launch classes of K-DELTA: 2 = values + prediction graph fit LDS, one wave (k_delta_wave); else the dataflow workgroup, 0 = large, 1 = small
+static inline uint64_t delta_wave_need(const DeltaJob &d) { return delta_wave_lds(d.nvert, d.N, d.is_u8 != 0); }
+static inline int delta_class(const DeltaJob &d) { return delta_wave_need(d) <= DELTA_WAVE_LDS_MAX ? 2 : d.nvert > DELTA_SMALL_NVERT ? 0 : 1; }
 static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 32767 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
 struct Launch {
@@ -669,7 +672,8 @@ static int build_and_launch(crthip_batch *b) {
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real;
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
 					const uint64_t need = (((uint64_t)nvert*N*(is_u8 ? 1 : 4) + 15) & ~15ull) + nvert;
-					if(need <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((need + 15) & ~15ull));
+					if(delta_class(d) == 2) pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)delta_wave_need(d));
+					else if(need <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((need + 15) & ~15ull));
 					pl.delta.v.push_back(d);
 				} else {
 					CloudJob c{};
@@ -736,7 +740,8 @@ static int build_and_launch(crthip_batch *b) {
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
 	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return d.nvert > DELTA_SMALL_NVERT; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) == 0; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) <= 1; });
 	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
 	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.normal_fused_ids); place(pl.dequant); place(pl.dequant_block_job);
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
@@ -855,12 +860,14 @@ static int build_and_launch(crthip_batch *b) {
 		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
-		uint32_t nlarge = 0;
-		for(auto &d : pl.delta.v) nlarge += d.nvert > DELTA_SMALL_NVERT;
-		const uint32_t nsmall = (uint32_t)pl.delta.v.size() - nlarge;
+		uint32_t ncls[3] = {0, 0, 0};
+		for(auto &d : pl.delta.v) ncls[delta_class(d)]++;
+		static uint32_t dw_attr = 0;                           // raise the dynamic-LDS limit once
+		if(pl.delta_wave_lds > 64*1024 && !dw_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_delta_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA_WAVE_LDS_MAX)); dw_attr = 1; }
 		LT.begin("delta_mesh");
-		if(nlarge) hipLaunchKernelGGL(k_delta_mesh, dim3(nlarge), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), nlarge, pl.delta_lds);
-		if(nsmall) hipLaunchKernelGGL(k_delta_mesh, dim3(nsmall), dim3(DELTA_THREADS/2), pl.delta_lds, st, D(pl.delta) + nlarge, nsmall, pl.delta_lds);
+		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), ncls[0], pl.delta_lds);
+		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), pl.delta_lds, st, D(pl.delta) + ncls[0], ncls[1], pl.delta_lds);
+		if(ncls[2]) hipLaunchKernelGGL(k_delta_wave, dim3(ncls[2]), dim3(64), pl.delta_wave_lds, st, D(pl.delta) + ncls[0] + ncls[1], ncls[2]);
 		LT.end();
 	}
 	if(cloud_chunks) {

@@ -694,4 +694,147 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// K-DELTA for an attribute that fits LDS: ONE wave.  In the breadth-first CLERS order nearly every vertex predicts from
+// the vertex made just before it (a = i-1) and two vertices one ring of the front back, so the dependency graph is a
+// set of "stretches" - runs of consecutive vertices, each run a serial chain - skewed against each other by two steps:
+// the parallelism (about 13 wide on a 4K-triangle blob) is ACROSS stretches.  Lane k walks stretch k, k+64, ... in
+// order; a vertex fires when the fired flags of its three parents are set.  One wave executes its LDS accesses in
+// program order, so a flag or value written in one pass is what the next pass reads: no fences, no barriers, no
+// polling waves (the dataflow form above keeps 8-16 waves per attribute spinning on flags for the same 13-wide work).
+// The lowest unfired vertex always is the current vertex of its lane and its parents are lower, so every pass fires
+// at least one vertex.  Any triple set is handled (a malformed or adversarial one only costs passes).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int NC>
+__device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, CRT_LDS uint8_t *fired,
+                                               CRT_LDS const uint16_t *starts, uint32_t ns, uint32_t nvert, uint32_t Nrt) {
+	const uint32_t n = NC ? (uint32_t)NC : Nrt;
+	uint32_t k = threadIdx.x;
+	bool active = k < ns;
+	uint32_t i = active ? starts[k] : 0u, end = active ? (k + 1 < ns ? (uint32_t)starts[k + 1] : nvert) : 0u;
+	uint32_t a = active ? pa[i] : 0u, bc = active ? pbc[i] : 0u;
+	while(__any(active)) {
+		if(active) {
+			const bool inv = a == 0xFFFFu;                                   // malformed triple (and vertex 0): the value stays
+			const uint32_t aa = inv ? 0u : a, b = bc & 0xFFFFu, c = bc >> 16;
+			const uint32_t ready = (uint32_t)fired[aa] & fired[b] & fired[c];
+			if(NC) {                                                         // values are fetched with the flags: one LDS round trip per pass
+				T x[NC ? NC : 1];
+#pragma unroll
+				for(uint32_t q = 0; q < (uint32_t)NC; q++) x[q] = (T)(v[i*n + q] + v[aa*n + q] + v[b*n + q] - v[c*n + q]);
+				if(ready && !inv) {
+#pragma unroll
+					for(uint32_t q = 0; q < (uint32_t)NC; q++) v[i*n + q] = x[q];
+				}
+			} else if(ready && !inv) {
+				for(uint32_t q = 0; q < n; q++) v[i*n + q] = (T)(v[i*n + q] + v[aa*n + q] + v[b*n + q] - v[c*n + q]);
+			}
+			if(ready) {
+				fired[i] = 1;
+				i++;
+				if(i == end) {
+					k += 64; active = k < ns;
+					if(active) { i = starts[k]; end = k + 1 < ns ? (uint32_t)starts[k + 1] : nvert; }
+				}
+				if(active) { a = pa[i]; bc = pbc[i]; }
+			}
+		}
+		asm volatile("" ::: "memory");
+	}
+}
+
+__global__ __launch_bounds__(64) void k_delta_wave(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const DeltaJob J = jobs[blockIdx.x];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const uint32_t lane = threadIdx.x, nvert = J.nvert, N = J.N;
+	const uint32_t bytes = nvert*N*(J.is_u8 ? 1u : 4u);
+	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
+	CRT_LDS uint16_t *pa = (CRT_LDS uint16_t *)(l8 + delta_wave_vbytes(nvert, N, J.is_u8));
+	CRT_LDS uint32_t *pbc = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)pa + delta_wave_a_bytes(nvert));
+	CRT_LDS uint8_t *fired = (CRT_LDS uint8_t *)(pbc + nvert);
+	CRT_LDS uint16_t *starts = (CRT_LDS uint16_t *)(fired + delta_wave_fired_bytes(nvert));
+	CRT_GLOBAL uint8_t *g8 = as_global((uint8_t *)J.values);
+	CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
+
+	// values -> LDS: 16-byte vectors, eight in flight per lane (a lone wave that waited for each load before issuing the next
+	// would spend ~1 us per KB).  LDS mirrors the caller's alignment phase so that both sides of the body are 16-aligned;
+	// unaligned heads/tails (3-component colours, odd caller buffers) go bytewise.
+	const uint32_t phase = (uint32_t)((uintptr_t)J.values & 15);
+	const uint32_t head = (16 - phase) & 15;
+	const bool vec = bytes >= 64;
+	const uint32_t nvec = vec ? (bytes - head) >> 4 : 0u;
+	l8 += vec ? phase : 0u;                                              // (l8 + head) is 16-aligned; phase % 4 == 0 whenever the caller's ints are aligned
+	CRT_GLOBAL const u32x4 *g4 = (CRT_GLOBAL const u32x4 *)(g8 + head);
+	CRT_LDS u32x4 *l4 = (CRT_LDS u32x4 *)(l8 + head);
+	for(uint32_t i = lane; i < nvec; i += 64*8) {
+		u32x4 t[8];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) t[u] = g4[i + u*64];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) l4[i + u*64] = t[u];
+	}
+	const uint32_t nhead = vec ? head : 0u;
+	for(uint32_t i = lane; i < nhead; i += 64) l8[i] = g8[i];
+	for(uint32_t i = nhead + nvec*16 + lane; i < bytes; i += 64) l8[i] = g8[i];
+
+	// prediction triples -> a | (b, c) | stretch starts.  Four rounds of 64 vertices in flight.
+	uint32_t ns = 0;
+	for(uint32_t base = 0; base < nvert; base += 256) {
+		uint32_t ta[4], tb[4], tc[4];
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) {
+			const uint32_t i = base + u*64 + lane;
+			ta[u] = tb[u] = tc[u] = 0;
+			if(i < nvert) { ta[u] = pred[(size_t)i*3]; tb[u] = tc[u] = ta[u]; if(J.parallelogram) { tb[u] = pred[(size_t)i*3 + 1]; tc[u] = pred[(size_t)i*3 + 2]; } }
+		}
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) {
+			const uint32_t i = base + u*64 + lane;
+			const bool in = i < nvert;
+			const bool valid = in && ta[u] < i && tb[u] < i && tc[u] < i;   // well-formed streams always predict from earlier vertices
+			const bool start = in && !(valid && ta[u] + 1 == i);
+			if(in) {
+				pa[i] = (uint16_t)(valid ? ta[u] : 0xFFFFu);
+				pbc[i] = valid && J.parallelogram ? tb[u] | (tc[u] << 16) : 0u;   // v += v[a] alone: b = c = vertex 0 cancel
+				fired[i] = i == 0;
+			}
+			const uint64_t m = __ballot(start);
+			if(start) starts[ns + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+			ns += __popcll(m);
+		}
+	}
+	__syncthreads();
+
+	if(J.is_u8) {
+		CRT_LDS uint8_t *v = l8;
+		switch(N) {
+		case 3: delta_wave_run<uint8_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		case 4: delta_wave_run<uint8_t, 4>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		default: delta_wave_run<uint8_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		}
+	} else {
+		CRT_LDS uint32_t *v = (CRT_LDS uint32_t *)l8;
+		switch(N) {
+		case 1: delta_wave_run<uint32_t, 1>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		case 2: delta_wave_run<uint32_t, 2>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		case 3: delta_wave_run<uint32_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		default: delta_wave_run<uint32_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+		}
+	}
+	__syncthreads();
+
+	CRT_GLOBAL u32x4 *o4 = (CRT_GLOBAL u32x4 *)(g8 + head);
+	for(uint32_t i = lane; i < nvec; i += 64*8) {
+		u32x4 t[8];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) t[u] = l4[i + u*64];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) o4[i + u*64] = t[u];
+	}
+	for(uint32_t i = lane; i < nhead; i += 64) g8[i] = l8[i];
+	for(uint32_t i = nhead + nvec*16 + lane; i < bytes; i += 64) g8[i] = l8[i];
+}
+
 } // namespace corto_hip
