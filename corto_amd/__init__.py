@@ -132,6 +132,8 @@ def lib():
         L.crthip_arena_layout.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
         L.crthip_encode.restype = C.c_int64
         L.crthip_encode.argtypes = [C.POINTER(MeshDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.crthip_tunstall_encode_blocks.restype = C.c_int64
+        L.crthip_tunstall_encode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.crthip_tunstall_decode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.POINTER(KernelTimes)]
         _lib = L
@@ -483,3 +485,21 @@ def tunstall_decode_blocks(ctx: Context, host_blocks: np.ndarray, device_blocks,
     _check(lib().crthip_tunstall_decode_blocks(ctx.handle, len(bo), _np_ptr(host_blocks), C.c_void_p(device_blocks.data_ptr()),
                                                _np_ptr(bo), C.c_void_p(device_out.data_ptr()), _np_ptr(oo), C.byref(t)))
     return t.as_dict()
+
+
+def tunstall_encode_blocks(ctx: Context, streams: Sequence[np.ndarray], with_times: bool = False):
+    """GPU encoder stage (crthip_tunstall_encode_blocks): the reference's OutStream::tunstall_compress block of every
+    byte stream in `streams`.  Returns a list of uint8 arrays (one block each) [, per-kernel ms]."""
+    streams = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+    n = len(streams)
+    ptrs = (C.c_void_p * max(n, 1))(*[s.ctypes.data if len(s) else None for s in streams])
+    sizes = np.array([len(s) for s in streams], dtype=np.uint32)
+    cap = int(sizes.sum()) + 600 * n + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    t = KernelTimes()
+    r = lib().crthip_tunstall_encode_blocks(ctx.handle, n, ptrs, _np_ptr(sizes), _np_ptr(out), cap, _np_ptr(offs), C.byref(t))
+    if r < 0:
+        _check(int(r))
+    blocks = [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(n)]
+    return (blocks, t.as_dict()) if with_times else blocks

@@ -16,6 +16,7 @@
 #include "../../include/corto_hip.h"
 #include "crt_format.h"
 #include "device_plan.h"
+#include "encoder_internal.h"
 #include "kernels.h"
 
 using namespace corto_hip;
@@ -42,6 +43,8 @@ extern "C" const char *crthip_strerror(int code) {
 	return "unknown error";
 }
 static int fail(int code) { return fail(code, crthip_strerror(code)); }
+// context plumbing for the encoder stages (encoder_internal.h)
+namespace corto_hip { int ctx_fail(int code, const char *msg) { return fail(code, msg ? std::string(msg) : std::string(crthip_strerror(code))); } }
 extern "C" const char *crthip_last_error(void) { return g_error.c_str(); }
 extern "C" uint32_t crthip_abi_version(void) { return CRTHIP_ABI_VERSION; }
 
@@ -216,6 +219,15 @@ struct crthip_ctx {
 	std::vector<BlobScratch> plan_scratch;
 	std::vector<const uint8_t *> plan_clers, plan_logs;
 };
+
+namespace corto_hip {
+int ctx_device(crthip_ctx *ctx) { return ctx->device; }
+hipStream_t ctx_stream(crthip_ctx *ctx) { return ctx->stream; }
+int ctx_quiesce(crthip_ctx *ctx) {
+	if(ctx->in_flight) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
+	return CRTHIP_OK;
+}
+}
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4; };
 

@@ -125,4 +125,21 @@ struct DequantJob {
 	uint8_t is_color, pad[3];
 };
 
+// ---- encoder stages (k_encode.hip, encode_gpu.cpp) ----
+// a piece of a source stream for the byte histogram (src/tunstall.cpp:83-115)
+struct EncChunk { const uint8_t *src; uint32_t size, stream; };
+
+// one stream for the Tunstall coder (src/tunstall.cpp:384-428): the host-made encoder tables and where the codewords go
+struct EncStream {
+	const uint8_t *src;            // size symbols
+	uint8_t *dst;                  // room for size + 64 codewords
+	const int16_t *trie;           // the reference's 2-symbol-step trie, levels of nsym*nsym entries: >= 0 codeword, < 0 minus the next level's number
+	const uint8_t *remap;          // 256: symbol -> index
+	const uint16_t *lengths;       // 256: word length by codeword
+	uint32_t *csize;               // out: number of codewords
+	uint32_t size, nsym, ntrie, pad;
+};
+constexpr uint32_t ENC_STAGE = 4096, ENC_STAGE_PAD = 576;      // bytes staged in LDS per refill; look-ahead a 64-byte window may need (words <= 255 symbols)
+constexpr uint32_t ENC_HIST_CHUNK = 1u << 18;
+
 } // namespace corto_hip

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/corto_hip.h"
+#include "encoder_internal.h"
 
 namespace {
 
@@ -85,6 +86,9 @@ struct Tunstall {
 	void probabilities(const uint8_t *data, int size) {                               // tunstall.cpp:83-115
 		std::vector<int> cnt(256, 0);
 		for(int i = 0; i < size; i++) cnt[data[i]]++;
+		from_counts(cnt, size);
+	}
+	void from_counts(const std::vector<int> &cnt, int size) {
 		probs.clear();
 		for(int i = 0; i < 256; i++) if(cnt[i] > 0) probs.push_back(Sym{(uint8_t)i, (uint8_t)(cnt[i]*255/size)});
 		std::sort(probs.begin(), probs.end(), [](const Sym &a, const Sym &b) -> bool { return a.probability > b.probability; });
@@ -636,3 +640,20 @@ int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *
 }
 
 } // extern "C"
+
+
+// the encoder-side Tunstall tables of one stream, from its byte histogram (for the GPU encoder stages, encode_gpu.cpp)
+void corto_hip::tun_encoder_tables(const uint32_t counts[256], uint32_t size, TunEncoderTables &out) {
+	Tunstall t;
+	std::vector<int> cnt(counts, counts + 256);
+	t.from_counts(cnt, (int)size);
+	t.build();
+	t.trie();
+	out.nsym = (uint32_t)t.probs.size();
+	for(uint32_t i = 0; i < out.nsym; i++) { out.probs[2*i] = t.probs[i].symbol; out.probs[2*i + 1] = t.probs[i].probability; }
+	memset(out.remap, 0, sizeof(out.remap));
+	memset(out.lengths, 0, sizeof(out.lengths));
+	for(size_t i = 0; i < t.remap.size() && i < 256; i++) out.remap[i] = t.remap[i];
+	for(size_t i = 0; i < t.lengths.size() && i < 256; i++) out.lengths[i] = (uint16_t)t.lengths[i];
+	out.offsets.assign(t.offsets.begin(), t.offsets.end());
+}

@@ -1,0 +1,30 @@
+// encoder_internal.h — pieces of the host encoder (encoder.cpp) and of the context (batch.cpp) that the GPU encoder
+// stages (encode_gpu.cpp, k_encode.hip) use.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/corto_hip.h"
+
+namespace corto_hip {
+
+// What Tunstall::compress walks (src/tunstall.cpp:384-428), made from a byte histogram exactly as
+// getProbabilities + createDecodingTables2 + createEncodingTables make it (src/tunstall.cpp:83-115, 125-256, 335-382).
+struct TunEncoderTables {
+	uint32_t nsym = 0;
+	uint8_t probs[512];                 // nsym x (symbol, probability), sorted as the reference sorts them
+	uint8_t remap[256];                 // symbol -> index in probs
+	uint16_t lengths[256];              // word lengths by codeword
+	std::vector<int32_t> offsets;       // the 2-symbol-step trie: >= 0 codeword, < 0 minus the offset of the next level
+};
+void tun_encoder_tables(const uint32_t counts[256], uint32_t size, TunEncoderTables &out);
+
+// context plumbing (batch.cpp)
+int ctx_fail(int code, const char *msg);
+int ctx_device(crthip_ctx *ctx);
+hipStream_t ctx_stream(crthip_ctx *ctx);
+int ctx_quiesce(crthip_ctx *ctx);       // wait for whatever batch is in flight on the context
+
+} // namespace corto_hip

@@ -1,0 +1,107 @@
+// k_encode.hip — GPU stages of the encoder for gfx950: the Tunstall coder of a batch of byte streams.
+//
+// Replaces, for many streams at once, the data-parallel part of
+//   crt::Tunstall::getProbabilities   src/tunstall.cpp:83-115   (byte histogram)               -> k_enc_hist
+//   crt::Tunstall::compress           src/tunstall.cpp:384-428  (greedy parse over the trie)   -> k_enc_tun_parse
+// The 256-word dictionary and its 2-symbol-step trie are a few microseconds of serial work per stream and depend on
+// std::sort's order of equal probabilities; they stay on the host (encoder.cpp: tun_encoder_tables), between the two kernels.
+//
+// K-ENC-PARSE: one wave per stream.  The reference parse is a serial chain - a codeword starts where the previous one
+// ended - but where a codeword WOULD end if one started at byte p depends on p alone.  So the 64 lanes walk the trie from
+// 64 consecutive start positions at once (same loop as the reference's, per lane), and the chain through that window is
+// then a handful of scalar readlanes: cur -> next[cur].  Codewords are collected one per lane and stored 64 at a time.
+// Source bytes are staged through LDS already remapped to symbol indices; the trie sits in LDS when it fits.
+#include "kernels_common.h"
+#include "kernels.h"
+
+namespace corto_hip {
+
+__global__ __launch_bounds__(256) void k_enc_hist(const EncChunk *__restrict__ chunks, uint32_t nchunks, uint32_t *__restrict__ counts) {
+	if(blockIdx.x >= nchunks) return;
+	const EncChunk c = chunks[blockIdx.x];
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	CRT_GLOBAL const uint8_t *src = as_global(c.src);
+	const uint32_t head = min((uint32_t)((0u - (uint32_t)(uintptr_t)c.src) & 3u), c.size);
+	if(threadIdx.x < head) atomicAdd(&h[src[threadIdx.x]], 1u);
+	const uint32_t ndw = (c.size - head) >> 2;
+	CRT_GLOBAL const uint32_t *src32 = (CRT_GLOBAL const uint32_t *)(src + head);
+	for(uint32_t i = threadIdx.x; i < ndw; i += 256) {
+		const uint32_t x = src32[i];
+		atomicAdd(&h[x & 255u], 1u); atomicAdd(&h[(x >> 8) & 255u], 1u); atomicAdd(&h[(x >> 16) & 255u], 1u); atomicAdd(&h[x >> 24], 1u);
+	}
+	for(uint32_t i = head + ndw*4 + threadIdx.x; i < c.size; i += 256) atomicAdd(&h[src[i]], 1u);
+	__syncthreads();
+	const uint32_t v = h[threadIdx.x];
+	if(v) atomicAdd(&counts[(size_t)c.stream*256 + threadIdx.x], v);
+}
+
+// LDS: remap u8[256] | lengths u16[256] | staged symbol indices u8[ENC_STAGE + ENC_STAGE_PAD] | trie i16[ntrie] (when it fits)
+template <bool TRIE_IN_LDS>
+__device__ __forceinline__ void enc_parse_body(const EncStream &S, CRT_LDS uint8_t *lds) {
+	const uint32_t lane = threadIdx.x, size = S.size, n = S.nsym, span = n*n;
+	CRT_LDS uint8_t *remap = lds;
+	CRT_LDS uint16_t *lengths = (CRT_LDS uint16_t *)(lds + 256);
+	CRT_LDS uint8_t *stg = lds + 768;
+	CRT_LDS int16_t *ltrie = (CRT_LDS int16_t *)(lds + 768 + ENC_STAGE + ENC_STAGE_PAD);
+	CRT_GLOBAL const int16_t *gtrie = as_global(S.trie);
+	CRT_GLOBAL const uint8_t *src = as_global(S.src);
+	CRT_GLOBAL uint8_t *dst = as_global(S.dst);
+	for(uint32_t i = lane; i < 256; i += 64) { remap[i] = S.remap[i]; lengths[i] = S.lengths[i]; }
+	if(TRIE_IN_LDS) for(uint32_t i = lane; i < S.ntrie; i += 64) ltrie[i] = gtrie[i];
+	__syncthreads();
+	auto TR = [&](uint32_t i) -> int32_t { return i < S.ntrie ? (int32_t)(TRIE_IN_LDS ? ltrie[i] : gtrie[i]) : 0; };
+
+	uint32_t base = 0, nout = 0, s0 = 0, s1 = 0;                       // staged: symbol indices of positions [s0, s1)
+	int outv = 0;
+	while(base < size && nout <= size) {
+		if(base + 64 + ENC_STAGE_PAD > s1 && s1 < size) {              // restage from the window's first byte
+			__syncthreads();
+			s0 = base; s1 = min(size, s0 + ENC_STAGE + ENC_STAGE_PAD);
+			for(uint32_t i = lane; i < s1 - s0; i += 64) stg[i] = remap[src[s0 + i]];
+			__syncthreads();
+		}
+		// every lane: the reference's loop (tunstall.cpp:395-420) started at byte p, up to its first codeword
+		const uint32_t p = base + lane;
+		int32_t code = 0; uint32_t next = p;
+		if(p < size) {
+			uint32_t in = p, woff = 0, level = 0;                             // level: offset of the trie level being looked at (the reference's -off)
+			for(;;) {
+				int32_t t;
+				if(in >= size) {                                              // ran off the end inside a word: follow the (0,0) entries down
+					do { t = TR(level); level = (uint32_t)(-t)*span; } while(t < 0);
+					code = t; next = in; break;
+				}
+				uint32_t low = (uint32_t)stg[in - s0]*n;
+				if(size - in >= 2) low += stg[in + 1 - s0];
+				t = TR(level + low);
+				if(t >= 0) { code = t; next = in + lengths[t & 255] - woff; break; }
+				level = (uint32_t)(-t)*span; woff += 2; in += 2;
+			}
+		}
+		// the chain through this window
+		uint32_t cur = base;
+		while(cur < size && cur - base < 64 && nout <= size) {
+			const uint32_t l = cur - base;
+			const int c = __builtin_amdgcn_readlane(code, (int)l);
+			cur = (uint32_t)__builtin_amdgcn_readlane((int)next, (int)l);
+			outv = lane == (nout & 63u) ? c : outv;
+			nout++;
+			if((nout & 63u) == 0) dst[nout - 64 + lane] = (uint8_t)outv;
+		}
+		base = cur;
+	}
+	if(lane < (nout & 63u)) dst[(nout & ~63u) + lane] = (uint8_t)outv;
+	if(lane == 0) *S.csize = nout;
+}
+
+__global__ __launch_bounds__(64) void k_enc_tun_parse(const EncStream *__restrict__ streams, uint32_t nstreams, uint32_t trie_lds_entries) {
+	if(blockIdx.x >= nstreams) return;
+	const EncStream S = streams[blockIdx.x];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_[];
+	if(S.ntrie <= trie_lds_entries) enc_parse_body<true>(S, as_lds(lds_));
+	else enc_parse_body<false>(S, as_lds(lds_));
+}
+
+} // namespace corto_hip

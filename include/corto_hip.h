@@ -220,6 +220,17 @@ int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const uint8_t *ho
                                   crthip_kernel_times *times);
 int crthip_ctx_sync(crthip_ctx *ctx);
 
+/* GPU encoder stage: the entropy coder of crt::Encoder for a batch of n byte streams, i.e.
+ * OutStream::tunstall_compress (src/cstream.cpp:89-109) n times: byte histogram and greedy Tunstall parse
+ * (Tunstall::getProbabilities / compress, src/tunstall.cpp:83-115, 384-428) run on the device, one wave per stream;
+ * the 256-word dictionary and its trie (src/tunstall.cpp:125-256, 335-382) are built on the host in between.
+ * src[i] / sizes[i]: HOST symbol arrays (<= 2^23 symbols each).  Writes the n blocks back to back into out
+ * ("u8 nsym | nsym*(sym,prob) | i32 size | i32 csize | codewords", byte-identical to the reference's), their
+ * starts into block_offset[0..n] (n+1 entries), and returns the total size, or <0.  out == NULL sizes only.
+ * No CPU fallback: CRTHIP_E_DEVICE without a HIP device. */
+int64_t crthip_tunstall_encode_blocks(crthip_ctx *ctx, uint32_t n, const uint8_t *const *src, const uint32_t *sizes,
+                                      uint8_t *out, size_t cap, uint64_t *block_offset, crthip_kernel_times *times);
+
 #ifdef __cplusplus
 }
 #endif

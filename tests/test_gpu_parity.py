@@ -389,6 +389,47 @@ def test_tunstall_long_streams_every_step_geometry(ctx):
 
 
 # ---------------------------------------------------------------------------------------------------
+# GPU encoder stage: crthip_tunstall_encode_blocks = OutStream::tunstall_compress for a batch of streams
+def _enc_kat():
+    z = np.load(os.path.join(GOLDEN, "tunstall_enc_kat.npz"))
+    n = int(z["count"])
+    return [z["input_%02d" % i] for i in range(n)], [z["block_%02d" % i] for i in range(n)]
+
+
+def test_tunstall_encode_blocks_kat(ctx):
+    """every block byte-identical to what the reference wrote for the same symbols (logs-like, CLERS-like, low-entropy runs,
+    64 and 200 distinct symbols (the 200-symbol trie is walked in L2, not LDS), one symbol, streams ending inside a word)"""
+    streams, blocks = _enc_kat()
+    got, times = ca.tunstall_encode_blocks(ctx, streams, with_times=True)
+    assert "enc_hist" in times and "enc_tun_parse" in times
+    for i, (g, e) in enumerate(zip(got, blocks)):
+        assert g.tobytes() == e.tobytes(), (i, len(g), len(e))
+    # empty batch, empty stream
+    assert ca.tunstall_encode_blocks(ctx, []) == []
+    assert ca.tunstall_encode_blocks(ctx, [np.zeros(0, np.uint8)])[0].tobytes() == bytes(9)
+
+
+def test_tunstall_encode_blocks_round_trip_and_reference(ctx):
+    """hundreds of random streams in one call, one of them several windows' restaging long: the device decoder returns the
+    input; where oracle/_ref travelled, the reference's own block is the same bytes"""
+    from oracle import refcodec as rc
+    rng = np.random.default_rng(123)
+    streams = []
+    for k in range(300):
+        n = int(rng.integers(1, 5000)) if k else 300_001
+        nsym = int(rng.integers(1, 48))
+        p = rng.dirichlet(np.full(nsym, 0.25 if k % 3 else 3.0))
+        streams.append(rng.choice((np.arange(nsym) * 5 % 256).astype(np.uint8), n, p=p))
+    blocks = ca.tunstall_encode_blocks(ctx, streams)
+    outs, _ = _run_blocks(ctx, blocks, [len(s) for s in streams])
+    for i, (o, s) in enumerate(zip(outs, streams)):
+        assert np.array_equal(o, s), i
+    if rc.available():
+        for i in range(0, 300, 7):
+            assert blocks[i].tobytes() == rc.tunstall_compress_block(streams[i]).tobytes(), i
+
+
+# ---------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: inputs synthesised on the box by the repo's own encoder (byte-identical to the reference's,
 # tests/test_encoder_cpu.py), outputs checked against the C oracle and, when oracle/_ref travelled, the reference itself.
 def _maybe_ref_decode(blob):

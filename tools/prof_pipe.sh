@@ -2,23 +2,29 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pipe
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tools/pipe_probe.py > $OUT/log.txt 2>&1
+GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- env SPECS=2x3 python tools/pipe_probe_mt.py > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 topo = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_topology_lds" in r["Kernel_Name"]]
-# depth-4 phase = last 46 topology launches
+# steady state = the last 40 topology launches
 ph = topo[-40:]
 t0, t1 = ph[0][0], ph[-1][1]
-print("depth-4 phase: %d topology launches in %.2f ms -> %.3f ms/step" % (len(ph), (t1 - t0) / 1e6, (t1 - t0) / 1e6 / len(ph)))
+print("2x3 steady state: %d topology launches in %.2f ms -> %.3f ms/step" % (len(ph), (t1 - t0) / 1e6, (t1 - t0) / 1e6 / len(ph)))
 ev = sorted([(s, 1) for s, e in ph] + [(e, -1) for s, e in ph])
 cur = 0; last = t0; hist = collections.Counter()
 for t, d in ev:
     hist[cur] += t - last; last = t; cur += d
 print("time share by number of concurrent topology kernels:", {k: round(v / (t1 - t0), 3) for k, v in sorted(hist.items())})
 print("topology duration avg %.0f us" % (sum(e - s for s, e in ph) / len(ph) / 1e3))
+allk = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if t0 <= int(r["Start_Timestamp"]) <= t1]
+ev = sorted([(s, 1) for s, e in allk] + [(e, -1) for s, e in allk])
+cur = 0; last = t0; hist = collections.Counter()
+for t, d in ev:
+    hist[min(cur, 12)] += t - last; last = t; cur += d
+print("time share by number of concurrent kernels (any):", {k: round(v / (t1 - t0), 3) for k, v in sorted(hist.items())})
 acc = collections.defaultdict(list)
 for r in rows:
     s = int(r["Start_Timestamp"])
