@@ -132,6 +132,10 @@ def lib():
         L.crthip_arena_layout.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
         L.crthip_encode.restype = C.c_int64
         L.crthip_encode.argtypes = [C.POINTER(MeshDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.crthip_encode_gpu.restype = C.c_int64
+        L.crthip_encode_gpu.argtypes = [C.c_void_p, C.POINTER(MeshDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.crthip_encode_values.restype = C.c_int64
+        L.crthip_encode_values.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.crthip_tunstall_encode_blocks.restype = C.c_int64
         L.crthip_tunstall_encode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.crthip_tunstall_decode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -196,8 +200,9 @@ DIFF, ESTIMATED, BORDER = 0, 1, 2
 
 
 def encode(mesh, position_bits=14, position_q=0.0, normal_bits=10, normal_prediction=BORDER, color_bits=(6, 7, 6, 5),
-           uv_bits=12, radius_q=1.0, entropy=1, exif=None, with_normal=True, with_color=True, with_uv=True) -> np.ndarray:
-    """.crt blob of a corto_amd.synth.Mesh (host only; byte-identical to upstream crt::Encoder, see csrc/encoder.cpp).
+           uv_bits=12, radius_q=1.0, entropy=1, exif=None, with_normal=True, with_color=True, with_uv=True, ctx=None) -> np.ndarray:
+    """.crt blob of a corto_amd.synth.Mesh (byte-identical to upstream crt::Encoder, see csrc/encoder.cpp).  Host only by
+    default; with ctx=Context the value coding and the entropy coder run on the device (crthip_encode_gpu) - same bytes.
     Same keyword meaning as upstream's CLI: -v position_bits, -n normal_bits, -N prediction, -u uv_bits (src/main.cpp:93-216)."""
     m = MeshDesc()
     m.nvert, m.nface = mesh.nvert, mesh.nface
@@ -223,6 +228,16 @@ def encode(mesh, position_bits=14, position_q=0.0, normal_bits=10, normal_predic
     if exif:
         flat = b"".join(k.encode() + b"\0" + v.encode() + b"\0" for k, v in exif.items())
         m.exif = flat; m.nexif = len(exif)
+    if ctx is not None:                                  # one pass: the device stages are not run twice just to learn the size
+        cap = 64 * (mesh.nvert + mesh.nface) + 65536
+        out = np.zeros(cap + 16, dtype=np.uint8)
+        off = (-out.ctypes.data) % 16
+        n = lib().crthip_encode_gpu(ctx.handle, C.byref(m), out[off:].ctypes.data_as(C.c_void_p), cap, None, None)
+        if n < 0:
+            _check(int(n))
+        if n > cap:
+            raise CortoError(-9, "encode: blob larger than the estimate")
+        return out[off:off + int(n)]
     n = lib().crthip_encode(C.byref(m), None, 0, None, None)
     if n < 0:
         _check(int(n))
@@ -503,3 +518,35 @@ def tunstall_encode_blocks(ctx: Context, streams: Sequence[np.ndarray], with_tim
         _check(int(r))
     blocks = [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(n)]
     return (blocks, t.as_dict()) if with_times else blocks
+
+
+ENC_SYMBOLS, ENC_ARRAY, ENC_VALUES_I32, ENC_VALUES_I8 = 0, 1, 2, 3
+
+
+class EncStream(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("count", C.c_uint32), ("components", C.c_uint32), ("reserved", C.c_uint32), ("values", C.c_void_p)]
+
+
+def encode_values(ctx: Context, streams, entropy: int = 1, with_times: bool = False):
+    """GPU encoder stage (crthip_encode_values).  streams: list of (kind, array); ARRAY / VALUES arrays are (count, N) int32
+    (int8 for ENC_VALUES_I8), SYMBOLS arrays are uint8.  Returns one uint8 array per stream: "u32 nwords | words | blocks"."""
+    n = len(streams)
+    desc = (EncStream * max(n, 1))()
+    keep = []
+    cap = 1024
+    for i, (kind, a) in enumerate(streams):
+        a = np.ascontiguousarray(a, dtype=np.uint8 if kind == ENC_SYMBOLS else np.int8 if kind == ENC_VALUES_I8 else np.int32)
+        keep.append(a)
+        count = a.shape[0] if a.ndim else 0
+        comps = 1 if kind == ENC_SYMBOLS or a.ndim < 2 else a.shape[1]
+        desc[i].kind, desc[i].count, desc[i].components = kind, count, comps
+        desc[i].values = a.ctypes.data if a.size else None
+        cap += a.size * 5 + 600 * (comps + 1) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    t = KernelTimes()
+    r = lib().crthip_encode_values(ctx.handle, entropy, n, desc, _np_ptr(out), cap, _np_ptr(offs), C.byref(t))
+    if r < 0:
+        _check(int(r))
+    res = [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(n)]
+    return (res, t.as_dict()) if with_times else res

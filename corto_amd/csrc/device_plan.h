@@ -139,6 +139,15 @@ struct EncStream {
 	uint32_t *csize;               // out: number of codewords
 	uint32_t size, nsym, ntrie, pad;
 };
+// one value array for the bit-width + bit-packing kernel (include/corto/cstream.h:115-164)
+struct PackJob {
+	const void *values;            // count*N int32 (ARRAY, VALUES_I32) or int8 (VALUES_I8)
+	uint8_t *logs;                 // ARRAY: count bytes; VALUES: N arrays of count bytes, component-major
+	uint32_t *words;               // MSB-first bit stream (src/bitstream.cpp:86-101)
+	uint32_t *nwords;              // out
+	uint32_t count, N, kind, pad;  // kind: CRTHIP_ENC_ARRAY / VALUES_I32 / VALUES_I8
+};
+constexpr uint32_t ENC_PACK_MAX_N = 16;                          // components per element the packing tile is sized for
 constexpr uint32_t ENC_STAGE = 4096, ENC_STAGE_PAD = 576;      // bytes staged in LDS per refill; look-ahead a 64-byte window may need (words <= 255 symbols)
 constexpr uint32_t ENC_HIST_CHUNK = 1u << 18;
 

@@ -38,9 +38,21 @@ int32_t f2i(float x) {                                                          
 	return (int32_t)x;
 }
 
+// ---- streams left to the device (crthip_encode_gpu): recorded instead of written, spliced in at `at` afterwards ----
+struct Deferred {
+	size_t at = 0;                      // position in the sink's bytes where the stream belongs
+	uint32_t kind = 0;                  // CRTHIP_ENC_*, or DEFER_BITS for a bit stream that is already packed (CLERS split bits)
+	uint32_t count = 0, N = 1;
+	std::vector<uint8_t> bytes;         // symbols / int8 values
+	std::vector<int32_t> ints;          // int32 values
+	std::vector<uint32_t> words;        // DEFER_BITS
+};
+constexpr uint32_t DEFER_BITS = 0xFFu;
+
 // ---- byte sink (OutStream, include/corto/cstream.h:42-105) ----
 struct Sink {
 	std::vector<uint8_t> b;
+	std::vector<Deferred> *defer = nullptr;   // non-null: value / symbol / bit streams are recorded, not written
 	void u8(uint32_t v) { b.push_back((uint8_t)v); }
 	void u16(uint32_t v) { u8(v); u8(v >> 8); }
 	void u32(uint32_t v) { u8(v); u8(v >> 8); u8(v >> 16); u8(v >> 24); }
@@ -67,6 +79,7 @@ struct BitWriter {
 	void flush() { if(bits != 32) { words.push_back(buff << bits); buff = 0; bits = 32; } }
 	void emit(Sink &s) {                // OutStream::write(BitStream&), cstream.h:79-89
 		flush();
+		if(s.defer) { Deferred d; d.at = s.b.size(); d.kind = DEFER_BITS; d.words = words; s.defer->push_back(std::move(d)); return; }
 		s.u32((uint32_t)words.size());
 		while(s.b.size() & 3) s.u8(0);
 		for(uint32_t w : words) s.u32(w);
@@ -191,6 +204,7 @@ struct Tunstall {
 
 // entropy-coded byte array (OutStream::compress / tunstall_compress, cstream.cpp:43-64, 89-109)
 void put_symbols(Sink &s, uint32_t entropy, const uint8_t *data, uint32_t size) {
+	if(s.defer) { Deferred d; d.at = s.b.size(); d.kind = CRTHIP_ENC_SYMBOLS; d.count = size; d.bytes.assign(data, data + size); s.defer->push_back(std::move(d)); return; }
 	if(entropy == CRTHIP_ENTROPY_NONE) { s.u32(size); s.raw(data, size); return; }
 	Tunstall t;
 	t.probabilities(data, (int)size);
@@ -215,6 +229,12 @@ int needed(int a) {                                                             
 
 // encodeValues (cstream.h:115-141): component-major logs, sign folding
 template <class T> void put_values(Sink &s, uint32_t entropy, uint32_t size, const T *values, int N) {
+	if(s.defer) {
+		Deferred d; d.at = s.b.size(); d.count = size; d.N = (uint32_t)N;
+		if(sizeof(T) == 1) { d.kind = CRTHIP_ENC_VALUES_I8; d.bytes.assign((const uint8_t *)values, (const uint8_t *)values + (size_t)size*N); }
+		else { d.kind = CRTHIP_ENC_VALUES_I32; d.ints.assign((const int32_t *)values, (const int32_t *)values + (size_t)size*N); }
+		s.defer->push_back(std::move(d)); return;
+	}
 	BitWriter bw;
 	std::vector<std::vector<uint8_t>> logs((size_t)N, std::vector<uint8_t>(size));
 	for(int c = 0; c < N; c++) for(uint32_t i = 0; i < size; i++) {
@@ -232,6 +252,7 @@ template <class T> void put_values(Sink &s, uint32_t entropy, uint32_t size, con
 
 // encodeArray (cstream.h:143-164): one log per element
 void put_array(Sink &s, uint32_t entropy, uint32_t size, const int32_t *values, int N) {
+	if(s.defer) { Deferred d; d.at = s.b.size(); d.kind = CRTHIP_ENC_ARRAY; d.count = size; d.N = (uint32_t)N; d.ints.assign(values, values + (size_t)size*N); s.defer->push_back(std::move(d)); return; }
 	BitWriter bw;
 	std::vector<uint8_t> logs(size);
 	for(uint32_t i = 0; i < size; i++) {
@@ -565,9 +586,11 @@ extern "C" {
 
 // Encode a mesh / point cloud into a .crt blob (host only).  Returns the blob size (also when out == NULL or cap is too
 // small: call twice), or <0.  out_nvert/out_nface = counts after unreferenced vertices / degenerate faces are dropped.
-int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface) {
+static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface, crthip_ctx *gpu) {
 	if(!m || !m->position) return CRTHIP_E_ARGUMENT;
 	Encoder E;
+	std::vector<Deferred> deferred;
+	if(gpu) E.s.defer = &deferred;
 	E.nvert = m->nvert; E.nface = m->index ? m->nface : 0; E.entropy = (uint32_t)m->entropy;
 	const char *p = m->exif;
 	for(uint32_t i = 0; i < m->nexif; i++) { std::string k(p); p += k.size() + 1; std::string v(p); p += v.size() + 1; E.exif[k] = v; }
@@ -635,8 +658,45 @@ int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *
 	if(E.nface > 0) E.encode_mesh(); else E.encode_cloud();
 	if(out_nvert) *out_nvert = E.nvert;
 	if(out_nface) *out_nface = E.nface;
+	if(gpu) {
+		// the recorded streams go through the device stages in one call, then everything is spliced together; the zero padding
+		// in front of every bit stream (OutStream::write(BitStream&), cstream.h:79-89) depends on the final position, so it is made here
+		std::vector<corto_hip::EncValueStream> in;
+		for(const Deferred &d : deferred) {
+			if(d.kind == DEFER_BITS) continue;
+			corto_hip::EncValueStream v;
+			v.kind = d.kind; v.count = d.count; v.components = d.N;
+			v.values = d.kind == CRTHIP_ENC_SYMBOLS || d.kind == CRTHIP_ENC_VALUES_I8 ? (const void *)d.bytes.data() : (const void *)d.ints.data();
+			in.push_back(v);
+		}
+		std::vector<corto_hip::EncValueResult> res;
+		const int err = corto_hip::encode_value_streams(gpu, E.entropy, in, res, nullptr);
+		if(err) return err;
+		Sink f;
+		size_t prev = 0, k = 0;
+		auto bits = [&](const std::vector<uint32_t> &w) { f.u32((uint32_t)w.size()); while(f.b.size() & 3) f.u8(0); for(uint32_t x : w) f.u32(x); };
+		for(const Deferred &d : deferred) {
+			f.raw(E.s.b.data() + prev, d.at - prev); prev = d.at;
+			if(d.kind == DEFER_BITS) { bits(d.words); continue; }
+			const corto_hip::EncValueResult &r = res[k++];
+			if(d.kind != CRTHIP_ENC_SYMBOLS) bits(r.words);
+			for(const std::vector<uint8_t> &b : r.blocks) f.raw(b.data(), b.size());
+		}
+		f.raw(E.s.b.data() + prev, E.s.b.size() - prev);
+		E.s.b.swap(f.b);
+	}
 	if(out && cap >= E.s.b.size()) memcpy(out, E.s.b.data(), E.s.b.size());
 	return (int64_t)E.s.b.size();
+}
+
+int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface) {
+	return encode_impl(m, out, cap, out_nvert, out_nface, nullptr);
+}
+
+// crthip_encode with the value coding (bit widths, bit packing) and the entropy coder on the device (encode_gpu.cpp)
+int64_t crthip_encode_gpu(crthip_ctx *ctx, const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface) {
+	if(!ctx) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode_gpu: null context (there is no CPU fallback: use crthip_encode for the host encoder)");
+	return encode_impl(m, out, cap, out_nvert, out_nface, ctx);
 }
 
 } // extern "C"

@@ -21,6 +21,15 @@ struct TunEncoderTables {
 };
 void tun_encoder_tables(const uint32_t counts[256], uint32_t size, TunEncoderTables &out);
 
+// value arrays for the device stages (encode_gpu.cpp); values are HOST pointers
+struct EncValueStream { uint32_t kind = 0, count = 0, components = 1; const void *values = nullptr; };   // kind: CRTHIP_ENC_*
+struct EncValueResult {
+	std::vector<uint32_t> words;                    // the bit stream (empty for a symbol stream); the writer pads to 4 bytes before it
+	std::vector<std::vector<uint8_t>> blocks;       // entropy-coded log arrays (1 for ARRAY, components for VALUES) or the symbol block
+};
+int encode_value_streams(crthip_ctx *ctx, uint32_t entropy, const std::vector<EncValueStream> &in, std::vector<EncValueResult> &res,
+                         crthip_kernel_times *times);
+
 // context plumbing (batch.cpp)
 int ctx_fail(int code, const char *msg);
 int ctx_device(crthip_ctx *ctx);

@@ -37,6 +37,89 @@ __global__ __launch_bounds__(256) void k_enc_hist(const EncChunk *__restrict__ c
 	if(v) atomicAdd(&counts[(size_t)c.stream*256 + threadIdx.x], v);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// K-ENC-PACK: bit widths + bit packing of one value array per workgroup (OutStream::encodeArray / encodeValues,
+// include/corto/cstream.h:115-164; BitStream::write, src/bitstream.cpp:86-101).  256 items per tile: every thread sizes its
+// item (ARRAY: one width for the N components of an element; VALUES: one width per value, component-major, sign folded),
+// a block scan gives the bit offsets, the fields are OR-ed MSB-first into an LDS tile (ds_or), whole words are flushed
+// coalesced and the partial last word is carried into the next tile.
+constexpr uint32_t ENC_PACK_TILE_WORDS = 256*ENC_PACK_MAX_N;
+
+__device__ __forceinline__ uint32_t enc_needed(int32_t a) {              // cstream.h:105-112
+	if(a == 0) return 0;
+	if(a == -1) return 1;
+	const uint32_t u = a < 0 ? ~(uint32_t)a : (uint32_t)a;
+	return 2u + (31u - (uint32_t)__clz((int)u));
+}
+
+__device__ __forceinline__ void enc_put_bits(uint32_t *buf, uint32_t b, uint32_t v, uint32_t w) {   // w in 1..32, MSB first
+	const uint32_t k = b >> 5, o = b & 31u;
+	if(o + w <= 32u) atomicOr(&buf[k], v << (32u - o - w));
+	else { const uint32_t r = o + w - 32u; atomicOr(&buf[k], v >> r); atomicOr(&buf[k + 1], v << (32u - r)); }
+}
+
+__global__ __launch_bounds__(256) void k_enc_pack(const PackJob *__restrict__ jobs, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const PackJob J = jobs[blockIdx.x];
+	__shared__ uint32_t buf[ENC_PACK_TILE_WORDS + 4];
+	__shared__ uint32_t scan[4];
+	const uint32_t t = threadIdx.x, N = J.N, count = J.count;
+	const bool array = J.kind == 1u;                                      // CRTHIP_ENC_ARRAY
+	const bool bytes = J.kind == 3u;                                      // CRTHIP_ENC_VALUES_I8
+	const uint32_t nitems = array ? count : count*N;
+	CRT_GLOBAL const int32_t *v32 = as_global((const int32_t *)J.values);
+	CRT_GLOBAL const int8_t *v8 = as_global((const int8_t *)J.values);
+	CRT_GLOBAL uint8_t *logs = as_global(J.logs);
+	CRT_GLOBAL uint32_t *words = as_global(J.words);
+	for(uint32_t i = t; i < ENC_PACK_TILE_WORDS + 4; i += 256) buf[i] = 0;
+	__syncthreads();
+	uint32_t carry_bits = 0, gw = 0;
+	for(uint32_t base = 0; base < nitems; base += 256) {
+		const uint32_t it = base + t;
+		uint32_t w = 0, nb = 0, val = 0;
+		if(it < nitems) {
+			if(array) {
+				for(uint32_t c = 0; c < N; c++) { const uint32_t d = enc_needed(v32[(size_t)it*N + c]); w = d > w ? d : w; }
+				nb = w*N;
+			} else {
+				const uint32_t c = it/count, i = it - c*count;
+				int32_t x = bytes ? (int32_t)v8[(size_t)i*N + c] : v32[(size_t)i*N + c];
+				if(x != 0) {
+					const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+					w = 32u - (uint32_t)__clz((int)ax);                     // ilog2(abs) + 1
+					const uint32_t middle = (1u << w) >> 1;
+					val = x < 0 ? ax - middle : (uint32_t)x;
+				}
+				nb = w;
+			}
+			logs[it] = (uint8_t)w;
+		}
+		uint32_t total;
+		const uint32_t excl = block256_exclusive_scan<uint32_t>(nb, scan, &total);
+		if(nb) {
+			uint32_t b = carry_bits + excl;
+			if(array) {
+				const uint32_t mx = 1u << (w - 1u);
+				for(uint32_t c = 0; c < N; c++) { enc_put_bits(buf, b, (uint32_t)v32[(size_t)it*N + c] + mx, w); b += w; }
+			} else enc_put_bits(buf, b, val, w);
+		}
+		__syncthreads();
+		const uint32_t tile_bits = carry_bits + total, fw = tile_bits >> 5;
+		for(uint32_t k = t; k < fw; k += 256) words[gw + k] = buf[k];
+		const uint32_t cw = buf[fw];
+		__syncthreads();
+		for(uint32_t k = t; k <= fw + 1; k += 256) buf[k] = 0;
+		__syncthreads();
+		if(t == 0) buf[0] = cw;
+		__syncthreads();
+		gw += fw; carry_bits = tile_bits & 31u;
+	}
+	if(t == 0) {
+		if(carry_bits) words[gw++] = buf[0];
+		*J.nwords = gw;
+	}
+}
+
 // LDS: remap u8[256] | lengths u16[256] | staged symbol indices u8[ENC_STAGE + ENC_STAGE_PAD] | trie i16[ntrie] (when it fits)
 template <bool TRIE_IN_LDS>
 __device__ __forceinline__ void enc_parse_body(const EncStream &S, CRT_LDS uint8_t *lds) {

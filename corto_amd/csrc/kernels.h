@@ -83,6 +83,7 @@ constexpr uint32_t NORMAL_LDS_MAX = 150*1024;
 
 // k_encode.hip
 __global__ void k_enc_hist(const EncChunk *chunks, uint32_t nchunks, uint32_t *counts);
+__global__ void k_enc_pack(const PackJob *jobs, uint32_t njobs);
 __global__ void k_enc_tun_parse(const EncStream *streams, uint32_t nstreams, uint32_t trie_lds_entries);
 inline uint32_t enc_parse_lds(uint32_t trie_entries) { return 768 + ENC_STAGE + ENC_STAGE_PAD + 2*((trie_entries + 7) & ~7u); }
 constexpr uint32_t ENC_TRIE_LDS_MAX = 24*1024;         // entries (48 KiB) of trie kept in LDS at most; bigger tries are walked in L2

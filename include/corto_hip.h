@@ -231,6 +231,29 @@ int crthip_ctx_sync(crthip_ctx *ctx);
 int64_t crthip_tunstall_encode_blocks(crthip_ctx *ctx, uint32_t n, const uint8_t *const *src, const uint32_t *sizes,
                                       uint8_t *out, size_t cap, uint64_t *block_offset, crthip_kernel_times *times);
 
+/* GPU encoder stage: the value coders of crt::Encoder for a batch of integer arrays - OutStream::encodeArray<int>
+ * (one bit width per element, include/corto/cstream.h:143-164), OutStream::encodeValues<int|char> (component-major, one
+ * width per value, sign folded, :115-141) and plain symbol streams.  Bit widths and bit packing (src/bitstream.cpp:86-101)
+ * run on the device; the width arrays go through the Tunstall coder above without leaving HBM (entropy 1), or are
+ * written raw (entropy 0, src/cstream.cpp:43-64).
+ * Stream i is written as  "u32 nwords | nwords x u32 | block(s)"  (symbol streams: the block alone).  The reference pads
+ * with zeros to a 4-byte stream position between nwords and the words (OutStream::write(BitStream&), cstream.h:79-89);
+ * that depends on where the caller puts the stream, so it is the caller's to insert.  Returns the total size or <0. */
+#define CRTHIP_ENC_SYMBOLS 0u       /* count bytes */
+#define CRTHIP_ENC_ARRAY 1u         /* count x components int32, encodeArray */
+#define CRTHIP_ENC_VALUES_I32 2u    /* count x components int32, encodeValues<int> */
+#define CRTHIP_ENC_VALUES_I8 3u     /* count x components int8, encodeValues<char> (colours) */
+typedef struct crthip_enc_stream {
+	uint32_t kind, count, components, reserved;
+	const void *values;             /* HOST pointer */
+} crthip_enc_stream;
+int64_t crthip_encode_values(crthip_ctx *ctx, uint32_t entropy, uint32_t n, const crthip_enc_stream *streams,
+                             uint8_t *out, size_t cap, uint64_t *stream_offset, crthip_kernel_times *times);
+
+/* crthip_encode with the value coding and the entropy coder on the device (the topology pass, quantisation and the
+ * container stay on the host): same arguments plus the context, byte-identical output. */
+int64_t crthip_encode_gpu(crthip_ctx *ctx, const crthip_mesh *mesh, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface);
+
 #ifdef __cplusplus
 }
 #endif

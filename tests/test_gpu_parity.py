@@ -429,6 +429,96 @@ def test_tunstall_encode_blocks_round_trip_and_reference(ctx):
             assert blocks[i].tobytes() == rc.tunstall_compress_block(streams[i]).tobytes(), i
 
 
+def _model_bits(fields):
+    """MSB-first bit writer (src/bitstream.cpp:86-101): fields = iterable of (value, nbits) -> uint32 words"""
+    acc, nb, words = 0, 0, []
+    for v, n in fields:
+        acc = (acc << n) | (int(v) & ((1 << n) - 1)); nb += n
+        while nb >= 32:
+            words.append((acc >> (nb - 32)) & 0xFFFFFFFF); nb -= 32; acc &= (1 << nb) - 1
+    if nb:
+        words.append((acc << (32 - nb)) & 0xFFFFFFFF)
+    return np.array(words, dtype=np.uint32)
+
+
+def _model_array(a):
+    """OutStream::encodeArray<int> (include/corto/cstream.h:143-164): one width per element -> (words, [logs])"""
+    def needed(x):
+        x = int(x)
+        if x == 0: return 0
+        if x == -1: return 1
+        if x < 0: x = -x - 1
+        return 1 + x.bit_length()
+    logs = np.array([max(needed(x) for x in row) for row in a], dtype=np.uint8)
+    fields = [(int(x) + (1 << (int(d) - 1)), int(d)) for row, d in zip(a, logs) if d for x in row]
+    return _model_bits(fields), [logs]
+
+
+def _model_values(a):
+    """OutStream::encodeValues (include/corto/cstream.h:115-141): component-major, one width per value, sign folded"""
+    logs, fields = [], []
+    for c in range(a.shape[1]):
+        lg = np.zeros(len(a), dtype=np.uint8)
+        for i, x in enumerate(a[:, c]):
+            x = int(x)
+            if x == 0: continue
+            r = abs(x).bit_length()
+            lg[i] = r
+            fields.append((x if x > 0 else -x - (1 << (r - 1)), r))
+        logs.append(lg)
+    return _model_bits(fields), logs
+
+
+def test_encode_values_stage_against_the_cstream_model(ctx):
+    """crthip_encode_values: bit widths + bit packing on the device; the words equal a direct restatement of
+    encodeArray / encodeValues, the blocks equal the (reference-pinned) Tunstall stage run on the model's width arrays"""
+    rng = np.random.default_rng(31)
+    streams, models = [], []
+    for k, (n, N, scale) in enumerate(((2112, 3, 40), (1000, 2, 3), (257, 1, 2000), (513, 4, 1), (1, 3, 5), (300, 16, 9), (4000, 3, 100000))):
+        a = np.rint(rng.normal(0, scale, (n, N))).astype(np.int32)
+        if k == 0:
+            a[5] = (-1, 0, -1); a[6] = 0; a[7] = (2**31 - 1, 0, 0); a[8] = (-2**31 + 1, 1, -2)
+        streams.append((ca.ENC_ARRAY, a)); models.append(_model_array(a))
+        streams.append((ca.ENC_VALUES_I32, a)); models.append(_model_values(a))
+    c8 = np.rint(rng.normal(0, 6, (2112, 4))).clip(-128, 127).astype(np.int8)
+    streams.append((ca.ENC_VALUES_I8, c8)); models.append(_model_values(c8.astype(np.int32)))
+    sym = rng.integers(0, 7, 4319).astype(np.uint8)
+    streams.append((ca.ENC_SYMBOLS, sym)); models.append((None, [sym]))
+    for entropy in (1, 0):
+        got, times = ca.encode_values(ctx, streams, entropy=entropy, with_times=True)
+        assert "enc_pack" in times
+        flat = [lg for _, logs in models for lg in logs]
+        blocks = ca.tunstall_encode_blocks(ctx, flat) if entropy else [np.concatenate([np.array([len(x)], dtype="<u4").view(np.uint8), x]) for x in flat]
+        bi = 0
+        for i, (g, (words, logs)) in enumerate(zip(got, models)):
+            exp = b""
+            if words is not None:
+                exp += np.array([len(words)], dtype="<u4").tobytes() + words.astype("<u4").tobytes()
+            for _ in logs:
+                exp += blocks[bi].tobytes(); bi += 1
+            assert g.tobytes() == exp, (entropy, i, len(g), len(exp))
+
+
+def test_gpu_encoder_blobs_identical_to_the_reference_made_fixtures(ctx):
+    """crthip_encode_gpu (value coding + entropy coder on the device, topology and container on the host) writes the same
+    bytes as the reference encoder did for every golden case, as the host encoder on the C4 units, and for entropy NONE"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from cases import cases
+    from corto_amd import synth
+    for name, mesh, kw in cases():
+        g = load_golden(name)
+        mine = ca.encode(mesh, ctx=ctx, **kw)
+        assert len(mine) == len(g["crt"]) and mine.tobytes() == g["crt"].tobytes(), name
+    for seed in (0, 7):
+        m = synth.bumpy_sphere(64, 32, seed=seed)
+        assert ca.encode(m, normal_prediction=ca.BORDER, ctx=ctx).tobytes() == ca.encode(m, normal_prediction=ca.BORDER).tobytes()
+    cloud = synth.point_cloud(60, 30, seed=3)
+    assert ca.encode(cloud, normal_prediction=ca.DIFF, ctx=ctx).tobytes() == ca.encode(cloud, normal_prediction=ca.DIFF).tobytes()
+    m = synth.bumpy_sphere(260, 130, seed=34)
+    assert ca.encode(m, normal_prediction=ca.BORDER, ctx=ctx).tobytes() == load_golden("mid34k_digest")["crt"].tobytes()
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: inputs synthesised on the box by the repo's own encoder (byte-identical to the reference's,
 # tests/test_encoder_cpu.py), outputs checked against the C oracle and, when oracle/_ref travelled, the reference itself.
