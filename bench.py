@@ -189,6 +189,17 @@ def encoder_stage(ctx, ca):
            "call_ms": round(best * 1e3, 3), "msymbols_per_s": round(nbytes / best / 1e6, 1),
            "kernel_ms": {k: round(v["ms"], 4) for k, v in times.items()},
            "note": "call = upload + device histogram + host dictionaries/tries (2304 x std::sort + 256-word build) + device parse + download + framing; blocks byte-identical to the reference's"}
+    # whole blobs: crthip_encode (host) vs crthip_encode_gpu (value coding + entropy coder on the device), same bytes
+    from corto_amd import synth
+    out["blob_encode"] = {}
+    for key, mesh in (("C4_unit_4k_tris", synth.bumpy_sphere(64, 32, seed=1)), ("C2_mesh_128k_verts", synth.bumpy_sphere(512, 250, seed=1))):
+        kw = dict(position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
+        ca.encode(mesh, ctx=ctx, **kw)
+        t0 = time.perf_counter(); a = ca.encode(mesh, **kw); t_host = time.perf_counter() - t0
+        t0 = time.perf_counter(); b = ca.encode(mesh, ctx=ctx, **kw); t_gpu = time.perf_counter() - t0
+        out["blob_encode"][key] = {"host_ms": round(t_host * 1e3, 3), "gpu_stages_ms": round(t_gpu * 1e3, 3), "identical": bool(a.tobytes() == b.tobytes()),
+                                   "crt_bytes": int(len(a))}
+    out["blob_encode"]["note"] = "topology (CLERS), quantisation and prediction stay on the host in both: one object at a time the device stages do not pay for their transfers and syncs - they are for batches of streams (above)"
     try:
         from oracle import refcodec as rc
         if rc.available():

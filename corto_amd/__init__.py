@@ -228,24 +228,21 @@ def encode(mesh, position_bits=14, position_q=0.0, normal_bits=10, normal_predic
     if exif:
         flat = b"".join(k.encode() + b"\0" + v.encode() + b"\0" for k, v in exif.items())
         m.exif = flat; m.nexif = len(exif)
-    if ctx is not None:                                  # one pass: the device stages are not run twice just to learn the size
-        cap = 64 * (mesh.nvert + mesh.nface) + 65536
+    cap = 64 * (mesh.nvert + mesh.nface) + 65536            # one pass unless the estimate is too small
+    for _ in range(2):
         out = np.zeros(cap + 16, dtype=np.uint8)
         off = (-out.ctypes.data) % 16
-        n = lib().crthip_encode_gpu(ctx.handle, C.byref(m), out[off:].ctypes.data_as(C.c_void_p), cap, None, None)
+        dst = out[off:].ctypes.data_as(C.c_void_p)
+        if ctx is not None:
+            n = lib().crthip_encode_gpu(ctx.handle, C.byref(m), dst, cap, None, None)
+        else:
+            n = lib().crthip_encode(C.byref(m), dst, cap, None, None)
         if n < 0:
             _check(int(n))
-        if n > cap:
-            raise CortoError(-9, "encode: blob larger than the estimate")
-        return out[off:off + int(n)]
-    n = lib().crthip_encode(C.byref(m), None, 0, None, None)
-    if n < 0:
-        _check(int(n))
-    out = np.zeros(int(n) + 16, dtype=np.uint8)
-    off = (-out.ctypes.data) % 16
-    view = out[off:off + int(n)]
-    lib().crthip_encode(C.byref(m), view.ctypes.data_as(C.c_void_p), int(n), None, None)
-    return view
+        if n <= cap:
+            return out[off:off + int(n)]
+        cap = int(n)
+    raise CortoError(-9, "encode: size changed between calls")
 
 
 class Context:
