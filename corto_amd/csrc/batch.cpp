@@ -176,6 +176,7 @@ struct Plan {
 	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
 	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
 	HostArr<DeltaJob> delta;
+	HostArr<DeltaGroup> delta_groups;                       // blobs whose attributes share one k_delta_wave workgroup
 	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
 	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first, normal_fused_ids;
 	uint32_t normal_fused_lds = 0;
@@ -192,7 +193,7 @@ struct Plan {
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
 	void reset() {                                          // keep every vector's capacity
 		clr(tun); clr(tun_chunk_stream); clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
-		clr(unpack); clr(unpack_chunk_job); clr(delta); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
+		clr(unpack); clr(unpack_chunk_job); clr(delta); clr(delta_groups); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
 		clr(nf_block_job); clr(nf_block_first); clr(normal_fused_ids); clr(dequant); clr(dequant_block_job);
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
@@ -261,6 +262,7 @@ extern "C" int crthip_device_count(void) {
 	return n;
 }
 
+extern "C" void crthip_ctx_destroy(crthip_ctx *c);
 extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	if(!out) return fail(CRTHIP_E_ARGUMENT);
 	int n = 0;
@@ -272,6 +274,14 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
+	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
+	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
+	   hipFuncSetAttribute((const void *)k_delta_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA_WAVE_LDS_MAX) != hipSuccess ||
+	   hipFuncSetAttribute((const void *)k_normal_blob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NORMAL_LDS_MAX) != hipSuccess ||
+	   hipFuncSetAttribute((const void *)k_enc_tun_parse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_parse_lds(ENC_TRIE_LDS_MAX)) != hipSuccess) {
+		crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+	}
 	*out = c;
 	return CRTHIP_OK;
 }
@@ -445,7 +455,10 @@ static int32_t f2i_x86_host(float x) {
 
 static const uint32_t DELTA_LDS_MAX = 64*1024;
 // launch classes of K-DELTA: 2 = values + prediction graph fit LDS, one wave (k_delta_wave); else the dataflow workgroup, 0 = large, 1 = small
-static inline uint64_t delta_wave_need(const DeltaJob &d) { return delta_wave_lds(d.nvert, d.N, d.is_u8 != 0); }
+static inline uint64_t delta_wave_need(const DeltaJob &d) {           // alone in a workgroup; ~0 wraps to "too big"
+	const uint64_t g = delta_wave_graph_lds(d.nvert), a = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
+	return g == ~0ull || a == ~0ull ? ~0ull : g + a;
+}
 static inline int delta_class(const DeltaJob &d) { return delta_wave_need(d) <= DELTA_WAVE_LDS_MAX ? 2 : d.nvert > DELTA_SMALL_NVERT ? 0 : 1; }
 static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 32767 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
@@ -684,7 +697,7 @@ static int build_and_launch(crthip_batch *b) {
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real;
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
 					const uint64_t need = (((uint64_t)nvert*N*(is_u8 ? 1 : 4) + 15) & ~15ull) + nvert;
-					if(delta_class(d) == 2) pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)delta_wave_need(d));
+					if(delta_class(d) == 2) {}
 					else if(need <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((need + 15) & ~15ull));
 					pl.delta.v.push_back(d);
 				} else {
@@ -754,7 +767,26 @@ static int build_and_launch(crthip_batch *b) {
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) == 0; });
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) <= 1; });
-	place(pl.delta); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
+	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph (k_delta_wave): consecutive
+		// class-2 jobs with the same prediction array, up to DELTA_GROUP_MAX
+		size_t j = 0;
+		while(j < pl.delta.v.size() && delta_class(pl.delta.v[j]) != 2) j++;
+		while(j < pl.delta.v.size()) {
+			const DeltaJob &d0 = pl.delta.v[j];
+			uint64_t lds = delta_wave_need(d0);
+			DeltaGroup g{(uint32_t)j, 1};
+			while(j + g.count < pl.delta.v.size() && g.count < DELTA_GROUP_MAX) {
+				const DeltaJob &d = pl.delta.v[j + g.count];
+				const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
+				if(d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;
+				lds += more; g.count++;
+			}
+			pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)lds);
+			pl.delta_groups.v.push_back(g);
+			j += g.count;
+		}
+	}
+	place(pl.delta); place(pl.delta_groups); place(pl.cloud); place(pl.cloud_chunk_job); place(pl.normal); place(pl.nv_block_job); place(pl.nv_block_first);
 	place(pl.nf_block_job); place(pl.nf_block_first); place(pl.normal_fused_ids); place(pl.dequant); place(pl.dequant_block_job);
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
 	pl.total = cv.take(0);
@@ -800,7 +832,7 @@ static int build_and_launch(crthip_batch *b) {
 	uint8_t *stage = (uint8_t *)ctx->staging.p;
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
 	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
-	put(pl.delta); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
+	put(pl.delta); put(pl.delta_groups); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
 	t2 = now_us();
@@ -833,8 +865,6 @@ static int build_and_launch(crthip_batch *b) {
 	};
 	auto topology = [&]() -> int {
 		if(!pl.topo_lds_ids.v.empty() || !pl.topo_big_ids.v.empty()) {
-			static uint32_t lds_attr = 0;                      // raise the dynamic-LDS limit once
-			if(std::max(pl.topo_lds, pl.topo_big_lds) > lds_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX)); lds_attr = TOPO_LDS_MAX; }
 			LT.begin("topology_lds");
 			if(!pl.topo_big_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_big_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_big_lds, st, D(pl.topo), D(pl.topo_big_ids), nj); }
 			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); }
@@ -874,12 +904,10 @@ static int build_and_launch(crthip_batch *b) {
 	if(!pl.delta.v.empty()) {
 		uint32_t ncls[3] = {0, 0, 0};
 		for(auto &d : pl.delta.v) ncls[delta_class(d)]++;
-		static uint32_t dw_attr = 0;                           // raise the dynamic-LDS limit once
-		if(pl.delta_wave_lds > 64*1024 && !dw_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_delta_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA_WAVE_LDS_MAX)); dw_attr = 1; }
 		LT.begin("delta_mesh");
 		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), ncls[0], pl.delta_lds);
 		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), pl.delta_lds, st, D(pl.delta) + ncls[0], ncls[1], pl.delta_lds);
-		if(ncls[2]) hipLaunchKernelGGL(k_delta_wave, dim3(ncls[2]), dim3(64), pl.delta_wave_lds, st, D(pl.delta) + ncls[0] + ncls[1], ncls[2]);
+		if(ncls[2]) hipLaunchKernelGGL(k_delta_wave, dim3((uint32_t)pl.delta_groups.v.size()), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups), (uint32_t)pl.delta_groups.v.size());
 		LT.end();
 	}
 	if(cloud_chunks) {
@@ -889,8 +917,6 @@ static int build_and_launch(crthip_batch *b) {
 	}
 	const uint32_t nvb = (uint32_t)pl.nv_block_job.v.size(), nfb = (uint32_t)pl.nf_block_job.v.size();
 	if(!pl.normal_fused_ids.v.empty()) {
-		static uint32_t nl_attr = 0;
-		if(pl.normal_fused_lds > nl_attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_normal_blob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NORMAL_LDS_MAX)); nl_attr = NORMAL_LDS_MAX; }
 		const uint32_t nj = (uint32_t)pl.normal_fused_ids.v.size();
 		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), pl.normal_fused_lds, st, D(pl.normal), D(pl.normal_fused_ids), nj); LT.end();
 	}

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/corto_hip.h"
@@ -78,9 +79,16 @@ int tun_encode_device(hipStream_t st, uint32_t n, const uint8_t *const *d_src, c
 	std::vector<uint64_t> tab_off(n, 0);
 	uint64_t tbytes = 0;
 	uint32_t trie_lds = 0;
+	{	// independent per stream: spread over a few host threads when there are many
+		const uint32_t nthreads = n >= 64 ? std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+		auto work = [&](uint32_t t) { for(uint32_t i = t; i < n; i += nthreads) if(sizes[i]) tun_encoder_tables(&counts[(size_t)i*256], sizes[i], tabs[i]); };
+		std::vector<std::thread> pool;
+		for(uint32_t t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+		work(0);
+		for(auto &th : pool) th.join();
+	}
 	for(uint32_t i = 0; i < n; i++) {
 		if(sizes[i] == 0) continue;
-		tun_encoder_tables(&counts[(size_t)i*256], sizes[i], tabs[i]);
 		if(tabs[i].nsym < 2) continue;                                // one symbol: no payload (tunstall.cpp:386-389)
 		gpu_ids.push_back(i);
 		tab_off[i] = tbytes;
@@ -118,8 +126,6 @@ int tun_encode_device(hipStream_t st, uint32_t n, const uint8_t *const *d_src, c
 		memcpy(h_tab.data() + o_streams, es.data(), es.size()*sizeof(EncStream));
 		ENC_TRY(hipMemcpyAsync(dtab.p, h_tab.data(), tab_total, hipMemcpyHostToDevice, st));
 		const uint32_t lds = enc_parse_lds(trie_lds);
-		static bool attr_set = false;
-		if(lds > 64*1024 && !attr_set) { ENC_TRY(hipFuncSetAttribute((const void *)k_enc_tun_parse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_parse_lds(ENC_TRIE_LDS_MAX))); attr_set = true; }
 		ENC_TRY(hipEventRecord(ev.e[2], st));
 		hipLaunchKernelGGL(k_enc_tun_parse, dim3((uint32_t)es.size()), dim3(64), lds, st, (const EncStream *)(tb + o_streams), (uint32_t)es.size(), trie_lds);
 		ENC_TRY(hipEventRecord(ev.e[3], st));

@@ -708,16 +708,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T, int NC>
 __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, CRT_LDS uint8_t *fired,
-                                               CRT_LDS const uint16_t *starts, uint32_t ns, uint32_t nvert, uint32_t Nrt) {
+                                               CRT_LDS const uint16_t *starts, uint32_t ns, uint32_t nvert, uint32_t Nrt, bool para) {
 	const uint32_t n = NC ? (uint32_t)NC : Nrt;
-	uint32_t k = threadIdx.x;
+	uint32_t k = lane_id();
 	bool active = k < ns;
 	uint32_t i = active ? starts[k] : 0u, end = active ? (k + 1 < ns ? (uint32_t)starts[k + 1] : nvert) : 0u;
 	uint32_t a = active ? pa[i] : 0u, bc = active ? pbc[i] : 0u;
 	while(__any(active)) {
 		if(active) {
-			const bool inv = a == 0xFFFFu;                                   // malformed triple (and vertex 0): the value stays
-			const uint32_t aa = inv ? 0u : a, b = bc & 0xFFFFu, c = bc >> 16;
+			// malformed triple (and vertex 0): the value stays.  v += v[a] alone: b = c = vertex 0 cancel
+			const bool inv = a == 0xFFFFu || (para && bc == 0xFFFFFFFFu);
+			const uint32_t aa = inv ? 0u : a, b = inv || !para ? 0u : bc & 0xFFFFu, c = inv || !para ? 0u : bc >> 16;
 			const uint32_t ready = (uint32_t)fired[aa] & fired[b] & fired[c];
 			if(NC) {                                                         // values are fetched with the flags: one LDS round trip per pass
 				T x[NC ? NC : 1];
@@ -744,97 +745,118 @@ __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint1
 	}
 }
 
-__global__ __launch_bounds__(64) void k_delta_wave(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;
-	const DeltaJob J = jobs[blockIdx.x];
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const uint32_t lane = threadIdx.x, nvert = J.nvert, N = J.N;
-	const uint32_t bytes = nvert*N*(J.is_u8 ? 1u : 4u);
-	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
-	CRT_LDS uint16_t *pa = (CRT_LDS uint16_t *)(l8 + delta_wave_vbytes(nvert, N, J.is_u8));
-	CRT_LDS uint32_t *pbc = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)pa + delta_wave_a_bytes(nvert));
-	CRT_LDS uint8_t *fired = (CRT_LDS uint8_t *)(pbc + nvert);
-	CRT_LDS uint16_t *starts = (CRT_LDS uint16_t *)(fired + delta_wave_fired_bytes(nvert));
-	CRT_GLOBAL uint8_t *g8 = as_global((uint8_t *)J.values);
-	CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
+// values of one attribute <-> LDS by one wave: 16-byte vectors, eight in flight per lane (a lone wave that waited for each load
+// before issuing the next would spend ~1 us per KB).  LDS mirrors the caller's alignment phase so that both sides of the
+// body are 16-aligned; unaligned heads/tails (3-component colours, odd caller buffers) go bytewise.
+struct DeltaStage { CRT_LDS uint8_t *l8; CRT_GLOBAL uint8_t *g8; uint32_t bytes, head, nvec; };
 
-	// values -> LDS: 16-byte vectors, eight in flight per lane (a lone wave that waited for each load before issuing the next
-	// would spend ~1 us per KB).  LDS mirrors the caller's alignment phase so that both sides of the body are 16-aligned;
-	// unaligned heads/tails (3-component colours, odd caller buffers) go bytewise.
-	const uint32_t phase = (uint32_t)((uintptr_t)J.values & 15);
-	const uint32_t head = (16 - phase) & 15;
+__device__ __forceinline__ DeltaStage delta_stage_plan(CRT_LDS uint8_t *lds, void *values, uint32_t bytes) {
+	DeltaStage S;
+	const uint32_t phase = (uint32_t)((uintptr_t)values & 15);
 	const bool vec = bytes >= 64;
-	const uint32_t nvec = vec ? (bytes - head) >> 4 : 0u;
-	l8 += vec ? phase : 0u;                                              // (l8 + head) is 16-aligned; phase % 4 == 0 whenever the caller's ints are aligned
-	CRT_GLOBAL const u32x4 *g4 = (CRT_GLOBAL const u32x4 *)(g8 + head);
-	CRT_LDS u32x4 *l4 = (CRT_LDS u32x4 *)(l8 + head);
-	for(uint32_t i = lane; i < nvec; i += 64*8) {
+	S.g8 = as_global((uint8_t *)values); S.bytes = bytes;
+	S.head = vec ? (16 - phase) & 15 : 0u;
+	S.nvec = vec ? (bytes - S.head) >> 4 : 0u;
+	S.l8 = lds + (vec ? phase : 0u);                                     // (l8 + head) is 16-aligned; phase % 4 == 0 whenever the caller's ints are aligned
+	return S;
+}
+
+template <bool IN>
+__device__ __forceinline__ void delta_stage_copy(const DeltaStage &S) {
+	const uint32_t lane = lane_id();
+	CRT_GLOBAL u32x4 *g4 = (CRT_GLOBAL u32x4 *)(S.g8 + S.head);
+	CRT_LDS u32x4 *l4 = (CRT_LDS u32x4 *)(S.l8 + S.head);
+	for(uint32_t i = lane; i < S.nvec; i += 64*8) {
 		u32x4 t[8];
 #pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) t[u] = g4[i + u*64];
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) t[u] = IN ? g4[i + u*64] : l4[i + u*64];
 #pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) l4[i + u*64] = t[u];
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) { if(IN) l4[i + u*64] = t[u]; else g4[i + u*64] = t[u]; }
 	}
-	const uint32_t nhead = vec ? head : 0u;
-	for(uint32_t i = lane; i < nhead; i += 64) l8[i] = g8[i];
-	for(uint32_t i = nhead + nvec*16 + lane; i < bytes; i += 64) l8[i] = g8[i];
+	for(uint32_t i = lane; i < S.head; i += 64) { if(IN) S.l8[i] = S.g8[i]; else S.g8[i] = S.l8[i]; }
+	for(uint32_t i = S.head + S.nvec*16 + lane; i < S.bytes; i += 64) { if(IN) S.l8[i] = S.g8[i]; else S.g8[i] = S.l8[i]; }
+}
 
-	// prediction triples -> a | (b, c) | stretch starts.  Four rounds of 64 vertices in flight.
-	uint32_t ns = 0;
-	for(uint32_t base = 0; base < nvert; base += 256) {
-		uint32_t ta[4], tb[4], tc[4];
+// One workgroup per blob: up to four attributes share the prediction graph in LDS (a | b,c | stretch starts), one wave each walks
+// it with its own fired flags; the graph is made by the first wave that has no attribute (or by wave 0 before its own staging).
+__global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__ jobs, const DeltaGroup *__restrict__ groups, uint32_t ngroups) {
+	if(blockIdx.x >= ngroups) return;
+	const DeltaGroup G = groups[blockIdx.x];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	__shared__ uint32_t ns_shared;
+	const uint32_t lane = lane_id(), w = wave_id();
+	const DeltaJob J0 = jobs[G.first];
+	const uint32_t nvert = J0.nvert;
+	// LDS: values of every attribute | a u16 | b,c u32 | starts u16 | fired u8 x count
+	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
+	uint32_t myoff = 0, vtot = 0;
+	for(uint32_t k = 0; k < G.count; k++) { const uint32_t vb = delta_wave_vbytes(nvert, jobs[G.first + k].N, jobs[G.first + k].is_u8 != 0); if(k < w) myoff += vb; vtot += vb; }
+	CRT_LDS uint16_t *pa = (CRT_LDS uint16_t *)(l8 + vtot);
+	CRT_LDS uint32_t *pbc = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)pa + delta_wave_a_bytes(nvert));
+	CRT_LDS uint16_t *starts = (CRT_LDS uint16_t *)(pbc + nvert);
+	CRT_LDS uint8_t *fired_all = (CRT_LDS uint8_t *)starts + delta_wave_a_bytes(nvert);
+	const uint32_t builder = G.count < 4 ? G.count : 0u;
+	if(w == builder) {
+		// prediction triples -> a | (b, c) | stretch starts.  Four rounds of 64 vertices in flight.
+		CRT_GLOBAL const uint32_t *pred = as_global(J0.pred);
+		uint32_t ns = 0;
+		for(uint32_t base = 0; base < nvert; base += 256) {
+			uint32_t ta[4], tb[4], tc[4];
 #pragma unroll
-		for(uint32_t u = 0; u < 4; u++) {
-			const uint32_t i = base + u*64 + lane;
-			ta[u] = tb[u] = tc[u] = 0;
-			if(i < nvert) { ta[u] = pred[(size_t)i*3]; tb[u] = tc[u] = ta[u]; if(J.parallelogram) { tb[u] = pred[(size_t)i*3 + 1]; tc[u] = pred[(size_t)i*3 + 2]; } }
-		}
-#pragma unroll
-		for(uint32_t u = 0; u < 4; u++) {
-			const uint32_t i = base + u*64 + lane;
-			const bool in = i < nvert;
-			const bool valid = in && ta[u] < i && tb[u] < i && tc[u] < i;   // well-formed streams always predict from earlier vertices
-			const bool start = in && !(valid && ta[u] + 1 == i);
-			if(in) {
-				pa[i] = (uint16_t)(valid ? ta[u] : 0xFFFFu);
-				pbc[i] = valid && J.parallelogram ? tb[u] | (tc[u] << 16) : 0u;   // v += v[a] alone: b = c = vertex 0 cancel
-				fired[i] = i == 0;
+			for(uint32_t u = 0; u < 4; u++) {
+				const uint32_t i = base + u*64 + lane;
+				ta[u] = tb[u] = tc[u] = 0;
+				if(i < nvert) { ta[u] = pred[(size_t)i*3]; tb[u] = pred[(size_t)i*3 + 1]; tc[u] = pred[(size_t)i*3 + 2]; }
 			}
-			const uint64_t m = __ballot(start);
-			if(start) starts[ns + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-			ns += __popcll(m);
+#pragma unroll
+			for(uint32_t u = 0; u < 4; u++) {
+				const uint32_t i = base + u*64 + lane;
+				const bool in = i < nvert;
+				const bool va = in && ta[u] < i;                                // well-formed streams always predict from earlier vertices
+				const bool start = in && !(va && ta[u] + 1 == i);
+				if(in) {
+					pa[i] = (uint16_t)(va ? ta[u] : 0xFFFFu);
+					pbc[i] = tb[u] < i && tc[u] < i ? tb[u] | (tc[u] << 16) : 0xFFFFFFFFu;
+				}
+				const uint64_t m = __ballot(start);
+				if(start) starts[ns + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+				ns += __popcll(m);
+			}
 		}
+		if(lane == 0) ns_shared = ns;
+	}
+	DeltaJob J = J0;
+	DeltaStage S{};
+	CRT_LDS uint8_t *fired = fired_all + w*delta_wave_fired_bytes(nvert);
+	if(w < G.count) {
+		J = jobs[G.first + w];
+		S = delta_stage_plan(l8 + myoff, J.values, nvert*J.N*(J.is_u8 ? 1u : 4u));
+		delta_stage_copy<true>(S);
+		for(uint32_t i = lane; i < nvert; i += 64) fired[i] = i == 0;
 	}
 	__syncthreads();
-
-	if(J.is_u8) {
-		CRT_LDS uint8_t *v = l8;
-		switch(N) {
-		case 3: delta_wave_run<uint8_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N); break;
-		case 4: delta_wave_run<uint8_t, 4>(v, pa, pbc, fired, starts, ns, nvert, N); break;
-		default: delta_wave_run<uint8_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N); break;
+	if(w < G.count) {
+		const uint32_t ns = ns_shared, N = J.N;
+		const bool para = J.parallelogram != 0;
+		if(J.is_u8) {
+			CRT_LDS uint8_t *v = S.l8;
+			switch(N) {
+			case 3: delta_wave_run<uint8_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			case 4: delta_wave_run<uint8_t, 4>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			default: delta_wave_run<uint8_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			}
+		} else {
+			CRT_LDS uint32_t *v = (CRT_LDS uint32_t *)S.l8;
+			switch(N) {
+			case 1: delta_wave_run<uint32_t, 1>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			case 2: delta_wave_run<uint32_t, 2>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			case 3: delta_wave_run<uint32_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			default: delta_wave_run<uint32_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			}
 		}
-	} else {
-		CRT_LDS uint32_t *v = (CRT_LDS uint32_t *)l8;
-		switch(N) {
-		case 1: delta_wave_run<uint32_t, 1>(v, pa, pbc, fired, starts, ns, nvert, N); break;
-		case 2: delta_wave_run<uint32_t, 2>(v, pa, pbc, fired, starts, ns, nvert, N); break;
-		case 3: delta_wave_run<uint32_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N); break;
-		default: delta_wave_run<uint32_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N); break;
-		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		delta_stage_copy<false>(S);
 	}
-	__syncthreads();
-
-	CRT_GLOBAL u32x4 *o4 = (CRT_GLOBAL u32x4 *)(g8 + head);
-	for(uint32_t i = lane; i < nvec; i += 64*8) {
-		u32x4 t[8];
-#pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) t[u] = l4[i + u*64];
-#pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < nvec) o4[i + u*64] = t[u];
-	}
-	for(uint32_t i = lane; i < nhead; i += 64) g8[i] = l8[i];
-	for(uint32_t i = nhead + nvec*16 + lane; i < bytes; i += 64) g8[i] = l8[i];
 }
 
 } // namespace corto_hip

@@ -53,16 +53,20 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of the dataflow workgroup of one (blob, attribute)
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);
-// one wave per (blob, attribute) whose values + prediction graph fit LDS (k_mesh.hip): values | a u16 | b,c u32 | fired u8 | stretch starts u16
-constexpr uint32_t DELTA_WAVE_LDS_MAX = 128*1024;
+// one workgroup per blob, one wave per attribute (up to four), when the attributes' values + the prediction graph fit LDS (k_mesh.hip):
+// values of every attribute | a u16 | b,c u32 | stretch starts u16 | fired u8 per attribute
+constexpr uint32_t DELTA_WAVE_LDS_MAX = 128*1024, DELTA_GROUP_MAX = 4;
 __host__ __device__ inline uint32_t delta_wave_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return ((nvert*N*(is_u8 ? 1u : 4u) + 15u) & ~15u) + 32u; }
 __host__ __device__ inline uint32_t delta_wave_a_bytes(uint32_t nvert) { return (2u*nvert + 15u) & ~15u; }
 __host__ __device__ inline uint32_t delta_wave_fired_bytes(uint32_t nvert) { return (nvert + 15u) & ~15u; }
-__host__ __device__ inline uint64_t delta_wave_lds(uint32_t nvert, uint32_t N, bool is_u8) {
+// LDS of the shared graph (+64 slack) and of one attribute riding on it; ~0 when the vertex ids do not fit 16 bits
+__host__ __device__ inline uint64_t delta_wave_graph_lds(uint32_t nvert) { return nvert > 65534u ? ~0ull : 2ull*delta_wave_a_bytes(nvert) + 4ull*nvert + 64; }
+__host__ __device__ inline uint64_t delta_wave_attr_lds(uint32_t nvert, uint32_t N, bool is_u8) {
 	if(nvert > 65534u || (uint64_t)nvert*N > (1u << 24)) return ~0ull;
-	return (uint64_t)delta_wave_vbytes(nvert, N, is_u8) + delta_wave_a_bytes(nvert) + 4ull*nvert + delta_wave_fired_bytes(nvert) + 2ull*nvert + 64;
+	return (uint64_t)delta_wave_vbytes(nvert, N, is_u8) + delta_wave_fired_bytes(nvert);
 }
-__global__ void k_delta_wave(const DeltaJob *jobs, uint32_t njobs);
+struct DeltaGroup { uint32_t first, count; };     // DeltaJob entries [first, first + count) of one blob
+__global__ void k_delta_wave(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
 
 // k_normal.hip
 __global__ void k_normal_diff(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks);
