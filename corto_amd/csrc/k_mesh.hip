@@ -270,6 +270,23 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mov_b32 v47, %[t0]\n" \
 	"  global_store_dword v47, v44, %[faceb]\n" \
 	"  global_store_short v47, v46, %[faceb] offset:4\n"
+// after a consumed symbol: advance the nibble window (every eighth symbol takes the out-of-line refill), test the end of the
+// group, and dispatch the NEXT symbol right here - "threaded": one taken branch per symbol instead of four (a taken branch
+// restarts the lone wave's instruction fetch, ~20 clocks each)
+#define TOPO_ASM_TAIL \
+							"  s_lshr_b32 %[sw], %[sw], 4\n" \
+							"  s_add_u32 %[cler], %[cler], 1\n" \
+							"  s_and_b32 %[t0], %[cler], 7\n"   /* SCC = result != 0 */ \
+							"  s_cbranch_scc0 Lrefill_%=\n" \
+							"  s_cmp_lt_u32 %[start], %[end]\n" \
+							"  s_cbranch_scc0 Lexit_%=\n" \
+							"  s_and_b32 %[c], %[sw], 15\n" \
+							"  s_cbranch_scc0 Lvertex_%=\n" \
+							"  s_cmp_eq_u32 %[c], 1\n" \
+							"  s_cbranch_scc1 Lleft_%=\n" \
+							"  s_cmp_eq_u32 %[c], 2\n" \
+							"  s_cbranch_scc1 Lright_%=\n" \
+							"  s_branch Lexit_%=\n"
 #define TOPO_FAST_PATH(FACE) \
 						asm volatile( \
 							"Ltop_%=:\n" \
@@ -314,7 +331,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_mov_b32 %[v1], %[vc]\n" \
 							"  s_mov_b32 %[en], %[t1]\n" \
 							"  s_add_u32 %[vc], %[vc], 1\n" \
-							"  s_branch Lconsumed_%=\n" \
+							TOPO_ASM_TAIL \
    /* ---------------- LEFT (decoder.cpp:311-317), neighbour in the ring */ \
 							"Lleft_%=:\n" \
 							"  s_cmp_gt_u32 %[ep], %[mask]\n" \
@@ -333,7 +350,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_mov_b32 %[v2], %[v0]\n" \
 							"  s_mov_b32 %[v0], %[t1]\n" \
 							"  s_mov_b32 %[ep], %[t2]\n" \
-							"  s_branch Lconsumed_%=\n" \
+							TOPO_ASM_TAIL \
    /* ---------------- RIGHT (decoder.cpp:319-325): against the edge VERTEX just made (cached), or a ring neighbour */ \
 							"Lright_%=:\n" \
 							"  s_lshl_b32 %[t0], %[en], 4\n" \
@@ -360,12 +377,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_mov_b32 %[v2], %[v1]\n" \
 							"  s_mov_b32 %[v1], %[t1]\n" \
 							"  s_mov_b32 %[en], %[t2]\n" \
-   /* ---------------- the symbol is consumed; every eighth one pulls the next word of the window */ \
-							"Lconsumed_%=:\n" \
-							"  s_lshr_b32 %[sw], %[sw], 4\n" \
-							"  s_add_u32 %[cler], %[cler], 1\n" \
-							"  s_and_b32 %[t0], %[cler], 7\n" \
-							"  s_cbranch_scc1 Lnext_%=\n" \
+							TOPO_ASM_TAIL \
+   /* ---------------- every eighth symbol: the next word of the window, then the loop test and the dispatch at the top */ \
+							"Lrefill_%=:\n" \
 							"  s_mov_b32 %[sw], %[swn]\n" \
 							"  s_lshr_b32 %[t0], %[cler], 3\n" \
 							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
@@ -375,7 +389,6 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  ds_read_b32 v55, v55\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
 							"  v_readfirstlane_b32 %[swn], v55\n" \
-							"Lnext_%=:\n" \
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc1 Ltop_%=\n" \
 							"Lexit_%=:\n" \
