@@ -187,7 +187,7 @@ struct Plan {
 	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
 	uint64_t jobs_begin = 0, jobs_bytes = 0;
 	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
-	uint32_t delta_lds = 0, delta_wave_lds = 0;
+	uint32_t delta_wave_lds = 0;
 	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
 	uint64_t total = 0;
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
@@ -198,7 +198,7 @@ struct Plan {
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
 		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
-		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_lds = 0; delta_wave_lds = 0;
+		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0;
 		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0;
 	}
 };
@@ -453,7 +453,6 @@ static int32_t f2i_x86_host(float x) {
 } // namespace
 
 
-static const uint32_t DELTA_LDS_MAX = 64*1024;
 // launch classes of K-DELTA: 2 = values + prediction graph fit LDS, one wave (k_delta_wave); else the dataflow workgroup, 0 = large, 1 = small
 static inline uint64_t delta_wave_need(const DeltaJob &d) {           // alone in a workgroup; ~0 wraps to "too big"
 	const uint64_t g = delta_wave_graph_lds(d.nvert), a = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
@@ -525,8 +524,11 @@ static int build_and_launch(crthip_batch *b) {
 		for(size_t k = 0; k < L.attrs.size(); k++) {
 			if(!P.bind[k].buffer) continue;
 			const AttrHeader &a = L.h.attrs[k];
-			const uint64_t per = a.codec == CRTHIP_CODEC_NORMAL ? 8 : a.codec == CRTHIP_CODEC_COLOR ? a.N : (uint64_t)a.N*4;
-			if(((L.h.nvert*per + 15) & ~15ull) + L.h.nvert > DELTA_LDS_MAX) bs[i].attr[k].fired = cv.take((uint64_t)L.h.nvert + 16, 16);
+			const bool u8 = a.codec == CRTHIP_CODEC_COLOR;
+			const uint32_t n = a.codec == CRTHIP_CODEC_NORMAL ? 2u : a.N;
+			const uint64_t g = delta_wave_graph_lds(L.h.nvert), w = delta_wave_attr_lds(L.h.nvert, n, u8);
+			if(g == ~0ull || w == ~0ull || g + w > DELTA_WAVE_LDS_MAX)          // k_delta_mesh: fired flags (zeroed) + the list of stretch starts behind them
+				bs[i].attr[k].fired = cv.take((((uint64_t)L.h.nvert + 15) & ~15ull) + 4ull*L.h.nvert + 16, 16);
 		}
 	}
 	pl.zero_end = cv.take(0);
@@ -696,9 +698,6 @@ static int build_and_launch(crthip_batch *b) {
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real;
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
-					const uint64_t need = (((uint64_t)nvert*N*(is_u8 ? 1 : 4) + 15) & ~15ull) + nvert;
-					if(delta_class(d) == 2) {}
-					else if(need <= DELTA_LDS_MAX) pl.delta_lds = std::max<uint32_t>(pl.delta_lds, (uint32_t)((need + 15) & ~15ull));
 					pl.delta.v.push_back(d);
 				} else {
 					CloudJob c{};
@@ -905,8 +904,8 @@ static int build_and_launch(crthip_batch *b) {
 		uint32_t ncls[3] = {0, 0, 0};
 		for(auto &d : pl.delta.v) ncls[delta_class(d)]++;
 		LT.begin("delta_mesh");
-		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), pl.delta_lds, st, D(pl.delta), ncls[0], pl.delta_lds);
-		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), pl.delta_lds, st, D(pl.delta) + ncls[0], ncls[1], pl.delta_lds);
+		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
+		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
 		if(ncls[2]) hipLaunchKernelGGL(k_delta_wave, dim3((uint32_t)pl.delta_groups.v.size()), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups), (uint32_t)pl.delta_groups.v.size());
 		LT.end();
 	}

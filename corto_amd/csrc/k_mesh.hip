@@ -634,76 +634,107 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 // when they fit (dynamic LDS = values | flags), else in HBM (workgroup-scope release/acquire; one CU's waves
 // share its L1).
 
-template <typename T, typename VPtr, typename FPtr>
-__device__ void delta_dataflow(VPtr v, FPtr fired, CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t N, bool para, uint32_t THREADS) {
-	uint32_t i = threadIdx.x == 0 ? THREADS : threadIdx.x;
-	// prediction triples are fetched ONE VERTEX AHEAD: a fetch in the fire path would park the whole wave on an
-	// HBM/L2 round trip while its other lanes are ready to fire.
-	uint32_t na = 0, nb = 0, nc = 0;
-	auto prefetch = [&](uint32_t j) {
-		if(j < nvert) { na = pred[(size_t)j*3]; nb = na; nc = na; if(para) { nb = pred[(size_t)j*3 + 1]; nc = pred[(size_t)j*3 + 2]; } }
+// Attributes too big for LDS (meshes of tens of thousands of vertices): the same stretch walk as k_delta_wave below, over
+// HBM/L2 by one workgroup.  Thread k walks stretches k, k+T, ... in order and carries the value of the vertex it has just
+// finished in registers (a = i-1 inside a stretch), so the only waiting is for the two parents one ring back - which the
+// neighbouring stretch, two steps ahead, has normally published already.  Flags and values cross waves through L2 with
+// release/acquire at workgroup scope.  One loop, test-and-fire in the same iteration: a lane that spun in an inner wait
+// loop would keep the lanes it is waiting for (same wave) parked at the reconvergence point.
+template <typename T, int NC>
+__device__ void delta_stretch_global(CRT_GLOBAL T *v, CRT_GLOBAL uint8_t *fired, CRT_GLOBAL const uint32_t *starts, uint32_t ns,
+                                     CRT_GLOBAL const uint32_t *pred, uint32_t nvert, uint32_t Nrt, bool para, uint32_t THREADS) {
+	const uint32_t n = NC ? (uint32_t)NC : Nrt;
+	uint32_t k = threadIdx.x;
+	bool active = k < ns;
+	uint32_t i = 0, end = 0;
+	if(active) { i = starts[k]; end = k + 1 < ns ? starts[k + 1] : nvert; }
+	uint32_t a = 0, b = 0, c = 0, na = 0, nb = 0, nc = 0;
+	auto fetch = [&](uint32_t j, uint32_t &x, uint32_t &y, uint32_t &z) {
+		x = y = z = 0;
+		if(j < nvert) { x = pred[(size_t)j*3]; y = x; z = x; if(para) { y = pred[(size_t)j*3 + 1]; z = pred[(size_t)j*3 + 2]; } }
 	};
-	prefetch(i);
-	uint32_t a = na, b = nb, c = nc;
-	prefetch(i + THREADS);
-	bool valid = a < i && b < i && c < i;                            // well-formed streams always predict from earlier vertices
-	if(!valid) a = b = c = 0;                                        // vertex 0 is fired from the start
-	// ONE loop, test-and-fire in the same iteration: a lane that spun in an inner wait loop would keep the lanes it is
-	// waiting for (same wave) parked at the reconvergence point - the classic SIMT spin deadlock.
-	while(i < nvert) {
-		const uint32_t ready = __hip_atomic_load(&fired[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
-		                       __hip_atomic_load(&fired[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
-		                       __hip_atomic_load(&fired[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if(active) { fetch(i, a, b, c); fetch(i + 1, na, nb, nc); }             // the next triple is always one vertex ahead of its use
+	T prev[NC ? NC : 1];
+	bool at_start = true;
+	while(active) {
+		const bool inv = !(a < i && b < i && c < i);                        // malformed triple (and vertex 0): the value stays
+		const uint32_t da = inv || !at_start ? 0u : a, db = inv ? 0u : b, dc = inv ? 0u : c;
+		const uint32_t ready = __hip_atomic_load(&fired[da], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
+		                       __hip_atomic_load(&fired[db], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
+		                       __hip_atomic_load(&fired[dc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if(ready) {
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			if(valid) {
-				if(para) for(uint32_t k = 0; k < N; k++) v[(size_t)i*N + k] = (T)(v[(size_t)i*N + k] + v[(size_t)a*N + k] + v[(size_t)b*N + k] - v[(size_t)c*N + k]);
-				else for(uint32_t k = 0; k < N; k++) v[(size_t)i*N + k] = (T)(v[(size_t)i*N + k] + v[(size_t)a*N + k]);
+			if(NC) {
+#pragma unroll
+				for(uint32_t q = 0; q < (uint32_t)NC; q++) {
+					T x = v[(size_t)i*n + q];
+					if(!inv) {
+						const T pa = at_start ? v[(size_t)a*n + q] : prev[q];
+						x = (T)(x + pa + (para ? (T)(v[(size_t)b*n + q] - v[(size_t)c*n + q]) : (T)0));
+						v[(size_t)i*n + q] = x;
+					}
+					prev[q] = x;
+				}
+			} else if(!inv) {
+				for(uint32_t q = 0; q < n; q++)
+					v[(size_t)i*n + q] = (T)(v[(size_t)i*n + q] + v[(size_t)a*n + q] + (para ? (T)(v[(size_t)b*n + q] - v[(size_t)c*n + q]) : (T)0));
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__hip_atomic_store(&fired[i], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			i += THREADS;
+			i++; at_start = false;
 			a = na; b = nb; c = nc;
-			valid = a < i && b < i && c < i;
-			if(!valid) a = b = c = 0;
-			prefetch(i + THREADS);
+			if(i == end) {
+				k += THREADS; active = k < ns;
+				if(active) { i = starts[k]; end = k + 1 < ns ? starts[k + 1] : nvert; fetch(i, a, b, c); at_start = true; }
+			}
+			if(active) fetch(i + 1, na, nb, nc);
 		}
-		if(!__any(ready)) __builtin_amdgcn_s_sleep(4);                 // nothing to do in this wave: leave the issue slots to the waves that fire
+		if(!__any(ready)) __builtin_amdgcn_s_sleep(2);                      // nothing to do in this wave: leave the issue slots to the waves that fire
 	}
 }
 
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs, uint32_t lds_bytes) {
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
 	const DeltaJob J = jobs[blockIdx.x];
-	const uint32_t THREADS = blockDim.x;             // DELTA_THREADS for large attributes, a quarter for small ones (fewer waves to spin and to place)
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const size_t bytes = (size_t)J.nvert*J.N*(J.is_u8 ? 1 : 4);
-	const size_t vbytes = (bytes + 15) & ~(size_t)15;
-	const bool in_lds = vbytes + J.nvert <= lds_bytes;                // the host plans with the same rule (batch.cpp)
+	const uint32_t THREADS = blockDim.x, nvert = J.nvert, t = threadIdx.x, lane = lane_id(), w = wave_id(), nwaves = THREADS >> 6;
 	CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
-	if(in_lds) {
-		CRT_LDS uint32_t *l32 = (CRT_LDS uint32_t *)as_lds(lds);
-		CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)l32;
-		CRT_LDS uint8_t *fired = l8 + vbytes;
-		CRT_GLOBAL uint32_t *g32 = as_global((uint32_t *)J.values);
-		CRT_GLOBAL uint8_t *g8 = as_global((uint8_t *)J.values);
-		const bool al = (((uintptr_t)J.values) & 3) == 0;
-		const uint32_t ndw = al ? (uint32_t)(bytes >> 2) : 0u;            // dword body + byte tail (3-component colours: odd sizes)
-		for(uint32_t i = threadIdx.x; i < ndw; i += THREADS) l32[i] = g32[i];
-		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += THREADS) l8[i] = g8[i];
-		for(uint32_t i = threadIdx.x; i < J.nvert; i += THREADS) fired[i] = i == 0;
+	CRT_GLOBAL uint8_t *fired = as_global(J.fired);                       // zero-filled by the host; the stretch starts live behind it
+	CRT_GLOBAL uint32_t *starts = (CRT_GLOBAL uint32_t *)(fired + ((nvert + 15u) & ~15u));
+	__shared__ uint32_t wcount[DELTA_THREADS/64];
+	// stretch starts: vertices that do not predict from the vertex right before them (ordered compaction, THREADS vertices a round)
+	uint32_t ns = 0;
+	for(uint32_t base = 0; base < nvert; base += THREADS) {
+		const uint32_t i = base + t;
+		bool start = false;
+		if(i < nvert) { const uint32_t a = pred[(size_t)i*3]; start = !(a < i && a + 1 == i); }
+		const uint64_t m = __ballot(start);
+		if(lane == 0) wcount[w] = __popcll(m);
 		__syncthreads();
-		if(J.is_u8) delta_dataflow<uint8_t>(l8, fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
-		else delta_dataflow<uint32_t>(l32, fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
+		uint32_t before = 0, total = 0;
+		for(uint32_t q = 0; q < nwaves; q++) { const uint32_t x = wcount[q]; total += x; if(q < w) before += x; }
+		if(start) starts[ns + before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+		ns += total;
 		__syncthreads();
-		for(uint32_t i = threadIdx.x; i < ndw; i += THREADS) g32[i] = l32[i];
-		for(uint32_t i = ndw*4 + threadIdx.x; i < bytes; i += THREADS) g8[i] = l8[i];
+	}
+	if(t == 0) __hip_atomic_store(&fired[0], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	__threadfence_block();
+	__syncthreads();
+	const bool para = J.parallelogram != 0;
+	if(J.is_u8) {
+		CRT_GLOBAL uint8_t *v = as_global((uint8_t *)J.values);
+		switch(J.N) {
+		case 3: delta_stretch_global<uint8_t, 3>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		case 4: delta_stretch_global<uint8_t, 4>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		default: delta_stretch_global<uint8_t, 0>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		}
 	} else {
-		CRT_GLOBAL uint8_t *fired = as_global(J.fired);                // zero-filled by the host
-		if(threadIdx.x == 0) __hip_atomic_store(&fired[0], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__syncthreads();
-		if(J.is_u8) delta_dataflow<uint8_t>(as_global((uint8_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
-		else delta_dataflow<uint32_t>(as_global((uint32_t *)J.values), fired, pred, J.nvert, J.N, J.parallelogram, THREADS);
+		CRT_GLOBAL uint32_t *v = as_global((uint32_t *)J.values);
+		switch(J.N) {
+		case 1: delta_stretch_global<uint32_t, 1>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		case 2: delta_stretch_global<uint32_t, 2>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		case 3: delta_stretch_global<uint32_t, 3>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		default: delta_stretch_global<uint32_t, 0>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
+		}
 	}
 }
 

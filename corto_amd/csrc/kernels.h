@@ -52,7 +52,7 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 }
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of the dataflow workgroup of one (blob, attribute)
-__global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t lds_bytes);
+__global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs);
 // one workgroup per blob, one wave per attribute (up to four), when the attributes' values + the prediction graph fit LDS (k_mesh.hip):
 // values of every attribute | a u16 | b,c u32 | stretch starts u16 | fired u8 per attribute
 constexpr uint32_t DELTA_WAVE_LDS_MAX = 128*1024, DELTA_GROUP_MAX = 4;
