@@ -453,7 +453,7 @@ static int32_t f2i_x86_host(float x) {
 } // namespace
 
 
-// launch classes of K-DELTA: 2 = values + prediction graph fit LDS, one wave (k_delta_wave); else the dataflow workgroup, 0 = large, 1 = small
+// launch classes of K-DELTA: 2 = values + prediction graph fit LDS, one wave (k_delta_wave); else the stretch walk over HBM (k_delta_mesh), 0 = large, 1 = small
 static inline uint64_t delta_wave_need(const DeltaJob &d) {           // alone in a workgroup; ~0 wraps to "too big"
 	const uint64_t g = delta_wave_graph_lds(d.nvert), a = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
 	return g == ~0ull || a == ~0ull ? ~0ull : g + a;

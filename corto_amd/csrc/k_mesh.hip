@@ -625,14 +625,12 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 
 // ------------------------------------------------------------------------------------------------
 // K-DELTA (mesh): v[i] += v[a] + v[b] - v[c] (or += v[a]) for i = 1..nvert-1 in index order
-// (vertex_attribute.h:165-176).  a, b, c < i, so the recurrence is a DAG whose depth is only ~3.5*sqrt(n)
-// (158 levels for the 2 112-vertex C4 unit).  Barrier-free dataflow inside one DELTA_THREADS-wide
-// workgroup per (blob, attribute): thread t owns vertices t, t+DELTA_THREADS, ...; it spins on the "fired" flags of the
-// three vertices its current vertex is predicted from, fires (updates all N components), publishes its own flag
-// and moves to its next vertex.  The lowest unfired vertex is always ready, so the sweep cannot stall, and the
-// critical path is ~depth x (two LDS round trips) instead of nvert serial steps.  Values and flags live in LDS
-// when they fit (dynamic LDS = values | flags), else in HBM (workgroup-scope release/acquire; one CU's waves
-// share its L1).
+// (vertex_attribute.h:165-176).  a, b, c < i, so the recurrence is a DAG; its depth is only ~3.5*sqrt(n)
+// (158 levels for the 2 112-vertex C4 unit), and it has a shape: in the breadth-first CLERS order nearly
+// every vertex predicts from the vertex made just before it (a = i-1) and two vertices one ring of the front back.
+// So the graph is a set of "stretches" - runs of consecutive vertices, each run a serial chain - skewed against each
+// other by two steps, and the parallelism is ACROSS stretches.  Both kernels below give each lane / thread whole
+// stretches to walk; they differ in where the values live (LDS: k_delta_wave, HBM: k_delta_mesh).
 
 // Attributes too big for LDS (meshes of tens of thousands of vertices): the same stretch walk as k_delta_wave below, over
 // HBM/L2 by one workgroup.  Thread k walks stretches k, k+T, ... in order and carries the value of the vertex it has just
@@ -745,7 +743,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 // the parallelism (about 13 wide on a 4K-triangle blob) is ACROSS stretches.  Lane k walks stretch k, k+64, ... in
 // order; a vertex fires when the fired flags of its three parents are set.  One wave executes its LDS accesses in
 // program order, so a flag or value written in one pass is what the next pass reads: no fences, no barriers, no
-// polling waves (the dataflow form above keeps 8-16 waves per attribute spinning on flags for the same 13-wide work).
+// polling waves (a strided assignment - thread t owns vertices t, t+T, ... - keeps 8-16 waves per attribute spinning on
+// flags for the same 13-wide work).
 // The lowest unfired vertex always is the current vertex of its lane and its parents are lower, so every pass fires
 // at least one vertex.  Any triple set is handled (a malformed or adversarial one only costs passes).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -51,7 +51,7 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;
 }
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
-constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of the dataflow workgroup of one (blob, attribute)
+constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of k_delta_mesh's workgroup for one (blob, attribute) too big for LDS; half of them up to DELTA_SMALL_NVERT vertices
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs);
 // one workgroup per blob, one wave per attribute (up to four), when the attributes' values + the prediction graph fit LDS (k_mesh.hip):
 // values of every attribute | a u16 | b,c u32 | stretch starts u16 | fired u8 per attribute
