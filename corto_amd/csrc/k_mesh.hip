@@ -480,15 +480,33 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 				u32x4 t0;
 				uint32_t nd_;
 				if(qpos != nq) {
-					// most queued edges are dead by the time they are popped (closed by a neighbouring chain): look at four ring
-					// records per LDS round trip and skip the dead ones together; a popped slot is free from here on
-					const u32x4 r0 = rec[qpos & MASK], r1 = rec[(qpos + 1) & MASK], r2 = rec[(qpos + 2) & MASK], r3 = rec[(qpos + 3) & MASK];
+					// Most queued edges are dead by the time they are popped (closed by a neighbouring chain: nine in ten on a
+					// sphere-like mesh).  The other 63 lanes of the wave are parked, so for one instruction sequence they are
+					// switched back on and each looks at the flags of ONE of the next 64 queue entries: the first live one is
+					// found in a single LDS round trip however many dead ones sit in front of it.  A popped slot is free from here on.
 					const uint32_t avail = nq - qpos;
-					if(!(r0.z & TOPO_DEAD)) { t0 = r0; qpos += 1; }
-					else if(avail > 1 && !(r1.z & TOPO_DEAD)) { t0 = r1; qpos += 2; }
-					else if(avail > 2 && !(r2.z & TOPO_DEAD)) { t0 = r2; qpos += 3; }
-					else if(avail > 3 && !(r3.z & TOPO_DEAD)) { t0 = r3; qpos += 4; }
-					else { qpos += avail < 4 ? avail : 4u; continue; }         // all dead: no symbol consumed (decoder.cpp:278-279)
+					uint64_t alive, save;
+					asm volatile(
+						"s_mov_b64 %[sv], exec\n"
+						"s_mov_b64 exec, -1\n"
+						"v_mbcnt_lo_u32_b32 v60, -1, 0\n"
+						"v_mbcnt_hi_u32_b32 v60, -1, v60\n"
+						"v_add_u32 v61, %[qpos], v60\n"
+						"v_and_b32 v61, %[mask], v61\n"
+						"v_lshlrev_b32 v61, 4, v61\n"
+						"v_add_u32 v61, %[base], v61\n"
+						"ds_read_b32 v61, v61 offset:8\n"          /* v2 | flags of entry qpos + lane */
+						"s_waitcnt lgkmcnt(0)\n"
+						"v_cmp_gt_i32 %[alive], v61, -1\n"        /* TOPO_DEAD is the sign bit */
+						"s_mov_b64 exec, %[sv]\n"
+						: [alive] "=s"(alive), [sv] "=&s"(save)
+						: [qpos] "s"(qpos), [mask] "s"(MASK), [base] "s"((uint32_t)(uintptr_t)rec)
+						: "memory", "v60", "v61");
+					if(avail < 64) alive &= (1ull << avail) - 1ull;
+					if(!alive) { qpos += avail < 64 ? avail : 64u; continue; }         // all dead: no symbol consumed (decoder.cpp:278-279)
+					const uint32_t j = (uint32_t)__builtin_ctzll(alive);
+					t0 = rec[(qpos + j) & MASK];
+					qpos += j + 1;
 					f = 0;
 				}
 				else if((nd_ = cold[K_NDELAYED]) != 0) { f = delayed[nd_ - 1]; cold[K_NDELAYED] = nd_ - 1; t0 = rec[f]; const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)f; cold[K_NFREE] = n_ + 1; }
