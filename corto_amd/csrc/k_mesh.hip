@@ -442,7 +442,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	for(uint32_t w = threadIdx.x; w < nspl; w += 64) spl[w] = split[w];
 	__syncthreads();
 	if(threadIdx.x != 0) return true;
-	cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0; cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
+	cold[K_NDELAYED] = 0; cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
+	uint32_t mbump = RING, nfree = 0;                                    // pool bump pointer, free-list fill: touched at every chain end, kept in registers (the hot loop is an asm block that does not carry them)
 	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
 	uint32_t sw = TOPO_S(cl32[0]), swn = TOPO_S(cl32[1]);   // TOPO_S: a value lane 0 alone computes is uniform by construction; tell the compiler (SGPR)
 	uint32_t wbias = 1, slide_at = SYMW < nclers ? SYMW - 2048u : 0xFFFFFFFFu;   // next symbol word = cl32[(cler >> 3) + wbias]; slide when cler gets here
@@ -456,17 +457,17 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = TOPO_S(cl32[(cler >> 3) + wbias]); } } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
-#define TOPO_RELEASE(id, z) do { if((id) > MASK && !((z) & TOPO_DELAYED)) { const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)(id); cold[K_NFREE] = n_ + 1; } } while(0)
+#define TOPO_RELEASE(id, z) do { if((id) > MASK && !(TOPO_S(z) & TOPO_DELAYED)) { freel[nfree] = (uint16_t)(id); nfree++; } } while(0)
 	// give the surviving current edge a pool slot, its record, and its neighbours their links to it
-#define TOPO_MATERIALISE(flags) do { const uint32_t nf_ = cold[K_NFREE], mb_ = cold[K_MBUMP]; \
-	if(nf_) { f = freel[nf_ - 1]; cold[K_NFREE] = nf_ - 1; } else if(mb_ < RING + POOL) { f = mb_; cold[K_MBUMP] = mb_ + 1; } else { err = 2; break; } \
+#define TOPO_MATERIALISE(flags) do { \
+	if(nfree) { nfree--; f = TOPO_S(freel[nfree]); } else if(mbump < RING + POOL) { f = mbump; mbump++; } else { err = 2; break; } \
 	TOPO_PUT(f, v0, v1, v2 | (flags), ep, en); rec16[ep*8 + 7] = (uint16_t)f; rec16[en*8 + 6] = (uint16_t)f; } while(0)
 
 			for(uint32_t g = 0; g < J.ngroups && !err; g++) {              // every group starts from an empty front (decoder.cpp:173-178)
 			const uint32_t ge = TOPO_S(group_end[g]);
 			if(ge > J.nface || ge*3 < start) { err = 1; break; }
 			const uint32_t end = ge*3;
-			nq = 0; qpos = 0; cold[K_MBUMP] = RING; cold[K_NFREE] = 0; cold[K_NDELAYED] = 0;
+			nq = 0; qpos = 0; mbump = RING; nfree = 0; cold[K_NDELAYED] = 0;
 			while(start < end && !err) {
 				if(cler >= slide_at) {                                      // between chains: slide the window before it runs low
 					winbase = cler & ~7u;
@@ -509,7 +510,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 					qpos += j + 1;
 					f = 0;
 				}
-				else if((nd_ = cold[K_NDELAYED]) != 0) { f = delayed[nd_ - 1]; cold[K_NDELAYED] = nd_ - 1; t0 = rec[f]; const uint32_t n_ = cold[K_NFREE]; freel[n_] = (uint16_t)f; cold[K_NFREE] = n_ + 1; }
+				else if((nd_ = cold[K_NDELAYED]) != 0) { f = delayed[nd_ - 1]; cold[K_NDELAYED] = nd_ - 1; t0 = rec[f]; freel[nfree] = (uint16_t)f; nfree++; }
 				else {                                                     // seed face (decoder.cpp:224-259)
 					uint32_t c; TOPO_SYMBOL(c);
 					uint32_t last = vc - 1, vi[3], mask = 0;
