@@ -215,6 +215,8 @@ struct crthip_ctx {
 	bool profiling = false;
 	KernelTimer timer;
 	crthip_batch *in_flight = nullptr;
+	// feedback on the LDS edge slots of the CLERS automaton: raised after a batch with fallbacks, lowered after a long calm run
+	uint32_t topo_scale = 1, topo_calm = 0, topo_patience = 64;
 	// planner state reused from one decode call to the next (batch.cpp: build_and_launch)
 	Plan plan;
 	std::vector<BlobScratch> plan_scratch;
@@ -641,8 +643,13 @@ static int build_and_launch(crthip_batch *b) {
 			{
 				// every mesh takes the LDS path; a lone big mesh may use most of a CU's LDS, a batch keeps its blobs small
 				uint32_t ring, pool, symwin;
-				topo_lds_geometry(nface, L.clers.size, 4096, ring, pool, symwin);
-				const uint32_t need = topo_lds_bytes(ring, pool, pool, symwin);          // every delayed edge is a pool record: same capacity
+				uint32_t scale = ctx->topo_scale, need;
+				for(;;) {                                                                // as much of the context's scale as fits a CU
+					topo_lds_geometry(nface, L.clers.size, 4096, scale, ring, pool, symwin);
+					need = topo_lds_bytes(ring, pool, pool, symwin);                     // every delayed edge is a pool record: same capacity
+					if(need <= TOPO_LDS_MAX || scale == 1) break;
+					scale >>= 1;
+				}
 				if(need <= TOPO_LDS_MAX) {
 					t.lds_ring = ring; t.lds_pool = pool; t.lds_delayed_cap = pool; t.lds_symwin = symwin;
 					if(need <= 32*1024) { pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need); }
@@ -953,6 +960,7 @@ static int build_and_launch(crthip_batch *b) {
 	// stats
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun;
 	b->stats.scratch_bytes = pl.total;
+	b->stats.topology_scale = ctx->topo_scale;
 	uint64_t ob = 0;
 	for(auto &P : b->blobs) {
 		const BlobLayout &L = P.L;
@@ -994,6 +1002,15 @@ extern "C" int crthip_batch_sync(crthip_batch *b, int32_t *status) {
 		}
 		b->stats.topology_fallbacks = 0;
 		for(size_t i = 0; i < b->blobs.size(); i++) b->stats.topology_fallbacks += (uint64_t)(hs[b->blobs.size() + i] & 1);
+		// more than one blob in twenty redone on the HBM front (5x slower): four times the edge slots from the next batch on;
+		// a long run without any: try half again, and be more patient the next time that turns out to be too little
+		if(b->stats.topology_fallbacks*20 > b->blobs.size()) {
+			if(ctx->topo_scale < 16) ctx->topo_scale *= 4;
+			if(ctx->topo_calm == 0 && ctx->topo_patience < (1u << 20)) ctx->topo_patience *= 2;    // fell back right after scaling down
+			ctx->topo_calm = 0;
+		} else if(b->stats.topology_fallbacks == 0 && ctx->topo_scale > 1 && ++ctx->topo_calm >= ctx->topo_patience) {
+			ctx->topo_scale /= 2; ctx->topo_calm = 0;
+		}
 		ctx->in_flight = nullptr;
 	}
 	for(size_t i = 0; i < b->blobs.size(); i++) {

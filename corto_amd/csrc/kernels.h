@@ -43,9 +43,11 @@ constexpr uint32_t TOPO_SYMWIN_MAX = 8192;
 // The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the ring gets 8*sqrt(nface)
 // rounded up to a power of two (at least 256, at most `ring_max`), the pool as much again (it also holds every edge of the mesh's own
 // boundary for good).  What does not fit - a torus' queue is ten times a sphere's, a ribbon is all boundary - is redone on the HBM front.
-inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
+// `scale` (a power of two) multiplies both: the context raises it after a batch whose blobs fell back (batch.cpp).
+inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
 	uint32_t want = 256;
 	while((uint64_t)want*want < (uint64_t)64*nface && want < ring_max) want <<= 1;
+	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }
 	ring = want; pool = want;
 	const uint32_t all = (nclers + 64 + 7) & ~7u;
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;

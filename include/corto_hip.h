@@ -192,6 +192,9 @@ typedef struct {
 	float host_stage_us;        /* ... pointer fix-up + staging of the descriptors ... */
 	float host_launch_us;       /* ... and issuing the copies / kernel launches (asynchronous; no device wait) */
 	float host_create_us;       /* host time of crthip_batch_create: header parse + bounds-checked walk of every blob */
+	uint32_t topology_scale;    /* factor on the LDS edge slots this decode was planned with (1, 2, 4 ...): the context raises it
+	                               after a batch with fallbacks, so that meshes with long fronts (handles, many boundary loops)
+	                               stay in LDS from the next batch on, and lowers it again after a long run without any */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

@@ -499,6 +499,18 @@ def test_encode_values_stage_against_the_cstream_model(ctx):
             assert g.tobytes() == exp, (entropy, i, len(g), len(exp))
 
 
+def test_encoder_stage_argument_errors(ctx):
+    """bad descriptors are refused with an error code and a message, nothing is launched"""
+    a = np.zeros((4, 3), np.int32)
+    for kind, arr in ((7, a), (ca.ENC_ARRAY, np.zeros((4, 17), np.int32))):
+        with pytest.raises(ca.CortoError):
+            ca.encode_values(ctx, [(kind, arr)])
+    with pytest.raises(ca.CortoError):
+        ca.encode_values(ctx, [(ca.ENC_ARRAY, a)], entropy=5)
+    # still usable afterwards
+    assert len(ca.encode_values(ctx, [(ca.ENC_ARRAY, a)])[0]) > 4
+
+
 def test_gpu_encoder_blobs_identical_to_the_reference_made_fixtures(ctx):
     """crthip_encode_gpu (value coding + entropy coder on the device, topology and container on the host) writes the same
     bytes as the reference encoder did for every golden case, as the host encoder on the C4 units, and for entropy NONE"""
@@ -558,21 +570,26 @@ def test_config3_167k_point_cloud(ctx):
         assert_same(got, r, KEYS, "C3 vs reference")
 
 
-def test_topology_lds_slot_overflow_redone_on_hbm_front(ctx):
+def test_topology_lds_slot_overflow_redone_on_hbm_front():
     """the LDS automaton holds the LIVE front: a ring of 8*sqrt(nface) queued edges and a pool as large for surviving ones.  A
     torus' queue and a ribbon's boundary outgrow that; those blobs are redone on the HBM front - same results, reported in the
-    stats - in one batch with blobs that fit"""
+    stats - in one batch with blobs that fit.  The context learns from it: the next decode is planned with four times the edge
+    slots and keeps all of them in LDS."""
     from corto_amd import synth
+    ctx = ca.Context(0)                      # its own context: the feedback is per context
     meshes = [synth.strip(400, seed=3), synth.bumpy_sphere(24, 12, seed=5), synth.torus(100, 50, seed=4), synth.holey_disc(40, seed=2, color_components=4)]
     blobs = [ca.encode(m, normal_prediction=ca.BORDER) for m in meshes]
-    for u16 in (False, True):
+    for u16, scale, fallbacks in ((False, 1, 3), (True, 4, 0), (False, 4, 0)):
         b = run_batch(ctx, blobs, index16=u16)
         for i in range(len(blobs)):
             exp = oc.decode(blobs[i])
             if u16:
                 exp["index"] = exp["index"].astype(np.uint16)
             assert_same(b.host_outputs(i), exp, KEYS, "blob %d u16=%s" % (i, u16))
-        assert b.stats().topology_fallbacks == 3, b.stats().topology_fallbacks   # the ribbon (800 boundary edges), the torus (queue of 3 800), the holey disc
+        # first pass: the ribbon (800 boundary edges), the torus (queue of 3 800), the holey disc
+        assert (b.stats().topology_scale, b.stats().topology_fallbacks) == (scale, fallbacks), (b.stats().topology_scale, b.stats().topology_fallbacks)
+        b.close()
+    ctx.close()
 
 
 def test_large_and_small_meshes_in_one_batch(ctx):
