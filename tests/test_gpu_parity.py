@@ -570,6 +570,32 @@ def test_config3_167k_point_cloud(ctx):
         assert_same(got, r, KEYS, "C3 vs reference")
 
 
+def test_random_corpus_one_batch(ctx):
+    """the oracle-vs-reference corpus (tests/test_oracle_vs_reference.py: spheres, holey discs with shuffled vertex order, tori,
+    closed spheres, a merge of components with a 4-component colour) plus clouds, ribbons and two-group meshes, every blob with its
+    own quantisation / normal prediction / entropy, decoded in ONE batch: each equals the oracle byte for byte (f32 and i16/u16)"""
+    from corto_amd import synth as S
+    rng = np.random.default_rng(2027)
+    meshes = []
+    for seed in range(6):
+        meshes += [S.bumpy_sphere(8 + 7 * seed, 4 + 5 * seed, seed), S.shuffled(S.holey_disc(6 + 6 * seed, seed, hole_frac=0.05 + 0.05 * seed), seed),
+                   S.torus(6 + 5 * seed, 4 + 3 * seed, seed), S.closed_sphere(5 + 4 * seed, 3 + 3 * seed, seed)]
+    meshes += [S.merge([S.closed_sphere(9, 5, 1), S.closed_sphere(7, 4, 2), S.torus(8, 5, 3), S.holey_disc(9, 4, color_components=4)]),
+               S.strip(37, seed=4), S.point_cloud(17, 9, 1), S.point_cloud(64, 40, 2), S.bumpy_sphere(20, 10, 5, color_components=3)]
+    blobs = []
+    for k, m in enumerate(meshes):
+        cloud = m.nface == 0
+        pred = (ca.DIFF if cloud else (ca.DIFF, ca.ESTIMATED, ca.BORDER)[k % 3])
+        blobs.append(ca.encode(m, position_bits=int(rng.choice([9, 12, 14, 18])), normal_bits=int(rng.choice([8, 10, 12])), uv_bits=int(rng.choice([8, 12])),
+                               normal_prediction=pred, entropy=0 if k % 7 == 3 else 1))
+    for kw, okw in ((dict(color_components=4), dict(color_components=4)),
+                    (dict(color_components=4, normal_format=ca.FMT_INT16, index16=True), dict(color_components=4, normal_format=oc.FMT_INT16, index16=True))):
+        b = run_batch(ctx, blobs, **kw)
+        for i, blob in enumerate(blobs):
+            assert_same(b.host_outputs(i), oc.decode(blob, **okw), KEYS, "corpus blob %d %s" % (i, sorted(kw)))
+        b.close()
+
+
 def test_topology_lds_slot_overflow_redone_on_hbm_front():
     """the LDS automaton holds the LIVE front: a ring of 8*sqrt(nface) queued edges and a pool as large for surviving ones.  A
     torus' queue and a ribbon's boundary outgrow that; those blobs are redone on the HBM front - same results, reported in the
