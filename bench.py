@@ -217,8 +217,8 @@ def encoder_stage(ctx, ca):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (contexts) per host thread; 1 = unpipelined")
     ap.add_argument("--host-threads", type=int, default=2, help="host threads feeding the GPU (the C ABI releases the GIL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
