@@ -731,7 +731,7 @@ static int build_and_launch(crthip_batch *b) {
 						if(normal_fused(nvert, nface)) {
 							n.fused = 1;
 							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
-							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds(nvert, nface));
+							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= NORMAL_FN_LDS_MAX ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
 						} else {
 							n.vbase = est_vbase; n.fbase = est_fbase; est_vbase += nvert; est_fbase += nface;
 							pl.any_est_normal = true;
@@ -924,7 +924,7 @@ static int build_and_launch(crthip_batch *b) {
 	const uint32_t nvb = (uint32_t)pl.nv_block_job.v.size(), nfb = (uint32_t)pl.nf_block_job.v.size();
 	if(!pl.normal_fused_ids.v.empty()) {
 		const uint32_t nj = (uint32_t)pl.normal_fused_ids.v.size();
-		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), pl.normal_fused_lds, st, D(pl.normal), D(pl.normal_fused_ids), nj); LT.end();
+		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), pl.normal_fused_lds, st, D(pl.normal), D(pl.normal_fused_ids), nj, pl.normal_fused_lds); LT.end();
 	}
 	if(pl.any_est_normal) {
 		float *facen = (float *)(base + pl.facen_off);

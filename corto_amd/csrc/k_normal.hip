@@ -10,6 +10,7 @@
 // atomics (arbitrary order), then each vertex walks its own short list in ascending face id.  All float
 // code is compiled with -ffp-contract=off: an FMA changes the reference's bits.
 #include "kernels_common.h"
+#include "kernels.h"
 
 namespace corto_hip {
 
@@ -50,10 +51,10 @@ __device__ __forceinline__ void to_sphere(int32_t x, int32_t y, int32_t unit, fl
 
 __device__ __forceinline__ void store_normal(const NormalJob &J, uint32_t i, float nx, float ny, float nz) {
 	if(J.out_i16) {                                     // Point3s(n*32767) (normal_attribute.h:121)
-		int16_t *o = (int16_t *)J.out + (size_t)i*3;
+		CRT_GLOBAL int16_t *o = as_global((int16_t *)J.out) + (size_t)i*3;     // explicit address space: a FLAT store would make the next LDS read wait for its acknowledgement
 		o[0] = f2s_x86(nx*32767); o[1] = f2s_x86(ny*32767); o[2] = f2s_x86(nz*32767);
 	} else {
-		float *o = (float *)J.out + (size_t)i*3;
+		CRT_GLOBAL float *o = as_global((float *)J.out) + (size_t)i*3;
 		o[0] = nx; o[1] = ny; o[2] = nz;
 	}
 }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
 // the batches behind it in a pipelined decode (k_mesh.hip: three 49 KB fronts per CU leave little).
 // Dynamic LDS layout: cnt[nvert+1] u32 | start[nvert+1] u16 | slot[nvert+1] u16 | bnd[nvert] u32, later adj[3*nface] u16
 // (the boundary flag moves into slot's top bit - nvert <= 32767 - once the slots are scanned, and the adjacency takes bnd's place)
-__global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+__global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs, uint32_t lds_bytes) {
 	if(blockIdx.x >= njobs) return;
 	const NormalJob J = jobs[job_ids[blockIdx.x]];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -206,6 +207,11 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	CRT_LDS uint16_t *slot = start + ((nv + 2) & ~1u);
 	CRT_LDS uint32_t *bnd = (CRT_LDS uint32_t *)(slot + ((nv + 2) & ~1u));
 	CRT_LDS uint16_t *adj = (CRT_LDS uint16_t *)bnd;
+	// small blobs: every face's normal is computed once, while the incidence is counted, and kept in LDS; the ordered accumulation
+	// then never leaves LDS.  Bigger blobs recompute it per incident vertex from HBM/L2 (two dependent loads per face and vertex)
+	// to stay within a CU's LDS.
+	const bool fn_lds = normal_blob_lds_fn(nv, nf) <= lds_bytes;
+	CRT_LDS float *fn = (CRT_LDS float *)(as_lds(lds_raw) + ((normal_blob_lds(nv, nf) + 15u) & ~15u));
 	__shared__ uint32_t scan_s[4];
 	CRT_GLOBAL const int32_t *pos = as_global(J.position);
 	CRT_GLOBAL const uint32_t *f32 = J.faces_u16 ? nullptr : as_global((const uint32_t *)J.faces);
@@ -222,6 +228,13 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		uint32_t a, b, c; face(f, a, b, c);
 		if(a >= nv || b >= nv || c >= nv) { bad = true; continue; }
 		atomicAdd((uint32_t *)&cnt[a], 1u); atomicAdd((uint32_t *)&cnt[b], 1u); atomicAdd((uint32_t *)&cnt[c], 1u);
+		if(fn_lds) {
+			CRT_GLOBAL const int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
+			const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
+			const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
+			const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;
+			fn[3*f] = ay*bz - az*by; fn[3*f + 1] = az*bx - ax*bz; fn[3*f + 2] = ax*by - ay*bx;   // point.h:113-115
+		}
 		if(J.prediction == 2) { atomicXor((uint32_t *)&bnd[a], b ^ c); atomicXor((uint32_t *)&bnd[b], c ^ a); atomicXor((uint32_t *)&bnd[c], a ^ b); }
 	}
 	if(bad) *as_global(J.status) = -5;
@@ -253,6 +266,25 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	for(uint32_t i = tid; i < nv; i += 256) {
 		const uint32_t s0 = start[i], deg = (uint32_t)start[i + 1] - s0;
 		float ex = 0.f, ey = 0.f, ez = 0.f;
+		if(fn_lds && deg <= 8) {
+			// the usual vertex: its (at most eight) incident faces sorted by id with a branch-free network, their normals read from
+			// LDS and added in that order.  Equal ids (a face naming the vertex twice) end up adjacent and are added twice, as the
+			// reference does.  (The selection loop below takes deg^2 data-dependent branches; a lone wave pays ~20 clocks for each.)
+			uint32_t id[8];
+#pragma unroll
+			for(uint32_t k = 0; k < 8; k++) id[k] = k < deg ? (uint32_t)adj[s0 + k] : 0xFFFFFFFFu;
+#define CRT_CX(p, q) { const uint32_t lo_ = min(id[p], id[q]), hi_ = max(id[p], id[q]); id[p] = lo_; id[q] = hi_; }
+			CRT_CX(0, 1) CRT_CX(2, 3) CRT_CX(4, 5) CRT_CX(6, 7)
+			CRT_CX(0, 2) CRT_CX(1, 3) CRT_CX(4, 6) CRT_CX(5, 7)
+			CRT_CX(1, 2) CRT_CX(5, 6) CRT_CX(0, 4) CRT_CX(3, 7)
+			CRT_CX(1, 5) CRT_CX(2, 6)
+			CRT_CX(1, 4) CRT_CX(3, 6)
+			CRT_CX(2, 4) CRT_CX(3, 5)
+			CRT_CX(3, 4)
+#undef CRT_CX
+#pragma unroll
+			for(uint32_t k = 0; k < 8; k++) if(k < deg) { ex += fn[3*id[k]]; ey += fn[3*id[k] + 1]; ez += fn[3*id[k] + 2]; }
+		} else {
 		int32_t last = -1;
 		for(uint32_t done = 0; done < deg;) {
 			uint32_t best = 0xFFFFFFFFu, mult = 0;
@@ -260,21 +292,26 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 				const uint32_t f = adj[s0 + k];
 				if((int32_t)f > last) { if(f < best) { best = f; mult = 1; } else if(f == best) mult++; }
 			}
-			uint32_t a, b, c; face(best, a, b, c);
-			CRT_GLOBAL const int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
-			const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
-			const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
-			const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;
-			const float nx = ay*bz - az*by, ny = az*bx - ax*bz, nz = ax*by - ay*bx;   // point.h:113-115
+			float nx, ny, nz;
+			if(fn_lds) { nx = fn[3*best]; ny = fn[3*best + 1]; nz = fn[3*best + 2]; }
+			else {
+				uint32_t a, b, c; face(best, a, b, c);
+				CRT_GLOBAL const int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
+				const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
+				const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
+				const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;
+				nx = ay*bz - az*by; ny = az*bx - ax*bz; nz = ax*by - ay*bx;   // point.h:113-115
+			}
 			for(uint32_t m = 0; m < mult; m++) { ex += nx; ey += ny; ez += nz; }
 			last = (int32_t)best; done += mult;
+		}
 		}
 		if(slot[i] & 0x8000u) {                                          // ESTIMATED: every vertex; BORDER: boundary vertices
 			const uint32_t sl = slot[i] & 0x7FFFu;
 			int32_t qx, qy;
 			to_octa(ex, ey, ez, J.unit, qx, qy);
 			int32_t dx = 0, dy = 0;
-			if(sl < J.ndiffs) { dx = J.diffs[2*(size_t)sl]; dy = J.diffs[2*(size_t)sl + 1]; }
+			if(sl < J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)sl; dx = dp[0]; dy = dp[1]; }
 			int32_t x = (int32_t)((uint32_t)qx + (uint32_t)dx), y = (int32_t)((uint32_t)qy + (uint32_t)dy);
 			if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }
 			float nx, ny, nz;
@@ -284,12 +321,12 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			float len = norm3(ex, ey, ez);
 			if(!(len < 0.00001f)) {
 				len = 32767.0f/len;
-				int16_t *o = (int16_t *)J.out + (size_t)i*3;
+				CRT_GLOBAL int16_t *o = as_global((int16_t *)J.out) + (size_t)i*3;
 				o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
 			}
 		} else {
 			const float len = norm3(ex, ey, ez);
-			float *o = (float *)J.out + (size_t)i*3;
+			CRT_GLOBAL float *o = as_global((float *)J.out) + (size_t)i*3;
 			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
 		}
 	}
