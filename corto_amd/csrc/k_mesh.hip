@@ -13,11 +13,8 @@ enum : uint32_t { C_VERTEX = 0, C_LEFT = 1, C_RIGHT = 2, C_END = 3, C_BOUNDARY =
 constexpr int32_t ERR_TOPOLOGY = -5;   // CRTHIP_E_TOPOLOGY
 
 // ------------------------------------------------------------------------------------------------
-// K-TOPO.  The automaton is written once against a "front store" policy:
-//   GlobalFront : front / queues in HBM scratch sized by the stream's max_front (any mesh size)
-//   LdsFront    : the same state in the CU's LDS, 12 bytes per edge (u16 vertex ids and links), for
-//                 blobs whose whole front fits: every dependent read is an LDS round trip (~100 cycles)
-//                 instead of an L2/HBM one (~500-2000).
+// K-TOPO.  The reference automaton as it stands, with the front and its queues in HBM scratch sized by the stream's
+// max_front (any mesh size): the redo path of blobs whose live front outgrows the LDS slots of topo_lds_body below.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -43,31 +40,43 @@ struct GlobalFront {
 	__device__ uint32_t order_get(uint32_t i) const { return order[i]; }
 	__device__ void delayed_put(uint32_t i, uint32_t e) { delayed[i] = e; }
 	__device__ uint32_t delayed_get(uint32_t i) const { return delayed[i]; }
-};
-
-struct LdsFront {
-	CRT_LDS uint32_t *va;            // v0 | v1 << 16
-	CRT_LDS uint32_t *vb;            // v2 | deleted << 16
-	CRT_LDS uint32_t *lk;            // prev | next << 16
-	CRT_LDS uint16_t *order;
-	CRT_LDS uint16_t *delayed;
-	__device__ void core(uint32_t e, uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &dead) const {
-		const uint32_t a = va[e], b = vb[e];
-		v0 = a & 0xFFFFu; v1 = a >> 16; v2 = b & 0xFFFFu; dead = b >> 16;
+	// Next LIVE edge of the queue [iorder, norder), or false if the next 64 entries are all deleted (iorder moves past what was
+	// looked at either way).  Nine queued edges in ten are dead by the time they are popped, and here each costs two dependent
+	// L2 round trips (the queue entry, then the edge's deleted flag): the wave's 63 parked lanes are switched on for the two
+	// loads, so 64 entries are examined per pair of round trips.  The queue holds edge ids this automaton wrote itself.
+	__device__ bool pop_live(uint32_t &iorder, uint32_t norder, uint32_t &f) const {
+		const uint32_t io = (uint32_t)__builtin_amdgcn_readfirstlane((int)iorder), avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(norder - iorder));
+		const uint64_t po = (uint64_t)(uintptr_t)order, pf = (uint64_t)(uintptr_t)fa;
+		const uint64_t ord = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)po) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(po >> 32)) << 32;
+		const uint64_t fab = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pf) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pf >> 32)) << 32;
+		uint64_t alive, save;
+		uint32_t ent;
+		asm volatile(
+			"s_mov_b64 %[sv], exec\n"
+			"s_mov_b64 exec, -1\n"
+			"v_mbcnt_lo_u32_b32 v60, -1, 0\n"
+			"v_mbcnt_hi_u32_b32 v60, -1, v60\n"
+			"v_cmp_gt_u32 vcc, %[avail], v60\n"
+			"s_mov_b64 exec, vcc\n"
+			"v_add_u32 v61, %[io], v60\n"
+			"v_lshlrev_b32 v61, 2, v61\n"
+			"global_load_dword v62, v61, %[ord]\n"
+			"s_waitcnt vmcnt(0)\n"
+			"v_lshlrev_b32 v61, 4, v62\n"
+			"global_load_dword v63, v61, %[fab] offset:12\n"
+			"s_waitcnt vmcnt(0)\n"
+			"v_cmp_eq_u32 %[alive], 0, v63\n"
+			"v_mov_b32 %[ent], v62\n"
+			"s_mov_b64 exec, %[sv]\n"
+			: [alive] "=s"(alive), [sv] "=&s"(save), [ent] "=&v"(ent)
+			: [avail] "s"(avail), [io] "s"(io), [ord] "s"(ord), [fab] "s"(fab)
+			: "memory", "vcc", "v60", "v61", "v62", "v63");
+		if(!alive) { iorder = io + (avail < 64 ? avail : 64u); return false; }
+		const uint32_t j = (uint32_t)__builtin_ctzll(alive);
+		f = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)j);
+		iorder = io + j + 1;
+		return true;
 	}
-	__device__ void links(uint32_t e, uint32_t &p, uint32_t &n) const { const uint32_t t = lk[e]; p = t & 0xFFFFu; n = t >> 16; }
-	__device__ uint32_t prev(uint32_t e) const { return lk[e] & 0xFFFFu; }
-	__device__ uint32_t next(uint32_t e) const { return lk[e] >> 16; }
-	__device__ uint32_t v0(uint32_t e) const { return va[e] & 0xFFFFu; }
-	__device__ uint32_t v1(uint32_t e) const { return va[e] >> 16; }
-	__device__ void set_prev(uint32_t e, uint32_t x) { ((CRT_LDS uint16_t *)lk)[2*e] = (uint16_t)x; }
-	__device__ void set_next(uint32_t e, uint32_t x) { ((CRT_LDS uint16_t *)lk)[2*e + 1] = (uint16_t)x; }
-	__device__ void kill(uint32_t e) { ((CRT_LDS uint16_t *)vb)[2*e + 1] = 1; }
-	__device__ void put(uint32_t e, uint32_t a, uint32_t b, uint32_t c, uint32_t p, uint32_t n) { va[e] = a | (b << 16); vb[e] = c; lk[e] = p | (n << 16); }
-	__device__ void order_put(uint32_t i, uint32_t e) { order[i] = (uint16_t)e; }
-	__device__ uint32_t order_get(uint32_t i) const { return order[i]; }
-	__device__ void delayed_put(uint32_t i, uint32_t e) { delayed[i] = (uint16_t)e; }
-	__device__ uint32_t delayed_get(uint32_t i) const { return delayed[i]; }
 };
 
 template <class ClersPtr>
@@ -135,7 +144,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 		}
 		uint32_t f;
 		if(new_edge != -1) { f = (uint32_t)new_edge; new_edge = -1; }
-		else if(iorder < norder) f = F.order_get(iorder++);
+		else if(iorder < norder) { if(!F.pop_live(iorder, norder, f)) continue; }   // (deleted entries consume no symbol, decoder.cpp:278-279)
 		else f = F.delayed_get(--ndelayed);
 		if(f >= nfront) FAIL();
 		uint32_t v0, v1, v2, dead;
