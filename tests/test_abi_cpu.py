@@ -29,6 +29,15 @@ def test_exports_every_declared_symbol(L):
     assert L.crthip_abi_version() == 1
 
 
+def test_headers_are_plain_c(tmp_path):
+    """the boundary is a C ABI: include/corto_hip.h and include/corto/emcorto.h compile as strict C99 (no C++, no torch types)"""
+    import subprocess
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "corto_hip.h"\n#include "corto/emcorto.h"\n'
+                   'int main(void) { crthip_batch_stats s; crthip_enc_stream e; crthip_blob_info i; (void)s; (void)e; (void)i; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_probe_matches_golden(L, name):
     g = load_golden(name)
