@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -214,7 +215,14 @@ struct crthip_ctx {
 	PinnedBuf status_host;
 	bool profiling = false;
 	KernelTimer timer;
-	crthip_batch *in_flight = nullptr;
+	crthip_batch *in_flight = nullptr;   // decode enqueued, status not harvested yet
+	crthip_batch *last_decoded = nullptr;// whose intermediates the scratch block holds (crthip_batch_debug_read)
+	// crthip_decode_host: everything a one-blob decode with host buffers needs, kept from call to call (no hipMalloc / create in the
+	// steady state) and guarded by a mutex so that callers may share a context between threads
+	std::mutex host_mutex;
+	crthip_batch *host_batch = nullptr;
+	DeviceBuf host_out;       // decoded outputs of the one blob, back to back
+	PinnedBuf host_pin;       // ... and their landing zone in pinned host memory (one async D2H copy)
 	// feedback on the LDS edge slots of the CLERS automaton: raised after a batch with fallbacks, lowered after a long calm run
 	uint32_t topo_scale = 1, topo_calm = 0, topo_patience = 64;
 	// planner state reused from one decode call to the next (batch.cpp: build_and_launch)
@@ -222,15 +230,6 @@ struct crthip_ctx {
 	std::vector<BlobScratch> plan_scratch;
 	std::vector<const uint8_t *> plan_clers, plan_logs;
 };
-
-namespace corto_hip {
-int ctx_device(crthip_ctx *ctx) { return ctx->device; }
-hipStream_t ctx_stream(crthip_ctx *ctx) { return ctx->stream; }
-int ctx_quiesce(crthip_ctx *ctx) {
-	if(ctx->in_flight) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
-	return CRTHIP_OK;
-}
-}
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4; };
 
@@ -258,6 +257,42 @@ struct crthip_batch {
 	bool decoded = false;
 };
 
+// Wait for the batch in flight on this context (if any) and move its per-blob status from the pinned landing zone into the
+// batch object.  EVERY place that is about to reuse the context's stream, scratch or status buffer goes through here, so a
+// decode(A); decode(B); sync(A) sequence still reports A's failures (status used to be read only by crthip_batch_sync(A) and
+// was lost when another call had synchronised first).
+static int harvest(crthip_ctx *ctx) {
+	crthip_batch *b = ctx->in_flight;
+	if(!b) return CRTHIP_OK;
+	if(hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->in_flight = nullptr; return CRTHIP_E_DEVICE; }
+	const int32_t *hs = (const int32_t *)ctx->status_host.p;
+	const size_t n = b->blobs.size();
+	for(size_t i = 0; i < n; i++) b->status[i] = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
+	b->stats.topology_fallbacks = 0;
+	for(size_t i = 0; i < n; i++) b->stats.topology_fallbacks += (uint64_t)(hs[n + i] & 1);
+	// more than one blob in twenty redone on the HBM front (5x slower): four times the edge slots from the next batch on;
+	// a long run without any: try half again, and be more patient the next time that turns out to be too little
+	if(b->stats.topology_fallbacks*20 > n) {
+		if(ctx->topo_scale < 16) ctx->topo_scale *= 4;
+		if(ctx->topo_calm == 0 && ctx->topo_patience < (1u << 20)) ctx->topo_patience *= 2;    // fell back right after scaling down
+		ctx->topo_calm = 0;
+	} else if(b->stats.topology_fallbacks == 0 && ctx->topo_scale > 1 && ++ctx->topo_calm >= ctx->topo_patience) {
+		ctx->topo_scale /= 2; ctx->topo_calm = 0;
+	}
+	ctx->in_flight = nullptr;
+	return CRTHIP_OK;
+}
+
+namespace corto_hip {
+int ctx_device(crthip_ctx *ctx) { return ctx->device; }
+hipStream_t ctx_stream(crthip_ctx *ctx) { return ctx->stream; }
+int ctx_quiesce(crthip_ctx *ctx) {
+	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
+	ctx->last_decoded = nullptr;                         // the encoder stages reuse the scratch block
+	return CRTHIP_OK;
+}
+}
+
 extern "C" int crthip_device_count(void) {
 	int n = 0;
 	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -265,6 +300,7 @@ extern "C" int crthip_device_count(void) {
 }
 
 extern "C" void crthip_ctx_destroy(crthip_ctx *c);
+extern "C" void crthip_batch_destroy(crthip_batch *b);
 extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	if(!out) return fail(CRTHIP_E_ARGUMENT);
 	int n = 0;
@@ -293,7 +329,8 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	c->timer.release();
-	c->scratch.release(); c->staging.release(); c->status_host.release();
+	if(c->host_batch) { crthip_batch *hb = c->host_batch; c->host_batch = nullptr; crthip_batch_destroy(hb); }
+	c->scratch.release(); c->staging.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
 	(void)hipStreamSynchronize(c->stream2);
 	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
 	(void)hipStreamDestroy(c->stream2);
@@ -344,7 +381,7 @@ static int batch_fill(crthip_ctx *ctx, crthip_batch *b, uint32_t nblobs, const u
 	if(device_arena) b->d_arena = (const uint8_t *)device_arena;
 	else if(off) {
 		if(b->own_arena.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-		if(ctx->in_flight) { (void)hipStreamSynchronize(ctx->stream); ctx->in_flight = nullptr; }
+		if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);      // the staging buffer may still feed the batch in flight
 		if(ctx->staging.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 		uint8_t *h = (uint8_t *)ctx->staging.p;
 		for(uint32_t i = 0; i < nblobs; i++) memcpy(h + b->blobs[i].arena_off, blobs[i], lens[i]);
@@ -372,7 +409,8 @@ extern "C" int crthip_batch_reset(crthip_batch *b, uint32_t nblobs, const uint8_
 	if(!b || !b->ctx || (nblobs && (!blobs || !lens))) return fail(CRTHIP_E_ARGUMENT);
 	crthip_ctx *ctx = b->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));
-	if(ctx->in_flight == b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
+	if(ctx->in_flight == b) { if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE); }
+	if(ctx->last_decoded == b) ctx->last_decoded = nullptr;
 	return batch_fill(ctx, b, nblobs, blobs, lens, device_arena);       // on failure the batch is left empty-handed: reset or destroy it
 }
 
@@ -381,6 +419,8 @@ extern "C" void crthip_batch_destroy(crthip_batch *b) {
 	if(b->ctx) {
 		(void)hipSetDevice(b->ctx->device);
 		if(b->ctx->in_flight == b) { (void)hipStreamSynchronize(b->ctx->stream); b->ctx->in_flight = nullptr; }
+		if(b->ctx->last_decoded == b) b->ctx->last_decoded = nullptr;
+		if(b->ctx->host_batch == b) b->ctx->host_batch = nullptr;
 	}
 	b->own_arena.release();
 	delete b;
@@ -799,8 +839,7 @@ static int build_and_launch(crthip_batch *b) {
 
 	t1 = now_us();
 	// ---- reserve device + pinned memory; one batch in flight per context ----
-	if(ctx->in_flight && ctx->in_flight != b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
-	if(ctx->in_flight == b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);        // one batch in flight per context: the previous one's status is kept in its object
 	if(ctx->scratch.reserve(pl.total + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 	if(ctx->staging.reserve(pl.jobs_bytes + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 	uint8_t *base = (uint8_t *)ctx->scratch.p;
@@ -974,7 +1013,7 @@ static int build_and_launch(crthip_batch *b) {
 		}
 	}
 	b->stats.output_bytes = ob;
-	ctx->in_flight = b;
+	ctx->in_flight = b; ctx->last_decoded = b;
 	b->decoded = true;
 	b->dirty = false;
 	t3 = now_us();
@@ -992,27 +1031,8 @@ extern "C" int crthip_batch_sync(crthip_batch *b, int32_t *status) {
 	if(!b || !b->ctx) return fail(CRTHIP_E_ARGUMENT);
 	crthip_ctx *ctx = b->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if(ctx->in_flight == b) { if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE); }   // else: harvested when the context moved on (or never decoded)
 	int first = CRTHIP_OK;
-	if(ctx->in_flight == b) {
-		const int32_t *hs = (const int32_t *)ctx->status_host.p;
-		for(size_t i = 0; i < b->blobs.size(); i++) {
-			int32_t s = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
-			b->status[i] = s;
-		}
-		b->stats.topology_fallbacks = 0;
-		for(size_t i = 0; i < b->blobs.size(); i++) b->stats.topology_fallbacks += (uint64_t)(hs[b->blobs.size() + i] & 1);
-		// more than one blob in twenty redone on the HBM front (5x slower): four times the edge slots from the next batch on;
-		// a long run without any: try half again, and be more patient the next time that turns out to be too little
-		if(b->stats.topology_fallbacks*20 > b->blobs.size()) {
-			if(ctx->topo_scale < 16) ctx->topo_scale *= 4;
-			if(ctx->topo_calm == 0 && ctx->topo_patience < (1u << 20)) ctx->topo_patience *= 2;    // fell back right after scaling down
-			ctx->topo_calm = 0;
-		} else if(b->stats.topology_fallbacks == 0 && ctx->topo_scale > 1 && ++ctx->topo_calm >= ctx->topo_patience) {
-			ctx->topo_scale /= 2; ctx->topo_calm = 0;
-		}
-		ctx->in_flight = nullptr;
-	}
 	for(size_t i = 0; i < b->blobs.size(); i++) {
 		if(status) status[i] = b->status[i];
 		if(b->status[i] && !first) { first = b->status[i]; fail(first, std::string(crthip_strerror(first)) + " (blob " + std::to_string(i) + ")"); }
@@ -1045,6 +1065,7 @@ extern "C" int crthip_batch_kernel_times(crthip_batch *b, crthip_kernel_times *t
 extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const char *what, void *host_out, size_t cap) {
 	if(!b || i >= b->blobs.size() || !what || !host_out || !b->decoded) return fail(CRTHIP_E_ARGUMENT);
 	crthip_ctx *ctx = b->ctx;
+	if(ctx->last_decoded != b) return fail(CRTHIP_E_ARGUMENT, "the context's scratch block has been reused by a later call");
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	BlobPlan &P = b->blobs[i];
 	const uint8_t *src = nullptr; size_t n = 0;
@@ -1061,52 +1082,51 @@ extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const ch
 }
 
 // ------------------------------------------------------------------------------------------------
-// one blob, host buffers: the crt::Decoder facade's decode()
+// one blob, host buffers: the crt::Decoder facade's decode().  The batch object, the device output block and its pinned landing
+// zone live in the context: in the steady state a call is one upload of the blob, one upload of the job descriptors, the kernels,
+// and ONE download of all outputs - no allocation, no per-attribute copies.  Serialised per context (host_mutex).
 extern "C" int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
                                   void *index, uint32_t index_format) {
 	if(!ctx || !blob) return fail(CRTHIP_E_ARGUMENT);
+	if(len > 0xFFFFFFFFull) return fail(CRTHIP_E_LIMIT, "blob larger than 4 GiB");
+	std::lock_guard<std::mutex> lock(ctx->host_mutex);
 	HIP_TRY(hipSetDevice(ctx->device));
-	crthip_batch *b = nullptr;
 	uint32_t l32 = (uint32_t)len;
-	int err = crthip_batch_create(ctx, 1, &blob, &l32, nullptr, &b);
+	int err;
+	if(!ctx->host_batch) err = crthip_batch_create(ctx, 1, &blob, &l32, nullptr, &ctx->host_batch);
+	else err = crthip_batch_reset(ctx->host_batch, 1, &blob, &l32, nullptr);
 	if(err) return err;
+	crthip_batch *b = ctx->host_batch;
 	const BlobLayout &L = b->blobs[0].L;
 	const uint32_t nvert = L.h.nvert, nface = L.h.nface;
-	std::vector<crthip_attr_binding> dev(L.h.attrs.size());
-	std::vector<size_t> bytes(L.h.attrs.size(), 0);
-	std::vector<void *> allocs;
-	auto cleanup = [&]() { for(void *p : allocs) (void)hipFree(p); crthip_batch_destroy(b); };
-	for(size_t k = 0; k < L.h.attrs.size(); k++) {
-		dev[k] = attrs ? attrs[k] : crthip_attr_binding{nullptr, 0, 0};
+	const size_t na = L.h.attrs.size();
+	if(na && !attrs) return fail(CRTHIP_E_ARGUMENT);
+	crthip_attr_binding dev[CRTHIP_MAX_ATTRS];
+	size_t off[CRTHIP_MAX_ATTRS + 1], bytes[CRTHIP_MAX_ATTRS + 1];
+	size_t total = 0;
+	for(size_t k = 0; k < na; k++) {
+		dev[k] = attrs[k]; bytes[k] = 0; off[k] = 0;
 		if(!dev[k].buffer) continue;
 		const AttrHeader &a = L.h.attrs[k];
-		size_t nb;
-		if(a.codec == CRTHIP_CODEC_NORMAL) nb = (size_t)nvert*3*(dev[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
-		else if(a.codec == CRTHIP_CODEC_COLOR) nb = (size_t)nvert*(dev[k].out_components ? dev[k].out_components : 4);
-		else nb = (size_t)nvert*a.N*4;
-		bytes[k] = nb;
-		void *d = nullptr;
-		if(hipMalloc(&d, nb + 16) != hipSuccess) { cleanup(); return fail(CRTHIP_E_NOMEM); }
-		allocs.push_back(d);
-		dev[k].buffer = d;
+		if(a.codec == CRTHIP_CODEC_NORMAL) bytes[k] = (size_t)nvert*3*(dev[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
+		else if(a.codec == CRTHIP_CODEC_COLOR) bytes[k] = (size_t)nvert*(dev[k].out_components ? dev[k].out_components : 4);
+		else bytes[k] = (size_t)nvert*a.N*4;
+		off[k] = total; total += (bytes[k] + 15) & ~(size_t)15;
 	}
-	void *dindex = nullptr; size_t ibytes = 0;
-	if(index && nface) {
-		ibytes = (size_t)nface*3*(index_format == CRTHIP_FMT_UINT16 ? 2 : 4);
-		if(hipMalloc(&dindex, ibytes + 16) != hipSuccess) { cleanup(); return fail(CRTHIP_E_NOMEM); }
-		allocs.push_back(dindex);
-	}
-	err = crthip_batch_bind(b, 0, dev.data(), dindex, index_format);
+	bytes[na] = 0; off[na] = total;
+	if(index && nface) { bytes[na] = (size_t)nface*3*(index_format == CRTHIP_FMT_UINT16 ? 2 : 4); total += (bytes[na] + 15) & ~(size_t)15; }
+	if(ctx->host_out.reserve(total + 16) != CRTHIP_OK || ctx->host_pin.reserve(total + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	uint8_t *dbase = (uint8_t *)ctx->host_out.p, *hbase = (uint8_t *)ctx->host_pin.p;
+	for(size_t k = 0; k < na; k++) if(dev[k].buffer) dev[k].buffer = dbase + off[k];
+	err = crthip_batch_bind(b, 0, dev, bytes[na] ? dbase + off[na] : nullptr, index_format);
 	if(!err) err = crthip_batch_decode(b);
-	if(!err) err = crthip_batch_sync(b, nullptr);
+	if(!err && total && hipMemcpyAsync(hbase, dbase, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
+	const int serr = crthip_batch_sync(b, nullptr);          // waits for the copy too (same stream); keeps the context consistent on error
+	if(!err) err = serr;
 	if(!err) {
-		for(size_t k = 0; k < dev.size() && !err; k++)
-			if(dev[k].buffer && hipMemcpy(attrs[k].buffer, dev[k].buffer, bytes[k], hipMemcpyDeviceToHost) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
-		if(dindex && !err && hipMemcpy(index, dindex, ibytes, hipMemcpyDeviceToHost) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
+		for(size_t k = 0; k < na; k++) if(bytes[k]) memcpy(attrs[k].buffer, hbase + off[k], bytes[k]);
+		if(bytes[na]) memcpy(index, hbase + off[na], bytes[na]);
 	}
-	std::string keep = g_error;
-	cleanup();
-	g_error = keep;
 	return err;
 }
 
@@ -1117,7 +1137,8 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
                                              crthip_kernel_times *times) {
 	if(!ctx || !host_blocks || !device_blocks || !block_offset || !device_out || !out_offset) return fail(CRTHIP_E_ARGUMENT);
 	HIP_TRY(hipSetDevice(ctx->device));
-	if(ctx->in_flight) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->in_flight = nullptr; }
+	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
+	ctx->last_decoded = nullptr;
 	std::vector<TunStream> tun; std::vector<uint32_t> chunk_stream; std::vector<FillJob> fills;
 	uint32_t chunks = 0; bool multi = false;
 	for(uint32_t i = 0; i < n; i++) {

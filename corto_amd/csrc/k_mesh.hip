@@ -308,6 +308,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lexit_%=\n" \
    /* ---------------- VERTEX (decoder.cpp:294-309) */ \
 							"Lvertex_%=:\n" \
+							"  s_and_b32 %[t0], %[sw], 0xffff\n"   /* VERTEX LEFT VERTEX LEFT ahead: leave for the run step (TOPO_RUN_STEP) */ \
+							"  s_cmp_eq_u32 %[t0], 0x1010\n" \
+							"  s_cbranch_scc1 Lrun_%=\n" \
 							"  s_sub_u32 %[budget], %[budget], 1\n"   /* vertex ids and ring slots left (SCC = borrow: none) */ \
 							"  s_cbranch_scc1 Lexit_%=\n" \
 							"  s_and_b32 %[t1], %[nq], %[mask]\n"   /* s: slot of the second new edge */ \
@@ -400,15 +403,256 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  v_readfirstlane_b32 %[swn], v55\n" \
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc1 Ltop_%=\n" \
+							"  s_branch Lexit_%=\n" \
+							"Lrun_%=:\n" \
+							"  s_mov_b32 %[run], 1\n" \
 							"Lexit_%=:\n" \
 							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start), \
 							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en), \
 							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1), \
-							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [t3] "=&s"(t3_), [budget] "+s"(budget_) \
+							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [t3] "=&s"(t3_), [budget] "+s"(budget_), [run] "+s"(run_) \
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
 							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+
+// The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
+// is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
+// with SWAR arithmetic, four words written per lane.  Used for the first fill and for every slide of the window, which lane 0
+// alone did a byte at a time before: 0.1 ms per slide, 4 ms for a 256K-triangle mesh's 42 slides - more than its whole automaton now.
+//   X: four symbol bytes -> (in the low 16 bits) four nibbles
+#define TOPO_PACK4(X, T, U) \
+	"  v_and_b32 " T ", 0x7f7f7f7f, " X "\n" \
+	"  v_add_u32 " T ", 0x79797979, " T "\n" \
+	"  v_or_b32 " T ", " T ", " X "\n" \
+	"  v_and_b32 " T ", 0x80808080, " T "\n"       /* 0x80 in every byte >= 7 */ \
+	"  v_lshrrev_b32 " T ", 7, " T "\n" \
+	"  v_lshlrev_b32 " U ", 4, " T "\n" \
+	"  v_sub_u32 " T ", " U ", " T "\n"            /* 15 there */ \
+	"  v_or_b32 " X ", " X ", " T "\n" \
+	"  v_and_b32 " X ", 0x0f0f0f0f, " X "\n" \
+	"  v_lshrrev_b32 " T ", 4, " X "\n" \
+	"  v_or_b32 " X ", " X ", " T "\n" \
+	"  v_and_b32 " X ", 0x00ff00ff, " X "\n" \
+	"  v_lshrrev_b32 " T ", 8, " X "\n" \
+	"  v_or_b32 " X ", " X ", " T "\n"
+//   W = nibbles of LO | nibbles of HI << 16, then every nibble from (rem - 8*I) on set to 15 (symbols behind the stream)
+#define TOPO_PACK_WORD(W, LO, HI, I) \
+	TOPO_PACK4(LO, "v62", "v63") \
+	TOPO_PACK4(HI, "v62", "v63") \
+	"  v_and_b32 " LO ", 0xffff, " LO "\n" \
+	"  v_lshl_or_b32 " W ", " HI ", 16, " LO "\n" \
+	"  v_add_u32 v62, " I ", v42\n" \
+	"  v_max_i32 v62, 0, v62\n" \
+	"  v_min_u32 v62, 8, v62\n" \
+	"  v_lshlrev_b32 v62, 2, v62\n" \
+	"  v_lshlrev_b64 v[56:57], v62, v[58:59]\n" \
+	"  v_or_b32 " W ", " W ", v56\n"
+#define TOPO_FILL_WINDOW(WINBASE) do { \
+	uint64_t fsv_, fm0_, fm1_; uint32_t fwb_; \
+	asm volatile( \
+		"  s_mov_b64 %[sv], exec\n" \
+		"  s_mov_b64 exec, -1\n" \
+		"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+		"  v_mbcnt_hi_u32_b32 v60, -1, v60\n" \
+		"  v_lshlrev_b32 v61, 2, v60\n"                  /* a lane's first word of a pass */ \
+		"  v_mov_b32 v58, -1\n" \
+		"  v_mov_b32 v59, 0\n" \
+		"  s_mov_b32 %[wb], 0\n" \
+		"Lfpass_%=:\n" \
+		"  v_add_u32 v40, %[wb], v61\n"                  /* word w of the window */ \
+		"  v_cmp_gt_u32 vcc, %[symwords], v40\n" \
+		"  s_and_saveexec_b64 %[m0], vcc\n" \
+		"  s_cbranch_execz Lfnext_%=\n" \
+		"  v_lshlrev_b32 v41, 3, v40\n" \
+		"  v_add_u32 v41, %[winbase], v41\n"             /* its first symbol */ \
+		"  v_sub_u32 v42, %[nclers], v41\n"              /* symbols of the stream from there on (signed) */ \
+		"  v_mov_b32 v44, 0\n" \
+		"  v_mov_b32 v45, 0\n" \
+		"  v_mov_b32 v46, 0\n" \
+		"  v_mov_b32 v47, 0\n" \
+		"  v_mov_b32 v48, 0\n" \
+		"  v_mov_b32 v49, 0\n" \
+		"  v_mov_b32 v50, 0\n" \
+		"  v_mov_b32 v51, 0\n" \
+		"  v_cmp_lt_i32 vcc, 0, v42\n" \
+		"  s_and_saveexec_b64 %[m1], vcc\n" \
+		"  global_load_dwordx4 v[44:47], v41, %[gcl]\n" \
+		"  s_mov_b64 exec, %[m1]\n" \
+		"  v_cmp_lt_i32 vcc, 16, v42\n" \
+		"  s_and_saveexec_b64 %[m1], vcc\n" \
+		"  global_load_dwordx4 v[48:51], v41, %[gcl] offset:16\n" \
+		"  s_mov_b64 exec, %[m1]\n" \
+		"  s_waitcnt vmcnt(0)\n" \
+		TOPO_PACK_WORD("v52", "v44", "v45", "0") \
+		TOPO_PACK_WORD("v53", "v46", "v47", "-8") \
+		TOPO_PACK_WORD("v54", "v48", "v49", "-16") \
+		TOPO_PACK_WORD("v55", "v50", "v51", "-24") \
+		"  v_lshlrev_b32 v40, 2, v40\n" \
+		"  v_add_u32 v40, %[clbase], v40\n" \
+		"  ds_write_b128 v40, v[52:55]\n" \
+		"Lfnext_%=:\n" \
+		"  s_mov_b64 exec, -1\n" \
+		"  s_add_u32 %[wb], %[wb], 256\n" \
+		"  s_cmp_lt_u32 %[wb], %[symwords]\n" \
+		"  s_cbranch_scc1 Lfpass_%=\n" \
+		"  s_mov_b64 exec, 3\n"                          /* two words of "window exhausted" nibbles behind it */ \
+		"  v_add_u32 v40, %[symwords], v60\n" \
+		"  v_lshlrev_b32 v40, 2, v40\n" \
+		"  v_add_u32 v40, %[clbase], v40\n" \
+		"  v_mov_b32 v41, 0xeeeeeeee\n" \
+		"  ds_write_b32 v40, v41\n" \
+		"  s_waitcnt lgkmcnt(0)\n" \
+		"  s_mov_b64 exec, %[sv]\n" \
+		: [sv] "=&s"(fsv_), [m0] "=&s"(fm0_), [m1] "=&s"(fm1_), [wb] "=&s"(fwb_) \
+		: [winbase] "s"(WINBASE), [nclers] "s"(nclers), [symwords] "s"(symwords), [clbase] "s"((uint32_t)(uintptr_t)cl32), [gcl] "s"(gcl) \
+		: "memory", "scc", "vcc", "v40", "v41", "v42", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
+		  "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"); } while(0)
+
+// The run step.  A sphere-like mesh's symbol stream is "VERTEX LEFT" repeated (89 % of a 4K-triangle blob's symbols sit in 120
+// such runs of 16 pairs on average, 98 % of a 256K-triangle mesh's in runs of 126), and a run is regular: its LEFTs close
+// against the edges the previous layer queued, which sit in CONSECUTIVE ring slots linked prev -> slot + 1, its VERTEXes
+// take consecutive vertex ids and ring slots.  So pair j of a run is a function of the state before the run, j, and the
+// records of ring slots ep+j-2 .. ep+j - and the wave's 63 parked lanes are switched on to do up to 63 pairs in one pass:
+//   lane j reads its pair of symbols and the records of slots ep+j, ep+j-1, ep+j-2 (x = v0, w = links);
+//   valid_j = symbols are (VERTEX, LEFT) && link(ep+j-1).prev == ep+j (j > 0) && ep+j != e.next && j < kmax; k = first invalid lane;
+//   with a_j = j ? x[j-1] : v0,  b_j = j ? vc+j-1 : v1,  c_j = j > 1 ? x[j-2] : j ? v0 : v2   (the current edge before pair j is
+//   (a_j, b_j, c_j)), lanes j < k write: prediction[vc+j] = (b_j, a_j, c_j); faces (b_j, a_j, vc+j) and (vc+j, a_j, x[j]);
+//   the queued edge's record rec[nq+j] = {vc+j, b_j, a_j, prev = nq+j+1 (lazy for the last), next = nq+j-1 (e.next for the first)};
+//   the deleted flag of slot ep+j.  Lane 0 links e.next.prev = nq.  The state after the run comes from lane k-1 (readlane),
+//   the symbol window registers from lane k (the words it read are the ones the serial loop continues with).
+// (e.next's prev link is stale while the current edge is lazy, hence the ep+j != e.next cut; every other prev link the chain
+// follows belongs to a live queued edge.)  Checked against the oracle on the host model tools/topo_run_model.py before it was
+// written here.  Wait states for gfx950's VALU-SGPR / readlane / wide-store hazards are inside the string (s_nop).
+#define TOPO_RUN_FACE32 \
+	"  v_mov_b32 v35, v34\n" \
+	"  v_mov_b32 v36, v33\n" \
+	"  v_mov_b32 v37, v46\n" \
+	"  v_mad_u32_u24 v59, v60, 24, %[fbyte]\n" \
+	"  global_store_dwordx4 v59, v[32:35], %[faceb]\n" \
+	"  global_store_dwordx2 v59, v[36:37], %[faceb] offset:16\n"
+#define TOPO_RUN_FACE16 \
+	"  v_and_b32 v36, 0xffff, v32\n" \
+	"  v_lshl_or_b32 v36, v33, 16, v36\n" \
+	"  v_and_b32 v37, 0xffff, v34\n" \
+	"  v_lshl_or_b32 v37, v34, 16, v37\n" \
+	"  v_and_b32 v38, 0xffff, v33\n" \
+	"  v_lshl_or_b32 v38, v46, 16, v38\n" \
+	"  v_mad_u32_u24 v59, v60, 12, %[fbyte]\n" \
+	"  global_store_dwordx3 v59, v[36:38], %[faceb]\n"
+#define TOPO_RUN_STEP(FACE) \
+	asm volatile( \
+		"  s_mov_b64 %[sv], exec\n" \
+		"  s_mov_b64 exec, -1\n" \
+		"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+		"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
+		"  v_lshlrev_b32 v40, 1, v60\n" \
+		"  v_add_u32 v40, %[cler], v40\n"                /* p = cler + 2j: the pair's first symbol */ \
+		"  v_lshrrev_b32 v41, 3, v40\n" \
+		"  v_add_u32 v41, %[wb], v41\n" \
+		"  v_lshlrev_b32 v41, 2, v41\n" \
+		"  v_add_u32 v41, %[clbase], v41\n" \
+		"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
+		"  v_add_u32 v44, %[ep], v60\n" \
+		"  v_add_u32 v48, -1, v44\n" \
+		"  v_add_u32 v49, -2, v44\n" \
+		"  v_and_b32 v44, %[mask], v44\n"                /* slot ep+j */ \
+		"  v_and_b32 v48, %[mask], v48\n" \
+		"  v_and_b32 v49, %[mask], v49\n" \
+		"  v_lshlrev_b32 v45, 4, v44\n" \
+		"  v_lshlrev_b32 v48, 4, v48\n" \
+		"  v_lshlrev_b32 v49, 4, v49\n" \
+		"  v_add_u32 v45, %[recb], v45\n" \
+		"  v_add_u32 v48, %[recb], v48\n" \
+		"  v_add_u32 v49, %[recb], v49\n" \
+		"  ds_read2_b32 v[46:47], v45 offset1:3\n"       /* x[j], w[j] */ \
+		"  ds_read2_b32 v[50:51], v48 offset1:3\n"       /* x[j-1], w[j-1] */ \
+		"  ds_read_b32 v52, v49\n"                       /* x[j-2] */ \
+		"  v_and_b32 v53, 7, v40\n" \
+		"  v_lshlrev_b32 v53, 2, v53\n" \
+		"  s_waitcnt lgkmcnt(0)\n" \
+		"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
+		"  v_and_b32 v56, 0xff, v54\n" \
+		"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
+		"  v_cmp_eq_u32 vcc, 16, v56\n"                  /* (VERTEX, LEFT) */ \
+		"  v_cmp_eq_u32 %[m0], v57, v44\n" \
+		"  v_cmp_eq_u32 %[m1], 0, v60\n" \
+		"  s_nop 1\n" \
+		"  s_or_b64 %[m0], %[m0], %[m1]\n" \
+		"  s_and_b64 vcc, vcc, %[m0]\n" \
+		"  v_cmp_ne_u32 %[m0], %[en], v44\n" \
+		"  v_cmp_gt_u32 %[m1], %[kmax], v60\n" \
+		"  s_nop 1\n" \
+		"  s_and_b64 %[m0], %[m0], %[m1]\n" \
+		"  s_and_b64 vcc, vcc, %[m0]\n" \
+		"  s_not_b64 %[m0], vcc\n" \
+		"  s_ff1_i32_b64 %[k], %[m0]\n"                  /* first lane that cannot join (kmax < 64: there is one) */ \
+		"  s_cmp_eq_u32 %[k], 0\n" \
+		"  s_cbranch_scc1 Lrdone_%=\n" \
+		"  s_sub_u32 %[km1], %[k], 1\n" \
+		"  v_readlane_b32 %[swo], v54, %[k]\n" \
+		"  v_readlane_b32 %[swno], v43, %[k]\n" \
+		"  v_readlane_b32 %[xl], v46, %[km1]\n" \
+		"  v_readlane_b32 %[wl], v47, %[km1]\n" \
+		"  s_bfm_b64 exec, %[k], 0\n"                    /* lanes 0 .. k-1 */ \
+		"  v_cmp_ne_u32 vcc, 0, v60\n" \
+		"  v_cmp_lt_u32 %[m1], 1, v60\n" \
+		"  v_mov_b32 v38, %[v0]\n" \
+		"  v_mov_b32 v39, %[v1]\n" \
+		"  v_add_u32 v34, %[vc], v60\n"                  /* the new vertex vc+j */ \
+		"  v_add_u32 v32, -1, v34\n" \
+		"  v_cndmask_b32 v33, v38, v50, vcc\n"           /* a_j */ \
+		"  v_cndmask_b32 v32, v39, v32, vcc\n"           /* b_j */ \
+		"  v_cndmask_b32 v58, v38, v52, %[m1]\n" \
+		"  v_mov_b32 v39, %[v2]\n" \
+		"  s_nop 0\n" \
+		"  v_cndmask_b32 v58, v39, v58, vcc\n"           /* c_j */ \
+		"  v_mov_b32 v56, v32\n" \
+		"  v_mov_b32 v57, v33\n" \
+		"  v_mul_lo_u32 v59, v34, 12\n" \
+		"  s_nop 0\n" \
+		"  v_readlane_b32 %[al], v33, %[km1]\n" \
+		"  v_readlane_b32 %[bl], v32, %[km1]\n" \
+		"  global_store_dwordx3 v59, v[56:58], %[predb]\n" \
+		FACE \
+		"  v_add_u32 v40, %[nq], v60\n" \
+		"  v_add_u32 v53, 1, v40\n" \
+		"  v_add_u32 v54, -1, v40\n" \
+		"  v_and_b32 v41, %[mask], v40\n"                /* its slot nq+j */ \
+		"  v_and_b32 v53, %[mask], v53\n" \
+		"  v_and_b32 v54, %[mask], v54\n" \
+		"  v_mov_b32 v55, %[en]\n" \
+		"  v_cmp_eq_u32 %[m1], %[km1], v60\n" \
+		"  v_cndmask_b32 v54, v55, v54, vcc\n"           /* next: e.next for the first, else slot nq+j-1 */ \
+		"  v_mov_b32 v55, 0xffff\n" \
+		"  s_nop 0\n" \
+		"  v_cndmask_b32 v53, v53, v55, %[m1]\n"         /* prev: slot nq+j+1, lazy for the last */ \
+		"  v_lshl_or_b32 v51, v54, 16, v53\n" \
+		"  v_mov_b32 v48, v34\n" \
+		"  v_mov_b32 v49, v32\n" \
+		"  v_mov_b32 v50, v33\n" \
+		"  v_lshlrev_b32 v41, 4, v41\n" \
+		"  v_add_u32 v41, %[recb], v41\n" \
+		"  ds_write_b128 v41, v[48:51]\n" \
+		"  v_mov_b32 v55, 0x8000\n" \
+		"  ds_write_b16 v45, v55 offset:10\n"            /* slot ep+j: deleted */ \
+		"  s_mov_b64 exec, %[sv]\n" \
+		"  s_and_b32 %[m0s], %[nq], %[mask]\n"           /* e.next.prev = first new slot */ \
+		"  s_lshl_b32 %[km1], %[en], 4\n" \
+		"  s_add_u32 %[km1], %[km1], %[recb]\n" \
+		"  v_mov_b32 v40, %[m0s]\n" \
+		"  v_mov_b32 v41, %[km1]\n" \
+		"  ds_write_b16 v41, v40 offset:12\n" \
+		"  s_nop 1\n" \
+		"Lrdone_%=:\n" \
+		"  s_mov_b64 exec, %[sv]\n" \
+		: [k] "=&s"(rk_), [km1] "=&s"(rkm1_), [swo] "=&s"(rswo_), [swno] "=&s"(rswno_), [xl] "=&s"(rxl_), [wl] "=&s"(rwl_), \
+		  [al] "=&s"(ral_), [bl] "=&s"(rbl_), [sv] "=&s"(rsv_), [m0] "=&s"(rm0_), [m1] "=&s"(rm1_), [m0s] "=&s"(rm0s_) \
+		: [cler] "s"(cler), [wb] "s"(wbias - 1u), [clbase] "s"((uint32_t)(uintptr_t)cl32), [ep] "s"(ep), [en] "s"(en), [mask] "s"(MASK), \
+		  [recb] "s"((uint32_t)(uintptr_t)rec), [kmax] "s"(rkmax_), [v0] "s"(v0), [v1] "s"(v1), [v2] "s"(v2), [vc] "s"(vc), [nq] "s"(nq), \
+		  [fbyte] "s"(start*(U16 ? 2u : 4u)), [predb] "s"(predb), [faceb] "s"(faceb) \
+		: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
+		  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 
 template <bool U16>
 __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
@@ -424,12 +668,6 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	const uint32_t nspl = J.split_nwords < TOPO_SPLIT_LDS ? J.split_nwords : TOPO_SPLIT_LDS;   // waits ~2 us (the load, and every store in flight before it)
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	const uint32_t nclers = J.nclers, symwords = SYMW/8;
-	auto pack8 = [&](uint32_t s0) -> uint32_t {                         // symbols s0 .. s0+7 as nibbles; any invalid byte, and
-		uint32_t v = 0;                                                    // everything behind the stream, is the invalid nibble
-		for(uint32_t k = 0; k < 8; k++) { const uint32_t i = s0 + k, b = i < nclers ? (uint32_t)gcl[i] : 15u; v |= (b < 7u ? b : 15u) << (4*k); }
-		return v;
-	};
-
 	// automaton state, alive across window refills (uniform: only lane 0 ever changes it)
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
 	CRT_GLOBAL uint8_t *predb = (CRT_GLOBAL uint8_t *)as_global(J.pred);   // prediction triple of vertex vc at byte 12*vc (vertices are numbered in creation order)
@@ -447,7 +685,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	// slides the window by itself between chains when a mesh has more symbols than the window (3 instructions per symbol)
 	// (two words behind the window: "window exhausted" nibbles - a chain that outruns the window ends in the HBM redo, so that the
 	// loop never loads symbols from HBM itself: a load's s_waitcnt would also wait for every face / prediction store in flight)
-	for(uint32_t w = threadIdx.x; w < symwords + 2; w += 64) cl32[w] = w < symwords ? pack8(8*w) : 0xEEEEEEEEu;
+	TOPO_FILL_WINDOW(0u);
 	for(uint32_t w = threadIdx.x; w < nspl; w += 64) spl[w] = split[w];
 	__syncthreads();
 	if(threadIdx.x != 0) return true;
@@ -464,6 +702,10 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	else { u32x3 f_; f_.x = (a); f_.y = (b); f_.z = (c); *(CRT_GLOBAL u32x3 *)(faceb + start*4u) = f_; } start += 3; } while(0)
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)(predb + vc*12u) = p_; } while(0)   // always right before vc++
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
+	// slide the symbol window up to the current symbol (whole wave, TOPO_FILL_WINDOW) and reload the two window registers
+#define TOPO_SLIDE() do { winbase = cler & ~31u; TOPO_FILL_WINDOW(winbase); \
+	{ const uint32_t wi_ = (cler - winbase) >> 3; sw = TOPO_S(cl32[wi_]) >> (4*(cler & 7u)); swn = TOPO_S(cl32[wi_ + 1]); } \
+	wbias = 1u - (winbase >> 3); slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = TOPO_S(cl32[(cler >> 3) + wbias]); } } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
 #define TOPO_RELEASE(id, z) do { if((id) > MASK && !(TOPO_S(z) & TOPO_DELAYED)) { freel[nfree] = (uint16_t)(id); nfree++; } } while(0)
@@ -478,13 +720,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 			const uint32_t end = ge*3;
 			nq = 0; qpos = 0; mbump = RING; nfree = 0; cold[K_NDELAYED] = 0;
 			while(start < end && !err) {
-				if(cler >= slide_at) {                                      // between chains: slide the window before it runs low
-					winbase = cler & ~7u;
-					for(uint32_t w = 0; w < symwords; w++) cl32[w] = pack8(winbase + 8*w);
-					sw = TOPO_S(cl32[0]) >> (4*(cler & 7u)); swn = TOPO_S(cl32[1]);
-					wbias = 1u - (winbase >> 3);
-					slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu;
-				}
+				if(cler >= slide_at) TOPO_SLIDE();                          // slide the window before it runs low
 				// ---- cold: fetch the next edge to process: ring, DELAY stack, or a new seed face ----
 				uint32_t f;
 				u32x4 t0;
@@ -551,16 +787,33 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 
 				// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
 				for(;;) {
+					if(cler >= slide_at) TOPO_SLIDE();                      // (a chain longer than the window's margin: mid-chain)
 					{
 						// The common steps in hand-scheduled gfx950 ISA: VERTEX, and LEFT / RIGHT against a ring-slot (queued)
 						// neighbour, ~40 instructions per symbol where the compiler's dispatch of the C++ below spends ~68
 						// (scalar copies at every join).  The block PEEKS at the next symbol and leaves with the state
 						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
 						// or ring running out, the group's last face - which the C++ below then handles.
-						uint32_t t0_, t1_, t2_, t3_, c_;
+						uint32_t t0_, t1_, t2_, t3_, c_, run_ = 0;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
 						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32); }
 						if(start >= end) break;
+						if(run_ && ep <= MASK) {
+							// (VERTEX LEFT)^k ahead: up to 63 pairs in one pass of the whole wave (TOPO_RUN_STEP above).  Bounded by the
+							// vertex ids and ring slots left, the group's faces and the symbols in the LDS window.
+							uint32_t rk_, rkm1_, rswo_, rswno_, rxl_, rwl_, ral_, rbl_, rm0s_;
+							uint64_t rsv_, rm0_, rm1_;
+							const uint32_t rkmax_ = TOPO_S(min(min(budget_, 63u), min((end - start)/6u, (winbase + SYMW - cler) >> 1)));
+							if constexpr(U16) { TOPO_RUN_STEP(TOPO_RUN_FACE16); } else { TOPO_RUN_STEP(TOPO_RUN_FACE32); }
+							if(rk_) {
+								nc_next = rk_ == 1 ? en : (nq + rk_ - 2u) & MASK;
+								v0 = rxl_; v2 = ral_; nc_v1 = rbl_; ep = rwl_ & 0xFFFFu;
+								v1 = vc + rk_ - 1u; en = (nq + rk_ - 1u) & MASK; nc = en;
+								vc += rk_; nq += rk_; start += 6u*rk_; cler += 2u*rk_; sw = rswo_; swn = rswno_;
+								if(start >= end) break;
+								continue;
+							}
+						}
 					}
 					uint32_t c; TOPO_SYMBOL(c);
 					if(c == C_VERTEX) {                                    // decoder.cpp:294-309
@@ -631,6 +884,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #undef TOPO_PRED
 #undef TOPO_PUT
 #undef TOPO_SYMBOL
+#undef TOPO_SLIDE
 #undef TOPO_RELEASE
 #undef TOPO_MATERIALISE
 		}

@@ -49,7 +49,7 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 	while((uint64_t)want*want < (uint64_t)64*nface && want < ring_max) want <<= 1;
 	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }
 	ring = want; pool = want;
-	const uint32_t all = (nclers + 64 + 7) & ~7u;
+	const uint32_t all = (nclers + 64 + 31) & ~31u;       // whole 16-byte vectors of nibbles (k_mesh.hip: TOPO_FILL_WINDOW)
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;
 }
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Host model of k_topology_lds's data structure (ring of queued edges + pool of survivors + lazy current edge) with the
+(VERTEX LEFT)^k run step done "in parallel" - the formulation the kernel uses (k_mesh.hip: TOPO_RUN_STEP), checked here
+against the oracle's faces and prediction triples before it is written in ISA.  Development aid: not a product path and
+not a test (tests/ compare the real kernel with the oracle)."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+V, L, R, E, B, D, S = range(7)
+LAZY = 0xFFFF
+
+
+class Model:
+    def __init__(self, clers, nvert, nface, group_end, ring=1 << 12, pool=1 << 12, use_runs=True, ref_faces=None):
+        self.cl = list(clers) + [15] * 64
+        self.nvert, self.nface = nvert, nface
+        self.RING, self.MASK, self.POOL = ring, ring - 1, pool
+        self.rec = [[0, 0, 0, 0, 0, 0] for _ in range(ring + pool)]   # v0 v1 v2 flags(0 live,1 dead) prev next
+        self.faces = []
+        self.pred = np.zeros((nvert, 3), dtype=np.int64)
+        self.use_runs = use_runs
+        self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
+        self.group_end = group_end
+        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0)
+
+    def run(self):
+        cl = self.cl
+        MASK = self.MASK
+        rec = self.rec
+        cler = 0; vc = 0; start = 0
+        for ge in self.group_end:
+            end = ge * 3
+            nq = qpos = 0; mbump = self.RING; free = []; delayed = []
+            while start < end:
+                # fetch next edge
+                if qpos != nq:
+                    t = rec[qpos & MASK]; qpos += 1
+                    if t[3]: continue
+                    cur = list(t)
+                elif delayed:
+                    f = delayed.pop(); t = rec[f]; free.append(f)
+                    if t[3]: continue
+                    cur = list(t)
+                else:
+                    c = cl[cler]; cler += 1
+                    assert c in (V, S)
+                    last = vc - 1; vi = []
+                    for k in range(3):
+                        rv = int(self.ref_faces[start // 3][k])
+                        if c == S and rv != vc: v = rv
+                        else:
+                            self.pred[vc] = (last, last, last) if last >= 0 else (0xFFFFFFFF,) * 3
+                            last = v = vc; vc += 1
+                        vi.append(v)
+                    self.faces += vi; start += 3
+                    e0, e1, e2 = nq & MASK, (nq + 1) & MASK, (nq + 2) & MASK
+                    rec[e0] = [vi[1], vi[2], vi[0], 0, e2, e1]
+                    rec[e1] = [vi[2], vi[0], vi[1], 0, e0, e2]
+                    rec[e2] = [vi[0], vi[1], vi[2], 0, e1, e0]
+                    nq += 3
+                    continue
+                v0, v1, v2, _, ep, en = cur
+                while True:
+                    # ---- the run step: k pairs of (VERTEX, LEFT) at once
+                    if self.use_runs and cl[cler] == V and cl[cler + 1] == L and cl[cler + 2] == V and cl[cler + 3] == L:
+                        kmax = min(64, self.nvert - vc, self.RING - (nq - qpos), (end - start) // 6)
+                        ok = []
+                        for j in range(64):
+                            slot = (ep + j) & MASK
+                            o = j < kmax and cl[cler + 2 * j] == V and cl[cler + 2 * j + 1] == L and ep <= MASK and slot != en
+                            if j >= 1:
+                                o = o and rec[(ep + j - 1) & MASK][4] == slot
+                            ok.append(o)
+                        k = 0
+                        while k < 64 and ok[k]: k += 1
+                        if k < 64 and k < kmax and cl[cler + 2 * k] == V and cl[cler + 2 * k + 1] == L:
+                            if ((ep + k) & MASK) == en: self.stats['cut_en'] += 1
+                            else: self.stats['cut_chain'] += 1
+                        if k >= 1:
+                            x = [rec[(ep + j) & MASK][0] for j in range(k)]
+                            w = [rec[(ep + j) & MASK][4] for j in range(k)]
+                            en0 = en
+                            for j in range(k):
+                                a = v0 if j == 0 else x[j - 1]
+                                b = v1 if j == 0 else vc + j - 1
+                                c = v2 if j == 0 else (v0 if j == 1 else x[j - 2])
+                                self.pred[vc + j] = (b, a, c)
+                                self.faces += [b, a, vc + j, vc + j, a, x[j]]
+                                s = (nq + j) & MASK
+                                rec[s] = [vc + j, b, a, 0, ((nq + j + 1) & MASK) if j < k - 1 else LAZY, en0 if j == 0 else ((nq + j - 1) & MASK)]
+                                rec[(ep + j) & MASK][3] = 1
+                            rec[en0][4] = nq & MASK
+                            la = v0 if k == 1 else x[k - 2]
+                            v0n, v1n, v2n = x[k - 1], vc + k - 1, la
+                            epn = w[k - 1]; enn = (nq + k - 1) & MASK
+                            v0, v1, v2, ep, en = v0n, v1n, v2n, epn, enn
+                            vc += k; nq += k; start += 6 * k; cler += 2 * k
+                            self.stats['runs'] += 1; self.stats['run_pairs'] += k
+                            if start >= end: break
+                            continue
+                    c = cl[cler]; cler += 1
+                    self.stats['serial'] += 1
+                    if c == V or c == S:
+                        if c == S: opp = int(self.ref_faces[start // 3][2])
+                        else:
+                            self.pred[vc] = (v1, v0, v2); opp = vc; vc += 1
+                        assert nq - qpos <= MASK
+                        s = nq & MASK; nq += 1
+                        self.faces += [v1, v0, opp]; start += 3
+                        rec[en][4] = s
+                        rec[s] = [opp, v1, v0, 0, LAZY, en]
+                        v2 = v1; v1 = opp; en = s
+                    elif c == L:
+                        t = rec[ep]; pp, opp = t[4], t[0]; t[3] = 1
+                        if ep > MASK and ep not in delayed: free.append(ep)
+                        self.faces += [v1, v0, opp]; start += 3
+                        v2 = v0; v0 = opp; ep = pp
+                    elif c == R:
+                        t = rec[en]; nn, opp = t[5], t[1]; t[3] = 1
+                        if en > MASK and en not in delayed: free.append(en)
+                        self.faces += [v1, v0, opp]; start += 3
+                        v2 = v1; v1 = opp; en = nn
+                    else:
+                        def materialise():
+                            nonlocal mbump
+                            if free: f = free.pop()
+                            else: f = mbump; mbump += 1
+                            rec[f] = [v0, v1, v2, 0, ep, en]; rec[ep][5] = f; rec[en][4] = f
+                            return f
+                        if c == B: materialise()
+                        elif c == D: delayed.append(materialise())
+                        elif c == E:
+                            tp, tn = rec[ep], rec[en]
+                            pp, nn, opp = tp[4], tn[5], tp[0]
+                            tp[3] = 1; tn[3] = 1
+                            if ep > MASK and ep not in delayed: free.append(ep)
+                            if en > MASK and en not in delayed: free.append(en)
+                            rec[pp][5] = nn; rec[nn][4] = pp
+                            self.faces += [v1, v0, opp]; start += 3
+                        else:
+                            raise RuntimeError("bad symbol %d at %d" % (c, cler))
+                        break
+                    if start >= end: break
+        return np.array(self.faces, dtype=np.uint32).reshape(-1, 3), self.pred.astype(np.uint32)
+
+
+def check(mesh, name, **kw):
+    import corto_amd as ca
+    from oracle import oracle as oc
+    blob = ca.aligned_blob(ca.encode(mesh, **kw))
+    r = oc.decode(blob, trace=True)
+    cl = r["_clers"]
+    groups = ca.probe_groups(blob)
+    m = Model(cl, r["nvert"], r["nface"], groups, ref_faces=r["index"])
+    faces, pred = m.run()
+    okf = np.array_equal(faces, r["index"])
+    p = r["_prediction"]
+    okp = np.array_equal(pred[1:], p[1:])
+    print(name, "faces", okf, "pred", okp, m.stats)
+    assert okf and okp
+
+
+if __name__ == "__main__":
+    from corto_amd import synth
+    check(synth.closed_sphere(24, 12), "closed")
+    check(synth.closed_sphere(64, 40), "closed-big")
+    check(synth.bumpy_sphere(64, 32, seed=3), "c4")
+    check(synth.torus(48, 24), "torus")
+    check(synth.holey_disc(40), "disc")
+    check(synth.strip(400), "strip")
+    check(synth.merge([synth.bumpy_sphere(20, 10, seed=1), synth.torus(16, 8), synth.closed_sphere(10, 6)]), "merged")
+    check(synth.shuffled(synth.bumpy_sphere(32, 16, seed=5)), "shuffled")
+    check(synth.bumpy_sphere(512, 250, seed=1), "c2")
