@@ -76,6 +76,16 @@ class MeshDesc(C.Structure):
     ]
 
 
+class PoolItem(C.Structure):
+    _fields_ = [("nblobs", C.c_uint32), ("blobs", C.c_void_p), ("lens", C.c_void_p), ("device_arena", C.c_void_p)]
+
+
+class PoolReport(C.Structure):
+    _fields_ = [("elapsed_s", C.c_double), ("steps", C.c_uint64), ("triangles", C.c_uint64), ("vertices", C.c_uint64),
+                ("failed_blobs", C.c_uint64), ("first_error", C.c_int32), ("devices_used", C.c_uint32),
+                ("steps_per_device", C.c_uint64 * 16), ("topology_fallbacks", C.c_uint64)]
+
+
 class KernelTimes(C.Structure):
     _fields_ = [("count", C.c_uint32), ("name", C.c_char_p * MAX_KERNELS), ("ms", C.c_float * MAX_KERNELS),
                 ("launches", C.c_uint32 * MAX_KERNELS)]
@@ -141,6 +151,15 @@ def lib():
         L.crthip_tunstall_encode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.crthip_tunstall_decode_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.POINTER(KernelTimes)]
+        L.crthip_pool_create.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.crthip_pool_destroy.argtypes = [C.c_void_p]
+        L.crthip_pool_lanes.restype = C.c_uint32
+        L.crthip_pool_lanes.argtypes = [C.c_void_p]
+        L.crthip_pool_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(PoolReport), C.c_void_p]
+        L.crthip_pool_lane_item.restype = C.c_int64
+        L.crthip_pool_lane_item.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.crthip_pool_lane_read.restype = C.c_int64
+        L.crthip_pool_lane_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -414,6 +433,65 @@ class Batch:
     def close(self):
         if self.handle:
             lib().crthip_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """crthip_pool: the multi-GPU decode pool - `devices` GPUs, `threads` host threads per GPU with `depth` batches in flight each,
+    one shared work queue over the submitted batches, no collective (include/corto_hip.h)."""
+
+    def __init__(self, devices: Sequence[int], threads: int = 2, depth: int = 3):
+        self.devices = list(devices)
+        self.handle = C.c_void_p()
+        arr = np.array(self.devices, dtype=np.int32)
+        _check(lib().crthip_pool_create(len(self.devices), _np_ptr(arr), threads, depth, C.byref(self.handle)))
+        self.lanes = int(lib().crthip_pool_lanes(self.handle))
+        self._keep = None
+
+    def run(self, items, steps: int, warmup: int = 0, arenas=None):
+        """items: list of batches (each a list of aligned uint8 blobs).  arenas: None (every step uploads its blobs) or, per item, a
+        list with one device tensor per pool device (the item's blobs resident there in arena_layout order).
+        Returns (PoolReport, completion times of the timed steps in seconds since the timed region began)."""
+        n = len(items)
+        arr = (PoolItem * n)()
+        keep = []
+        for j, blobs in enumerate(items):
+            ptrs = (C.c_void_p * max(len(blobs), 1))(*[b.ctypes.data for b in blobs])
+            lens = np.array([len(b) for b in blobs], dtype=np.uint32)
+            ar = None
+            if arenas is not None and arenas[j] is not None:
+                ar = (C.c_void_p * len(self.devices))(*[(t.data_ptr() if t is not None else None) for t in arenas[j]])
+            keep.append((ptrs, lens, ar))
+            arr[j].nblobs = len(blobs); arr[j].blobs = C.cast(ptrs, C.c_void_p); arr[j].lens = lens.ctypes.data
+            arr[j].device_arena = C.cast(ar, C.c_void_p) if ar is not None else None
+        self._keep = (arr, keep, items, arenas)
+        rep = PoolReport()
+        stamps = np.zeros(max(steps, 1), dtype=np.float64)
+        _check(lib().crthip_pool_run(self.handle, n, arr, steps, warmup, C.byref(rep), _np_ptr(stamps)))
+        return rep, stamps[:steps]
+
+    def lane_item(self, lane: int):
+        slot = C.c_uint32()
+        it = int(lib().crthip_pool_lane_item(self.handle, lane, C.byref(slot)))
+        return it, int(slot.value)
+
+    def lane_read(self, lane: int, blob: int, what: str, dtype, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=dtype)
+        n = int(lib().crthip_pool_lane_read(self.handle, lane, blob, what.encode(), _np_ptr(out), out.nbytes))
+        if n < 0:
+            _check(n)
+        assert n == out.nbytes, (n, out.nbytes)
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().crthip_pool_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

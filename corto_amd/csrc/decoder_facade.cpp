@@ -3,18 +3,16 @@
 // on the device behind crthip_decode_host.
 #include "../../include/corto/decoder.h"
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "../../include/corto_hip.h"
 
 namespace crt {
 namespace {
-
-std::mutex g_mutex;
-crthip_ctx *g_ctx = nullptr;
-int g_device = -1;
 
 // upstream throws string literals; the C ABI hands back the same literals
 [[noreturn]] void raise(int code) {
@@ -31,23 +29,76 @@ int g_device = -1;
 	}
 }
 
-crthip_ctx *context() {
-	std::lock_guard<std::mutex> lock(g_mutex);
-	if(!g_ctx) {
-		int dev = g_device;
-		if(dev < 0) { const char *e = getenv("CORTO_HIP_DEVICE"); dev = e ? atoi(e) : 0; }
-		int err = crthip_ctx_create(dev, &g_ctx);
-		if(err) raise(err);
-	}
-	return g_ctx;
+// Upstream's Decoder objects share nothing (the library's only global is the read-only bmask[], src/bitstream.cpp:29-33), so
+// distinct objects may decode on different threads at once.  Here they share the GPU: a small pool of contexts (each with its
+// own HIP streams, scratch block, batch object and pinned staging - include/corto_hip.h: crthip_decode_host), one borrowed
+// for the duration of a decode().  Up to POOL_MAX decodes overlap on the device; more callers wait for a free context.
+// setDevice() retires the pool: idle contexts at once, borrowed ones when they come back.
+struct Pool {
+	std::mutex m;
+	std::condition_variable cv;
+	std::vector<crthip_ctx *> idle;
+	int live = 0, device = -1, limit = 0;
+	uint64_t generation = 0;
+} g_pool;
+
+int pool_limit() {
+	const char *e = getenv("CORTO_HIP_CONTEXTS");
+	int n = e ? atoi(e) : 8;
+	return n < 1 ? 1 : n > 64 ? 64 : n;
 }
+
+struct Lease {
+	crthip_ctx *ctx = nullptr;
+	uint64_t generation = 0;
+	Lease() {
+		std::unique_lock<std::mutex> lock(g_pool.m);
+		if(!g_pool.limit) g_pool.limit = pool_limit();
+		for(;;) {
+			if(!g_pool.idle.empty()) { ctx = g_pool.idle.back(); g_pool.idle.pop_back(); break; }
+			if(g_pool.live < g_pool.limit) {
+				int dev = g_pool.device;
+				if(dev < 0) { const char *e = getenv("CORTO_HIP_DEVICE"); dev = e ? atoi(e) : 0; }
+				g_pool.live++;                                   // reserve the slot, create outside the lock
+				const uint64_t gen = g_pool.generation;
+				lock.unlock();
+				crthip_ctx *c = nullptr;
+				const int err = crthip_ctx_create(dev, &c);
+				lock.lock();
+				if(err) { g_pool.live--; g_pool.cv.notify_one(); lock.unlock(); raise(err); }
+				if(gen != g_pool.generation) { g_pool.live--; lock.unlock(); crthip_ctx_destroy(c); lock.lock(); continue; }   // setDevice() meanwhile
+				ctx = c;
+				break;
+			}
+			g_pool.cv.wait(lock);
+		}
+		generation = g_pool.generation;
+	}
+	~Lease() {
+		if(!ctx) return;
+		std::unique_lock<std::mutex> lock(g_pool.m);
+		if(generation == g_pool.generation) { g_pool.idle.push_back(ctx); lock.unlock(); }
+		else { g_pool.live--; lock.unlock(); crthip_ctx_destroy(ctx); }
+		g_pool.cv.notify_one();
+	}
+	Lease(const Lease &) = delete;
+	Lease &operator=(const Lease &) = delete;
+};
 
 } // namespace
 
 void Decoder::setDevice(int device) {
-	std::lock_guard<std::mutex> lock(g_mutex);
-	if(g_ctx && device != g_device) { crthip_ctx_destroy(g_ctx); g_ctx = nullptr; }
-	g_device = device;
+	std::vector<crthip_ctx *> retire;
+	{
+		std::lock_guard<std::mutex> lock(g_pool.m);
+		if(device == g_pool.device) return;
+		g_pool.device = device;
+		g_pool.generation++;                                  // contexts out on loan are destroyed when they return
+		retire.swap(g_pool.idle);
+		g_pool.live -= (int)retire.size();
+	}
+	for(crthip_ctx *c : retire) crthip_ctx_destroy(c);
+	g_pool.cv.notify_all();
 }
 
 Decoder::Decoder(int len, const uchar *input): nvert(0), nface(0), input_(input), len_(len) {
@@ -130,7 +181,11 @@ void Decoder::decode() {
 	}
 	void *idx = index.faces16 ? (void *)index.faces16 : (void *)index.faces32;   // faces16 wins (src/decoder.cpp:246-249)
 	uint32_t ifmt = index.faces16 ? CRTHIP_FMT_UINT16 : CRTHIP_FMT_UINT32;
-	int err = crthip_decode_host(context(), input_, (size_t)len_, binds.data(), idx, ifmt);
+	int err;
+	{
+		Lease lease;                                          // a context of the pool for the duration of this decode
+		err = crthip_decode_host(lease.ctx, input_, (size_t)len_, binds.data(), idx, ifmt);
+	}
 	if(err) raise(err);
 }
 

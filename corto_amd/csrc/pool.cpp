@@ -1,0 +1,233 @@
+// pool.cpp — the multi-GPU decode pool of include/corto_hip.h: a list of independent batches of .crt blobs
+// decoded by every GPU of the node, one shared work queue, no collective.  Built on the public C ABI only (crthip_ctx /
+// crthip_batch_*), plus hipMalloc for the lanes' output blocks.
+//
+// Reference anchor: independent crt::Decoder objects, src/decoder.cpp:126-196 (nothing shared between two decodes).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/corto_hip.h"
+#include "encoder_internal.h"
+
+using corto_hip::ctx_fail;
+
+namespace {
+
+struct Lane {                       // one context = one batch in flight
+	uint32_t slot = 0;              // pool device index
+	int device = 0;
+	crthip_ctx *ctx = nullptr;
+	crthip_batch *batch = nullptr;
+	void *out = nullptr; size_t out_cap = 0;
+	// bindings of the item the batch object is planned for
+	std::vector<crthip_attr_binding> binds;
+	std::vector<void *> index_ptr;
+	std::vector<uint32_t> index_fmt;
+	std::vector<size_t> attr_off, index_off;     // byte offsets inside `out` (attr_off: per binding entry)
+	std::vector<uint32_t> first_attr;            // first binding entry of blob i
+	std::vector<int32_t> status;
+	int64_t item = -1;              // item of the step in flight / last executed
+	uint64_t step = 0;              // its global step number
+	bool busy = false;
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+} // namespace
+
+struct crthip_pool {
+	uint32_t ndevices = 0, threads_per_device = 0, depth = 0;
+	std::vector<int> devices;
+	std::vector<Lane> lanes;        // [device][thread][depth]
+	// state of one run
+	std::atomic<uint64_t> next{0}, completed{0};
+	std::mutex m;
+	int error = CRTHIP_OK; std::string error_msg;
+};
+
+static void destroy_lane(Lane &L) {
+	(void)hipSetDevice(L.device);
+	if(L.batch) crthip_batch_destroy(L.batch);
+	if(L.ctx) crthip_ctx_destroy(L.ctx);
+	if(L.out) (void)hipFree(L.out);
+	L.batch = nullptr; L.ctx = nullptr; L.out = nullptr; L.out_cap = 0;
+}
+
+extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_t threads_per_device, uint32_t depth, crthip_pool **out) {
+	if(!out || ndevices == 0 || ndevices > 16 || threads_per_device == 0 || depth == 0 || threads_per_device*depth > 64) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	crthip_pool *p = new crthip_pool();
+	p->ndevices = ndevices; p->threads_per_device = threads_per_device; p->depth = depth;
+	for(uint32_t d = 0; d < ndevices; d++) p->devices.push_back(devices ? devices[d] : (int)d);
+	p->lanes.resize((size_t)ndevices*threads_per_device*depth);
+	for(size_t i = 0; i < p->lanes.size(); i++) {
+		Lane &L = p->lanes[i];
+		L.slot = (uint32_t)(i/((size_t)threads_per_device*depth)); L.device = p->devices[L.slot];
+		const int err = crthip_ctx_create(L.device, &L.ctx);
+		if(err) { for(auto &x : p->lanes) destroy_lane(x); delete p; return err; }
+	}
+	*out = p;
+	return CRTHIP_OK;
+}
+
+extern "C" void crthip_pool_destroy(crthip_pool *p) {
+	if(!p) return;
+	for(auto &L : p->lanes) destroy_lane(L);
+	delete p;
+}
+
+extern "C" uint32_t crthip_pool_lanes(const crthip_pool *p) { return p ? (uint32_t)p->lanes.size() : 0; }
+
+// plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
+static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id) {
+	const void *arena = it.device_arena ? it.device_arena[L.slot] : nullptr;
+	int err = L.batch ? crthip_batch_reset(L.batch, it.nblobs, it.blobs, it.lens, arena)
+	                  : crthip_batch_create(L.ctx, it.nblobs, it.blobs, it.lens, arena, &L.batch);
+	if(err) return err;
+	if(L.item != item_id || L.binds.empty()) {                // the layout of an item's outputs depends on the item alone
+		L.binds.clear(); L.attr_off.clear(); L.first_attr.assign(it.nblobs, 0);
+		L.index_ptr.assign(it.nblobs, nullptr); L.index_fmt.assign(it.nblobs, CRTHIP_FMT_UINT32); L.index_off.assign(it.nblobs, 0);
+		size_t off = 0;
+		auto take = [&](size_t n) { off = (off + 255) & ~(size_t)255; const size_t r = off; off += n; return r; };
+		crthip_blob_info info;
+		for(uint32_t i = 0; i < it.nblobs; i++) {
+			if((err = crthip_batch_info(L.batch, i, &info)) != 0) return err;
+			L.first_attr[i] = (uint32_t)L.binds.size();
+			for(uint32_t k = 0; k < info.nattr; k++) {
+				const crthip_attr_info &a = info.attr[k];
+				crthip_attr_binding b; b.buffer = nullptr; b.format = CRTHIP_FMT_FLOAT; b.out_components = 0;
+				size_t n;
+				if(a.codec == CRTHIP_CODEC_NORMAL) n = (size_t)info.nvert*12;
+				else if(a.codec == CRTHIP_CODEC_COLOR) { b.format = CRTHIP_FMT_UINT8; b.out_components = 4; n = (size_t)info.nvert*4; }
+				else n = (size_t)info.nvert*a.components*4;
+				L.attr_off.push_back(take(n));
+				L.binds.push_back(b);
+			}
+			if(info.nface) L.index_off[i] = take((size_t)info.nface*12);
+		}
+		const size_t total = off + 256;
+		if(total > L.out_cap) {
+			if(L.out) (void)hipFree(L.out);
+			L.out = nullptr; L.out_cap = 0;
+			if(hipMalloc(&L.out, total + total/8) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
+			L.out_cap = total + total/8;
+		}
+		uint8_t *base = (uint8_t *)L.out;
+		for(size_t k = 0; k < L.binds.size(); k++) L.binds[k].buffer = base + L.attr_off[k];
+		for(uint32_t i = 0; i < it.nblobs; i++) {
+			if((err = crthip_batch_info(L.batch, i, &info)) != 0) return err;
+			L.index_ptr[i] = info.nface ? base + L.index_off[i] : nullptr;
+		}
+		L.status.assign(it.nblobs, 0);
+	}
+	L.item = item_id;
+	return crthip_batch_bind_all(L.batch, L.binds.data(), L.index_ptr.data(), L.index_fmt.data());
+}
+
+extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_pool_item *items, uint64_t steps, uint64_t warmup,
+                               crthip_pool_report *report, double *completion_s) {
+	if(!p || !items || nitems == 0 || !report) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	memset(report, 0, sizeof(*report));
+	// triangles / vertices of every item (header parse only)
+	std::vector<uint64_t> item_tris(nitems, 0), item_verts(nitems, 0);
+	for(uint32_t j = 0; j < nitems; j++)
+		for(uint32_t i = 0; i < items[j].nblobs; i++) {
+			crthip_blob_info info;
+			const int err = crthip_probe(items[j].blobs[i], items[j].lens[i], &info);
+			if(err) return err;
+			item_tris[j] += info.nface; item_verts[j] += info.nvert;
+		}
+	const uint64_t timed_end = warmup + steps;
+	const uint64_t total = timed_end + p->lanes.size();      // the tail keeps every context busy until the last timed completion
+	p->next = 0; p->completed = 0; p->error = CRTHIP_OK; p->error_msg.clear();
+	for(auto &L : p->lanes) { L.busy = false; L.item = -1; L.binds.clear(); }   // (an item id means this call's items[] only)
+	std::vector<double> stamps(timed_end + 1, 0.0);           // stamps[c] = time at which the c-th completion happened (1-based)
+	std::atomic<uint64_t> failed{0}, fallbacks{0}, tris{0}, verts{0};
+	std::vector<std::atomic<uint64_t>> per_dev(p->ndevices);
+	for(auto &x : per_dev) x = 0;
+	std::atomic<int32_t> first_error{0};
+	const double t_launch = now_s();
+	stamps[0] = t_launch;
+
+	auto worker = [&](uint32_t slot, uint32_t t) {
+		(void)hipSetDevice(p->devices[slot]);
+		Lane *mine = &p->lanes[((size_t)slot*p->threads_per_device + t)*p->depth];
+		auto finish = [&](Lane &L) -> int {
+			const int rc = crthip_batch_sync(L.batch, L.status.data());
+			L.busy = false;
+			const uint64_t c = ++p->completed;                   // completion order
+			if(c <= timed_end) stamps[c] = now_s();
+			uint64_t bad = 0;
+			for(int32_t s : L.status) if(s) { bad++; int32_t z = 0; first_error.compare_exchange_strong(z, s); }
+			failed += bad;
+			crthip_batch_stats st;
+			if(crthip_batch_get_stats(L.batch, &st) == CRTHIP_OK) fallbacks += st.topology_fallbacks;
+			if(c > warmup && c <= timed_end) { per_dev[slot]++; tris += item_tris[(size_t)L.item]; verts += item_verts[(size_t)L.item]; }
+			if(rc == CRTHIP_E_DEVICE || rc == CRTHIP_E_NOMEM) return rc;
+			return CRTHIP_OK;
+		};
+		int err = CRTHIP_OK;
+		for(uint64_t n = 0; !err; n++) {
+			Lane &L = mine[n % p->depth];
+			if(L.busy) err = finish(L);
+			if(err) break;
+			const uint64_t step = p->next.fetch_add(1);
+			if(step >= total) break;
+			const uint32_t j = (uint32_t)(step % nitems);
+			err = lane_plan(p, L, items[j], (int64_t)j);
+			if(!err) err = crthip_batch_decode(L.batch);
+			if(!err) { L.busy = true; L.step = step; }
+		}
+		for(uint32_t k = 0; k < p->depth; k++) if(mine[k].busy) { const int e2 = finish(mine[k]); if(!err) err = e2; }
+		if(err) {
+			std::lock_guard<std::mutex> lock(p->m);
+			if(!p->error) { p->error = err; p->error_msg = crthip_last_error(); }
+			p->next = total;                                     // stop handing out work
+		}
+	};
+	std::vector<std::thread> threads;
+	for(uint32_t d = 0; d < p->ndevices; d++)
+		for(uint32_t t = 0; t < p->threads_per_device; t++) threads.emplace_back(worker, d, t);
+	for(auto &th : threads) th.join();
+	if(p->error) return ctx_fail(p->error, p->error_msg.c_str());
+	report->elapsed_s = stamps[timed_end] - stamps[warmup];
+	report->steps = steps; report->triangles = tris; report->vertices = verts;
+	report->failed_blobs = failed; report->first_error = first_error; report->topology_fallbacks = fallbacks;
+	for(uint32_t d = 0; d < p->ndevices; d++) { report->steps_per_device[d] = per_dev[d]; if(per_dev[d]) report->devices_used++; }
+	if(completion_s) for(uint64_t c = 0; c < steps; c++) completion_s[c] = stamps[warmup + 1 + c] - stamps[warmup];
+	return CRTHIP_OK;
+}
+
+extern "C" int64_t crthip_pool_lane_item(const crthip_pool *p, uint32_t lane, uint32_t *device_slot) {
+	if(!p || lane >= p->lanes.size()) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	if(device_slot) *device_slot = p->lanes[lane].slot;
+	return p->lanes[lane].item;
+}
+
+extern "C" int64_t crthip_pool_lane_read(crthip_pool *p, uint32_t lane, uint32_t blob, const char *what, void *host_out, size_t cap) {
+	if(!p || lane >= p->lanes.size() || !what || !host_out) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	Lane &L = p->lanes[lane];
+	if(!L.batch || L.item < 0 || blob >= crthip_batch_size(L.batch)) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	crthip_blob_info info;
+	int err = crthip_batch_info(L.batch, blob, &info);
+	if(err) return err;
+	const uint8_t *src = nullptr; size_t n = 0;
+	if(!strcmp(what, "index")) { if(!info.nface) return 0; src = (const uint8_t *)L.index_ptr[blob]; n = (size_t)info.nface*12; }
+	else {
+		for(uint32_t k = 0; k < info.nattr; k++) if(!strcmp(info.attr[k].name, what)) {
+			const crthip_attr_info &a = info.attr[k];
+			src = (const uint8_t *)L.binds[L.first_attr[blob] + k].buffer;
+			n = a.codec == CRTHIP_CODEC_NORMAL ? (size_t)info.nvert*12 : a.codec == CRTHIP_CODEC_COLOR ? (size_t)info.nvert*4 : (size_t)info.nvert*a.components*4;
+		}
+		if(!src) return ctx_fail(CRTHIP_E_ARGUMENT, "no such attribute");
+	}
+	if(n > cap) n = cap;
+	if(hipSetDevice(L.device) != hipSuccess || hipMemcpy(host_out, src, n, hipMemcpyDeviceToHost) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, nullptr);
+	return (int64_t)n;
+}

@@ -12,6 +12,13 @@
 //   * generic attributes decode to FLOAT only, colours to UINT8, normals to FLOAT or INT16 (the formats
 //     upstream's own callers use; SURVEY.md a17 lists the rest as never executed by Decoder).
 // Errors are thrown as `const char *` with upstream's own messages (src/decoder.cpp:44,51,274 ...).
+//
+// Threading: as upstream (whose only global is the read-only bmask[], src/bitstream.cpp:29-33) - distinct Decoder objects may
+// be constructed and decode() on different threads concurrently; one object is not re-entrant and decode() is one-shot.
+// decode() borrows one of a process-wide pool of device contexts (at most $CORTO_HIP_CONTEXTS, default 8, created on
+// demand; each owns its HIP streams, device scratch and pinned staging, reused from call to call), so up to that many
+// decodes overlap on the GPU and further callers wait for a free one.  setDevice() may be called at any time: decodes
+// already running finish on the old device.
 #ifndef CRT_HIP_DECODER_H
 #define CRT_HIP_DECODER_H
 
@@ -85,7 +92,7 @@ public:
 
 	void decode();                                       // src/decoder.cpp:126-196, on the GPU
 
-	// which HIP device the process-wide context of this facade uses (default 0, or $CORTO_HIP_DEVICE)
+	// which HIP device the process-wide context pool of this facade uses (default 0, or $CORTO_HIP_DEVICE)
 	static void setDevice(int device);
 
 private:

@@ -145,6 +145,58 @@ int crthip_batch_sync(crthip_batch *b, int32_t *status);
 int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
                        void *index, uint32_t index_format);
 
+/* ---- multi-GPU decode pool ------------------------------------------------------------------------
+ * Upstream decodes one blob on one thread; its Decoder objects are independent (src/decoder.cpp:126-196 touches nothing
+ * shared), so a list of blobs shards by blob with NO collective.  The pool is that, for the GPUs of one node: `ndevices`
+ * devices, `depth` batches in flight per host thread and `threads_per_device` host threads per device, every batch on its
+ * own context (crthip_ctx: own HIP streams, scratch, descriptors) with its own output block in that device's HBM.  All
+ * threads of all devices pull work items from ONE queue - an atomic counter over the submitted list - so a faster or less
+ * loaded GPU simply takes more items: no RCCL, no peer traffic, no static assignment.
+ * devices == NULL: devices 0 .. ndevices-1.  A device id may repeat (several pool "devices" on one GPU: how the N > 1 path
+ * is exercised on a one-GPU box). */
+typedef struct crthip_pool crthip_pool;
+int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_t threads_per_device, uint32_t depth, crthip_pool **out);
+void crthip_pool_destroy(crthip_pool *pool);
+uint32_t crthip_pool_lanes(const crthip_pool *pool);     /* ndevices * threads_per_device * depth contexts */
+
+/* One work item = one batch of blobs (HOST pointers, borrowed for the duration of crthip_pool_run).
+ * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step;
+ *               else ndevices DEVICE pointers, entry d = the item's blobs already resident on pool device d in
+ *               crthip_arena_layout order (an entry may be NULL: that device uploads). */
+typedef struct {
+	uint32_t nblobs;
+	const uint8_t *const *blobs;
+	const uint32_t *lens;
+	const void *const *device_arena;
+} crthip_pool_item;
+
+typedef struct {
+	double elapsed_s;            /* wall time from the completion of the last warm-up step to the completion of the last timed step:
+	                                the pipeline is full at both ends (extra steps are queued behind the timed ones and drained untimed) */
+	uint64_t steps;              /* timed steps completed (= the `steps` asked for) */
+	uint64_t triangles, vertices;/* decoded by the timed steps */
+	uint64_t failed_blobs;       /* blobs (over all executed steps) whose status was not CRTHIP_OK */
+	int32_t first_error;         /* first failing status seen, or CRTHIP_OK */
+	uint32_t devices_used;       /* pool devices that completed at least one timed step */
+	uint64_t steps_per_device[16];
+	uint64_t topology_fallbacks;
+} crthip_pool_report;
+
+/* Decode items[(first_step + i) % nitems] for i in [0, warmup + steps) (+ a few more to keep every context busy until the
+ * last timed completion), outputs into the contexts' own device blocks: every attribute bound in its natural format
+ * (generic FLOAT, normal FLOAT, colour UINT8 x 4, index UINT32).  completion_s: NULL, or `steps` doubles that receive the
+ * completion time of every timed step in seconds since the start of the timed region, in completion order.
+ * Blocks until everything has drained.  Returns CRTHIP_OK or the first HIP / planning error (per-blob decode failures are
+ * counted in the report, not returned). */
+int crthip_pool_run(crthip_pool *pool, uint32_t nitems, const crthip_pool_item *items, uint64_t steps, uint64_t warmup,
+                    crthip_pool_report *report, double *completion_s);
+
+/* After a run every lane (context) still holds the outputs of the last step it executed: which item that was, on which pool
+ * device, and a copy of one output array of one of its blobs to the host ("position", "normal", "color", "uv", ... or "index").
+ * Returns bytes written / the item index, or <0.  This is how bench.py and the tests check what every GPU decoded. */
+int64_t crthip_pool_lane_item(const crthip_pool *pool, uint32_t lane, uint32_t *device_slot);
+int64_t crthip_pool_lane_read(crthip_pool *pool, uint32_t lane, uint32_t blob, const char *what, void *host_out, size_t cap);
+
 /* ---- .crt writer (host only) -------------------------------------------------------------
  * Byte-identical to upstream's crt::Encoder (src/encoder.cpp:207-722) for positions, normals (all three predictions),
  * rgb/rgba colours, uvs, one generic "radius" attribute, groups, exif, entropy NONE/TUNSTALL, meshes and point clouds.

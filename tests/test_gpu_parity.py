@@ -172,6 +172,121 @@ def test_cpp_decoder_dropin(ctx, tmp_path):
     assert out.returncode == 1 and "Not a crt file." in out.stderr
 
 
+@pytest.fixture(scope="module")
+def c5_blobs():
+    """BASELINE config C5: 2 048 distinct C4-unit blobs (seeds 0 .. 2047), made by the repo's byte-identical writer"""
+    from corto_amd import synth
+    return [ca.encode(synth.bumpy_sphere(64, 32, seed=i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
+            for i in range(2048)]
+
+
+@pytest.mark.timeout(300)
+def test_c5_every_shard_on_one_gpu(ctx, c5_blobs):
+    """config C5 without eight GPUs: the 2 048-blob list is cut with shard.balanced_ranges(.., 8) exactly as bench.py cuts it, and
+    every one of the eight shards is decoded here (one batch each), a sample of every shard compared with the oracle"""
+    from corto_amd import shard
+    ranges = shard.balanced_ranges([4096 + 2112] * len(c5_blobs), 8)
+    assert [hi - lo for lo, hi in ranges] == [256] * 8 and ranges[0][0] == 0 and ranges[-1][1] == 2048
+    b = None
+    for r, (lo, hi) in enumerate(ranges):
+        part = c5_blobs[lo:hi]
+        if b is None:
+            b = ca.Batch(ctx, part)
+        else:
+            b.reset(part)
+        b.allocate_outputs()
+        b.decode()
+        st = b.sync()
+        assert (st == 0).all(), (r, st)
+        assert b.stats().total_nface == 256 * 4096
+        for i in range(r, 256, 41):
+            assert_same(b.host_outputs(i), oc.decode(part[i]), KEYS, "C5 shard %d blob %d" % (r, lo + i))
+    b.close()
+
+
+@pytest.mark.timeout(300)
+def test_pool_shared_queue_two_devices(c5_blobs):
+    """crthip_pool: two pool devices (both on this box's one GPU), 2 threads x 2 batches in flight each, four C5 shards as
+    work items on ONE queue; every context's last outputs against the oracle; inputs resident in HBM, then uploaded per step"""
+    items = [c5_blobs[256 * g: 256 * g + 64] for g in range(4)]          # 64 blobs of each of four shards: enough to overlap
+    pool = ca.Pool([0, 0], threads=2, depth=2)
+    assert pool.lanes == 8
+    arenas = [[ca.upload_arena(it, 0), ca.upload_arena(it, 0)] for it in items]
+    dts = {"position": (np.float32, 3), "normal": (np.float32, 3), "color": (np.uint8, 4), "uv": (np.float32, 2), "index": (np.uint32, 3)}
+    for ar in (arenas, None):
+        rep, stamps = pool.run(items, steps=40, warmup=8, arenas=ar)
+        assert rep.steps == 40 and rep.failed_blobs == 0 and rep.first_error == 0
+        assert rep.devices_used == 2 and sum(list(rep.steps_per_device)[:2]) == 40
+        assert rep.triangles == sum(64 * 4096 for _ in range(40)) and rep.elapsed_s > 0
+        assert len(stamps) == 40 and (np.diff(stamps) >= 0).all() and abs(stamps[-1] - rep.elapsed_s) < 1e-9
+        seen = set()
+        for lane in range(pool.lanes):
+            it, slot = pool.lane_item(lane)
+            assert 0 <= it < 4 and slot == lane // 4
+            seen.add(it)
+            for i in (lane, 63 - lane):
+                ref = oc.decode(items[it][i])
+                for k, (dt, w) in dts.items():
+                    got = pool.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
+                    assert got.tobytes() == ref[k].tobytes(), (lane, it, i, k)
+        assert len(seen) >= 2
+    # a blob that cannot be decoded is counted, not fatal
+    bad = aligned(items[0][1].copy())
+    probs = int(ca.probe(bad).body_offset) + 9 + 4 + 1
+    bad[probs:probs + 2] = (7, 255)
+    rep, _ = pool.run([[items[0][0], bad]], steps=4, warmup=0)
+    assert rep.failed_blobs >= 4 and rep.first_error == -5
+    pool.close()
+
+
+def test_cpp_decoder_threads(ctx, tmp_path):
+    """SURVEY §8b Threading: distinct crt::Decoder objects on 4 threads at once (tests/cpp/facade_threads.cpp), every decode
+    repeated and compared with its first, thread 0's outputs compared with the oracle"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "facade_threads")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_threads.cpp"),
+                           "-L", os.path.dirname(ca.LIB_PATH), "-lcorto_hip", "-Wl,-rpath," + os.path.dirname(ca.LIB_PATH), "-o", exe])
+    names = ("c4_unit", "two_groups", "torus", "holey_disc", "nrm_estimated_rgb", "cloud_diff")
+    files = []
+    for name in names:
+        g = load_golden(name)
+        src = str(tmp_path / (name + ".crt")); g["crt"].tofile(src); files.append(src)
+    out = subprocess.run([exe, "4", "6", str(tmp_path / "out"), *files], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    for i, name in enumerate(names):
+        g = load_golden(name)
+        exp = oc.decode(g["crt"], color_components=4)
+        keys = [k for k in ("position", "normal", "color", "uv", "index") if k in exp]
+        want = np.concatenate([exp[k].reshape(-1).view(np.uint8) for k in keys])
+        blob = np.fromfile(str(tmp_path / ("out%d.bin" % i)), dtype=np.uint8)
+        assert blob.tobytes() == want.tobytes(), name
+    # two pool contexts only: the other two threads wait their turn
+    out = subprocess.run([exe, "4", "2", "-", *files], capture_output=True, text=True, env=dict(os.environ, CORTO_HIP_CONTEXTS="2"))
+    assert out.returncode == 0, out.stderr + out.stdout
+
+
+def test_status_survives_other_batches(ctx):
+    """decode(A); decode(B) on one context; sync(A) must still report A's per-blob failures (they used to be lost when
+    another call synchronised the stream first)"""
+    g = load_golden("c4_unit")
+    good = aligned(g["crt"])
+    bad = aligned(g["crt"].copy())
+    probs = int(ca.probe(bad).body_offset) + 9 + 4 + 1     # groups (u32 n, u32 end, u8 nprops), max_front, u8 nsym
+    bad[probs:probs + 2] = (7, 255)                          # the likeliest CLERS symbol becomes the invalid symbol 7: topology must fail
+    a = ca.Batch(ctx, [good, bad]); a.allocate_outputs()
+    b = ca.Batch(ctx, [good]); b.allocate_outputs()
+    a.decode()
+    b.decode()                                     # implicit sync of A inside the library
+    sb = b.sync()
+    sa = a.sync(raise_on_error=False)
+    assert (sb == 0).all()
+    assert sa[0] == 0 and sa[1] == -5, sa
+    ref = oc.decode(good)
+    assert_same(a.host_outputs(0), ref, KEYS, "good blob of batch A")
+    a.close(); b.close()
+
+
 def test_unity_veneer_decode_mesh(ctx):
     """CreateDecoder / DecodeMesh / DestroyDecoder (include/corto/corto_codec.h = upstream src/corto_codec.h:41-43) driven the
     way unity/CortoMeshLoader.cs does: arrays sized from info, one DecodeMesh call"""
