@@ -73,6 +73,7 @@ class MeshDesc(C.Structure):
         ("group_end", C.c_void_p), ("ngroups", C.c_uint32),
         ("entropy", C.c_int32),
         ("exif", C.c_char_p), ("nexif", C.c_uint32),
+        ("group_nprops", C.c_void_p), ("group_props", C.c_char_p),
     ]
 
 
@@ -244,6 +245,11 @@ def encode(mesh, position_bits=14, position_q=0.0, normal_bits=10, normal_predic
     if mesh.groups is not None:
         g = np.ascontiguousarray(mesh.groups, dtype=np.uint32); keep.append(g)
         m.group_end = g.ctypes.data; m.ngroups = len(g)
+        props = getattr(mesh, "group_props", None)          # list of dicts, one per group (Encoder::addGroup(end, props))
+        if props:
+            cnt = np.array([len(d) for d in props], dtype=np.uint32); keep.append(cnt)
+            gflat = b"".join(k.encode() + b"\0" + v.encode() + b"\0" for d in props for k, v in d.items())
+            m.group_nprops = cnt.ctypes.data; m.group_props = gflat
     m.entropy = entropy
     if exif:
         flat = b"".join(k.encode() + b"\0" + v.encode() + b"\0" for k, v in exif.items())

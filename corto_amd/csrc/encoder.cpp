@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -336,6 +337,7 @@ struct Encoder {
 	uint32_t nvert, nface, entropy;
 	std::vector<uint32_t> faces;                 // original indexing, degenerate faces removed in encode_mesh
 	std::vector<uint32_t> group_end;
+	std::vector<std::map<std::string, std::string>> group_props;
 	std::map<std::string, std::string> exif;
 	std::map<std::string, Attr> data;            // std::map: alphabetical like upstream
 	std::vector<uint8_t> clers;
@@ -522,7 +524,17 @@ struct Encoder {
 		for(auto &kv : data) { const Attr &a = kv.second; s.str(kv.first); s.u32((uint32_t)a.codec); s.f32(a.q); s.u8((uint32_t)a.N); s.u8((uint32_t)a.format); s.u8((uint32_t)a.strategy); }
 	}
 
-	void groups() { s.u32((uint32_t)group_end.size()); for(uint32_t g : group_end) { s.u32(g); s.u8(0); } }
+	// IndexAttribute::encodeGroups (include/corto/index_attribute.h:71-81): properties in std::map order = sorted by key
+	void groups() {
+		s.u32((uint32_t)group_end.size());
+		for(size_t g = 0; g < group_end.size(); g++) {
+			s.u32(group_end[g]);
+			if(g < group_props.size()) {
+				s.u8((uint8_t)group_props[g].size());
+				for(auto &kv : group_props[g]) { s.str(kv.first); s.str(kv.second); }
+			} else s.u8(0);
+		}
+	}
 
 	void encode_mesh() {                                                               // src/encoder.cpp:311-381
 		encoded.assign(nvert, -1);
@@ -595,6 +607,16 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 	const char *p = m->exif;
 	for(uint32_t i = 0; i < m->nexif; i++) { std::string k(p); p += k.size() + 1; std::string v(p); p += v.size() + 1; E.exif[k] = v; }
 	for(uint32_t g = 0; g < m->ngroups; g++) E.group_end.push_back(m->group_end[g]);
+	if(m->group_nprops && m->group_props) {
+		const char *gp = m->group_props;
+		E.group_props.resize(m->ngroups);
+		for(uint32_t g = 0; g < m->ngroups; g++)
+			for(uint32_t i = 0; i < m->group_nprops[g]; i++) {
+				std::string k(gp); gp += k.size() + 1;
+				std::string v(gp); gp += v.size() + 1;
+				E.group_props[g][k] = v;
+			}
+	}
 	if(E.nface) E.faces.assign(m->index, m->index + (size_t)E.nface*3);
 	const uint32_t nv = m->nvert;
 	{	// positions (src/encoder.cpp:49-100, vertex_attribute.h:79-128)
@@ -689,14 +711,51 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 	return (int64_t)E.s.b.size();
 }
 
+// Arguments are checked before anything is indexed with them (upstream trusts its caller: an index >= nvert writes past its
+// vectors, src/encoder.cpp:341-347), and nothing is thrown across the C boundary.
+static int64_t encode_checked(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface, crthip_ctx *gpu) {
+	if(!m || !m->position) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: no mesh / no positions");
+	if(m->index && m->nface) {
+		if((uint64_t)m->nface*3 > 0xFFFFFFFFull) return corto_hip::ctx_fail(CRTHIP_E_LIMIT, "crthip_encode: too many faces");
+		for(size_t i = 0; i < (size_t)m->nface*3; i++)
+			if(m->index[i] >= m->nvert) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: face index out of range");
+	}
+	if(m->color) {
+		if(m->color_components != 3 && m->color_components != 4) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: color_components must be 3 or 4");
+		for(int k = 0; k < m->color_components; k++)
+			if(m->color_bits[k] < 1 || m->color_bits[k] > 8) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: color_bits must be 1..8");
+	}
+	if(m->normal && (m->normal_bits < 1 || m->normal_bits > 16 || m->normal_prediction < 0 || m->normal_prediction > 2))
+		return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: normal_bits must be 1..16, normal_prediction 0..2");
+	if(m->position_bits > 31) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: position_bits must be < 32");
+	if(m->entropy != CRTHIP_ENTROPY_NONE && m->entropy != CRTHIP_ENTROPY_TUNSTALL) return corto_hip::ctx_fail(CRTHIP_E_ENTROPY, nullptr);
+	if(m->ngroups) {
+		if(!m->group_end || m->ngroups > (1u << 24)) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: groups");
+		uint32_t prev = 0;
+		for(uint32_t g = 0; g < m->ngroups; g++) {
+			// (a point cloud's group table is written as given and never used to index anything, src/encoder.cpp:238-296)
+			if(m->group_end[g] < prev || (m->index && m->nface && m->group_end[g] > m->nface)) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: group ends must be ascending and <= nface");
+			prev = m->group_end[g];
+			if(m->group_nprops && m->group_nprops[g] > 255) return corto_hip::ctx_fail(CRTHIP_E_LIMIT, "crthip_encode: more than 255 properties in a group");
+		}
+	}
+	try {
+		return encode_impl(m, out, cap, out_nvert, out_nface, gpu);
+	} catch(const std::bad_alloc &) {
+		return corto_hip::ctx_fail(CRTHIP_E_NOMEM, nullptr);
+	} catch(...) {
+		return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode: internal error");
+	}
+}
+
 int64_t crthip_encode(const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface) {
-	return encode_impl(m, out, cap, out_nvert, out_nface, nullptr);
+	return encode_checked(m, out, cap, out_nvert, out_nface, nullptr);
 }
 
 // crthip_encode with the value coding (bit widths, bit packing) and the entropy coder on the device (encode_gpu.cpp)
 int64_t crthip_encode_gpu(crthip_ctx *ctx, const crthip_mesh *m, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface) {
 	if(!ctx) return corto_hip::ctx_fail(CRTHIP_E_ARGUMENT, "crthip_encode_gpu: null context (there is no CPU fallback: use crthip_encode for the host encoder)");
-	return encode_impl(m, out, cap, out_nvert, out_nface, ctx);
+	return encode_checked(m, out, cap, out_nvert, out_nface, ctx);
 }
 
 } // extern "C"

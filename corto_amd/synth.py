@@ -49,6 +49,7 @@ class Mesh:
         self.uv = None if uv is None else np.ascontiguousarray(uv, dtype=np.float32)
         self.radius = None if radius is None else np.ascontiguousarray(radius, dtype=np.float32)
         self.groups = groups
+        self.group_props = None      # optional: one {key: value} dict per group (Group::properties)
 
     @property
     def nvert(self):

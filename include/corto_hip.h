@@ -222,6 +222,10 @@ typedef struct {
 	int32_t entropy;              /* CRTHIP_ENTROPY_* */
 	const char *exif;             /* "k\0v\0..." nexif pairs or NULL */
 	uint32_t nexif;
+	/* Group::properties (Encoder::addGroup(end, props), include/corto/encoder.h:75): group g has group_nprops[g] pairs, all pairs
+	 * of all groups flat in group_props as "k\0v\0...".  Written sorted by key like upstream's std::map.  NULL: no properties. */
+	const uint32_t *group_nprops;
+	const char *group_props;
 } crthip_mesh;
 /* returns the blob size (also when out == NULL or cap is too small), or <0 */
 int64_t crthip_encode(const crthip_mesh *mesh, uint8_t *out, size_t cap, uint32_t *out_nvert, uint32_t *out_nface);

@@ -44,6 +44,8 @@ typedef struct {
 	int32_t entropy;              // 0 NONE, 1 TUNSTALL
 	const char *exif;             // "k\0v\0k\0v\0..." nexif pairs, or NULL
 	uint32_t nexif;
+	const uint32_t *group_nprops; // pairs per group, or NULL: Encoder::addGroup(end, props) (include/corto/encoder.h:75)
+	const char *group_props;      // all pairs of all groups, "k\0v\0..."
 } ref_mesh_t;
 
 typedef struct {
@@ -73,8 +75,18 @@ int64_t ref_encode(const ref_mesh_t *m, uint8_t *out, int64_t cap, uint32_t *out
 			std::string v(p); p += v.size() + 1;
 			enc.exif[k] = v;
 		}
-		for(uint32_t g = 0; g < m->ngroups; g++)
-			enc.addGroup((int)m->group_end[g]);
+		const char *gp = m->group_props;
+		for(uint32_t g = 0; g < m->ngroups; g++) {
+			if(m->group_nprops && gp) {
+				std::map<std::string, std::string> props;
+				for(uint32_t i = 0; i < m->group_nprops[g]; i++) {
+					std::string k(gp); gp += k.size() + 1;
+					std::string v(gp); gp += v.size() + 1;
+					props[k] = v;
+				}
+				enc.addGroup((int)m->group_end[g], props);
+			} else enc.addGroup((int)m->group_end[g]);
+		}
 		if(m->nface == 0 || !m->index) {
 			if(m->position_bits > 0) enc.addPositionsBits(m->position, m->position_bits);
 			else enc.addPositions(m->position, m->position_q);
@@ -137,6 +149,29 @@ static void bind(Decoder &dec, const ref_out_t *o) {
 	if(o->radius) dec.setAttribute("radius", (char *)o->radius, VertexAttribute::FLOAT);
 	if(o->index16) dec.setIndex(o->index16);
 	if(o->index32) dec.setIndex(o->index32);
+}
+
+// What the reference Decoder leaves in index.groups after decode() (IndexAttribute::decodeGroups, include/corto/index_attribute.h:89-99):
+// u32 ngroups | per group: u32 end, u32 nprops, nprops x "k\0v\0".  Returns bytes (also when cap is too small), or -1.
+int64_t ref_groups(const uint8_t *blob, int len, uint8_t *out, int64_t cap) {
+	try {
+		Decoder dec(len, blob);
+		std::vector<uint32_t> idx((size_t)dec.nface*3 + 3);
+		if(dec.nface) dec.setIndex(idx.data());
+		dec.decode();
+		std::string flat;
+		auto u32 = [&](uint32_t v) { flat.append((const char *)&v, 4); };
+		u32((uint32_t)dec.index.groups.size());
+		for(auto &g : dec.index.groups) {
+			u32(g.end); u32((uint32_t)g.properties.size());
+			for(auto &kv : g.properties) { flat += kv.first; flat.push_back('\0'); flat += kv.second; flat.push_back('\0'); }
+		}
+		if(out && cap >= (int64_t)flat.size()) memcpy(out, flat.data(), flat.size());
+		return (int64_t)flat.size();
+	} catch(const char *e) {
+		g_err = e;
+		return -1;
+	}
 }
 
 // Full decode with the reference crt::Decoder (src/decoder.cpp:126-196).

@@ -29,6 +29,7 @@ class _Mesh(C.Structure):
         ("group_end", C.c_void_p), ("ngroups", C.c_uint32),
         ("entropy", C.c_int32),
         ("exif", C.c_char_p), ("nexif", C.c_uint32),
+        ("group_nprops", C.c_void_p), ("group_props", C.c_char_p),
     ]
 
 
@@ -55,6 +56,7 @@ def lib():
         _lib.ref_last_error.restype = C.c_char_p
         _lib.ref_encode.restype = C.c_int64
         _lib.ref_tunstall_compress_block.restype = C.c_int64
+        _lib.ref_groups.restype = C.c_int64
     return _lib
 
 
@@ -85,6 +87,11 @@ def encode(mesh, position_bits=14, position_q=0.0, normal_bits=10, normal_predic
     if mesh.groups is not None:
         g = np.ascontiguousarray(mesh.groups, dtype=np.uint32); keep.append(g)
         m.group_end = _ptr(g); m.ngroups = len(g)
+        props = getattr(mesh, "group_props", None)
+        if props:
+            cnt = np.array([len(d) for d in props], dtype=np.uint32); keep.append(cnt)
+            gflat = b"".join(k.encode() + b"\0" + v.encode() + b"\0" for d in props for k, v in d.items())
+            m.group_nprops = _ptr(cnt); m.group_props = gflat
     m.entropy = entropy
     if exif:
         flat = b"".join(k.encode() + b"\0" + v.encode() + b"\0" for k, v in exif.items())
@@ -108,6 +115,27 @@ def aligned_copy(b: np.ndarray, align=16) -> np.ndarray:
     v = raw[off:off + len(b)]
     v[:] = b
     return v
+
+
+def groups(blob: np.ndarray):
+    """what the reference Decoder leaves in index.groups after decode(): [(end, {key: value}), ...]"""
+    cap = 1 << 16
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().ref_groups(_ptr(blob), len(blob), _ptr(out), C.c_int64(cap))
+    if n < 0:
+        raise RuntimeError("ref_groups: " + lib().ref_last_error().decode())
+    raw = out[:n].tobytes()
+    ng = int.from_bytes(raw[:4], "little"); p = 4
+    res = []
+    for _ in range(ng):
+        end = int.from_bytes(raw[p:p + 4], "little"); cnt = int.from_bytes(raw[p + 4:p + 8], "little"); p += 8
+        d = {}
+        for _ in range(cnt):
+            e = raw.index(b"\0", p); k = raw[p:e].decode(); p = e + 1
+            e = raw.index(b"\0", p); v = raw[p:e].decode(); p = e + 1
+            d[k] = v
+        res.append((end, d))
+    return res
 
 
 def probe(blob: np.ndarray):

@@ -10,7 +10,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-MESH_CASES = ["pos_only", "nrm_diff", "nrm_estimated_rgb", "c4_unit", "two_groups", "holey_disc",
+MESH_CASES = ["pos_only", "nrm_diff", "nrm_estimated_rgb", "c4_unit", "two_groups", "group_props", "holey_disc",
               "multi_component", "torus", "closed_sphere", "radius_attr", "entropy_none"]
 CLOUD_CASES = ["cloud_diff", "cloud_border"]
 ALL_CASES = MESH_CASES + CLOUD_CASES

@@ -35,6 +35,11 @@ int main(int argc, char **argv) {
 		fwrite(index.data(), 4, index.size(), o);
 		fclose(o);
 		printf("nvert %u nface %u groups %zu exif %zu\n", nvert, nface, decoder.index.groups.size(), decoder.exif.size());
+		for(auto &g : decoder.index.groups) {                      // Group::end + properties, as upstream callers read them (src/main.cpp:285-294)
+			printf("group %u", g.end);
+			for(auto &kv : g.properties) printf("\t%s=%s", kv.first.c_str(), kv.second.c_str());
+			printf("\n");
+		}
 	} catch(const char *msg) {
 		fprintf(stderr, "error: %s\n", msg);
 		return 1;

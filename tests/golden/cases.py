@@ -10,6 +10,9 @@ DIFF, ESTIMATED, BORDER = 0, 1, 2
 def cases():
     two_groups = S.bumpy_sphere(32, 16, seed=11)
     two_groups.groups = [400, two_groups.nface]
+    group_props = S.bumpy_sphere(24, 12, seed=12, color_components=3)
+    group_props.groups = [100, 101, 400, group_props.nface]
+    group_props.group_props = [{"material": "skin", "texture": "t0.png"}, {}, {"z": "last", "a": "first", "m": ""}, {"material": "cloth"}]
     multi = S.merge([S.closed_sphere(20, 10, seed=1), S.torus(16, 8, seed=2), S.holey_disc(14, seed=3, color_components=4)])
     radius = S.bumpy_sphere(24, 12, seed=21)
     radius.radius = (0.25 + np.arange(radius.nvert, dtype=np.float32) % 17).reshape(-1, 1)
@@ -19,6 +22,7 @@ def cases():
         ("nrm_estimated_rgb", S.bumpy_sphere(64, 32, seed=3, color_components=3), dict(normal_prediction=ESTIMATED)),
         ("c4_unit", S.bumpy_sphere(64, 32, seed=0), dict(normal_prediction=BORDER)),
         ("two_groups", two_groups, dict(normal_prediction=BORDER)),
+        ("group_props", group_props, dict(normal_prediction=ESTIMATED)),
         ("holey_disc", S.shuffled(S.holey_disc(40, seed=5), seed=3), dict(normal_prediction=BORDER)),
         ("multi_component", multi, dict(normal_prediction=ESTIMATED)),
         ("torus", S.torus(48, 24, seed=4), dict(normal_prediction=BORDER)),

@@ -32,8 +32,11 @@ from cases import cases  # noqa: E402
 
 
 def main():
+    only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None   # add a case without rewriting the others
     index = []
     for name, mesh, kw in cases():
+        if only is not None and name not in only:
+            continue
         blob = rc.encode(mesh, **kw)
         cc = mesh.color.shape[1] if mesh.color is not None and kw.get("with_color", True) else 4
         ref = rc.decode_trace(blob, color_components=cc)
@@ -48,10 +51,14 @@ def main():
         if "index" in ref16 and ref16["index"].dtype == np.uint16:
             d["index_u16_sha256"] = np.frombuffer(sha(ref16["index"]).encode(), dtype=np.uint8)
         d["color_components"] = np.array(cc)
+        # index.groups as the reference Decoder reports them after decode(): "end\tkey=value\tkey=value" per group, one group per line
+        d["groups_ref"] = np.frombuffer("\n".join("\t".join([str(e)] + ["%s=%s" % kv for kv in p.items()]) for e, p in rc.groups(blob)).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
         index.append((name, len(blob), ref["nvert"], ref["nface"]))
         print("%-20s crt %7d B  nvert %6d nface %6d" % index[-1])
 
+    if only is not None:
+        return
     # mid-size mesh (C1-class, 34 060 verts / 67 600 tris): blob + digests only
     m = synth.bumpy_sphere(260, 130, seed=34)
     blob = rc.encode(m, normal_prediction=rc.BORDER)

@@ -73,6 +73,34 @@ def test_exif_and_groups(L):
     assert ca.probe_groups(load_golden("cloud_diff")["crt"]) == []
 
 
+def probe_group_props(blob, g):
+    n = L_().crthip_probe_group_props(blob.ctypes.data_as(C.c_void_p), len(blob), g, None, 0)
+    assert n >= 0
+    buf = C.create_string_buffer(max(int(n), 1))
+    L_().crthip_probe_group_props(blob.ctypes.data_as(C.c_void_p), len(blob), g, buf, int(n))
+    parts = buf.raw[:n].split(b"\0")[:-1] if n else []
+    return {parts[i].decode(): parts[i + 1].decode() for i in range(0, len(parts), 2)}
+
+
+def L_():
+    return ca.lib()
+
+
+def test_group_properties_match_the_reference(L):
+    """Group::properties (include/corto/index_attribute.h:89-99): the blob was written by the reference's addGroup(end, props)
+    (include/corto/encoder.h:75) and `groups_ref` is what the reference Decoder reported back for it"""
+    g = load_golden("group_props")
+    blob = aligned(g["crt"])
+    want = []
+    for line in g["groups_ref"].tobytes().decode().split("\n"):
+        f = line.split("\t")
+        want.append((int(f[0]), dict(kv.split("=", 1) for kv in f[1:])))
+    assert [e for e, _ in want] == [100, 101, 400, 576] and want[2][1] == {"a": "first", "m": "", "z": "last"}
+    assert ca.probe_groups(blob) == [e for e, _ in want]
+    for i, (_, props) in enumerate(want):
+        assert probe_group_props(blob, i) == props
+
+
 def test_truncated_bodies_are_rejected_on_the_host(L):
     g = load_golden("holey_disc")
     blob = g["crt"]

@@ -75,3 +75,30 @@ def test_random_corpus_against_reference():
     m = S.bumpy_sphere(20, 10, 3); m.groups = [100, 250, m.nface]
     kw = dict(position_bits=0, position_q=0.0137, exif={"a": "b"})
     assert ca.encode(m, **kw).tobytes() == rc.encode(m, **kw).tobytes()
+
+
+def test_bad_arguments_are_rejected_not_trusted():
+    """upstream trusts its caller (an index >= nvert writes past its vectors, src/encoder.cpp:341-347); the C ABI checks"""
+    import copy
+    base = synth.bumpy_sphere(8, 4, seed=1)
+    def enc(**kw):
+        m = copy.copy(base)
+        for k, v in kw.items():
+            setattr(m, k, v)
+        return m
+    bad_index = base.index.copy(); bad_index[5, 1] = base.nvert
+    with pytest.raises(ca.CortoError, match="out of range"):
+        ca.encode(enc(index=bad_index))
+    with pytest.raises(ca.CortoError, match="color_bits"):
+        ca.encode(base, color_bits=(6, 9, 6, 5))
+    with pytest.raises(ca.CortoError, match="color_bits"):
+        ca.encode(base, color_bits=(0, 7, 6, 5))
+    with pytest.raises(ca.CortoError, match="color_components"):
+        ca.encode(enc(color=np.zeros((base.nvert, 2), np.uint8)))
+    with pytest.raises(ca.CortoError, match="group ends"):
+        ca.encode(enc(groups=[30, 20, base.nface]))
+    with pytest.raises(ca.CortoError, match="group ends"):
+        ca.encode(enc(groups=[base.nface + 1]))
+    with pytest.raises(ca.CortoError):
+        ca.encode(base, entropy=7)
+    assert len(ca.encode(base)) > 100

@@ -155,12 +155,15 @@ def test_cpp_decoder_dropin(ctx, tmp_path):
     exe = str(tmp_path / "facade_decode")
     subprocess.check_call(["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_decode.cpp"),
                            "-L", os.path.dirname(ca.LIB_PATH), "-lcorto_hip", "-Wl,-rpath," + os.path.dirname(ca.LIB_PATH), "-o", exe])
-    for name in ("c4_unit", "two_groups", "radius_attr"):
+    for name in ("c4_unit", "two_groups", "radius_attr", "group_props"):
         g = load_golden(name)
         src, dst = str(tmp_path / (name + ".crt")), str(tmp_path / (name + ".bin"))
         g["crt"].tofile(src)
         out = subprocess.run([exe, src, dst], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
+        if "groups_ref" in g:                       # Decoder::index.groups[g].end / .properties == what the reference Decoder reported
+            got = [l[len("group "):] for l in out.stdout.splitlines() if l.startswith("group ")]
+            assert got == g["groups_ref"].tobytes().decode().split("\n"), name
         cc = int(g["color_components"])
         exp = oc.decode(g["crt"], color_components=4)
         blob = np.fromfile(dst, dtype=np.uint8)
