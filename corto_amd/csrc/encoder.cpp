@@ -295,42 +295,51 @@ struct Attr {
 	std::vector<int32_t> boundary;
 };
 
-// ---- topology (src/encoder.cpp:383-504) ----
-struct McFace { uint32_t f[3], t[3], i[3]; };
-struct McEdge {
-	uint32_t face, side, v0, v1; bool inverted;
-	McEdge() {}
-	McEdge(uint32_t f, uint32_t s, uint32_t a, uint32_t b): face(f), side(s), inverted(false) { if(a < b) { v0 = a; v1 = b; } else { v1 = a; v0 = b; inverted = true; } }
-	bool operator<(const McEdge &e) const { if(v0 < e.v0) return true; if(v0 > e.v0) return false; return v1 < e.v1; }
-	bool match(const McEdge &e) const { if(inverted == e.inverted) return false; return v0 == e.v0 && v1 == e.v1; }
+// ---- face adjacency: every directed side of a triangle is a HALF-EDGE, id 3*face + side, side s running opposite corner s
+// (side 0 = corners 1->2, side 1 = 2->0, side 2 = 0->1); twin[h] = the half-edge of the neighbouring face running the other way
+// along the same two vertices, or NO_TWIN.  Same result as upstream's buildTopology (src/encoder.cpp:450-504) - including on
+// non-manifold input, where WHICH two of several candidates get paired depends on the order std::sort leaves equal keys in:
+// so the half-edges are bucketed by their smaller vertex in the same order, and every bucket goes through std::sort with an
+// equivalent strict-weak order on (smaller vertex, larger vertex).  std::sort's permutation is a function of the comparison
+// results alone, so a different element type does not change it.
+constexpr uint32_t NO_TWIN = 0xffffffffu;
+struct SideKey {
+	uint32_t lo, hi;        // the side's two vertices, lo < hi
+	uint32_t half;          // 3*face + side
+	uint32_t flipped;       // the side runs hi -> lo
+	bool operator<(const SideKey &o) const { return lo != o.lo ? lo < o.lo : hi < o.hi; }
 };
 
-void build_topology(std::vector<McFace> &faces, uint32_t nvert) {
-	std::vector<uint32_t> count(nvert, 0);
-	for(McFace &f : faces) { count[std::min(f.f[0], f.f[1])]++; count[std::min(f.f[1], f.f[2])]++; count[std::min(f.f[2], f.f[0])]++; }
-	uint32_t partial = 0;
-	for(uint32_t &c : count) { const uint32_t tmp = c; c = partial; partial += tmp; }
-	std::vector<McEdge> edges(faces.size()*3);
-	for(size_t i = 0; i < faces.size(); i++) {
-		McFace &f = faces[i];
-		edges[count[std::min(f.f[1], f.f[2])]++] = McEdge((uint32_t)i, 0, f.f[1], f.f[2]);
-		edges[count[std::min(f.f[2], f.f[0])]++] = McEdge((uint32_t)i, 1, f.f[2], f.f[0]);
-		edges[count[std::min(f.f[0], f.f[1])]++] = McEdge((uint32_t)i, 2, f.f[0], f.f[1]);
-	}
-	if(!count.empty()) {
-		std::sort(edges.begin(), edges.begin() + count[0]);
-		for(uint32_t i = 0; i + 1 < count.size(); i++) { if(count[i] == 0) continue; std::sort(edges.begin() + count[i], edges.begin() + count[i + 1]); }
-	}
-	McEdge prev(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff);
-	for(const McEdge &e : edges) {
-		if(e.match(prev)) {
-			uint32_t &a = faces[e.face].t[e.side], &b = faces[prev.face].t[prev.side];
-			if(a == 0xffffffff && b == 0xffffffff) { a = prev.face; faces[e.face].i[e.side] = prev.side; b = e.face; faces[prev.face].i[prev.side] = e.side; }
-		} else prev = e;
+static void pair_half_edges(const uint32_t *corner, size_t ntri, uint32_t nvert, std::vector<uint32_t> &twin) {
+	twin.assign(ntri*3, NO_TWIN);
+	// bucket b = sides whose smaller vertex is b, filled face by face, side 0, 1, 2
+	std::vector<uint32_t> fill(nvert + 1, 0);
+	auto ends = [&](size_t t, int side, uint32_t &from, uint32_t &to) { from = corner[3*t + (side + 1)%3]; to = corner[3*t + (side + 2)%3]; };
+	for(size_t t = 0; t < ntri; t++)
+		for(int side = 0; side < 3; side++) { uint32_t a, b; ends(t, side, a, b); fill[std::min(a, b) + 1]++; }
+	for(uint32_t v = 0; v < nvert; v++) fill[v + 1] += fill[v];
+	std::vector<uint32_t> first(fill.begin(), fill.end() - 1);              // bucket starts (fill[] becomes the write cursors)
+	std::vector<SideKey> sides(ntri*3);
+	for(size_t t = 0; t < ntri; t++)
+		for(int side = 0; side < 3; side++) {
+			uint32_t a, b; ends(t, side, a, b);
+			SideKey k; k.lo = std::min(a, b); k.hi = std::max(a, b); k.half = (uint32_t)(3*t + side); k.flipped = a > b;
+			sides[fill[k.lo]++] = k;
+		}
+	// (upstream skips every bucket after the first that starts at offset 0 - i.e. while no smaller vertex had a side of its own,
+	// src/encoder.cpp:481-485 - so the sides of the first non-empty bucket stay unsorted, and pair only where they happen to lie
+	// next to each other, when vertex 0 is not the smaller end of any side; byte identity needs the same)
+	for(uint32_t v = 0; v < nvert; v++) { if(v > 0 && first[v] == 0) continue; std::sort(sides.begin() + first[v], sides.begin() + fill[v]); }
+	// a side pairs with the candidate kept from before it when they run opposite ways along the same vertices and neither has a
+	// twin yet; any side that does not pair becomes the candidate
+	const SideKey *cand = nullptr;
+	for(const SideKey &k : sides) {
+		if(cand && cand->lo == k.lo && cand->hi == k.hi && cand->flipped != k.flipped) {
+			if(twin[k.half] == NO_TWIN && twin[cand->half] == NO_TWIN) { twin[k.half] = cand->half; twin[cand->half] = k.half; }
+		} else cand = &k;
 	}
 }
 
-struct CEdge { uint32_t face, side, prev, next; bool deleted; };
 enum { VERTEX = 0, LEFT = 1, RIGHT = 2, END = 3, BOUNDARY = 4, DELAY = 5, SPLIT = 6 };
 
 struct Encoder {
@@ -347,91 +356,111 @@ struct Encoder {
 	std::vector<Quad> prediction;
 	Sink s;
 
-	void encode_faces(int start, int end) {                                            // src/encoder.cpp:522-722
-		std::vector<McFace> mf((size_t)(end - start));
-		for(int i = start; i < end; i++) { McFace &f = mf[(size_t)(i - start)]; for(int k = 0; k < 3; k++) { f.f[k] = faces[(size_t)i*3 + k]; f.t[k] = 0xffffffff; f.i[k] = 0; } }
-		build_topology(mf, nvert);
-		uint32_t current = 0, order = 0;
-		std::vector<int> delayed, faceorder;
-		std::vector<CEdge> front;
-		std::vector<bool> visited(mf.size(), false);
-		uint32_t totfaces = (uint32_t)mf.size();
-		std::vector<bool> referenced(nvert, false);
-		for(uint32_t v : faces) referenced[v] = true;
-		uint32_t nref = 0; for(bool r : referenced) if(r) nref++;
-		const int splitbits = ilog2u(nref) + 1;
-		int new_edge = -1;
-		auto nxt = [](int t) { return t == 2 ? 0 : t + 1; };
-		while(totfaces > 0) {
-			if(new_edge == -1 && order >= faceorder.size() && delayed.empty()) {
-				while(current != mf.size() && visited[current]) current++;
-				if(current == mf.size()) break;
-				const uint32_t ce = (uint32_t)front.size();
-				McFace &face = mf[current];
-				int mask = 0;
-				for(int k = 0; k < 3; k++) if(encoded[face.f[k]] != -1) mask |= 1 << k;
-				if(mask) { clers.push_back(SPLIT); split.write((uint32_t)mask, 3); } else clers.push_back(VERTEX);
+	// The CLERS writer for faces [start, end) (one group): the region-growing walk of upstream's encodeFaces (src/encoder.cpp:522-722)
+	// - same symbols, same split / vertex-id bits, same vertex numbering and parallelogram corners - on this repo's own terms:
+	// the advancing front is a circular list threaded THROUGH the half-edges (a half-edge joins the front at most once, so
+	// before[] / after[] / where[] are indexed by half-edge id and there is no separate edge store), gates wait in a FIFO of
+	// half-edge ids, postponed ones on a stack.
+	void encode_faces(int start, int end) {
+		const size_t ntri = (size_t)(end - start);
+		const uint32_t *corner = faces.data() + (size_t)start*3;
+		std::vector<uint32_t> twin;
+		pair_half_edges(corner, ntri, nvert, twin);
+
+		enum : uint8_t { OFF_FRONT = 0, ON_FRONT = 1, CLOSED = 2 };
+		std::vector<uint8_t> where(ntri*3, OFF_FRONT);                    // a half-edge's life: not reached / on the front / swallowed by a later face
+		std::vector<uint32_t> before(ntri*3, 0), after(ntri*3, 0);        // its neighbours along the front
+		std::vector<uint8_t> coded(ntri, 0);                              // faces already written
+		std::vector<uint32_t> gates, postponed;
+		size_t gate_cursor = 0, seed_cursor = 0, remaining = ntri;
+		uint32_t joined = 0;                                              // half-edges that ever joined the front (upstream's front.size())
+		uint32_t pending = NO_TWIN;                                       // the front edge the previous step made: always the next gate
+
+		std::vector<uint8_t> used(nvert, 0);
+		for(uint32_t v : faces) used[v] = 1;
+		uint32_t nused = 0; for(uint8_t u : used) nused += u;
+		const int idbits = ilog2u(nused) + 1;                              // bits of a known vertex's number in the split stream
+
+		auto onto_front = [&](uint32_t h, uint32_t p, uint32_t n) { where[h] = ON_FRONT; before[h] = p; after[h] = n; joined++; };
+		auto introduce = [&](uint32_t v, uint32_t a, uint32_t b, uint32_t c) {      // a vertex seen for the first time gets the next number
+			prediction[current_vertex] = Quad{v, a, b, c};
+			encoded[v] = (int)current_vertex++;
+			last_index = v;
+		};
+		auto mention = [&](uint32_t v) { split.write((uint32_t)encoded[v], idbits); };
+
+		while(remaining) {
+			uint32_t gate;
+			if(pending != NO_TWIN) { gate = pending; pending = NO_TWIN; }
+			else if(gate_cursor < gates.size()) gate = gates[gate_cursor++];
+			else if(!postponed.empty()) { gate = postponed.back(); postponed.pop_back(); }
+			else {
+				// nothing left to grow from: start a new component with the first face not written yet
+				while(seed_cursor < ntri && coded[seed_cursor]) seed_cursor++;
+				if(seed_cursor == ntri) break;
+				const uint32_t t = (uint32_t)seed_cursor;
+				const uint32_t *c3 = corner + 3*(size_t)t;
+				uint32_t known = 0;
+				for(int k = 0; k < 3; k++) if(encoded[c3[k]] != -1) known |= 1u << k;
+				if(known) { clers.push_back(SPLIT); split.write(known, 3); } else clers.push_back(VERTEX);
 				for(int k = 0; k < 3; k++) {
-					const uint32_t v = face.f[k];
-					int &enc = encoded[v];
-					if(enc != -1) split.write((uint32_t)enc, splitbits);
-					else { prediction[current_vertex] = Quad{v, last_index, last_index, last_index}; enc = (int)current_vertex++; last_index = v; }
+					if(encoded[c3[k]] != -1) mention(c3[k]);
+					else introduce(c3[k], last_index, last_index, last_index);
 				}
-				faceorder.push_back((int)front.size()); front.push_back(CEdge{current, 0, ce + 2, ce + 1, false});
-				faceorder.push_back((int)front.size()); front.push_back(CEdge{current, 1, ce + 0, ce + 2, false});
-				faceorder.push_back((int)front.size()); front.push_back(CEdge{current, 2, ce + 1, ce + 0, false});
-				visited[current] = true; current++; totfaces--;
+				const uint32_t h = 3*t;                                      // its three sides circle the face: side 0 -> 1 -> 2 -> 0
+				onto_front(h, h + 2, h + 1); onto_front(h + 1, h, h + 2); onto_front(h + 2, h + 1, h);
+				gates.push_back(h); gates.push_back(h + 1); gates.push_back(h + 2);
+				coded[t] = 1; remaining--;
 				continue;
 			}
-			int c;
-			if(new_edge != -1) { c = new_edge; new_edge = -1; }
-			else if(order < faceorder.size()) c = faceorder[order++];
-			else { c = delayed.back(); delayed.pop_back(); }
-			CEdge e = front[(size_t)c];
-			if(e.deleted) continue;
-			const uint32_t of = mf[e.face].t[e.side];
-			const int os = (int)mf[e.face].i[e.side];
-			if(of == 0xffffffff || visited[of]) { clers.push_back(BOUNDARY); continue; }
-			McFace &face = mf[of];
-			const int k2 = os, k0 = nxt(k2), k1 = nxt(k0);
-			const int eprev = (int)e.prev, enext = (int)e.next;
-			const CEdge pe = front[(size_t)eprev], ne = front[(size_t)enext];
-			const bool close_left = mf[pe.face].t[pe.side] == of, close_right = mf[ne.face].t[ne.side] == of;
-			new_edge = (int)front.size();
-			if(close_left && close_right) {
+			if(where[gate] == CLOSED) continue;
+			const uint32_t tw = twin[gate];
+			if(tw == NO_TWIN || coded[tw/3]) { clers.push_back(BOUNDARY); continue; }
+			const uint32_t across = tw/3;                                    // the face on the other side of the gate
+			const uint32_t s_far = tw%3, s_a = (s_far + 1)%3, s_b = (s_a + 1)%3;   // its corner opposite the gate, then the gate's two ends
+			const uint32_t left = before[gate], right = after[gate];
+			const bool zip_left = twin[left] != NO_TWIN && twin[left]/3 == across;
+			const bool zip_right = twin[right] != NO_TWIN && twin[right]/3 == across;
+			const uint32_t h_a = 3*across + s_a, h_b = 3*across + s_b;       // the two sides of `across` that may join the front
+			if(zip_left && zip_right) {                                      // the face closes a triangular hole
 				clers.push_back(END);
-				front[(size_t)eprev].deleted = true; front[(size_t)enext].deleted = true;
-				front[pe.prev].next = ne.next; front[ne.next].prev = pe.prev;
-				new_edge = -1;
-			} else if(close_left) {
+				const uint32_t ll = before[left], rr = after[right];
+				where[left] = CLOSED; where[right] = CLOSED;
+				after[ll] = rr; before[rr] = ll;
+			} else if(zip_left) {
 				clers.push_back(LEFT);
-				front[(size_t)eprev].deleted = true;
-				front[pe.prev].next = (uint32_t)new_edge; front[(size_t)enext].prev = (uint32_t)new_edge;
-				front.push_back(CEdge{of, (uint32_t)k1, pe.prev, (uint32_t)enext, false});
-			} else if(close_right) {
+				const uint32_t ll = before[left];
+				where[left] = CLOSED;
+				onto_front(h_b, ll, right);
+				after[ll] = h_b; before[right] = h_b;
+				pending = h_b;
+			} else if(zip_right) {
 				clers.push_back(RIGHT);
-				front[(size_t)enext].deleted = true;
-				front[ne.next].prev = (uint32_t)new_edge; front[(size_t)eprev].next = (uint32_t)new_edge;
-				front.push_back(CEdge{of, (uint32_t)k0, (uint32_t)eprev, ne.next, false});
+				const uint32_t rr = after[right];
+				where[right] = CLOSED;
+				onto_front(h_a, left, rr);
+				before[rr] = h_a; after[left] = h_a;
+				pending = h_a;
 			} else {
-				const uint32_t v0 = face.f[k0], v1 = face.f[k1], opp = face.f[k2];
-				if(encoded[opp] != -1 && order < faceorder.size()) { delayed.push_back(c); clers.push_back(DELAY); new_edge = -1; continue; }
-				if(encoded[opp] != -1) { clers.push_back(SPLIT); split.write((uint32_t)encoded[opp], splitbits); }
+				const uint32_t far = corner[3*(size_t)across + s_far];
+				if(encoded[far] != -1 && gate_cursor < gates.size()) {          // a known vertex while gates are still waiting: come back to this one later
+					postponed.push_back(gate); clers.push_back(DELAY);
+					continue;
+				}
+				if(encoded[far] != -1) { clers.push_back(SPLIT); mention(far); }
 				else {
 					clers.push_back(VERTEX);
-					const uint32_t v2 = mf[e.face].f[e.side];
-					prediction[current_vertex] = Quad{opp, v0, v1, v2};
-					encoded[opp] = (int)current_vertex++;
-					last_index = opp;
+					// parallelogram corners: the gate's two ends and the corner of the gate's own face opposite it
+					introduce(far, corner[3*(size_t)across + s_a], corner[3*(size_t)across + s_b], corner[gate]);
 				}
-				front[(size_t)eprev].next = (uint32_t)new_edge; front[(size_t)enext].prev = (uint32_t)new_edge + 1;
-				front.push_back(CEdge{of, (uint32_t)k0, (uint32_t)eprev, (uint32_t)new_edge + 1, false});
-				faceorder.push_back((int)front.size());
-				front.push_back(CEdge{of, (uint32_t)k1, (uint32_t)new_edge, (uint32_t)enext, false});
+				onto_front(h_a, left, h_b); onto_front(h_b, h_a, right);
+				after[left] = h_a; before[right] = h_b;
+				gates.push_back(h_b);
+				pending = h_a;
 			}
-			visited[of] = true; totfaces--;
+			coded[across] = 1; remaining--;
 		}
-		max_front = std::max(max_front, (uint32_t)front.size());
+		max_front = std::max(max_front, joined);
 	}
 
 	// NormalAttr::preDelta (normal_attribute.cpp:113-143): uses ORIGINAL vertex ids and quantised positions

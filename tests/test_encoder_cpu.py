@@ -77,6 +77,37 @@ def test_random_corpus_against_reference():
     assert ca.encode(m, **kw).tobytes() == rc.encode(m, **kw).tobytes()
 
 
+def test_non_manifold_input_pairs_like_the_reference():
+    """Duplicated faces, reversed duplicates, fins on an edge and a 120-side fan around vertex 0: WHICH faces upstream's buildTopology
+    pairs there depends on the order std::sort leaves equal keys in (src/encoder.cpp:450-504).  The repo's adjacency builder sorts
+    its own element type; same bytes as the reference on all of these (the permutation std::sort produces is a function of the
+    comparison results alone)."""
+    import copy
+    from oracle import refcodec as rc
+    if not rc.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(7)
+    meshes = [synth.bumpy_sphere(6 + t % 9, 4 + t % 5, t) for t in range(30)]
+    ring = 60
+    ang = np.linspace(0, 2 * np.pi, ring, endpoint=False)
+    fan_pos = np.concatenate([[[0, 0, 1]], np.stack([np.cos(ang), np.sin(ang), 0 * ang], 1)]).astype(np.float32)
+    fan_idx = np.array([[0, 1 + i, 1 + (i + 1) % ring] for i in range(ring)], dtype=np.uint32)
+    meshes += [synth.Mesh(fan_pos, fan_idx) for _ in range(6)]
+    for t, m in enumerate(meshes):
+        idx = m.index.copy()
+        extra = []
+        for _ in range(int(rng.integers(1, 40))):
+            f = idx[int(rng.integers(0, len(idx)))]
+            kind = int(rng.integers(0, 3))
+            extra.append(f.copy() if kind == 0 else f[::-1].copy() if kind == 1 else np.array([f[0], f[1], int(rng.integers(0, m.nvert))], dtype=idx.dtype))
+        extra = [e for e in extra if len(set(e.tolist())) == 3]
+        m2 = copy.copy(m)
+        m2.index = np.concatenate([idx, np.array(extra, dtype=idx.dtype).reshape(-1, 3)])
+        m2.index = np.ascontiguousarray(m2.index[rng.permutation(len(m2.index))])
+        kw = dict(normal_prediction=t % 3, with_normal=m.normal is not None)
+        assert ca.encode(m2, **kw).tobytes() == np.asarray(rc.encode(m2, **kw)).tobytes(), t
+
+
 def test_bad_arguments_are_rejected_not_trusted():
     """upstream trusts its caller (an index >= nvert writes past its vectors, src/encoder.cpp:341-347); the C ABI checks"""
     import copy
