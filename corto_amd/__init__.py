@@ -49,7 +49,7 @@ class BlobInfo(C.Structure):
 
 
 class AttrBinding(C.Structure):
-    _fields_ = [("buffer", C.c_void_p), ("format", C.c_uint32), ("out_components", C.c_uint32)]
+    _fields_ = [("buffer", C.c_void_p), ("format", C.c_uint32), ("out_components", C.c_uint32), ("stride", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BatchStats(C.Structure):
@@ -330,6 +330,7 @@ class Batch:
             self.infos.append(info)
         self.outputs: List[Dict[str, object]] = []
         self._keep = None
+        self._interleaved = None
 
     def __len__(self):
         return len(self.blobs)
@@ -386,9 +387,60 @@ class Batch:
             else:
                 index_ptrs[i] = base + o; index_fmt[i] = fmt
         self._keep = (buf, binds, index_ptrs, index_fmt)
+        self._interleaved = None
         self.outputs = outs
         self.rebind()
         return outs
+
+    def allocate_interleaved(self, normal_format=FMT_INT16, index16=True, fill: Optional[int] = None):
+        """Render-ready outputs: every blob gets ONE interleaved vertex buffer - each vertex a record of
+        position f32x3 | normal (i16x3 + 2 bytes of padding, or f32x3) | uv f32x2 | colour u8x4 | other generic attributes f32xN, in
+        that order, for the attributes the blob has - bound through crthip_attr_binding.stride, and a u16 (or u32) index buffer.
+        host_outputs() de-interleaves.  Returns the per-blob record layouts {name: (offset, dtype, components)} and strides."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        order = {"position": 0, "normal": 1, "uv": 2, "color": 3}
+        off = 0
+        metas = []
+        for i, info in enumerate(self.infos):
+            nv, nf = info.nvert, info.nface
+            attrs = info.attrs()
+            rec, layout = 0, {}
+            for k, a in sorted(enumerate(attrs), key=lambda ka: (order.get(ka[1]["name"], 4), ka[0])):
+                if a["codec"] == CODEC_NORMAL:
+                    dt, comps, size, fmt, oc = ("i16", 3, 8, FMT_INT16, 0) if normal_format == FMT_INT16 else ("f32", 3, 12, FMT_FLOAT, 0)
+                elif a["codec"] == CODEC_COLOR:
+                    dt, comps, size, fmt, oc = "u8", 4, 4, FMT_UINT8, 4
+                else:
+                    dt, comps, size, fmt, oc = "f32", a["components"], 4 * a["components"], FMT_FLOAT, 0
+                layout[a["name"]] = (rec, dt, comps, k, fmt, oc)
+                rec += size
+            off = (off + 255) & ~255
+            vb = off; off += nv * rec
+            ib = None
+            if nf:
+                off = (off + 255) & ~255
+                ib = off; off += nf * 3 * (2 if index16 and nv < 65536 else 4)
+            metas.append((vb, rec, layout, ib, bool(nf and index16 and nv < 65536)))
+        total = max(off, 256)
+        buf = torch.empty(total, dtype=torch.uint8, device=dev) if fill is None else torch.full((total,), fill, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        nattr_total = sum(info.nattr for info in self.infos)
+        binds = (AttrBinding * max(nattr_total, 1))()
+        first = np.cumsum([0] + [info.nattr for info in self.infos])
+        index_ptrs = (C.c_void_p * max(len(self), 1))()
+        index_fmt = np.full(max(len(self), 1), FMT_UINT32, dtype=np.uint32)
+        for i, (vb, rec, layout, ib, i16) in enumerate(metas):
+            for name, (o, dt, comps, k, fmt, oc) in layout.items():
+                bd = binds[int(first[i]) + k]
+                bd.buffer = base + vb + o; bd.format = fmt; bd.out_components = oc; bd.stride = rec
+            if ib is not None:
+                index_ptrs[i] = base + ib; index_fmt[i] = FMT_UINT16 if i16 else FMT_UINT32
+        self._keep = (buf, binds, index_ptrs, index_fmt)
+        self._interleaved = metas
+        self.outputs = [dict() for _ in self.infos]
+        self.rebind()
+        return metas
 
     def rebind(self):
         """(Re)apply the bindings prepared by allocate_outputs: one C call for the whole batch."""
@@ -402,6 +454,19 @@ class Batch:
     def host_outputs(self, i: int) -> Dict[str, np.ndarray]:
         """Copy blob i's outputs to the host as numpy arrays with the reference's dtypes."""
         res = {}
+        metas = getattr(self, "_interleaved", None)
+        if metas is not None and not self.outputs[i]:
+            vb, rec, layout, ib, i16 = metas[i]
+            nv, nf = self.infos[i].nvert, self.infos[i].nface
+            raw = self._keep[0][vb:vb + nv * rec].cpu().numpy().reshape(nv, rec) if nv * rec else np.zeros((nv, rec), np.uint8)
+            for name, (o, dt, comps, k, fmt, oc) in layout.items():
+                w = comps * np.dtype(_DT[dt]).itemsize
+                res[name] = np.ascontiguousarray(raw[:, o:o + w]).view(_DT[dt]).reshape(nv, comps)
+            if ib is not None:
+                nb = nf * 3 * (2 if i16 else 4)
+                res["index"] = self._keep[0][ib:ib + nb].cpu().numpy().view(np.uint16 if i16 else np.uint32).reshape(nf, 3)
+            res["nvert"], res["nface"] = nv, nf
+            return res
         for name, (t, dt) in self.outputs[i].items():
             a = t.cpu().numpy()
             res[name] = a.view(_DT[dt]) if a.dtype != _DT[dt] else a

@@ -157,8 +157,8 @@ template <typename T> struct HostArr {  // host image of a device array + where 
 };
 
 struct AttrScratch {
-	uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull; std::vector<uint64_t> sym;
-	void reset() { color = diffs = fired = ~0ull; sym.clear(); }
+	uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull, vals = ~0ull; std::vector<uint64_t> sym;   // vals: int32 workspace of a generic attribute bound with a stride
+	void reset() { color = diffs = fired = vals = ~0ull; sym.clear(); }
 };
 struct BlobScratch {
 	uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
@@ -231,7 +231,7 @@ struct crthip_ctx {
 	std::vector<const uint8_t *> plan_clers, plan_logs;
 };
 
-struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4; };
+struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
 
 struct BlobPlan {
 	BlobLayout L;
@@ -436,15 +436,24 @@ extern "C" int crthip_batch_info(const crthip_batch *b, uint32_t i, crthip_blob_
 
 static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
 	if(!bd.buffer) return CRTHIP_OK;
-	if(a.codec == CRTHIP_CODEC_NORMAL) return (bd.format == CRTHIP_FMT_FLOAT || bd.format == CRTHIP_FMT_INT16) ? CRTHIP_OK : CRTHIP_E_FORMAT;
+	const uint32_t st = bd.stride;
+	if(a.codec == CRTHIP_CODEC_NORMAL) {
+		if(bd.format != CRTHIP_FMT_FLOAT && bd.format != CRTHIP_FMT_INT16) return CRTHIP_E_FORMAT;
+		const uint32_t el = bd.format == CRTHIP_FMT_INT16 ? 2u : 4u;
+		if(st && (st < 3*el || st % el || ((uintptr_t)bd.buffer) % el)) return CRTHIP_E_ARGUMENT;
+		return CRTHIP_OK;
+	}
 	if(a.codec == CRTHIP_CODEC_COLOR) {
 		if(bd.format != CRTHIP_FMT_UINT8) return CRTHIP_E_FORMAT;        // FLOAT colour output is broken upstream (color_attribute.cpp:96-110)
 		uint32_t oc = bd.out_components ? bd.out_components : 4;
 		if(a.N < 1 || a.N > 4 || oc > 4 || oc < a.N) return CRTHIP_E_FORMAT;
+		if(st && st < oc) return CRTHIP_E_ARGUMENT;
 		return CRTHIP_OK;
 	}
 	if(a.N < 1) return CRTHIP_E_FORMAT;
-	return bd.format == CRTHIP_FMT_FLOAT ? CRTHIP_OK : CRTHIP_E_FORMAT;   // integer output formats: SURVEY a17, not on the device path
+	if(bd.format != CRTHIP_FMT_FLOAT) return CRTHIP_E_FORMAT;            // integer output formats: SURVEY a17, not on the device path
+	if(st && (st < 4*a.N || st % 4 || ((uintptr_t)bd.buffer) % 4)) return CRTHIP_E_ARGUMENT;
+	return CRTHIP_OK;
 }
 
 extern "C" int crthip_batch_bind(crthip_batch *b, uint32_t i, const crthip_attr_binding *attrs, void *index, uint32_t index_format) {
@@ -459,6 +468,11 @@ extern "C" int crthip_batch_bind(crthip_batch *b, uint32_t i, const crthip_attr_
 	for(size_t k = 0; k < P.bind.size(); k++) {
 		P.bind[k].buffer = attrs[k].buffer; P.bind[k].format = attrs[k].format;
 		P.bind[k].out_components = attrs[k].out_components ? attrs[k].out_components : 4;
+		// a stride equal to the packed element size is the packed layout (the buffer then doubles as int32 workspace, as upstream's does)
+		const AttrHeader &a = P.L.h.attrs[k];
+		const uint32_t packed = a.codec == CRTHIP_CODEC_NORMAL ? (attrs[k].format == CRTHIP_FMT_INT16 ? 6u : 12u)
+		                      : a.codec == CRTHIP_CODEC_COLOR ? P.bind[k].out_components : 4u*a.N;
+		P.bind[k].stride = attrs[k].stride == packed ? 0u : attrs[k].stride;
 	}
 	P.index = index; P.index_u16 = index && index_format == CRTHIP_FMT_UINT16;
 	b->dirty = true;
@@ -609,6 +623,7 @@ static int build_and_launch(crthip_batch *b) {
 			A.sym.resize(L.attrs[k].logs.size());
 			for(size_t j = 0; j < A.sym.size(); j++) need_stream(L.attrs[k].logs[j], A.sym[j]);
 			if(a.codec == CRTHIP_CODEC_COLOR) A.color = cv.take((uint64_t)L.h.nvert*a.N + 16, 16);
+			if(a.codec != CRTHIP_CODEC_COLOR && a.codec != CRTHIP_CODEC_NORMAL && bd.stride) A.vals = cv.take((uint64_t)L.h.nvert*a.N*4 + 16, 16);
 			if(a.codec == CRTHIP_CODEC_NORMAL) {
 				A.diffs = cv.take((uint64_t)L.h.nvert*8 + 16, 16);
 			}
@@ -735,9 +750,12 @@ static int build_and_launch(crthip_batch *b) {
 				for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], SP(A.color), false, 1, 1, (uint16_t)a.N, (uint16_t)c, 1);
 				values = SP(A.color); is_u8 = 1; para = (a.strategy & CRTHIP_PARALLEL) != 0;
 			} else {
-				if(a.strategy & CRTHIP_CORRELATED) push_unpack(as.logs[0], logs[0], bd.buffer, true, 0, (uint16_t)a.N, (uint16_t)a.N, 0, 0);
-				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], bd.buffer, true, 1, 1, (uint16_t)a.N, (uint16_t)c, 0);
-				values = bd.buffer; values_real = true; para = (a.strategy & CRTHIP_PARALLEL) != 0;
+				// packed output: the caller's buffer is the int32 workspace (like upstream, vertex_attribute.h:190-193); with a stride: scratch
+				void *work = bd.stride ? (void *)SP(A.vals) : bd.buffer;
+				const bool work_real = !bd.stride;
+				if(a.strategy & CRTHIP_CORRELATED) push_unpack(as.logs[0], logs[0], work, work_real, 0, (uint16_t)a.N, (uint16_t)a.N, 0, 0);
+				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], work, work_real, 1, 1, (uint16_t)a.N, (uint16_t)c, 0);
+				values = work; values_real = work_real; para = (a.strategy & CRTHIP_PARALLEL) != 0;
 			}
 			if(do_delta && nvert > 1) {
 				if(mesh) {
@@ -760,14 +778,17 @@ static int build_and_launch(crthip_batch *b) {
 				if(pr == 0 || (mesh && (pr == 1 || pr == 2))) {       // clouds: postDelta never runs (decoder.cpp:142-143)
 					NormalJob n{};
 					n.diffs = (int32_t *)SP(A.diffs); n.out = bd.buffer; n.nvert = nvert; n.nface = nface;
+					n.out_stride = bd.stride ? bd.stride : (bd.format == CRTHIP_FMT_INT16 ? 6u : 12u);
 					n.ndiffs = std::min(as.logs[0].size, nvert); n.unit = f2i_x86_host(a.q);
 					n.prediction = (uint8_t)pr; n.out_i16 = bd.format == CRTHIP_FMT_INT16;
 					n.status = (int32_t *)SP(pl.status_off + (uint64_t)i*4);
 					if(pr != 0) {
 						const bool pos_ok = pos_k >= 0 && L.h.attrs[pos_k].codec == CRTHIP_CODEC_GENERIC && L.h.attrs[pos_k].N == 3 && P.bind[pos_k].buffer;
 						if(!pos_ok) { P.host_status = CRTHIP_E_NORMAL_NEEDS_POSITION; continue; }
-						n.position = (const int32_t *)P.bind[pos_k].buffer;
-						n.faces = P.index ? P.index : (void *)SP(S.faces); n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0));   // bit7: faces is a real pointer (cleared at fixup)
+						const bool pos_scratch = P.bind[pos_k].stride != 0;               // the integer positions: in the caller's packed buffer, or in scratch
+						n.position = pos_scratch ? (const int32_t *)SP(S.attr[pos_k].vals) : (const int32_t *)P.bind[pos_k].buffer;
+						n.faces = P.index ? P.index : (void *)SP(S.faces);
+						n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0) | (pos_scratch ? 0x40 : 0));   // bit7: faces is a real pointer, bit6: position is a scratch offset (both cleared at fixup)
 						if(normal_fused(nvert, nface)) {
 							n.fused = 1;
 							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
@@ -785,7 +806,9 @@ static int build_and_launch(crthip_batch *b) {
 				for(int c = 0; c < 4; c++) q.qc[c] = as.qc[c];
 				q.block0 = (uint32_t)pl.dequant_block_job.v.size();
 				q.is_color = a.codec == CRTHIP_CODEC_COLOR;
-				if(q.is_color) q.color_src = SP(A.color);
+				q.stride = bd.stride;
+				if(q.is_color) q.src = SP(A.color);
+				else if(bd.stride) q.src = SP(A.vals);
 				const uint64_t elems = q.is_color ? nvert : (uint64_t)nvert*a.N;
 				const uint32_t nb = (uint32_t)((elems + CHUNK - 1)/CHUNK);
 				for(uint32_t c = 0; c < nb; c++) pl.dequant_block_job.v.push_back((uint32_t)pl.dequant.v.size());
@@ -868,9 +891,10 @@ static int build_and_launch(crthip_batch *b) {
 	for(auto &n : pl.normal.v) {
 		n.diffs = (int32_t *)R(n.diffs); n.status = (int32_t *)R(n.status);
 		if(n.prediction != 0 && !(n.faces_u16 & 0x80)) n.faces = R(n.faces);
-		n.faces_u16 &= 0x7F;
+		if(n.prediction != 0 && (n.faces_u16 & 0x40)) n.position = (const int32_t *)R(n.position);
+		n.faces_u16 &= 0x3F;
 	}
-	for(auto &q : pl.dequant.v) if(q.is_color) q.color_src = R(q.color_src);
+	for(auto &q : pl.dequant.v) if(q.is_color || q.stride) q.src = R(q.src);
 	for(auto &P : b->blobs) { (void)P; }
 
 	// host image -> device (one copy)
@@ -1105,7 +1129,7 @@ extern "C" int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t l
 	size_t off[CRTHIP_MAX_ATTRS + 1], bytes[CRTHIP_MAX_ATTRS + 1];
 	size_t total = 0;
 	for(size_t k = 0; k < na; k++) {
-		dev[k] = attrs[k]; bytes[k] = 0; off[k] = 0;
+		dev[k] = attrs[k]; dev[k].stride = 0; dev[k].reserved = 0; bytes[k] = 0; off[k] = 0;   // (host buffers: upstream's packed layouts)
 		if(!dev[k].buffer) continue;
 		const AttrHeader &a = L.h.attrs[k];
 		if(a.codec == CRTHIP_CODEC_NORMAL) bytes[k] = (size_t)nvert*3*(dev[k].format == CRTHIP_FMT_INT16 ? 2 : 4);

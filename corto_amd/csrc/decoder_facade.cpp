@@ -177,6 +177,7 @@ void Decoder::decode() {
 		b.buffer = it.second->buffer;
 		b.format = (uint32_t)it.second->format;
 		b.out_components = (uint32_t)it.second->out_components;
+		b.stride = 0; b.reserved = 0;
 		binds.push_back(b);
 	}
 	void *idx = index.faces16 ? (void *)index.faces16 : (void *)index.faces32;   // faces16 wins (src/decoder.cpp:246-249)

@@ -113,16 +113,20 @@ struct NormalJob {
 	int32_t unit;                  // (int)q
 	uint8_t prediction, out_i16, faces_u16, fused;   // fused: handled by k_normal_blob (whole pipeline in one workgroup)
 	int32_t *status;
+	uint32_t out_stride;           // bytes from one vertex's normal to the next (12 or 6 when packed)
+	uint32_t pad;
 };
 
 struct DequantJob {
-	void *buffer;                  // generic: in-place int32 -> float; colour: destination
-	const uint8_t *color_src;      // colour: delta-decoded N-component bytes
+	void *buffer;                  // destination (generic, packed: the int32 values are here already and turn into floats in place)
+	const uint8_t *src;            // colour: delta-decoded N-component bytes; generic with a stride: the int32 values (packed scratch)
 	float q;
 	uint32_t nvert, N, out_components;
 	uint32_t qc[4];
 	uint32_t block0;               // first block of this job in the block->job map
 	uint8_t is_color, pad[3];
+	uint32_t stride;               // bytes from one vertex to the next in `buffer`; 0 = packed
+	uint32_t pad2;
 };
 
 // ---- encoder stages (k_encode.hip, encode_gpu.cpp) ----

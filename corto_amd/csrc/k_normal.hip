@@ -51,10 +51,10 @@ __device__ __forceinline__ void to_sphere(int32_t x, int32_t y, int32_t unit, fl
 
 __device__ __forceinline__ void store_normal(const NormalJob &J, uint32_t i, float nx, float ny, float nz) {
 	if(J.out_i16) {                                     // Point3s(n*32767) (normal_attribute.h:121)
-		CRT_GLOBAL int16_t *o = as_global((int16_t *)J.out) + (size_t)i*3;     // explicit address space: a FLAT store would make the next LDS read wait for its acknowledgement
+		CRT_GLOBAL int16_t *o = (CRT_GLOBAL int16_t *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);     // explicit address space: a FLAT store would make the next LDS read wait for its acknowledgement
 		o[0] = f2s_x86(nx*32767); o[1] = f2s_x86(ny*32767); o[2] = f2s_x86(nz*32767);
 	} else {
-		CRT_GLOBAL float *o = as_global((float *)J.out) + (size_t)i*3;
+		CRT_GLOBAL float *o = (CRT_GLOBAL float *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
 		o[0] = nx; o[1] = ny; o[2] = nz;
 	}
 }
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
 		float len = norm3(ex, ey, ez);
 		if(!(len < 0.00001f)) {
 			len = 32767.0f/len;
-			int16_t *o = (int16_t *)J.out + (size_t)i*3;
+			int16_t *o = (int16_t *)((uint8_t *)J.out + (size_t)i*J.out_stride);
 			o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
 		}
 	} else {                                            // normal_attribute.cpp:317-322
 		const float len = norm3(ex, ey, ez);
-		float *o = (float *)J.out + (size_t)i*3;
+		float *o = (float *)((uint8_t *)J.out + (size_t)i*J.out_stride);
 		o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
 	}
 }
@@ -321,12 +321,12 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			float len = norm3(ex, ey, ez);
 			if(!(len < 0.00001f)) {
 				len = 32767.0f/len;
-				CRT_GLOBAL int16_t *o = as_global((int16_t *)J.out) + (size_t)i*3;
+				CRT_GLOBAL int16_t *o = (CRT_GLOBAL int16_t *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
 				o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
 			}
 		} else {
 			const float len = norm3(ex, ey, ez);
-			CRT_GLOBAL float *o = as_global((float *)J.out) + (size_t)i*3;
+			CRT_GLOBAL float *o = (CRT_GLOBAL float *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
 			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
 		}
 	}

@@ -193,7 +193,16 @@ __global__ __launch_bounds__(256) void k_dequant(const DequantJob *__restrict__ 
 		const uint32_t n = J.nvert*J.N;
 		CRT_GLOBAL int32_t *vi = as_global((int32_t *)J.buffer);
 		CRT_GLOBAL float *vf = as_global((float *)J.buffer);
-		if(e0 + 3 < n && (((uintptr_t)J.buffer) & 15) == 0) {      // the usual case: one 16-byte load and store per thread
+		if(J.stride) {                                          // interleaved vertex buffer: values from packed scratch, floats to vertex i's record
+			CRT_GLOBAL const int32_t *vs = as_global((const int32_t *)J.src);
+			CRT_GLOBAL uint8_t *base = as_global((uint8_t *)J.buffer);
+#pragma unroll
+			for(int k = 0; k < 4; k++) if(e0 + k < n) {
+				const uint32_t e = e0 + k, i = e/J.N, c = e - i*J.N;
+				const float f = (float)vs[e];
+				*(CRT_GLOBAL float *)(base + (size_t)i*J.stride + 4u*c) = f*J.q;
+			}
+		} else if(e0 + 3 < n && (((uintptr_t)J.buffer) & 15) == 0) {      // the usual case: one 16-byte load and store per thread
 			typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 			typedef float f32x4 __attribute__((ext_vector_type(4)));
 			const i32x4 v = *(CRT_GLOBAL const i32x4 *)(vi + e0);
@@ -205,18 +214,18 @@ __global__ __launch_bounds__(256) void k_dequant(const DequantJob *__restrict__ 
 			for(int k = 0; k < 4; k++) if(e0 + k < n) { const float f = (float)vi[e0 + k]; vf[e0 + k] = f*J.q; }
 		}
 	} else {                                                   // YCC -> RGB, x qc, u8 wrap (color_attribute.cpp:76-95, point.h:214)
-		CRT_GLOBAL const uint8_t *src = as_global(J.color_src);
+		CRT_GLOBAL const uint8_t *src = as_global(J.src);
 		CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.buffer);
 #pragma unroll
 		for(int k = 0; k < 4; k++) {
 			const uint32_t i = e0 + k;
 			if(i >= J.nvert) break;
 			uint32_t col[4] = {0, 0, 0, 255};
-			if(J.N == 4 && (((uintptr_t)J.color_src) & 3) == 0) { const uint32_t x = *(CRT_GLOBAL const uint32_t *)(src + (size_t)i*4); col[0] = x & 255u; col[1] = (x >> 8) & 255u; col[2] = (x >> 16) & 255u; col[3] = x >> 24; }
+			if(J.N == 4 && (((uintptr_t)J.src) & 3) == 0) { const uint32_t x = *(CRT_GLOBAL const uint32_t *)(src + (size_t)i*4); col[0] = x & 255u; col[1] = (x >> 8) & 255u; col[2] = (x >> 16) & 255u; col[3] = x >> 24; }
 			else for(uint32_t c = 0; c < J.N && c < 4; c++) col[c] = src[(size_t)i*J.N + c];
 			const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
-			CRT_GLOBAL uint8_t *out = dst + (size_t)i*J.out_components;
-			if(J.out_components == 4 && (((uintptr_t)J.buffer) & 3) == 0)
+			CRT_GLOBAL uint8_t *out = dst + (size_t)i*(J.stride ? J.stride : J.out_components);
+			if(J.out_components == 4 && (((uintptr_t)out) & 3) == 0)
 				*(CRT_GLOBAL uint32_t *)out = ((rgb[0]*J.qc[0]) & 255u) | ((rgb[1]*J.qc[1]) & 255u) << 8 | ((rgb[2]*J.qc[2]) & 255u) << 16 | ((rgb[3]*J.qc[3]) & 255u) << 24;
 			else for(uint32_t c = 0; c < J.out_components && c < 4; c++) out[c] = (uint8_t)(rgb[c]*J.qc[c]);
 		}

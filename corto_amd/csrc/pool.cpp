@@ -101,7 +101,7 @@ static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_
 			L.first_attr[i] = (uint32_t)L.binds.size();
 			for(uint32_t k = 0; k < info.nattr; k++) {
 				const crthip_attr_info &a = info.attr[k];
-				crthip_attr_binding b; b.buffer = nullptr; b.format = CRTHIP_FMT_FLOAT; b.out_components = 0;
+				crthip_attr_binding b; b.buffer = nullptr; b.format = CRTHIP_FMT_FLOAT; b.out_components = 0; b.stride = 0; b.reserved = 0;
 				size_t n;
 				if(a.codec == CRTHIP_CODEC_NORMAL) n = (size_t)info.nvert*12;
 				else if(a.codec == CRTHIP_CODEC_COLOR) { b.format = CRTHIP_FMT_UINT8; b.out_components = 4; n = (size_t)info.nvert*4; }

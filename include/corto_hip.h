@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 1
+#define CRTHIP_ABI_VERSION 2   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_* */
 
 /* VertexAttribute::Format, include/corto/vertex_attribute.h:32 */
 enum { CRTHIP_FMT_UINT32 = 0, CRTHIP_FMT_INT32 = 1, CRTHIP_FMT_UINT16 = 2, CRTHIP_FMT_INT16 = 3,
@@ -87,6 +87,13 @@ typedef struct {
 	void *buffer;
 	uint32_t format;
 	uint32_t out_components;
+	uint32_t stride;             /* bytes from one vertex to the next; 0 = tightly packed (the layouts above).  A stride lets several
+	                                attributes land in ONE interleaved vertex buffer (buffer = base + the attribute's offset in the
+	                                vertex record): SURVEY.md 8f-3, the render-ready form of Decoder::setNormals(int16_t*) /
+	                                setIndex(uint16_t*) (include/corto/decoder.h:53,61).  Must be a multiple of 4 for FLOAT outputs, of 2
+	                                for INT16 normals, and at least the element's size; with a stride the attribute is decoded in device
+	                                scratch and only its final values touch the buffer (a packed generic buffer doubles as int32 workspace) */
+	uint32_t reserved;           /* 0 */
 } crthip_attr_binding;
 
 typedef struct crthip_ctx crthip_ctx;       /* one per device; owns streams + scratch pool */

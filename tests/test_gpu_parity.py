@@ -175,6 +175,46 @@ def test_cpp_decoder_dropin(ctx, tmp_path):
     assert out.returncode == 1 and "Not a crt file." in out.stderr
 
 
+def test_interleaved_vertex_buffers(ctx):
+    """every fixture decoded into ONE interleaved vertex buffer per blob (crthip_attr_binding.stride: position f32x3 |
+    normal i16x3 + pad | uv f32x2 | colour u8x4 | radius f32) + u16 indices, all in one batch; de-interleaved it is the reference's
+    output.  Bytes between the records' fields keep the fill value: nothing is written outside the attributes."""
+    names = list(ALL_CASES)
+    gs = [load_golden(n) for n in names]
+    b = ca.Batch(ctx, [g["crt"] for g in gs])
+    b.allocate_interleaved(fill=0)
+    b.decode()
+    assert (b.sync() == 0).all()
+    for i, (g, name) in enumerate(zip(gs, names)):
+        got = b.host_outputs(i)
+        want = oc.decode(g["crt"], normal_format=oc.FMT_INT16, color_components=4, index16=True)
+        assert_same(got, want, KEYS, "interleaved i16 " + name)
+        if "normal_i16" in g:
+            assert got["normal"].tobytes() == g["normal_i16"].tobytes(), name        # the reference's own int16 normals
+        if "index_u16_sha256" in g:
+            assert sha(got["index"]) == g["index_u16_sha256"].tobytes().decode(), name
+    # f32 normals + u32 indices interleaved as well
+    b.allocate_interleaved(normal_format=ca.FMT_FLOAT, index16=False, fill=0)
+    b.decode(); assert (b.sync() == 0).all()
+    for i, (g, name) in enumerate(zip(gs, names)):
+        assert_same(b.host_outputs(i), oc.decode(g["crt"], color_components=4), KEYS, "interleaved f32 " + name)
+    # the 2 padding bytes behind an i16 normal are nobody's: they keep what the caller had there
+    metas = b.allocate_interleaved(fill=0xA5)
+    b.decode(); assert (b.sync() == 0).all()
+    i = names.index("c4_unit")
+    vb, rec, layout, ib, i16 = metas[i]
+    nv = b.infos[i].nvert
+    raw = b._keep[0][vb:vb + nv * rec].cpu().numpy().reshape(nv, rec)
+    o = layout["normal"][0]
+    assert rec == 32 and (raw[:, o + 6:o + 8] == 0xA5).all() and not (raw[:, :o + 6] == 0xA5).all()
+    # a stride that cannot hold the element, or breaks its alignment, is refused
+    info = b.infos[0]
+    bad = (ca.AttrBinding * info.nattr)()
+    bad[0].buffer = b._keep[0].data_ptr(); bad[0].format = ca.FMT_FLOAT; bad[0].stride = 6
+    assert ca.lib().crthip_batch_bind(b.handle, 0, bad, None, ca.FMT_UINT32) == -8
+    b.close()
+
+
 @pytest.fixture(scope="module")
 def c5_blobs():
     """BASELINE config C5: 2 048 distinct C4-unit blobs (seeds 0 .. 2047), made by the repo's byte-identical writer"""
