@@ -218,15 +218,17 @@ def tunstall_scaled(ctx, ca, z, table_ids=None):
     dblk = torch.from_numpy(host).cuda()
     dout = torch.empty(ot + 16, dtype=torch.uint8, device="cuda")
     best = None
-    for _ in range(4):
+    ca.tunstall_decode_blocks(ctx, host, dblk, offs, dout, oo)             # first use: scratch allocation, code upload
+    for _ in range(5):                                                     # the run whose kernels together took least
         t = ca.tunstall_decode_blocks(ctx, host, dblk, offs, dout, oo)
-        if best is None or t["tunstall_decode"]["ms"] < best["tunstall_decode"]["ms"]:
+        if best is None or sum(v["ms"] for v in t.values()) < sum(v["ms"] for v in best.values()):
             best = t
     rd, wr = nstream * ncode, sum(sizes)
     dec_ms = best["tunstall_decode"]["ms"]
     all_ms = sum(v["ms"] for v in best.values())
     return {"streams": nstream, "codewords_per_stream": ncode, "bytes_read": rd, "bytes_written": wr,
-            "decode_kernel_ms": round(dec_ms, 4), "all_tunstall_kernels_ms": round(all_ms, 4),
+            "decode_kernel_ms": round(dec_ms, 4), "all_tunstall_kernels_ms": round(all_ms, 4), "kernels_ms": {k: round(v["ms"], 4) for k, v in best.items()},
+            "all_kernels_GBps": round((rd + wr) / all_ms / 1e6, 1), "all_kernels_frac_of_8TBps": round((rd + wr) / all_ms / 1e6 / 8000.0, 4),
             "decode_kernel_GBps": round((rd + wr) / dec_ms / 1e6, 1), "read_only_GBps": round(rd / dec_ms / 1e6, 1),
             "frac_of_8TBps": round((rd + wr) / dec_ms / 1e6 / 8000.0, 4)}
 

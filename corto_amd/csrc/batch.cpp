@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -209,7 +210,11 @@ struct crthip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;  // attribute streams (Tunstall + bit-unpack) run here while the main stream does topology
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t stream3 = nullptr;  // long Tunstall streams: the three word-width classes of the staged decode run side by side (k_tunstall.hip)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: chunk sums + scan + decode instead of the single pass with look-back (A/B measurements)
+	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
+	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
 	PinnedBuf staging;        // host image of the job arrays
 	PinnedBuf status_host;
@@ -310,8 +315,12 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	c->device = device;
 	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
 	   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+	   hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+	   hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	{ const char *e = getenv("CORTO_TUN_TWO_PASS"); c->tun_two_pass = e && e[0] == '1'; }
+	{ const char *e = getenv("CORTO_TUN_SIDE_STREAMS"); c->tun_side = e && e[0] == '1'; }
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
@@ -331,8 +340,9 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	c->timer.release();
 	if(c->host_batch) { crthip_batch *hb = c->host_batch; c->host_batch = nullptr; crthip_batch_destroy(hb); }
 	c->scratch.release(); c->staging.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
-	(void)hipStreamSynchronize(c->stream2);
-	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
+	(void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3);
+	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_join3);
+	(void)hipStreamDestroy(c->stream3);
 	(void)hipStreamDestroy(c->stream2);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -744,6 +754,9 @@ static int build_and_launch(crthip_batch *b) {
 			void *values = nullptr; bool values_real = false; uint8_t is_u8 = 0; uint32_t N = a.N; bool para = false; bool do_delta = true;
 			if(a.codec == CRTHIP_CODEC_NORMAL) {
 				push_unpack(as.logs[0], logs[0], SP(A.diffs), false, 0, 2, 2, 0, 0);
+				// a (malformed) stream with fewer diffs than vertices: upstream's vector is zero-filled behind them (normal_attribute.cpp:180-184)
+				// (only DIFF reads all nvert entries; the other predictions stop at ndiffs)
+				if(as.normal_prediction == 0 && as.logs[0].size < nvert) pl.fill.v.push_back(FillJob{SP(A.diffs + (uint64_t)as.logs[0].size*8), (nvert - as.logs[0].size)*8u, 0u});
 				values = SP(A.diffs); N = 2; para = false;
 				do_delta = as.normal_prediction == 0;                     // DIFF only (normal_attribute.cpp:190-191)
 			} else if(a.codec == CRTHIP_CODEC_COLOR) {
@@ -921,7 +934,7 @@ static int build_and_launch(crthip_batch *b) {
 	const uint32_t nfill = (uint32_t)pl.fill.v.size();
 	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
 		if(t1 > t0) {
-			LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables); LT.end();
+			LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables, (uint64_t *)nullptr, 0u); LT.end();
 			LT.begin("tunstall_decode", s); hipLaunchKernelGGL(k_tun_decode, dim3(c1 - c0), dim3(256), 0, s, D(pl.tun), D(pl.tun_chunk_stream), c1 - c0, tables, tun_partial, c0); LT.end();
 		}
 		if(f1 > f0) { LT.begin("fill", s); hipLaunchKernelGGL(k_fill, dim3(f1 - f0), dim3(256), 0, s, D(pl.fill) + f0, f1 - f0); LT.end(); }
@@ -947,10 +960,12 @@ static int build_and_launch(crthip_batch *b) {
 	};
 	if(pl.tun_multi_chunk) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables); LT.end();
-		LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
-		LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end();
-		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial)) return fail(CRTHIP_E_DEVICE); LT.end();
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables, ctx->tun_two_pass ? (uint64_t *)nullptr : tun_partial, tun_chunks); LT.end();
+		if(ctx->tun_two_pass) {
+			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
+			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end();
+		}                                                                          // (single pass: K-TAB cleared the chunks' look-back state words)
+		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, !ctx->tun_two_pass)) return fail(CRTHIP_E_DEVICE); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
@@ -1201,19 +1216,24 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	TunTable *tables = (TunTable *)(base + o_tab); uint64_t *part = (uint64_t *)(base + o_part);
 	const uint32_t ntun = (uint32_t)tun.size();
 	if(ntun) {
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables); LT.end();
-		if(multi) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables, multi && !ctx->tun_two_pass ? part : (uint64_t *)nullptr, chunks); LT.end();
+		if(multi && ctx->tun_two_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
 			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end();
 		}
 		LT.begin("tunstall_decode");
-		if(multi) { if(launch_tun_decode_staged(st, dt, dcs, chunks, tables, part)) return fail(CRTHIP_E_DEVICE); }
+		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, !ctx->tun_two_pass)) return fail(CRTHIP_E_DEVICE); }
 		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
 		LT.end();
 	}
 	if(!fills.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)fills.size()), dim3(256), 0, st, (FillJob *)(base + o_fill), (uint32_t)fills.size()); LT.end(); }
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
+	if(multi && !ctx->tun_two_pass) {                                       // a chunk that gave up waiting for its predecessor (k_tunstall.hip: tun_lookback)
+		uint64_t gave_up = 0;
+		HIP_TRY(hipMemcpy(&gave_up, part + chunks, 8, hipMemcpyDeviceToHost));
+		if(gave_up) return fail(CRTHIP_E_DEVICE, "Tunstall look-back: a chunk never saw its predecessor's total");
+	}
 	if(times) {
 		memset(times, 0, sizeof(*times));
 		for(auto &r : ctx->timer.recs) {

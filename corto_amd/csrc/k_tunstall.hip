@@ -25,7 +25,7 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // K-TAB
 __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__ streams, uint32_t nstreams,
-                                                    TunTable *__restrict__ tables) {
+                                                    TunTable *__restrict__ tables, uint64_t *lookback_state, uint32_t lookback_words) {
 	const uint32_t s = blockIdx.x;
 	if(s >= nstreams) return;
 	const TunStream st = streams[s];
@@ -201,6 +201,9 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	const uint32_t *src32 = (const uint32_t *)buf;
 	uint32_t *dst32 = (uint32_t *)T.bytes;
 	for(uint32_t i = lane; i < ndw; i += 64) dst32[i] = src32[i];
+	// a long stream's chunks find their output offsets by look-back (tun_lookback below): their state words start out empty
+	if(lookback_state && st.nchunks > 1) for(uint32_t i = lane; i < st.nchunks; i += 64) lookback_state[st.chunk0 + i] = 0;
+	if(lookback_state && s == 0 && lane == 0) lookback_state[lookback_words] = 0;        // the give-up counter behind them
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -420,12 +423,69 @@ __device__ __forceinline__ void tun_drain_long(uint32_t win0, CRT_LDS const uint
 	}
 }
 
+// Decoded bytes of codewords [first, last) of a stream, by one wave; the total in every lane.  Four dwords in flight per lane: the
+// loop is a chain of HBM load -> four LDS byte reads per dword, and one dword at a time ran at a tenth of what the CU can do.
+__device__ __forceinline__ uint32_t tun_wave_bytes(CRT_GLOBAL const uint8_t *src, uint32_t first, uint32_t last, CRT_LDS const uint8_t *len8) {
+	const uint32_t lane = lane_id();
+	uint32_t sum = 0;
+	const uint32_t head = min((uint32_t)((0u - (uint32_t)(uintptr_t)(src + first)) & 3u), last - first);   // aligned dword body, byte head/tail
+	if(lane < head) sum += len8[src[first + lane]];
+	const uint32_t body0 = first + head, ndw = (last - body0) >> 2;
+	CRT_GLOBAL const uint32_t *src32 = (CRT_GLOBAL const uint32_t *)(src + body0);
+	auto four = [&](uint32_t x) { return (uint32_t)len8[x & 255u] + len8[(x >> 8) & 255u] + len8[(x >> 16) & 255u] + len8[x >> 24]; };
+	uint32_t i = lane;
+	for(; i + 15*64 < ndw; i += 16*64) {                                // sixteen loads in flight: under the decode kernels' write traffic a read takes microseconds
+		uint32_t x[16];
+#pragma unroll
+		for(int k = 0; k < 16; k++) x[k] = src32[i + 64*k];
+#pragma unroll
+		for(int k = 0; k < 16; k++) sum += four(x[k]);
+	}
+	for(; i + 192 < ndw; i += 256) {
+		const uint32_t x0 = src32[i], x1 = src32[i + 64], x2 = src32[i + 128], x3 = src32[i + 192];
+		sum += four(x0) + four(x1) + four(x2) + four(x3);
+	}
+	for(; i < ndw; i += 64) sum += four(src32[i]);
+	const uint32_t tail0 = body0 + ndw*4;
+	if(tail0 + lane < last) sum += len8[src[tail0 + lane]];
+	sum = wave_inclusive_scan_u32(sum);
+	return (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+}
+
+// SINGLE PASS over a long stream (decoupled look-back): a chunk's output offset is the decoded size of every earlier chunk of its
+// stream.  Instead of a kernel that adds up every chunk, a device-wide scan and a second read of all codewords, each workgroup
+// adds up its own chunk (its four waves their quarters), publishes the total in the chunk's state word, and walks back over its
+// predecessors' words - "total of this chunk" (keep walking) or "total of everything up to here" (done) - spinning only on a
+// predecessor that has not published yet.  Workgroups start in chunk order (MI355X_MICROARCH.md: observed, not promised - so the
+// spin is bounded and a chunk that gives up flags the error word behind the state array), chunk 0 of every stream publishes an
+// inclusive total at once, so a walk never leaves its stream.  The state word IS the payload: 8-byte agent-scope atomics on both
+// sides, no fences (the per-XCD L2s are not coherent; sc1 accesses go to memory).
+constexpr uint64_t TUN_ST_LOCAL = 1ull << 62, TUN_ST_INCL = 2ull << 62, TUN_ST_MASK = (1ull << 62) - 1ull;
+__device__ __forceinline__ uint64_t tun_lookback(uint64_t *state, uint32_t c, uint32_t chunk0, uint64_t total, uint32_t nchunks_all) {
+	uint64_t prefix = 0;
+	if(c == chunk0) { __hip_atomic_store(&state[c], TUN_ST_INCL | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+	__hip_atomic_store(&state[c], TUN_ST_LOCAL | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for(uint32_t i = c - 1;; i--) {
+		uint64_t v = 0;
+		for(uint32_t spins = 0; spins < (1u << 22); spins++) {
+			v = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if(v >> 62) break;
+			__builtin_amdgcn_s_sleep(8);
+		}
+		if(!(v >> 62)) { atomicAdd((unsigned long long *)&state[nchunks_all], 1ull); break; }   // gave up: the output is wrong, the host is told
+		prefix += v & TUN_ST_MASK;
+		if((v >> 62) == 2 || i == chunk0) break;
+	}
+	__hip_atomic_store(&state[c], TUN_ST_INCL | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return prefix;
+}
+
 template <int W, int CPL> constexpr uint32_t tun_win_bytes() { return W == 1 ? 2048 + 64 : W == 2 ? 4096 + 64 : 6*1024 - 64; }
 constexpr uint32_t tun_staged_lds(uint32_t win) { return 4*(win + 64); }                // dynamic LDS: the four waves' windows
 
 template <int W, int CPL>
-__device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTable &T, uint32_t c, const uint64_t *__restrict__ chunk_out,
-                                                TunLds &L, uint32_t *t16, uint32_t (*longbuf)[TUN_LONGQ], uint32_t *winbuf) {
+__device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTable &T, uint32_t c, uint64_t *chunk_out, uint32_t single_pass, uint32_t nchunks_all,
+                                                TunLds &L, uint32_t *t16, uint32_t (*longbuf)[TUN_LONGQ], uint32_t *winbuf, uint64_t *share) {
 	constexpr uint32_t TUN_WIN = tun_win_bytes<W, CPL>();
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	tun_load_table(L, T, T.used);
@@ -446,10 +506,19 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 	const uint32_t chunk_codes = st.chunk_codes, quarter = chunk_codes/4;
 	const uint32_t cfirst = (c - st.chunk0)*chunk_codes;
 	const uint32_t first = min(cfirst + w*quarter, st.csize), last = min(first + quarter, min(cfirst + chunk_codes, st.csize));
-	uint64_t base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];
 	const uint64_t size = st.size;
 	const uint32_t csize = st.csize;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
+	uint64_t base;
+	if(single_pass) {                                                     // (tun_lookback above)
+		const uint32_t mine = tun_wave_bytes(src, first, last, as_lds(L.len));
+		if(lane == 0) share[1 + w] = mine;
+		__syncthreads();
+		if(tid == 0) share[0] = tun_lookback(chunk_out, c, st.chunk0, share[1] + share[2] + share[3] + share[4], nchunks_all);
+		__syncthreads();
+		base = share[0];
+		for(uint32_t k = 0; k < w; k++) base += share[1 + k];
+	} else base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];   // two passes: k_tun_chunk_sums + scan ran before
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
 	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(winbuf) + w*(TUN_WIN + 64);   // window byte i lives at wb[16 + i]
 	CRT_LDS u32x4_t *win = (CRT_LDS u32x4_t *)(wb + 16);
@@ -630,8 +699,8 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 template <int W>
 __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                            uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                           const uint64_t *__restrict__ chunk_out, uint32_t chunk_base) {
-	const uint32_t c = blockIdx.x + chunk_base;
+                                                           uint64_t *chunk_out, uint32_t single_pass) {
+	const uint32_t c = blockIdx.x;
 	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
 	const TunTable &T = tables[st.table];
@@ -640,21 +709,29 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	__shared__ __attribute__((aligned(16))) uint32_t t16[256*(W == 1 ? 2 : W)];
 	__shared__ uint32_t longbuf[W == 4 ? 4 : 1][TUN_LONGQ];
 	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];                   // [4][(TUN_WIN + 64)/4]: 16 bytes of slack in front, 48 behind
-	if constexpr(W != 4) tun_staged_body<W, 8>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+	__shared__ uint64_t share[5];                                                       // single pass: the chunk's offset, the four quarters' bytes
+	if constexpr(W != 4) tun_staged_body<W, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
 	else {
-		if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
-		else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
-		else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
-		else tun_staged_body<4, 1>(st, T, c, chunk_out, L, t16, longbuf, winbuf);
+		if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+		else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+		else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+		else tun_staged_body<4, 1>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
 	}
 }
 
-// host side: the three launches, short words first
-int launch_tun_decode_staged(hipStream_t st, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                             const uint64_t *chunk_out) {
-#define TUN_LAUNCH(W_) hipLaunchKernelGGL((k_tun_decode_staged<W_>), dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<W_, 8>()), st, \
-                                          streams, chunk_stream, nchunks, tables, chunk_out, 0u)
-	TUN_LAUNCH(1); TUN_LAUNCH(2); TUN_LAUNCH(4);
+// host side: the three launches.  They touch disjoint chunks, so they run side by side on three HIP streams (fork / join with
+// events around them): the tail of one class's chunks overlaps the body of the next.  single_pass: the chunk state words
+// (chunk_out[0 .. nchunks], zeroed by the caller) carry the look-back; otherwise chunk_out holds the scanned quarter offsets.
+int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                             uint64_t *chunk_out, uint32_t single_pass) {
+#define TUN_LAUNCH(W_, S_) hipLaunchKernelGGL((k_tun_decode_staged<W_>), dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<W_, 8>()), S_, \
+                                          streams, chunk_stream, nchunks, tables, chunk_out, single_pass)
+	const bool side = q.side[0] && q.side[1] && q.fork && q.join[0] && q.join[1];
+	if(side) {
+		if(hipEventRecord(q.fork, q.main) != hipSuccess || hipStreamWaitEvent(q.side[0], q.fork, 0) != hipSuccess || hipStreamWaitEvent(q.side[1], q.fork, 0) != hipSuccess) return -1;
+		TUN_LAUNCH(4, q.main); TUN_LAUNCH(1, q.side[0]); TUN_LAUNCH(2, q.side[1]);
+		for(int k = 0; k < 2; k++) if(hipEventRecord(q.join[k], q.side[k]) != hipSuccess || hipStreamWaitEvent(q.main, q.join[k], 0) != hipSuccess) return -1;
+	} else { TUN_LAUNCH(1, q.main); TUN_LAUNCH(2, q.main); TUN_LAUNCH(4, q.main); }
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 #undef TUN_LAUNCH
 }
