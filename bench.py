@@ -9,8 +9,8 @@ Workload (config C4 of BASELINE.json): a batch of 256 independent ~4K-triangle .
 = 1 048 576 triangles / 540 672 vertices PER GPU (weak scaling: config C5 = 8 GPUs x 256 blobs).
 A "step" = one pass of the hot path over that batch with the compressed blobs already resident in HBM:
 re-plan (crthip_batch_reset: host walk of every blob) + bind + decode (descriptor upload, all kernels) + sync; outputs stay in HBM.
-Steps run on the library's decode pool (crthip_pool, csrc/pool.cpp): per GPU --host-threads (default 2) native host threads
-each keep --depth (default 3) batches in flight, every batch on its own context (own HIP streams, scratch and output
+Steps run on the library's decode pool (crthip_pool, csrc/pool.cpp): per GPU --host-threads (default 4) native host threads
+each keep --depth (default 2) batches in flight, every batch on its own context (own HIP streams, scratch and output
 block), all threads of all GPUs pulling batches from ONE work queue (an atomic counter) - no collective anywhere.
 Timing: barrier + device sync, then W warm-up steps flow straight into the K timed steps (the pipeline is NOT drained in
 between); the clock runs from the completion of the last warm-up step to the completion of the K-th timed step, a few more
@@ -179,7 +179,8 @@ def pmc_traffic(kernel):
     --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None when no profile is committed."""
     import glob
     name = {"topology_lds": "corto_hip::k_topology_lds", "topology": "corto_hip::k_topology", "delta_mesh": "corto_hip::k_delta_mesh",
-            "tunstall_tables": "corto_hip::k_tun_tables", "tunstall_decode": "corto_hip::k_tun_decode"}.get(kernel)
+            "tunstall_tables": "corto_hip::k_tun_tables", "tunstall_decode": "corto_hip::k_tun_decode", "tunstall_stream": "corto_hip::k_tun_stream",
+            "delta_mesh": "corto_hip::k_delta_wave"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_per_dispatch.json")))
     if not name or not files:
         return None
@@ -310,8 +311,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=480)
     ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight (contexts) per host thread; 1 = unpipelined")
-    ap.add_argument("--host-threads", type=int, default=2, help="native host threads per GPU feeding it (crthip_pool)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight (contexts) per host thread; 1 = unpipelined")
+    ap.add_argument("--host-threads", type=int, default=4, help="native host threads per GPU feeding it (crthip_pool)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-object C2 / C3 decodes (tools/prof_run.sh: keeps the rocprofv3 kernel averages about the C4 batch)")
@@ -509,6 +510,7 @@ def main():
             # CLERS symbols + split words read; index (12 B/tri) + prediction triples (12 B/vert) written
             "topology_lds": topo_bytes, "topology": topo_bytes,
             "tunstall_decode": int(stats0.tunstall_in + stats0.tunstall_out), "tunstall_tables": int(stats0.tunstall_tables + stats0.tunstall_streams * 9216),
+            "tunstall_stream": int(stats0.tunstall_tables + stats0.tunstall_in + stats0.tunstall_out),
         }
         whole_path_bytes = int(stats0.arena_bytes + stats0.output_bytes)
         dom_bytes = alg.get(dom) or whole_path_bytes

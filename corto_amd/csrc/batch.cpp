@@ -213,6 +213,7 @@ struct crthip_ctx {
 	hipStream_t stream3 = nullptr;  // long Tunstall streams: the three word-width classes of the staged decode run side by side (k_tunstall.hip)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
 	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: chunk sums + scan + decode instead of the single pass with look-back (A/B measurements)
+	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
 	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
 	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
@@ -315,12 +316,13 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	c->device = device;
 	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
 	   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-	   hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
 	{ const char *e = getenv("CORTO_TUN_TWO_PASS"); c->tun_two_pass = e && e[0] == '1'; }
 	{ const char *e = getenv("CORTO_TUN_SIDE_STREAMS"); c->tun_side = e && e[0] == '1'; }
+	if(c->tun_side && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE); }   // (a stream is a hardware queue: not made unless asked for)
+	{ const char *e = getenv("CORTO_EXP_NORMAL_FN_MAX"); if(e) c->exp_normal_fn_max = (uint32_t)atoi(e); }
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
@@ -340,9 +342,9 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	c->timer.release();
 	if(c->host_batch) { crthip_batch *hb = c->host_batch; c->host_batch = nullptr; crthip_batch_destroy(hb); }
 	c->scratch.release(); c->staging.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
-	(void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3);
+	(void)hipStreamSynchronize(c->stream2); if(c->stream3) (void)hipStreamSynchronize(c->stream3);
 	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_join3);
-	(void)hipStreamDestroy(c->stream3);
+	if(c->stream3) (void)hipStreamDestroy(c->stream3);
 	(void)hipStreamDestroy(c->stream2);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -805,7 +807,7 @@ static int build_and_launch(crthip_batch *b) {
 						if(normal_fused(nvert, nface)) {
 							n.fused = 1;
 							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
-							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= NORMAL_FN_LDS_MAX ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
+							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= ctx->exp_normal_fn_max ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
 						} else {
 							n.vbase = est_vbase; n.fbase = est_fbase; est_vbase += nvert; est_fbase += nface;
 							pl.any_est_normal = true;
@@ -933,9 +935,9 @@ static int build_and_launch(crthip_batch *b) {
 	const uint32_t ntun = (uint32_t)pl.tun.v.size();
 	const uint32_t nfill = (uint32_t)pl.fill.v.size();
 	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
-		if(t1 > t0) {
-			LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables, (uint64_t *)nullptr, 0u); LT.end();
-			LT.begin("tunstall_decode", s); hipLaunchKernelGGL(k_tun_decode, dim3(c1 - c0), dim3(256), 0, s, D(pl.tun), D(pl.tun_chunk_stream), c1 - c0, tables, tun_partial, c0); LT.end();
+		if(t1 > t0) {                                        // every stream here is one chunk: dictionary + decode in one kernel, one wave per stream
+			(void)c0; (void)c1;
+			LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0); LT.end();
 		}
 		if(f1 > f0) { LT.begin("fill", s); hipLaunchKernelGGL(k_fill, dim3(f1 - f0), dim3(256), 0, s, D(pl.fill) + f0, f1 - f0); LT.end(); }
 	};

@@ -24,12 +24,14 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // K-TAB
-__global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__ streams, uint32_t nstreams,
-                                                    TunTable *__restrict__ tables, uint64_t *lookback_state, uint32_t lookback_words) {
-	const uint32_t s = blockIdx.x;
-	if(s >= nstreams) return;
-	const TunStream st = streams[s];
-	TunTable &T = tables[st.table];
+// The dictionary of one stream, by one wave.  Tg != null: written to the stream's TunTable in HBM (long streams: many workgroups
+// decode from it).  Otherwise it stays in LDS - word bytes in tun_words(), offsets / lengths in loff / llen - for the same wave to
+// decode from (k_tun_stream below).  Returns (used bytes, longest word).
+struct TunBuilt { uint32_t used, maxlen; };
+__shared__ __attribute__((aligned(16))) uint8_t g_tun_words[TUN_TABLE_BYTES];        // (one definition: both kernels below are single-wave workgroups)
+__device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTable *Tg, uint16_t *loff, uint8_t *llen) {
+	TunTable &T = *Tg;                           // (only touched when Tg != null)
+	uint8_t *buf = g_tun_words;
 	const uint32_t n = st.nsym;                 // 2..255 (host guarantees)
 	const uint32_t lane = threadIdx.x;
 
@@ -40,7 +42,6 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	__shared__ uint16_t P[256];                 // probability << 8  (16.16-ish fixed point)
 	__shared__ uint16_t pw[256];                // P0^k (successive (a*b)>>16), low-entropy seed only
 	__shared__ uint8_t sym[256];
-	__shared__ __attribute__((aligned(16))) uint8_t buf[TUN_TABLE_BYTES];
 
 	for(uint32_t i = lane; i < n; i += 64) { sym[i] = st.probs[2*i]; P[i] = (uint32_t)st.probs[2*i + 1] << 8; }
 	for(uint32_t i = lane; i < TUN_ENTRY_CAP; i += 64) { eprob[i] = 0; eoff[i] = 0; elen[i] = 0; }
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 		const uint32_t off = made ? wpos + incl - len : take ? (uint32_t)eoff[e] : 0u;
 		wpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		if(take) {
-			T.off[rank] = (uint16_t)off; T.len[rank] = (uint8_t)len;
+			if(Tg) { T.off[rank] = (uint16_t)off; T.len[rank] = (uint8_t)len; } else { loff[rank] = (uint16_t)off; llen[rank] = (uint8_t)len; }
 			used = off + len > used ? off + len : used;
 			maxlen = len > maxlen ? len : maxlen;
 		}
@@ -194,13 +195,25 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 		w += __popcll(mask);
 	}
 	used = wave_max_u32(used); maxlen = wave_max_u32(maxlen);
-	for(uint32_t c = w + lane; c < 256; c += 64) { T.off[c] = 0; T.len[c] = 0; }   // never on valid input
-	if(lane == 0) { T.used = used; T.maxlen = maxlen; }
+	for(uint32_t c = w + lane; c < 256; c += 64) { if(Tg) { T.off[c] = 0; T.len[c] = 0; } else { loff[c] = 0; llen[c] = 0; } }   // never on valid input
 	__syncthreads();
-	const uint32_t ndw = (used + 3) >> 2;
-	const uint32_t *src32 = (const uint32_t *)buf;
-	uint32_t *dst32 = (uint32_t *)T.bytes;
-	for(uint32_t i = lane; i < ndw; i += 64) dst32[i] = src32[i];
+	if(Tg) {
+		if(lane == 0) { T.used = used; T.maxlen = maxlen; }
+		const uint32_t ndw = (used + 3) >> 2;
+		const uint32_t *src32 = (const uint32_t *)buf;
+		uint32_t *dst32 = (uint32_t *)T.bytes;
+		for(uint32_t i = lane; i < ndw; i += 64) dst32[i] = src32[i];
+	}
+	return TunBuilt{used, maxlen};
+}
+
+__global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__ streams, uint32_t nstreams,
+                                                    TunTable *__restrict__ tables, uint64_t *lookback_state, uint32_t lookback_words) {
+	const uint32_t s = blockIdx.x;
+	if(s >= nstreams) return;
+	const TunStream st = streams[s];
+	const uint32_t lane = threadIdx.x;
+	tun_tables_body(st, &tables[st.table], nullptr, nullptr);
 	// a long stream's chunks find their output offsets by look-back (tun_lookback below): their state words start out empty
 	if(lookback_state && st.nchunks > 1) for(uint32_t i = lane; i < st.nchunks; i += 64) lookback_state[st.chunk0 + i] = 0;
 	if(lookback_state && s == 0 && lane == 0) lookback_state[lookback_words] = 0;        // the give-up counter behind them
@@ -326,6 +339,60 @@ __device__ __forceinline__ void tun_tile_prepare(TunTile &t, const TunStream &st
 		} else nb = 0;
 		t.nb[k] = nb;
 		oo += t.l[k];
+	}
+}
+
+// K-STREAM: dictionary AND decode of one short stream (the .crt case: a few hundred codewords, a few KiB of symbols) by ONE wave.
+// A batch of 256 blobs has 2 304 such streams; as two kernels (k_tun_tables, then k_tun_decode with 256 threads per stream) every
+// dictionary made a 9 KB round trip through HBM, the decode workgroups sat behind the slowest dictionary of the launch, and a
+// step had two more launches on each of its two chains.  Here the dictionary stays in the LDS of the wave that built it (the build is
+// ~45 us of dependent steps, the decode of a 2 112-symbol stream a few more), and the symbols are written straight to HBM: four
+// codewords per lane and step, lengths scanned across the wave, each lane's run emitted through the aligned byte FIFO.
+__global__ __launch_bounds__(64) void k_tun_stream(const TunStream *__restrict__ streams, uint32_t nstreams) {
+	const uint32_t s = blockIdx.x;
+	if(s >= nstreams) return;
+	const TunStream st = streams[s];
+	__shared__ uint16_t loff[256];
+	__shared__ uint8_t llen[256];
+	tun_tables_body(st, nullptr, loff, llen);
+	__syncthreads();
+	const uint32_t lane = threadIdx.x, csize = st.csize;
+	const uint64_t size = st.size;
+	CRT_GLOBAL const uint8_t *src = as_global(st.src);
+	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
+	CRT_LDS const uint8_t *len8 = as_lds(llen);
+	CRT_LDS const uint16_t *off16 = as_lds(loff);
+	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(g_tun_words);
+	uint64_t base = 0;
+	for(uint32_t tile = 0; tile < csize; tile += 256) {
+		const uint32_t j0 = tile + 4*lane;
+		uint32_t code[4], l[4], sum = 0;
+#pragma unroll
+		for(int k = 0; k < 4; k++) {
+			const bool ok = j0 + k < csize;
+			code[k] = ok ? (uint32_t)src[j0 + k] : 0u;
+			l[k] = ok ? (uint32_t)len8[code[k]] : 0u;
+			sum += l[k];
+		}
+		const uint32_t inc = wave_inclusive_scan_u32(sum);
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+		uint64_t oo = base + inc - sum;
+		const uint64_t o_run = oo;
+		uint32_t wo[4], nb[4];
+#pragma unroll
+		for(int k = 0; k < 4; k++) {                       // every word whole; the stream's last codeword emits what is left (tunstall.cpp:447-451)
+			uint32_t n_ = l[k];
+			wo[k] = off16[code[k]];
+			if(j0 + k < csize) {
+				if(j0 + k + 1 == csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
+				else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
+			} else n_ = 0;
+			nb[k] = n_;
+			oo += l[k];
+		}
+		CRT_GLOBAL uint8_t *d = gdst + o_run;
+		tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
+		base += total;
 	}
 }
 
