@@ -137,11 +137,34 @@ struct EncChunk { const uint8_t *src; uint32_t size, stream; };
 struct EncStream {
 	const uint8_t *src;            // size symbols
 	uint8_t *dst;                  // room for size + 64 codewords
-	const int16_t *trie;           // the reference's 2-symbol-step trie, levels of nsym*nsym entries: >= 0 codeword, < 0 minus the next level's number
+	int16_t *trie;                 // the reference's 2-symbol-step trie, levels of nsym*nsym entries: >= 0 codeword, < 0 minus the next level's number
+	                               // (made on the host, or by k_enc_trie in place: then ntrie is what that kernel wrote)
 	const uint8_t *remap;          // 256: symbol -> index
 	const uint16_t *lengths;       // 256: word length by codeword
 	uint32_t *csize;               // out: number of codewords
 	uint32_t size, nsym, ntrie, pad;
+};
+// one attribute to quantise (k_enc_quantize): include/corto/vertex_attribute.h:79-128, src/normal_attribute.cpp:61-111,
+// src/color_attribute.cpp:23-70
+struct QuantJob {
+	const void *in;                // GENERIC: count floats; NORMAL: count x 3 floats; COLOR: count x N bytes
+	void *out;                     // GENERIC: count int32; NORMAL: count x 2 int32 (octahedral); COLOR: count x N bytes (YCC)
+	uint32_t count, kind, N;       // kind: 0 GENERIC, 1 NORMAL, 2 COLOR
+	float q;                       // GENERIC: the step
+	int32_t unit;                  // NORMAL: (int)q
+	uint32_t qc[4];                // COLOR: per-channel divisors
+};
+// what k_enc_tables leaves per stream for the Tunstall coder: the block header (probabilities) and the encoder tables
+struct EncTab {
+	uint32_t nsym;                 // symbols that occur (0: empty stream, 1: no payload)
+	uint32_t level_bound;          // upper bound on the levels of the stream's trie: 1 + sum over words of (length - 1)/2
+	uint32_t used;                 // dictionary bytes
+	uint32_t pad;
+	uint8_t probs[512];            // nsym x (symbol, probability) in the reference's order (std::sort of src/tunstall.cpp:111-112)
+	uint8_t remap[256];            // symbol -> index in probs
+	uint16_t lengths[256];         // word lengths by codeword
+	uint16_t index[256];           // word starts in words[]
+	uint8_t words[TUN_TABLE_BYTES];
 };
 // one value array for the bit-width + bit-packing kernel (include/corto/cstream.h:115-164)
 struct PackJob {

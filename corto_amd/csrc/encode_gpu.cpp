@@ -37,7 +37,7 @@ struct Events {
 	hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	~Events() { for(auto &x : e) if(x) (void)hipEventDestroy(x); }
 };
-struct StageTimes { float hist = 0, parse = 0, pack = 0; bool any_hist = false, any_parse = false, any_pack = false; };
+struct StageTimes { float hist = 0, parse = 0, pack = 0, tables = 0, trie = 0; bool any_hist = false, any_parse = false, any_pack = false, any_tables = false; uint32_t host_table_streams = 0; };
 
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, (std::string(#expr ": ") + hipGetErrorString(e_)).c_str()); } while(0)
 
@@ -69,43 +69,73 @@ int tun_encode_device(hipStream_t st, uint32_t n, const uint8_t *const *d_src, c
 		ENC_TRY(hipEventRecord(ev.e[0], st));
 		hipLaunchKernelGGL(k_enc_hist, dim3((uint32_t)chunks.size()), dim3(256), 0, st, (const EncChunk *)(base + o_chunks), (uint32_t)chunks.size(), (uint32_t *)base);
 		ENC_TRY(hipEventRecord(ev.e[1], st));
-		ENC_TRY(hipMemcpyAsync(counts.data(), base, counts.size()*4, hipMemcpyDeviceToHost, st));
 	}
-	ENC_TRY(hipStreamSynchronize(st));
 
-	// host: probabilities, dictionary, trie of every stream
+	// device: probabilities (in std::sort's order), dictionary and - where it fits the LDS of one workgroup - the encoding trie of every
+	// stream (k_enc_tables, k_enc_trie).  The host only sizes the trie regions in between and frames the blocks at the end; a stream
+	// whose trie could outgrow ENC_TRIE_LDS_MAX entries (large alphabets) gets its tables from the host routine instead.
 	std::vector<TunEncoderTables> tabs(n);
-	std::vector<uint32_t> gpu_ids;
-	std::vector<uint64_t> tab_off(n, 0);
-	uint64_t tbytes = 0;
-	uint32_t trie_lds = 0;
-	{	// independent per stream: spread over a few host threads when there are many
-		const uint32_t nthreads = n >= 64 ? std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-		auto work = [&](uint32_t t) { for(uint32_t i = t; i < n; i += nthreads) if(sizes[i]) tun_encoder_tables(&counts[(size_t)i*256], sizes[i], tabs[i]); };
-		std::vector<std::thread> pool;
-		for(uint32_t t = 1; t < nthreads; t++) pool.emplace_back(work, t);
-		work(0);
-		for(auto &th : pool) th.join();
-	}
-	for(uint32_t i = 0; i < n; i++) {
-		if(sizes[i] == 0) continue;
-		if(tabs[i].nsym < 2) continue;                                // one symbol: no payload (tunstall.cpp:386-389)
-		gpu_ids.push_back(i);
-		tab_off[i] = tbytes;
-		tbytes += 256 + 512 + ((tabs[i].offsets.size()*2 + 15) & ~15ull);
-		if(tabs[i].offsets.size() <= ENC_TRIE_LDS_MAX) trie_lds = std::max<uint32_t>(trie_lds, (uint32_t)tabs[i].offsets.size());
-	}
 	std::vector<uint32_t> csize(n, 0);
 	std::vector<uint8_t> h_codes;
-	DevMem dtab;
-	if(!gpu_ids.empty()) {
-		const uint64_t o_streams = tbytes;
-		const uint64_t tab_total = tbytes + gpu_ids.size()*sizeof(EncStream) + 16;
+	DevMem dtabs, dtrie, dstreams;
+	constexpr size_t HEAD = 16 + 512;                                     // EncTab: four words + the probabilities
+	std::vector<uint8_t> heads((size_t)n*HEAD);
+	std::vector<uint32_t> dev_ids, host_ids;
+	float ms_tables = 0, ms_trie = 0;
+	if(n) {
+		DevMem dsizes;
+		ENC_TRY(hipMalloc(&dsizes.p, (size_t)n*4 + 16));
+		ENC_TRY(hipMalloc(&dtabs.p, (size_t)n*sizeof(EncTab) + 16));
+		ENC_TRY(hipMemcpyAsync(dsizes.p, sizes, (size_t)n*4, hipMemcpyHostToDevice, st));
+		ENC_TRY(hipEventRecord(ev.e[2], st));
+		hipLaunchKernelGGL(k_enc_tables, dim3(n), dim3(64), 0, st, (const uint32_t *)base, (const uint32_t *)dsizes.p, n, (EncTab *)dtabs.p);
+		ENC_TRY(hipEventRecord(ev.e[3], st));
+		ENC_TRY(hipMemcpy2DAsync(heads.data(), HEAD, dtabs.p, sizeof(EncTab), HEAD, n, hipMemcpyDeviceToHost, st));
+		ENC_TRY(hipStreamSynchronize(st));
+		ENC_TRY(hipGetLastError());
+		if(hipEventElapsedTime(&ms_tables, ev.e[2], ev.e[3]) != hipSuccess) ms_tables = 0;
+	}
+	std::vector<uint64_t> trie_off(n, 0);
+	uint64_t trie_bytes = 0;
+	for(uint32_t i = 0; i < n; i++) {
+		const uint32_t *hd = (const uint32_t *)(heads.data() + (size_t)i*HEAD);
+		tabs[i].nsym = sizes[i] ? hd[0] : 0u;
+		memcpy(tabs[i].probs, heads.data() + (size_t)i*HEAD + 16, 512);
+		if(tabs[i].nsym < 2) continue;                                    // one symbol: no payload (tunstall.cpp:386-389)
+		const uint64_t entries = (uint64_t)hd[1]*tabs[i].nsym*tabs[i].nsym;
+		if(entries <= ENC_TRIE_LDS_MAX) { dev_ids.push_back(i); trie_off[i] = trie_bytes; trie_bytes += (entries*2 + 15) & ~15ull; }
+		else host_ids.push_back(i);
+	}
+	std::vector<uint64_t> tab_off(n, 0);
+	uint64_t tbytes = 0;
+	if(!host_ids.empty()) {                                               // the few the device leaves to the host: from the histogram, as before
+		ENC_TRY(hipMemcpy(counts.data(), base, counts.size()*4, hipMemcpyDeviceToHost));
+		for(uint32_t i : host_ids) {
+			tun_encoder_tables(&counts[(size_t)i*256], sizes[i], tabs[i]);
+			tab_off[i] = tbytes;
+			tbytes += 256 + 512 + ((tabs[i].offsets.size()*2 + 15) & ~15ull);
+		}
+	}
+	const uint32_t ngpu = (uint32_t)(dev_ids.size() + host_ids.size());
+	uint32_t trie_lds = 0;
+	if(ngpu) {
+		const uint64_t o_streams = tbytes, o_ids = o_streams + (((uint64_t)ngpu*sizeof(EncStream) + 15) & ~15ull);
+		const uint64_t tab_total = o_ids + (uint64_t)dev_ids.size()*4 + 16;
 		std::vector<uint8_t> h_tab(tab_total);
-		ENC_TRY(hipMalloc(&dtab.p, tab_total));
-		uint8_t *tb = dtab.u8();
+		ENC_TRY(hipMalloc(&dstreams.p, tab_total));
+		ENC_TRY(hipMalloc(&dtrie.p, trie_bytes + 16));
+		uint8_t *tb = dstreams.u8();
+		EncTab *dt = (EncTab *)dtabs.p;
 		std::vector<EncStream> es;
-		for(uint32_t i : gpu_ids) {
+		for(uint32_t i : dev_ids) {                                       // device-made tables first: k_enc_trie indexes this array by position
+			EncStream s{};
+			s.src = d_src[i]; s.dst = base + dst_off[i];
+			s.remap = dt[i].remap; s.lengths = dt[i].lengths; s.trie = (int16_t *)(dtrie.u8() + trie_off[i]);
+			s.csize = (uint32_t *)(base + o_csize) + i;
+			s.size = sizes[i]; s.nsym = tabs[i].nsym; s.ntrie = 0;
+			es.push_back(s);
+		}
+		for(uint32_t i : host_ids) {
 			const TunEncoderTables &T = tabs[i];
 			uint8_t *h = h_tab.data() + tab_off[i];
 			memcpy(h, T.remap, 256);
@@ -118,26 +148,47 @@ int tun_encode_device(hipStream_t st, uint32_t n, const uint8_t *const *d_src, c
 			}
 			EncStream s{};
 			s.src = d_src[i]; s.dst = base + dst_off[i];
-			s.remap = tb + tab_off[i]; s.lengths = (const uint16_t *)(tb + tab_off[i] + 256); s.trie = (const int16_t *)(tb + tab_off[i] + 768);
+			s.remap = tb + tab_off[i]; s.lengths = (const uint16_t *)(tb + tab_off[i] + 256); s.trie = (int16_t *)(tb + tab_off[i] + 768);
 			s.csize = (uint32_t *)(base + o_csize) + i;
 			s.size = sizes[i]; s.nsym = T.nsym; s.ntrie = (uint32_t)T.offsets.size();
+			if(T.offsets.size() <= ENC_TRIE_LDS_MAX) trie_lds = std::max<uint32_t>(trie_lds, (uint32_t)T.offsets.size());
 			es.push_back(s);
 		}
 		memcpy(h_tab.data() + o_streams, es.data(), es.size()*sizeof(EncStream));
-		ENC_TRY(hipMemcpyAsync(dtab.p, h_tab.data(), tab_total, hipMemcpyHostToDevice, st));
+		if(!dev_ids.empty()) memcpy(h_tab.data() + o_ids, dev_ids.data(), dev_ids.size()*4);
+		ENC_TRY(hipMemcpyAsync(dstreams.p, h_tab.data(), tab_total, hipMemcpyHostToDevice, st));
+		if(!dev_ids.empty()) {
+			const uint32_t nd = (uint32_t)dev_ids.size();
+			ENC_TRY(hipEventRecord(ev.e[4], st));
+			hipLaunchKernelGGL(k_enc_trie, dim3(nd), dim3(64), ENC_TRIE_LDS_MAX*2, st, (const EncTab *)dtabs.p, (const uint32_t *)(tb + o_ids), (EncStream *)(tb + o_streams), nd, ENC_TRIE_LDS_MAX);
+			ENC_TRY(hipEventRecord(ev.e[5], st));
+			ENC_TRY(hipMemcpyAsync(es.data(), tb + o_streams, (size_t)nd*sizeof(EncStream), hipMemcpyDeviceToHost, st));
+			ENC_TRY(hipStreamSynchronize(st));
+			ENC_TRY(hipGetLastError());
+			if(hipEventElapsedTime(&ms_trie, ev.e[4], ev.e[5]) != hipSuccess) ms_trie = 0;
+			for(uint32_t k = 0; k < nd; k++) {
+				if(es[k].ntrie == 0xFFFFFFFFu || es[k].ntrie == 0) return ctx_fail(CRTHIP_E_DEVICE, "k_enc_trie: a trie outgrew the bound the dictionary gives");
+				trie_lds = std::max(trie_lds, es[k].ntrie);
+			}
+		}
 		const uint32_t lds = enc_parse_lds(trie_lds);
-		ENC_TRY(hipEventRecord(ev.e[2], st));
-		hipLaunchKernelGGL(k_enc_tun_parse, dim3((uint32_t)es.size()), dim3(64), lds, st, (const EncStream *)(tb + o_streams), (uint32_t)es.size(), trie_lds);
-		ENC_TRY(hipEventRecord(ev.e[3], st));
+		hipEvent_t p0 = nullptr, p1 = nullptr;
+		ENC_TRY(hipEventCreate(&p0)); ENC_TRY(hipEventCreate(&p1));
+		ENC_TRY(hipEventRecord(p0, st));
+		hipLaunchKernelGGL(k_enc_tun_parse, dim3(ngpu), dim3(64), lds, st, (const EncStream *)(tb + o_streams), ngpu, trie_lds);
+		ENC_TRY(hipEventRecord(p1, st));
 		ENC_TRY(hipMemcpyAsync(csize.data(), base + o_csize, (size_t)n*4, hipMemcpyDeviceToHost, st));
 		h_codes.resize(o_csize - dst_off[0]);
 		ENC_TRY(hipMemcpyAsync(h_codes.data(), base + dst_off[0], h_codes.size(), hipMemcpyDeviceToHost, st));
 		ENC_TRY(hipStreamSynchronize(st));
 		ENC_TRY(hipGetLastError());
+		float pm = 0;
+		if(hipEventElapsedTime(&pm, p0, p1) == hipSuccess) { tm.parse += pm; tm.any_parse = true; }
+		(void)hipEventDestroy(p0); (void)hipEventDestroy(p1);
 	}
+	if(n) { tm.tables += ms_tables; tm.trie += ms_trie; tm.any_tables = true; tm.host_table_streams += (uint32_t)host_ids.size(); }
 	float ms = 0;
 	if(!chunks.empty() && hipEventElapsedTime(&ms, ev.e[0], ev.e[1]) == hipSuccess) { tm.hist += ms; tm.any_hist = true; }
-	if(!gpu_ids.empty() && hipEventElapsedTime(&ms, ev.e[2], ev.e[3]) == hipSuccess) { tm.parse += ms; tm.any_parse = true; }
 
 	// block framing (src/cstream.cpp:96-107)
 	for(uint32_t i = 0; i < n; i++) {
@@ -160,6 +211,8 @@ void report(crthip_kernel_times *times, const StageTimes &tm) {
 	uint32_t k = 0;
 	if(tm.any_pack) { times->name[k] = "enc_pack"; times->ms[k] = tm.pack; times->launches[k] = 1; k++; }
 	if(tm.any_hist) { times->name[k] = "enc_hist"; times->ms[k] = tm.hist; times->launches[k] = 1; k++; }
+	if(tm.any_tables) { times->name[k] = "enc_tables"; times->ms[k] = tm.tables; times->launches[k] = 1; k++;
+	                    times->name[k] = "enc_trie"; times->ms[k] = tm.trie; times->launches[k] = tm.host_table_streams; k++; }   // (launches of enc_trie: streams whose tables the HOST made instead)
 	if(tm.any_parse) { times->name[k] = "enc_tun_parse"; times->ms[k] = tm.parse; times->launches[k] = 1; k++; }
 	times->count = k;
 }
@@ -198,6 +251,40 @@ extern "C" int64_t crthip_tunstall_encode_blocks(crthip_ctx *ctx, uint32_t n, co
 	block_offset[n] = w;
 	if(out && w > cap) return ctx_fail(CRTHIP_E_ARGUMENT, "crthip_tunstall_encode_blocks: output buffer too small");
 	return (int64_t)w;
+}
+
+// the quantisation step of every attribute of one mesh on the device: one upload, one kernel per attribute, one download
+int corto_hip::quantize_device(crthip_ctx *ctx, const std::vector<QuantRequest> &reqs) {
+	if(!ctx) return ctx_fail(CRTHIP_E_ARGUMENT, "quantize_device: null context");
+	ENC_TRY(hipSetDevice(ctx_device(ctx)));
+	{ const int e = ctx_quiesce(ctx); if(e) return e; }
+	hipStream_t st = ctx_stream(ctx);
+	auto in_bytes = [](const QuantRequest &r) -> uint64_t { return r.kind == 0 ? (uint64_t)r.count*4 : r.kind == 1 ? (uint64_t)r.count*12 : (uint64_t)r.count*r.N; };
+	auto out_bytes = [](const QuantRequest &r) -> uint64_t { return r.kind == 0 ? (uint64_t)r.count*4 : r.kind == 1 ? (uint64_t)r.count*8 : (uint64_t)r.count*r.N; };
+	std::vector<uint64_t> ioff(reqs.size()), ooff(reqs.size());
+	uint64_t o = 0;
+	for(size_t k = 0; k < reqs.size(); k++) { ioff[k] = o; o += (in_bytes(reqs[k]) + 15) & ~15ull; }
+	const uint64_t in_total = o;
+	for(size_t k = 0; k < reqs.size(); k++) { ooff[k] = o; o += (out_bytes(reqs[k]) + 15) & ~15ull; }
+	if(o == 0) return CRTHIP_OK;
+	DevMem dev;
+	ENC_TRY(hipMalloc(&dev.p, o + 16));
+	std::vector<uint8_t> h(o);
+	for(size_t k = 0; k < reqs.size(); k++) if(in_bytes(reqs[k])) memcpy(h.data() + ioff[k], reqs[k].in, in_bytes(reqs[k]));
+	ENC_TRY(hipMemcpyAsync(dev.p, h.data(), in_total, hipMemcpyHostToDevice, st));
+	for(size_t k = 0; k < reqs.size(); k++) {
+		const QuantRequest &r = reqs[k];
+		if(!r.count) continue;
+		QuantJob J{};
+		J.in = dev.u8() + ioff[k]; J.out = dev.u8() + ooff[k]; J.count = r.count; J.kind = r.kind; J.N = r.N; J.q = r.q; J.unit = r.unit;
+		for(int c = 0; c < 4; c++) J.qc[c] = r.qc[c] ? r.qc[c] : 1u;
+		hipLaunchKernelGGL(k_enc_quantize, dim3((r.count + 255)/256), dim3(256), 0, st, J);
+	}
+	ENC_TRY(hipMemcpyAsync(h.data() + in_total, dev.u8() + in_total, o - in_total, hipMemcpyDeviceToHost, st));
+	ENC_TRY(hipStreamSynchronize(st));
+	ENC_TRY(hipGetLastError());
+	for(size_t k = 0; k < reqs.size(); k++) if(out_bytes(reqs[k])) memcpy(reqs[k].out, h.data() + ooff[k], out_bytes(reqs[k]));
+	return CRTHIP_OK;
 }
 
 // bit-width logs + bit packing of n value arrays on the device, then the Tunstall coder over the logs (or raw logs for entropy NONE)

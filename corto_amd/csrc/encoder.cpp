@@ -648,6 +648,7 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 	}
 	if(E.nface) E.faces.assign(m->index, m->index + (size_t)E.nface*3);
 	const uint32_t nv = m->nvert;
+	std::vector<corto_hip::QuantRequest> quant;                     // (device path) the attributes' quantisation, collected and run in one call
 	{	// positions (src/encoder.cpp:49-100, vertex_attribute.h:79-128)
 		float q = m->position_q;
 		if(m->position_bits > 0) {
@@ -674,7 +675,8 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 		a.name = "position"; a.N = 3; a.q = q; a.format = CRTHIP_FMT_FLOAT;
 		a.strategy = CRTHIP_CORRELATED | (E.nface > 0 ? CRTHIP_PARALLEL : 0);
 		a.values.resize((size_t)nv*3);
-		for(size_t i = 0; i < (size_t)nv*3; i++) a.values[i] = f2i((m->position[i] - 0.0f)/q);
+		if(gpu) { corto_hip::QuantRequest r; r.kind = 0; r.count = nv*3; r.in = m->position; r.out = a.values.data(); r.q = q; quant.push_back(r); }
+		else for(size_t i = 0; i < (size_t)nv*3; i++) a.values[i] = f2i((m->position[i] - 0.0f)/q);
 	}
 	if(m->normal) {
 		Attr &a = E.data["normal"];
@@ -682,7 +684,8 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 		a.format = CRTHIP_FMT_FLOAT; a.strategy = CRTHIP_CORRELATED; a.prediction = m->normal_prediction;
 		a.values.resize((size_t)nv*2);
 		const int unit = f2i(a.q);
-		for(uint32_t i = 0; i < nv; i++) to_octa(m->normal + (size_t)i*3, unit, &a.values[(size_t)i*2]);
+		if(gpu) { corto_hip::QuantRequest r; r.kind = 1; r.count = nv; r.in = m->normal; r.out = a.values.data(); r.unit = unit; quant.push_back(r); }
+		else for(uint32_t i = 0; i < nv; i++) to_octa(m->normal + (size_t)i*3, unit, &a.values[(size_t)i*2]);
 	}
 	if(m->color) {
 		Attr &a = E.data["color"];
@@ -690,7 +693,8 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 		for(int k = 0; k < 3; k++) a.qc[k] = 1 << (8 - m->color_bits[k]);
 		a.qc[3] = m->color_components == 3 ? 1 : 1 << (8 - m->color_bits[3]);           // addColors3: setQ(r, g, b, 8)
 		a.cvalues.resize((size_t)nv*a.N);
-		for(uint32_t i = 0; i < nv; i++) {                                              // color_attribute.cpp:30-44, point.h:213
+		if(gpu) { corto_hip::QuantRequest r; r.kind = 2; r.count = nv; r.N = (uint32_t)a.N; r.in = m->color; r.out = a.cvalues.data(); for(int k = 0; k < 4; k++) r.qc[k] = (uint32_t)a.qc[k]; quant.push_back(r); }
+		else for(uint32_t i = 0; i < nv; i++) {                                         // color_attribute.cpp:30-44, point.h:213
 			uint8_t y[4] = {0, 0, 0, 0};
 			for(int k = 0; k < a.N; k++) y[k] = (uint8_t)(m->color[(size_t)i*a.N + k]/a.qc[k]);
 			const uint8_t ycc[4] = {y[1], (uint8_t)(y[2] - y[1]), (uint8_t)(y[0] - y[1]), y[3]};
@@ -701,10 +705,12 @@ static int64_t encode_impl(const crthip_mesh *m, uint8_t *out, size_t cap, uint3
 		Attr &a = E.data[name];
 		a.name = name; a.N = N; a.q = q; a.format = CRTHIP_FMT_FLOAT; a.strategy = 0;
 		a.values.resize((size_t)nv*N);
-		for(size_t i = 0; i < (size_t)nv*N; i++) a.values[i] = f2i(buf[i]/q);
+		if(gpu) { corto_hip::QuantRequest r; r.kind = 0; r.count = nv*(uint32_t)N; r.in = buf; r.out = a.values.data(); r.q = q; quant.push_back(r); }
+		else for(size_t i = 0; i < (size_t)nv*N; i++) a.values[i] = f2i(buf[i]/q);
 	};
 	if(m->uv) generic("uv", m->uv, 2, m->uv_q);
 	if(m->radius) generic("radius", m->radius, 1, m->radius_q);
+	if(gpu) { const int qerr = corto_hip::quantize_device(gpu, quant); if(qerr) return qerr; }   // every attribute's quantisation in one device call (k_enc_quantize)
 	E.header();
 	if(E.nface > 0) E.encode_mesh(); else E.encode_cloud();
 	if(out_nvert) *out_nvert = E.nvert;

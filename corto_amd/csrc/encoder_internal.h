@@ -30,6 +30,10 @@ struct EncValueResult {
 int encode_value_streams(crthip_ctx *ctx, uint32_t entropy, const std::vector<EncValueStream> &in, std::vector<EncValueResult> &res,
                          crthip_kernel_times *times);
 
+// quantisation on the device (encode_gpu.cpp: k_enc_quantize): HOST arrays in, HOST arrays out, one upload / download for all of them
+struct QuantRequest { uint32_t kind = 0, count = 0, N = 1; const void *in = nullptr; void *out = nullptr; float q = 0; int32_t unit = 0; uint32_t qc[4] = {1, 1, 1, 1}; };
+int quantize_device(crthip_ctx *ctx, const std::vector<QuantRequest> &reqs);
+
 // context plumbing (batch.cpp)
 int ctx_fail(int code, const char *msg);
 int ctx_device(crthip_ctx *ctx);

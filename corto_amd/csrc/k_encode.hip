@@ -13,8 +13,11 @@
 // Source bytes are staged through LDS already remapped to symbol indices; the trie sits in LDS when it fits.
 #include "kernels_common.h"
 #include "kernels.h"
+#include "std_sort_model.h"
 
 namespace corto_hip {
+
+#include "tun_tables.h"
 
 __global__ __launch_bounds__(256) void k_enc_hist(const EncChunk *__restrict__ chunks, uint32_t nchunks, uint32_t *__restrict__ counts) {
 	if(blockIdx.x >= nchunks) return;
@@ -118,6 +121,143 @@ __global__ __launch_bounds__(256) void k_enc_pack(const PackJob *__restrict__ jo
 		if(carry_bits) words[gw++] = buf[0];
 		*J.nwords = gw;
 	}
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Quantisation, elementwise.  The float recipes are upstream's, operation by operation (no FMA: the library is built with
+// -ffp-contract=off; IEEE divide): GENERIC (int)(x/q) (vertex_attribute.h:97-99); NORMAL toOcta (normal_attribute.h:75-85):
+// s = (|x| + |y|) + |z|, p = (x/s, y/s), folded when z < 0, (int)(p*unit); COLOR byte/qc then (g, b - g, r - g, a) (color_attribute.cpp:30-44,
+// point.h:213).  (int) is x86's cvttss2si: INT_MIN when out of range.
+__global__ __launch_bounds__(256) void k_enc_quantize(QuantJob J) {
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if(i >= J.count) return;
+	if(J.kind == 0) {
+		const float x = ((const float *)J.in)[i] - 0.0f;
+		((int32_t *)J.out)[i] = f2i_x86(x/J.q);
+	} else if(J.kind == 1) {
+		const float *v = (const float *)J.in + (size_t)i*3;
+		const float vx = v[0], vy = v[1], vz = v[2];
+		float s = fabsf(vx) + fabsf(vy); s = s + fabsf(vz);
+		float px = vx/s, py = vy/s;
+		if(vz < 0) {
+			const float qx = 1.0f - fabsf(py), qy = 1.0f - fabsf(px);
+			px = qx; py = qy;
+			if(vx < 0) px = -px;
+			if(vy < 0) py = -py;
+		}
+		int32_t *o = (int32_t *)J.out + (size_t)i*2;
+		o[0] = f2i_x86(px*(float)J.unit); o[1] = f2i_x86(py*(float)J.unit);
+	} else {
+		const uint8_t *c = (const uint8_t *)J.in + (size_t)i*J.N;
+		uint8_t y[4] = {0, 0, 0, 0};
+		for(uint32_t k = 0; k < J.N && k < 4; k++) y[k] = (uint8_t)(c[k]/J.qc[k]);
+		const uint8_t ycc[4] = {y[1], (uint8_t)(y[2] - y[1]), (uint8_t)(y[0] - y[1]), y[3]};
+		uint8_t *o = (uint8_t *)J.out + (size_t)i*J.N;
+		for(uint32_t k = 0; k < J.N && k < 4; k++) o[k] = ycc[k];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Encoder tables of one stream, by one wave: what getProbabilities + createDecodingTables2 leave (src/tunstall.cpp:83-115, 125-256).
+//   probabilities  count*255/size of every symbol that occurs, in symbol order, then ordered by std::sort with a comparator on the
+//                  probability alone - lane 0 runs std_sort_model.h, the restatement of libstdc++'s introsort, because the order
+//                  std::sort leaves EQUAL probabilities in decides the dictionary;
+//   dictionary     tun_tables.h, the builder the decoder uses (the encoder's dictionary IS the decoder's);
+//   level_bound    a word of length L opens at most (L - 1)/2 levels of the 2-symbol-step trie: the host sizes the trie region.
+__global__ __launch_bounds__(64) void k_enc_tables(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ sizes, uint32_t nstreams,
+                                                    EncTab *__restrict__ tabs) {
+	const uint32_t s = blockIdx.x, lane = threadIdx.x;
+	if(s >= nstreams) return;
+	EncTab &E = tabs[s];
+	const uint32_t size = sizes[s];
+	__shared__ uint16_t pr[256];                           // symbol | probability << 8
+	__shared__ uint8_t pb[512];
+	__shared__ uint16_t loff[256];
+	__shared__ uint8_t llen[256];
+	uint32_t n = 0;
+	for(uint32_t r = 0; r < 4; r++) {                      // symbols that occur, in symbol order
+		const uint32_t sym = r*64 + lane, c = size ? counts[(size_t)s*256 + sym] : 0u;
+		const uint64_t m = __ballot(c > 0);
+		if(c > 0) pr[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(sym | ((c*255u/size) & 255u) << 8);
+		n += (uint32_t)__popcll(m);
+	}
+	__syncthreads();
+	if(lane == 0) std_sort_model((uint16_t *)pr, (int)n, [](uint16_t a, uint16_t b) -> bool { return (a >> 8) > (b >> 8); });
+	__syncthreads();
+	for(uint32_t i = lane; i < 256; i += 64) { E.remap[i] = 0; if(i >= n) { E.probs[2*i] = 0; E.probs[2*i + 1] = 0; } }
+	__syncthreads();
+	for(uint32_t i = lane; i < n; i += 64) {
+		const uint32_t v = pr[i];
+		pb[2*i] = (uint8_t)v; pb[2*i + 1] = (uint8_t)(v >> 8);
+		E.probs[2*i] = (uint8_t)v; E.probs[2*i + 1] = (uint8_t)(v >> 8);
+		E.remap[v & 255u] = (uint8_t)i;
+	}
+	if(lane == 0) { E.nsym = n; E.level_bound = 0; E.used = 0; E.pad = 0; }
+	__syncthreads();
+	if(n < 2) return;                                      // one symbol: no dictionary, no payload (tunstall.cpp:386-389)
+	TunStream st{};
+	st.nsym = n;
+	const TunBuilt B = tun_tables_body(st, nullptr, loff, llen, pb);
+	__syncthreads();
+	uint32_t bound = 0;
+	for(uint32_t c = lane; c < 256; c += 64) {
+		const uint32_t l = llen[c];
+		E.lengths[c] = (uint16_t)l; E.index[c] = loff[c];
+		bound += l > 2 ? (l - 1)/2 : 0u;
+	}
+	bound = wave_inclusive_scan_u32(bound);
+	for(uint32_t i = lane; i < (B.used + 3)/4; i += 64) ((uint32_t *)E.words)[i] = ((const uint32_t *)g_tun_words)[i];
+	if(lane == 63) { E.level_bound = 1 + bound; E.used = B.used; }
+}
+
+// createEncodingTables (src/tunstall.cpp:335-382) for the streams ids[]: the 2-symbol-step trie, grown in LDS by one wave.  The
+// walk over the 256 words is the reference's, word by word, level by level (a later word overwrites what an earlier one left: the
+// order is the result); what the wave adds is width - a new level's nsym^2 entries, and the range of entries a word's tail covers,
+// are written by all lanes.  Entries: >= 0 a codeword, < 0 minus a level number; "no word yet" is 255, which is what the host's
+// conversion of the reference's 0xffffff gives (it keeps the low byte), and behaves the same in the walk (any value >= 0 is copied).
+__global__ __launch_bounds__(64) void k_enc_trie(const EncTab *__restrict__ tabs, const uint32_t *__restrict__ ids, EncStream *__restrict__ streams,
+                                                  uint32_t nids, uint32_t trie_cap) {
+	const uint32_t j = blockIdx.x, lane = threadIdx.x;
+	if(j >= nids) return;
+	const EncTab &E = tabs[ids[j]];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_[];
+	CRT_LDS int16_t *t = (CRT_LDS int16_t *)as_lds(lds_);
+	__shared__ uint8_t remap[256];
+	__shared__ uint16_t index[256], lengths[256];
+	__shared__ __attribute__((aligned(16))) uint8_t words[TUN_TABLE_BYTES];
+	const uint32_t n = E.nsym, span = n*n;
+	for(uint32_t i = lane; i < 256; i += 64) { remap[i] = E.remap[i]; index[i] = E.index[i]; lengths[i] = E.lengths[i]; }
+	for(uint32_t i = lane; i < (E.used + 3)/4; i += 64) ((uint32_t *)words)[i] = ((const uint32_t *)E.words)[i];
+	for(uint32_t k = lane; k < span && k < trie_cap; k += 64) t[k] = 255;
+	__syncthreads();
+	uint32_t size = span;
+	bool overflow = span > trie_cap;
+	for(uint32_t i = 0; i < 256 && !overflow; i++) {
+		const uint32_t wl = lengths[i], w0 = index[i];
+		uint32_t off = 0, toff = 0;
+		for(;;) {
+			const uint32_t rem = wl - off;
+			uint32_t low = remap[words[w0 + off]], high;
+			if(rem >= 2) { low = low*n + remap[words[w0 + off + 1]]; high = low + 1; }
+			else { low *= n; high = low + n; }                    // a one-symbol tail covers every second symbol (wordCode, tunstall.h:117-132)
+			if(rem <= 2) { for(uint32_t k = low + lane; k < high; k += 64) t[toff + k] = (int16_t)i; break; }
+			const int32_t wv = t[toff + low];
+			if(wv >= 0) {                                         // a complete word (or nothing) sits here: open a level that starts out as it
+				if(size + span > trie_cap) { overflow = true; break; }
+				if(lane == 0) t[toff + low] = (int16_t)-(int32_t)(size/span);
+				for(uint32_t k = lane; k < span; k += 64) t[size + k] = (int16_t)wv;
+				size += span;
+			}
+			__syncthreads();
+			toff = (uint32_t)(-(int32_t)t[toff + low])*span;
+			off += 2;
+		}
+		__syncthreads();
+	}
+	__syncthreads();
+	EncStream &S = streams[j];
+	if(!overflow) for(uint32_t k = lane; k < size; k += 64) S.trie[k] = t[k];
+	if(lane == 0) S.ntrie = overflow ? 0xFFFFFFFFu : size;
 }
 
 // LDS: remap u8[256] | lengths u16[256] | staged symbol indices u8[ENC_STAGE + ENC_STAGE_PAD] | trie i16[ntrie] (when it fits)

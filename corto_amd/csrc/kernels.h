@@ -96,6 +96,12 @@ constexpr uint32_t NORMAL_FN_LDS_MAX = 100*1024;
 __global__ void k_enc_hist(const EncChunk *chunks, uint32_t nchunks, uint32_t *counts);
 __global__ void k_enc_pack(const PackJob *jobs, uint32_t njobs);
 __global__ void k_enc_tun_parse(const EncStream *streams, uint32_t nstreams, uint32_t trie_lds_entries);
+// probabilities in std::sort's order + the 256-word dictionary of every stream (one wave each), then the encoding trie of the
+// streams listed in ids[] (built in LDS, at most trie_cap entries, written to streams[j].trie; streams[j].ntrie = its size,
+// ~0u if it did not fit)
+__global__ void k_enc_quantize(QuantJob job);           // float / byte attribute -> quantised integers, elementwise
+__global__ void k_enc_tables(const uint32_t *counts, const uint32_t *sizes, uint32_t nstreams, EncTab *tabs);
+__global__ void k_enc_trie(const EncTab *tabs, const uint32_t *ids, EncStream *streams, uint32_t nids, uint32_t trie_cap);
 inline uint32_t enc_parse_lds(uint32_t trie_entries) { return 768 + ENC_STAGE + ENC_STAGE_PAD + 2*((trie_entries + 7) & ~7u); }
 constexpr uint32_t ENC_TRIE_LDS_MAX = 24*1024;         // entries (48 KiB) of trie kept in LDS at most; bigger tries are walked in L2
 

@@ -65,3 +65,13 @@ def test_window_parse_model_round_trips_through_the_oracle(model):
         assert np.array_equal(dec, s)
         o += 9 + 2 * ns + csize
     assert o == len(out)
+
+
+def test_std_sort_model_matches_libstdcxx(tmp_path):
+    """csrc/std_sort_model.h (what k_enc_tables runs on the device to order equal probabilities) against std::sort itself:
+    80 000 tie-heavy arrays, incl. the heapsort branch (tests/cpp/sort_model_test.cpp)"""
+    import subprocess
+    exe = str(tmp_path / "sort_model_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "sort_model_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr

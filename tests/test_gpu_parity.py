@@ -587,6 +587,35 @@ def test_tunstall_encode_blocks_round_trip_and_reference(ctx):
             assert blocks[i].tobytes() == rc.tunstall_compress_block(streams[i]).tobytes(), i
 
 
+def test_tunstall_encoder_tables_made_on_the_device(ctx):
+    """probabilities, dictionary and trie of every stream come from k_enc_tables / k_enc_trie.  The streams here are
+    made of symbols with EQUAL counts (17 .. 40 of them, more than std::sort's insertion-sort threshold), so the block depends on
+    the order libstdc++'s introsort leaves equal probabilities in (csrc/std_sort_model.h): every block against the reference's."""
+    from oracle import refcodec as rc
+    rng = np.random.default_rng(77)
+    streams = []
+    for k in range(120):
+        nsym = 2 + k % 39
+        reps = [int(rng.integers(1, 4)) * (3 if j % 5 == 0 else 1) for j in range(nsym)] if k % 2 else [7] * nsym
+        sym = np.repeat((np.arange(nsym) * 11 % 251).astype(np.uint8), np.array(reps) * 9)
+        streams.append(rng.permutation(sym))
+    blocks, times = ca.tunstall_encode_blocks(ctx, streams, with_times=True)
+    assert "enc_tables" in times and "enc_trie" in times
+    assert times["enc_trie"]["launches"] == 0, "every one of these tries fits the device builder"      # (= streams the host had to make tables for)
+    outs, _ = _run_blocks(ctx, blocks, [len(s) for s in streams])
+    for i, (o, s) in enumerate(zip(outs, streams)):
+        assert np.array_equal(o, s), i
+    if rc.available():
+        for i, s in enumerate(streams):
+            assert blocks[i].tobytes() == rc.tunstall_compress_block(s).tobytes(), i
+    # a 200-symbol alphabet: its trie is left to the host routine, same bytes
+    big = rng.integers(0, 200, 30000).astype(np.uint8)
+    b2, t2 = ca.tunstall_encode_blocks(ctx, [big, streams[3]], with_times=True)
+    assert t2["enc_trie"]["launches"] == 1
+    if rc.available():
+        assert b2[0].tobytes() == rc.tunstall_compress_block(big).tobytes() and b2[1].tobytes() == blocks[3].tobytes()
+
+
 def _model_bits(fields):
     """MSB-first bit writer (src/bitstream.cpp:86-101): fields = iterable of (value, nbits) -> uint32 words"""
     acc, nb, words = 0, 0, []
