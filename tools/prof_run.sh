@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash tools/prof_run.sh <tag>
 # writes rocprofv3 summaries under gpurun_out/prof_<tag>; the ones to be judged are copied into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
