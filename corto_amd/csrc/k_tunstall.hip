@@ -366,6 +366,13 @@ __device__ __forceinline__ uint64_t tun_lookback(uint64_t *state, uint32_t c, ui
 	return prefix;
 }
 
+// the decoded bytes leave through non-temporal stores: six bytes are written for every byte read, and as ordinary stores they
+// pushed the chunk's codewords out of the XCD's L2 between the look-back's adding-up pass and the decode pass
+#ifndef TUN_FLUSH_PLAIN
+#define TUN_FLUSH_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define TUN_FLUSH_STORE(v, p) (*(p) = (v))
+#endif
 template <int W, int CPL> constexpr uint32_t tun_win_bytes() { return W == 1 ? 2048 + 64 : W == 2 ? 4096 + 64 : 6*1024 - 64; }
 constexpr uint32_t tun_staged_lds(uint32_t win) { return 4*(win + 64); }                // dynamic LDS: the four waves' windows
 
@@ -531,7 +538,7 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 					if(lane == 0) win[0] = u32x4_t{0, 0, 0, 0};
 					i0 = 1;
 				}
-				for(uint32_t i = i0 + lane; i < nvec; i += 64) { gv[i] = win[i]; win[i] = u32x4_t{0, 0, 0, 0}; }
+				for(uint32_t i = i0 + lane; i < nvec; i += 64) { TUN_FLUSH_STORE(win[i], &gv[i]); win[i] = u32x4_t{0, 0, 0, 0}; }
 				if(nvec) {
 					foreign = 0;
 					if((end & 15u) && lane == 0) { const u32x4_t t = win[nvec]; win[nvec] = u32x4_t{0, 0, 0, 0}; win[0] = t; }   // carry the tail
