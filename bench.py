@@ -259,7 +259,9 @@ def other_configs(ctx, ca):
                 out[key]["cpu_reference_ms"] = round(float(min(ns)) * 1e-6, 3)
         except Exception:
             pass
-    out["note"] = "one object per decode: no blob-level parallelism; the 128K-vertex mesh is ONE serial CLERS chain on one lane and loses to a CPU core (DESIGN.md 3.1)"
+    out["note"] = ("one object per decode: no blob-level parallelism.  The 128K-vertex mesh is ONE serial CLERS chain, whose (VERTEX LEFT) runs the whole wave "
+                   "does 63 pairs at a time (DESIGN.md 3.1); below a few tens of thousands of triangles a single mesh is faster on a CPU core "
+                   "(see facade_per_blob: one 4K-triangle blob) - the batch API is the GPU's case")
     return out
 
 
@@ -280,7 +282,7 @@ def encoder_stage(ctx, ca):
     out = {"workload": "2304 streams x 2112 symbols (bit-width logs of one C4 batch)", "symbols": nbytes, "compressed_bytes": int(sum(len(b) for b in blocks)),
            "call_ms": round(best * 1e3, 3), "msymbols_per_s": round(nbytes / best / 1e6, 1),
            "kernel_ms": {k: round(v["ms"], 4) for k, v in times.items()},
-           "note": "call = upload + device histogram + host dictionaries/tries (2304 x std::sort + 256-word build) + device parse + download + framing; blocks byte-identical to the reference's"}
+           "note": "call = upload + device histogram, probabilities (std::sort's order), dictionaries, tries and parse + download + framing; enc_trie.launches = streams whose tables the host had to make; blocks byte-identical to the reference's"}
     # whole blobs: crthip_encode (host) vs crthip_encode_gpu (value coding + entropy coder on the device), same bytes
     from corto_amd import synth
     out["blob_encode"] = {}
@@ -291,7 +293,7 @@ def encoder_stage(ctx, ca):
         t0 = time.perf_counter(); b = ca.encode(mesh, ctx=ctx, **kw); t_gpu = time.perf_counter() - t0
         out["blob_encode"][key] = {"host_ms": round(t_host * 1e3, 3), "gpu_stages_ms": round(t_gpu * 1e3, 3), "identical": bool(a.tobytes() == b.tobytes()),
                                    "crt_bytes": int(len(a))}
-    out["blob_encode"]["note"] = "topology (CLERS), quantisation and prediction stay on the host in both: one object at a time the device stages do not pay for their transfers and syncs - they are for batches of streams (above)"
+    out["blob_encode"]["note"] = "the CLERS encode and the prediction deltas stay on the host in both: one object at a time the device stages (quantisation, value coding, entropy coder) do not pay for their transfers and syncs - they are for batches of streams (above)"
     try:
         from oracle import refcodec as rc
         if rc.available():
