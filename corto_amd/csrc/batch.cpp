@@ -214,6 +214,7 @@ struct crthip_ctx {
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
 	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: chunk sums + scan + decode instead of the single pass with look-back (A/B measurements)
 	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
+	uint8_t exp_delta_walk = 0;                       // experiments: $CORTO_EXP_DELTA_WALK=1 - K-DELTA without the scan passes
 	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
 	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
@@ -323,6 +324,7 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	{ const char *e = getenv("CORTO_TUN_SIDE_STREAMS"); c->tun_side = e && e[0] == '1'; }
 	if(c->tun_side && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE); }   // (a stream is a hardware queue: not made unless asked for)
 	{ const char *e = getenv("CORTO_EXP_NORMAL_FN_MAX"); if(e) c->exp_normal_fn_max = (uint32_t)atoi(e); }
+	{ const char *e = getenv("CORTO_EXP_DELTA_WALK"); c->exp_delta_walk = e && e[0] == '1'; }
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
@@ -776,7 +778,7 @@ static int build_and_launch(crthip_batch *b) {
 				if(mesh) {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
-					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real;
+					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->exp_delta_walk;   // pad[1]: experiments - the flag-driven walk only
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
 					pl.delta.v.push_back(d);
 				} else {

@@ -295,7 +295,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Lleft_%=\n" \
 							"  s_cmp_eq_u32 %[c], 2\n" \
 							"  s_cbranch_scc1 Lright_%=\n" \
-							"  s_branch Lexit_%=\n"
+							"  s_branch Lcold_%=\n"
 #define TOPO_FAST_PATH(FACE) \
 						asm volatile( \
 							"Ltop_%=:\n" \
@@ -305,7 +305,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Lleft_%=\n" \
 							"  s_cmp_eq_u32 %[c], 2\n" \
 							"  s_cbranch_scc1 Lright_%=\n" \
-							"  s_branch Lexit_%=\n" \
+							"  s_branch Lcold_%=\n" \
    /* ---------------- VERTEX (decoder.cpp:294-309) */ \
 							"Lvertex_%=:\n" \
 							"  s_and_b32 %[t0], %[sw], 0xffff\n"   /* VERTEX LEFT VERTEX LEFT ahead: leave for the run step (TOPO_RUN_STEP) */ \
@@ -404,17 +404,179 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc1 Ltop_%=\n" \
 							"  s_branch Lexit_%=\n" \
+   /* ---------------- BOUNDARY (decoder.cpp:282-283) and DELAY (:327-331): the chain ends and the current edge survives - it gets a pool slot \
+      (free list, else the bump pointer), its record, and its neighbours their links to it - then the next gate is fetched from the ring: \
+      the wave's parked lanes look at 64 queue entries at once, the first live one becomes the current edge, and the dispatch goes on \
+      without leaving the block.  pk1 = pool bump pointer | free-list fill << 16, pk2 = DELAY stack fill | its capacity << 16. \
+      Layout (records at LDS address 0, ring = pool = mask + 1): free list at (mask+1)*32, DELAY stack at (mask+1)*34. \
+      Anything else (END, SPLIT, an invalid or window-end nibble, no slot left, empty ring, window about to run out) leaves for the C++. */ \
+							"Lcold_%=:\n" \
+							"  s_cmp_eq_u32 %[c], 4\n" \
+							"  s_cbranch_scc1 Lbnd_%=\n" \
+							"  s_cmp_eq_u32 %[c], 5\n" \
+							"  s_cbranch_scc0 Lexit_%=\n" \
+							"  s_and_b32 %[t0], %[pk2], 0xffff\n"   /* DELAY: room on the stack? */ \
+							"  s_lshr_b32 %[t2], %[pk2], 16\n" \
+							"  s_cmp_ge_u32 %[t0], %[t2]\n" \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"Lbnd_%=:\n" \
+							"  s_lshr_b32 %[t0], %[pk1], 16\n"   /* free-list fill */ \
+							"  s_cmp_eq_u32 %[t0], 0\n" \
+							"  s_cbranch_scc1 Lbump_%=\n" \
+							"  s_sub_u32 %[t0], %[t0], 1\n" \
+							"  s_add_u32 %[t2], %[mask], 1\n" \
+							"  s_lshl_b32 %[t2], %[t2], 5\n" \
+							"  s_lshl_b32 %[t0], %[t0], 1\n" \
+							"  s_add_u32 %[t0], %[t0], %[t2]\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_read_u16 v52, v52\n" \
+							"  s_sub_u32 %[pk1], %[pk1], 0x10000\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[t1], v52\n"   /* the slot */ \
+							"  s_branch Lhave_%=\n" \
+							"Lbump_%=:\n" \
+							"  s_and_b32 %[t1], %[pk1], 0xffff\n" \
+							"  s_add_u32 %[t2], %[mask], 1\n" \
+							"  s_lshl_b32 %[t2], %[t2], 1\n" \
+							"  s_cmp_ge_u32 %[t1], %[t2]\n"   /* pool exhausted: the C++ flags the blob for the HBM redo */ \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_add_u32 %[pk1], %[pk1], 1\n" \
+							"Lhave_%=:\n" \
+							"  s_mov_b32 %[t2], %[v2]\n" \
+							"  s_cmp_eq_u32 %[c], 5\n" \
+							"  s_cbranch_scc0 Lput_%=\n" \
+							"  s_or_b32 %[t2], %[t2], 0x40000000\n"   /* TOPO_DELAYED; and push the slot */ \
+							"  s_and_b32 %[t0], %[pk2], 0xffff\n" \
+							"  s_lshl_b32 %[t0], %[t0], 1\n" \
+							"  s_add_u32 %[t3], %[mask], 1\n" \
+							"  s_mul_i32 %[t3], %[t3], 34\n" \
+							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  v_mov_b32 v53, %[t1]\n" \
+							"  ds_write_b16 v52, v53\n" \
+							"  s_add_u32 %[pk2], %[pk2], 1\n" \
+							"Lput_%=:\n" \
+							"  s_lshl_b32 %[t3], %[en], 16\n" \
+							"  s_or_b32 %[t3], %[t3], %[ep]\n" \
+							"  v_mov_b32 v48, %[v0]\n" \
+							"  v_mov_b32 v49, %[v1]\n" \
+							"  v_mov_b32 v50, %[t2]\n" \
+							"  v_mov_b32 v51, %[t3]\n" \
+							"  s_lshl_b32 %[t0], %[t1], 4\n" \
+							"  v_mov_b32 v54, %[t0]\n" \
+							"  ds_write_b128 v54, v[48:51]\n" \
+							"  v_mov_b32 v53, %[t1]\n" \
+							"  s_lshl_b32 %[t0], %[ep], 4\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_write_b16 v52, v53 offset:14\n"   /* front[e.prev].next = slot */ \
+							"  s_lshl_b32 %[t0], %[en], 4\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_write_b16 v52, v53 offset:12\n"   /* front[e.next].prev = slot */ \
+							"  s_lshr_b32 %[sw], %[sw], 4\n"        /* the symbol is consumed */ \
+							"  s_add_u32 %[cler], %[cler], 1\n" \
+							"  s_and_b32 %[t0], %[cler], 7\n" \
+							"  s_cbranch_scc1 Lpop_%=\n" \
+							"  s_mov_b32 %[sw], %[swn]\n" \
+							"  s_lshr_b32 %[t0], %[cler], 3\n" \
+							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
+							"  s_lshl_b32 %[t0], %[t0], 2\n" \
+							"  s_add_u32 %[t0], %[t0], %[clbase]\n" \
+							"  v_mov_b32 v55, %[t0]\n" \
+							"  ds_read_b32 v55, v55\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[swn], v55\n" \
+							"Lpop_%=:\n" \
+							"  s_cmp_ge_u32 %[cler], %[slideat]\n" \
+							"  s_cbranch_scc1 Lended_%=\n" \
+							"  s_sub_u32 %[t2], %[nq], %[qpos]\n"   /* queued entries */ \
+							"  s_cmp_eq_u32 %[t2], 0\n" \
+							"  s_cbranch_scc1 Ldpop_%=\n" \
+							"  s_mov_b64 exec, -1\n" \
+							"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+							"  v_mbcnt_hi_u32_b32 v60, -1, v60\n" \
+							"  v_cmp_gt_u32 vcc, %[t2], v60\n" \
+							"  s_mov_b64 exec, vcc\n" \
+							"  v_add_u32 v61, %[qpos], v60\n" \
+							"  v_and_b32 v61, %[mask], v61\n" \
+							"  v_lshlrev_b32 v61, 4, v61\n" \
+							"  ds_read_b32 v61, v61 offset:8\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_cmp_gt_i32 vcc, v61, -1\n"        /* TOPO_DEAD is the sign bit; lanes past the queue's end report 0 */ \
+							"  s_mov_b64 exec, 1\n" \
+							"  s_cmp_eq_u64 vcc, 0\n" \
+							"  s_cbranch_scc0 Lfound_%=\n" \
+							"  s_min_u32 %[t2], %[t2], 64\n"       /* all dead: step over them (no symbol consumed, decoder.cpp:278-279) */ \
+							"  s_add_u32 %[qpos], %[qpos], %[t2]\n" \
+							"  s_branch Lpop_%=\n" \
+							"Lfound_%=:\n" \
+							"  s_ff1_i32_b64 %[t0], vcc\n" \
+							"  s_add_u32 %[t2], %[qpos], %[t0]\n" \
+							"  s_and_b32 %[t2], %[t2], %[mask]\n" \
+							"  s_add_u32 %[qpos], %[qpos], %[t0]\n" \
+							"  s_add_u32 %[qpos], %[qpos], 1\n" \
+							"  s_lshl_b32 %[t2], %[t2], 4\n" \
+							"  v_mov_b32 v52, %[t2]\n" \
+							"  ds_read_b128 v[56:59], v52\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[v0], v56\n" \
+							"  v_readfirstlane_b32 %[v1], v57\n" \
+							"  v_readfirstlane_b32 %[v2], v58\n" \
+							"  v_readfirstlane_b32 %[t0], v59\n" \
+							"  s_and_b32 %[v2], %[v2], 0x3fffffff\n" \
+							"  s_and_b32 %[ep], %[t0], 0xffff\n" \
+							"  s_lshr_b32 %[en], %[t0], 16\n" \
+							"  s_mov_b32 %[nc], -1\n" \
+							"  s_branch Ltop_%=\n" \
+   /* the ring is empty: the youngest postponed gate (decoder.cpp:266-270); its pool slot goes back to the free list */ \
+							"Ldpop_%=:\n" \
+							"  s_and_b32 %[t0], %[pk2], 0xffff\n" \
+							"  s_cmp_eq_u32 %[t0], 0\n" \
+							"  s_cbranch_scc1 Lended_%=\n" \
+							"  s_sub_u32 %[pk2], %[pk2], 1\n" \
+							"  s_sub_u32 %[t0], %[t0], 1\n" \
+							"  s_lshl_b32 %[t0], %[t0], 1\n" \
+							"  s_add_u32 %[t3], %[mask], 1\n" \
+							"  s_mul_i32 %[t2], %[t3], 34\n" \
+							"  s_add_u32 %[t0], %[t0], %[t2]\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_read_u16 v52, v52\n" \
+							"  s_lshr_b32 %[t0], %[pk1], 16\n"      /* free list: where the slot id goes */ \
+							"  s_lshl_b32 %[t0], %[t0], 1\n" \
+							"  s_lshl_b32 %[t3], %[t3], 5\n" \
+							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
+							"  v_mov_b32 v53, %[t0]\n" \
+							"  s_add_u32 %[pk1], %[pk1], 0x10000\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  ds_write_b16 v53, v52\n" \
+							"  v_lshlrev_b32 v54, 4, v52\n" \
+							"  ds_read_b128 v[56:59], v54\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[v2], v58\n" \
+							"  s_cmp_lt_i32 %[v2], 0\n"              /* deleted while it waited: no symbol consumed, next */ \
+							"  s_cbranch_scc1 Lpop_%=\n" \
+							"  v_readfirstlane_b32 %[v0], v56\n" \
+							"  v_readfirstlane_b32 %[v1], v57\n" \
+							"  v_readfirstlane_b32 %[t0], v59\n" \
+							"  s_and_b32 %[v2], %[v2], 0x3fffffff\n" \
+							"  s_and_b32 %[ep], %[t0], 0xffff\n" \
+							"  s_lshr_b32 %[en], %[t0], 16\n" \
+							"  s_mov_b32 %[nc], -1\n" \
+							"  s_branch Ltop_%=\n" \
+							"Lended_%=:\n" \
+							"  s_mov_b32 %[c], 0x200\n"             /* nothing is current: the C++ fetches the next gate (slide, DELAY stack, seed face) */ \
+							"  s_branch Lexit_%=\n" \
 							"Lrun_%=:\n" \
-							"  s_mov_b32 %[run], 1\n" \
+							"  s_mov_b32 %[c], 0x100\n" \
 							"Lexit_%=:\n" \
 							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start), \
 							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en), \
 							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1), \
-							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [t3] "=&s"(t3_), [budget] "+s"(budget_), [run] "+s"(run_) \
-							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), \
+							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [t3] "=&s"(t3_), [budget] "+s"(budget_), \
+							  [pk1] "+s"(pk1), [pk2] "+s"(pk2), [qpos] "+s"(qpos) \
+							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
-							: "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+							: "memory", "scc", "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61");
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -668,6 +830,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	const uint32_t nspl = J.split_nwords < TOPO_SPLIT_LDS ? J.split_nwords : TOPO_SPLIT_LDS;   // waits ~2 us (the load, and every store in flight before it)
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	const uint32_t nclers = J.nclers, symwords = SYMW/8;
+	// the ISA block addresses records from LDS address 0 and finds the free list and the DELAY stack behind ring + pool records with
+	// pool = ring (topo_lds_geometry): anything else takes the HBM path
+	if((uint32_t)(uintptr_t)rec != 0u || POOL != RING || dcap > 0xFFFFu || RING + POOL > 0xFFFFu) return false;
 	// automaton state, alive across window refills (uniform: only lane 0 ever changes it)
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
 	CRT_GLOBAL uint8_t *predb = (CRT_GLOBAL uint8_t *)as_global(J.pred);   // prediction triple of vertex vc at byte 12*vc (vertices are numbered in creation order)
@@ -679,7 +844,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	uint32_t start = 0;
 	uint32_t nq = 0, qpos = 0;                                           // ring [qpos, nq)
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
-	enum { K_MBUMP = 0, K_NFREE = 1, K_NDELAYED = 2, K_BIT_LO = 3, K_BIT_HI = 4 };   // pool bump pointer, free list / DELAY stack fill, split-bit cursor
+	enum { K_BIT_LO = 3, K_BIT_HI = 4 };                                 // split-bit cursor
 
 	// the whole wave fills the symbol window once; from then on lane 0 is alone (and the compiler sees uniform code), and
 	// slides the window by itself between chains when a mesh has more symbols than the window (3 instructions per symbol)
@@ -689,8 +854,13 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	for(uint32_t w = threadIdx.x; w < nspl; w += 64) spl[w] = split[w];
 	__syncthreads();
 	if(threadIdx.x != 0) return true;
-	cold[K_NDELAYED] = 0; cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
-	uint32_t mbump = RING, nfree = 0;                                    // pool bump pointer, free-list fill: touched at every chain end, kept in registers (the hot loop is an asm block that does not carry them)
+	cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
+	// pool bump pointer | free-list fill << 16, DELAY stack fill | its capacity << 16: touched at every chain end, kept in registers and
+	// packed in pairs - the ISA block carries them, and an asm statement takes 30 operands at most
+	uint32_t pk1 = RING, pk2 = dcap << 16;
+#define TOPO_NFREE() (pk1 >> 16)
+#define TOPO_MBUMP() (pk1 & 0xFFFFu)
+#define TOPO_NDEL() (pk2 & 0xFFFFu)
 	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
 	uint32_t sw = TOPO_S(cl32[0]), swn = TOPO_S(cl32[1]);   // TOPO_S: a value lane 0 alone computes is uniform by construction; tell the compiler (SGPR)
 	uint32_t wbias = 1, slide_at = SYMW < nclers ? SYMW - 2048u : 0xFFFFFFFFu;   // next symbol word = cl32[(cler >> 3) + wbias]; slide when cler gets here
@@ -708,17 +878,17 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	wbias = 1u - (winbase >> 3); slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu; } while(0)
 #define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = TOPO_S(cl32[(cler >> 3) + wbias]); } } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
-#define TOPO_RELEASE(id, z) do { if((id) > MASK && !(TOPO_S(z) & TOPO_DELAYED)) { freel[nfree] = (uint16_t)(id); nfree++; } } while(0)
+#define TOPO_RELEASE(id, z) do { if((id) > MASK && !(TOPO_S(z) & TOPO_DELAYED)) { freel[TOPO_NFREE()] = (uint16_t)(id); pk1 += 0x10000u; } } while(0)
 	// give the surviving current edge a pool slot, its record, and its neighbours their links to it
 #define TOPO_MATERIALISE(flags) do { \
-	if(nfree) { nfree--; f = TOPO_S(freel[nfree]); } else if(mbump < RING + POOL) { f = mbump; mbump++; } else { err = 2; break; } \
+	if(TOPO_NFREE()) { pk1 -= 0x10000u; f = TOPO_S(freel[TOPO_NFREE()]); } else if(TOPO_MBUMP() < RING + POOL) { f = TOPO_MBUMP(); pk1++; } else { err = 2; break; } \
 	TOPO_PUT(f, v0, v1, v2 | (flags), ep, en); rec16[ep*8 + 7] = (uint16_t)f; rec16[en*8 + 6] = (uint16_t)f; } while(0)
 
 			for(uint32_t g = 0; g < J.ngroups && !err; g++) {              // every group starts from an empty front (decoder.cpp:173-178)
 			const uint32_t ge = TOPO_S(group_end[g]);
 			if(ge > J.nface || ge*3 < start) { err = 1; break; }
 			const uint32_t end = ge*3;
-			nq = 0; qpos = 0; mbump = RING; nfree = 0; cold[K_NDELAYED] = 0;
+			nq = 0; qpos = 0; pk1 = RING; pk2 = dcap << 16;
 			while(start < end && !err) {
 				if(cler >= slide_at) TOPO_SLIDE();                          // slide the window before it runs low
 				// ---- cold: fetch the next edge to process: ring, DELAY stack, or a new seed face ----
@@ -755,7 +925,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 					qpos += j + 1;
 					f = 0;
 				}
-				else if((nd_ = cold[K_NDELAYED]) != 0) { f = delayed[nd_ - 1]; cold[K_NDELAYED] = nd_ - 1; t0 = rec[f]; freel[nfree] = (uint16_t)f; nfree++; }
+				else if((nd_ = TOPO_NDEL()) != 0) { f = delayed[nd_ - 1]; pk2--; t0 = rec[f]; freel[TOPO_NFREE()] = (uint16_t)f; pk1 += 0x10000u; }
 				else {                                                     // seed face (decoder.cpp:224-259)
 					uint32_t c; TOPO_SYMBOL(c);
 					uint32_t last = vc - 1, vi[3], mask = 0;
@@ -794,11 +964,12 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						// (scalar copies at every join).  The block PEEKS at the next symbol and leaves with the state
 						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
 						// or ring running out, the group's last face - which the C++ below then handles.
-						uint32_t t0_, t1_, t2_, t3_, c_, run_ = 0;
+						uint32_t t0_, t1_, t2_, t3_, c_;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
 						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32); }
 						if(start >= end) break;
-						if(run_ && ep <= MASK) {
+						if(c_ == 0x200u) break;                                   // the block ended the chain (BOUNDARY / DELAY) and found no gate to go on with
+						if(c_ == 0x100u && ep <= MASK) {
 							// (VERTEX LEFT)^k ahead: up to 63 pairs in one pass of the whole wave (TOPO_RUN_STEP above).  Bounded by the
 							// vertex ids and ring slots left, the group's faces and the symbols in the LDS window.
 							uint32_t rk_, rkm1_, rswo_, rswno_, rxl_, rwl_, ral_, rbl_, rm0s_;
@@ -860,10 +1031,10 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							v2 = v1; v1 = opp; en = s;
 							if(start < end) continue;                      // SPLIT continues the chain like VERTEX
 						} else if(c == C_DELAY) {                          // decoder.cpp:327-331
-							const uint32_t nd2_ = cold[K_NDELAYED];
+							const uint32_t nd2_ = TOPO_NDEL();
 							if(nd2_ >= dcap) { err = 2; break; }
 							TOPO_MATERIALISE(TOPO_DELAYED);
-							if(!err) { delayed[nd2_] = (uint16_t)f; cold[K_NDELAYED] = nd2_ + 1; }
+							if(!err) { delayed[nd2_] = (uint16_t)f; pk2++; }
 						} else if(c == C_END) {                            // decoder.cpp:333-339
 							const u32x4 tp = rec[ep], tn = rec[en];
 							const uint32_t pp = tp.w & 0xFFFFu, nn = tn.w >> 16, opp = tp.x;
@@ -887,6 +1058,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #undef TOPO_SLIDE
 #undef TOPO_RELEASE
 #undef TOPO_MATERIALISE
+#undef TOPO_NFREE
+#undef TOPO_MBUMP
+#undef TOPO_NDEL
 		}
 	}
 	if(err == 2) return false;
@@ -1033,11 +1207,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T, int NC>
 __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, CRT_LDS uint8_t *fired,
-                                               CRT_LDS const uint16_t *starts, uint32_t ns, uint32_t nvert, uint32_t Nrt, bool para) {
+                                               CRT_LDS const uint16_t *starts, uint32_t ns, uint32_t nvert, uint32_t Nrt, bool para, uint32_t first) {
 	const uint32_t n = NC ? (uint32_t)NC : Nrt;
+	for(uint32_t j = lane_id(); j < nvert; j += 64) fired[j] = j < first;        // vertices below `first` are final already (delta_scan_run)
 	uint32_t k = lane_id();
 	bool active = k < ns;
-	uint32_t i = active ? starts[k] : 0u, end = active ? (k + 1 < ns ? (uint32_t)starts[k + 1] : nvert) : 0u;
+	uint32_t i = 0, end = 0;
+	auto take = [&]() {                                                    // stretch k, from `first` on; stretches that end below it are done
+		while(active) {
+			i = starts[k]; end = k + 1 < ns ? (uint32_t)starts[k + 1] : nvert;
+			if(i < first) i = first;
+			if(i < end) break;
+			k += 64; active = k < ns;
+		}
+	};
+	take();
 	uint32_t a = active ? pa[i] : 0u, bc = active ? pbc[i] : 0u;
 	while(__any(active)) {
 		if(active) {
@@ -1059,15 +1243,69 @@ __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint1
 			if(ready) {
 				fired[i] = 1;
 				i++;
-				if(i == end) {
-					k += 64; active = k < ns;
-					if(active) { i = starts[k]; end = k + 1 < ns ? (uint32_t)starts[k + 1] : nvert; }
-				}
+				if(i == end) { k += 64; active = k < ns; take(); }
 				if(active) { a = pa[i]; bc = pbc[i]; }
 			}
 		}
 		asm volatile("" ::: "memory");
 	}
+}
+
+// K-DELTA as SCANS (round 2).  v[i] += v[a] + v[b] - v[c] with a = i-1 is a prefix sum: v[i] = v[s-1] + sum_{k=s..i} (d[k] + v[b_k] - v[c_k])
+// as long as every b, c lies below s.  In the CLERS order that is the common case - the vertices of a (VERTEX LEFT) run predict from
+// their predecessor and from two vertices of the previous ring of the front - so the wave takes the next up-to-64 vertices [s, s+64),
+// cuts the block at the first vertex with a parent inside the block that is not its predecessor, and finishes the rest in one pass:
+// gathers of v[b], v[c] (and v[a] for the heads: vertices whose a is not i-1; a < s then), one DPP wave scan per component, and,
+// because a block may hold several heads, each lane subtracts the exclusive sum at its own segment's head (a max-scan of head lanes
+// + one bpermute per component) - all sums wrap mod 2^32 (mod 2^8 for colours), like the reference's int / uchar arithmetic.
+// The first vertex of a block always qualifies (its parents are below it), so every pass advances; a 4K-triangle blob with its
+// growing rings needs ~110 passes (the 34K- and 128K-vertex meshes average 47 and 54 vertices a pass) where the flag-driven walk
+// below needs at least one round of dependent LDS trips per level of the DAG (158 levels there, 480 on a small torus).  Meshes whose blocks
+// stay short (irregular connectivity) are handed to that walk, from where the scans stopped.
+// Returns the first vertex not done (nvert: finished).
+template <typename T, int NC>
+__device__ __forceinline__ uint32_t delta_scan_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, uint32_t nvert, bool para) {
+	const uint32_t lane = lane_id();
+	uint32_t s = 1, passes = 0;
+	while(s < nvert) {
+		const uint32_t i = s + lane;
+		const bool in = i < nvert;
+		const uint32_t a = in ? pa[i] : 0xFFFFu, bc = in ? pbc[i] : 0xFFFFFFFFu;
+		const bool inv = a == 0xFFFFu || (para && bc == 0xFFFFFFFFu);           // malformed triple: the value stays (a head with base 0)
+		const uint32_t b = bc & 0xFFFFu, c = bc >> 16;
+		const bool chained = !inv && a + 1 == i && lane != 0;                   // continues its predecessor's sum
+		const bool ok = in && (inv || ((chained || a < s) && (!para || (b < s && c < s))));
+		const uint64_t bad = ~__ballot(ok);
+		const uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;           // lanes [0, L) go now (L >= 1)
+		const bool mine = lane < L;
+		const bool head = mine && !chained;
+		// the lane's own head = the highest head lane at or below it (lane 0 is always one): from the ballot, no cross-lane traffic
+		const uint64_t heads = __ballot(head) | 1ull;
+		const uint32_t hidx = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63u - lane)));
+		// the components side by side, phase by phase: every gather of the pass in flight at once, then the scans, the bpermutes, the
+		// stores (written as a loop over components the stores of one fenced in the loads of the next: three LDS round trips each)
+		uint32_t x[NC], incl[NC], eh[NC];
+		const uint32_t ri = mine ? i : 0u, rb = mine && !inv && para ? b : 0u, rc = mine && !inv && para ? c : 0u, ra = head && !inv ? a : 0u;
+#pragma unroll
+		for(uint32_t q = 0; q < (uint32_t)NC; q++) {
+			const uint32_t vi = (uint32_t)v[ri*NC + q], vb = (uint32_t)v[rb*NC + q], vc = (uint32_t)v[rc*NC + q], va = (uint32_t)v[ra*NC + q];
+			x[q] = mine ? vi + (!inv && para ? vb - vc : 0u) + (head && !inv ? va : 0u) : 0u;
+		}
+#pragma unroll
+		for(uint32_t q = 0; q < (uint32_t)NC; q++) incl[q] = wave_inclusive_scan_u32(x[q]);
+#pragma unroll
+		for(uint32_t q = 0; q < (uint32_t)NC; q++) eh[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hidx << 2), (int)(incl[q] - x[q]));
+		if(mine) {
+#pragma unroll
+			for(uint32_t q = 0; q < (uint32_t)NC; q++) v[i*NC + q] = (T)(incl[q] - eh[q]);
+		}
+		s += L;
+		// a front grows from its seed triangle, so the first blocks are short whatever the mesh; by pass 96 a mesh with rings to speak
+		// of has done well over a thousand vertices (a 4K-triangle grid: 1 700) and one that has not yet done 576 (a holey disc, a
+		// ribbon: ~5 a pass) has a shallower DAG than it has blocks - the walk takes over from s
+		if(++passes == 96 && s < 96*6) break;
+	}
+	return s < nvert ? s : nvert;
 }
 
 // values of one attribute <-> LDS by one wave: 16-byte vectors, eight in flight per lane (a lone wave that waited for each load
@@ -1157,28 +1395,31 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 		J = jobs[G.first + w];
 		S = delta_stage_plan(l8 + myoff, J.values, nvert*J.N*(J.is_u8 ? 1u : 4u));
 		delta_stage_copy<true>(S);
-		for(uint32_t i = lane; i < nvert; i += 64) fired[i] = i == 0;
 	}
 	__syncthreads();
 	if(w < G.count) {
 		const uint32_t ns = ns_shared, N = J.N;
 		const bool para = J.parallelogram != 0;
+		// scans first (delta_scan_run); what they leave - short blocks: irregular connectivity - to the flag-driven walk
+#define CRT_DELTA(T_, NC_, V_) do { uint32_t first_ = 1; if(NC_ && !J.pad[1]) first_ = delta_scan_run<T_, (NC_) ? (NC_) : 1>(V_, pa, pbc, nvert, para); \
+		if(first_ < nvert) delta_wave_run<T_, NC_>(V_, pa, pbc, fired, starts, ns, nvert, N, para, first_); } while(0)
 		if(J.is_u8) {
 			CRT_LDS uint8_t *v = S.l8;
 			switch(N) {
-			case 3: delta_wave_run<uint8_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
-			case 4: delta_wave_run<uint8_t, 4>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
-			default: delta_wave_run<uint8_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			case 3: CRT_DELTA(uint8_t, 3, v); break;
+			case 4: CRT_DELTA(uint8_t, 4, v); break;
+			default: CRT_DELTA(uint8_t, 0, v); break;
 			}
 		} else {
 			CRT_LDS uint32_t *v = (CRT_LDS uint32_t *)S.l8;
 			switch(N) {
-			case 1: delta_wave_run<uint32_t, 1>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
-			case 2: delta_wave_run<uint32_t, 2>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
-			case 3: delta_wave_run<uint32_t, 3>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
-			default: delta_wave_run<uint32_t, 0>(v, pa, pbc, fired, starts, ns, nvert, N, para); break;
+			case 1: CRT_DELTA(uint32_t, 1, v); break;
+			case 2: CRT_DELTA(uint32_t, 2, v); break;
+			case 3: CRT_DELTA(uint32_t, 3, v); break;
+			default: CRT_DELTA(uint32_t, 0, v); break;
 			}
 		}
+#undef CRT_DELTA
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		delta_stage_copy<false>(S);
 	}
