@@ -413,6 +413,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lcold_%=:\n" \
 							"  s_cmp_eq_u32 %[c], 4\n" \
 							"  s_cbranch_scc1 Lbnd_%=\n" \
+							"  s_cmp_eq_u32 %[c], 6\n" \
+							"  s_cbranch_scc1 Lsplit_%=\n" \
 							"  s_cmp_eq_u32 %[c], 5\n" \
 							"  s_cbranch_scc0 Lexit_%=\n" \
 							"  s_and_b32 %[t0], %[pk2], 0xffff\n"   /* DELAY: room on the stack? */ \
@@ -499,9 +501,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  v_add_u32 v61, %[qpos], v60\n" \
 							"  v_and_b32 v61, %[mask], v61\n" \
 							"  v_lshlrev_b32 v61, 4, v61\n" \
-							"  ds_read_b32 v61, v61 offset:8\n" \
+							"  ds_read_b128 v[56:59], v61\n"        /* every lane its whole record: the live one is then a readlane away, not another round trip */ \
 							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_cmp_gt_i32 vcc, v61, -1\n"        /* TOPO_DEAD is the sign bit; lanes past the queue's end report 0 */ \
+							"  v_cmp_gt_i32 vcc, v58, -1\n"        /* TOPO_DEAD is the sign bit; lanes past the queue's end report 0 */ \
 							"  s_mov_b64 exec, 1\n" \
 							"  s_cmp_eq_u64 vcc, 0\n" \
 							"  s_cbranch_scc0 Lfound_%=\n" \
@@ -510,18 +512,12 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lpop_%=\n" \
 							"Lfound_%=:\n" \
 							"  s_ff1_i32_b64 %[t0], vcc\n" \
-							"  s_add_u32 %[t2], %[qpos], %[t0]\n" \
-							"  s_and_b32 %[t2], %[t2], %[mask]\n" \
 							"  s_add_u32 %[qpos], %[qpos], %[t0]\n" \
 							"  s_add_u32 %[qpos], %[qpos], 1\n" \
-							"  s_lshl_b32 %[t2], %[t2], 4\n" \
-							"  v_mov_b32 v52, %[t2]\n" \
-							"  ds_read_b128 v[56:59], v52\n" \
-							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_readfirstlane_b32 %[v0], v56\n" \
-							"  v_readfirstlane_b32 %[v1], v57\n" \
-							"  v_readfirstlane_b32 %[v2], v58\n" \
-							"  v_readfirstlane_b32 %[t0], v59\n" \
+							"  v_readlane_b32 %[v0], v56, %[t0]\n" \
+							"  v_readlane_b32 %[v1], v57, %[t0]\n" \
+							"  v_readlane_b32 %[v2], v58, %[t0]\n" \
+							"  v_readlane_b32 %[t0], v59, %[t0]\n" \
 							"  s_and_b32 %[v2], %[v2], 0x3fffffff\n" \
 							"  s_and_b32 %[ep], %[t0], 0xffff\n" \
 							"  s_lshr_b32 %[en], %[t0], 16\n" \
@@ -562,6 +558,69 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_lshr_b32 %[en], %[t0], 16\n" \
 							"  s_mov_b32 %[nc], -1\n" \
 							"  s_branch Ltop_%=\n" \
+   /* ---------------- SPLIT (decoder.cpp:294-309 with a known vertex): VERTEX's step with the opposite vertex read from the split / \
+      vertex-id bits instead of made - no prediction triple, no new id.  The bit cursor, the width of an id and the number of bits the \
+      staged words hold sit in cold[3..6], 1056 bytes below the symbol window, the words themselves 1024 below it; a field that does \
+      not lie inside the staged words is left to the C++ (which also reports a stream that runs out of bits).  vcc is scratch here: \
+      the two words as a 64-bit value, then the vertex id. */ \
+							"Lsplit_%=:\n" \
+							"  s_sub_u32 %[budget], %[budget], 1\n"   /* a ring slot (SCC = borrow: none) */ \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_sub_u32 %[t0], %[clbase], 1056\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_read2_b32 v[56:57], v52 offset0:3 offset1:4\n" \
+							"  ds_read2_b32 v[58:59], v52 offset0:5 offset1:6\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[t0], v56\n" \
+							"  v_readfirstlane_b32 %[t1], v57\n" \
+							"  v_readfirstlane_b32 %[t2], v58\n" \
+							"  v_readfirstlane_b32 %[t3], v59\n" \
+							"  s_cmp_lg_u32 %[t1], 0\n" \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_add_u32 %[t1], %[t0], %[t2]\n" \
+							"  s_cmp_gt_u32 %[t1], %[t3]\n" \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  v_mov_b32 v53, %[t1]\n" \
+							"  ds_write_b32 v52, v53 offset:12\n"     /* the cursor moves on */ \
+							"  s_lshr_b32 %[t1], %[t0], 5\n" \
+							"  s_lshl_b32 %[t1], %[t1], 2\n" \
+							"  s_add_u32 %[t1], %[t1], %[clbase]\n" \
+							"  s_sub_u32 %[t1], %[t1], 1024\n" \
+							"  v_mov_b32 v54, %[t1]\n" \
+							"  ds_read2_b32 v[56:57], v54 offset1:1\n" \
+							"  s_and_b32 %[t0], %[t0], 31\n" \
+							"  s_sub_u32 %[t2], 64, %[t2]\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 vcc_hi, v56\n" \
+							"  v_readfirstlane_b32 vcc_lo, v57\n" \
+							"  s_nop 0\n" \
+							"  s_lshl_b64 vcc, vcc, %[t0]\n" \
+							"  s_lshr_b64 vcc, vcc, %[t2]\n" \
+							"  s_and_b32 vcc_lo, vcc_lo, 0x3fffffff\n"   /* the opposite vertex */ \
+							"  s_and_b32 %[t1], %[nq], %[mask]\n" \
+							"  s_add_u32 %[nq], %[nq], 1\n" \
+							FACE("vcc_lo") \
+							"  s_add_u32 %[start], %[start], 3\n" \
+							"  s_lshl_b32 %[t0], %[en], 4\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  v_mov_b32 v53, %[t1]\n" \
+							"  ds_write_b16 v52, v53 offset:12\n" \
+							"  s_lshl_b32 %[t2], %[en], 16\n" \
+							"  s_or_b32 %[t2], %[t2], 0xffff\n" \
+							"  v_mov_b32 v48, vcc_lo\n" \
+							"  v_mov_b32 v49, %[v1]\n" \
+							"  v_mov_b32 v50, %[v0]\n" \
+							"  v_mov_b32 v51, %[t2]\n" \
+							"  s_lshl_b32 %[t0], %[t1], 4\n" \
+							"  v_mov_b32 v54, %[t0]\n" \
+							"  ds_write_b128 v54, v[48:51]\n" \
+							"  s_mov_b32 %[nc], %[t1]\n" \
+							"  s_mov_b32 %[ncnext], %[en]\n" \
+							"  s_mov_b32 %[ncv1], %[v1]\n" \
+							"  s_mov_b32 %[v2], %[v1]\n" \
+							"  s_mov_b32 %[v1], vcc_lo\n" \
+							"  s_mov_b32 %[en], %[t1]\n" \
+							TOPO_ASM_TAIL \
 							"Lended_%=:\n" \
 							"  s_mov_b32 %[c], 0x200\n"             /* nothing is current: the C++ fetches the next gate (slide, DELAY stack, seed face) */ \
 							"  s_branch Lexit_%=\n" \
@@ -824,9 +883,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	CRT_LDS uint16_t *rec16 = (CRT_LDS uint16_t *)rec;
 	CRT_LDS uint16_t *freel = (CRT_LDS uint16_t *)(rec + RING + POOL);
 	CRT_LDS uint16_t *delayed = freel + ((POOL + 7) & ~7u);
-	CRT_LDS uint32_t *cl32 = (CRT_LDS uint32_t *)(delayed + ((dcap + 7) & ~7u));
-	CRT_LDS uint32_t *cold = cl32 + SYMW/8 + 2;                         // state only the cold paths touch lives here, not in loop-carried registers
+	CRT_LDS uint32_t *cold = (CRT_LDS uint32_t *)(delayed + ((dcap + 7) & ~7u));   // state only the cold paths touch lives here, not in loop-carried registers
 	CRT_LDS uint32_t *spl = cold + 8;                                   // the first TOPO_SPLIT_LDS words of the split / vertex-id bits: a SPLIT that loads them from HBM
+	CRT_LDS uint32_t *cl32 = spl + TOPO_SPLIT_LDS;                      // the symbol window LAST: the ISA block finds cold[] and spl[] at fixed distances below it
 	const uint32_t nspl = J.split_nwords < TOPO_SPLIT_LDS ? J.split_nwords : TOPO_SPLIT_LDS;   // waits ~2 us (the load, and every store in flight before it)
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	const uint32_t nclers = J.nclers, symwords = SYMW/8;
@@ -844,7 +903,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	uint32_t start = 0;
 	uint32_t nq = 0, qpos = 0;                                           // ring [qpos, nq)
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
-	enum { K_BIT_LO = 3, K_BIT_HI = 4 };                                 // split-bit cursor
+	enum { K_BIT_LO = 3, K_BIT_HI = 4, K_SPLITBITS = 5, K_BIT_LIMIT = 6 };   // split-bit cursor; bits of a vertex id; bits the staged words hold (for the ISA block's SPLIT)
 
 	// the whole wave fills the symbol window once; from then on lane 0 is alone (and the compiler sees uniform code), and
 	// slides the window by itself between chains when a mesh has more symbols than the window (3 instructions per symbol)
@@ -854,7 +913,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	for(uint32_t w = threadIdx.x; w < nspl; w += 64) spl[w] = split[w];
 	__syncthreads();
 	if(threadIdx.x != 0) return true;
-	cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0;
+	cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0; cold[K_SPLITBITS] = splitbits;
+	{ const uint64_t lim = (uint64_t)nspl*32u; cold[K_BIT_LIMIT] = (uint32_t)(lim < bit_end ? lim : bit_end); }
 	// pool bump pointer | free-list fill << 16, DELAY stack fill | its capacity << 16: touched at every chain end, kept in registers and
 	// packed in pairs - the ISA block carries them, and an asm statement takes 30 operands at most
 	uint32_t pk1 = RING, pk2 = dcap << 16;

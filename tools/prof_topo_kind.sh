@@ -14,9 +14,12 @@ for f in sorted(glob.glob("$OUT/p/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]; acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
-    for k, v in acc.items():
-        if "topology" in k:
-            d = {c: x/len(n[k]) for c, x in v.items()}
-            print(k, len(n[k]), "per symbol:", {c: round(x/sym, 2) for c, x in d.items()})
+    # the LAST dispatch only: the first decodes of a context may still redo blobs on the HBM front (the LDS slots adapt)
+    rows = [r for r in csv.DictReader(open(f)) if "topology" in r["Kernel_Name"]]
+    last = max(int(r["Dispatch_Id"]) for r in rows)
+    d = collections.defaultdict(float)
+    for r in rows:
+        if int(r["Dispatch_Id"]) == last: d[r["Counter_Name"]] += float(r["Counter_Value"])
+    print("last dispatch, per symbol:", {c: round(x/sym, 2) for c, x in d.items()})
 PY
 tail -3 $OUT/log.txt
