@@ -259,9 +259,31 @@ def other_configs(ctx, ca):
                 out[key]["cpu_reference_ms"] = round(float(min(ns)) * 1e-6, 3)
         except Exception:
             pass
+    # where a single mesh stops losing to one CPU core: the same decode on grids of growing size
+    sweep = []
+    for nu, nv in ((64, 32), (128, 64), (256, 125), (384, 190)):
+        mesh = synth.bumpy_sphere(nu, nv, seed=1)
+        blob = ca.encode(mesh, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
+        b = ca.Batch(ctx, [blob]); b.allocate_outputs()
+        b.decode(); b.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            b.decode(); b.sync()
+        dt = (time.perf_counter() - t0) / 5
+        row = {"triangles": int(mesh.nface), "gpu_ms": round(dt * 1e3, 3)}
+        b.close()
+        try:
+            from oracle import refcodec as rc
+            if rc.available():
+                ns, _ = rc.decode_timed(blob, 3)
+                row["cpu_reference_ms"] = round(float(min(ns)) * 1e-6, 3)
+        except Exception:
+            pass
+        sweep.append(row)
+    out["single_mesh_sweep"] = sweep
     out["note"] = ("one object per decode: no blob-level parallelism.  The 128K-vertex mesh is ONE serial CLERS chain, whose (VERTEX LEFT) runs the whole wave "
-                   "does 63 pairs at a time (DESIGN.md 3.1); below a few tens of thousands of triangles a single mesh is faster on a CPU core "
-                   "(see facade_per_blob: one 4K-triangle blob) - the batch API is the GPU's case")
+                   "does 63 pairs at a time (DESIGN.md 3.1); single_mesh_sweep shows the size below which one mesh alone is faster on a CPU core "
+                   "(a decode is a dozen dependent launches and one serial chain whatever the size) - batches are the GPU's case")
     return out
 
 

@@ -175,6 +175,38 @@ def test_cpp_decoder_dropin(ctx, tmp_path):
     assert out.returncode == 1 and "Not a crt file." in out.stderr
 
 
+@pytest.mark.timeout(300)
+def test_random_corpus_of_mesh_kinds(ctx):
+    """the CLERS automaton's ISA paths (runs of (VERTEX LEFT) pairs, BOUNDARY / DELAY / SPLIT, ring and DELAY-stack pops) and the delta
+    scans against the oracle on ~200 meshes of every kind the generator has - grids, tori, closed spheres, discs with holes, ribbons,
+    merged components, shuffled faces and vertices, several groups - in batches, u32 and u16 indices, f32 and i16 normals"""
+    from corto_amd import synth as S
+    rng = np.random.default_rng(99)
+    meshes = []
+    for k in range(40):
+        a, b2 = int(rng.integers(5, 70)), int(rng.integers(4, 40))
+        meshes += [S.bumpy_sphere(a, b2, seed=k), S.torus(max(a, 6), max(b2, 5), seed=k), S.closed_sphere(max(a // 2, 4), max(b2 // 2, 3), seed=k),
+                   S.holey_disc(max(a // 2, 6), seed=k, hole_frac=0.03 + 0.01 * (k % 12))]
+        if k % 4 == 0:
+            meshes.append(S.strip(20 + 17 * k, seed=k))
+            meshes.append(S.merge([S.closed_sphere(6 + k % 5, 4, seed=k), S.holey_disc(8 + k % 7, seed=k, color_components=4), S.torus(7, 5, seed=k)]))
+        if k % 3 == 0:
+            meshes[-1] = S.shuffled(meshes[-1], seed=k)
+        if k % 5 == 0:
+            g = meshes[-2]; g.groups = sorted(set([g.nface // 3, g.nface // 2, g.nface]))
+    blobs = [ca.encode(m, normal_prediction=i % 3, position_bits=10 + i % 9) for i, m in enumerate(meshes)]
+    refs = [oc.decode(b, color_components=4) for b in blobs]
+    for lo in range(0, len(blobs), 64):
+        part = blobs[lo:lo + 64]
+        b = run_batch(ctx, part, color_components=4)
+        for i in range(len(part)):
+            assert_same(b.host_outputs(i), refs[lo + i], KEYS, "corpus mesh %d" % (lo + i))
+        b16 = run_batch(ctx, part, normal_format=ca.FMT_INT16, index16=True, color_components=4)
+        for i in range(len(part)):
+            r16 = oc.decode(part[i], normal_format=oc.FMT_INT16, color_components=4, index16=True)
+            assert_same(b16.host_outputs(i), r16, KEYS, "corpus mesh %d (i16/u16)" % (lo + i))
+
+
 def test_interleaved_vertex_buffers(ctx):
     """every fixture decoded into ONE interleaved vertex buffer per blob (crthip_attr_binding.stride: position f32x3 |
     normal i16x3 + pad | uv f32x2 | colour u8x4 | radius f32) + u16 indices, all in one batch; de-interleaved it is the reference's
