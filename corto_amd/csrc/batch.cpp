@@ -601,6 +601,14 @@ static int build_and_launch(crthip_batch *b) {
 				bs[i].attr[k].fired = cv.take((((uint64_t)L.h.nvert + 15) & ~15ull) + 4ull*L.h.nvert + 16, 16);
 		}
 	}
+	{	// look-back state words of the bit-unpack chunks (k_unpack_extract): one per 1 024 logs of every bound stream, + the error word
+		uint64_t up = 0;
+		for(uint32_t i = 0; i < nblobs; i++) {
+			const BlobPlan &P = b->blobs[i];
+			for(size_t k = 0; k < P.L.attrs.size(); k++) if(P.bind[k].buffer) for(const StreamRef &lg : P.L.attrs[k].logs) up += ((uint64_t)lg.size + CHUNK - 1)/CHUNK;
+		}
+		pl.unpack_partial_off = cv.take((up + 1)*8);
+	}
 	pl.zero_end = cv.take(0);
 	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0;
 
@@ -843,7 +851,6 @@ static int build_and_launch(crthip_batch *b) {
 	}
 
 	pl.tun_partial_off = cv.take(((uint64_t)tun_chunks*4 + 4)*8);
-	pl.unpack_partial_off = cv.take(((uint64_t)unpack_chunks + 1)*8);
 	pl.cloud_partial_off = cv.take(((uint64_t)cloud_chunks + 1)*8);
 
 	// job arrays region
@@ -945,8 +952,6 @@ static int build_and_launch(crthip_batch *b) {
 	};
 	auto unpack = [&](hipStream_t s) {
 		if(!unpack_chunks) return;
-		LT.begin("unpack_sums", s); hipLaunchKernelGGL(k_unpack_sums, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
-		LT.begin("scan", s); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, unpack_partial, unpack_chunks); LT.end();
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
 	};
 	auto topology = [&]() -> int {

@@ -72,25 +72,11 @@ __device__ __forceinline__ uint32_t unpack_bits_of(const UnpackJob &J, uint32_t 
 	return d*J.fields;
 }
 
-__global__ __launch_bounds__(256) void k_unpack_sums(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
-                                                     uint32_t nchunks, uint64_t *__restrict__ partial) {
-	const uint32_t c = blockIdx.x;
-	if(c >= nchunks) return;
-	const UnpackJob J = jobs[chunk_job[c]];
-	const uint32_t i0 = (c - J.chunk0)*CHUNK + 4*threadIdx.x;
-	uint32_t s = 0;
-#pragma unroll
-	for(int k = 0; k < 4; k++) if(i0 + k < J.count) s += unpack_bits_of(J, J.logs[i0 + k]);
-#pragma unroll
-	for(int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-	__shared__ uint32_t red[4];
-	if(lane_id() == 0) red[wave_id()] = s;
-	__syncthreads();
-	if(threadIdx.x == 0) partial[c] = (uint64_t)red[0] + red[1] + red[2] + red[3];
-}
-
+// One pass: a chunk adds up the bits of its own 1 024 logs, finds where its fields start by look-back over the earlier chunks of
+// its bit block (chain_lookback, wait-free: at most a dozen state words for a 4-component attribute of a C4 blob) and extracts - round 1 ran a
+// sums kernel and a device-wide scan in front of this one, two more launches on the attribute chain of every batch.
 __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
-                                                        uint32_t nchunks, const uint64_t *__restrict__ partial) {
+                                                        uint32_t nchunks, uint64_t *state) {
 	const uint32_t c = blockIdx.x;
 	if(c >= nchunks) return;
 	const UnpackJob J = jobs[chunk_job[c]];
@@ -103,8 +89,24 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 		s += lg[k]*J.fields;
 	}
 	__shared__ uint32_t smem[4];
+	__shared__ uint64_t before;                        // look-back scratch
 	uint32_t total;
-	uint64_t o = partial[c] - partial[J.chain_chunk0] + block256_exclusive_scan<uint32_t>(s, smem, &total);
+	const uint32_t mine = block256_exclusive_scan<uint32_t>(s, smem, &total);
+	__shared__ uint32_t red[4];
+	auto chunk_bits = [&](uint32_t ci) -> uint64_t {      // the bits of another chunk of this bit block (maybe another component's log stream)
+		const UnpackJob K = jobs[chunk_job[ci]];
+		const uint32_t k0 = (ci - K.chunk0)*CHUNK + 4*threadIdx.x;
+		uint32_t t = 0;
+#pragma unroll
+		for(int k = 0; k < 4; k++) if(k0 + k < K.count) t += unpack_bits_of(K, K.logs[k0 + k]);
+#pragma unroll
+		for(int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+		__syncthreads();
+		if(lane_id() == 0) red[wave_id()] = t;
+		__syncthreads();
+		return (uint64_t)red[0] + red[1] + red[2] + red[3];
+	};
+	uint64_t o = chain_lookback(state, c, J.chain_chunk0, total, 0u, &before, chunk_bits) + mine;
 	const uint32_t *__restrict__ words = J.words;
 #pragma unroll
 	for(int k = 0; k < 4; k++) {

@@ -346,26 +346,6 @@ __device__ __forceinline__ uint32_t tun_wave_bytes(CRT_GLOBAL const uint8_t *src
 // spin is bounded and a chunk that gives up flags the error word behind the state array), chunk 0 of every stream publishes an
 // inclusive total at once, so a walk never leaves its stream.  The state word IS the payload: 8-byte agent-scope atomics on both
 // sides, no fences (the per-XCD L2s are not coherent; sc1 accesses go to memory).
-constexpr uint64_t TUN_ST_LOCAL = 1ull << 62, TUN_ST_INCL = 2ull << 62, TUN_ST_MASK = (1ull << 62) - 1ull;
-__device__ __forceinline__ uint64_t tun_lookback(uint64_t *state, uint32_t c, uint32_t chunk0, uint64_t total, uint32_t nchunks_all) {
-	uint64_t prefix = 0;
-	if(c == chunk0) { __hip_atomic_store(&state[c], TUN_ST_INCL | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
-	__hip_atomic_store(&state[c], TUN_ST_LOCAL | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	for(uint32_t i = c - 1;; i--) {
-		uint64_t v = 0;
-		for(uint32_t spins = 0; spins < (1u << 22); spins++) {
-			v = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if(v >> 62) break;
-			__builtin_amdgcn_s_sleep(8);
-		}
-		if(!(v >> 62)) { atomicAdd((unsigned long long *)&state[nchunks_all], 1ull); break; }   // gave up: the output is wrong, the host is told
-		prefix += v & TUN_ST_MASK;
-		if((v >> 62) == 2 || i == chunk0) break;
-	}
-	__hip_atomic_store(&state[c], TUN_ST_INCL | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return prefix;
-}
-
 // the decoded bytes leave through non-temporal stores: six bytes are written for every byte read, and as ordinary stores they
 // pushed the chunk's codewords out of the XCD's L2 between the look-back's adding-up pass and the decode pass
 #ifndef TUN_FLUSH_PLAIN
@@ -407,10 +387,19 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 		const uint32_t mine = tun_wave_bytes(src, first, last, as_lds(L.len));
 		if(lane == 0) share[1 + w] = mine;
 		__syncthreads();
-		if(tid == 0) share[0] = tun_lookback(chunk_out, c, st.chunk0, share[1] + share[2] + share[3] + share[4], nchunks_all);
-		__syncthreads();
-		base = share[0];
-		for(uint32_t k = 0; k < w; k++) base += share[1 + k];
+		const uint64_t q0 = share[1], q1 = share[2], q2 = share[3], q3 = share[4];
+		auto chunk_bytes = [&](uint32_t ci) -> uint64_t {                  // the decoded size of another chunk of this stream: same dictionary, its codewords
+			const uint32_t cf = (ci - st.chunk0)*chunk_codes;
+			const uint32_t f_ = min(cf + w*quarter, st.csize), l_ = min(f_ + quarter, min(cf + chunk_codes, st.csize));
+			const uint32_t t = tun_wave_bytes(src, f_, l_, as_lds(L.len));
+			__syncthreads();
+			if(lane == 0) share[5 + w] = t;
+			__syncthreads();
+			return share[5] + share[6] + share[7] + share[8];
+		};
+		(void)nchunks_all;
+		base = chain_lookback(chunk_out, c, st.chunk0, q0 + q1 + q2 + q3, 512u, &share[0], chunk_bytes);
+		base += w > 0 ? q0 : 0; base += w > 1 ? q1 : 0; base += w > 2 ? q2 : 0;
 	} else base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];   // two passes: k_tun_chunk_sums + scan ran before
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
 	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(winbuf) + w*(TUN_WIN + 64);   // window byte i lives at wb[16 + i]
@@ -602,7 +591,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	__shared__ __attribute__((aligned(16))) uint32_t t16[256*(W == 1 ? 2 : W)];
 	__shared__ uint32_t longbuf[W == 4 ? 4 : 1][TUN_LONGQ];
 	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];                   // [4][(TUN_WIN + 64)/4]: 16 bytes of slack in front, 48 behind
-	__shared__ uint64_t share[5];                                                       // single pass: the chunk's offset, the four quarters' bytes
+	__shared__ uint64_t share[9];                                                       // single pass: look-back scratch, the four quarters' bytes, a recomputed predecessor's
 	if constexpr(W != 4) tun_staged_body<W, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
 	else {
 		if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);

@@ -103,6 +103,55 @@ __device__ __forceinline__ uint32_t bit_field(WordPtr w, uint32_t nwords, uint64
 	return (uint32_t)((win << sh) >> (64 - n));
 }
 
+// Look-back over the chunks [chunk0, c) of one chain (a long Tunstall stream, the log streams of one bit block): a chunk's output offset is
+// the sum of its predecessors' totals.  Every chunk publishes its own total in its state word ("total of this chunk"), later
+// "total of everything up to and including this chunk"; a chunk walks back over the words until it meets an inclusive one.
+// State words start out 0; the word IS the payload (8-byte agent-scope atomics both sides, no fences: the per-XCD L2s are not
+// coherent, sc1 accesses go to memory).
+// NOT the textbook version, which spins on a predecessor that has not published yet: that needs the predecessor to be RUNNING, and
+// MI355X promises no such thing - each XCD dispatches its share of a grid on its own, and with several launches in flight (eight
+// contexts of a decode pool) XCD A can be full of launch X's chunks waiting for a chunk that XCD B has not started because B is full
+// of launch Y's chunks waiting for one A has not started.  Measured: steps of 2.5 s (the spin's bound) in the pipelined bench.
+// Here nobody waits: a chunk that finds a predecessor's word empty works that predecessor's total out ITSELF (`recompute`, all
+// threads of the workgroup; a chunk's total is a function of its input alone) and walks on.  Polling first (`patience` reads, one
+// by thread 0 per round) is only worth it where recomputing is dear.
+constexpr uint64_t CHAIN_ST_LOCAL = 1ull << 62, CHAIN_ST_INCL = 2ull << 62, CHAIN_ST_MASK = (1ull << 62) - 1ull;
+template <class Recompute>
+__device__ __forceinline__ uint64_t chain_lookback(uint64_t *state, uint32_t c, uint32_t chunk0, uint64_t total, uint32_t patience, uint64_t *share, Recompute recompute) {
+	const bool t0 = threadIdx.x == 0;
+	if(c == chunk0) { if(t0) __hip_atomic_store(&state[c], CHAIN_ST_INCL | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+	if(t0) __hip_atomic_store(&state[c], CHAIN_ST_LOCAL | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	uint64_t prefix = 0;
+	for(uint32_t i = c - 1;; i--) {
+		__syncthreads();                                              // (share is free again)
+		if(t0) {
+			uint64_t v = 0;
+			for(uint32_t tries = 0; tries <= patience; tries++) {
+				v = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if(v >> 62) break;
+				__builtin_amdgcn_s_sleep(8);
+			}
+			*share = v;
+		}
+		__syncthreads();
+		const uint64_t v = *share;
+		if(v >> 62) {
+			prefix += v & CHAIN_ST_MASK;
+			if((v >> 62) == 2) break;
+		} else {
+			const uint64_t t = recompute(i);                            // uniform over the workgroup
+			prefix += t;
+			if(t0) {                                                     // publish it on the predecessor's behalf (the same value it would store)
+				unsigned long long expect = 0;
+				__hip_atomic_compare_exchange_strong((unsigned long long *)&state[i], &expect, (unsigned long long)(CHAIN_ST_LOCAL | t), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		if(i == chunk0) break;
+	}
+	if(t0) __hip_atomic_store(&state[c], CHAIN_ST_INCL | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return prefix;
+}
+
 // x86 cvttss2si: out-of-range / NaN -> INT_MIN (what the reference's (int) casts do on its CPU)
 __device__ __forceinline__ int32_t f2i_x86(float x) {
 	if(!(x > -2147483904.0f && x < 2147483648.0f)) return (int32_t)0x80000000;

@@ -556,6 +556,45 @@ def test_tunstall_long_streams_multi_chunk(ctx):
     assert "tunstall_chunk_sums" in times or not times  # multi-chunk path taken when profiling is on
 
 
+@pytest.mark.timeout(120)
+def test_tunstall_long_streams_on_four_contexts_at_once(ctx):
+    """the single-pass decode finds a chunk's output offset by look-back over its predecessors' state words; with several launches in
+    flight a predecessor may not have started (each XCD dispatches on its own), so nobody may WAIT for one (kernels_common.h:
+    chain_lookback recomputes instead).  Four contexts decode long streams concurrently, four rounds each: exact, and no stall."""
+    import threading, time
+    rng = np.random.default_rng(8)
+    k = _kat()
+    jobs = []
+    for t in range(4):
+        blocks, sizes, expect = [], [], []
+        for i in (3 + t, 20, 9, 37, 13, 25):
+            pr = k["probs_%02d" % i]
+            idx, ln, tab = oc.tunstall_tables(pr)
+            payload = rng.integers(0, 256, 400_000 + 1000 * t).astype(np.uint8)
+            size = int(np.asarray(ln)[payload].sum())
+            hdr = bytes([len(pr)]) + pr.tobytes() + size.to_bytes(4, "little") + len(payload).to_bytes(4, "little")
+            blocks.append(np.frombuffer(hdr + payload.tobytes(), dtype=np.uint8)); sizes.append(size)
+            expect.append(oc.tunstall_decompress(pr, payload, size))
+        jobs.append((ca.Context(0), blocks, sizes, expect))
+    errors = []
+    def work(job):
+        try:
+            c, blocks, sizes, expect = job
+            for _ in range(4):
+                outs, _ = _run_blocks(c, blocks, sizes)
+                for i, (o, e) in enumerate(zip(outs, expect)):
+                    assert np.array_equal(o, e), i
+        except BaseException as e:
+            errors.append(e)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    assert not errors, errors[0]
+    assert time.perf_counter() - t0 < 60
+    for j in jobs: j[0].close()
+
+
 def test_tunstall_long_streams_every_step_geometry(ctx):
     """the staged decode sizes a wave's step (8/4/2/1 codewords per lane) and the chunk from the stream's mean word
     length: low-entropy dictionaries (two symbols, words up to 255 bytes) down to flat ones, multi-chunk, clipped ends"""
