@@ -576,13 +576,16 @@ static int build_and_launch(crthip_batch *b) {
 		for(size_t k = 0; k < L.attrs.size(); k++)
 			if(L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && L.attrs[k].normal_prediction != 0 && !normal_fused(L.h.nvert, L.h.nface)) { est_v += L.h.nvert; est_f += L.h.nface; }
 	}
-	pl.zero_begin = cv.take(0);
-	pl.status_off = cv.take((uint64_t)nblobs*8);                        // per blob: status, then flags (TopoJob::flags)
+	// Per-blob status and flags live in the context's PINNED HOST block: the kernels write there directly (only a failing or
+	// redone blob does), the host zeroes it before the launch and reads it after the sync - no memset kernel in front of a step
+	// and no copy kernel behind it (each stretched to 50-100 us with eight batches in flight).  Prediction triples are not cleared
+	// either: the automaton writes every vertex it makes and clears the ones it never reached itself (k_mesh.hip).
 	for(uint32_t i = 0; i < nblobs; i++) {
 		const BlobLayout &L = b->blobs[i].L;
 		if(L.h.nface > 0) bs[i].pred = cv.take((uint64_t)L.h.nvert*12, 16);
 	}
-	pl.est_nvert = (uint32_t)est_v; pl.est_nface = (uint32_t)est_f;
+	pl.zero_begin = cv.take(0);                                          // zeroed by a memset, present only for big meshes: the counters of the
+	pl.est_nvert = (uint32_t)est_v; pl.est_nface = (uint32_t)est_f;      // unfused normal pipeline and the fired flags of k_delta_mesh
 	if(est_v) {
 		pl.cnt_off = cv.take(est_v*4 + 16); pl.cursor_off = cv.take(est_v*4 + 16); pl.bnd_off = cv.take(est_v*4 + 16);
 	}
@@ -601,15 +604,12 @@ static int build_and_launch(crthip_batch *b) {
 				bs[i].attr[k].fired = cv.take((((uint64_t)L.h.nvert + 15) & ~15ull) + 4ull*L.h.nvert + 16, 16);
 		}
 	}
-	{	// look-back state words of the bit-unpack chunks (k_unpack_extract): one per 1 024 logs of every bound stream, + the error word
-		uint64_t up = 0;
-		for(uint32_t i = 0; i < nblobs; i++) {
-			const BlobPlan &P = b->blobs[i];
-			for(size_t k = 0; k < P.L.attrs.size(); k++) if(P.bind[k].buffer) for(const StreamRef &lg : P.L.attrs[k].logs) up += ((uint64_t)lg.size + CHUNK - 1)/CHUNK;
-		}
-		pl.unpack_partial_off = cv.take((up + 1)*8);
-	}
 	pl.zero_end = cv.take(0);
+	uint64_t unpack_state_words = 1;                                      // look-back state words of the bit-unpack chunks (k_unpack_extract): one per
+	for(uint32_t i = 0; i < nblobs; i++) {                              // 1 024 logs of every bound stream, + a spare; uploaded as zeros with the jobs
+		const BlobPlan &P = b->blobs[i];
+		for(size_t k = 0; k < P.L.attrs.size(); k++) if(P.bind[k].buffer) for(const StreamRef &lg : P.L.attrs[k].logs) unpack_state_words += ((uint64_t)lg.size + CHUNK - 1)/CHUNK;
+	}
 	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0;
 
 	auto need_stream = [&](const StreamRef &s, uint64_t &sym_off) {
@@ -661,6 +661,10 @@ static int build_and_launch(crthip_batch *b) {
 	// ---- pass 2: job structs with offsets stored in pointer fields (rebased after the block is reserved) ----
 	// To keep one pass, pointers are built as (uint8_t*)offset and fixed up by adding the scratch base.
 	auto SP = [](uint64_t off) { return (uint8_t *)(uintptr_t)off; };   // scratch-relative pseudo pointer
+	if((size_t)nblobs*8 + 16 > ctx->status_host.cap && harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);   // the block is about to move: the batch in flight writes to it
+	if(ctx->status_host.reserve((size_t)nblobs*8 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	int32_t *const hs_base = (int32_t *)ctx->status_host.p;
+	auto HS = [&](uint64_t k) { return (int32_t *)((uintptr_t)(hs_base + k) | (1ull << 63)); };   // real pointer (bit 63: R() leaves it alone)
 
 	uint32_t tun_chunks = 0, unpack_chunks = 0, cloud_chunks = 0;
 	auto add_stream = [&](const StreamRef &s, uint64_t sym_off, uint64_t blob_off) -> const uint8_t * {
@@ -712,8 +716,8 @@ static int build_and_launch(crthip_batch *b) {
 			t.pred = (uint32_t *)SP(S.pred);
 			t.front_a = (uint4 *)SP(S.front_a); t.front_b = (uint2 *)SP(S.front_b);
 			t.order = (uint32_t *)SP(S.order); t.delayed = (uint32_t *)SP(S.delayed);
-			t.status = (int32_t *)SP(pl.status_off + (uint64_t)i*4);
-			t.flags = (int32_t *)SP(pl.status_off + (uint64_t)(nblobs + i)*4);
+			t.status = HS(i);
+			t.flags = HS(nblobs + i);
 			t.nclers = L.clers.size; t.split_nwords = L.split.nwords; t.ngroups = (uint32_t)L.group_end.size();
 			t.nvert = nvert; t.nface = nface; t.front_cap = S.front_cap; t.faces_u16 = P.index ? P.index_u16 : 0;
 			t.pad = P.index ? 1u : 0u;                                   // pad = 1: faces is a real pointer
@@ -806,7 +810,7 @@ static int build_and_launch(crthip_batch *b) {
 					n.out_stride = bd.stride ? bd.stride : (bd.format == CRTHIP_FMT_INT16 ? 6u : 12u);
 					n.ndiffs = std::min(as.logs[0].size, nvert); n.unit = f2i_x86_host(a.q);
 					n.prediction = (uint8_t)pr; n.out_i16 = bd.format == CRTHIP_FMT_INT16;
-					n.status = (int32_t *)SP(pl.status_off + (uint64_t)i*4);
+					n.status = HS(i);
 					if(pr != 0) {
 						const bool pos_ok = pos_k >= 0 && L.h.attrs[pos_k].codec == CRTHIP_CODEC_GENERIC && L.h.attrs[pos_k].N == 3 && P.bind[pos_k].buffer;
 						if(!pos_ok) { P.host_status = CRTHIP_E_NORMAL_NEEDS_POSITION; continue; }
@@ -855,6 +859,7 @@ static int build_and_launch(crthip_batch *b) {
 
 	// job arrays region
 	pl.jobs_begin = cv.take(0);
+	pl.unpack_partial_off = cv.take(unpack_state_words*8, 16);           // (first thing in the uploaded block: zeros)
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
 	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
@@ -923,6 +928,8 @@ static int build_and_launch(crthip_batch *b) {
 
 	// host image -> device (one copy)
 	uint8_t *stage = (uint8_t *)ctx->staging.p;
+	memset(stage + (pl.unpack_partial_off - pl.jobs_begin), 0, unpack_state_words*8);
+	memset(ctx->status_host.p, 0, (size_t)nblobs*8);                       // (after the harvest above: the previous batch's words have been read)
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
 	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
 	put(pl.delta); put(pl.delta_groups); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
@@ -1039,10 +1046,7 @@ static int build_and_launch(crthip_batch *b) {
 	const uint32_t ndq = (uint32_t)pl.dequant_block_job.v.size();
 	if(ndq) { LT.begin("dequantize"); hipLaunchKernelGGL(k_dequant, dim3(ndq), dim3(256), 0, st, D(pl.dequant), D(pl.dequant_block_job), ndq); LT.end(); }
 
-	// status back to the host
-	if(ctx->status_host.reserve((size_t)nblobs*8 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-	if(nblobs) HIP_TRY(hipMemcpyAsync(ctx->status_host.p, base + pl.status_off, (size_t)nblobs*8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipGetLastError());                                            // (status: written by the kernels straight into the pinned block)
 
 	// stats
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun;

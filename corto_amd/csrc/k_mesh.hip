@@ -222,6 +222,9 @@ __device__ void topo_run(const TopoJob &J, ClersPtr clers, Front &F) {
 		topo_group(S, F, start*3, ge*3);
 		start = ge;
 	}
+	// vertices the stream never made keep the prediction (0, 0, 0), as in the reference's zero-filled vector (src/decoder.cpp:171): the
+	// scratch block is not cleared in front of a batch, so the automaton finishes the array itself (nothing to do for a valid stream)
+	for(uint32_t v = S.vertex_count; v < J.nvert; v++) S.predict(v, 0, 0, 0);
 	if(S.err) *as_global(J.status) = S.err;
 }
 
@@ -1124,6 +1127,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 		}
 	}
 	if(err == 2) return false;
+	for(uint32_t v = vc; v < nvert; v++) { CRT_GLOBAL uint32_t *p_ = (CRT_GLOBAL uint32_t *)(predb + (size_t)v*12u); p_[0] = 0; p_[1] = 0; p_[2] = 0; }   // never reached: (0, 0, 0) (see topo_run)
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
 	return true;
 }
