@@ -215,6 +215,7 @@ struct crthip_ctx {
 	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: chunk sums + scan + decode instead of the single pass with look-back (A/B measurements)
 	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
 	uint8_t exp_delta_walk = 0;                       // experiments: $CORTO_EXP_DELTA_WALK=1 - K-DELTA without the scan passes
+	uint8_t exp_no_deq_fold = 0;                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
 	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
 	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
@@ -325,6 +326,7 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	if(c->tun_side && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE); }   // (a stream is a hardware queue: not made unless asked for)
 	{ const char *e = getenv("CORTO_EXP_NORMAL_FN_MAX"); if(e) c->exp_normal_fn_max = (uint32_t)atoi(e); }
 	{ const char *e = getenv("CORTO_EXP_DELTA_WALK"); c->exp_delta_walk = e && e[0] == '1'; }
+	{ const char *e = getenv("CORTO_EXP_NO_DEQ_FOLD"); c->exp_no_deq_fold = e && e[0] == '1'; }
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
@@ -743,6 +745,17 @@ static int build_and_launch(crthip_batch *b) {
 		// position attribute (needed by ESTIMATED/BORDER normals)
 		int pos_k = -1;
 		for(size_t k = 0; k < L.attrs.size(); k++) if(L.h.attrs[k].name == "position") pos_k = (int)k;
+		// who turns the integer positions into floats: estimated normals read them as integers after K-DELTA, so the fused normal
+		// kernel does it as their last reader (pos_by_normal), the separate normal kernels leave it to k_dequant behind them, and
+		// without such normals K-DELTA does it on the way out of LDS like for every other attribute
+		bool pos_ints_needed = false, pos_by_normal = false;
+		{
+			uint32_t readers = 0;
+			for(size_t k = 0; k < L.attrs.size(); k++)
+				if(mesh && L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && (L.attrs[k].normal_prediction == 1 || L.attrs[k].normal_prediction == 2)) readers++;
+			pos_ints_needed = readers > 0;
+			pos_by_normal = readers == 1 && !ctx->exp_no_deq_fold && normal_fused(nvert, nface);
+		}
 
 		for(size_t k = 0; k < L.attrs.size(); k++) {
 			const AttrHeader &a = L.h.attrs[k];
@@ -786,12 +799,20 @@ static int build_and_launch(crthip_batch *b) {
 				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], work, work_real, 1, 1, (uint16_t)a.N, (uint16_t)c, 0);
 				values = work; values_real = work_real; para = (a.strategy & CRTHIP_PARALLEL) != 0;
 			}
+			bool dequantised = false;                                // by K-DELTA or by the fused normal kernel: no k_dequant job
 			if(do_delta && nvert > 1) {
 				if(mesh) {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->exp_delta_walk;   // pad[1]: experiments - the flag-driven walk only
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
+					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d) == 2 && !ctx->exp_no_deq_fold) {
+						if(a.codec == CRTHIP_CODEC_COLOR) {
+							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;
+							for(int c = 0; c < 4; c++) d.qc[c] = as.qc[c];
+							dequantised = true;
+						} else if(!bd.stride && !((int)k == pos_k && pos_ints_needed)) { d.deq = 1; d.q = a.q; dequantised = true; }
+					}
 					pl.delta.v.push_back(d);
 				} else {
 					CloudJob c{};
@@ -820,6 +841,7 @@ static int build_and_launch(crthip_batch *b) {
 						n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0) | (pos_scratch ? 0x40 : 0));   // bit7: faces is a real pointer, bit6: position is a scratch offset (both cleared at fixup)
 						if(normal_fused(nvert, nface)) {
 							n.fused = 1;
+							if(pos_by_normal) { n.pos_out = P.bind[pos_k].buffer; n.pos_stride = P.bind[pos_k].stride ? P.bind[pos_k].stride : 12u; n.pos_q = L.h.attrs[pos_k].q; }
 							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
 							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= ctx->exp_normal_fn_max ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
 						} else {
@@ -829,7 +851,7 @@ static int build_and_launch(crthip_batch *b) {
 					} else pl.any_diff_normal = true;
 					pl.normal.v.push_back(n);
 				}
-			} else {
+			} else if(!dequantised && !((int)k == pos_k && pos_by_normal)) {
 				DequantJob q{};
 				q.buffer = bd.buffer; q.q = a.q; q.nvert = nvert; q.N = a.N; q.out_components = bd.out_components;
 				for(int c = 0; c < 4; c++) q.qc[c] = as.qc[c];

@@ -101,7 +101,13 @@ struct DeltaJob {
 	uint8_t *fired;                // nvert zeroed flags in HBM, used only when values + flags do not fit LDS
 	uint32_t nvert, N;
 	uint8_t parallelogram, is_u8, pad[2];
-	uint32_t pad2;
+	// k_delta_wave can finish the attribute on its way out of LDS (no k_dequant launch, no second trip through HBM):
+	uint32_t deq;                  // 0: write the integers back; 1: generic, packed: (float)v*q in place (vertex_attribute.h:190-193);
+	                               // 2: colour: YCC -> RGB x qc into `out` (color_attribute.cpp:76-95)
+	float q;
+	uint32_t qc[4];
+	void *out;                     // colour destination
+	uint32_t out_components, out_stride;
 };
 
 // point-cloud running sum, one job per (blob, attribute) (vertex_attribute.h:177-181, normal_attribute.cpp:202-207)
@@ -123,6 +129,10 @@ struct NormalJob {
 	uint8_t prediction, out_i16, faces_u16, fused;   // fused: handled by k_normal_blob (whole pipeline in one workgroup)
 	int32_t *status;
 	uint32_t out_stride;           // bytes from one vertex's normal to the next (12 or 6 when packed)
+	// k_normal_blob is the last reader of the integer positions and turns them into floats itself (no k_dequant launch):
+	uint32_t pos_stride;           // bytes from one vertex to the next in pos_out (12 = packed, in place when pos_out == position)
+	void *pos_out;                 // null: leave the positions alone
+	float pos_q;
 	uint32_t pad;
 };
 

@@ -1404,6 +1404,43 @@ __device__ __forceinline__ void delta_stage_copy(const DeltaStage &S) {
 	for(uint32_t i = S.head + S.nvec*16 + lane; i < S.bytes; i += 64) { if(IN) S.l8[i] = S.g8[i]; else S.g8[i] = S.l8[i]; }
 }
 
+// a generic attribute leaves LDS as floats: (float)v*q, in place of the integers (vertex_attribute.h:190-193)
+__device__ __forceinline__ void delta_stage_out_float(const DeltaStage &S, float q) {
+	const uint32_t lane = lane_id();
+	typedef float f32x4_t __attribute__((ext_vector_type(4)));
+	CRT_GLOBAL f32x4_t *g4 = (CRT_GLOBAL f32x4_t *)(S.g8 + S.head);
+	CRT_LDS u32x4 *l4 = (CRT_LDS u32x4 *)(S.l8 + S.head);
+	for(uint32_t i = lane; i < S.nvec; i += 64*8) {
+		u32x4 t[8];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) t[u] = l4[i + u*64];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) {
+			f32x4_t f;
+			f.x = (float)(int32_t)t[u].x*q; f.y = (float)(int32_t)t[u].y*q; f.z = (float)(int32_t)t[u].z*q; f.w = (float)(int32_t)t[u].w*q;
+			g4[i + u*64] = f;
+		}
+	}
+	// heads and tails are whole dwords (the caller's ints are 4-byte aligned)
+	for(uint32_t i = lane*4; i + 3 < S.head; i += 256) *(CRT_GLOBAL float *)(S.g8 + i) = (float)*(CRT_LDS const int32_t *)(S.l8 + i)*q;
+	for(uint32_t i = S.head + S.nvec*16 + lane*4; i + 3 < S.bytes; i += 256) *(CRT_GLOBAL float *)(S.g8 + i) = (float)*(CRT_LDS const int32_t *)(S.l8 + i)*q;
+}
+
+// a colour attribute leaves LDS as RGB(A): (r, g, b, a) = (v2 + v0, v0, v1 + v0, v3) x qc, u8 wrap (color_attribute.cpp:76-95, point.h:214)
+__device__ __forceinline__ void delta_stage_out_color(CRT_LDS const uint8_t *v, const DeltaJob &J) {
+	CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
+	const uint32_t N = J.N, oc = J.out_components, stride = J.out_stride ? J.out_stride : oc;
+	for(uint32_t i = lane_id(); i < J.nvert; i += 64) {
+		uint32_t col[4] = {0, 0, 0, 255};
+		for(uint32_t c = 0; c < N && c < 4; c++) col[c] = v[i*N + c];
+		const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
+		CRT_GLOBAL uint8_t *o = dst + (size_t)i*stride;
+		if(oc == 4 && (((uintptr_t)o) & 3) == 0)
+			*(CRT_GLOBAL uint32_t *)o = ((rgb[0]*J.qc[0]) & 255u) | ((rgb[1]*J.qc[1]) & 255u) << 8 | ((rgb[2]*J.qc[2]) & 255u) << 16 | ((rgb[3]*J.qc[3]) & 255u) << 24;
+		else for(uint32_t c = 0; c < oc && c < 4; c++) o[c] = (uint8_t)(rgb[c]*J.qc[c]);
+	}
+}
+
 // One workgroup per blob: up to four attributes share the prediction graph in LDS (a | b,c | stretch starts), one wave each walks
 // it with its own fired flags; the graph is made by the first wave that has no attribute (or by wave 0 before its own staging).
 __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__ jobs, const DeltaGroup *__restrict__ groups, uint32_t ngroups) {
@@ -1485,7 +1522,9 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 		}
 #undef CRT_DELTA
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		delta_stage_copy<false>(S);
+		if(J.deq == 1 && !J.is_u8 && ((S.head | (uint32_t)(uintptr_t)S.g8) & 3u) == 0) delta_stage_out_float(S, J.q);
+		else if(J.deq == 2 && J.is_u8) delta_stage_out_color(S.l8, J);
+		else delta_stage_copy<false>(S);
 	}
 }
 

@@ -239,6 +239,18 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	}
 	if(bad) *as_global(J.status) = -5;
 	__syncthreads();
+	// the integer positions have been read for the last time when the face normals sit in LDS: they become floats now (in place, or
+	// into an interleaved vertex buffer), while the rest of the kernel works from LDS; otherwise at the very end (below)
+	auto positions_out = [&]() {
+		if(!J.pos_out) return;
+		CRT_GLOBAL uint8_t *po = as_global((uint8_t *)J.pos_out);
+		for(uint32_t e = tid; e < 3*nv; e += 256) {
+			const uint32_t i = e/3, c = e - 3*i;
+			const float f = (float)pos[e];
+			*(CRT_GLOBAL float *)(po + (size_t)i*J.pos_stride + 4u*c) = f*J.pos_q;
+		}
+	};
+	if(fn_lds) positions_out();
 	// two block-wide exclusive scans over the vertices: CSR offsets of cnt, and correction slots of the flags
 	const uint32_t per = (nv + 255)/256;
 	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint16_t *out, bool flags) {
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
 		}
 	}
+	if(!fn_lds) { __syncthreads(); positions_out(); }
 }
 
 } // namespace corto_hip
