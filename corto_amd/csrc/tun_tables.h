@@ -15,16 +15,16 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 	const uint32_t n = st.nsym;                 // 2..255 (host guarantees)
 	const uint32_t lane = threadIdx.x;
 
-	__shared__ uint16_t eprob[TUN_ENTRY_CAP];   // entry e (creation order) lives in FIFO row e % n; probabilities are 16-bit ((a*b) >> 16 of 16-bit factors)
+	__shared__ uint32_t epl[TUN_ENTRY_CAP];     // entry e (creation order) lives in FIFO row e % n.  Low half: its probability, 16-bit ((a*b) >> 16 of 16-bit
+	                                            // factors); high half: its length (n <= 64: | last symbol << 8) - one LDS read serves both
 	__shared__ uint16_t eoff[TUN_ENTRY_CAP];
-	__shared__ uint16_t elen[TUN_ENTRY_CAP];
 	__shared__ uint16_t head[256];              // oldest not-yet-expanded entry of each row
 	__shared__ uint16_t P[256];                 // probability << 8  (16.16-ish fixed point)
 	__shared__ uint16_t pw[256];                // P0^k (successive (a*b)>>16), low-entropy seed only
 	__shared__ uint8_t sym[256];
 
 	for(uint32_t i = lane; i < n; i += 64) { sym[i] = probs[2*i]; P[i] = (uint32_t)probs[2*i + 1] << 8; }
-	for(uint32_t i = lane; i < TUN_ENTRY_CAP; i += 64) { eprob[i] = 0; eoff[i] = 0; elen[i] = 0; }
+	for(uint32_t i = lane; i < TUN_ENTRY_CAP; i += 64) { epl[i] = 0; eoff[i] = 0; }
 	__syncthreads();
 
 	// how long a run of the likeliest symbol stays likelier than the runner-up (tunstall.cpp:143-151)
@@ -51,19 +51,19 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		for(uint32_t e = lane; e < count*n; e += 64) {
 			const uint32_t col = e/n, row = e - col*n;
 			if(row == 0) continue;
-			eprob[e] = (uint16_t)(col == 0 ? (uint32_t)P[row] : ((uint32_t)pw[col]*(uint32_t)P[row]) >> 16);
+			const uint32_t pr = col == 0 ? (uint32_t)P[row] : ((uint32_t)pw[col]*(uint32_t)P[row]) >> 16;
 			eoff[e] = (uint16_t)(row*count - col);
-			elen[e] = (uint16_t)((col + 1) | (row << 8));     // high byte: row = last symbol (used by the n <= 64 path)
+			epl[e] = (pr & 0xFFFFu) | ((col + 1) | ((uint32_t)sym[row] << 8)) << 16;     // (last symbol: used by the n <= 64 path)
 		}
 		for(uint32_t k = lane; k < n; k += 64) head[k] = (uint16_t)(k == 0 ? (count - 1)*n : k);
 		__syncthreads();
-		if(lane == 0) { const uint32_t first = (count - 1)*n; eprob[first] = pw[count]; eoff[first] = 0; elen[first] = (uint16_t)count; }
+		if(lane == 0) { const uint32_t first = (count - 1)*n; epl[first] = (uint32_t)pw[count] | (count | (uint32_t)A << 8) << 16; eoff[first] = 0; }
 		nwords = 1 + count*(n - 1);
 		end = count*n;
 		pos = total;
 	} else {                                    // one-symbol words (tunstall.cpp:195-205)
 		for(uint32_t i = lane; i < n; i += 64) {
-			head[i] = (uint16_t)i; eprob[i] = P[i]; eoff[i] = (uint16_t)i; elen[i] = (uint16_t)(1u | (i << 8)); buf[i] = sym[i];
+			head[i] = (uint16_t)i; epl[i] = (uint32_t)P[i] | (1u | ((uint32_t)sym[i] << 8)) << 16; eoff[i] = (uint16_t)i; buf[i] = sym[i];
 		}
 		nwords = n; end = n; pos = n;
 	}
@@ -76,33 +76,73 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		// probability, length) in registers, so picking the likeliest head is a register-only wave reduction.  A child is
 		// recorded as (parent entry, row) - no bytes are copied while the dictionary grows; the 256 surviving words are
 		// spelled out once at the end by walking up to the seed.  For the entries made here eoff[] holds the PARENT ENTRY and
-		// the high byte of elen[] the row (= index of the last symbol).                                  tunstall.cpp:207-241
-		uint32_t h = lane < n ? head[lane] : 0xFFFFu, hp = 0, hl = 0;
-		if(lane < n && h < TUN_ENTRY_CAP) { hp = eprob[h]; hl = elen[h] & 255u; }
-		const uint32_t myP = lane < n ? P[lane] : 0u;
-		while(nwords < 256) {
-			// likeliest head, first row wins ties, all-zero -> row 0: one DPP wave reduction + readlane broadcasts
-			const uint32_t key = wave_max_u32(hp ? ((hp << 16) | (0xFFFFu - lane)) : 0u);
-			const uint32_t best = (key >> 16) ? 0xFFFFu - (key & 0xFFFFu) : 0u;
-			const uint32_t parent = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)best);
-			if(parent >= TUN_ENTRY_CAP) break;                                    // malformed probabilities
-			const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)hp, (int)best), pl = (uint32_t)__builtin_amdgcn_readlane((int)hl, (int)best);
-			const bool full = nwords + n > 255;                                   // dictionary fills up during this expansion: parent stays
-			const uint32_t m = full ? 256 - nwords : n;
-			const uint32_t tot = m*(pl + 1);
-			if(end + m > TUN_ENTRY_CAP || pos + tot > TUN_TABLE_BYTES) break;     // where the reference's buffers would overflow
-			if(lane < m) {
-				const uint32_t e = end + lane, cp = (pp*myP) >> 16;
-				eprob[e] = (uint16_t)cp; eoff[e] = (uint16_t)parent; elen[e] = (uint16_t)((pl + 1) | (lane << 8));
-				if(h == e) { hp = cp; hl = pl + 1; }                              // the row's FIFO was empty: the child is its new head
-			}
-			asm volatile("" ::: "memory");                                        // one wave: LDS executes in program order
-			if(!full && lane == best) {                                            // parent fully expanded: pop it
-				h = parent + n;
-				if(h < end + m && h < TUN_ENTRY_CAP) { hp = eprob[h]; hl = elen[h] & 255u; } else { hp = 0; hl = 0; }
-			}
-			end += m; pos += tot; nwords += n - 1;
+		// the top byte of epl[] the word's last symbol.                                    tunstall.cpp:207-241
+		// The loop runs up to 254 times (two symbols) and one wave issues an instruction every four clocks at best, so its length in
+		// INSTRUCTIONS is what a short stream's decode costs; per lane r < n, packed for few selects:
+		//   K   head key: probability << 16 | (0xFFFF - r), probability 0 when the FIFO is empty   (max = likeliest head, first row on ties,
+		//       row 0 when all are zero)                 HL  head entry (or, FIFO empty, the entry the row's next child will be) | length << 16
+		//   NR  the record (epl[] format) of the entry behind the head, or 0       NX  that entry's index       E  the lane's next child entry
+		// A row's FIFO is the children lane r made, in order, so head and next stay in registers: the record behind the new next is read
+		// from LDS when a head is popped and merged an iteration later - no LDS round trip on the critical path.  Bounds: end <= 510 + n
+		// whatever the probabilities (every expansion adds n entries and n - 1 words), so HL < 640 and NX < 704 < TUN_ENTRY_CAP - 1;
+		// lanes >= n write their (ignored) child to the spare entry TUN_ENTRY_CAP - 1.
+		const bool rowlane = lane < n;
+		const uint32_t rowc = 0xFFFFu - lane;
+		const uint32_t myP = rowlane ? P[lane] : 0u, sym24 = rowlane ? (uint32_t)sym[lane] << 24 : 0u;
+		uint32_t K = 0, HL = 0xFFFFu, NR = 0, NX = 0xFFFFu, LD = 0;
+		if(rowlane) {
+			const uint32_t h = head[lane], v = epl[h];
+			K = (v << 16) | rowc; HL = h | (v & 0xFF0000u); NX = h + n;
+			if(h + n < end) NR = epl[h + n];
 		}
+		uint32_t E = rowlane ? end + lane : TUN_ENTRY_CAP - 1;
+		const uint32_t inc = rowlane ? n : 0u;
+		__builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): no LDS read pending into the loop (its waits would land on the loop's top)
+		const uint32_t width = n <= 4 ? 4u : n <= 16 ? 16u : 64u;                  // lanes that can hold a row
+		auto likeliest = [&](uint32_t key) -> uint32_t {
+			if(width == 64) return wave_max_u32(key);
+#define CRT_DPP_MAX(ctrl) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, ctrl, 0xf, 0xf, false); key = o_ > key ? o_ : key; }
+			CRT_DPP_MAX(0xB1) CRT_DPP_MAX(0x4E)                                   // quad_perm [1,0,3,2], [2,3,0,1]
+			if(width == 16) { CRT_DPP_MAX(0x141) CRT_DPP_MAX(0x140) }             // row_half_mirror, row_mirror
+#undef CRT_DPP_MAX
+			return (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+		};
+		bool pend = false;
+		uint32_t whole = nwords + n <= 255 ? (255 - n - nwords)/(n - 1) + 1 : 0;   // expansions that pop their parent
+		nwords += whole*(n - 1); end += whole*n;
+		for(; whole; whole--) {
+			const uint32_t key = likeliest(K);
+			const uint32_t best = 0xFFFFu & ~key;
+			const uint32_t hq = (uint32_t)__builtin_amdgcn_readlane((int)HL, (int)best);
+			const uint32_t parent = hq & 0xFFFFu, len1 = (hq & 0xFF0000u) + 0x10000u;   // the children's length, in place
+			const uint32_t t = __umul24(key >> 16, myP);                          // child probability = t >> 16
+			const uint32_t recv = (t >> 16) | sym24 | len1;
+			epl[E] = recv; eoff[E] = (uint16_t)parent;
+			asm volatile("" ::: "memory");                                        // one wave: LDS executes in program order
+			NR = pend ? LD : NR; pend = false;                                    // (the read issued by the previous pop)
+			const bool is_head = (HL & 0xFFFFu) == E;                             // the row's FIFO was empty: the child is its head
+			K = is_head ? ((t & 0xFFFF0000u) | rowc) : K;
+			HL = is_head ? (E | len1) : HL;
+			NR = NX == E ? recv : NR;                                             // ... held only its head: the child is next
+			if(lane == best) {                                                     // the parent is fully expanded: pop it
+				const uint32_t hnew = parent + n;
+				K = (NR << 16) | rowc; HL = hnew | (NR & 0xFF0000u);
+				NX = hnew + n;
+				LD = epl[NX]; pend = true;                                        // (zero behind the last entry)
+			}
+			E += inc;
+		}
+		NR = pend ? LD : NR;
+		if(nwords < 256) {                                                        // the dictionary fills up during the last expansion: its parent stays
+			const uint32_t m = 256 - nwords;
+			const uint32_t key = likeliest(K);
+			const uint32_t best = 0xFFFFu & ~key;
+			const uint32_t hq = (uint32_t)__builtin_amdgcn_readlane((int)HL, (int)best);
+			const uint32_t t = __umul24(key >> 16, myP);
+			if(lane < m) { epl[E] = (t >> 16) | sym24 | ((hq & 0xFF0000u) + 0x10000u); eoff[E] = (uint16_t)(hq & 0xFFFFu); }
+			end += m; nwords = 256;
+		}
+		const uint32_t h = HL & 0xFFFFu;
 		if(lane < n) head[lane] = (uint16_t)min(h, 0xFFFFu);
 		__syncthreads();
 	} else
@@ -111,7 +151,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		uint32_t key = 0;
 		for(uint32_t r = lane; r < n; r += 64) {
 			const uint32_t h = head[r];
-			const uint32_t p = h < TUN_ENTRY_CAP ? eprob[h] : 0u;
+			const uint32_t p = h < TUN_ENTRY_CAP ? epl[h] & 0xFFFFu : 0u;
 			const uint32_t k = p ? ((p << 16) | (0xFFFFu - r)) : 0u;
 			key = k > key ? k : key;
 		}
@@ -120,16 +160,15 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		const uint32_t best = (key >> 16) ? 0xFFFFu - (key & 0xFFFFu) : 0u;
 		const uint32_t parent = head[best];
 		if(parent >= TUN_ENTRY_CAP) break;      // malformed probabilities (reference: out-of-bounds read)
-		const uint32_t pp = eprob[parent], po = eoff[parent], pl = elen[parent];
+		const uint32_t pp = epl[parent] & 0xFFFFu, po = eoff[parent], pl = (epl[parent] >> 16) & 255u;   // (a seed's top byte is its symbol)
 		const bool full = nwords + n > 255;     // dictionary fills up during this expansion: parent stays
 		const uint32_t m = full ? 256 - nwords : n;
 		const uint32_t tot = m*(pl + 1);
 		if(end + m > TUN_ENTRY_CAP || pos + tot > TUN_TABLE_BYTES) break;
 		for(uint32_t r = lane; r < m; r += 64) {
 			const uint32_t e = end + r;
-			eprob[e] = (pp*P[r]) >> 16;
+			epl[e] = (((pp*P[r]) >> 16) & 0xFFFFu) | (pl + 1) << 16;
 			eoff[e] = (uint16_t)(pos + r*(pl + 1));
-			elen[e] = (uint16_t)(pl + 1);
 		}
 		for(uint32_t b = lane; b < tot; b += 64) {   // child r = parent bytes + sym[r]
 			const uint32_t r = b/(pl + 1), j = b - r*(pl + 1);
@@ -155,21 +194,24 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		const uint64_t mask = __ballot(alive);
 		const uint32_t rank = w + __popcll(mask & ((1ull << lane) - 1ull));
 		const bool take = alive && rank < 256;
-		const uint32_t len = take ? (uint32_t)elen[e] & 255u : 0u;
+		const uint32_t len_ = take ? (epl[e] >> 16) & 255u : 0u;
 		const bool made = tree && take && e >= seed_end;                  // spelled out here
-		const uint32_t incl = wave_inclusive_scan_u32(made ? len : 0u);
-		const uint32_t off = made ? wpos + incl - len : take ? (uint32_t)eoff[e] : 0u;
+		const uint32_t incl = wave_inclusive_scan_u32(made ? len_ : 0u);
+		uint32_t off = made ? wpos + incl - len_ : take ? (uint32_t)eoff[e] : 0u;
 		wpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		const bool fits = off + len_ <= TUN_TABLE_BYTES;                    // (always, on streams the reference decodes without overrunning its own buffer)
+		if(!fits) { off = 0; }
+		const uint32_t len = fits ? len_ : 0u;
 		if(take) {
 			if(Tg) { T.off[rank] = (uint16_t)off; T.len[rank] = (uint8_t)len; } else { loff[rank] = (uint16_t)off; llen[rank] = (uint8_t)len; }
 			used = off + len > used ? off + len : used;
 			maxlen = len > maxlen ? len : maxlen;
 		}
-		if(made) {
+		if(made && len) {
 			uint32_t cur = e, j = off + len;
-			while(cur >= seed_end) { const uint32_t lr = elen[cur]; buf[--j] = sym[lr >> 8]; cur = eoff[cur]; }
-			const uint32_t lr = elen[cur];
-			buf[--j] = sym[lr >> 8];
+			while(cur >= seed_end && j > off + 1) { const uint32_t lr = epl[cur]; buf[--j] = (uint8_t)(lr >> 24); cur = eoff[cur]; }
+			const uint32_t lr = epl[cur];
+			buf[--j] = (uint8_t)(lr >> 24);
 			while(j > off) buf[--j] = A;
 		}
 		w += __popcll(mask);

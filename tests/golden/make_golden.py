@@ -31,58 +31,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from cases import cases  # noqa: E402
 
 
-def main():
-    only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None   # add a case without rewriting the others
-    index = []
-    for name, mesh, kw in cases():
-        if only is not None and name not in only:
-            continue
-        blob = rc.encode(mesh, **kw)
-        cc = mesh.color.shape[1] if mesh.color is not None and kw.get("with_color", True) else 4
-        ref = rc.decode_trace(blob, color_components=cc)
-        ref16 = rc.decode(blob, normal_format=rc.INT16, color_components=cc, index16=ref["nvert"] < 65536)
-        d = {"crt": np.asarray(blob).copy()}
-        for k, v in ref.items():
-            if isinstance(v, np.ndarray):
-                d[k] = v
-        d["_max_front"] = np.array(ref["_max_front"])
-        if "normal" in ref16:
-            d["normal_i16"] = ref16["normal"]
-        if "index" in ref16 and ref16["index"].dtype == np.uint16:
-            d["index_u16_sha256"] = np.frombuffer(sha(ref16["index"]).encode(), dtype=np.uint8)
-        d["color_components"] = np.array(cc)
-        # index.groups as the reference Decoder reports them after decode(): "end\tkey=value\tkey=value" per group, one group per line
-        d["groups_ref"] = np.frombuffer("\n".join("\t".join([str(e)] + ["%s=%s" % kv for kv in p.items()]) for e, p in rc.groups(blob)).encode(), dtype=np.uint8)
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
-        index.append((name, len(blob), ref["nvert"], ref["nface"]))
-        print("%-20s crt %7d B  nvert %6d nface %6d" % index[-1])
-
-    if only is not None:
-        return
-    # mid-size mesh (C1-class, 34 060 verts / 67 600 tris): blob + digests only
-    m = synth.bumpy_sphere(260, 130, seed=34)
-    blob = rc.encode(m, normal_prediction=rc.BORDER)
-    ref = rc.decode(blob)
-    d = {"crt": np.asarray(blob).copy()}
-    for k, v in ref.items():
-        if isinstance(v, np.ndarray):
-            d[k + "_sha256"] = np.frombuffer(sha(v).encode(), dtype=np.uint8)
-    d["nvert"] = np.array(ref["nvert"]); d["nface"] = np.array(ref["nface"])
-    np.savez_compressed(os.path.join(OUT, "mid34k_digest.npz"), **d)
-    print("mid34k_digest        crt %7d B  nvert %6d nface %6d" % (len(blob), ref["nvert"], ref["nface"]))
-
-    # 16 distinct C4-unit blobs (seeds 0..15) for bench / batch tests: blobs + per-array digests
-    d = {}
-    for seed in range(16):
-        m = synth.bumpy_sphere(64, 32, seed=seed)
-        blob = rc.encode(m, normal_prediction=rc.BORDER)
-        ref = rc.decode(blob)
-        d["crt_%02d" % seed] = np.asarray(blob).copy()
-        for k in ("position", "normal", "color", "uv", "index"):
-            d["%s_sha256_%02d" % (k, seed)] = np.frombuffer(sha(ref[k]).encode(), dtype=np.uint8)
-    np.savez_compressed(os.path.join(OUT, "c4_blobs16.npz"), **d)
-    print("c4_blobs16           %d blobs" % 16)
-
+def tunstall_kat():
     # Tunstall known-answer tables (createDecodingTables2) incl. the low-entropy branch, ties, zero tails
     rng = np.random.default_rng(20250926)
     kats = {}
@@ -101,6 +50,16 @@ def main():
         else:
             p = np.sort((255 * rng.dirichlet(np.ones(n) * 4)).astype(int))[::-1]
         plist.append(np.stack([rng.permutation(256)[:n], np.clip(p, 0, 255)], 1))
+    # alphabets above 64 symbols (the device's general path: two or three expansions, seeds among the parents)
+    rng65 = np.random.default_rng(65)
+    for n, kind in ((65, 0), (66, 1), (70, 2), (90, 0), (100, 1), (127, 2), (128, 0), (129, 1), (200, 0)):
+        if kind == 0:
+            p = np.sort(rng65.integers(1, 8, n))[::-1]
+        elif kind == 1:
+            p = np.array([120, 60, 30] + [1] * (n - 3))
+        else:
+            p = np.sort((255 * rng65.dirichlet(np.ones(n) * 0.5)).astype(int))[::-1]
+        plist.append(np.stack([rng65.permutation(256)[:n], np.clip(p, 0, 255)], 1))
     for i, pr in enumerate(plist):
         pr = pr.astype(np.uint8)
         idx, ln, tab = rc.tunstall_tables(pr)
@@ -129,6 +88,63 @@ def main():
         kats["stream_symbols_%d" % i] = sym
     np.savez_compressed(os.path.join(OUT, "tunstall_kat.npz"), **kats)
     print("tunstall_kat         %d tables, 8 streams" % len(plist))
+
+
+def main():
+    only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None   # add a case without rewriting the others
+    index = []
+    for name, mesh, kw in cases():
+        if only is not None and name not in only:
+            continue
+        blob = rc.encode(mesh, **kw)
+        cc = mesh.color.shape[1] if mesh.color is not None and kw.get("with_color", True) else 4
+        ref = rc.decode_trace(blob, color_components=cc)
+        ref16 = rc.decode(blob, normal_format=rc.INT16, color_components=cc, index16=ref["nvert"] < 65536)
+        d = {"crt": np.asarray(blob).copy()}
+        for k, v in ref.items():
+            if isinstance(v, np.ndarray):
+                d[k] = v
+        d["_max_front"] = np.array(ref["_max_front"])
+        if "normal" in ref16:
+            d["normal_i16"] = ref16["normal"]
+        if "index" in ref16 and ref16["index"].dtype == np.uint16:
+            d["index_u16_sha256"] = np.frombuffer(sha(ref16["index"]).encode(), dtype=np.uint8)
+        d["color_components"] = np.array(cc)
+        # index.groups as the reference Decoder reports them after decode(): "end\tkey=value\tkey=value" per group, one group per line
+        d["groups_ref"] = np.frombuffer("\n".join("\t".join([str(e)] + ["%s=%s" % kv for kv in p.items()]) for e, p in rc.groups(blob)).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        index.append((name, len(blob), ref["nvert"], ref["nface"]))
+        print("%-20s crt %7d B  nvert %6d nface %6d" % index[-1])
+
+    if only is not None:
+        if "tunstall_kat" in only:
+            tunstall_kat()
+        return
+    # mid-size mesh (C1-class, 34 060 verts / 67 600 tris): blob + digests only
+    m = synth.bumpy_sphere(260, 130, seed=34)
+    blob = rc.encode(m, normal_prediction=rc.BORDER)
+    ref = rc.decode(blob)
+    d = {"crt": np.asarray(blob).copy()}
+    for k, v in ref.items():
+        if isinstance(v, np.ndarray):
+            d[k + "_sha256"] = np.frombuffer(sha(v).encode(), dtype=np.uint8)
+    d["nvert"] = np.array(ref["nvert"]); d["nface"] = np.array(ref["nface"])
+    np.savez_compressed(os.path.join(OUT, "mid34k_digest.npz"), **d)
+    print("mid34k_digest        crt %7d B  nvert %6d nface %6d" % (len(blob), ref["nvert"], ref["nface"]))
+
+    # 16 distinct C4-unit blobs (seeds 0..15) for bench / batch tests: blobs + per-array digests
+    d = {}
+    for seed in range(16):
+        m = synth.bumpy_sphere(64, 32, seed=seed)
+        blob = rc.encode(m, normal_prediction=rc.BORDER)
+        ref = rc.decode(blob)
+        d["crt_%02d" % seed] = np.asarray(blob).copy()
+        for k in ("position", "normal", "color", "uv", "index"):
+            d["%s_sha256_%02d" % (k, seed)] = np.frombuffer(sha(ref[k]).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "c4_blobs16.npz"), **d)
+    print("c4_blobs16           %d blobs" % 16)
+
+    tunstall_kat()
 
 
 if __name__ == "__main__":
