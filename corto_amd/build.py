@@ -24,7 +24,7 @@ SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_normal.hip", "k_en
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
     os.path.join("..", "..", "include", "corto_hip.h"), os.path.join("..", "..", "include", "corto", "decoder.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function", "-x", "hip"]
+         "-Wall", "-Wno-unused-function", "-x", "hip"] + ["-D" + d for d in os.environ.get("CORTO_BUILD_DEFINES", "").split(",") if d]   # (probes: CORTO_TUN_STAMPS)
 
 
 def hipcc() -> str:

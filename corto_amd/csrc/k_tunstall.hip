@@ -213,6 +213,10 @@ __global__ __launch_bounds__(64) void k_tun_stream(const TunStream *__restrict__
 		tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
 		base += total;
 	}
+#ifdef CORTO_TUN_STAMPS
+	TUN_STAMP(4);
+	if(threadIdx.x == 0 && blockIdx.x < 4096) { g_tun_stamps[blockIdx.x*8 + 5] = st.nsym; g_tun_stamps[blockIdx.x*8 + 6] = st.csize; g_tun_stamps[blockIdx.x*8 + 7] = st.size; }
+#endif
 }
 
 // pass B, short streams (the .crt case: one chunk, a few KiB): small LDS footprint so that it can run next to the
@@ -627,3 +631,7 @@ __global__ __launch_bounds__(256) void k_fill(const FillJob *__restrict__ jobs, 
 }
 
 } // namespace corto_hip
+
+#ifdef CORTO_TUN_STAMPS
+extern "C" int crthip_debug_tun_stamps(uint64_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_tun_stamps), sizeof(uint64_t)*8*4096); }
+#endif

@@ -7,6 +7,14 @@
 // decode from it).  Otherwise it stays in LDS - word bytes in tun_words(), offsets / lengths in loff / llen - for the same wave to
 // decode from (k_tun_stream below).  Returns (used bytes, longest word).
 struct TunBuilt { uint32_t used, maxlen; };
+// -DCORTO_TUN_STAMPS (CORTO_BUILD_DEFINES=CORTO_TUN_STAMPS python -m corto_amd.build --force; tools/tun_stamp_probe.py): where a stream's
+// time goes - 100 MHz stamps of workgroups 0..4095 at the phase boundaries, read back with crthip_debug_tun_stamps
+#ifdef CORTO_TUN_STAMPS
+__device__ uint64_t g_tun_stamps[8*4096];
+#define TUN_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < 4096) g_tun_stamps[blockIdx.x*8 + (k)] = wall_clock64(); } while(0)
+#else
+#define TUN_STAMP(k) do { } while(0)
+#endif
 __shared__ __attribute__((aligned(16))) uint8_t g_tun_words[TUN_TABLE_BYTES];        // (one definition: both kernels below are single-wave workgroups)
 __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTable *Tg, uint16_t *loff, uint8_t *llen, const uint8_t *probs_override = nullptr) {
 	const uint8_t *probs = probs_override ? probs_override : st.probs;   // nsym x (symbol, probability), sorted as stored in the stream
@@ -23,6 +31,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 	__shared__ uint16_t pw[256];                // P0^k (successive (a*b)>>16), low-entropy seed only
 	__shared__ uint8_t sym[256];
 
+	TUN_STAMP(0);
 	for(uint32_t i = lane; i < n; i += 64) { sym[i] = probs[2*i]; P[i] = (uint32_t)probs[2*i + 1] << 8; }
 	for(uint32_t i = lane; i < TUN_ENTRY_CAP; i += 64) { epl[i] = 0; eoff[i] = 0; }
 	__syncthreads();
@@ -69,6 +78,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 	}
 	__syncthreads();
 
+	TUN_STAMP(1);
 	const bool tree = n <= 64;
 	const uint32_t seed_end = end, seed_bytes = pos;
 	if(tree) {
@@ -142,6 +152,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 			if(lane < m) { epl[E] = (t >> 16) | sym24 | ((hq & 0xFF0000u) + 0x10000u); eoff[E] = (uint16_t)(hq & 0xFFFFu); }
 			end += m; nwords = 256;
 		}
+		TUN_STAMP(2);
 		const uint32_t h = HL & 0xFFFFu;
 		if(lane < n) head[lane] = (uint16_t)min(h, 0xFFFFu);
 		__syncthreads();
@@ -216,6 +227,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		}
 		w += __popcll(mask);
 	}
+	TUN_STAMP(3);
 	used = wave_max_u32(used); maxlen = wave_max_u32(maxlen);
 	for(uint32_t c = w + lane; c < 256; c += 64) { if(Tg) { T.off[c] = 0; T.len[c] = 0; } else { loff[c] = 0; llen[c] = 0; } }   // never on valid input
 	__syncthreads();

@@ -1,3 +1,5 @@
+"""Where a short Tunstall stream's time goes (k_tun_stream): needs the library built with CORTO_BUILD_DEFINES=CORTO_TUN_STAMPS
+(python -m corto_amd.build --force); phases: seed, dictionary growth, survivors spelled out, decode."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
