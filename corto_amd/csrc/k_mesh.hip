@@ -1430,7 +1430,20 @@ __device__ __forceinline__ void delta_stage_out_float(const DeltaStage &S, float
 __device__ __forceinline__ void delta_stage_out_color(CRT_LDS const uint8_t *v, const DeltaJob &J) {
 	CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
 	const uint32_t N = J.N, oc = J.out_components, stride = J.out_stride ? J.out_stride : oc;
-	for(uint32_t i = lane_id(); i < J.nvert; i += 64) {
+	uint32_t done = 0;
+	if(N == 4 && oc == 4 && stride == 4 && (((uintptr_t)dst | (uintptr_t)v) & 15) == 0) {      // packed RGBA: four vertices per lane, 16-byte loads and stores
+		const uint32_t q0 = J.qc[0], q1 = J.qc[1], q2 = J.qc[2], q3 = J.qc[3];
+		CRT_LDS const u32x4 *v4 = (CRT_LDS const u32x4 *)v;
+		CRT_GLOBAL u32x4 *d4 = (CRT_GLOBAL u32x4 *)dst;
+		const uint32_t nq = J.nvert >> 2;
+		auto px = [&](uint32_t w) -> uint32_t {                                                   // bytes y, u, v, a -> r, g, b, a
+			const uint32_t y = w & 255u, cu = (w >> 8) & 255u, cv = (w >> 16) & 255u, al = w >> 24;
+			return (((cv + y)*q0) & 255u) | ((y*q1) & 255u) << 8 | (((cu + y)*q2) & 255u) << 16 | ((al*q3) & 255u) << 24;
+		};
+		for(uint32_t k = lane_id(); k < nq; k += 64) { const u32x4 w = v4[k]; d4[k] = u32x4{px(w.x), px(w.y), px(w.z), px(w.w)}; }
+		done = nq << 2;
+	}
+	for(uint32_t i = done + lane_id(); i < J.nvert; i += 64) {
 		uint32_t col[4] = {0, 0, 0, 255};
 		for(uint32_t c = 0; c < N && c < 4; c++) col[c] = v[i*N + c];
 		const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
