@@ -369,6 +369,7 @@ class Batch:
                 plan.append((i, "index", take(nf * 3 * np.dtype(_DT[dt]).itemsize), dt, (nf, 3), -1, FMT_UINT16 if index16 else FMT_UINT32, 0))
         total = max(off, 256)
         buf = torch.empty(total, dtype=torch.uint8, device=dev) if fill is None else torch.full((total,), fill, dtype=torch.uint8, device=dev)
+        _torch_ready(dev)                            # (the fill runs on torch's stream; the decode on the context's own)
         base = buf.data_ptr()
         nattr_total = sum(info.nattr for info in self.infos)
         binds = (AttrBinding * max(nattr_total, 1))()
@@ -424,6 +425,7 @@ class Batch:
             metas.append((vb, rec, layout, ib, bool(nf and index16 and nv < 65536)))
         total = max(off, 256)
         buf = torch.empty(total, dtype=torch.uint8, device=dev) if fill is None else torch.full((total,), fill, dtype=torch.uint8, device=dev)
+        _torch_ready(dev)                            # (the fill runs on torch's stream; the decode on the context's own)
         base = buf.data_ptr()
         nattr_total = sum(info.nattr for info in self.infos)
         binds = (AttrBinding * max(nattr_total, 1))()
@@ -572,6 +574,14 @@ class Pool:
             pass
 
 
+def _torch_ready(device) -> None:
+    """The library's HIP streams are non-blocking: they do not wait for work torch queued on ITS stream (a fill of the output block, an
+    upload).  Whoever prepares device buffers with torch finishes that work before handing the pointers over (include/corto_hip.h:
+    "device buffers")."""
+    import torch
+    torch.cuda.current_stream(device).synchronize()
+
+
 def upload_arena(blobs: Sequence[np.ndarray], device: int = 0):
     """Stage blobs back to back (16-byte aligned starts) into one device tensor: the 'inputs resident in
     HBM' form that Batch(device_arena=...) consumes."""
@@ -580,7 +590,9 @@ def upload_arena(blobs: Sequence[np.ndarray], device: int = 0):
     host = np.zeros(max(total, 16), dtype=np.uint8)
     for b, o in zip(blobs, offs):
         host[int(o):int(o) + len(b)] = b
-    return torch.from_numpy(host).to(torch.device("cuda", device))
+    arena = torch.from_numpy(host).to(torch.device("cuda", device))
+    _torch_ready(arena.device)
+    return arena
 
 
 class Decoder:
@@ -644,6 +656,7 @@ def tunstall_decode_blocks(ctx: Context, host_blocks: np.ndarray, device_blocks,
     bo = np.ascontiguousarray(block_offsets, dtype=np.uint64)
     oo = np.ascontiguousarray(out_offsets, dtype=np.uint64)
     t = KernelTimes()
+    _torch_ready(device_out.device)                   # device_blocks / device_out are the caller's torch tensors
     _check(lib().crthip_tunstall_decode_blocks(ctx.handle, len(bo), _np_ptr(host_blocks), C.c_void_p(device_blocks.data_ptr()),
                                                _np_ptr(bo), C.c_void_p(device_out.data_ptr()), _np_ptr(oo), C.byref(t)))
     return t.as_dict()

@@ -728,7 +728,7 @@ static int build_and_launch(crthip_batch *b) {
 				uint32_t ring, pool, symwin;
 				uint32_t scale = ctx->topo_scale, need;
 				for(;;) {                                                                // as much of the context's scale as fits a CU
-					topo_lds_geometry(nface, L.clers.size, 4096, scale, ring, pool, symwin);
+					topo_lds_geometry(nface, L.clers.size, 4096, scale, nblobs >= 32 ? 4u : 8u, ring, pool, symwin);
 					need = topo_lds_bytes(ring, pool, pool, symwin);                     // every delayed edge is a pool record: same capacity
 					if(need <= TOPO_LDS_MAX || scale == 1) break;
 					scale >>= 1;

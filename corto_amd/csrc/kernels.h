@@ -41,13 +41,17 @@ inline uint32_t topo_lds_bytes(uint32_t ring, uint32_t pool, uint32_t dcap, uint
 	return (ring + pool)*16 + ((pool + 7) & ~7u)*2 + ((dcap + 7) & ~7u)*2 + symwin/2 + 8 + 32 + TOPO_SPLIT_LDS*4 + 16;
 }
 constexpr uint32_t TOPO_SYMWIN_MAX = 8192;
-// The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the ring gets 8*sqrt(nface)
+// The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the ring gets `slots`*sqrt(nface)
 // rounded up to a power of two (at least 256, at most `ring_max`), the pool as much again (it also holds every edge of the mesh's own
 // boundary for good).  What does not fit - a torus' queue is ten times a sphere's, a ribbon is all boundary - is redone on the HBM front.
 // `scale` (a power of two) multiplies both: the context raises it after a batch whose blobs fell back (batch.cpp).
-inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
+// slots = 8 for a few big meshes (LDS is not contended: leave room), 4 for a batch of many blobs: a 4K-triangle blob then takes 12.5 KB,
+// and that it is NOT MORE THAN THE 16 KB of a K-STREAM wave matters more than the size itself: the automaton's workgroups are dispatched
+// while the attribute streams' 2 000 waves fill every CU ten to a CU, and a 16 KB hole opens whenever one of those ends - a 22 KB
+// request waits for two neighbouring ones (0.237 -> 0.200 ms per C4 batch unpipelined, +5 % pipelined).
+inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t slots, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
 	uint32_t want = 256;
-	while((uint64_t)want*want < (uint64_t)64*nface && want < ring_max) want <<= 1;
+	while((uint64_t)want*want < (uint64_t)slots*slots*nface && want < ring_max) want <<= 1;
 	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }
 	ring = want; pool = want;
 	const uint32_t all = (nclers + 64 + 31) & ~31u;       // whole 16-byte vectors of nibbles (k_mesh.hip: TOPO_FILL_WINDOW)

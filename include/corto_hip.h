@@ -18,6 +18,12 @@
  *
  * There is NO CPU fallback behind this ABI: if no HIP device is usable the calls fail with
  * CRTHIP_E_DEVICE.
+ *
+ * Device buffers: a context decodes on its own NON-BLOCKING HIP streams, which do not wait for the null stream or for any
+ * stream of the caller.  Work the caller queued on the buffers it hands over (a fill of the output block, an upload of the
+ * arena on another stream) must have completed before crthip_batch_decode / crthip_tunstall_decode_blocks is called, and the
+ * outputs are complete when crthip_batch_sync (or the host-output call) returns - the same contract as handing a buffer to
+ * any library that owns its streams.
  */
 #ifndef CORTO_HIP_H
 #define CORTO_HIP_H

@@ -505,8 +505,8 @@ def _run_blocks(ctx, blocks, sizes):
     for s in sizes:
         oo.append(ot); ot += (s + 15) & ~15
     dblk = torch.from_numpy(host).cuda()
-    dout = torch.full((ot + 16,), 0xEE, dtype=torch.uint8, device="cuda")
-    times = ca.tunstall_decode_blocks(ctx, host, dblk, offs, dout, oo)
+    dout = torch.full((ot + 16,), 0xEE, dtype=torch.uint8, device="cuda")     # (tunstall_decode_blocks waits for this fill: the library's
+    times = ca.tunstall_decode_blocks(ctx, host, dblk, offs, dout, oo)         #  streams are non-blocking, include/corto_hip.h "Device buffers")
     out = dout.cpu().numpy()
     return [out[o:o + s] for o, s in zip(oo, sizes)], times
 
