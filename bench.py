@@ -520,6 +520,20 @@ def main():
     barrier()
     elapsed_h = shard.max_over_ranks(rep_h.elapsed_s, dist, red_dev)
 
+    # beside `value`: the same pipelined steps with one Tunstall dictionary built PER STREAM ($CORTO_TUN_SHARE=0; read when a context is
+    # made, so: a second pool).  By default the streams of a batch that carry the same probability table share one dictionary, and the
+    # synthetic blobs - one generator, 256 seeds, the same connectivity - repeat tables far more than unrelated meshes would.
+    os.environ["CORTO_TUN_SHARE"] = "0"
+    pool_ns = ca.Pool(devices, threads=nthreads, depth=depth)
+    del os.environ["CORTO_TUN_SHARE"]
+    pool_ns.run(items, steps=4 * pool_ns.lanes, warmup=0, arenas=arenas)
+    barrier()
+    rep_ns, _ = pool_ns.run(items, steps=fh_steps, warmup=2 * pool_ns.lanes, arenas=arenas)
+    barrier()
+    elapsed_ns = shard.max_over_ranks(rep_ns.elapsed_s, dist, red_dev)
+    tris_ns = shard.sum_over_ranks(float(rep_ns.triangles), dist, red_dev)
+    pool_ns.close()
+
     tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev)
     verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev)
     tris_h = shard.sum_over_ranks(float(rep_h.triangles), dist, red_dev)
@@ -558,6 +572,11 @@ def main():
             "bit_exact": True, "bit_exact_blobs_checked": checked, "topology_fallbacks": int(rep.topology_fallbacks),
             "steps_per_device": steps_per_device,
             "steady_state": window_stats(stamps, pool.lanes),
+            "tunstall_dictionaries": {"streams": int(stats0.tunstall_streams), "built": int(stats0.tunstall_dictionaries),
+                                      "note": "per batch (rebuilt every step): streams of a batch with the same probability table share one dictionary; "
+                                              "one generator with 256 seeds repeats tables more than unrelated meshes would - see without_dictionary_sharing"},
+            "without_dictionary_sharing": {"mtri_per_s": round(tris_ns / elapsed_ns / 1e6, 2), "ms_per_step": round(elapsed_ns / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
+                                           "note": "same pipelined steps with $CORTO_TUN_SHARE=0: every stream builds its own dictionary (round 2's earlier figure)"},
             "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
                                     **window_stats(stamps_h, pool.lanes),
                                     "note": "same pipelined steps, but every step uploads its %.1f MB of compressed blobs from host memory (PCIe H2D inside the step); "

@@ -172,7 +172,7 @@ struct BlobScratch {
 
 struct Plan {
 	// job arrays
-	HostArr<TunStream> tun; HostArr<uint32_t> tun_chunk_stream;
+	HostArr<TunStream> tun, tun_dict; HostArr<uint32_t> tun_chunk_stream;   // tun_dict: one entry per DISTINCT probability table (shared dictionaries)
 	HostArr<FillJob> fill;
 	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
 	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
@@ -194,7 +194,7 @@ struct Plan {
 	uint64_t total = 0;
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
 	void reset() {                                          // keep every vector's capacity
-		clr(tun); clr(tun_chunk_stream); clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
+		clr(tun); clr(tun_dict); clr(tun_chunk_stream); clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
 		clr(unpack); clr(unpack_chunk_job); clr(delta); clr(delta_groups); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
 		clr(nf_block_job); clr(nf_block_first); clr(normal_fused_ids); clr(dequant); clr(dequant_block_job);
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
@@ -237,6 +237,12 @@ struct crthip_ctx {
 	Plan plan;
 	std::vector<BlobScratch> plan_scratch;
 	std::vector<const uint8_t *> plan_clers, plan_logs;
+	// streams of a batch that carry the same probability table share one dictionary: exact match on the table's bytes (alphabets of up
+	// to 16 symbols; bigger ones hardly ever repeat and are quick to build), open addressing on a hash of them
+	struct DictKey { uint8_t n, bytes[32]; };
+	std::vector<DictKey> dict_keys;
+	std::vector<uint32_t> dict_slots, dict_used, dict_ids;
+	int tun_share = -1;                               // $CORTO_TUN_SHARE: 0 never, 1 whenever possible, unset: when at least half of a launch's streams repeat a table
 };
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
@@ -323,6 +329,7 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	   hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
 	{ const char *e = getenv("CORTO_TUN_TWO_PASS"); c->tun_two_pass = e && e[0] == '1'; }
 	{ const char *e = getenv("CORTO_TUN_SIDE_STREAMS"); c->tun_side = e && e[0] == '1'; }
+	{ const char *e = getenv("CORTO_TUN_SHARE"); if(e && (e[0] == '0' || e[0] == '1')) c->tun_share = e[0] - '0'; }
 	if(c->tun_side && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE); }   // (a stream is a hardware queue: not made unless asked for)
 	{ const char *e = getenv("CORTO_EXP_NORMAL_FN_MAX"); if(e) c->exp_normal_fn_max = (uint32_t)atoi(e); }
 	{ const char *e = getenv("CORTO_EXP_DELTA_WALK"); c->exp_delta_walk = e && e[0] == '1'; }
@@ -612,7 +619,7 @@ static int build_and_launch(crthip_batch *b) {
 		const BlobPlan &P = b->blobs[i];
 		for(size_t k = 0; k < P.L.attrs.size(); k++) if(P.bind[k].buffer) for(const StreamRef &lg : P.L.attrs[k].logs) unpack_state_words += ((uint64_t)lg.size + CHUNK - 1)/CHUNK;
 	}
-	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0;
+	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0, stat_dicts = 0;
 
 	auto need_stream = [&](const StreamRef &s, uint64_t &sym_off) {
 		sym_off = ~0ull;
@@ -669,6 +676,32 @@ static int build_and_launch(crthip_batch *b) {
 	auto HS = [&](uint64_t k) { return (int32_t *)((uintptr_t)(hs_base + k) | (1ull << 63)); };   // real pointer (bit 63: R() leaves it alone)
 
 	uint32_t tun_chunks = 0, unpack_chunks = 0, cloud_chunks = 0;
+	// the dictionary (TunTable slot) of a stream: a new one, or the one an earlier stream of this launch group with the same table got
+	if(ctx->dict_slots.size() != 8192) ctx->dict_slots.assign(8192, 0u);
+	for(uint32_t u : ctx->dict_used) ctx->dict_slots[u] = 0;
+	ctx->dict_used.clear(); ctx->dict_keys.clear();
+	std::vector<uint32_t> &dict_ids = ctx->dict_ids; dict_ids.clear();
+	uint32_t dict_group0 = 0;                                              // first dictionary of the current group (CLERS streams / attribute streams)
+	auto dict_of = [&](const StreamRef &s, const TunStream &t) -> uint32_t {
+		const uint32_t fresh = (uint32_t)pl.tun_dict.v.size();
+		auto make = [&]() { TunStream d = t; d.table = fresh; d.dict = fresh; d.nchunks = 1; pl.tun_dict.v.push_back(d); return fresh; };
+		if(s.nsym > 16 || fresh - dict_group0 >= 4096) return make();
+		uint64_t h = 0x9E3779B97F4A7C15ull ^ s.nsym;
+		for(uint32_t k = 0; k < 2*s.nsym; k += 8) { uint64_t w; memcpy(&w, s.probs16 + k, 8); h = (h ^ w)*0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+		for(uint32_t pos = (uint32_t)h & 8191u;; pos = (pos + 1) & 8191u) {
+			const uint32_t e = ctx->dict_slots[pos];
+			if(!e) {
+				ctx->dict_slots[pos] = (uint32_t)ctx->dict_keys.size() + 1; ctx->dict_used.push_back(pos);
+				crthip_ctx::DictKey key; key.n = (uint8_t)s.nsym; memcpy(key.bytes, s.probs16, 32);
+				ctx->dict_keys.push_back(key);
+				const uint32_t d = make();
+				dict_ids.push_back(d);
+				return d;
+			}
+			const crthip_ctx::DictKey &key = ctx->dict_keys[e - 1];
+			if(key.n == s.nsym && memcmp(key.bytes, s.probs16, 2*s.nsym) == 0) return dict_ids[e - 1];
+		}
+	};
 	auto add_stream = [&](const StreamRef &s, uint64_t sym_off, uint64_t blob_off) -> const uint8_t * {
 		// returns the (pseudo or real) device pointer where the decoded symbols will be; real pointers have bit 63 set
 		if(s.mode == STREAM_RAW) return (const uint8_t *)((uintptr_t)(arena + blob_off + s.payload_off) | (1ull << 63));
@@ -681,6 +714,7 @@ static int build_and_launch(crthip_batch *b) {
 		if(t.nchunks > 1) pl.tun_multi_chunk = true;
 		for(uint32_t c = 0; c < t.nchunks; c++) pl.tun_chunk_stream.v.push_back((uint32_t)pl.tun.v.size());
 		tun_chunks += t.nchunks;
+		t.dict = dict_of(s, t);
 		pl.tun.v.push_back(t);
 		return SP(sym_off);
 	};
@@ -694,6 +728,11 @@ static int build_and_launch(crthip_batch *b) {
 		if(L.h.nface > 0) clers_ptrs[i] = add_stream(L.clers, bs[i].clers, b->blobs[i].arena_off);
 	}
 	const uint32_t clers_tun = (uint32_t)pl.tun.v.size(), clers_chunks = tun_chunks, clers_fill = (uint32_t)pl.fill.v.size();
+	const uint32_t clers_dict = (uint32_t)pl.tun_dict.v.size();
+	// the attribute streams are a launch of their own: their dictionaries are not shared with the CLERS streams' (different HIP streams)
+	for(uint32_t u : ctx->dict_used) ctx->dict_slots[u] = 0;
+	ctx->dict_used.clear(); ctx->dict_keys.clear(); dict_ids.clear();
+	dict_group0 = clers_dict;
 
 	uint32_t est_vbase = 0, est_fbase = 0;
 	for(uint32_t i = 0; i < nblobs; i++) {
@@ -883,7 +922,7 @@ static int build_and_launch(crthip_batch *b) {
 	pl.jobs_begin = cv.take(0);
 	pl.unpack_partial_off = cv.take(unpack_state_words*8, 16);           // (first thing in the uploaded block: zeros)
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
-	place(pl.tun); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
+	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) == 0; });
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) <= 1; });
@@ -923,6 +962,7 @@ static int build_and_launch(crthip_batch *b) {
 		return base + v;
 	};
 	for(auto &t : pl.tun.v) t.dst = R(t.dst);
+	for(auto &t : pl.tun_dict.v) t.dst = nullptr;
 	for(auto &f : pl.fill.v) f.dst = R(f.dst);
 	for(auto &t : pl.topo.v) {
 		t.clers = R(t.clers);
@@ -953,7 +993,7 @@ static int build_and_launch(crthip_batch *b) {
 	memset(stage + (pl.unpack_partial_off - pl.jobs_begin), 0, unpack_state_words*8);
 	memset(ctx->status_host.p, 0, (size_t)nblobs*8);                       // (after the harvest above: the previous batch's words have been read)
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
-	put(pl.tun); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
+	put(pl.tun); put(pl.tun_dict); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
 	put(pl.delta); put(pl.delta_groups); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
@@ -972,10 +1012,24 @@ static int build_and_launch(crthip_batch *b) {
 
 	const uint32_t ntun = (uint32_t)pl.tun.v.size();
 	const uint32_t nfill = (uint32_t)pl.fill.v.size();
+	const uint32_t ndict = (uint32_t)pl.tun_dict.v.size();
+	// a launch's streams share dictionaries when at least half of them repeat another one's table (and there are enough of them for it to matter)
+	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { return ctx->tun_share == 1 ? ndicts < nstreams : ctx->tun_share != 0 && nstreams >= 64 && 2*ndicts <= nstreams; };
+	const bool share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict), share_attrs = !pl.tun_multi_chunk && shares(ntun - clers_tun, ndict - clers_dict);
+	stat_dicts = (share_clers ? clers_dict : clers_tun) + (share_attrs ? ndict - clers_dict : ntun - clers_tun);
 	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
-		if(t1 > t0) {                                        // every stream here is one chunk: dictionary + decode in one kernel, one wave per stream
+		if(t1 > t0) {                                        // every stream here is one chunk: one wave per stream
 			(void)c0; (void)c1;
-			LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0); LT.end();
+			// [t0, t1) is the CLERS streams, the attribute streams, or both (dictionaries are numbered the same way)
+			const bool has_clers = t0 == 0 && clers_tun > 0, has_attrs = t1 == ntun && ntun > clers_tun;
+			const bool share = (!has_clers || share_clers) && (!has_attrs || share_attrs) && (has_clers || has_attrs);
+			if(share) {                                        // distinct tables first, then every stream decodes from its (shared) dictionary
+				const uint32_t d0 = has_clers ? 0u : clers_dict, d1 = has_attrs ? ndict : clers_dict;
+				LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(d1 - d0), dim3(64), 0, s, D(pl.tun_dict) + d0, d1 - d0, tables, (uint64_t *)nullptr, 0u); LT.end();
+				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream_shared, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables); LT.end();
+			} else {                                           // dictionary + decode in one kernel
+				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0); LT.end();
+			}
 		}
 		if(f1 > f0) { LT.begin("fill", s); hipLaunchKernelGGL(k_fill, dim3(f1 - f0), dim3(256), 0, s, D(pl.fill) + f0, f1 - f0); LT.end(); }
 	};
@@ -1071,7 +1125,7 @@ static int build_and_launch(crthip_batch *b) {
 	HIP_TRY(hipGetLastError());                                            // (status: written by the kernels straight into the pinned block)
 
 	// stats
-	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun;
+	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
 	b->stats.scratch_bytes = pl.total;
 	b->stats.topology_scale = ctx->topo_scale;
 	uint64_t ob = 0;

@@ -89,6 +89,7 @@ StreamRef byte_block(Cursor &c, uint32_t entropy, int &err) {
 	s.nsym = c.u8();
 	s.probs_off = (uint32_t)c.pos;
 	if(c.need((size_t)s.nsym * 2) && s.nsym >= 1) s.fill = c.p[c.pos];
+	if(c.need((size_t)s.nsym * 2) && s.nsym >= 2 && s.nsym <= 16) memcpy(s.probs16, c.p + c.pos, (size_t)s.nsym * 2);
 	c.skip((size_t)s.nsym * 2);
 	s.size = c.u32();
 	s.csize = c.u32();

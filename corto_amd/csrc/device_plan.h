@@ -30,6 +30,8 @@ struct TunStream {
 	uint32_t nchunks;
 	uint32_t chunk_codes;          // codewords per chunk (= per K-TUN workgroup), a multiple of 256*cpl
 	uint32_t cpl;                  // staged decode: codewords per lane per step (8, 4, 2 or 1)
+	uint32_t dict;                 // k_tun_stream_shared: TunTable slot of the dictionary this stream shares
+	uint32_t pad_;
 };
 
 // Chunk geometry of one stream, from its mean word length size/csize (both are in the stream header): workgroups are

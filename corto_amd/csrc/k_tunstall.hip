@@ -161,27 +161,15 @@ __device__ __forceinline__ void tun_tile_prepare(TunTile &t, const TunStream &st
 	}
 }
 
-// K-STREAM: dictionary AND decode of one short stream (the .crt case: a few hundred codewords, a few KiB of symbols) by ONE wave.
-// A batch of 256 blobs has 2 304 such streams; as two kernels (k_tun_tables, then k_tun_decode with 256 threads per stream) every
-// dictionary made a 9 KB round trip through HBM, the decode workgroups sat behind the slowest dictionary of the launch, and a
-// step had two more launches on each of its two chains.  Here the dictionary stays in the LDS of the wave that built it (the build is
-// ~45 us of dependent steps, the decode of a 2 112-symbol stream a few more), and the symbols are written straight to HBM: four
-// codewords per lane and step, lengths scanned across the wave, each lane's run emitted through the aligned byte FIFO.
-__global__ __launch_bounds__(64) void k_tun_stream(const TunStream *__restrict__ streams, uint32_t nstreams) {
-	const uint32_t s = blockIdx.x;
-	if(s >= nstreams) return;
-	const TunStream st = streams[s];
-	__shared__ uint16_t loff[256];
-	__shared__ uint8_t llen[256];
-	tun_tables_body(st, nullptr, loff, llen);
-	__syncthreads();
+// the decode of one short stream by one wave from a dictionary in LDS (offsets, lengths, word bytes): four codewords per lane and step
+__device__ __forceinline__ void tun_stream_decode(const TunStream &st, const uint16_t *loff, const uint8_t *llen, const uint8_t *words) {
 	const uint32_t lane = threadIdx.x, csize = st.csize;
 	const uint64_t size = st.size;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
 	CRT_LDS const uint8_t *len8 = as_lds(llen);
 	CRT_LDS const uint16_t *off16 = as_lds(loff);
-	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(g_tun_words);
+	CRT_LDS const uint32_t *tab32 = (CRT_LDS const uint32_t *)as_lds(words);
 	uint64_t base = 0;
 	for(uint32_t tile = 0; tile < csize; tile += 256) {
 		const uint32_t j0 = tile + 4*lane;
@@ -213,10 +201,52 @@ __global__ __launch_bounds__(64) void k_tun_stream(const TunStream *__restrict__
 		tun_emit_run(d, (uint32_t)(uintptr_t)d, tab32, wo, nb);
 		base += total;
 	}
+}
+
+// K-STREAM: dictionary AND decode of one short stream (the .crt case: a few hundred codewords, a few KiB of symbols) by ONE wave.
+// A batch of 256 blobs has 2 304 such streams; as two kernels (k_tun_tables, then k_tun_decode with 256 threads per stream) every
+// dictionary made a 9 KB round trip through HBM, the decode workgroups sat behind the slowest dictionary of the launch, and a
+// step had two more launches on each of its two chains.  Here the dictionary stays in the LDS of the wave that built it (the build is
+// ~45 us of dependent steps, the decode of a 2 112-symbol stream a few more), and the symbols are written straight to HBM: four
+// codewords per lane and step, lengths scanned across the wave, each lane's run emitted through the aligned byte FIFO.
+__global__ __launch_bounds__(64) void k_tun_stream(const TunStream *__restrict__ streams, uint32_t nstreams) {
+	const uint32_t s = blockIdx.x;
+	if(s >= nstreams) return;
+	const TunStream st = streams[s];
+	__shared__ uint16_t loff[256];
+	__shared__ uint8_t llen[256];
+	tun_tables_body(st, nullptr, loff, llen);
+	__syncthreads();
+	tun_stream_decode(st, loff, llen, g_tun_words);
 #ifdef CORTO_TUN_STAMPS
 	TUN_STAMP(4);
 	if(threadIdx.x == 0 && blockIdx.x < 4096) { g_tun_stamps[blockIdx.x*8 + 5] = st.nsym; g_tun_stamps[blockIdx.x*8 + 6] = st.csize; g_tun_stamps[blockIdx.x*8 + 7] = st.size; }
 #endif
+}
+
+// K-STREAM, shared dictionaries: the streams of a batch repeat one another's probability tables - an alphabet of two symbols has
+// ~127 possible tables - and the dictionary is a function of the table alone, so the planner (batch.cpp) has every DISTINCT table
+// built once (k_tun_tables, into its TunTable in HBM) and each stream's wave only loads it: 768 bytes of offsets / lengths and the
+// `used` bytes of words, from L2.  10 KB of LDS for ~8 us instead of 16 KB for ~37.
+__global__ __launch_bounds__(64) void k_tun_stream_shared(const TunStream *__restrict__ streams, uint32_t nstreams, const TunTable *__restrict__ tables) {
+	const uint32_t s = blockIdx.x;
+	if(s >= nstreams) return;
+	const TunStream st = streams[s];
+	__shared__ uint16_t loff[256];
+	__shared__ uint8_t llen[256];
+	__shared__ __attribute__((aligned(16))) uint8_t words[TUN_TABLE_BYTES];
+	const TunTable &T = tables[st.dict];
+	const uint32_t lane = threadIdx.x;
+	{
+		CRT_GLOBAL const u32x4_t *o4 = (CRT_GLOBAL const u32x4_t *)as_global(T.off);       // 512 + 256 bytes: 48 16-byte vectors
+		if(lane < 32) ((CRT_LDS u32x4_t *)as_lds(loff))[lane] = o4[lane];
+		else if(lane < 48) ((CRT_LDS u32x4_t *)as_lds(llen))[lane - 32] = ((CRT_GLOBAL const u32x4_t *)as_global(T.len))[lane - 32];
+		const uint32_t nv = (min(T.used, TUN_TABLE_BYTES) + 15u) >> 4;
+		CRT_GLOBAL const u32x4_t *w4 = (CRT_GLOBAL const u32x4_t *)as_global(T.bytes);
+		for(uint32_t i = lane; i < nv; i += 64) ((CRT_LDS u32x4_t *)as_lds(words))[i] = w4[i];
+	}
+	__syncthreads();
+	tun_stream_decode(st, loff, llen, words);
 }
 
 // pass B, short streams (the .crt case: one chunk, a few KiB): small LDS footprint so that it can run next to the

@@ -264,6 +264,9 @@ typedef struct {
 	uint32_t topology_scale;    /* factor on the LDS edge slots this decode was planned with (1, 2, 4 ...): the context raises it
 	                               after a batch with fallbacks, so that meshes with long fronts (handles, many boundary loops)
 	                               stay in LDS from the next batch on, and lowers it again after a long run without any */
+	uint32_t tunstall_dictionaries; /* Tunstall dictionaries the last decode BUILT: streams of a batch that carry the same probability table
+	                               share one (the dictionary is a function of the table alone, src/tunstall.cpp:125-256), so this is
+	                               <= tunstall_streams; $CORTO_TUN_SHARE=0 builds one per stream */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

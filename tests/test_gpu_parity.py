@@ -86,6 +86,35 @@ def test_heterogeneous_batch(ctx):
         assert_same(b.host_outputs(i), g, KEYS, ALL_CASES[i])
 
 
+def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
+    """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
+    table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_shared); $CORTO_TUN_SHARE=0
+    builds one per stream (k_tun_stream).  Same bytes either way: every fixture twice + the 16 C4 blobs, in one batch."""
+    z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
+    gs = [load_golden(n) for n in ALL_CASES]
+    blobs = [g["crt"] for g in gs] * 2 + [aligned(z["crt_%02d" % s]) for s in range(16)]
+    seen = {}
+    for share in ("1", "0", None):
+        if share is None:
+            monkeypatch.delenv("CORTO_TUN_SHARE", raising=False)
+        else:
+            monkeypatch.setenv("CORTO_TUN_SHARE", share)
+        c = ca.Context(0)                                  # (the switch is read when a context is made)
+        b = run_batch(c, blobs)
+        for i, g in enumerate(gs + gs):
+            assert_same(b.host_outputs(i), g, KEYS, "%s share=%s" % (ALL_CASES[i % len(gs)], share))
+        for s_ in range(16):
+            got = b.host_outputs(2 * len(gs) + s_)
+            for k in ("position", "normal", "color", "uv", "index"):
+                assert sha(got[k]) == z["%s_sha256_%02d" % (k, s_)].tobytes().decode(), (s_, k, share)
+        st = b.stats()
+        seen[share] = (st.tunstall_dictionaries, st.tunstall_streams)
+        b.close(); c.close()
+    assert seen["0"][0] == seen["0"][1], seen                       # one dictionary per stream
+    assert seen["1"][0] < seen["1"][1] // 2, seen                   # every fixture is there twice
+    assert seen[None][0] <= seen["0"][0], seen
+
+
 def test_rgb_expands_to_rgba(ctx):
     g = load_golden("nrm_estimated_rgb")
     b = run_batch(ctx, [g["crt"]], color_components=4)
