@@ -10,7 +10,7 @@ Workload (config C4 of BASELINE.json): a batch of 256 independent ~4K-triangle .
 A "step" = one pass of the hot path over that batch with the compressed blobs already resident in HBM:
 re-plan (crthip_batch_reset: host walk of every blob) + bind + decode (descriptor upload, all kernels) + sync; outputs stay in HBM.
 Steps run on the library's decode pool (crthip_pool, csrc/pool.cpp): per GPU --host-threads (default 4) native host threads
-each keep --depth (default 3) batches in flight, every batch on its own context (own HIP streams, scratch and output
+each keep --depth (default 4) batches in flight, every batch on its own context (own HIP streams, scratch and output
 block), all threads of all GPUs pulling batches from ONE work queue (an atomic counter) - no collective anywhere.
 Timing: barrier + device sync, then W warm-up steps flow straight into the K timed steps (the pipeline is NOT drained in
 between); the clock runs from the completion of the last warm-up step to the completion of the K-th timed step, a few more
@@ -335,7 +335,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=480)
     ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight (contexts) per host thread; 1 = unpipelined")
+    ap.add_argument("--depth", type=int, default=4, help="batches in flight (contexts) per host thread; 1 = unpipelined")
     ap.add_argument("--host-threads", type=int, default=4, help="native host threads per GPU feeding it (crthip_pool)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")

@@ -128,6 +128,7 @@ def lib():
         L.crthip_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.crthip_ctx_destroy.argtypes = [C.c_void_p]
         L.crthip_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.crthip_ctx_set_single_stream.argtypes = [C.c_void_p, C.c_int]
         L.crthip_ctx_sync.argtypes = [C.c_void_p]
         L.crthip_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.crthip_batch_destroy.argtypes = [C.c_void_p]
@@ -281,6 +282,10 @@ class Context:
 
     def set_profiling(self, on: bool):
         _check(lib().crthip_ctx_set_profiling(self.handle, int(on)))
+
+    def set_single_stream(self, on: bool = True):
+        """one HIP stream per context instead of two: faster from about $GPU_MAX_HW_QUEUES / 2 contexts per GPU up (corto_hip.h)"""
+        _check(lib().crthip_ctx_set_single_stream(self.handle, int(on)))
 
     def sync(self):
         _check(lib().crthip_ctx_sync(self.handle))

@@ -215,7 +215,8 @@ struct crthip_ctx {
 	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: chunk sums + scan + decode instead of the single pass with look-back (A/B measurements)
 	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
 	uint8_t exp_delta_walk = 0;                       // experiments: $CORTO_EXP_DELTA_WALK=1 - K-DELTA without the scan passes
-	uint8_t exp_no_deq_fold = 0;                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
+	uint8_t exp_no_deq_fold = 0;
+	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
 	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
 	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
@@ -364,6 +365,12 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 extern "C" int crthip_ctx_set_profiling(crthip_ctx *c, int enable) {
 	if(!c) return fail(CRTHIP_E_ARGUMENT);
 	c->profiling = enable != 0;
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_ctx_set_single_stream(crthip_ctx *c, int on) {
+	if(!c) return fail(CRTHIP_E_ARGUMENT);
+	c->single_stream = on != 0;
 	return CRTHIP_OK;
 }
 
@@ -1061,7 +1068,7 @@ static int build_and_launch(crthip_batch *b) {
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
-	} else if(!pl.topo.v.empty() && (ntun > clers_tun || nfill > clers_fill || unpack_chunks)) {
+	} else if(!pl.topo.v.empty() && (ntun > clers_tun || nfill > clers_fill || unpack_chunks) && !ctx->single_stream) {
 		// fork: attribute streams on stream2, CLERS + topology on the main stream
 		hipStream_t s2 = ctx->stream2;
 		HIP_TRY(hipEventRecord(ctx->ev_fork, st));

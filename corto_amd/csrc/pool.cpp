@@ -3,6 +3,7 @@
 // crthip_batch_*), plus hipMalloc for the lanes' output blocks.
 //
 // Reference anchor: independent crt::Decoder objects, src/decoder.cpp:126-196 (nothing shared between two decodes).
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -66,10 +67,14 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 	p->ndevices = ndevices; p->threads_per_device = threads_per_device; p->depth = depth;
 	for(uint32_t d = 0; d < ndevices; d++) p->devices.push_back(devices ? devices[d] : (int)d);
 	p->lanes.resize((size_t)ndevices*threads_per_device*depth);
+	uint32_t hw_queues = 4;                                      // ROCm's default
+	{ const char *e = getenv("GPU_MAX_HW_QUEUES"); if(e && atoi(e) > 0) hw_queues = (uint32_t)atoi(e); }
 	for(size_t i = 0; i < p->lanes.size(); i++) {
 		Lane &L = p->lanes[i];
 		L.slot = (uint32_t)(i/((size_t)threads_per_device*depth)); L.device = p->devices[L.slot];
-		const int err = crthip_ctx_create(L.device, &L.ctx);
+		int err = crthip_ctx_create(L.device, &L.ctx);
+		// two HIP streams per context only while every stream of the device gets a hardware queue of its own (corto_hip.h)
+		if(!err && 2*threads_per_device*depth > hw_queues) err = crthip_ctx_set_single_stream(L.ctx, 1);
 		if(err) { for(auto &x : p->lanes) destroy_lane(x); delete p; return err; }
 	}
 	*out = p;

@@ -121,6 +121,11 @@ int64_t crthip_probe_group_props(const uint8_t *blob, size_t len, uint32_t g, ch
 
 int crthip_ctx_create(int device, crthip_ctx **out);
 void crthip_ctx_destroy(crthip_ctx *ctx);
+/* A context decodes a batch on two HIP streams (CLERS streams + topology on one, the attribute streams' entropy decode and bit-unpack
+ * on the other, joined before the delta stage): the shortest latency for one batch.  With many contexts on one GPU the streams
+ * outnumber the hardware queues ($GPU_MAX_HW_QUEUES, ROCm default 4) and streams that share a queue serialise each other's kernels:
+ * from about queues/2 contexts up, one stream per context is faster (12 contexts, 16 queues: +15 %; crthip_pool chooses by itself). */
+int crthip_ctx_set_single_stream(crthip_ctx *ctx, int on);
 int crthip_device_count(void);
 
 /* Plan a batch: parse every header, walk every body (validating all extents against lens[i]),
