@@ -212,13 +212,16 @@ struct crthip_ctx {
 	hipStream_t stream2 = nullptr;  // attribute streams (Tunstall + bit-unpack) run here while the main stream does topology
 	hipStream_t stream3 = nullptr;  // long Tunstall streams: the three word-width classes of the staged decode run side by side (k_tunstall.hip)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
-	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: chunk sums + scan + decode instead of the single pass with look-back (A/B measurements)
+	// long streams: by default chunk sums, a scan per stream (k_tun_stream_scan), the decode; $CORTO_TUN_TWO_PASS=1: one device-wide scan kernel
+	// instead (round 1); $CORTO_TUN_SINGLE_PASS=1: the adding-up and a wait-free look-back inside the decode kernel (round 2's first half)
+	bool tun_two_pass = false, tun_single_pass = false;
 	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
 	uint8_t exp_delta_walk = 0;                       // experiments: $CORTO_EXP_DELTA_WALK=1 - K-DELTA without the scan passes
 	uint8_t exp_no_deq_fold = 0;
 	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
 	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
-	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}}; }
+	bool tun_three = false;         // $CORTO_TUN_THREE_LAUNCHES=1: one decode kernel per word-width class (A/B measurements)
+	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}, false} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}, !tun_three}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
 	PinnedBuf staging;        // host image of the job arrays
 	PinnedBuf status_host;
@@ -329,6 +332,8 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
 	{ const char *e = getenv("CORTO_TUN_TWO_PASS"); c->tun_two_pass = e && e[0] == '1'; }
+	{ const char *e = getenv("CORTO_TUN_THREE_LAUNCHES"); c->tun_three = e && e[0] == '1'; }
+	{ const char *e = getenv("CORTO_TUN_SINGLE_PASS"); c->tun_single_pass = e && e[0] == '1' && !c->tun_two_pass; }
 	{ const char *e = getenv("CORTO_TUN_SIDE_STREAMS"); c->tun_side = e && e[0] == '1'; }
 	{ const char *e = getenv("CORTO_TUN_SHARE"); if(e && (e[0] == '0' || e[0] == '1')) c->tun_share = e[0] - '0'; }
 	if(c->tun_side && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE); }   // (a stream is a hardware queue: not made unless asked for)
@@ -1059,12 +1064,14 @@ static int build_and_launch(crthip_batch *b) {
 	};
 	if(pl.tun_multi_chunk) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables, ctx->tun_two_pass ? (uint64_t *)nullptr : tun_partial, tun_chunks); LT.end();
-		if(ctx->tun_two_pass) {
+		uint64_t *tun_state = tun_partial;                                     // (single pass: the look-back's chunk state words, cleared by K-TAB)
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables, ctx->tun_single_pass ? tun_state : (uint64_t *)nullptr, tun_chunks); LT.end();
+		if(!ctx->tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
-			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end();
-		}                                                                          // (single pass: K-TAB cleared the chunks' look-back state words)
-		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, !ctx->tun_two_pass)) return fail(CRTHIP_E_DEVICE); LT.end();
+			if(ctx->tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end(); }
+			else { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, D(pl.tun), ntun, tun_partial); LT.end(); }
+		}
+		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, ctx->tun_single_pass)) return fail(CRTHIP_E_DEVICE); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
@@ -1310,26 +1317,23 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	Launch LT{ctx};
 	TunStream *dt = (TunStream *)(base + o_tun); uint32_t *dcs = (uint32_t *)(base + o_cs);
 	TunTable *tables = (TunTable *)(base + o_tab); uint64_t *part = (uint64_t *)(base + o_part);
+	uint64_t *state = part;                                                  // (single pass: the chunk state words of the look-back, cleared by K-TAB)
 	const uint32_t ntun = (uint32_t)tun.size();
 	if(ntun) {
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables, multi && !ctx->tun_two_pass ? part : (uint64_t *)nullptr, chunks); LT.end();
-		if(multi && ctx->tun_two_pass) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables, multi && ctx->tun_single_pass ? state : (uint64_t *)nullptr, chunks); LT.end();
+		if(multi && !ctx->tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
-			LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end();
+			if(ctx->tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end(); }
+			else { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, dt, ntun, part); LT.end(); }
 		}
 		LT.begin("tunstall_decode");
-		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, !ctx->tun_two_pass)) return fail(CRTHIP_E_DEVICE); }
+		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, ctx->tun_single_pass)) return fail(CRTHIP_E_DEVICE); }
 		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
 		LT.end();
 	}
 	if(!fills.empty()) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3((uint32_t)fills.size()), dim3(256), 0, st, (FillJob *)(base + o_fill), (uint32_t)fills.size()); LT.end(); }
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
-	if(multi && !ctx->tun_two_pass) {                                       // a chunk that gave up waiting for its predecessor (k_tunstall.hip: tun_lookback)
-		uint64_t gave_up = 0;
-		HIP_TRY(hipMemcpy(&gave_up, part + chunks, 8, hipMemcpyDeviceToHost));
-		if(gave_up) return fail(CRTHIP_E_DEVICE, "Tunstall look-back: a chunk never saw its predecessor's total");
-	}
 	if(times) {
 		memset(times, 0, sizeof(*times));
 		for(auto &r : ctx->timer.recs) {

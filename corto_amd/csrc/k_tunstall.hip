@@ -372,6 +372,34 @@ __device__ __forceinline__ uint32_t tun_wave_bytes(CRT_GLOBAL const uint8_t *src
 	return (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
 }
 
+// Between pass A and the decode (the default for long streams): the quarter sums of ONE stream turned into that stream's quarter offsets
+// by one workgroup - streams are independent, so there is no device-wide scan (k_scan_u64: one workgroup over every chunk of every
+// stream, 71 us on the scaled run against 20 here, launch included) and no dependency between workgroups.  Measured against it on the
+// scaled run (adding-up + offsets, us): single pass inside the decode kernel (below) 144; a lean adding-up kernel with a wave-wide wait-free
+// look-back 95; the last chunk of a stream scanning it from inside the adding-up kernel ("last one out", a counter per stream) 125 - its
+// agent-scope stores and counter cost more than this launch; sums 51 + this kernel 20.
+__global__ __launch_bounds__(256) void k_tun_stream_scan(const TunStream *__restrict__ streams, uint32_t nstreams, uint64_t *__restrict__ chunk_out) {
+	const uint32_t s = blockIdx.x;
+	if(s >= nstreams) return;
+	const TunStream st = streams[s];
+	CRT_GLOBAL uint64_t *p = as_global(chunk_out) + (size_t)st.chunk0*4;
+	const uint32_t n = st.nchunks*4u, tid = threadIdx.x, w = wave_id(), lane = lane_id();
+	__shared__ uint32_t wsum[4];
+	uint64_t carry = 0;
+	for(uint32_t base = 0; base < n; base += 256) {                       // (a quarter chunk decodes to < 2^24 bytes: 256 of them fit 32 bits)
+		const uint32_t i = base + tid;
+		const uint32_t v = i < n ? (uint32_t)p[i] : 0u;
+		const uint32_t incl = wave_inclusive_scan_u32(v);
+		if(lane == 63) wsum[w] = incl;
+		__syncthreads();
+		const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
+		const uint32_t woff = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+		if(i < n) p[i] = carry + woff + incl - v;
+		carry += (uint64_t)w0 + w1 + w2 + w3;
+		__syncthreads();
+	}
+}
+
 // SINGLE PASS over a long stream (decoupled look-back): a chunk's output offset is the decoded size of every earlier chunk of its
 // stream.  Instead of a kernel that adds up every chunk, a device-wide scan and a second read of all codewords, each workgroup
 // adds up its own chunk (its four waves their quarters), publishes the total in the chunk's state word, and walks back over its
@@ -635,6 +663,30 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__re
 	}
 }
 
+// all three word-width classes in ONE launch: a workgroup runs the body of its stream's class.  Registers and LDS are the long-word
+// class's (the others' are within a few registers of it), and the launch has neither the two extra grids of workgroups that leave at
+// once nor the two under-filled tails between the classes.
+__global__ __launch_bounds__(256) void k_tun_decode_staged_any(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
+                                                               uint32_t nchunks, const TunTable *__restrict__ tables,
+                                                               uint64_t *chunk_out, uint32_t single_pass) {
+	const uint32_t c = blockIdx.x;
+	if(blockIdx.x >= nchunks) return;
+	const TunStream st = streams[chunk_stream[c]];
+	const TunTable &T = tables[st.table];
+	const uint32_t W = tun_width(st.cpl, T.maxlen);
+	__shared__ TunLds L;
+	__shared__ __attribute__((aligned(16))) uint32_t t16[256*4];
+	__shared__ uint32_t longbuf[4][TUN_LONGQ];
+	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];
+	__shared__ uint64_t share[9];
+	if(W == 1) tun_staged_body<1, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, (uint32_t (*)[TUN_LONGQ])longbuf, winbuf, share);
+	else if(W == 2) tun_staged_body<2, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, (uint32_t (*)[TUN_LONGQ])longbuf, winbuf, share);
+	else if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+	else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+	else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+	else tun_staged_body<4, 1>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+}
+
 // host side: the three launches.  They touch disjoint chunks, so they run side by side on three HIP streams (fork / join with
 // events around them): the tail of one class's chunks overlaps the body of the next.  single_pass: the chunk state words
 // (chunk_out[0 .. nchunks], zeroed by the caller) carry the look-back; otherwise chunk_out holds the scanned quarter offsets.
@@ -647,7 +699,8 @@ int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const
 		if(hipEventRecord(q.fork, q.main) != hipSuccess || hipStreamWaitEvent(q.side[0], q.fork, 0) != hipSuccess || hipStreamWaitEvent(q.side[1], q.fork, 0) != hipSuccess) return -1;
 		TUN_LAUNCH(4, q.main); TUN_LAUNCH(1, q.side[0]); TUN_LAUNCH(2, q.side[1]);
 		for(int k = 0; k < 2; k++) if(hipEventRecord(q.join[k], q.side[k]) != hipSuccess || hipStreamWaitEvent(q.main, q.join[k], 0) != hipSuccess) return -1;
-	} else { TUN_LAUNCH(1, q.main); TUN_LAUNCH(2, q.main); TUN_LAUNCH(4, q.main); }
+	} else if(q.one_launch) hipLaunchKernelGGL(k_tun_decode_staged_any, dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<4, 8>()), q.main, streams, chunk_stream, nchunks, tables, chunk_out, single_pass);
+	else { TUN_LAUNCH(1, q.main); TUN_LAUNCH(2, q.main); TUN_LAUNCH(4, q.main); }
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 #undef TUN_LAUNCH
 }

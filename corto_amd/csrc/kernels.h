@@ -10,6 +10,7 @@ namespace corto_hip {
 __global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables, uint64_t *lookback_state, uint32_t lookback_words);   // lookback_state: null, or the chunk state words to clear
 __global__ void k_tun_stream(const TunStream *streams, uint32_t nstreams);   // short streams: dictionary + decode by one wave, the dictionary never leaves LDS
 __global__ void k_tun_stream_shared(const TunStream *streams, uint32_t nstreams, const TunTable *tables);   // ... decode from a dictionary another wave built (k_tun_tables): streams of a batch that carry the same probability table
+__global__ void k_tun_stream_scan(const TunStream *streams, uint32_t nstreams, uint64_t *chunk_out);   // one stream's quarter sums -> its quarter offsets (one workgroup per stream)
 __global__ void k_tun_chunk_sums(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                                  uint64_t *chunk_out, uint32_t chunk_base);
 __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
@@ -17,9 +18,9 @@ __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_str
 // Dwords of a word's zero-padded copy the staged decode composes from (k_tunstall.hip): by the dictionary's longest word;
 // steps of fewer than 8 codewords per lane (mean word length > 8) are only compiled for 4.
 __host__ __device__ inline uint32_t tun_width(uint32_t cpl, uint32_t maxlen) { return cpl < 8 || maxlen > 8 ? 4u : maxlen > 4 ? 2u : 1u; }
-struct TunLaunch { hipStream_t main, side[2]; hipEvent_t fork, join[2]; };   // side streams / events may be null: everything on `main`
+struct TunLaunch { hipStream_t main, side[2]; hipEvent_t fork, join[2]; bool one_launch; };   // side streams / events may be null: everything on `main`; one_launch: all three classes in one kernel
 int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                             uint64_t *chunk_out, uint32_t single_pass);    // three kernels: words <= 4 bytes, <= 8 bytes, longer
+                             uint64_t *chunk_out, uint32_t single_pass);    // words <= 4 bytes, <= 8 bytes, longer: one kernel, or three
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
 
 // k_stream.hip
