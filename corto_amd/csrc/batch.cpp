@@ -191,6 +191,7 @@ struct Plan {
 	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
 	uint32_t delta_wave_lds = 0;
 	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
+	uint32_t tun_max_nchunks = 0;
 	uint64_t total = 0;
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
 	void reset() {                                          // keep every vector's capacity
@@ -201,7 +202,7 @@ struct Plan {
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
 		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
 		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0;
-		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0;
+		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0; tun_max_nchunks = 0;
 	}
 };
 } // namespace
@@ -724,6 +725,7 @@ static int build_and_launch(crthip_batch *b) {
 		t.csize = s.csize; t.size = s.size; t.nsym = s.nsym; t.table = (uint32_t)pl.tun.v.size();
 		t.chunk0 = tun_chunks; tun_pick_geometry(t);
 		if(t.nchunks > 1) pl.tun_multi_chunk = true;
+		pl.tun_max_nchunks = std::max(pl.tun_max_nchunks, t.nchunks);
 		for(uint32_t c = 0; c < t.nchunks; c++) pl.tun_chunk_stream.v.push_back((uint32_t)pl.tun.v.size());
 		tun_chunks += t.nchunks;
 		t.dict = dict_of(s, t);
@@ -1069,9 +1071,9 @@ static int build_and_launch(crthip_batch *b) {
 		if(!ctx->tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
 			if(ctx->tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end(); }
-			else { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, D(pl.tun), ntun, tun_partial); LT.end(); }
-		}
-		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, ctx->tun_single_pass)) return fail(CRTHIP_E_DEVICE); LT.end();
+			else if(pl.tun_max_nchunks > 256) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, D(pl.tun), ntun, tun_partial); LT.end(); }
+		}                                                                          // (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself)
+		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, ctx->tun_single_pass ? 1u : !ctx->tun_two_pass && pl.tun_max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
@@ -1282,7 +1284,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
 	ctx->last_decoded = nullptr;
 	std::vector<TunStream> tun; std::vector<uint32_t> chunk_stream; std::vector<FillJob> fills;
-	uint32_t chunks = 0; bool multi = false;
+	uint32_t chunks = 0, max_nchunks = 0; bool multi = false;
 	for(uint32_t i = 0; i < n; i++) {
 		const uint8_t *p = host_blocks + block_offset[i];
 		const uint32_t ns = p[0];
@@ -1297,6 +1299,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		t.src = dblk + 9 + 2*ns; t.dst = dst; t.probs = dblk + 1; t.csize = csize; t.size = size; t.nsym = ns; t.table = (uint32_t)tun.size();
 		t.chunk0 = chunks; tun_pick_geometry(t);
 		if(t.nchunks > 1) multi = true;
+		max_nchunks = std::max(max_nchunks, t.nchunks);
 		for(uint32_t c = 0; c < t.nchunks; c++) chunk_stream.push_back((uint32_t)tun.size());
 		chunks += t.nchunks;
 		tun.push_back(t);
@@ -1324,10 +1327,10 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		if(multi && !ctx->tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
 			if(ctx->tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end(); }
-			else { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, dt, ntun, part); LT.end(); }
-		}
+			else if(max_nchunks > 256) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, dt, ntun, part); LT.end(); }
+		}                                                                   // (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself)
 		LT.begin("tunstall_decode");
-		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, ctx->tun_single_pass)) return fail(CRTHIP_E_DEVICE); }
+		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, ctx->tun_single_pass ? 1u : !ctx->tun_two_pass && max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); }
 		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
 		LT.end();
 	}

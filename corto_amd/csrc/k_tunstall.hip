@@ -52,14 +52,16 @@ struct TunLds {
 	uint32_t scan[4];
 };
 
-__device__ __forceinline__ void tun_load_table(TunLds &L, const TunTable &T, uint32_t used) {
+__device__ __forceinline__ void tun_load_table(TunLds &L, const TunTable &T, uint32_t used) {      // 16-byte vectors: 48 of offsets / lengths, used/16 of words
 	const uint32_t t = threadIdx.x;
-	L.off[t] = T.off[t];
-	L.len[t] = T.len[t];
-	const uint32_t ndw = (used + 3) >> 2;
-	const uint32_t *src32 = (const uint32_t *)T.bytes;
-	uint32_t *dst32 = (uint32_t *)L.bytes;
-	for(uint32_t i = t; i < ndw; i += 256) dst32[i] = src32[i];
+	static_assert(offsetof(TunTable, len) == 512 && offsetof(TunTable, bytes) % 16 == 0 && sizeof(TunTable) % 16 == 0 && offsetof(TunLds, len) == 512 && offsetof(TunLds, bytes) % 16 == 0, "vector copy of a TunTable");
+	CRT_GLOBAL const u32x4_t *g = (CRT_GLOBAL const u32x4_t *)as_global((const uint8_t *)&T);
+	CRT_LDS u32x4_t *l = (CRT_LDS u32x4_t *)as_lds((uint8_t *)&L);
+	if(t < 48) l[t] = g[t];
+	const uint32_t nv = (min(used, TUN_TABLE_BYTES) + 15u) >> 4;
+	CRT_GLOBAL const u32x4_t *gb = (CRT_GLOBAL const u32x4_t *)as_global(T.bytes);
+	CRT_LDS u32x4_t *lb = (CRT_LDS u32x4_t *)as_lds(L.bytes);
+	for(uint32_t i = t; i < nv; i += 256) lb[i] = gb[i];
 }
 
 // pass A: decoded byte count of every quarter chunk (one wave's share of a chunk in pass B): chunk_out[4*c + w]
@@ -386,15 +388,21 @@ __global__ __launch_bounds__(256) void k_tun_stream_scan(const TunStream *__rest
 	const uint32_t n = st.nchunks*4u, tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	__shared__ uint32_t wsum[4];
 	uint64_t carry = 0;
-	for(uint32_t base = 0; base < n; base += 256) {                       // (a quarter chunk decodes to < 2^24 bytes: 256 of them fit 32 bits)
-		const uint32_t i = base + tid;
-		const uint32_t v = i < n ? (uint32_t)p[i] : 0u;
-		const uint32_t incl = wave_inclusive_scan_u32(v);
+	constexpr uint32_t PER = 8;                                           // values per thread and pass: eight loads in flight, one block scan per 2 048 values
+	for(uint32_t base = 0; base < n; base += 256*PER) {                   // (a quarter chunk decodes to < 2^21 bytes: 2 048 of them fit 32 bits)
+		const uint32_t i0 = base + tid*PER;
+		uint32_t v[PER], tot = 0;
+#pragma unroll
+		for(uint32_t k = 0; k < PER; k++) v[k] = i0 + k < n ? (uint32_t)p[i0 + k] : 0u;
+#pragma unroll
+		for(uint32_t k = 0; k < PER; k++) { const uint32_t x = v[k]; v[k] = tot; tot += x; }   // exclusive inside the thread
+		const uint32_t incl = wave_inclusive_scan_u32(tot);
 		if(lane == 63) wsum[w] = incl;
 		__syncthreads();
 		const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
-		const uint32_t woff = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
-		if(i < n) p[i] = carry + woff + incl - v;
+		const uint64_t off = carry + (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u) + (incl - tot);
+#pragma unroll
+		for(uint32_t k = 0; k < PER; k++) if(i0 + k < n) p[i0 + k] = off + v[k];
 		carry += (uint64_t)w0 + w1 + w2 + w3;
 		__syncthreads();
 	}
@@ -445,7 +453,7 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 	const uint32_t csize = st.csize;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	uint64_t base;
-	if(single_pass) {                                                     // (tun_lookback above)
+	if(single_pass == 1) {                                                // (tun_lookback above)
 		const uint32_t mine = tun_wave_bytes(src, first, last, as_lds(L.len));
 		if(lane == 0) share[1 + w] = mine;
 		__syncthreads();
@@ -462,7 +470,15 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 		(void)nchunks_all;
 		base = chain_lookback(chunk_out, c, st.chunk0, q0 + q1 + q2 + q3, 512u, &share[0], chunk_bytes);
 		base += w > 0 ? q0 : 0; base += w > 1 ? q1 : 0; base += w > 2 ? q2 : 0;
-	} else base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];   // two passes: k_tun_chunk_sums + scan ran before
+	} else if(single_pass == 2) {                                          // k_tun_chunk_sums ran before: the stream's quarter SUMS, not yet offsets - add up
+		CRT_GLOBAL const uint64_t *qs = as_global(chunk_out) + (size_t)st.chunk0*4;   // the ones in front of this wave's quarter (<= 1 024 of them: the
+		const uint32_t nq = (c - st.chunk0)*4u + w;                          // planner sends longer streams through k_tun_stream_scan)
+		uint64_t acc = 0;
+		for(uint32_t i = lane; i < nq; i += 64) acc += qs[i];
+#pragma unroll
+		for(int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+		base = acc;
+	} else base = chunk_out[(size_t)c*4 + w] - chunk_out[(size_t)st.chunk0*4];   // offsets: k_tun_chunk_sums + a scan ran before
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
 	CRT_LDS uint8_t *wb = (CRT_LDS uint8_t *)as_lds(winbuf) + w*(TUN_WIN + 64);   // window byte i lives at wb[16 + i]
 	CRT_LDS u32x4_t *win = (CRT_LDS u32x4_t *)(wb + 16);
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged_any(const TunStream *
 }
 
 // host side: the three launches.  They touch disjoint chunks, so they run side by side on three HIP streams (fork / join with
-// events around them): the tail of one class's chunks overlaps the body of the next.  single_pass: the chunk state words
+// events around them): the tail of one class's chunks overlaps the body of the next.  single_pass 1: the chunk state words
 // (chunk_out[0 .. nchunks], zeroed by the caller) carry the look-back; otherwise chunk_out holds the scanned quarter offsets.
 int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                              uint64_t *chunk_out, uint32_t single_pass) {

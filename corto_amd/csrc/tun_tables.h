@@ -233,10 +233,11 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 	__syncthreads();
 	if(Tg) {
 		if(lane == 0) { T.used = used; T.maxlen = maxlen; }
-		const uint32_t ndw = (used + 3) >> 2;
-		const uint32_t *src32 = (const uint32_t *)buf;
-		uint32_t *dst32 = (uint32_t *)T.bytes;
-		for(uint32_t i = lane; i < ndw; i += 64) dst32[i] = src32[i];
+		typedef uint32_t v4_t __attribute__((ext_vector_type(4)));
+		const uint32_t nv = ((used < TUN_TABLE_BYTES ? used : TUN_TABLE_BYTES) + 15u) >> 4;       // 16-byte vectors (both sides are 16-aligned)
+		const v4_t *src4 = (const v4_t *)buf;
+		v4_t *dst4 = (v4_t *)T.bytes;
+		for(uint32_t i = lane; i < nv; i += 64) dst4[i] = src4[i];
 	}
 	return TunBuilt{used, maxlen};
 }
