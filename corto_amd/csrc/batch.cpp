@@ -218,8 +218,8 @@ struct crthip_ctx {
 	bool tun_two_pass = false, tun_single_pass = false;
 	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
 	uint8_t exp_delta_walk = 0;                       // experiments: $CORTO_EXP_DELTA_WALK=1 - K-DELTA without the scan passes
-	uint8_t exp_no_deq_fold = 0;
-	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
+	uint8_t exp_no_deq_fold = 0;                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
+	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams
 	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
 	bool tun_three = false;         // $CORTO_TUN_THREE_LAUNCHES=1: one decode kernel per word-width class (A/B measurements)
 	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}, false} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}, !tun_three}; }
