@@ -115,6 +115,20 @@ def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     assert seen[None][0] <= seen["0"][0], seen
 
 
+def test_single_stream_context_decodes_the_same(ctx):
+    """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
+    the hardware queues) - same bytes as the two-stream schedule"""
+    gs = [load_golden(n) for n in ALL_CASES]
+    c = ca.Context(0)
+    c.set_single_stream(True)
+    for _ in range(2):
+        b = run_batch(c, [g["crt"] for g in gs])
+        for i, g in enumerate(gs):
+            assert_same(b.host_outputs(i), g, KEYS, ALL_CASES[i])
+        b.close()
+    c.close()
+
+
 def test_rgb_expands_to_rgba(ctx):
     g = load_golden("nrm_estimated_rgb")
     b = run_batch(ctx, [g["crt"]], color_components=4)
@@ -622,6 +636,36 @@ def test_tunstall_long_streams_on_four_contexts_at_once(ctx):
     assert not errors, errors[0]
     assert time.perf_counter() - t0 < 60
     for j in jobs: j[0].close()
+
+
+@pytest.mark.parametrize("env", [{}, {"CORTO_TUN_TWO_PASS": "1"}, {"CORTO_TUN_SINGLE_PASS": "1"}, {"CORTO_TUN_THREE_LAUNCHES": "1"}],
+                         ids=["sums+stream-scan", "sums+device-scan", "single-pass-lookback", "three-decode-launches"])
+def test_tunstall_long_stream_pipelines(monkeypatch, env):
+    """every way the long-stream path can find a chunk's output offset (k_tunstall.hip): quarter sums + a scan per stream (streams of more
+    than 256 chunks) or the decode waves adding up the sums in front of them (fewer), round 1's device-wide scan, the single pass with
+    wait-free look-back; one decode launch for all word-width classes or three.  A two-symbol dictionary with words up to 255 bytes
+    (hundreds of small chunks), a flat one, a short stream beside them."""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    c = ca.Context(0)                                    # (the switches are read when a context is made)
+    rng = np.random.default_rng(23)
+    k = _kat()
+    blocks, sizes, expect = [], [], []
+    for pr, ncode in ((np.array([[0, 240], [1, 15]], dtype=np.uint8), 1_200_000), (k["probs_20"], 700_001), (k["probs_09"], 5_000), (k["probs_37"], 90_000)):
+        idx, ln, tab = oc.tunstall_tables(pr)
+        payload = rng.integers(0, 256, ncode).astype(np.uint8)
+        size = int(np.asarray(ln)[payload].sum())
+        hdr = bytes([len(pr)]) + pr.tobytes() + size.to_bytes(4, "little") + ncode.to_bytes(4, "little")
+        blocks.append(np.frombuffer(hdr + payload.tobytes(), dtype=np.uint8)); sizes.append(size)
+        expect.append(oc.tunstall_decompress(pr, payload, size))
+    for _ in range(2):
+        outs, _t = _run_blocks(c, blocks, sizes)
+        for i, (o, e) in enumerate(zip(outs, expect)):
+            assert np.array_equal(o, e), (i, env)
+    outs, _t = _run_blocks(c, blocks[2:], sizes[2:])     # few chunks per stream: no scan launch
+    for i, (o, e) in enumerate(zip(outs, expect[2:])):
+        assert np.array_equal(o, e), (i, env, "short")
+    c.close()
 
 
 def test_tunstall_long_streams_every_step_geometry(ctx):
