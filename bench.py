@@ -16,6 +16,9 @@ Timing: barrier + device sync, then W warm-up steps flow straight into the K tim
 between); the clock runs from the completion of the last warm-up step to the completion of the K-th timed step, a few more
 steps are queued behind so that every context is still busy when the clock stops, then everything drains, barrier + sync.
 So `--steps 20` measures the same steady state as `--steps 480`.  value = K batches / that time (max over ranks).
+With K < 100 the K-step region is timed five times back to back (no drain in between) and the MEDIAN region is reported, every
+region's time in `timed_regions`: completions of sixteen batches in flight come in bursts, and one region of 20 steps lands
+anywhere within -15 / +30 % of the long-run rate (tools/pool_probe.py).
 `python bench.py --gpus N` without a launcher runs the N GPUs from this one process (one pool, shared queue, N x K steps);
 under torch.distributed.run every rank runs its own one-GPU pool on its shard (seeds 256*rank ..) and RCCL carries only the
 barrier and the max-over-ranks of the time.
@@ -477,9 +480,16 @@ def main():
     # whatever W is: every context used (scratch pools are allocated on first use) and the GPU at its working clocks before the clock starts
     pool.run(items, steps=8 * pool.lanes, warmup=0, arenas=arenas)
     barrier()
-    rep, stamps = pool.run(items, steps=args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
+    # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
+    # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
+    # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: one region.
+    R = 1 if args.steps >= 100 else 5
+    rep, stamps = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
     barrier()
-    elapsed = shard.max_over_ranks(rep.elapsed_s, dist, red_dev)
+    kk = args.steps * nloc
+    tt = np.concatenate([[0.0], np.asarray(stamps, dtype=np.float64)])             # completion times of the timed steps, from the last warm-up step's
+    regions = [shard.max_over_ranks(float(tt[(j + 1) * kk] - tt[j * kk]), dist, red_dev) for j in range(R)]
+    elapsed = float(np.median(regions))
     if rep.failed_blobs or rep.first_error:
         raise SystemExit("bench.py: %d blobs failed to decode (first status %d)" % (rep.failed_blobs, rep.first_error))
     if rep.devices_used != nloc:
@@ -534,8 +544,8 @@ def main():
     tris_ns = shard.sum_over_ranks(float(rep_ns.triangles), dist, red_dev)
     pool_ns.close()
 
-    tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev)
-    verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev)
+    tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev) / R     # (per K-step region)
+    verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev) / R
     tris_h = shard.sum_over_ranks(float(rep_h.triangles), dist, red_dev)
     if rank == 0:
         ntri, nvert = int(stats0.total_nface), int(stats0.total_nvert)
@@ -559,13 +569,15 @@ def main():
             "value": round(tris_total / elapsed / 1e6, 2), "unit": "Mtri/s",
             "mverts_per_s": round(verts_total / elapsed / 1e6, 2),
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "timed_regions": {"count": R, "ms_per_step": [round(e / args.steps * 1e3, 4) for e in regions],
+                              "note": "consecutive regions of exactly K steps each, pipeline full throughout; `value` and `ms_per_step` are the median region's"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 integer + f32 normals",
             "data": "synthetic: 256 distinct bumpy-sphere meshes per GPU (seeds 256*g ..), encoded by the repo's byte-identical .crt writer",
             "config": {"workload": "C4: 256 x (2112 verts / 4096 tris), pos14+uv12+normal10(BORDER)+rgba, per GPU; C5 when n_gpus=8",
                        "blobs_per_gpu": NBLOBS, "tris_per_gpu": ntri, "verts_per_gpu": nvert,
                        "timed_region": "K x [plan(host walk)+bind+kernels+sync] per GPU, compressed inputs resident in HBM, outputs left in HBM; clock from the "
                                        "completion of the last of W warm-up steps to the completion of the K-th timed step, pipeline full at both ends "
-                                       "(barrier + device sync before the warm-up and after the drain)",
+                                       "(barrier + device sync before the warm-up and after the drain); K < 100: five such regions back to back, the median one reported (timed_regions)",
                        "pipeline_depth": depth, "host_threads": nthreads, "launch": mode,
                        "parallelism": "blob-sharded x%d, no collective; %s; %d native host threads x %d batches in flight per GPU" % (
                            n_gpus, "one process, one work queue over all GPUs" if world == 1 else "one process per GPU, RCCL only for barrier/max", nthreads, depth)},
