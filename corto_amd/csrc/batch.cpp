@@ -1184,6 +1184,17 @@ extern "C" int crthip_batch_sync(crthip_batch *b, int32_t *status) {
 	return first;
 }
 
+extern "C" int crthip_batch_done(crthip_batch *b) {
+	if(!b || !b->ctx) return fail(CRTHIP_E_ARGUMENT);
+	crthip_ctx *ctx = b->ctx;
+	if(ctx->in_flight != b) return 1;                                  // harvested already, or never decoded
+	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+	const hipError_t e = hipStreamQuery(ctx->stream);
+	if(e == hipSuccess) return 1;
+	if(e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+	return fail(CRTHIP_E_DEVICE);
+}
+
 extern "C" int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s) {
 	if(!b || !s) return fail(CRTHIP_E_ARGUMENT);
 	*s = b->stats;

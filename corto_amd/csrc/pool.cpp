@@ -179,7 +179,21 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 		};
 		int err = CRTHIP_OK;
 		for(uint64_t n = 0; !err; n++) {
-			Lane &L = mine[n % p->depth];
+			// the next lane to refill: a free one, else whichever of the busy ones finishes first (they mostly finish in the order they
+			// were launched, but a thread that waited on the oldest while a younger one was done left that context idle)
+			uint32_t pick = p->depth;
+			for(uint32_t k = 0; k < p->depth && pick == p->depth; k++) if(!mine[(n + k) % p->depth].busy) pick = (uint32_t)((n + k) % p->depth);
+			for(uint32_t spins = 0; pick == p->depth && !err; spins++) {
+				for(uint32_t k = 0; k < p->depth; k++) {
+					Lane &C = mine[(n + k) % p->depth];
+					const int d = crthip_batch_done(C.batch);
+					if(d < 0) { err = d; break; }
+					if(d) { pick = (uint32_t)((n + k) % p->depth); break; }
+				}
+				if(pick == p->depth && !err) { if(spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(5)); }
+			}
+			if(err) break;
+			Lane &L = mine[pick];
 			if(L.busy) err = finish(L);
 			if(err) break;
 			const uint64_t step = p->next.fetch_add(1);

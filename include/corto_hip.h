@@ -157,6 +157,9 @@ int crthip_batch_decode(crthip_batch *b);
 /* Wait for completion and collect per-blob status: status[i] = CRTHIP_OK or CRTHIP_E_* (may be NULL).
  * Returns CRTHIP_OK if every blob decoded, else the first failing blob's code. */
 int crthip_batch_sync(crthip_batch *b, int32_t *status);
+/* Without waiting: 1 if crthip_batch_sync would return at once (the decode has finished, or none is in flight), 0 if it is still
+ * running, <0 on error.  For callers that keep several batches in flight and refill whichever finishes first (crthip_pool). */
+int crthip_batch_done(crthip_batch *b);
 
 /* One-blob convenience with HOST output buffers: probe + plan + device decode + copy back.
  * This is what the crt::Decoder facade (include/corto/decoder.h of this repo) calls. */
