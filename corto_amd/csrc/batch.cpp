@@ -377,6 +377,9 @@ extern "C" int crthip_ctx_set_profiling(crthip_ctx *c, int enable) {
 extern "C" int crthip_ctx_set_single_stream(crthip_ctx *c, int on) {
 	if(!c) return fail(CRTHIP_E_ARGUMENT);
 	c->single_stream = on != 0;
+	// many batches in flight: kernels wait for LDS to come free, and a request of 41 KB finds room long before one of 91 KB does - the
+	// normals kernel without its face-normal array takes twice as long alone (79 vs 39 us per C4 batch) and the pipelined rate is 10 % higher
+	if(!getenv("CORTO_EXP_NORMAL_FN_MAX")) c->exp_normal_fn_max = on ? 0u : NORMAL_FN_LDS_MAX;
 	return CRTHIP_OK;
 }
 
