@@ -951,7 +951,8 @@ static int build_and_launch(crthip_batch *b) {
 			const DeltaJob &d0 = pl.delta.v[j];
 			uint64_t lds = delta_wave_need(d0);
 			DeltaGroup g{(uint32_t)j, 1};
-			while(j + g.count < pl.delta.v.size() && g.count < DELTA_GROUP_MAX) {
+			static const uint32_t gmax_ = [] { const char *e = getenv("CORTO_EXP_DELTA_GROUP"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 1 && v <= DELTA_GROUP_MAX ? v : DELTA_GROUP_MAX; }();
+			while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
 				const DeltaJob &d = pl.delta.v[j + g.count];
 				const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
 				if(d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;

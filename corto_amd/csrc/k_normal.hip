@@ -296,6 +296,42 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 #undef CRT_CX
 #pragma unroll
 			for(uint32_t k = 0; k < 8; k++) if(k < deg) { ex += fn[3*id[k]]; ey += fn[3*id[k] + 1]; ez += fn[3*id[k] + 2]; }
+		} else if(deg <= 8) {
+			// the LDS-lean layout (no face-normal array: what a context gets when many batches are in flight): the same sorted ids, then the
+			// faces' indices and their nine coordinates are fetched four faces at a time - every load of a group in flight together, two
+			// dependent round trips per group instead of two per face - and the normals recomputed and added in id order
+			uint32_t id[8];
+#pragma unroll
+			for(uint32_t k = 0; k < 8; k++) id[k] = k < deg ? (uint32_t)adj[s0 + k] : 0xFFFFFFFFu;
+#define CRT_CX(p, q) { const uint32_t lo_ = min(id[p], id[q]), hi_ = max(id[p], id[q]); id[p] = lo_; id[q] = hi_; }
+			CRT_CX(0, 1) CRT_CX(2, 3) CRT_CX(4, 5) CRT_CX(6, 7)
+			CRT_CX(0, 2) CRT_CX(1, 3) CRT_CX(4, 6) CRT_CX(5, 7)
+			CRT_CX(1, 2) CRT_CX(5, 6) CRT_CX(0, 4) CRT_CX(3, 7)
+			CRT_CX(1, 5) CRT_CX(2, 6)
+			CRT_CX(1, 4) CRT_CX(3, 6)
+			CRT_CX(2, 4) CRT_CX(3, 5)
+			CRT_CX(3, 4)
+#undef CRT_CX
+#pragma unroll
+			for(uint32_t h = 0; h < 8; h += 4) {
+				if(h >= deg) break;
+				uint32_t fa[4][3];
+				int32_t P[4][9];
+#pragma unroll
+				for(uint32_t k = 0; k < 4; k++) { fa[k][0] = fa[k][1] = fa[k][2] = 0; if(h + k < deg) face(id[h + k], fa[k][0], fa[k][1], fa[k][2]); }
+#pragma unroll
+				for(uint32_t k = 0; k < 4; k++) if(h + k < deg) {
+#pragma unroll
+					for(uint32_t v = 0; v < 3; v++) { CRT_GLOBAL const int32_t *q = pos + 3*fa[k][v]; P[k][3*v] = q[0]; P[k][3*v + 1] = q[1]; P[k][3*v + 2] = q[2]; }
+				}
+#pragma unroll
+				for(uint32_t k = 0; k < 4; k++) if(h + k < deg) {
+					const float x0 = (float)P[k][0], y0 = (float)P[k][1], z0 = (float)P[k][2];
+					const float ax = (float)P[k][3] - x0, ay = (float)P[k][4] - y0, az = (float)P[k][5] - z0;
+					const float bx = (float)P[k][6] - x0, by = (float)P[k][7] - y0, bz = (float)P[k][8] - z0;
+					ex += ay*bz - az*by; ey += az*bx - ax*bz; ez += ax*by - ay*bx;   // point.h:113-115
+				}
+			}
 		} else {
 		int32_t last = -1;
 		for(uint32_t done = 0; done < deg;) {
