@@ -568,6 +568,40 @@ def test_tunstall_tables_kat_on_device(ctx):
         assert np.array_equal(o, e), i
 
 
+def test_tunstall_random_dictionaries_on_device(ctx):
+    """800 random probability tables - 2 to 255 symbols, flat / skewed / one dominant symbol (the low-entropy seed) / zero tails /
+    ties - built on the device and read back through the payload 0..255, against the oracle's tables (which are pinned to the
+    reference's createDecodingTables2 on 1 500 random tables, tests/test_oracle_vs_reference.py)"""
+    rng = np.random.default_rng(77)
+    blocks, sizes, expect = [], [], []
+    for t in range(800):
+        n = int(rng.integers(2, 256)) if t % 5 == 0 else int(rng.integers(2, 24)) if t % 5 < 3 else int(rng.integers(24, 130))
+        kind = t % 6
+        if kind == 0:
+            p = np.sort(rng.integers(0, 256, n))[::-1]
+        elif kind == 1:
+            p = np.sort((255 * rng.dirichlet(np.ones(n) * 0.3)).astype(int))[::-1]
+        elif kind == 2:
+            p = np.array([max(250 - n, 1)] + list(np.sort(rng.integers(0, 4, n - 1))[::-1]))
+        elif kind == 3:
+            p = np.sort((255 * rng.dirichlet(np.ones(n) * 4)).astype(int))[::-1]
+        elif kind == 4:
+            p = np.full(n, max(255 // n, 1))                                      # all ties
+        else:
+            p = np.sort(rng.integers(0, 3, n))[::-1]                              # mostly zeros
+        pr = np.stack([rng.permutation(256)[:n], np.clip(p, 0, 255)], 1).astype(np.uint8)
+        idx, ln, tab = oc.tunstall_tables(pr)
+        idx, ln = np.asarray(idx).astype(int), np.asarray(ln).astype(int)
+        words = np.concatenate([np.asarray(tab)[idx[c]:idx[c] + ln[c]] for c in range(256)]) if ln.sum() else np.zeros(0, np.uint8)
+        if (ln > 0).sum() < 256:                       # the reference's own word buffer would overflow (its assert at src/tunstall.cpp:229; all-zero
+            continue                                   # probabilities, which its encoder never writes): no reference result to agree with
+        hdr = bytes([len(pr)]) + pr.tobytes() + int(len(words)).to_bytes(4, "little") + (256).to_bytes(4, "little")
+        blocks.append(np.frombuffer(hdr + bytes(range(256)), dtype=np.uint8)); sizes.append(len(words)); expect.append(words)
+    outs, _ = _run_blocks(ctx, blocks, sizes)
+    bad = [i for i, (o, e) in enumerate(zip(outs, expect)) if not np.array_equal(o, e)]
+    assert not bad, (len(bad), bad[:5], [int(blocks[i][0]) for i in bad[:5]])
+
+
 def test_tunstall_streams_kat_on_device(ctx):
     k = _kat()
     blocks = [k["stream_block_%d" % i] for i in range(8)]
