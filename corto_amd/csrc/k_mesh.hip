@@ -1269,20 +1269,47 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 // at least one vertex.  Any triple set is handled (a malformed or adversarial one only costs passes).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// The walk's bookkeeping is bit-packed (it is the fallback of the scans below, and a byte per vertex and attribute of fired flags plus
+// two of stretch starts were 10.5 KB of a C4 blob's 74 KB of LDS): `fbits` one bit per vertex, set with ds_or; `sbits` one bit per
+// vertex that starts a stretch, `spre[j]` the number of starts in the dwords below j, so that lane k finds its stretches k, k+64, ...
+// with a binary search over spre and a select inside one dword.
+struct DeltaStarts { CRT_LDS const uint32_t *sbits; CRT_LDS const uint16_t *spre; uint32_t nw, ns; };
+
+__device__ __forceinline__ bool delta_take_stretch(const DeltaStarts &G, uint32_t k, uint32_t nvert, uint32_t &i, uint32_t &end) {
+	if(k >= G.ns) return false;
+	uint32_t lo = 0, hi = G.nw;                                           // largest j with spre[j] <= k
+	while(hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if((uint32_t)G.spre[mid] <= k) lo = mid; else hi = mid; }
+	uint32_t word = G.sbits[lo];
+	for(uint32_t r = k - G.spre[lo]; r; r--) word &= word - 1u;            // drop the starts in front of mine
+	const uint32_t bit = (uint32_t)__builtin_ctz(word | 0x80000000u);
+	i = lo*32u + bit;
+	word &= word - 1u;                                                     // the next start: where this stretch ends
+	uint32_t j = lo;
+	while(!word && ++j < G.nw) word = G.sbits[j];
+	end = word ? j*32u + (uint32_t)__builtin_ctz(word) : nvert;
+	if(end > nvert) end = nvert;
+	return true;
+}
+
 template <typename T, int NC>
-__device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, CRT_LDS uint8_t *fired,
-                                               CRT_LDS const uint16_t *starts, uint32_t ns, uint32_t nvert, uint32_t Nrt, bool para, uint32_t first) {
+__device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, CRT_LDS uint32_t *fbits,
+                                               const DeltaStarts &G, uint32_t nvert, uint32_t Nrt, bool para, uint32_t first) {
 	const uint32_t n = NC ? (uint32_t)NC : Nrt;
-	for(uint32_t j = lane_id(); j < nvert; j += 64) fired[j] = j < first;        // vertices below `first` are final already (delta_scan_run)
+	for(uint32_t d = lane_id(); d < G.nw; d += 64) {                       // vertices below `first` are final already (delta_scan_run)
+		const uint32_t b0 = d*32u;
+		fbits[d] = first >= b0 + 32u ? 0xFFFFFFFFu : first > b0 ? (1u << (first - b0)) - 1u : 0u;
+	}
+	auto is_fired = [&](uint32_t x) -> uint32_t { return (fbits[x >> 5] >> (x & 31u)) & 1u; };
 	uint32_t k = lane_id();
-	bool active = k < ns;
+	bool active = true;
 	uint32_t i = 0, end = 0;
 	auto take = [&]() {                                                    // stretch k, from `first` on; stretches that end below it are done
 		while(active) {
-			i = starts[k]; end = k + 1 < ns ? (uint32_t)starts[k + 1] : nvert;
+			active = delta_take_stretch(G, k, nvert, i, end);
+			if(!active) break;
 			if(i < first) i = first;
 			if(i < end) break;
-			k += 64; active = k < ns;
+			k += 64;
 		}
 	};
 	take();
@@ -1292,7 +1319,7 @@ __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint1
 			// malformed triple (and vertex 0): the value stays.  v += v[a] alone: b = c = vertex 0 cancel
 			const bool inv = a == 0xFFFFu || (para && bc == 0xFFFFFFFFu);
 			const uint32_t aa = inv ? 0u : a, b = inv || !para ? 0u : bc & 0xFFFFu, c = inv || !para ? 0u : bc >> 16;
-			const uint32_t ready = (uint32_t)fired[aa] & fired[b] & fired[c];
+			const uint32_t ready = is_fired(aa) & is_fired(b) & is_fired(c);
 			if(NC) {                                                         // values are fetched with the flags: one LDS round trip per pass
 				T x[NC ? NC : 1];
 #pragma unroll
@@ -1305,9 +1332,9 @@ __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint1
 				for(uint32_t q = 0; q < n; q++) v[i*n + q] = (T)(v[i*n + q] + v[aa*n + q] + v[b*n + q] - v[c*n + q]);
 			}
 			if(ready) {
-				fired[i] = 1;
+				(void)__hip_atomic_fetch_or(fbits + (i >> 5), 1u << (i & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_or_b32
 				i++;
-				if(i == end) { k += 64; active = k < ns; take(); }
+				if(i == end) { k += 64; take(); }
 				if(active) { a = pa[i]; bc = pbc[i]; }
 			}
 		}
@@ -1464,14 +1491,16 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 	const uint32_t lane = lane_id(), w = wave_id();
 	const DeltaJob J0 = jobs[G.first];
 	const uint32_t nvert = J0.nvert;
-	// LDS: values of every attribute | a u16 | b,c u32 | starts u16 | fired u8 x count
+	// LDS: values of every attribute | a u16 | b,c u32 | stretch-start bits, prefix counts | fired bits x count
 	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
 	uint32_t myoff = 0, vtot = 0;
 	for(uint32_t k = 0; k < G.count; k++) { const uint32_t vb = delta_wave_vbytes(nvert, jobs[G.first + k].N, jobs[G.first + k].is_u8 != 0); if(k < w) myoff += vb; vtot += vb; }
 	CRT_LDS uint16_t *pa = (CRT_LDS uint16_t *)(l8 + vtot);
 	CRT_LDS uint32_t *pbc = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)pa + delta_wave_a_bytes(nvert));
-	CRT_LDS uint16_t *starts = (CRT_LDS uint16_t *)(pbc + nvert);
-	CRT_LDS uint8_t *fired_all = (CRT_LDS uint8_t *)starts + delta_wave_a_bytes(nvert);
+	const uint32_t nw = delta_wave_bit_words(nvert);
+	CRT_LDS uint32_t *sbits = pbc + nvert;
+	CRT_LDS uint16_t *spre = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)sbits + delta_wave_fired_bytes(nvert));
+	CRT_LDS uint8_t *fired_all = (CRT_LDS uint8_t *)sbits + delta_wave_starts_bytes(nvert);
 	const uint32_t builder = G.count < 4 ? G.count : 0u;
 	if(w == builder) {
 		// prediction triples -> a | (b, c) | stretch starts.  Four rounds of 64 vertices in flight.
@@ -1495,8 +1524,12 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 					pa[i] = (uint16_t)(va ? ta[u] : 0xFFFFu);
 					pbc[i] = tb[u] < i && tc[u] < i ? tb[u] | (tc[u] << 16) : 0xFFFFFFFFu;
 				}
-				const uint64_t m = __ballot(start);
-				if(start) starts[ns + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+				const uint64_t m = __ballot(start);                              // the round's 64 vertices: two dwords of the start bitmap
+				if(lane == 0 && base + u*64 < nvert) {
+					const uint32_t d = (base + u*64) >> 5, lo32 = (uint32_t)m, hi32 = (uint32_t)(m >> 32);
+					sbits[d] = lo32; sbits[d + 1] = hi32;
+					spre[d] = (uint16_t)ns; spre[d + 1] = (uint16_t)(ns + __popc(lo32));
+				}
 				ns += __popcll(m);
 			}
 		}
@@ -1504,7 +1537,7 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 	}
 	DeltaJob J = J0;
 	DeltaStage S{};
-	CRT_LDS uint8_t *fired = fired_all + w*delta_wave_fired_bytes(nvert);
+	CRT_LDS uint32_t *fbits = (CRT_LDS uint32_t *)(fired_all + w*delta_wave_fired_bytes(nvert));
 	if(w < G.count) {
 		J = jobs[G.first + w];
 		S = delta_stage_plan(l8 + myoff, J.values, nvert*J.N*(J.is_u8 ? 1u : 4u));
@@ -1516,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 		const bool para = J.parallelogram != 0;
 		// scans first (delta_scan_run); what they leave - short blocks: irregular connectivity - to the flag-driven walk
 #define CRT_DELTA(T_, NC_, V_) do { uint32_t first_ = 1; if(NC_ && !J.pad[1]) first_ = delta_scan_run<T_, (NC_) ? (NC_) : 1>(V_, pa, pbc, nvert, para); \
-		if(first_ < nvert) delta_wave_run<T_, NC_>(V_, pa, pbc, fired, starts, ns, nvert, N, para, first_); } while(0)
+		if(first_ < nvert) delta_wave_run<T_, NC_>(V_, pa, pbc, fbits, DeltaStarts{sbits, spre, nw, ns}, nvert, N, para, first_); } while(0)
 		if(J.is_u8) {
 			CRT_LDS uint8_t *v = S.l8;
 			switch(N) {

@@ -63,13 +63,17 @@ constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of k_delta_mesh's workgroup for one (blob, attribute) too big for LDS; half of them up to DELTA_SMALL_NVERT vertices
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs);
 // one workgroup per blob, one wave per attribute (up to four), when the attributes' values + the prediction graph fit LDS (k_mesh.hip):
-// values of every attribute | a u16 | b,c u32 | stretch starts u16 | fired u8 per attribute
+// values of every attribute | a u16 | b,c u32 | stretch-start bits + their prefix counts | fired bits per attribute.  (The stretch list and
+// the fired flags serve the walk that takes over where the scans give up; as 2 + 1 bytes per vertex they were 10.5 KB of a C4 blob's 74 KB
+// for a path regular meshes never take - as bitmaps they are 1.2 KB, and 14 % less LDS per workgroup is 4 % more pipelined throughput.)
 constexpr uint32_t DELTA_WAVE_LDS_MAX = 128*1024, DELTA_GROUP_MAX = 4;
 __host__ __device__ inline uint32_t delta_wave_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return ((nvert*N*(is_u8 ? 1u : 4u) + 15u) & ~15u) + 32u; }
 __host__ __device__ inline uint32_t delta_wave_a_bytes(uint32_t nvert) { return (2u*nvert + 15u) & ~15u; }
-__host__ __device__ inline uint32_t delta_wave_fired_bytes(uint32_t nvert) { return (nvert + 15u) & ~15u; }
+__host__ __device__ inline uint32_t delta_wave_bit_words(uint32_t nvert) { return ((nvert + 63u) >> 6) << 1; }                   // whole 64-vertex rounds
+__host__ __device__ inline uint32_t delta_wave_fired_bytes(uint32_t nvert) { return (delta_wave_bit_words(nvert)*4u + 15u) & ~15u; }
+__host__ __device__ inline uint32_t delta_wave_starts_bytes(uint32_t nvert) { return delta_wave_fired_bytes(nvert) + (((delta_wave_bit_words(nvert) + 1u)*2u + 15u) & ~15u); }   // bits + u16 prefix counts
 // LDS of the shared graph (+64 slack) and of one attribute riding on it; ~0 when the vertex ids do not fit 16 bits
-__host__ __device__ inline uint64_t delta_wave_graph_lds(uint32_t nvert) { return nvert > 65534u ? ~0ull : 2ull*delta_wave_a_bytes(nvert) + 4ull*nvert + 64; }
+__host__ __device__ inline uint64_t delta_wave_graph_lds(uint32_t nvert) { return nvert > 65534u ? ~0ull : (uint64_t)delta_wave_a_bytes(nvert) + delta_wave_starts_bytes(nvert) + 4ull*nvert + 64; }
 __host__ __device__ inline uint64_t delta_wave_attr_lds(uint32_t nvert, uint32_t N, bool is_u8) {
 	if(nvert > 65534u || (uint64_t)nvert*N > (1u << 24)) return ~0ull;
 	return (uint64_t)delta_wave_vbytes(nvert, N, is_u8) + delta_wave_fired_bytes(nvert);
