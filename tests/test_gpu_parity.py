@@ -357,6 +357,30 @@ def test_pool_shared_queue_two_devices(c5_blobs):
     pool.close()
 
 
+@pytest.mark.timeout(300)
+def test_pool_of_sixteen_contexts_on_one_gpu(c5_blobs):
+    """the shape bench.py runs: 4 host threads x 4 batches in flight on one GPU - more streams than hardware queues, so the pool gives
+    every context ONE stream and the LDS-lean kernel layouts (crthip_ctx_set_single_stream), and its workers refill whichever batch
+    finishes first; every context's last outputs against the oracle"""
+    items = [c5_blobs[256 * g + 16: 256 * g + 16 + 96] for g in range(3)]
+    pool = ca.Pool([0], threads=4, depth=4)
+    assert pool.lanes == 16
+    arenas = [[ca.upload_arena(it, 0)] for it in items]
+    dts = {"position": (np.float32, 3), "normal": (np.float32, 3), "color": (np.uint8, 4), "uv": (np.float32, 2), "index": (np.uint32, 3)}
+    rep, stamps = pool.run(items, steps=96, warmup=16, arenas=arenas)
+    assert rep.steps == 96 and rep.failed_blobs == 0 and rep.first_error == 0 and rep.devices_used == 1
+    assert rep.triangles == 96 * 96 * 4096 and len(stamps) == 96
+    for lane in range(pool.lanes):
+        it, slot = pool.lane_item(lane)
+        assert 0 <= it < 3 and slot == 0
+        for i in (lane, 95 - lane, 40 + lane):
+            ref = oc.decode(items[it][i])
+            for k, (dt, w) in dts.items():
+                got = pool.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
+                assert got.tobytes() == ref[k].tobytes(), (lane, it, i, k)
+    pool.close()
+
+
 def test_cpp_decoder_threads(ctx, tmp_path):
     """SURVEY §8b Threading: distinct crt::Decoder objects on 4 threads at once (tests/cpp/facade_threads.cpp), every decode
     repeated and compared with its first, thread 0's outputs compared with the oracle"""
