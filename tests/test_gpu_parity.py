@@ -115,6 +115,26 @@ def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     assert seen[None][0] <= seen["0"][0], seen
 
 
+def test_vertex_counts_around_the_bitmap_words(monkeypatch):
+    """K-DELTA's fallback walk keeps its fired flags and stretch starts as bitmaps (one dword per 32 vertices, written 64 vertices a round):
+    vertex counts on and around the word boundaries, tiny meshes, a long thin strip (2 049 vertices: 683 stretches) - with the walk
+    forced ($CORTO_EXP_DELTA_WALK=1), with the scans, and on a single-stream context (the LDS-lean normals path)"""
+    from corto_amd import synth
+    meshes = [synth.bumpy_sphere(w, h, seed=w * h) for w, h in ((3, 2), (4, 3), (9, 6), (8, 7), (13, 4), (16, 7), (43, 2), (31, 32), (64, 31), (683, 2))]
+    assert [m.nvert for m in meshes] == [9, 16, 63, 64, 65, 128, 129, 1023, 2048, 2049]
+    blobs = [ca.encode(m, normal_prediction=ca.ESTIMATED if k % 2 else ca.BORDER) for k, m in enumerate(meshes)]
+    refs = [oc.decode(b) for b in blobs]
+    for walk, single in (("1", False), ("0", False), ("1", True), ("0", True)):
+        monkeypatch.setenv("CORTO_EXP_DELTA_WALK", walk)
+        c = ca.Context(0)
+        if single:
+            c.set_single_stream(True)
+        b = run_batch(c, blobs)
+        for i, r in enumerate(refs):
+            assert_same(b.host_outputs(i), r, KEYS, "nvert %d walk=%s single=%s" % (meshes[i].nvert, walk, single))
+        b.close(); c.close()
+
+
 def test_single_stream_context_decodes_the_same(ctx):
     """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
     the hardware queues) - same bytes as the two-stream schedule"""
