@@ -1361,7 +1361,12 @@ __device__ __forceinline__ uint32_t delta_scan_run(CRT_LDS T *v, CRT_LDS const u
 	while(s < nvert) {
 		const uint32_t i = s + lane;
 		const bool in = i < nvert;
-		const uint32_t a = in ? pa[i] : 0xFFFFu, bc = in ? pbc[i] : 0xFFFFFFFFu;
+		// (loads are unconditional, on clamped addresses, and pinned by empty asm statements: written as `in ? pa[i] : ...` the compiler sinks
+		// every load into its own exec-masked branch with its own wait - six LDS round trips a pass instead of three)
+		const uint32_t ic = in ? i : nvert - 1u;
+		uint32_t a = pa[ic], bc = pbc[ic];
+		asm volatile("" : "+v"(a), "+v"(bc));
+		a = in ? a : 0xFFFFu; bc = in ? bc : 0xFFFFFFFFu;
 		const bool inv = a == 0xFFFFu || (para && bc == 0xFFFFFFFFu);           // malformed triple: the value stays (a head with base 0)
 		const uint32_t b = bc & 0xFFFFu, c = bc >> 16;
 		const bool chained = !inv && a + 1 == i && lane != 0;                   // continues its predecessor's sum
@@ -1377,11 +1382,13 @@ __device__ __forceinline__ uint32_t delta_scan_run(CRT_LDS T *v, CRT_LDS const u
 		// stores (written as a loop over components the stores of one fenced in the loads of the next: three LDS round trips each)
 		uint32_t x[NC], incl[NC], eh[NC];
 		const uint32_t ri = mine ? i : 0u, rb = mine && !inv && para ? b : 0u, rc = mine && !inv && para ? c : 0u, ra = head && !inv ? a : 0u;
+		uint32_t g[NC][4];
 #pragma unroll
-		for(uint32_t q = 0; q < (uint32_t)NC; q++) {
-			const uint32_t vi = (uint32_t)v[ri*NC + q], vb = (uint32_t)v[rb*NC + q], vc = (uint32_t)v[rc*NC + q], va = (uint32_t)v[ra*NC + q];
-			x[q] = mine ? vi + (!inv && para ? vb - vc : 0u) + (head && !inv ? va : 0u) : 0u;
-		}
+		for(uint32_t q = 0; q < (uint32_t)NC; q++) { g[q][0] = (uint32_t)v[ri*NC + q]; g[q][1] = (uint32_t)v[rb*NC + q]; g[q][2] = (uint32_t)v[rc*NC + q]; g[q][3] = (uint32_t)v[ra*NC + q]; }
+#pragma unroll
+		for(uint32_t q = 0; q < (uint32_t)NC; q++) asm volatile("" : "+v"(g[q][0]), "+v"(g[q][1]), "+v"(g[q][2]), "+v"(g[q][3]));   // every gather in flight, one wait
+#pragma unroll
+		for(uint32_t q = 0; q < (uint32_t)NC; q++) x[q] = mine ? g[q][0] + (!inv && para ? g[q][1] - g[q][2] : 0u) + (head && !inv ? g[q][3] : 0u) : 0u;
 #pragma unroll
 		for(uint32_t q = 0; q < (uint32_t)NC; q++) incl[q] = wave_inclusive_scan_u32(x[q]);
 #pragma unroll
