@@ -278,13 +278,19 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	for(uint32_t i = tid; i < nv; i += 256) {
 		const uint32_t s0 = start[i], deg = (uint32_t)start[i + 1] - s0;
 		float ex = 0.f, ey = 0.f, ez = 0.f;
-		if(fn_lds && deg <= 8) {
-			// the usual vertex: its (at most eight) incident faces sorted by id with a branch-free network, their normals read from
-			// LDS and added in that order.  Equal ids (a face naming the vertex twice) end up adjacent and are added twice, as the
-			// reference does.  (The selection loop below takes deg^2 data-dependent branches; a lone wave pays ~20 clocks for each.)
+		if(deg <= 8 && deg > 0) {
+			// the usual vertex: its (at most eight) incident faces sorted by id with a branch-free network and their normals added in that
+			// order.  Equal ids (a face naming the vertex twice) end up adjacent and are added twice, as the reference does.  (The selection
+			// loop below takes deg^2 data-dependent branches; a lone wave pays ~20 clocks for each.)
+			// Every load here is UNCONDITIONAL, on a clamped index, and pinned by an empty asm statement: written as `k < deg ? adj[..] : ..`
+			// the compiler sinks each one into an exec-masked branch of its own with its own wait - eight LDS round trips for the ids and
+			// one per face for what follows, where one and two do.
 			uint32_t id[8];
 #pragma unroll
-			for(uint32_t k = 0; k < 8; k++) id[k] = k < deg ? (uint32_t)adj[s0 + k] : 0xFFFFFFFFu;
+			for(uint32_t k = 0; k < 8; k++) id[k] = (uint32_t)adj[s0 + (k < deg ? k : 0u)];
+			asm volatile("" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]), "+v"(id[5]), "+v"(id[6]), "+v"(id[7]));
+#pragma unroll
+			for(uint32_t k = 0; k < 8; k++) id[k] = k < deg ? id[k] : 0xFFFFFFFFu;
 #define CRT_CX(p, q) { const uint32_t lo_ = min(id[p], id[q]), hi_ = max(id[p], id[q]); id[p] = lo_; id[q] = hi_; }
 			CRT_CX(0, 1) CRT_CX(2, 3) CRT_CX(4, 5) CRT_CX(6, 7)
 			CRT_CX(0, 2) CRT_CX(1, 3) CRT_CX(4, 6) CRT_CX(5, 7)
@@ -294,42 +300,44 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			CRT_CX(2, 4) CRT_CX(3, 5)
 			CRT_CX(3, 4)
 #undef CRT_CX
+			const uint32_t id0 = id[0];                                      // a valid face: stands in for the unused slots' loads
+			if(fn_lds) {
+				float n[8][3];
 #pragma unroll
-			for(uint32_t k = 0; k < 8; k++) if(k < deg) { ex += fn[3*id[k]]; ey += fn[3*id[k] + 1]; ez += fn[3*id[k] + 2]; }
-		} else if(deg <= 8) {
-			// the LDS-lean layout (no face-normal array: what a context gets when many batches are in flight): the same sorted ids, then the
-			// faces' indices and their nine coordinates are fetched four faces at a time - every load of a group in flight together, two
-			// dependent round trips per group instead of two per face - and the normals recomputed and added in id order
-			uint32_t id[8];
+				for(uint32_t k = 0; k < 8; k++) { const uint32_t f = k < deg ? id[k] : id0; n[k][0] = fn[3*f]; n[k][1] = fn[3*f + 1]; n[k][2] = fn[3*f + 2]; }
 #pragma unroll
-			for(uint32_t k = 0; k < 8; k++) id[k] = k < deg ? (uint32_t)adj[s0 + k] : 0xFFFFFFFFu;
-#define CRT_CX(p, q) { const uint32_t lo_ = min(id[p], id[q]), hi_ = max(id[p], id[q]); id[p] = lo_; id[q] = hi_; }
-			CRT_CX(0, 1) CRT_CX(2, 3) CRT_CX(4, 5) CRT_CX(6, 7)
-			CRT_CX(0, 2) CRT_CX(1, 3) CRT_CX(4, 6) CRT_CX(5, 7)
-			CRT_CX(1, 2) CRT_CX(5, 6) CRT_CX(0, 4) CRT_CX(3, 7)
-			CRT_CX(1, 5) CRT_CX(2, 6)
-			CRT_CX(1, 4) CRT_CX(3, 6)
-			CRT_CX(2, 4) CRT_CX(3, 5)
-			CRT_CX(3, 4)
-#undef CRT_CX
+				for(uint32_t k = 0; k < 8; k++) asm volatile("" : "+v"(n[k][0]), "+v"(n[k][1]), "+v"(n[k][2]));
 #pragma unroll
-			for(uint32_t h = 0; h < 8; h += 4) {
-				if(h >= deg) break;
-				uint32_t fa[4][3];
-				int32_t P[4][9];
+				for(uint32_t k = 0; k < 8; k++) { const bool on = k < deg; ex = on ? ex + n[k][0] : ex; ey = on ? ey + n[k][1] : ey; ez = on ? ez + n[k][2] : ez; }   // (select AFTER the add: x + 0.0f is not x for x = -0.0f)
+			} else {
+				// the LDS-lean layout (no face-normal array: what a context gets when many batches are in flight): the faces' indices and their
+				// nine coordinates are fetched four faces at a time - every load of a group in flight together, two dependent round trips per
+				// group instead of two per face - and the normals recomputed and added in id order
 #pragma unroll
-				for(uint32_t k = 0; k < 4; k++) { fa[k][0] = fa[k][1] = fa[k][2] = 0; if(h + k < deg) face(id[h + k], fa[k][0], fa[k][1], fa[k][2]); }
+				for(uint32_t h = 0; h < 8; h += 4) {
+					if(h >= deg) break;
+					uint32_t fa[4][3];
+					int32_t P[4][9];
 #pragma unroll
-				for(uint32_t k = 0; k < 4; k++) if(h + k < deg) {
+					for(uint32_t k = 0; k < 4; k++) face(h + k < deg ? id[h + k] : id0, fa[k][0], fa[k][1], fa[k][2]);
 #pragma unroll
-					for(uint32_t v = 0; v < 3; v++) { CRT_GLOBAL const int32_t *q = pos + 3*fa[k][v]; P[k][3*v] = q[0]; P[k][3*v + 1] = q[1]; P[k][3*v + 2] = q[2]; }
-				}
+					for(uint32_t k = 0; k < 4; k++) asm volatile("" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]));
 #pragma unroll
-				for(uint32_t k = 0; k < 4; k++) if(h + k < deg) {
-					const float x0 = (float)P[k][0], y0 = (float)P[k][1], z0 = (float)P[k][2];
-					const float ax = (float)P[k][3] - x0, ay = (float)P[k][4] - y0, az = (float)P[k][5] - z0;
-					const float bx = (float)P[k][6] - x0, by = (float)P[k][7] - y0, bz = (float)P[k][8] - z0;
-					ex += ay*bz - az*by; ey += az*bx - ax*bz; ez += ax*by - ay*bx;   // point.h:113-115
+					for(uint32_t k = 0; k < 4; k++) {
+#pragma unroll
+						for(uint32_t v = 0; v < 3; v++) { CRT_GLOBAL const int32_t *q = pos + 3*fa[k][v]; P[k][3*v] = q[0]; P[k][3*v + 1] = q[1]; P[k][3*v + 2] = q[2]; }
+					}
+#pragma unroll
+					for(uint32_t k = 0; k < 4; k++) asm volatile("" : "+v"(P[k][0]), "+v"(P[k][1]), "+v"(P[k][2]), "+v"(P[k][3]), "+v"(P[k][4]), "+v"(P[k][5]), "+v"(P[k][6]), "+v"(P[k][7]), "+v"(P[k][8]));
+#pragma unroll
+					for(uint32_t k = 0; k < 4; k++) {
+						const float x0 = (float)P[k][0], y0 = (float)P[k][1], z0 = (float)P[k][2];
+						const float ax = (float)P[k][3] - x0, ay = (float)P[k][4] - y0, az = (float)P[k][5] - z0;
+						const float bx = (float)P[k][6] - x0, by = (float)P[k][7] - y0, bz = (float)P[k][8] - z0;
+						const bool on = h + k < deg;
+						const float nx = ay*bz - az*by, ny = az*bx - ax*bz, nz = ax*by - ay*bx;   // point.h:113-115
+						ex = on ? ex + nx : ex; ey = on ? ey + ny : ey; ez = on ? ez + nz : ez;
+					}
 				}
 			}
 		} else {
