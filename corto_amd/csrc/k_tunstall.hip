@@ -175,23 +175,39 @@ __device__ __forceinline__ void tun_stream_decode(const TunStream &st, const uin
 	uint64_t base = 0;
 	for(uint32_t tile = 0; tile < csize; tile += 256) {
 		const uint32_t j0 = tile + 4*lane;
+		// the lane's (up to) four codewords as ONE load: an unaligned dword at j0, or - the stream's last, partial group - the stream's last
+		// dword shifted down; then the four lengths and the four offsets, every read unconditional and pinned.  (Written as four
+		// `ok ? src[j0 + k] : 0` the compiler makes four exec-masked byte loads, each with its own wait and a dependent LDS read behind
+		// it: eight serial round trips per 256 codewords - most of this kernel's time on a stream of a few hundred.)
+		const uint32_t r = j0 < csize ? min(csize - j0, 4u) : 0u;            // valid codewords of this lane
+		uint32_t raw;
+		if(csize >= 4) {                                                    // (uniform)
+			uint32_t dw = *(CRT_GLOBAL const uint32_t *)(src + (r == 4u ? j0 : r ? csize - 4u : 0u));
+			asm volatile("" : "+v"(dw));
+			raw = r == 4u ? dw : r ? dw >> (8u*(4u - r)) : 0u;
+		} else {
+			raw = 0;
+			for(uint32_t k = 0; k < r; k++) raw |= (uint32_t)src[j0 + k] << (8u*k);
+		}
 		uint32_t code[4], l[4], sum = 0;
 #pragma unroll
-		for(int k = 0; k < 4; k++) {
-			const bool ok = j0 + k < csize;
-			code[k] = ok ? (uint32_t)src[j0 + k] : 0u;
-			l[k] = ok ? (uint32_t)len8[code[k]] : 0u;
-			sum += l[k];
-		}
+		for(int k = 0; k < 4; k++) code[k] = (raw >> (8*k)) & 255u;          // (0 beyond the stream's end: a valid table index)
+#pragma unroll
+		for(int k = 0; k < 4; k++) l[k] = (uint32_t)len8[code[k]];
+		asm volatile("" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
+#pragma unroll
+		for(int k = 0; k < 4; k++) { l[k] = (uint32_t)k < r ? l[k] : 0u; sum += l[k]; }
 		const uint32_t inc = wave_inclusive_scan_u32(sum);
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 		uint64_t oo = base + inc - sum;
 		const uint64_t o_run = oo;
 		uint32_t wo[4], nb[4];
 #pragma unroll
+		for(int k = 0; k < 4; k++) wo[k] = off16[code[k]];
+		asm volatile("" : "+v"(wo[0]), "+v"(wo[1]), "+v"(wo[2]), "+v"(wo[3]));
+#pragma unroll
 		for(int k = 0; k < 4; k++) {                       // every word whole; the stream's last codeword emits what is left (tunstall.cpp:447-451)
 			uint32_t n_ = l[k];
-			wo[k] = off16[code[k]];
 			if(j0 + k < csize) {
 				if(j0 + k + 1 == csize) n_ = oo < size ? (uint32_t)min((uint64_t)(TUN_TABLE_BYTES - wo[k]), size - oo) : 0u;
 				else if(oo + n_ > size) n_ = oo < size ? (uint32_t)(size - oo) : 0u;
