@@ -75,16 +75,35 @@ __device__ __forceinline__ uint32_t unpack_bits_of(const UnpackJob &J, uint32_t 
 // One pass: a chunk adds up the bits of its own 1 024 logs, finds where its fields start by look-back over the earlier chunks of
 // its bit block (chain_lookback, wait-free: at most a dozen state words for a 4-component attribute of a C4 blob) and extracts - round 1 ran a
 // sums kernel and a device-wide scan in front of this one, two more launches on the attribute chain of every batch.
+// the (up to four) logs at i0 .. of a stream as one load: an unaligned dword, or - the stream's last, partial group - its last dword
+// shifted down (streams shorter than four logs: bytewise).  r = the number of valid ones.
+__device__ __forceinline__ uint32_t unpack_logs4(CRT_GLOBAL const uint8_t *logs, uint32_t count, uint32_t i0, uint32_t &r) {
+	r = i0 < count ? min(count - i0, 4u) : 0u;
+	if(count >= 4) {
+		uint32_t dw = *(CRT_GLOBAL const uint32_t *)(logs + (r == 4u ? i0 : r ? count - 4u : 0u));
+		asm volatile("" : "+v"(dw));
+		return r == 4u ? dw : r ? dw >> (8u*(4u - r)) : 0u;
+	}
+	uint32_t raw = 0;
+	for(uint32_t k = 0; k < r; k++) raw |= (uint32_t)logs[i0 + k] << (8u*k);
+	return raw;
+}
+
 __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_job,
                                                         uint32_t nchunks, uint64_t *state) {
 	const uint32_t c = blockIdx.x;
 	if(c >= nchunks) return;
 	const UnpackJob J = jobs[chunk_job[c]];
 	const uint32_t i0 = (c - J.chunk0)*CHUNK + 4*threadIdx.x;
+	// Every load of a phase is in flight together: a thread's four logs are ONE dword, the bit words of its values are fetched
+	// unconditionally on clamped indices and pinned, the stores follow.  (As `i < count ? logs[i] : 0` and a bit_field() per value the
+	// compiler made a dozen dependent FLAT round trips per thread - generic pointers, every load in its own branch with its own wait.)
+	uint32_t r;
+	const uint32_t raw = unpack_logs4(as_global(J.logs), J.count, i0, r);
 	uint32_t lg[4], s = 0;
 #pragma unroll
 	for(int k = 0; k < 4; k++) {
-		lg[k] = i0 + k < J.count ? (uint32_t)J.logs[i0 + k] : 0u;
+		lg[k] = (uint32_t)k < r ? (raw >> (8*k)) & 255u : 0u;
 		if(lg[k] > 32) lg[k] = 32;
 		s += lg[k]*J.fields;
 	}
@@ -95,10 +114,11 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 	__shared__ uint32_t red[4];
 	auto chunk_bits = [&](uint32_t ci) -> uint64_t {      // the bits of another chunk of this bit block (maybe another component's log stream)
 		const UnpackJob K = jobs[chunk_job[ci]];
-		const uint32_t k0 = (ci - K.chunk0)*CHUNK + 4*threadIdx.x;
+		uint32_t rk;
+		const uint32_t w4 = unpack_logs4(as_global(K.logs), K.count, (ci - K.chunk0)*CHUNK + 4*threadIdx.x, rk);
 		uint32_t t = 0;
 #pragma unroll
-		for(int k = 0; k < 4; k++) if(k0 + k < K.count) t += unpack_bits_of(K, K.logs[k0 + k]);
+		for(int k = 0; k < 4; k++) if((uint32_t)k < rk) t += unpack_bits_of(K, (w4 >> (8*k)) & 255u);
 #pragma unroll
 		for(int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
 		__syncthreads();
@@ -107,32 +127,74 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 		return (uint64_t)red[0] + red[1] + red[2] + red[3];
 	};
 	uint64_t o = chain_lookback(state, c, J.chain_chunk0, total, 0u, &before, chunk_bits) + mine;
-	const uint32_t *__restrict__ words = J.words;
+	CRT_GLOBAL const uint32_t *words = as_global(J.words);
+	const uint32_t nwords = J.nwords, last_word = nwords ? nwords - 1u : 0u;
+	// two words of the bit block at bit offset `at` (clamped: what bit_field() would not read comes back as the last word and is masked)
+	auto window = [&](uint64_t at, uint32_t &hi, uint32_t &lo) {
+		const uint64_t wi = at >> 5;
+		hi = words[wi < nwords ? (uint32_t)wi : last_word];
+		lo = words[wi + 1 < nwords ? (uint32_t)wi + 1u : last_word];
+	};
+	auto field = [&](uint64_t at, uint32_t n, uint32_t hi, uint32_t lo) -> uint32_t {        // = bit_field(words, nwords, at, n)
+		if(n == 0) return 0u;
+		const uint64_t wi = at >> 5;
+		const uint32_t sh = (uint32_t)(at & 31);
+		const uint32_t h = wi < nwords ? hi : 0u, l = (sh + n > 32 && wi + 1 < nwords) ? lo : 0u;
+		return (uint32_t)(((((uint64_t)h << 32) | l) << sh) >> (64 - n));
+	};
+	if(J.mode != 0) {                                  // decodeValues: sign folding (cstream.h:304-316); one field per log
+		uint64_t at[4];
+		uint32_t hi[4], lo[4];
 #pragma unroll
-	for(int k = 0; k < 4; k++) {
-		const uint32_t i = i0 + k;
-		if(i >= J.count) break;
-		const uint32_t d = lg[k];
-		const bool store = i < J.out_limit;
-		if(J.mode == 0) {                              // decodeArray: v = raw - 2^(d-1); d == 0 -> zeros (cstream.h:337-357)
-			int32_t *out = (int32_t *)J.out + (size_t)i*J.stride;
-			const uint32_t half = d ? (uint32_t)((1ull << d) >> 1) : 0u;
-			for(uint32_t f = 0; f < J.fields; f++) {
-				const int32_t v = d ? (int32_t)(bit_field(words, J.nwords, o, d) - half) : 0;
-				o += d;
-				if(store) out[f] = v;
-			}
-		} else {                                       // decodeValues: sign folding (cstream.h:304-316)
+		for(int k = 0; k < 4; k++) { at[k] = o; o += lg[k]; }
+		if(nwords) {
+#pragma unroll
+			for(int k = 0; k < 4; k++) window(at[k], hi[k], lo[k]);
+			asm volatile("" : "+v"(hi[0]), "+v"(lo[0]), "+v"(hi[1]), "+v"(lo[1]), "+v"(hi[2]), "+v"(lo[2]), "+v"(hi[3]), "+v"(lo[3]));
+		} else {
+#pragma unroll
+			for(int k = 0; k < 4; k++) hi[k] = lo[k] = 0;
+		}
+#pragma unroll
+		for(int k = 0; k < 4; k++) {
+			const uint32_t i = i0 + k, d = lg[k];
 			int32_t v = 0;
 			if(d) {
-				v = (int32_t)bit_field(words, J.nwords, o, d);
+				v = (int32_t)field(at[k], d, hi[k], lo[k]);
 				const int32_t mid = (int32_t)(1u << (d - 1));
 				if(v < mid) v = -v - mid;
-				o += d;
 			}
-			if(store) {
-				if(J.out_u8) ((uint8_t *)J.out)[(size_t)i*J.stride + J.comp] = (uint8_t)v;
-				else ((int32_t *)J.out)[(size_t)i*J.stride + J.comp] = v;
+			if((uint32_t)k < r && i < J.out_limit) {
+				if(J.out_u8) as_global((uint8_t *)J.out)[(size_t)i*J.stride + J.comp] = (uint8_t)v;
+				else as_global((int32_t *)J.out)[(size_t)i*J.stride + J.comp] = v;
+			}
+		}
+		return;
+	}
+	// decodeArray: v = raw - 2^(d-1); d == 0 -> zeros (cstream.h:337-357); `fields` values per log, the same width
+#pragma unroll
+	for(int k = 0; k < 4; k++) {
+		const uint32_t i = i0 + k, d = lg[k];
+		if((uint32_t)k >= r) break;
+		const bool store = i < J.out_limit;
+		CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + (size_t)i*J.stride;
+		const uint32_t half = d ? (uint32_t)((1ull << d) >> 1) : 0u;
+		if(J.fields <= 4 && nwords) {                  // (uniform) every field's words in flight together
+			uint32_t hi[4], lo[4];
+#pragma unroll
+			for(uint32_t f = 0; f < 4; f++) window(o + (uint64_t)(f < J.fields ? f : 0u)*d, hi[f], lo[f]);
+			asm volatile("" : "+v"(hi[0]), "+v"(lo[0]), "+v"(hi[1]), "+v"(lo[1]), "+v"(hi[2]), "+v"(lo[2]), "+v"(hi[3]), "+v"(lo[3]));
+#pragma unroll
+			for(uint32_t f = 0; f < 4; f++) if(f < J.fields) {
+				const int32_t v = d ? (int32_t)(field(o + (uint64_t)f*d, d, hi[f], lo[f]) - half) : 0;
+				if(store) out[f] = v;
+			}
+			o += (uint64_t)d*J.fields;
+		} else {
+			for(uint32_t f = 0; f < J.fields; f++) {
+				const int32_t v = d ? (int32_t)(bit_field(words, nwords, o, d) - half) : 0;
+				o += d;
+				if(store) out[f] = v;
 			}
 		}
 	}
