@@ -1516,11 +1516,12 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 		for(uint32_t base = 0; base < nvert; base += 256) {
 			uint32_t ta[4], tb[4], tc[4];
 #pragma unroll
-			for(uint32_t u = 0; u < 4; u++) {
-				const uint32_t i = base + u*64 + lane;
-				ta[u] = tb[u] = tc[u] = 0;
-				if(i < nvert) { ta[u] = pred[(size_t)i*3]; tb[u] = pred[(size_t)i*3 + 1]; tc[u] = pred[(size_t)i*3 + 2]; }
+			for(uint32_t u = 0; u < 4; u++) {                                   // (unconditional on a clamped index and pinned: as `if(i < nvert) load` the four
+				const uint32_t i = base + u*64 + lane, ic = i < nvert ? i : nvert - 1u;   //  rounds were four dependent round trips, 36 for a C4 blob)
+				ta[u] = pred[(size_t)ic*3]; tb[u] = pred[(size_t)ic*3 + 1]; tc[u] = pred[(size_t)ic*3 + 2];
 			}
+#pragma unroll
+			for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(ta[u]), "+v"(tb[u]), "+v"(tc[u]));
 #pragma unroll
 			for(uint32_t u = 0; u < 4; u++) {
 				const uint32_t i = base + u*64 + lane;
