@@ -913,7 +913,14 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	// (two words behind the window: "window exhausted" nibbles - a chain that outruns the window ends in the HBM redo, so that the
 	// loop never loads symbols from HBM itself: a load's s_waitcnt would also wait for every face / prediction store in flight)
 	TOPO_FILL_WINDOW(0u);
-	for(uint32_t w = threadIdx.x; w < nspl; w += 64) spl[w] = split[w];
+	if(nspl) {                                                            // (<= 256 words: four loads per lane, in flight together)
+		uint32_t sw4[4];
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) { const uint32_t w = threadIdx.x + 64*u; sw4[u] = split[w < nspl ? w : nspl - 1u]; }
+		asm volatile("" : "+v"(sw4[0]), "+v"(sw4[1]), "+v"(sw4[2]), "+v"(sw4[3]));
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) { const uint32_t w = threadIdx.x + 64*u; if(w < nspl) spl[w] = sw4[u]; }
+	}
 	__syncthreads();
 	if(threadIdx.x != 0) return true;
 	cold[K_BIT_LO] = 0; cold[K_BIT_HI] = 0; cold[K_SPLITBITS] = splitbits;
