@@ -255,13 +255,17 @@ __global__ __launch_bounds__(64) void k_tun_stream_shared(const TunStream *__res
 	__shared__ __attribute__((aligned(16))) uint8_t words[TUN_TABLE_BYTES];
 	const TunTable &T = tables[st.dict];
 	const uint32_t lane = threadIdx.x;
-	{
-		CRT_GLOBAL const u32x4_t *o4 = (CRT_GLOBAL const u32x4_t *)as_global(T.off);       // 512 + 256 bytes: 48 16-byte vectors
-		if(lane < 32) ((CRT_LDS u32x4_t *)as_lds(loff))[lane] = o4[lane];
-		else if(lane < 48) ((CRT_LDS u32x4_t *)as_lds(llen))[lane - 32] = ((CRT_GLOBAL const u32x4_t *)as_global(T.len))[lane - 32];
-		const uint32_t nv = (min(T.used, TUN_TABLE_BYTES) + 15u) >> 4;
+	{	// offsets | lengths (48 16-byte vectors, contiguous in the TunTable) and the first KiB of words: both loads issued before the first
+		// wait, the table's `used` read beside them; longer dictionaries loop on
+		CRT_GLOBAL const u32x4_t *o4 = (CRT_GLOBAL const u32x4_t *)as_global(T.off);
 		CRT_GLOBAL const u32x4_t *w4 = (CRT_GLOBAL const u32x4_t *)as_global(T.bytes);
-		for(uint32_t i = lane; i < nv; i += 64) ((CRT_LDS u32x4_t *)as_lds(words))[i] = w4[i];
+		u32x4_t hv = o4[lane < 48 ? lane : 47u], wv = w4[lane];
+		asm volatile("" : "+v"(hv), "+v"(wv));
+		if(lane < 32) ((CRT_LDS u32x4_t *)as_lds(loff))[lane] = hv;
+		else if(lane < 48) ((CRT_LDS u32x4_t *)as_lds(llen))[lane - 32] = hv;
+		((CRT_LDS u32x4_t *)as_lds(words))[lane] = wv;
+		const uint32_t nv = (min(T.used, TUN_TABLE_BYTES) + 15u) >> 4;
+		for(uint32_t i = lane + 64; i < nv; i += 64) ((CRT_LDS u32x4_t *)as_lds(words))[i] = w4[i];
 	}
 	__syncthreads();
 	tun_stream_decode(st, loff, llen, words);
