@@ -255,11 +255,27 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	const uint32_t per = (nv + 255)/256;
 	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint16_t *out, bool flags) {
 		const uint32_t i0 = tid*per;
-		uint32_t s = 0;
-		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; }
-		uint32_t total;
-		uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
-		for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { const uint32_t x = flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; out[i] = (uint16_t)(flags ? o | x << 15 : o); o += x; } }
+		uint32_t s = 0, total;
+		if(per <= 16) {                                                    // (uniform) the thread's elements read once, all reads in flight, kept in registers
+			uint32_t x[16];
+#pragma unroll
+			for(uint32_t k = 0; k < 16; k++) x[k] = in[i0 + k < nv ? i0 + k : 0u];
+			asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+			asm volatile("" : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+#pragma unroll
+			for(uint32_t k = 0; k < 16; k++) {
+				const bool on = k < per && i0 + k < nv;
+				x[k] = on ? (flags ? (uint32_t)(J.prediction == 1 || x[k] != 0) : x[k]) : 0u;
+				s += x[k];
+			}
+			uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
+#pragma unroll
+			for(uint32_t k = 0; k < 16; k++) if(k < per && i0 + k < nv) { out[i0 + k] = (uint16_t)(flags ? o | x[k] << 15 : o); o += x[k]; }
+		} else {
+			for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; }
+			uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
+			for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { const uint32_t x = flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; out[i] = (uint16_t)(flags ? o | x << 15 : o); o += x; } }
+		}
 		if(tid == 0) out[nv] = (uint16_t)total;
 	};
 	block_scan(cnt, start, false);
