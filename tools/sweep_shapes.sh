@@ -1,4 +1,4 @@
-SHAPES=("4 2" "4 3" "6 2" "6 3" "4 4" "5 3" "8 2")
+SHAPES=("4 4" "6 3" "8 2" "5 3" "6 2" "5 4")
 # usage: bash tools/sweep_shapes.sh   (threads x depth shapes of the decode pool, one pipelined bench line each)
 for shape in "${SHAPES[@]:-4 2}"; do set -- $shape
 python bench.py --no-tunstall-scaled --no-cpu --no-other-configs --host-threads $1 --depth $2 2>/dev/null | tail -1 | python -c "
