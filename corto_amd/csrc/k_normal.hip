@@ -241,13 +241,43 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	__syncthreads();
 	// the integer positions have been read for the last time when the face normals sit in LDS: they become floats now (in place, or
 	// into an interleaved vertex buffer), while the rest of the kernel works from LDS; otherwise at the very end (below)
-	auto positions_out = [&]() {
+	auto positions_out = [&]() {                                           // (loads in groups, every one of a group in flight: one at a time this loop was a third of the kernel)
 		if(!J.pos_out) return;
 		CRT_GLOBAL uint8_t *po = as_global((uint8_t *)J.pos_out);
-		for(uint32_t e = tid; e < 3*nv; e += 256) {
-			const uint32_t i = e/3, c = e - 3*i;
-			const float f = (float)pos[e];
-			*(CRT_GLOBAL float *)(po + (size_t)i*J.pos_stride + 4u*c) = f*J.pos_q;
+		const uint32_t n3 = 3*nv;
+		if(n3 == 0) return;
+		typedef uint32_t nu4 __attribute__((ext_vector_type(4)));
+		typedef float nf4 __attribute__((ext_vector_type(4)));
+		uint32_t done = 0;
+		if(J.pos_stride == 12 && ((((uintptr_t)po) | ((uintptr_t)pos)) & 15) == 0 && n3 >= 4) {   // packed: 16-byte vectors, four per thread and pass
+			const uint32_t nvec = n3 >> 2;
+			CRT_GLOBAL const nu4 *src4 = (CRT_GLOBAL const nu4 *)pos;
+			CRT_GLOBAL nf4 *dst4 = (CRT_GLOBAL nf4 *)po;
+			for(uint32_t i = tid; i < nvec; i += 1024) {
+				nu4 t[4];
+#pragma unroll
+				for(uint32_t u = 0; u < 4; u++) t[u] = src4[i + 256*u < nvec ? i + 256*u : nvec - 1u];
+#pragma unroll
+				for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(t[u]));
+#pragma unroll
+				for(uint32_t u = 0; u < 4; u++) if(i + 256*u < nvec) {
+					nf4 f;
+					f.x = (float)(int32_t)t[u].x*J.pos_q; f.y = (float)(int32_t)t[u].y*J.pos_q; f.z = (float)(int32_t)t[u].z*J.pos_q; f.w = (float)(int32_t)t[u].w*J.pos_q;
+					dst4[i + 256*u] = f;
+				}
+			}
+			done = nvec << 2;
+		}
+		for(uint32_t e0 = done + tid; e0 < n3; e0 += 2048) {                // interleaved vertex buffers, tails: eight scalars per thread and pass
+			int32_t t[8];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) t[u] = pos[e0 + 256*u < n3 ? e0 + 256*u : n3 - 1u];
+			asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) {
+				const uint32_t e = e0 + 256*u;
+				if(e < n3) { const uint32_t i = e/3, c = e - 3*i; const float f = (float)t[u]; *(CRT_GLOBAL float *)(po + (size_t)i*J.pos_stride + 4u*c) = f*J.pos_q; }
+			}
 		}
 	};
 	if(fn_lds) positions_out();
