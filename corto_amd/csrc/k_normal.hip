@@ -224,18 +224,41 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	__syncthreads();
 	// incidence counts + boundary XOR (markBoundary, normal_attribute.cpp:24-37)
 	bool bad = false;
-	for(uint32_t f = tid; f < nf; f += 256) {
-		uint32_t a, b, c; face(f, a, b, c);
-		if(a >= nv || b >= nv || c >= nv) { bad = true; continue; }
-		atomicAdd((uint32_t *)&cnt[a], 1u); atomicAdd((uint32_t *)&cnt[b], 1u); atomicAdd((uint32_t *)&cnt[c], 1u);
-		if(fn_lds) {
-			CRT_GLOBAL const int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
-			const float x0 = (float)p0[0], y0 = (float)p0[1], z0 = (float)p0[2];
-			const float ax = (float)p1[0] - x0, ay = (float)p1[1] - y0, az = (float)p1[2] - z0;
-			const float bx = (float)p2[0] - x0, by = (float)p2[1] - y0, bz = (float)p2[2] - z0;
-			fn[3*f] = ay*bz - az*by; fn[3*f + 1] = az*bx - ax*bz; fn[3*f + 2] = ax*by - ay*bx;   // point.h:113-115
+	for(uint32_t f0 = tid; f0 < nf; f0 += 1024) {                           // four faces per thread and pass: their indices in flight together, then their
+		uint32_t A[4], B[4], C[4];                                           // 36 coordinates (one face at a time every pass was two dependent round trips)
+		bool ok[4];
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) face(f0 + 256*u < nf ? f0 + 256*u : nf - 1u, A[u], B[u], C[u]);
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(A[u]), "+v"(B[u]), "+v"(C[u]));
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) {
+			const bool in = f0 + 256*u < nf;
+			ok[u] = in && A[u] < nv && B[u] < nv && C[u] < nv;
+			bad |= in && !ok[u];
 		}
-		if(J.prediction == 2) { atomicXor((uint32_t *)&bnd[a], b ^ c); atomicXor((uint32_t *)&bnd[b], c ^ a); atomicXor((uint32_t *)&bnd[c], a ^ b); }
+		int32_t P[4][9];
+		if(fn_lds) {
+#pragma unroll
+			for(uint32_t u = 0; u < 4; u++) {
+				CRT_GLOBAL const int32_t *p0 = pos + 3*(ok[u] ? A[u] : 0u), *p1 = pos + 3*(ok[u] ? B[u] : 0u), *p2 = pos + 3*(ok[u] ? C[u] : 0u);
+				P[u][0] = p0[0]; P[u][1] = p0[1]; P[u][2] = p0[2]; P[u][3] = p1[0]; P[u][4] = p1[1]; P[u][5] = p1[2]; P[u][6] = p2[0]; P[u][7] = p2[1]; P[u][8] = p2[2];
+			}
+#pragma unroll
+			for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(P[u][0]), "+v"(P[u][1]), "+v"(P[u][2]), "+v"(P[u][3]), "+v"(P[u][4]), "+v"(P[u][5]), "+v"(P[u][6]), "+v"(P[u][7]), "+v"(P[u][8]));
+		}
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) if(ok[u]) {
+			const uint32_t f = f0 + 256*u, a = A[u], b = B[u], c = C[u];
+			atomicAdd((uint32_t *)&cnt[a], 1u); atomicAdd((uint32_t *)&cnt[b], 1u); atomicAdd((uint32_t *)&cnt[c], 1u);
+			if(fn_lds) {
+				const float x0 = (float)P[u][0], y0 = (float)P[u][1], z0 = (float)P[u][2];
+				const float ax = (float)P[u][3] - x0, ay = (float)P[u][4] - y0, az = (float)P[u][5] - z0;
+				const float bx = (float)P[u][6] - x0, by = (float)P[u][7] - y0, bz = (float)P[u][8] - z0;
+				fn[3*f] = ay*bz - az*by; fn[3*f + 1] = az*bx - ax*bz; fn[3*f + 2] = ax*by - ay*bx;   // point.h:113-115
+			}
+			if(J.prediction == 2) { atomicXor((uint32_t *)&bnd[a], b ^ c); atomicXor((uint32_t *)&bnd[b], c ^ a); atomicXor((uint32_t *)&bnd[c], a ^ b); }
+		}
 	}
 	if(bad) *as_global(J.status) = -5;
 	__syncthreads();
@@ -313,11 +336,26 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	__syncthreads();
 	for(uint32_t i = tid; i < nv; i += 256) cnt[i] = start[i];           // cnt becomes the fill cursor
 	__syncthreads();
-	for(uint32_t f = tid; f < nf; f += 256) {
-		uint32_t v[3]; face(f, v[0], v[1], v[2]);
-		if(v[0] >= nv || v[1] >= nv || v[2] >= nv) continue;
+	for(uint32_t f0 = tid; f0 < nf; f0 += 1024) {                           // four faces per thread and pass, as above; the twelve cursor bumps in flight together
+		uint32_t V[4][3], at[4][3];                                          // (a face that is out or malformed bumps the spare counter cnt[nv] and stores nothing)
 #pragma unroll
-		for(int k = 0; k < 3; k++) adj[atomicAdd((uint32_t *)&cnt[v[k]], 1u)] = (uint16_t)f;
+		for(uint32_t u = 0; u < 4; u++) face(f0 + 256*u < nf ? f0 + 256*u : nf - 1u, V[u][0], V[u][1], V[u][2]);
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(V[u][0]), "+v"(V[u][1]), "+v"(V[u][2]));
+		bool ok[4];
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) {
+			ok[u] = f0 + 256*u < nf && V[u][0] < nv && V[u][1] < nv && V[u][2] < nv;
+#pragma unroll
+			for(int k = 0; k < 3; k++) at[u][k] = atomicAdd((uint32_t *)&cnt[ok[u] ? V[u][k] : nv], 1u);
+		}
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(at[u][0]), "+v"(at[u][1]), "+v"(at[u][2]));
+#pragma unroll
+		for(uint32_t u = 0; u < 4; u++) if(ok[u]) {
+#pragma unroll
+			for(int k = 0; k < 3; k++) adj[at[u][k]] = (uint16_t)(f0 + 256*u);
+		}
 	}
 	__syncthreads();
 	// per vertex: ordered accumulation (estimateNormals :40-59) + computeNormals (:281-325)
