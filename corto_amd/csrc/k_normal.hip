@@ -361,6 +361,11 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	// per vertex: ordered accumulation (estimateNormals :40-59) + computeNormals (:281-325)
 	for(uint32_t i = tid; i < nv; i += 256) {
 		const uint32_t s0 = start[i], deg = (uint32_t)start[i + 1] - s0;
+		// the vertex' correction is fetched NOW (its slot is known), so that the load is back by the time the sum of face normals is
+		const uint32_t slw = slot[i];
+		const bool has_diff = (slw & 0x8000u) && (slw & 0x7FFFu) < J.ndiffs;
+		int32_t pdx = 0, pdy = 0;
+		if(J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)(has_diff ? slw & 0x7FFFu : 0u); pdx = dp[0]; pdy = dp[1]; }
 		float ex = 0.f, ey = 0.f, ez = 0.f;
 		if(deg <= 8 && deg > 0) {
 			// the usual vertex: its (at most eight) incident faces sorted by id with a branch-free network and their normals added in that
@@ -446,12 +451,11 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			last = (int32_t)best; done += mult;
 		}
 		}
-		if(slot[i] & 0x8000u) {                                          // ESTIMATED: every vertex; BORDER: boundary vertices
-			const uint32_t sl = slot[i] & 0x7FFFu;
+		if(slw & 0x8000u) {                                              // ESTIMATED: every vertex; BORDER: boundary vertices
 			int32_t qx, qy;
 			to_octa(ex, ey, ez, J.unit, qx, qy);
-			int32_t dx = 0, dy = 0;
-			if(sl < J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)sl; dx = dp[0]; dy = dp[1]; }
+			asm volatile("" : "+v"(pdx), "+v"(pdy));
+			const int32_t dx = has_diff ? pdx : 0, dy = has_diff ? pdy : 0;
 			int32_t x = (int32_t)((uint32_t)qx + (uint32_t)dx), y = (int32_t)((uint32_t)qy + (uint32_t)dy);
 			if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }
 			float nx, ny, nz;
