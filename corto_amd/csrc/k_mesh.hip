@@ -1190,12 +1190,22 @@ __device__ void delta_stretch_global(CRT_GLOBAL T *v, CRT_GLOBAL uint8_t *fired,
 		if(ready) {
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			if(NC) {
+				// every value of the step in flight together, then the sums, then the stores (component by component the store of one
+				// fenced in the loads of the next - v may alias itself - and a step was five L2 round trips instead of two)
+				uint32_t g[NC ? NC : 1][4];
 #pragma unroll
 				for(uint32_t q = 0; q < (uint32_t)NC; q++) {
-					T x = v[(size_t)i*n + q];
+					g[q][0] = (uint32_t)v[(size_t)i*n + q]; g[q][1] = (uint32_t)v[(size_t)(inv || !at_start ? 0u : a)*n + q];
+					g[q][2] = (uint32_t)v[(size_t)(inv || !para ? 0u : b)*n + q]; g[q][3] = (uint32_t)v[(size_t)(inv || !para ? 0u : c)*n + q];
+				}
+#pragma unroll
+				for(uint32_t q = 0; q < (uint32_t)NC; q++) asm volatile("" : "+v"(g[q][0]), "+v"(g[q][1]), "+v"(g[q][2]), "+v"(g[q][3]));
+#pragma unroll
+				for(uint32_t q = 0; q < (uint32_t)NC; q++) {
+					T x = (T)g[q][0];
 					if(!inv) {
-						const T pa = at_start ? v[(size_t)a*n + q] : prev[q];
-						x = (T)(x + pa + (para ? (T)(v[(size_t)b*n + q] - v[(size_t)c*n + q]) : (T)0));
+						const T pa = at_start ? (T)g[q][1] : prev[q];
+						x = (T)(x + pa + (para ? (T)((T)g[q][2] - (T)g[q][3]) : (T)0));
 						v[(size_t)i*n + q] = x;
 					}
 					prev[q] = x;
