@@ -1174,14 +1174,20 @@ __device__ void delta_stretch_global(CRT_GLOBAL T *v, CRT_GLOBAL uint8_t *fired,
 	uint32_t i = 0, end = 0;
 	if(active) { i = starts[k]; end = k + 1 < ns ? starts[k + 1] : nvert; }
 	uint32_t a = 0, b = 0, c = 0, na = 0, nb = 0, nc = 0;
-	auto fetch = [&](uint32_t j, uint32_t &x, uint32_t &y, uint32_t &z) {
-		x = y = z = 0;
-		if(j < nvert) { x = pred[(size_t)j*3]; y = x; z = x; if(para) { y = pred[(size_t)j*3 + 1]; z = pred[(size_t)j*3 + 2]; } }
+	typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+	auto issue = [&](uint32_t j) -> u32x3_t {                              // the triple of vertex j as one 12-byte load (clamped: unconditional)
+		return *(CRT_GLOBAL const u32x3_t *)(pred + (size_t)(j < nvert ? j : nvert - 1u)*3);
 	};
-	if(active) { fetch(i, a, b, c); fetch(i + 1, na, nb, nc); }             // the next triple is always one vertex ahead of its use
+	auto take = [&](uint32_t j, u32x3_t t, uint32_t &x, uint32_t &y, uint32_t &z) {
+		asm volatile("" : "+v"(t));
+		x = j < nvert ? t.x : 0u; y = j < nvert ? (para ? t.y : t.x) : 0u; z = j < nvert ? (para ? t.z : t.x) : 0u;
+	};
+	if(active) { const u32x3_t t0 = issue(i), t1 = issue(i + 1); take(i, t0, a, b, c); take(i + 1, t1, na, nb, nc); }   // the next triple is always one vertex ahead of its use
 	T prev[NC ? NC : 1];
-	bool at_start = true;
+	bool at_start = true, have2 = false;
+	u32x3_t t2 = {0, 0, 0};                                                // ... and the one behind it is in flight while this vertex waits for its parents and fires
 	while(active) {
+		if(!have2) { t2 = issue(i + 2); have2 = true; }
 		const bool inv = !(a < i && b < i && c < i);                        // malformed triple (and vertex 0): the value stays
 		const uint32_t da = inv || !at_start ? 0u : a, db = inv ? 0u : b, dc = inv ? 0u : c;
 		const uint32_t ready = __hip_atomic_load(&fired[da], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &
@@ -1218,11 +1224,15 @@ __device__ void delta_stretch_global(CRT_GLOBAL T *v, CRT_GLOBAL uint8_t *fired,
 			__hip_atomic_store(&fired[i], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			i++; at_start = false;
 			a = na; b = nb; c = nc;
+			take(i + 1, t2, na, nb, nc); have2 = false;                        // (issued at the top of this or an earlier pass: back by now)
 			if(i == end) {
 				k += THREADS; active = k < ns;
-				if(active) { i = starts[k]; end = k + 1 < ns ? starts[k + 1] : nvert; fetch(i, a, b, c); at_start = true; }
+				if(active) {
+					i = starts[k]; end = k + 1 < ns ? starts[k + 1] : nvert;
+					const u32x3_t t0 = issue(i), t1 = issue(i + 1);
+					take(i, t0, a, b, c); take(i + 1, t1, na, nb, nc); at_start = true;
+				}
 			}
-			if(active) fetch(i + 1, na, nb, nc);
 		}
 		if(!__any(ready)) __builtin_amdgcn_s_sleep(2);                      // nothing to do in this wave: leave the issue slots to the waves that fire
 	}
