@@ -544,6 +544,27 @@ def main():
     tris_ns = shard.sum_over_ranks(float(rep_ns.triangles), dist, red_dev)
     pool_ns.close()
 
+    # beside `value` too: the same batch shape with IRREGULAR connectivity (every grid quad's diagonal flipped per seed: valences 4-8, no two
+    # blobs share a CLERS stream; shorter (VERTEX LEFT) runs, shorter scan blocks) - what the pipeline does when meshes are not lat-long grids
+    irregular = None
+    if rank == 0 and not args.no_other_configs:
+        from corto_amd import synth
+        iblobs = [ca.encode(synth.bumpy_sphere_flipped(64, 32, seed=i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(NBLOBS)]
+        iarena = [[ca.upload_arena(iblobs, devices[0])]]
+        pool_i = ca.Pool(devices[:1], threads=nthreads, depth=depth)
+        pool_i.run([iblobs], steps=4 * pool_i.lanes, warmup=0, arenas=iarena)
+        rep_i, st_i = pool_i.run([iblobs], steps=fh_steps // nloc, warmup=2 * pool_i.lanes, arenas=iarena)
+        for lane in range(0, pool_i.lanes, 5):                                  # bit-exact spot check against the oracle
+            i = 7 * lane + 3
+            ref = oc.decode(iblobs[i])
+            for k, (dt, w) in dts.items():
+                got = pool_i.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
+                assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (irregular)", lane, i, k)
+        irregular = {"mtri_per_s": round(rep_i.triangles / rep_i.elapsed_s / 1e6, 2), "ms_per_step": round(rep_i.elapsed_s / (fh_steps // nloc) * 1e3, 4),
+                     "steps": fh_steps // nloc, "topology_fallbacks": int(rep_i.topology_fallbacks), "failed_blobs": int(rep_i.failed_blobs),
+                     "note": "one GPU; 256 x bumpy_sphere_flipped(64, 32, seed): 2112 verts / 4096 tris each, every quad's diagonal flipped with probability 1/2"}
+        pool_i.close()
+
     tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev) / R     # (per K-step region)
     verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev) / R
     tris_h = shard.sum_over_ranks(float(rep_h.triangles), dist, red_dev)
@@ -589,6 +610,7 @@ def main():
                                               "one generator with 256 seeds repeats tables more than unrelated meshes would - see without_dictionary_sharing"},
             "without_dictionary_sharing": {"mtri_per_s": round(tris_ns / elapsed_ns / 1e6, 2), "ms_per_step": round(elapsed_ns / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
                                            "note": "same pipelined steps with $CORTO_TUN_SHARE=0: every stream builds its own dictionary (round 2's earlier figure)"},
+            "irregular_connectivity": irregular,
             "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
                                     **window_stats(stamps_h, pool.lanes),
                                     "note": "same pipelined steps, but every step uploads its %.1f MB of compressed blobs from host memory (PCIe H2D inside the step); "

@@ -107,6 +107,23 @@ def bumpy_sphere(nu=64, nv=32, seed=0, color_components=4, noise=0.01):
     return Mesh(pos, tris, nrm, col, uv)
 
 
+def bumpy_sphere_flipped(nu=64, nv=32, seed=0, color_components=4, flip=0.5):
+    """bumpy_sphere with the diagonal of every grid quad flipped with probability `flip` (per-seed): the same vertex and triangle counts,
+    but vertex valences from 4 to 8 instead of 6 everywhere, so that no two seeds share a CLERS stream and the (VERTEX LEFT) runs, the
+    delta scans' blocks and the incident-face lists are those of an irregular mesh."""
+    m = bumpy_sphere(nu, nv, seed, color_components)
+    jj, ii = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = jj * nu + ii
+    b = jj * nu + (ii + 1) % nu
+    c = (jj + 1) * nu + (ii + 1) % nu
+    d = (jj + 1) * nu + ii
+    f = (_lcg_fast(seed * 7919 + 13, nv * nu).reshape(nv, nu) < flip)[..., None]
+    t0 = np.where(f, np.stack([a, b, d], -1), np.stack([a, b, c], -1))
+    t1 = np.where(f, np.stack([b, c, d], -1), np.stack([a, c, d], -1))
+    m.index = np.stack([t0, t1], axis=2).reshape(-1, 3).astype(m.index.dtype)
+    return m
+
+
 def closed_sphere(nu=24, nv=12, seed=0, color_components=4):
     """Closed genus-0 UV sphere with two pole vertices (triangle fans): 2 + nu*(nv-1) verts, 2*nu*(nv-1) tris.
     Closed surfaces end with END symbols and have no boundary."""

@@ -135,6 +135,23 @@ def test_vertex_counts_around_the_bitmap_words(monkeypatch):
         b.close(); c.close()
 
 
+def test_irregular_connectivity_batch(ctx):
+    """48 lat-long grids with every quad's diagonal flipped at random (valences 4-8, no two CLERS streams alike): short (VERTEX LEFT) runs,
+    short scan blocks, the walk taking over for some; on a two-stream and on a single-stream (LDS-lean) context"""
+    from corto_amd import synth
+    meshes = [synth.bumpy_sphere_flipped(64, 32, seed=s) for s in range(40)] + [synth.bumpy_sphere_flipped(24, 12, seed=100 + s, flip=0.3 + 0.1 * s) for s in range(8)]
+    blobs = [ca.encode(m, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER if k % 2 else ca.ESTIMATED) for k, m in enumerate(meshes)]
+    refs = [oc.decode(b) for b in blobs]
+    for single in (False, True):
+        c = ca.Context(0)
+        if single:
+            c.set_single_stream(True)
+        b = run_batch(c, blobs)
+        for i, r in enumerate(refs):
+            assert_same(b.host_outputs(i), r, KEYS, "flipped %d single=%s" % (i, single))
+        b.close(); c.close()
+
+
 def test_single_stream_context_decodes_the_same(ctx):
     """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
     the hardware queues) - same bytes as the two-stream schedule"""
