@@ -314,6 +314,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_and_b32 %[t0], %[sw], 0xffff\n"   /* VERTEX LEFT VERTEX LEFT ahead: leave for the run step (TOPO_RUN_STEP) */ \
 							"  s_cmp_eq_u32 %[t0], 0x1010\n" \
 							"  s_cbranch_scc1 Lrun_%=\n" \
+							"  s_and_b32 %[t1], %[t0], 0xeeee\n"   /* four symbols of VERTEX / LEFT ahead: maybe the mix step (checked out of line) */ \
+							"  s_cbranch_scc0 Lvmix_%=\n" \
+							"Lvgo_%=:\n" \
 							"  s_sub_u32 %[budget], %[budget], 1\n"   /* vertex ids and ring slots left (SCC = borrow: none) */ \
 							"  s_cbranch_scc1 Lexit_%=\n" \
 							"  s_and_b32 %[t1], %[nq], %[mask]\n"   /* s: slot of the second new edge */ \
@@ -351,6 +354,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lleft_%=:\n" \
 							"  s_cmp_gt_u32 %[ep], %[mask]\n" \
 							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_and_b32 %[t0], %[sw], 0xeeee\n" \
+							"  s_cbranch_scc0 Llmix_%=\n" \
+							"Llgo_%=:\n" \
 							"  s_lshl_b32 %[t0], %[ep], 4\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
 							"  ds_read_b128 v[56:59], v52\n" \
@@ -627,6 +633,25 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lended_%=:\n" \
 							"  s_mov_b32 %[c], 0x200\n"             /* nothing is current: the C++ fetches the next gate (slide, DELAY stack, seed face) */ \
 							"  s_branch Lexit_%=\n" \
+							   /* ---------------- four symbols of VERTEX / LEFT ahead: the mix step (TOPO_MIX_STEP) takes them, unless they are the head of a regular \
+							      run one symbol on (V VLV.., L VLV..: that symbol here, then the run step) or the window register holds fewer than four */ \
+							"Lvmix_%=:\n" \
+							"  s_cmp_eq_u32 %[t0], 0x0100\n" \
+							"  s_cbranch_scc1 Lvgo_%=\n" \
+							"  s_and_b32 %[t1], %[cler], 7\n" \
+							"  s_cmp_gt_u32 %[t1], 4\n" \
+							"  s_cbranch_scc1 Lvgo_%=\n" \
+							"  s_branch Lmix_%=\n" \
+							"Llmix_%=:\n" \
+							"  s_and_b32 %[t0], %[sw], 0xffff\n" \
+							"  s_cmp_eq_u32 %[t0], 0x0101\n" \
+							"  s_cbranch_scc1 Llgo_%=\n" \
+							"  s_and_b32 %[t1], %[cler], 7\n" \
+							"  s_cmp_gt_u32 %[t1], 4\n" \
+							"  s_cbranch_scc1 Llgo_%=\n" \
+							"Lmix_%=:\n" \
+							"  s_mov_b32 %[c], 0x300\n" \
+							"  s_branch Lexit_%=\n" \
 							"Lrun_%=:\n" \
 							"  s_mov_b32 %[c], 0x100\n" \
 							"Lexit_%=:\n" \
@@ -878,6 +903,201 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 		: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
 		  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 
+// The mix step.  Meshes whose quads are not split the same way everywhere (anything that is not a regular grid) do not give (VERTEX LEFT)
+// runs: their streams are still nine parts in ten VERTEX and LEFT, but in any order (VVLL, VLLV ...: two thirds of the symbols of a
+// 4K-triangle blob with random diagonals sat in the one-symbol-at-a-time path above, 0.65 ms where the regular blob takes 0.20).  Any
+// sequence over those two symbols is as regular as the pairs are, seen the right way: VERTEX changes v1 (to the new vertex) and e.next (to
+// the edge it queues) and nothing else, LEFT changes v0 (to the next vertex of the chain of ring slots behind e.prev) and e.prev and
+// nothing else.  So with nV_j / nL_j = the VERTEXes / LEFTs in front of symbol j (two ballots, two v_mbcnt) and x[i] = the v0 of ring
+// slot ep+i, the edge before symbol j is
+//   a_j (v0) = nL_j ? x[nL_j - 1] : v0      b_j (v1) = nV_j ? vc + nV_j - 1 : v1
+//   c_j (v2) = j == 0 ? v2 : symbol j-1 was a VERTEX ? (nV_j >= 2 ? vc + nV_j - 2 : v1) : (nL_j >= 2 ? x[nL_j - 2] : v0)
+// and lane j - ONE symbol a lane, up to 63 a pass - writes the face (b_j, a_j, opp_j), opp_j = vc + nV_j (VERTEX) or x[nL_j] (LEFT); a
+// VERTEX lane also its prediction triple (b_j, a_j, c_j) and the record of the edge it queues (slot nq + nV_j: prev = the next VERTEX's
+// slot, lazy for the last; next = the previous VERTEX's slot, e.next for the first), a LEFT lane the deleted flag of slot ep + nL_j.
+// The step ends at the first lane whose symbol is something else, whose LEFT would need a chain slot behind a broken link (slot ep+i is
+// usable while link(ep+i-1).prev == ep+i and ep+i != e.next, as in the run step), whose VERTEX has no vertex id or ring slot left, or
+// from which on a regular run lies ahead (VLVLVLVL: the run step does two symbols a lane).  The state after it is lane k's (a, b, c).
+// Two LDS round trips (symbols and links; then a lane's three x, whose addresses depend on nL_j).  Checked against the oracle on the
+// host model (tools/topo_run_model.py) before it was written here.
+#define TOPO_MIX_FACE32 \
+	"  v_mad_u32_u24 v59, v60, 12, %[fbyte]\n" \
+	"  global_store_dwordx3 v59, v[32:34], %[faceb]\n"
+#define TOPO_MIX_FACE16 \
+	"  v_and_b32 v36, 0xffff, v32\n" \
+	"  v_lshl_or_b32 v36, v33, 16, v36\n" \
+	"  v_mad_u32_u24 v59, v60, 6, %[fbyte]\n" \
+	"  global_store_dword v59, v36, %[faceb]\n" \
+	"  global_store_short v59, v34, %[faceb] offset:4\n"
+#define TOPO_MIX_STEP(FACE) \
+	asm volatile( \
+		"  s_mov_b64 %[sv], exec\n" \
+		"  s_mov_b64 exec, -1\n" \
+		"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+		"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
+		"  v_add_u32 v40, %[cler], v60\n"                /* p = cler + j: the lane's symbol */ \
+		"  v_lshrrev_b32 v41, 3, v40\n" \
+		"  v_add_u32 v41, %[wb], v41\n" \
+		"  v_lshlrev_b32 v41, 2, v41\n" \
+		"  v_add_u32 v41, %[clbase], v41\n" \
+		"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
+		"  v_add_u32 v44, %[ep], v60\n" \
+		"  v_add_u32 v48, -1, v44\n" \
+		"  v_and_b32 v44, %[mask], v44\n"                /* slot ep+j */ \
+		"  v_and_b32 v48, %[mask], v48\n" \
+		"  v_lshlrev_b32 v45, 4, v44\n" \
+		"  v_lshlrev_b32 v48, 4, v48\n" \
+		"  ds_read_b32 v47, v45 offset:12\n"             /* w[j]: the links of slot ep+j */ \
+		"  ds_read_b32 v51, v48 offset:12\n"             /* w[j-1] */ \
+		"  v_and_b32 v53, 7, v40\n" \
+		"  v_lshlrev_b32 v53, 2, v53\n" \
+		"  s_waitcnt lgkmcnt(0)\n" \
+		"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
+		"  v_and_b32 v56, 15, v54\n" \
+		"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
+		"  v_cmp_eq_u32 %[vm], 0, v56\n"                 /* VERTEX */ \
+		"  v_cmp_eq_u32 %[lm], 1, v56\n"                 /* LEFT */ \
+		"  v_cmp_gt_u32 %[m0], %[kmax], v60\n" \
+		"  v_cmp_eq_u32 vcc, 0x10101010, v54\n"          /* a regular run from here on ... */ \
+		"  v_cmp_ne_u32 %[m1], 0, v60\n"                 /* ... (not for lane 0: the run step had its chance) */ \
+		"  s_nop 3\n" \
+		"  s_and_b64 vcc, vcc, %[m1]\n" \
+		"  s_or_b64 %[m1], %[vm], %[lm]\n" \
+		"  s_and_b64 %[m1], %[m1], %[m0]\n" \
+		"  s_andn2_b64 %[m1], %[m1], vcc\n"              /* the lanes that may join as far as their own symbol goes */ \
+		"  s_not_b64 %[m0], %[m1]\n" \
+		"  s_ff1_i32_b64 %[k], %[m0]\n"                  /* the first that may not (kmax < 64: there is one) */ \
+		"  s_cmp_eq_u32 %[k], 0\n" \
+		"  s_cbranch_scc1 Lmdone_%=\n" \
+		"  s_bfm_b64 %[m0], %[k], 0\n"                   /* lanes below it */ \
+		"  s_and_b64 %[vm], %[vm], %[m0]\n" \
+		"  s_and_b64 %[lm], %[lm], %[m0]\n" \
+		"  v_cmp_eq_u32 vcc, v57, v44\n"                 /* link(ep+j-1).prev == slot ep+j */ \
+		"  v_cmp_eq_u32 %[m1], 0, v60\n" \
+		"  s_nop 3\n" \
+		"  s_or_b64 vcc, vcc, %[m1]\n" \
+		"  v_cmp_ne_u32 %[m1], %[en], v44\n" \
+		"  s_nop 3\n" \
+		"  s_and_b64 vcc, vcc, %[m1]\n" \
+		"  s_not_b64 vcc, vcc\n" \
+		"  s_ff1_i32_b64 %[tl], vcc\n"                   /* C: chain slots ep .. ep+C-1 are usable (-1: all 64) */ \
+		"  s_mov_b64 vcc, %[vm]\n" \
+		"  s_nop 0\n" \
+		"  v_mbcnt_lo_u32_b32 v38, vcc_lo, 0\n" \
+		"  v_mbcnt_hi_u32_b32 v38, vcc_hi, v38\n"        /* nV_j */ \
+		"  s_mov_b64 vcc, %[lm]\n" \
+		"  s_nop 0\n" \
+		"  v_mbcnt_lo_u32_b32 v39, vcc_lo, 0\n" \
+		"  v_mbcnt_hi_u32_b32 v39, vcc_hi, v39\n"        /* nL_j */ \
+		"  v_cmp_le_u32 %[m1], %[tl], v39\n"             /* a LEFT here needs chain slot number nL_j */ \
+		"  v_cmp_le_u32 vcc, %[budget], v38\n"           /* a VERTEX here needs vertex id / ring slot number nV_j */ \
+		"  s_nop 3\n" \
+		"  s_and_b64 %[m1], %[m1], %[lm]\n" \
+		"  s_and_b64 vcc, vcc, %[vm]\n" \
+		"  s_or_b64 %[m1], %[m1], vcc\n" \
+		"  s_orn2_b64 %[m1], %[m1], %[m0]\n" \
+		"  s_ff1_i32_b64 %[k], %[m1]\n"                  /* k: the symbols of this step */ \
+		"  s_cmp_eq_u32 %[k], 0\n" \
+		"  s_cbranch_scc1 Lmdone_%=\n" \
+		"  s_bfm_b64 %[m0], %[k], 0\n" \
+		"  s_and_b64 %[vm], %[vm], %[m0]\n" \
+		"  s_and_b64 %[lm], %[lm], %[m0]\n" \
+		"  s_bcnt1_i32_b64 %[tv], %[vm]\n" \
+		"  s_bcnt1_i32_b64 %[tl], %[lm]\n" \
+		"  v_add_u32 v49, %[ep], v39\n"                  /* x[nL_j], x[nL_j - 1], x[nL_j - 2] */ \
+		"  v_add_u32 v50, -1, v49\n" \
+		"  v_add_u32 v52, -2, v49\n" \
+		"  v_and_b32 v49, %[mask], v49\n" \
+		"  v_and_b32 v50, %[mask], v50\n" \
+		"  v_and_b32 v52, %[mask], v52\n" \
+		"  v_lshlrev_b32 v49, 4, v49\n" \
+		"  v_lshlrev_b32 v50, 4, v50\n" \
+		"  v_lshlrev_b32 v52, 4, v52\n" \
+		"  ds_read_b32 v46, v49\n" \
+		"  ds_read_b32 v35, v50\n" \
+		"  ds_read_b32 v61, v52\n" \
+		"  v_add_u32 v34, %[vc], v38\n"                  /* vc + nV_j: the new vertex of a VERTEX lane */ \
+		"  v_add_u32 v32, -1, v34\n" \
+		"  v_add_u32 v36, -2, v34\n" \
+		"  v_mov_b32 v58, %[v1]\n" \
+		"  v_cmp_lt_u32 vcc, 0, v38\n" \
+		"  v_cndmask_b32 v32, v58, v32, vcc\n"           /* b_j */ \
+		"  v_cmp_lt_u32 vcc, 1, v38\n" \
+		"  v_cndmask_b32 v36, v58, v36, vcc\n"           /* c_j if symbol j-1 was a VERTEX */ \
+		"  v_mov_b32 v58, %[v0]\n" \
+		"  s_waitcnt lgkmcnt(0)\n" \
+		"  v_cmp_lt_u32 vcc, 0, v39\n" \
+		"  v_cndmask_b32 v33, v58, v35, vcc\n"           /* a_j */ \
+		"  v_cmp_lt_u32 vcc, 1, v39\n" \
+		"  v_cndmask_b32 v37, v58, v61, vcc\n"           /* c_j if symbol j-1 was a LEFT */ \
+		"  s_lshl_b64 vcc, %[vm], 1\n" \
+		"  s_nop 0\n" \
+		"  v_cndmask_b32 v37, v37, v36, vcc\n" \
+		"  v_mov_b32 v58, %[v2]\n" \
+		"  v_cmp_eq_u32 vcc, 0, v60\n" \
+		"  v_cndmask_b32 v37, v37, v58, vcc\n"           /* c_j */ \
+		"  v_cndmask_b32 v34, v46, v34, %[vm]\n"         /* opp_j */ \
+		"  s_max_u32 %[t], %[tl], 1\n" \
+		"  s_sub_u32 %[t], %[t], 1\n" \
+		"  s_nop 1\n" \
+		"  v_readlane_b32 %[swo], v54, %[k]\n"           /* the state after the step: lane k's */ \
+		"  v_readlane_b32 %[swno], v43, %[k]\n" \
+		"  v_readlane_b32 %[v0], v33, %[k]\n" \
+		"  v_readlane_b32 %[v1], v32, %[k]\n" \
+		"  v_readlane_b32 %[v2], v37, %[k]\n" \
+		"  v_readlane_b32 %[epn], v47, %[t]\n"           /* e.prev: the prev link of the last slot a LEFT closed */ \
+		"  s_and_b32 %[epn], %[epn], 0xffff\n" \
+		"  s_cmp_eq_u32 %[tl], 0\n" \
+		"  s_cselect_b32 %[epn], %[ep], %[epn]\n" \
+		"  s_mov_b64 exec, %[m0]\n"                      /* lanes 0 .. k-1 */ \
+		FACE \
+		"  s_mov_b64 exec, %[vm]\n"                      /* the VERTEX lanes */ \
+		"  v_mov_b32 v56, v32\n" \
+		"  v_mov_b32 v57, v33\n" \
+		"  v_mov_b32 v58, v37\n" \
+		"  v_mul_lo_u32 v62, v34, 12\n" \
+		"  v_add_u32 v40, %[nq], v38\n"                  /* the edge it queues: slot nq + nV_j */ \
+		"  v_add_u32 v53, 1, v40\n" \
+		"  v_add_u32 v55, -1, v40\n" \
+		"  v_and_b32 v41, %[mask], v40\n" \
+		"  v_and_b32 v53, %[mask], v53\n" \
+		"  v_and_b32 v55, %[mask], v55\n" \
+		"  global_store_dwordx3 v62, v[56:58], %[predb]\n" \
+		"  v_mov_b32 v42, %[en]\n" \
+		"  v_cmp_eq_u32 vcc, 0, v38\n" \
+		"  v_cndmask_b32 v55, v55, v42, vcc\n"           /* next: e.next for the first */ \
+		"  s_sub_u32 %[t], %[tv], 1\n" \
+		"  v_mov_b32 v42, 0xffff\n" \
+		"  v_cmp_eq_u32 vcc, %[t], v38\n" \
+		"  v_cndmask_b32 v53, v53, v42, vcc\n"           /* prev: lazy for the last */ \
+		"  v_lshl_or_b32 v47, v55, 16, v53\n" \
+		"  v_mov_b32 v44, v34\n" \
+		"  v_mov_b32 v45, v32\n" \
+		"  v_mov_b32 v46, v33\n" \
+		"  v_lshlrev_b32 v41, 4, v41\n" \
+		"  ds_write_b128 v41, v[44:47]\n" \
+		"  s_mov_b64 exec, %[lm]\n"                      /* the LEFT lanes: slot ep + nL_j is deleted */ \
+		"  v_mov_b32 v42, 0x8000\n" \
+		"  ds_write_b16 v49, v42 offset:10\n" \
+		"  s_mov_b64 exec, %[sv]\n" \
+		"  s_cmp_eq_u32 %[tv], 0\n" \
+		"  s_cbranch_scc1 Lmdone_%=\n" \
+		"  s_and_b32 vcc_lo, %[nq], %[mask]\n"           /* e.next.prev = the first new slot */ \
+		"  s_lshl_b32 vcc_hi, %[en], 4\n" \
+		"  v_mov_b32 v40, vcc_lo\n" \
+		"  v_mov_b32 v41, vcc_hi\n" \
+		"  ds_write_b16 v41, v40 offset:12\n" \
+		"  s_nop 1\n" \
+		"Lmdone_%=:\n" \
+		"  s_mov_b64 exec, %[sv]\n" \
+		: [k] "=&s"(mk_), [tv] "=&s"(mtv_), [tl] "=&s"(mtl_), [swo] "=&s"(mswo_), [swno] "=&s"(mswno_), [epn] "=&s"(mepn_), [t] "=&s"(mt_), \
+		  [sv] "=&s"(msv_), [m0] "=&s"(mm0_), [m1] "=&s"(mm1_), [vm] "=&s"(mvm_), [lm] "=&s"(mlm_), [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2) \
+		: [cler] "s"(cler), [wb] "s"(wbias - 1u), [clbase] "s"((uint32_t)(uintptr_t)cl32), [ep] "s"(ep), [en] "s"(en), [mask] "s"(MASK), \
+		  [kmax] "s"(mkmax_), [budget] "s"(budget_), [vc] "s"(vc), [nq] "s"(nq), \
+		  [fbyte] "s"(start*(U16 ? 2u : 4u)), [predb] "s"(predb), [faceb] "s"(faceb) \
+		: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
+		  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+
 template <bool U16>
 __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1051,6 +1271,20 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 								v0 = rxl_; v2 = ral_; nc_v1 = rbl_; ep = rwl_ & 0xFFFFu;
 								v1 = vc + rk_ - 1u; en = (nq + rk_ - 1u) & MASK; nc = en;
 								vc += rk_; nq += rk_; start += 6u*rk_; cler += 2u*rk_; sw = rswo_; swn = rswno_;
+								if(start >= end) break;
+								continue;
+							}
+						}
+						if(c_ == 0x300u && ep <= MASK) {
+							// VERTEXes and LEFTs in any order ahead: up to 63 symbols in one pass of the whole wave (TOPO_MIX_STEP above)
+							uint32_t mk_, mtv_, mtl_, mswo_, mswno_, mepn_, mt_;
+							uint64_t msv_, mm0_, mm1_, mvm_, mlm_;
+							const uint32_t mkmax_ = TOPO_S(min(min(63u, (end - start)/3u), winbase + SYMW - cler));
+							if constexpr(U16) { TOPO_MIX_STEP(TOPO_MIX_FACE16); } else { TOPO_MIX_STEP(TOPO_MIX_FACE32); }
+							if(mk_) {
+								if(mtv_) en = (nq + mtv_ - 1u) & MASK;
+								ep = mepn_; nc = 0xFFFFFFFFu;                             // (every record is in LDS: a RIGHT reads e.next's)
+								vc += mtv_; nq += mtv_; start += 3u*mk_; cler += mk_; sw = mswo_; swn = mswno_;
 								if(start >= end) break;
 								continue;
 							}

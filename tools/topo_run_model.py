@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host model of k_topology_lds's data structure (ring of queued edges + pool of survivors + lazy current edge) with the
-(VERTEX LEFT)^k run step done "in parallel" - the formulation the kernel uses (k_mesh.hip: TOPO_RUN_STEP), checked here
+(VERTEX LEFT)^k run step and the VERTEX / LEFT mix step done "in parallel" - the formulations the kernel uses (k_mesh.hip:
+TOPO_RUN_STEP, TOPO_MIX_STEP), checked here
 against the oracle's faces and prediction triples before it is written in ISA.  Development aid: not a product path and
 not a test (tests/ compare the real kernel with the oracle)."""
 import sys, os
@@ -12,7 +13,7 @@ LAZY = 0xFFFF
 
 
 class Model:
-    def __init__(self, clers, nvert, nface, group_end, ring=1 << 12, pool=1 << 12, use_runs=True, ref_faces=None):
+    def __init__(self, clers, nvert, nface, group_end, ring=1 << 12, pool=1 << 12, use_runs=True, use_mix=True, ref_faces=None):
         self.cl = list(clers) + [15] * 64
         self.nvert, self.nface = nvert, nface
         self.RING, self.MASK, self.POOL = ring, ring - 1, pool
@@ -20,9 +21,14 @@ class Model:
         self.faces = []
         self.pred = np.zeros((nvert, 3), dtype=np.int64)
         self.use_runs = use_runs
+        self.use_mix = use_mix
+        self.any_align = os.environ.get('MIX_ANY_ALIGN', '0') == '1'   # experiment: a trigger that peeks into the next window word too (more one-symbol steps: not taken)
         self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
         self.group_end = group_end
-        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0)
+        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0, mixes=0, mix_symbols=0, mix_hist={})
+
+    def win_left(self, cler):
+        return 1 << 30                      # (the model holds the whole stream; the kernel bounds a step by its LDS window)
 
     def run(self):
         cl = self.cl
@@ -99,6 +105,69 @@ class Model:
                             self.stats['runs'] += 1; self.stats['run_pairs'] += k
                             if start >= end: break
                             continue
+                    # ---- the mix step: k symbols of any VERTEX / LEFT sequence at once, one symbol per lane (TOPO_MIX_STEP)
+                    if self.use_mix and ((cler & 7) <= 4 or self.any_align) and all(cl[cler + d] in (V, L) for d in range(4)) and ep <= MASK \
+                            and [cl[cler + d] for d in range(4)] not in ([V, L, V, L], [L, V, L, V], [V, V, L, V]):
+                        kmax = min(63, (end - start) // 3, self.win_left(cler))
+                        budget = min(self.nvert - vc, self.RING - (nq - qpos))
+                        sym = [cl[cler + j] for j in range(64)]
+                        k0 = 0
+                        while k0 < kmax and sym[k0] in (V, L): k0 += 1
+                        isV = [j < k0 and sym[j] == V for j in range(64)]
+                        isL = [j < k0 and sym[j] == L for j in range(64)]
+                        nV = [sum(isV[:j]) for j in range(64)]
+                        nL = [sum(isL[:j]) for j in range(64)]
+                        # the chain of ring slots behind ep: usable up to the first broken link (lane i looks at slot ep+i)
+                        chain_ok = []
+                        for i in range(64):
+                            slot = (ep + i) & MASK
+                            o = slot != en
+                            if i >= 1: o = o and rec[(ep + i - 1) & MASK][4] == slot
+                            chain_ok.append(o)
+                        C = 0
+                        while C < 64 and chain_ok[C]: C += 1
+                        bad = [not (isV[j] or isL[j]) or (isL[j] and nL[j] >= C) or (isV[j] and nV[j] >= budget) for j in range(64)]
+                        for j in range(1, 64):              # a regular run ahead: the run step does two symbols a lane
+                            if [cl[cler + j + d] for d in range(8)] == [V, L] * 4: bad[j] = True
+                        k = 0
+                        while k < 64 and not bad[k]: k += 1
+                        assert k <= 63
+                        if k >= 1:
+                            x = [rec[(ep + i) & MASK][0] for i in range(64)]
+                            w = [rec[(ep + i) & MASK][4] for i in range(64)]
+                            TV, TL = nV[k], nL[k]
+                            nV = [sum(isV[:min(j, k)]) for j in range(64)]      # masks cut at k (lane k reads the state after the step)
+                            nL = [sum(isL[:min(j, k)]) for j in range(64)]
+                            def abc(j):
+                                a = x[nL[j] - 1] if nL[j] else v0
+                                b = vc + nV[j] - 1 if nV[j] else v1
+                                if j == 0: c = v2
+                                elif sym[j - 1] == V: c = vc + nV[j] - 2 if nV[j] >= 2 else v1
+                                else: c = x[nL[j] - 2] if nL[j] >= 2 else v0
+                                return a, b, c
+                            en0 = en
+                            for j in range(k):
+                                a, b, c = abc(j)
+                                if isV[j]:
+                                    opp = vc + nV[j]
+                                    self.pred[opp] = (b, a, c)
+                                    s_ = (nq + nV[j]) & MASK
+                                    rec[s_] = [opp, b, a, 0, ((nq + nV[j] + 1) & MASK) if nV[j] + 1 < TV else LAZY, ((nq + nV[j] - 1) & MASK) if nV[j] else en0]
+                                else:
+                                    opp = x[nL[j]]
+                                    rec[(ep + nL[j]) & MASK][3] = 1
+                                self.faces += [b, a, opp]
+                            if TV: rec[en0][4] = nq & MASK
+                            a, b, c = abc(k)
+                            epn = w[TL - 1] if TL else ep
+                            enn = (nq + TV - 1) & MASK if TV else en
+                            v0, v1, v2, ep, en = a, b, c, epn, enn
+                            vc += TV; nq += TV; start += 3 * k; cler += k
+                            self.stats['mixes'] += 1; self.stats['mix_symbols'] += k
+                            self.stats['mix_hist'][k] = self.stats['mix_hist'].get(k, 0) + 1
+                            if k <= 2: self.stats.setdefault('short', {}); pat = ''.join('VLREBDS?'[min(c_, 7)] for c_ in cl[cler - k:cler - k + 8]); self.stats['short'][pat] = self.stats['short'].get(pat, 0) + 1
+                            if start >= end: break
+                            continue
                     c = cl[cler]; cler += 1
                     self.stats['serial'] += 1
                     if c == V or c == S:
@@ -171,4 +240,7 @@ if __name__ == "__main__":
     check(synth.strip(400), "strip")
     check(synth.merge([synth.bumpy_sphere(20, 10, seed=1), synth.torus(16, 8), synth.closed_sphere(10, 6)]), "merged")
     check(synth.shuffled(synth.bumpy_sphere(32, 16, seed=5)), "shuffled")
+    check(synth.bumpy_sphere_flipped(64, 32, seed=1), "flipped")
+    check(synth.bumpy_sphere_flipped(64, 32, seed=2, flip=0.1), "flipped 0.1")
+    check(synth.bumpy_sphere_flipped(128, 64, seed=3), "flipped 16K")
     check(synth.bumpy_sphere(512, 250, seed=1), "c2")
