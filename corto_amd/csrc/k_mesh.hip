@@ -1098,6 +1098,18 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 		: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
 		  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 
+// -DCORTO_TOPO_STAMPS (CORTO_BUILD_DEFINES=CORTO_TOPO_STAMPS python -m corto_amd.build --force; tools/topo_stamp_probe.py): where the
+// automaton's time goes - shader clocks (s_memtime), steps and symbols per phase of workgroups 0..4095, read back with
+// crthip_debug_topo_stamps.  Phases: 0 ISA block, 1 run step, 2 mix step, 3 C++ symbol, 4 gate fetch, 5 prologue; [15] = all of it.
+#ifdef CORTO_TOPO_STAMPS
+__device__ uint32_t g_topo_stamps[48*4096];
+#define TOPO_CLK() ((uint32_t)__builtin_amdgcn_s_memtime())
+#define TOPO_T0() const uint32_t tt0_ = TOPO_CLK(), tc0_ = cler
+#define TOPO_ACC(i) do { st_clk[i] += TOPO_CLK() - tt0_; st_cnt[i]++; st_sym[i] += cler - tc0_; } while(0)
+#else
+#define TOPO_T0() do { } while(0)
+#define TOPO_ACC(i) do { } while(0)
+#endif
 template <bool U16>
 __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1132,6 +1144,10 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	// slides the window by itself between chains when a mesh has more symbols than the window (3 instructions per symbol)
 	// (two words behind the window: "window exhausted" nibbles - a chain that outruns the window ends in the HBM redo, so that the
 	// loop never loads symbols from HBM itself: a load's s_waitcnt would also wait for every face / prediction store in flight)
+#ifdef CORTO_TOPO_STAMPS
+	uint32_t st_clk[6] = {0, 0, 0, 0, 0, 0}, st_cnt[6] = {0, 0, 0, 0, 0, 0}, st_sym[6] = {0, 0, 0, 0, 0, 0};
+	const uint32_t st_begin = TOPO_CLK();
+#endif
 	TOPO_FILL_WINDOW(0u);
 	if(nspl) {                                                            // (<= 256 words: four loads per lane, in flight together)
 		uint32_t sw4[4];
@@ -1151,6 +1167,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #define TOPO_NFREE() (pk1 >> 16)
 #define TOPO_MBUMP() (pk1 & 0xFFFFu)
 #define TOPO_NDEL() (pk2 & 0xFFFFu)
+#ifdef CORTO_TOPO_STAMPS
+	st_clk[5] = TOPO_CLK() - st_begin;
+#endif
 	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
 	uint32_t sw = TOPO_S(cl32[0]), swn = TOPO_S(cl32[1]);   // TOPO_S: a value lane 0 alone computes is uniform by construction; tell the compiler (SGPR)
 	uint32_t wbias = 1, slide_at = SYMW < nclers ? SYMW - 2048u : 0xFFFFFFFFu;   // next symbol word = cl32[(cler >> 3) + wbias]; slide when cler gets here
@@ -1181,6 +1200,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 			nq = 0; qpos = 0; pk1 = RING; pk2 = dcap << 16;
 			while(start < end && !err) {
 				if(cler >= slide_at) TOPO_SLIDE();                          // slide the window before it runs low
+				TOPO_T0();
 				// ---- cold: fetch the next edge to process: ring, DELAY stack, or a new seed face ----
 				uint32_t f;
 				u32x4 t0;
@@ -1244,6 +1264,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 				if(t0.z & TOPO_DEAD) continue;                             // deleted: no symbol consumed (decoder.cpp:278-279)
 				uint32_t v0 = TOPO_S(t0.x), v1 = TOPO_S(t0.y), v2 = TOPO_S(t0.z) & TOPO_VMASK, ep = TOPO_S(t0.w) & 0xFFFFu, en = TOPO_S(t0.w) >> 16;
 				uint32_t nc = 0xFFFFFFFFu, nc_next = 0, nc_v1 = 0;         // cached (next, v1) of edge nc
+				TOPO_ACC(4);
 
 				// ---- hot: follow the chain of freshly created edges while the symbols are VERTEX / LEFT / RIGHT ----
 				for(;;) {
@@ -1256,7 +1277,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						// or ring running out, the group's last face - which the C++ below then handles.
 						uint32_t t0_, t1_, t2_, t3_, c_;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
+						{ TOPO_T0();
 						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32); }
+						TOPO_ACC(0); }
 						if(start >= end) break;
 						if(c_ == 0x200u) break;                                   // the block ended the chain (BOUNDARY / DELAY) and found no gate to go on with
 						if(c_ == 0x100u && ep <= MASK) {
@@ -1265,12 +1288,14 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							uint32_t rk_, rkm1_, rswo_, rswno_, rxl_, rwl_, ral_, rbl_, rm0s_;
 							uint64_t rsv_, rm0_, rm1_;
 							const uint32_t rkmax_ = TOPO_S(min(min(budget_, 63u), min((end - start)/6u, (winbase + SYMW - cler) >> 1)));
+							TOPO_T0();
 							if constexpr(U16) { TOPO_RUN_STEP(TOPO_RUN_FACE16); } else { TOPO_RUN_STEP(TOPO_RUN_FACE32); }
 							if(rk_) {
 								nc_next = rk_ == 1 ? en : (nq + rk_ - 2u) & MASK;
 								v0 = rxl_; v2 = ral_; nc_v1 = rbl_; ep = rwl_ & 0xFFFFu;
 								v1 = vc + rk_ - 1u; en = (nq + rk_ - 1u) & MASK; nc = en;
 								vc += rk_; nq += rk_; start += 6u*rk_; cler += 2u*rk_; sw = rswo_; swn = rswno_;
+								TOPO_ACC(1);
 								if(start >= end) break;
 								continue;
 							}
@@ -1280,16 +1305,20 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							uint32_t mk_, mtv_, mtl_, mswo_, mswno_, mepn_, mt_;
 							uint64_t msv_, mm0_, mm1_, mvm_, mlm_;
 							const uint32_t mkmax_ = TOPO_S(min(min(63u, (end - start)/3u), winbase + SYMW - cler));
+							TOPO_T0();
 							if constexpr(U16) { TOPO_MIX_STEP(TOPO_MIX_FACE16); } else { TOPO_MIX_STEP(TOPO_MIX_FACE32); }
+							if(!mk_) TOPO_ACC(2);
 							if(mk_) {
 								if(mtv_) en = (nq + mtv_ - 1u) & MASK;
 								ep = mepn_; nc = 0xFFFFFFFFu;                             // (every record is in LDS: a RIGHT reads e.next's)
 								vc += mtv_; nq += mtv_; start += 3u*mk_; cler += mk_; sw = mswo_; swn = mswno_;
+								TOPO_ACC(2);
 								if(start >= end) break;
 								continue;
 							}
 						}
 					}
+					TOPO_T0();
 					uint32_t c; TOPO_SYMBOL(c);
 					if(c == C_VERTEX) {                                    // decoder.cpp:294-309
 						if(vc >= nvert) { err = 1; break; }
@@ -1348,8 +1377,10 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 							rec16[nn*8 + 6] = (uint16_t)pp;
 							TOPO_FACE(v1, v0, opp);
 						} else err = c == 14u ? 2u : 1u;                   // window exhausted mid-chain (redo on the HBM front) / invalid symbol or past the end
+						TOPO_ACC(3);
 						break;
 					}
+					TOPO_ACC(3);
 					if(start >= end) break;
 				}
 			}
@@ -1367,6 +1398,13 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #undef TOPO_NDEL
 		}
 	}
+#ifdef CORTO_TOPO_STAMPS
+	if(blockIdx.x < 4096) {
+		uint32_t *o_ = g_topo_stamps + blockIdx.x*48;
+		for(int i = 0; i < 6; i++) { o_[i] = st_clk[i]; o_[8 + i] = st_cnt[i]; o_[16 + i] = st_sym[i]; }
+		o_[15] = TOPO_CLK() - st_begin; o_[24] = cler; o_[25] = err;
+	}
+#endif
 	if(err == 2) return false;
 	for(uint32_t v = vc; v < nvert; v++) { CRT_GLOBAL uint32_t *p_ = (CRT_GLOBAL uint32_t *)(predb + (size_t)v*12u); p_[0] = 0; p_[1] = 0; p_[2] = 0; }   // never reached: (0, 0, 0) (see topo_run)
 	if(err || cler > J.nclers) *as_global(J.status) = ERR_TOPOLOGY;
@@ -1618,8 +1656,9 @@ __device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint1
 template <typename T, int NC>
 __device__ __forceinline__ uint32_t delta_scan_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, uint32_t nvert, bool para) {
 	const uint32_t lane = lane_id();
-	uint32_t s = 1, passes = 0;
+	uint32_t s = 1, passes = 0, sp0 = 1, sp1 = 1;
 	while(s < nvert) {
+		for(uint32_t pass16 = 0; pass16 < 16 && s < nvert; pass16++) {       // (sixteen passes, then the checks below: nothing but the block in the loop)
 		const uint32_t i = s + lane;
 		const bool in = i < nvert;
 		// (loads are unconditional, on clamped addresses, and pinned by empty asm statements: written as `in ? pa[i] : ...` the compiler sinks
@@ -1659,10 +1698,22 @@ __device__ __forceinline__ uint32_t delta_scan_run(CRT_LDS T *v, CRT_LDS const u
 			for(uint32_t q = 0; q < (uint32_t)NC; q++) v[i*NC + q] = (T)(incl[q] - eh[q]);
 		}
 		s += L;
+		}
 		// a front grows from its seed triangle, so the first blocks are short whatever the mesh; by pass 96 a mesh with rings to speak
 		// of has done well over a thousand vertices (a 4K-triangle grid: 1 700) and one that has not yet done 576 (a holey disc, a
-		// ribbon: ~5 a pass) has a shallower DAG than it has blocks - the walk takes over from s
-		if(++passes == 96 && s < 96*6) break;
+		// ribbon: ~5 a pass) has a shallower DAG than it has blocks - the walk takes over from s.  Most of those show it earlier:
+		// passes 33..48 take 230 vertices on a grid (123 on a torus, 140 on a grid with one quad in fifty split the other way), 60-85
+		// where the diagonals are random or the mesh is full of holes - fewer than 6 a pass there ends the scans at pass 48.
+		// And a mesh that is regular only in patches (one quad in fifty split the other way: 266 passes, 0.148 ms where the walk
+		// takes 0.073) shows in how its blocks grow: with whole rings a pass takes ~1.35x more vertices in passes 49..64 than in
+		// 33..48 (grid, torus), with patches 1.1x or less - under 1.2x with more than a hundred such passes to go ends the scans too.
+		// (Checked every 16 passes from the 64th on, while a pass takes fewer than 16 vertices.)
+		passes += 16;
+		const uint32_t g = s - sp1, g0 = sp1 - sp0;                            // vertices of the last 16 passes, and of the 16 before
+		if(passes == 48 && g < 16*6) break;
+		if(passes >= 64 && g < 16*16 && g*5 < g0*6 && (nvert - s)*16 > g*100) break;
+		if(passes == 96 && s < 96*6) break;
+		sp0 = sp1; sp1 = s;
 	}
 	return s < nvert ? s : nvert;
 }
@@ -1844,3 +1895,7 @@ __global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__
 }
 
 } // namespace corto_hip
+
+#ifdef CORTO_TOPO_STAMPS
+extern "C" int crthip_debug_topo_stamps(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_topo_stamps), sizeof(uint32_t)*48*4096); }
+#endif

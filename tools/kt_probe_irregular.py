@@ -1,11 +1,15 @@
-"""Per-kernel HIP-event times of one batch of 256 irregular blobs (bumpy_sphere_flipped), unpipelined; $FLIP sets the flip probability."""
+"""Per-kernel HIP-event times of one batch of 256 irregular blobs, unpipelined: $MESH = flipped (bumpy_sphere_flipped, $FLIP sets the
+flip probability) | torus | holey | strip | grid128."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import corto_amd as ca
 from corto_amd import synth
 flip = float(os.environ.get("FLIP", "0.5"))
-blobs = [ca.encode(synth.bumpy_sphere_flipped(64, 32, seed=i, flip=flip), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(256)]
+kind = os.environ.get("MESH", "flipped")                      # flipped | torus | holey | strip | grid128
+gen = {"flipped": lambda i: synth.bumpy_sphere_flipped(64, 32, seed=i, flip=flip), "torus": lambda i: synth.torus(48, 24, seed=i),
+       "holey": lambda i: synth.holey_disc(40, seed=i), "strip": lambda i: synth.strip(400, seed=i), "grid128": lambda i: synth.bumpy_sphere(128, 64, seed=i)}[kind]
+blobs = [ca.encode(gen(i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(256)]
 ctx = ca.Context(0); ctx.set_profiling(True)
 arena = ca.upload_arena(blobs, 0)
 b = ca.Batch(ctx, blobs, device_arena=arena); b.allocate_outputs()
@@ -17,4 +21,4 @@ for i in range(N + 3):
         for k, v in b.kernel_times().items():
             a = acc.setdefault(k, [0.0, 0]); a[0] += v["ms"]; a[1] += v.get("launches", 1)
 st = b.stats()
-print("flip", flip, {k: (round(v[0] / N, 4), v[1] // N) for k, v in acc.items()}, "dicts", st.tunstall_dictionaries, "of", st.tunstall_streams, "fallbacks", st.topology_fallbacks, "clers", st.clers_symbols // 256)
+print(kind, "flip", flip, {k: (round(v[0] / N, 4), v[1] // N) for k, v in acc.items()}, "dicts", st.tunstall_dictionaries, "of", st.tunstall_streams, "fallbacks", st.topology_fallbacks, "clers", st.clers_symbols // 256)
