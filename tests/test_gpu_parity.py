@@ -150,6 +150,18 @@ def test_irregular_connectivity_batch(ctx):
         for i, r in enumerate(refs):
             assert_same(b.host_outputs(i), r, KEYS, "flipped %d single=%s" % (i, single))
         b.close(); c.close()
+    # VERTEX / LEFT in any order is the automaton's mix step (one symbol a lane): meshes whose streams outgrow the LDS symbol window
+    # (the step runs up against the window's end and the slides), flip rates from one quad in fifty to all, u32 and u16 indices
+    big = [synth.bumpy_sphere_flipped(128, 64, seed=7), synth.bumpy_sphere_flipped(200, 100, seed=8, flip=0.1), synth.bumpy_sphere_flipped(90, 45, seed=9, flip=1.0)]
+    big += [synth.bumpy_sphere_flipped(64, 32, seed=200 + s, flip=f) for s, f in enumerate((0.02, 0.05, 0.2, 0.8, 0.98))]
+    blobs = [ca.encode(m, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for m in big]
+    for u16 in (False, True):
+        b = run_batch(ctx, blobs, index16=u16, normal_format=ca.FMT_INT16 if u16 else ca.FMT_FLOAT, color_components=4)
+        for i, blob in enumerate(blobs):
+            r = oc.decode(blob, index16=u16, normal_format=oc.FMT_INT16 if u16 else oc.FMT_FLOAT, color_components=4)
+            assert_same(b.host_outputs(i), r, KEYS, "big flipped %d u16=%s" % (i, u16))
+        assert b.stats().topology_fallbacks == 0
+        b.close()
 
 
 def test_single_stream_context_decodes_the_same(ctx):
