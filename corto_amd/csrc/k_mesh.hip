@@ -299,7 +299,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_eq_u32 %[c], 2\n" \
 							"  s_cbranch_scc1 Lright_%=\n" \
 							"  s_branch Lcold_%=\n"
-#define TOPO_FAST_PATH(FACE) \
+#define TOPO_FAST_PATH(FACE, RUNFACE, MIXFACE, FSHIFT) \
 						asm volatile( \
 							"Ltop_%=:\n" \
 							"  s_and_b32 %[c], %[sw], 15\n"   /* (SCC = result != 0) */ \
@@ -649,11 +649,16 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_and_b32 %[t1], %[cler], 7\n" \
 							"  s_cmp_gt_u32 %[t1], 4\n" \
 							"  s_cbranch_scc1 Llgo_%=\n" \
-							"Lmix_%=:\n" \
-							"  s_mov_b32 %[c], 0x300\n" \
-							"  s_branch Lexit_%=\n" \
-							"Lrun_%=:\n" \
-							"  s_mov_b32 %[c], 0x100\n" \
+							TOPO_ASM_MIX(MIXFACE, FSHIFT) \
+							TOPO_ASM_RUN(RUNFACE, FSHIFT) \
+							   /* ---------------- after a step: the group may be done, the window may want sliding (both the C++'s business), else the next symbol */ \
+							"Lstepped_%=:\n" \
+							"  s_mov_b32 %[c], 0\n" \
+							"  s_cmp_lt_u32 %[start], %[end]\n" \
+							"  s_cbranch_scc0 Lexit_%=\n" \
+							"  s_cmp_ge_u32 %[cler], %[slideat]\n" \
+							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_branch Ltop_%=\n" \
 							"Lexit_%=:\n" \
 							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start), \
 							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en), \
@@ -662,8 +667,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							  [pk1] "+s"(pk1), [pk2] "+s"(pk2), [qpos] "+s"(qpos) \
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
-							: "memory", "scc", "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61");
+							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -777,7 +782,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mov_b32 v35, v34\n" \
 	"  v_mov_b32 v36, v33\n" \
 	"  v_mov_b32 v37, v46\n" \
-	"  v_mad_u32_u24 v59, v60, 24, %[fbyte]\n" \
+	"  v_mad_u32_u24 v59, v60, 24, %[c]\n" \
 	"  global_store_dwordx4 v59, v[32:35], %[faceb]\n" \
 	"  global_store_dwordx2 v59, v[36:37], %[faceb] offset:16\n"
 #define TOPO_RUN_FACE16 \
@@ -787,121 +792,146 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_lshl_or_b32 v37, v34, 16, v37\n" \
 	"  v_and_b32 v38, 0xffff, v33\n" \
 	"  v_lshl_or_b32 v38, v46, 16, v38\n" \
-	"  v_mad_u32_u24 v59, v60, 12, %[fbyte]\n" \
+	"  v_mad_u32_u24 v59, v60, 12, %[c]\n" \
 	"  global_store_dwordx3 v59, v[36:38], %[faceb]\n"
-#define TOPO_RUN_STEP(FACE) \
-	asm volatile( \
-		"  s_mov_b64 %[sv], exec\n" \
-		"  s_mov_b64 exec, -1\n" \
-		"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
-		"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
-		"  v_lshlrev_b32 v40, 1, v60\n" \
-		"  v_add_u32 v40, %[cler], v40\n"                /* p = cler + 2j: the pair's first symbol */ \
-		"  v_lshrrev_b32 v41, 3, v40\n" \
-		"  v_add_u32 v41, %[wb], v41\n" \
-		"  v_lshlrev_b32 v41, 2, v41\n" \
-		"  v_add_u32 v41, %[clbase], v41\n" \
-		"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
-		"  v_add_u32 v44, %[ep], v60\n" \
-		"  v_add_u32 v48, -1, v44\n" \
-		"  v_add_u32 v49, -2, v44\n" \
-		"  v_and_b32 v44, %[mask], v44\n"                /* slot ep+j */ \
-		"  v_and_b32 v48, %[mask], v48\n" \
-		"  v_and_b32 v49, %[mask], v49\n" \
-		"  v_lshlrev_b32 v45, 4, v44\n" \
-		"  v_lshlrev_b32 v48, 4, v48\n" \
-		"  v_lshlrev_b32 v49, 4, v49\n" \
-		"  v_add_u32 v45, %[recb], v45\n" \
-		"  v_add_u32 v48, %[recb], v48\n" \
-		"  v_add_u32 v49, %[recb], v49\n" \
-		"  ds_read2_b32 v[46:47], v45 offset1:3\n"       /* x[j], w[j] */ \
-		"  ds_read2_b32 v[50:51], v48 offset1:3\n"       /* x[j-1], w[j-1] */ \
-		"  ds_read_b32 v52, v49\n"                       /* x[j-2] */ \
-		"  v_and_b32 v53, 7, v40\n" \
-		"  v_lshlrev_b32 v53, 2, v53\n" \
-		"  s_waitcnt lgkmcnt(0)\n" \
-		"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
-		"  v_and_b32 v56, 0xff, v54\n" \
-		"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
-		"  v_cmp_eq_u32 vcc, 16, v56\n"                  /* (VERTEX, LEFT) */ \
-		"  v_cmp_eq_u32 %[m0], v57, v44\n" \
-		"  v_cmp_eq_u32 %[m1], 0, v60\n" \
-		"  s_nop 1\n" \
-		"  s_or_b64 %[m0], %[m0], %[m1]\n" \
-		"  s_and_b64 vcc, vcc, %[m0]\n" \
-		"  v_cmp_ne_u32 %[m0], %[en], v44\n" \
-		"  v_cmp_gt_u32 %[m1], %[kmax], v60\n" \
-		"  s_nop 1\n" \
-		"  s_and_b64 %[m0], %[m0], %[m1]\n" \
-		"  s_and_b64 vcc, vcc, %[m0]\n" \
-		"  s_not_b64 %[m0], vcc\n" \
-		"  s_ff1_i32_b64 %[k], %[m0]\n"                  /* first lane that cannot join (kmax < 64: there is one) */ \
-		"  s_cmp_eq_u32 %[k], 0\n" \
-		"  s_cbranch_scc1 Lrdone_%=\n" \
-		"  s_sub_u32 %[km1], %[k], 1\n" \
-		"  v_readlane_b32 %[swo], v54, %[k]\n" \
-		"  v_readlane_b32 %[swno], v43, %[k]\n" \
-		"  v_readlane_b32 %[xl], v46, %[km1]\n" \
-		"  v_readlane_b32 %[wl], v47, %[km1]\n" \
-		"  s_bfm_b64 exec, %[k], 0\n"                    /* lanes 0 .. k-1 */ \
-		"  v_cmp_ne_u32 vcc, 0, v60\n" \
-		"  v_cmp_lt_u32 %[m1], 1, v60\n" \
-		"  v_mov_b32 v38, %[v0]\n" \
-		"  v_mov_b32 v39, %[v1]\n" \
-		"  v_add_u32 v34, %[vc], v60\n"                  /* the new vertex vc+j */ \
-		"  v_add_u32 v32, -1, v34\n" \
-		"  v_cndmask_b32 v33, v38, v50, vcc\n"           /* a_j */ \
-		"  v_cndmask_b32 v32, v39, v32, vcc\n"           /* b_j */ \
-		"  v_cndmask_b32 v58, v38, v52, %[m1]\n" \
-		"  v_mov_b32 v39, %[v2]\n" \
-		"  s_nop 0\n" \
-		"  v_cndmask_b32 v58, v39, v58, vcc\n"           /* c_j */ \
-		"  v_mov_b32 v56, v32\n" \
-		"  v_mov_b32 v57, v33\n" \
-		"  v_mul_lo_u32 v59, v34, 12\n" \
-		"  s_nop 0\n" \
-		"  v_readlane_b32 %[al], v33, %[km1]\n" \
-		"  v_readlane_b32 %[bl], v32, %[km1]\n" \
-		"  global_store_dwordx3 v59, v[56:58], %[predb]\n" \
-		FACE \
-		"  v_add_u32 v40, %[nq], v60\n" \
-		"  v_add_u32 v53, 1, v40\n" \
-		"  v_add_u32 v54, -1, v40\n" \
-		"  v_and_b32 v41, %[mask], v40\n"                /* its slot nq+j */ \
-		"  v_and_b32 v53, %[mask], v53\n" \
-		"  v_and_b32 v54, %[mask], v54\n" \
-		"  v_mov_b32 v55, %[en]\n" \
-		"  v_cmp_eq_u32 %[m1], %[km1], v60\n" \
-		"  v_cndmask_b32 v54, v55, v54, vcc\n"           /* next: e.next for the first, else slot nq+j-1 */ \
-		"  v_mov_b32 v55, 0xffff\n" \
-		"  s_nop 0\n" \
-		"  v_cndmask_b32 v53, v53, v55, %[m1]\n"         /* prev: slot nq+j+1, lazy for the last */ \
-		"  v_lshl_or_b32 v51, v54, 16, v53\n" \
-		"  v_mov_b32 v48, v34\n" \
-		"  v_mov_b32 v49, v32\n" \
-		"  v_mov_b32 v50, v33\n" \
-		"  v_lshlrev_b32 v41, 4, v41\n" \
-		"  v_add_u32 v41, %[recb], v41\n" \
-		"  ds_write_b128 v41, v[48:51]\n" \
-		"  v_mov_b32 v55, 0x8000\n" \
-		"  ds_write_b16 v45, v55 offset:10\n"            /* slot ep+j: deleted */ \
-		"  s_mov_b64 exec, %[sv]\n" \
-		"  s_and_b32 %[m0s], %[nq], %[mask]\n"           /* e.next.prev = first new slot */ \
-		"  s_lshl_b32 %[km1], %[en], 4\n" \
-		"  s_add_u32 %[km1], %[km1], %[recb]\n" \
-		"  v_mov_b32 v40, %[m0s]\n" \
-		"  v_mov_b32 v41, %[km1]\n" \
-		"  ds_write_b16 v41, v40 offset:12\n" \
-		"  s_nop 1\n" \
-		"Lrdone_%=:\n" \
-		"  s_mov_b64 exec, %[sv]\n" \
-		: [k] "=&s"(rk_), [km1] "=&s"(rkm1_), [swo] "=&s"(rswo_), [swno] "=&s"(rswno_), [xl] "=&s"(rxl_), [wl] "=&s"(rwl_), \
-		  [al] "=&s"(ral_), [bl] "=&s"(rbl_), [sv] "=&s"(rsv_), [m0] "=&s"(rm0_), [m1] "=&s"(rm1_), [m0s] "=&s"(rm0s_) \
-		: [cler] "s"(cler), [wb] "s"(wbias - 1u), [clbase] "s"((uint32_t)(uintptr_t)cl32), [ep] "s"(ep), [en] "s"(en), [mask] "s"(MASK), \
-		  [recb] "s"((uint32_t)(uintptr_t)rec), [kmax] "s"(rkmax_), [v0] "s"(v0), [v1] "s"(v1), [v2] "s"(v2), [vc] "s"(vc), [nq] "s"(nq), \
-		  [fbyte] "s"(start*(U16 ? 2u : 4u)), [predb] "s"(predb), [faceb] "s"(faceb) \
-		: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
-		  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+// Both steps are sections of the ISA block (TOPO_FAST_PATH jumps here from its VERTEX / LEFT entries and dispatches the next symbol
+// afterwards): as asm statements of their own they cost ~400 clocks of compiler-made glue a step - the exit, forty scalar instructions
+// of state shuffling either side, the way back in - a sixth of a regular blob's automaton.  Inside they live on the block's five scalar
+// temporaries and vcc: conditions are chained by narrowing exec (each compare sees the lanes that passed the ones before), masks are
+// rebuilt from per-lane values where they are needed again, exec is known to be lane 0 on entry.  FSHIFT: log2 of an index's bytes.
+#define TOPO_ASM_WINDOW_LEFT /* t2 = symbols the LDS window holds from cler on (63+ when it reaches the end of the stream) */ \
+	"  s_add_u32 %[t2], %[slideat], 2048\n" \
+	"  s_sub_u32 %[t2], %[t2], %[cler]\n" \
+	"  s_max_i32 %[t2], %[t2], 0\n" \
+	"  s_cmp_eq_u32 %[slideat], -1\n" \
+	"  s_cselect_b32 %[t2], 126, %[t2]\n"
+#define TOPO_ASM_RUN(FACE, FSHIFT) \
+	"Lrun_%=:\n" \
+	"  s_cmp_gt_u32 %[ep], %[mask]\n"                 /* e.prev in the pool: one symbol at a time */ \
+	"  s_cbranch_scc1 Lvgo_%=\n" \
+	"  s_sub_u32 %[t3], %[end], %[start]\n"           /* kmax = min(63, vertex ids / ring slots left, pairs the group and the window hold) */ \
+	"  s_mul_hi_u32 %[t3], %[t3], 0xaaaaaaab\n" \
+	"  s_lshr_b32 %[t3], %[t3], 2\n" \
+	"  s_min_u32 %[t3], %[t3], 63\n" \
+	"  s_min_u32 %[t3], %[t3], %[budget]\n" \
+	TOPO_ASM_WINDOW_LEFT \
+	"  s_lshr_b32 %[t2], %[t2], 1\n" \
+	"  s_min_u32 %[t3], %[t3], %[t2]\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
+	"  v_lshlrev_b32 v40, 1, v60\n" \
+	"  v_add_u32 v40, %[cler], v40\n"                /* p = cler + 2j: the pair's first symbol */ \
+	"  v_lshrrev_b32 v41, 3, v40\n" \
+	"  v_add_u32 v41, %[wbias], v41\n" \
+	"  v_lshlrev_b32 v41, 2, v41\n" \
+	"  v_add_u32 v41, %[clbase], v41\n" \
+	"  v_add_u32 v41, -4, v41\n"                     /* (the word of symbol p is cl32[(p >> 3) + wbias - 1]) */ \
+	"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
+	"  v_add_u32 v44, %[ep], v60\n" \
+	"  v_add_u32 v48, -1, v44\n" \
+	"  v_add_u32 v49, -2, v44\n" \
+	"  v_and_b32 v44, %[mask], v44\n"                /* slot ep+j */ \
+	"  v_and_b32 v48, %[mask], v48\n" \
+	"  v_and_b32 v49, %[mask], v49\n" \
+	"  v_lshlrev_b32 v45, 4, v44\n" \
+	"  v_lshlrev_b32 v48, 4, v48\n" \
+	"  v_lshlrev_b32 v49, 4, v49\n" \
+	"  ds_read2_b32 v[46:47], v45 offset1:3\n"       /* x[j], w[j] */ \
+	"  ds_read2_b32 v[50:51], v48 offset1:3\n"       /* x[j-1], w[j-1] */ \
+	"  ds_read_b32 v52, v49\n"                       /* x[j-2] */ \
+	"  v_and_b32 v53, 7, v40\n" \
+	"  v_lshlrev_b32 v53, 2, v53\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
+	"  v_and_b32 v56, 0xff, v54\n" \
+	"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
+	"  v_cmp_eq_u32 vcc, 0, v60\n" \
+	"  v_cndmask_b32 v57, v57, v44, vcc\n"           /* (lane 0 has no link to check) */ \
+	"  v_cmp_eq_u32 vcc, 16, v56\n"                  /* (VERTEX, LEFT) */ \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_eq_u32 vcc, v57, v44\n"                 /* link(ep+j-1).prev == slot ep+j */ \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_ne_u32 vcc, %[en], v44\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_gt_u32 vcc, %[t3], v60\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  s_not_b64 vcc, exec\n" \
+	"  s_ff1_i32_b64 %[t0], vcc\n"                   /* k: the first lane that cannot join (kmax < 64: there is one) */ \
+	"  s_cmp_eq_u32 %[t0], 0\n" \
+	"  s_cbranch_scc1 Lrun0_%=\n" \
+	"  s_sub_u32 %[t1], %[t0], 1\n" \
+	"  s_lshl_b32 %[c], %[start], " FSHIFT "\n"      /* byte offset of the step's first index */ \
+	"  s_bfm_b64 exec, %[t0], 0\n"                   /* lanes 0 .. k-1 */ \
+	"  v_mov_b32 v38, %[v0]\n" \
+	"  v_mov_b32 v39, %[v1]\n" \
+	"  v_add_u32 v34, %[vc], v60\n"                  /* the new vertex vc+j */ \
+	"  v_add_u32 v32, -1, v34\n" \
+	"  v_cmp_ne_u32 vcc, 0, v60\n" \
+	"  v_cndmask_b32 v33, v38, v50, vcc\n"           /* a_j */ \
+	"  v_cndmask_b32 v32, v39, v32, vcc\n"           /* b_j */ \
+	"  v_mov_b32 v39, %[v2]\n" \
+	"  v_cndmask_b32 v58, v39, v38, vcc\n" \
+	"  v_cmp_lt_u32 vcc, 1, v60\n" \
+	"  v_cndmask_b32 v58, v58, v52, vcc\n"           /* c_j */ \
+	"  v_mov_b32 v56, v32\n" \
+	"  v_mov_b32 v57, v33\n" \
+	"  v_mul_lo_u32 v59, v34, 12\n" \
+	"  global_store_dwordx3 v59, v[56:58], %[predb]\n" \
+	FACE \
+	"  v_add_u32 v40, %[nq], v60\n" \
+	"  v_add_u32 v53, 1, v40\n" \
+	"  v_add_u32 v55, -1, v40\n" \
+	"  v_and_b32 v41, %[mask], v40\n"                /* its slot nq+j */ \
+	"  v_and_b32 v53, %[mask], v53\n" \
+	"  v_and_b32 v55, %[mask], v55\n" \
+	"  v_mov_b32 v61, %[en]\n" \
+	"  v_cmp_ne_u32 vcc, 0, v60\n" \
+	"  v_cndmask_b32 v55, v61, v55, vcc\n"           /* next: e.next for the first, else slot nq+j-1 */ \
+	"  v_mov_b32 v61, 0xffff\n" \
+	"  v_cmp_eq_u32 vcc, %[t1], v60\n" \
+	"  v_cndmask_b32 v53, v53, v61, vcc\n"           /* prev: slot nq+j+1, lazy for the last */ \
+	"  v_lshl_or_b32 v51, v55, 16, v53\n" \
+	"  v_mov_b32 v48, v34\n" \
+	"  v_mov_b32 v49, v32\n" \
+	"  v_mov_b32 v50, v33\n" \
+	"  v_lshlrev_b32 v41, 4, v41\n" \
+	"  ds_write_b128 v41, v[48:51]\n" \
+	"  v_mov_b32 v61, 0x8000\n" \
+	"  ds_write_b16 v45, v61 offset:10\n"            /* slot ep+j: deleted */ \
+	"  v_readlane_b32 %[sw], v54, %[t0]\n"           /* the window registers: lane k's (the words it read are the ones the loop goes on with) */ \
+	"  v_readlane_b32 %[swn], v43, %[t0]\n" \
+	"  v_readlane_b32 %[t2], v47, %[t1]\n"           /* the state after the run: lane k-1's */ \
+	"  v_readlane_b32 %[v0], v46, %[t1]\n" \
+	"  v_readlane_b32 %[v2], v33, %[t1]\n" \
+	"  v_readlane_b32 %[ncv1], v32, %[t1]\n" \
+	"  s_mov_b64 exec, 1\n" \
+	"  s_and_b32 %[t3], %[nq], %[mask]\n"            /* e.next.prev = the first new slot */ \
+	"  s_lshl_b32 %[c], %[en], 4\n" \
+	"  v_mov_b32 v40, %[t3]\n" \
+	"  v_mov_b32 v41, %[c]\n" \
+	"  ds_write_b16 v41, v40 offset:12\n" \
+	"  s_and_b32 %[ep], %[t2], 0xffff\n" \
+	"  s_add_u32 %[t3], %[nq], %[t0]\n" \
+	"  s_sub_u32 %[c], %[t3], 2\n" \
+	"  s_and_b32 %[c], %[c], %[mask]\n" \
+	"  s_cmp_eq_u32 %[t0], 1\n" \
+	"  s_cselect_b32 %[ncnext], %[en], %[c]\n"       /* (next, v1) of the last queued edge, cached for a RIGHT */ \
+	"  s_add_u32 %[v1], %[vc], %[t1]\n" \
+	"  s_sub_u32 %[c], %[t3], 1\n" \
+	"  s_and_b32 %[en], %[c], %[mask]\n" \
+	"  s_mov_b32 %[nc], %[en]\n" \
+	"  s_add_u32 %[vc], %[vc], %[t0]\n" \
+	"  s_mov_b32 %[nq], %[t3]\n" \
+	"  s_sub_u32 %[budget], %[budget], %[t0]\n" \
+	"  s_mul_i32 %[c], %[t0], 6\n" \
+	"  s_add_u32 %[start], %[start], %[c]\n" \
+	"  s_lshl_b32 %[c], %[t0], 1\n" \
+	"  s_add_u32 %[cler], %[cler], %[c]\n" \
+	"  s_branch Lstepped_%=\n" \
+	"Lrun0_%=:\n"                                    /* not even one pair: the VERTEX goes the one-at-a-time way */ \
+	"  s_mov_b64 exec, 1\n" \
+	"  s_branch Lvgo_%=\n"
 
 // The mix step.  Meshes whose quads are not split the same way everywhere (anything that is not a regular grid) do not give (VERTEX LEFT)
 // runs: their streams are still nine parts in ten VERTEX and LEFT, but in any order (VVLL, VLLV ...: two thirds of the symbols of a
@@ -921,186 +951,201 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // Two LDS round trips (symbols and links; then a lane's three x, whose addresses depend on nL_j).  Checked against the oracle on the
 // host model (tools/topo_run_model.py) before it was written here.
 #define TOPO_MIX_FACE32 \
-	"  v_mad_u32_u24 v59, v60, 12, %[fbyte]\n" \
+	"  v_mad_u32_u24 v59, v60, 12, %[c]\n" \
 	"  global_store_dwordx3 v59, v[32:34], %[faceb]\n"
 #define TOPO_MIX_FACE16 \
 	"  v_and_b32 v36, 0xffff, v32\n" \
 	"  v_lshl_or_b32 v36, v33, 16, v36\n" \
-	"  v_mad_u32_u24 v59, v60, 6, %[fbyte]\n" \
+	"  v_mad_u32_u24 v59, v60, 6, %[c]\n" \
 	"  global_store_dword v59, v36, %[faceb]\n" \
 	"  global_store_short v59, v34, %[faceb] offset:4\n"
-#define TOPO_MIX_STEP(FACE) \
-	asm volatile( \
-		"  s_mov_b64 %[sv], exec\n" \
-		"  s_mov_b64 exec, -1\n" \
-		"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
-		"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
-		"  v_add_u32 v40, %[cler], v60\n"                /* p = cler + j: the lane's symbol */ \
-		"  v_lshrrev_b32 v41, 3, v40\n" \
-		"  v_add_u32 v41, %[wb], v41\n" \
-		"  v_lshlrev_b32 v41, 2, v41\n" \
-		"  v_add_u32 v41, %[clbase], v41\n" \
-		"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
-		"  v_add_u32 v44, %[ep], v60\n" \
-		"  v_add_u32 v48, -1, v44\n" \
-		"  v_and_b32 v44, %[mask], v44\n"                /* slot ep+j */ \
-		"  v_and_b32 v48, %[mask], v48\n" \
-		"  v_lshlrev_b32 v45, 4, v44\n" \
-		"  v_lshlrev_b32 v48, 4, v48\n" \
-		"  ds_read_b32 v47, v45 offset:12\n"             /* w[j]: the links of slot ep+j */ \
-		"  ds_read_b32 v51, v48 offset:12\n"             /* w[j-1] */ \
-		"  v_and_b32 v53, 7, v40\n" \
-		"  v_lshlrev_b32 v53, 2, v53\n" \
-		"  s_waitcnt lgkmcnt(0)\n" \
-		"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
-		"  v_and_b32 v56, 15, v54\n" \
-		"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
-		"  v_cmp_eq_u32 %[vm], 0, v56\n"                 /* VERTEX */ \
-		"  v_cmp_eq_u32 %[lm], 1, v56\n"                 /* LEFT */ \
-		"  v_cmp_gt_u32 %[m0], %[kmax], v60\n" \
-		"  v_cmp_eq_u32 vcc, 0x10101010, v54\n"          /* a regular run from here on ... */ \
-		"  v_cmp_ne_u32 %[m1], 0, v60\n"                 /* ... (not for lane 0: the run step had its chance) */ \
-		"  s_nop 3\n" \
-		"  s_and_b64 vcc, vcc, %[m1]\n" \
-		"  s_or_b64 %[m1], %[vm], %[lm]\n" \
-		"  s_and_b64 %[m1], %[m1], %[m0]\n" \
-		"  s_andn2_b64 %[m1], %[m1], vcc\n"              /* the lanes that may join as far as their own symbol goes */ \
-		"  s_not_b64 %[m0], %[m1]\n" \
-		"  s_ff1_i32_b64 %[k], %[m0]\n"                  /* the first that may not (kmax < 64: there is one) */ \
-		"  s_cmp_eq_u32 %[k], 0\n" \
-		"  s_cbranch_scc1 Lmdone_%=\n" \
-		"  s_bfm_b64 %[m0], %[k], 0\n"                   /* lanes below it */ \
-		"  s_and_b64 %[vm], %[vm], %[m0]\n" \
-		"  s_and_b64 %[lm], %[lm], %[m0]\n" \
-		"  v_cmp_eq_u32 vcc, v57, v44\n"                 /* link(ep+j-1).prev == slot ep+j */ \
-		"  v_cmp_eq_u32 %[m1], 0, v60\n" \
-		"  s_nop 3\n" \
-		"  s_or_b64 vcc, vcc, %[m1]\n" \
-		"  v_cmp_ne_u32 %[m1], %[en], v44\n" \
-		"  s_nop 3\n" \
-		"  s_and_b64 vcc, vcc, %[m1]\n" \
-		"  s_not_b64 vcc, vcc\n" \
-		"  s_ff1_i32_b64 %[tl], vcc\n"                   /* C: chain slots ep .. ep+C-1 are usable (-1: all 64) */ \
-		"  s_mov_b64 vcc, %[vm]\n" \
-		"  s_nop 0\n" \
-		"  v_mbcnt_lo_u32_b32 v38, vcc_lo, 0\n" \
-		"  v_mbcnt_hi_u32_b32 v38, vcc_hi, v38\n"        /* nV_j */ \
-		"  s_mov_b64 vcc, %[lm]\n" \
-		"  s_nop 0\n" \
-		"  v_mbcnt_lo_u32_b32 v39, vcc_lo, 0\n" \
-		"  v_mbcnt_hi_u32_b32 v39, vcc_hi, v39\n"        /* nL_j */ \
-		"  v_cmp_le_u32 %[m1], %[tl], v39\n"             /* a LEFT here needs chain slot number nL_j */ \
-		"  v_cmp_le_u32 vcc, %[budget], v38\n"           /* a VERTEX here needs vertex id / ring slot number nV_j */ \
-		"  s_nop 3\n" \
-		"  s_and_b64 %[m1], %[m1], %[lm]\n" \
-		"  s_and_b64 vcc, vcc, %[vm]\n" \
-		"  s_or_b64 %[m1], %[m1], vcc\n" \
-		"  s_orn2_b64 %[m1], %[m1], %[m0]\n" \
-		"  s_ff1_i32_b64 %[k], %[m1]\n"                  /* k: the symbols of this step */ \
-		"  s_cmp_eq_u32 %[k], 0\n" \
-		"  s_cbranch_scc1 Lmdone_%=\n" \
-		"  s_bfm_b64 %[m0], %[k], 0\n" \
-		"  s_and_b64 %[vm], %[vm], %[m0]\n" \
-		"  s_and_b64 %[lm], %[lm], %[m0]\n" \
-		"  s_bcnt1_i32_b64 %[tv], %[vm]\n" \
-		"  s_bcnt1_i32_b64 %[tl], %[lm]\n" \
-		"  v_add_u32 v49, %[ep], v39\n"                  /* x[nL_j], x[nL_j - 1], x[nL_j - 2] */ \
-		"  v_add_u32 v50, -1, v49\n" \
-		"  v_add_u32 v52, -2, v49\n" \
-		"  v_and_b32 v49, %[mask], v49\n" \
-		"  v_and_b32 v50, %[mask], v50\n" \
-		"  v_and_b32 v52, %[mask], v52\n" \
-		"  v_lshlrev_b32 v49, 4, v49\n" \
-		"  v_lshlrev_b32 v50, 4, v50\n" \
-		"  v_lshlrev_b32 v52, 4, v52\n" \
-		"  ds_read_b32 v46, v49\n" \
-		"  ds_read_b32 v35, v50\n" \
-		"  ds_read_b32 v61, v52\n" \
-		"  v_add_u32 v34, %[vc], v38\n"                  /* vc + nV_j: the new vertex of a VERTEX lane */ \
-		"  v_add_u32 v32, -1, v34\n" \
-		"  v_add_u32 v36, -2, v34\n" \
-		"  v_mov_b32 v58, %[v1]\n" \
-		"  v_cmp_lt_u32 vcc, 0, v38\n" \
-		"  v_cndmask_b32 v32, v58, v32, vcc\n"           /* b_j */ \
-		"  v_cmp_lt_u32 vcc, 1, v38\n" \
-		"  v_cndmask_b32 v36, v58, v36, vcc\n"           /* c_j if symbol j-1 was a VERTEX */ \
-		"  v_mov_b32 v58, %[v0]\n" \
-		"  s_waitcnt lgkmcnt(0)\n" \
-		"  v_cmp_lt_u32 vcc, 0, v39\n" \
-		"  v_cndmask_b32 v33, v58, v35, vcc\n"           /* a_j */ \
-		"  v_cmp_lt_u32 vcc, 1, v39\n" \
-		"  v_cndmask_b32 v37, v58, v61, vcc\n"           /* c_j if symbol j-1 was a LEFT */ \
-		"  s_lshl_b64 vcc, %[vm], 1\n" \
-		"  s_nop 0\n" \
-		"  v_cndmask_b32 v37, v37, v36, vcc\n" \
-		"  v_mov_b32 v58, %[v2]\n" \
-		"  v_cmp_eq_u32 vcc, 0, v60\n" \
-		"  v_cndmask_b32 v37, v37, v58, vcc\n"           /* c_j */ \
-		"  v_cndmask_b32 v34, v46, v34, %[vm]\n"         /* opp_j */ \
-		"  s_max_u32 %[t], %[tl], 1\n" \
-		"  s_sub_u32 %[t], %[t], 1\n" \
-		"  s_nop 1\n" \
-		"  v_readlane_b32 %[swo], v54, %[k]\n"           /* the state after the step: lane k's */ \
-		"  v_readlane_b32 %[swno], v43, %[k]\n" \
-		"  v_readlane_b32 %[v0], v33, %[k]\n" \
-		"  v_readlane_b32 %[v1], v32, %[k]\n" \
-		"  v_readlane_b32 %[v2], v37, %[k]\n" \
-		"  v_readlane_b32 %[epn], v47, %[t]\n"           /* e.prev: the prev link of the last slot a LEFT closed */ \
-		"  s_and_b32 %[epn], %[epn], 0xffff\n" \
-		"  s_cmp_eq_u32 %[tl], 0\n" \
-		"  s_cselect_b32 %[epn], %[ep], %[epn]\n" \
-		"  s_mov_b64 exec, %[m0]\n"                      /* lanes 0 .. k-1 */ \
-		FACE \
-		"  s_mov_b64 exec, %[vm]\n"                      /* the VERTEX lanes */ \
-		"  v_mov_b32 v56, v32\n" \
-		"  v_mov_b32 v57, v33\n" \
-		"  v_mov_b32 v58, v37\n" \
-		"  v_mul_lo_u32 v62, v34, 12\n" \
-		"  v_add_u32 v40, %[nq], v38\n"                  /* the edge it queues: slot nq + nV_j */ \
-		"  v_add_u32 v53, 1, v40\n" \
-		"  v_add_u32 v55, -1, v40\n" \
-		"  v_and_b32 v41, %[mask], v40\n" \
-		"  v_and_b32 v53, %[mask], v53\n" \
-		"  v_and_b32 v55, %[mask], v55\n" \
-		"  global_store_dwordx3 v62, v[56:58], %[predb]\n" \
-		"  v_mov_b32 v42, %[en]\n" \
-		"  v_cmp_eq_u32 vcc, 0, v38\n" \
-		"  v_cndmask_b32 v55, v55, v42, vcc\n"           /* next: e.next for the first */ \
-		"  s_sub_u32 %[t], %[tv], 1\n" \
-		"  v_mov_b32 v42, 0xffff\n" \
-		"  v_cmp_eq_u32 vcc, %[t], v38\n" \
-		"  v_cndmask_b32 v53, v53, v42, vcc\n"           /* prev: lazy for the last */ \
-		"  v_lshl_or_b32 v47, v55, 16, v53\n" \
-		"  v_mov_b32 v44, v34\n" \
-		"  v_mov_b32 v45, v32\n" \
-		"  v_mov_b32 v46, v33\n" \
-		"  v_lshlrev_b32 v41, 4, v41\n" \
-		"  ds_write_b128 v41, v[44:47]\n" \
-		"  s_mov_b64 exec, %[lm]\n"                      /* the LEFT lanes: slot ep + nL_j is deleted */ \
-		"  v_mov_b32 v42, 0x8000\n" \
-		"  ds_write_b16 v49, v42 offset:10\n" \
-		"  s_mov_b64 exec, %[sv]\n" \
-		"  s_cmp_eq_u32 %[tv], 0\n" \
-		"  s_cbranch_scc1 Lmdone_%=\n" \
-		"  s_and_b32 vcc_lo, %[nq], %[mask]\n"           /* e.next.prev = the first new slot */ \
-		"  s_lshl_b32 vcc_hi, %[en], 4\n" \
-		"  v_mov_b32 v40, vcc_lo\n" \
-		"  v_mov_b32 v41, vcc_hi\n" \
-		"  ds_write_b16 v41, v40 offset:12\n" \
-		"  s_nop 1\n" \
-		"Lmdone_%=:\n" \
-		"  s_mov_b64 exec, %[sv]\n" \
-		: [k] "=&s"(mk_), [tv] "=&s"(mtv_), [tl] "=&s"(mtl_), [swo] "=&s"(mswo_), [swno] "=&s"(mswno_), [epn] "=&s"(mepn_), [t] "=&s"(mt_), \
-		  [sv] "=&s"(msv_), [m0] "=&s"(mm0_), [m1] "=&s"(mm1_), [vm] "=&s"(mvm_), [lm] "=&s"(mlm_), [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2) \
-		: [cler] "s"(cler), [wb] "s"(wbias - 1u), [clbase] "s"((uint32_t)(uintptr_t)cl32), [ep] "s"(ep), [en] "s"(en), [mask] "s"(MASK), \
-		  [kmax] "s"(mkmax_), [budget] "s"(budget_), [vc] "s"(vc), [nq] "s"(nq), \
-		  [fbyte] "s"(start*(U16 ? 2u : 4u)), [predb] "s"(predb), [faceb] "s"(faceb) \
-		: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
-		  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+#define TOPO_ASM_MIX(FACE, FSHIFT) \
+	"Lmix_%=:\n" \
+	"  s_cmp_gt_u32 %[ep], %[mask]\n"                 /* e.prev in the pool: one symbol at a time */ \
+	"  s_cbranch_scc1 Lmix0_%=\n" \
+	"  s_sub_u32 %[t3], %[end], %[start]\n"           /* kmax = min(63, faces the group and symbols the window hold) */ \
+	"  s_mul_hi_u32 %[t3], %[t3], 0xaaaaaaab\n" \
+	"  s_lshr_b32 %[t3], %[t3], 1\n" \
+	"  s_min_u32 %[t3], %[t3], 63\n" \
+	TOPO_ASM_WINDOW_LEFT \
+	"  s_min_u32 %[t3], %[t3], %[t2]\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
+	"  v_add_u32 v40, %[cler], v60\n"                /* p = cler + j: the lane's symbol */ \
+	"  v_lshrrev_b32 v41, 3, v40\n" \
+	"  v_add_u32 v41, %[wbias], v41\n" \
+	"  v_lshlrev_b32 v41, 2, v41\n" \
+	"  v_add_u32 v41, %[clbase], v41\n" \
+	"  v_add_u32 v41, -4, v41\n" \
+	"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
+	"  v_add_u32 v44, %[ep], v60\n" \
+	"  v_add_u32 v48, -1, v44\n" \
+	"  v_and_b32 v44, %[mask], v44\n"                /* slot ep+j */ \
+	"  v_and_b32 v48, %[mask], v48\n" \
+	"  v_lshlrev_b32 v45, 4, v44\n" \
+	"  v_lshlrev_b32 v48, 4, v48\n" \
+	"  ds_read_b32 v47, v45 offset:12\n"             /* w[j]: the links of slot ep+j */ \
+	"  ds_read_b32 v51, v48 offset:12\n"             /* w[j-1] */ \
+	"  v_and_b32 v53, 7, v40\n" \
+	"  v_lshlrev_b32 v53, 2, v53\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
+	"  v_and_b32 v56, 15, v54\n"                     /* v56: the lane's symbol */ \
+	"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
+	"  v_cmp_ne_u32 vcc, 0, v60\n" \
+	"  v_cndmask_b32 v35, 0, v54, vcc\n"             /* (lane 0 may be the head of a regular run: the run step had its chance) */ \
+	"  v_cmp_gt_u32 vcc, 2, v56\n"                   /* VERTEX or LEFT ... */ \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_gt_u32 vcc, %[t3], v60\n"               /* ... within kmax ... */ \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_ne_u32 vcc, 0x10101010, v35\n"          /* ... and no regular run from here on */ \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  s_not_b64 vcc, exec\n" \
+	"  s_ff1_i32_b64 %[t0], vcc\n"                   /* the first lane out as far as its own symbol goes (kmax < 64: there is one) */ \
+	"  s_mov_b64 exec, -1\n" \
+	"  s_cmp_eq_u32 %[t0], 0\n" \
+	"  s_cbranch_scc1 Lmix0_%=\n" \
+	"  v_cmp_gt_u32 vcc, %[t0], v60\n" \
+	"  v_cndmask_b32 v56, 15, v56, vcc\n"            /* (from it on: no symbol) */ \
+	"  v_cmp_eq_u32 vcc, 0, v60\n" \
+	"  v_cndmask_b32 v57, v57, v44, vcc\n"           /* (lane 0 has no link to check) */ \
+	"  v_cmp_eq_u32 vcc, v57, v44\n"                 /* link(ep+j-1).prev == slot ep+j */ \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_ne_u32 vcc, %[en], v44\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  s_not_b64 vcc, exec\n" \
+	"  s_ff1_i32_b64 %[t1], vcc\n"                   /* C: chain slots ep .. ep+C-1 are usable (-1: all 64) */ \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_cmp_eq_u32 vcc, 0, v56\n" \
+	"  s_nop 1\n"                                   /* (gfx90a+: a VALU write of an SGPR / vcc needs two wait states before a VALU reads it as an operand) */ \
+	"  v_mbcnt_lo_u32_b32 v38, vcc_lo, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v38, vcc_hi, v38\n"        /* nV_j */ \
+	"  v_mov_b32 v35, %[t1]\n" \
+	"  v_mov_b32 v36, %[budget]\n" \
+	"  v_cndmask_b32 v35, v35, v36, vcc\n"           /* what the lane's symbol is bounded by: chain slots (LEFT), vertex ids / ring slots (VERTEX) */ \
+	"  v_cmp_eq_u32 vcc, 1, v56\n" \
+	"  s_nop 1\n" \
+	"  v_mbcnt_lo_u32_b32 v39, vcc_lo, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v39, vcc_hi, v39\n"        /* nL_j */ \
+	"  v_cndmask_b32 v36, v38, v39, vcc\n"           /* ... and the number it would take */ \
+	"  v_cmp_gt_u32 vcc, 2, v56\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_lt_u32 vcc, v36, v35\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  s_not_b64 vcc, exec\n" \
+	"  s_ff1_i32_b64 %[t0], vcc\n"                   /* k: the symbols of this step */ \
+	"  s_mov_b64 exec, -1\n" \
+	"  s_cmp_eq_u32 %[t0], 0\n" \
+	"  s_cbranch_scc1 Lmix0_%=\n" \
+	"  v_add_u32 v49, %[ep], v39\n"                  /* x[nL_j], x[nL_j - 1], x[nL_j - 2] */ \
+	"  v_add_u32 v50, -1, v49\n" \
+	"  v_add_u32 v52, -2, v49\n" \
+	"  v_and_b32 v49, %[mask], v49\n" \
+	"  v_and_b32 v50, %[mask], v50\n" \
+	"  v_and_b32 v52, %[mask], v52\n" \
+	"  v_lshlrev_b32 v49, 4, v49\n" \
+	"  v_lshlrev_b32 v50, 4, v50\n" \
+	"  v_lshlrev_b32 v52, 4, v52\n" \
+	"  ds_read_b32 v46, v49\n" \
+	"  ds_read_b32 v35, v50\n" \
+	"  ds_read_b32 v61, v52\n" \
+	"  v_add_u32 v34, %[vc], v38\n"                  /* vc + nV_j: the new vertex of a VERTEX lane */ \
+	"  v_add_u32 v32, -1, v34\n" \
+	"  v_add_u32 v36, -2, v34\n" \
+	"  v_mov_b32 v58, %[v1]\n" \
+	"  v_cmp_lt_u32 vcc, 0, v38\n" \
+	"  v_cndmask_b32 v32, v58, v32, vcc\n"           /* b_j */ \
+	"  v_cmp_lt_u32 vcc, 1, v38\n" \
+	"  v_cndmask_b32 v36, v58, v36, vcc\n"           /* c_j if symbol j-1 was a VERTEX */ \
+	"  v_mov_b32 v58, %[v0]\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_cmp_lt_u32 vcc, 0, v39\n" \
+	"  v_cndmask_b32 v33, v58, v35, vcc\n"           /* a_j */ \
+	"  v_cmp_lt_u32 vcc, 1, v39\n" \
+	"  v_cndmask_b32 v37, v58, v61, vcc\n"           /* c_j if symbol j-1 was a LEFT */ \
+	"  v_cmp_eq_u32 vcc, 0, v56\n" \
+	"  v_cndmask_b32 v34, v46, v34, vcc\n"           /* opp_j */ \
+	"  s_lshl_b64 vcc, vcc, 1\n"                     /* lane j: symbol j-1 was a VERTEX */ \
+	"  v_cndmask_b32 v37, v37, v36, vcc\n" \
+	"  v_mov_b32 v58, %[v2]\n" \
+	"  v_cmp_eq_u32 vcc, 0, v60\n" \
+	"  v_cndmask_b32 v37, v37, v58, vcc\n"           /* c_j */ \
+	"  v_readlane_b32 %[t1], v38, %[t0]\n"           /* VERTEXes and LEFTs of the step: lane k's counts */ \
+	"  v_readlane_b32 %[t2], v39, %[t0]\n" \
+	"  v_readlane_b32 %[sw], v54, %[t0]\n"           /* the state after the step: lane k's */ \
+	"  v_readlane_b32 %[swn], v43, %[t0]\n" \
+	"  v_readlane_b32 %[v0], v33, %[t0]\n" \
+	"  v_readlane_b32 %[v1], v32, %[t0]\n" \
+	"  v_readlane_b32 %[v2], v37, %[t0]\n" \
+	"  s_max_u32 %[t3], %[t2], 1\n" \
+	"  s_sub_u32 %[t3], %[t3], 1\n" \
+	"  v_readlane_b32 %[c], v47, %[t3]\n"            /* e.prev: the prev link of the last slot a LEFT closed */ \
+	"  s_and_b32 %[c], %[c], 0xffff\n" \
+	"  s_cmp_eq_u32 %[t2], 0\n" \
+	"  s_cselect_b32 %[ep], %[ep], %[c]\n" \
+	"  s_lshl_b32 %[c], %[start], " FSHIFT "\n"      /* byte offset of the step's first index */ \
+	"  s_bfm_b64 exec, %[t0], 0\n"                   /* lanes 0 .. k-1 */ \
+	FACE \
+	"  v_cmp_eq_u32 vcc, 0, v56\n" \
+	"  s_and_b64 exec, exec, vcc\n"                  /* the VERTEX lanes */ \
+	"  v_mov_b32 v50, v32\n" \
+	"  v_mov_b32 v51, v33\n" \
+	"  v_mov_b32 v52, v37\n" \
+	"  v_mul_lo_u32 v62, v34, 12\n" \
+	"  v_add_u32 v40, %[nq], v38\n"                  /* the edge it queues: slot nq + nV_j */ \
+	"  v_add_u32 v53, 1, v40\n" \
+	"  v_add_u32 v55, -1, v40\n" \
+	"  v_and_b32 v41, %[mask], v40\n" \
+	"  v_and_b32 v53, %[mask], v53\n" \
+	"  v_and_b32 v55, %[mask], v55\n" \
+	"  global_store_dwordx3 v62, v[50:52], %[predb]\n" \
+	"  v_mov_b32 v42, %[en]\n" \
+	"  v_cmp_eq_u32 vcc, 0, v38\n" \
+	"  v_cndmask_b32 v55, v55, v42, vcc\n"           /* next: e.next for the first */ \
+	"  s_sub_u32 %[t3], %[t1], 1\n" \
+	"  v_mov_b32 v42, 0xffff\n" \
+	"  v_cmp_eq_u32 vcc, %[t3], v38\n" \
+	"  v_cndmask_b32 v53, v53, v42, vcc\n"           /* prev: lazy for the last */ \
+	"  v_lshl_or_b32 v47, v55, 16, v53\n" \
+	"  v_mov_b32 v44, v34\n" \
+	"  v_mov_b32 v45, v32\n" \
+	"  v_mov_b32 v46, v33\n" \
+	"  v_lshlrev_b32 v41, 4, v41\n" \
+	"  ds_write_b128 v41, v[44:47]\n" \
+	"  s_bfm_b64 exec, %[t0], 0\n" \
+	"  v_cmp_eq_u32 vcc, 1, v56\n" \
+	"  s_and_b64 exec, exec, vcc\n"                  /* the LEFT lanes: slot ep + nL_j is deleted */ \
+	"  v_mov_b32 v42, 0x8000\n" \
+	"  ds_write_b16 v49, v42 offset:10\n" \
+	"  s_mov_b64 exec, 1\n" \
+	"  s_cmp_eq_u32 %[t1], 0\n" \
+	"  s_cbranch_scc1 Lmixnov_%=\n" \
+	"  s_and_b32 %[t3], %[nq], %[mask]\n"            /* e.next.prev = the first new slot */ \
+	"  s_lshl_b32 %[c], %[en], 4\n" \
+	"  v_mov_b32 v40, %[t3]\n" \
+	"  v_mov_b32 v41, %[c]\n" \
+	"  ds_write_b16 v41, v40 offset:12\n" \
+	"  s_add_u32 %[nq], %[nq], %[t1]\n" \
+	"  s_sub_u32 %[c], %[nq], 1\n" \
+	"  s_and_b32 %[en], %[c], %[mask]\n"             /* e.next: the last edge queued */ \
+	"  s_add_u32 %[vc], %[vc], %[t1]\n" \
+	"  s_sub_u32 %[budget], %[budget], %[t1]\n" \
+	"Lmixnov_%=:\n" \
+	"  s_mov_b32 %[nc], -1\n"                        /* (every record is in LDS: a RIGHT reads e.next's) */ \
+	"  s_mul_i32 %[c], %[t0], 3\n" \
+	"  s_add_u32 %[start], %[start], %[c]\n" \
+	"  s_add_u32 %[cler], %[cler], %[t0]\n" \
+	"  s_branch Lstepped_%=\n" \
+	"Lmix0_%=:\n"                                    /* nothing done: the symbol goes the one-at-a-time way */ \
+	"  s_mov_b64 exec, 1\n" \
+	"  s_and_b32 %[c], %[sw], 15\n" \
+	"  s_cbranch_scc0 Lvgo_%=\n" \
+	"  s_branch Llgo_%=\n"
 
 // -DCORTO_TOPO_STAMPS (CORTO_BUILD_DEFINES=CORTO_TOPO_STAMPS python -m corto_amd.build --force; tools/topo_stamp_probe.py): where the
 // automaton's time goes - shader clocks (s_memtime), steps and symbols per phase of workgroups 0..4095, read back with
-// crthip_debug_topo_stamps.  Phases: 0 ISA block, 1 run step, 2 mix step, 3 C++ symbol, 4 gate fetch, 5 prologue; [15] = all of it.
+// crthip_debug_topo_stamps.  Phases: 0 ISA block (run and mix steps included), 3 C++ symbol, 4 gate fetch, 5 prologue; [15] = all of it.
 #ifdef CORTO_TOPO_STAMPS
 __device__ uint32_t g_topo_stamps[48*4096];
 #define TOPO_CLK() ((uint32_t)__builtin_amdgcn_s_memtime())
@@ -1274,49 +1319,17 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						// neighbour, ~40 instructions per symbol where the compiler's dispatch of the C++ below spends ~68
 						// (scalar copies at every join).  The block PEEKS at the next symbol and leaves with the state
 						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
-						// or ring running out, the group's last face - which the C++ below then handles.
+						// or ring running out, the group's last face - which the C++ below then handles.  The run step and the mix step (the
+						// whole wave on up to 126 / 63 symbols at once, TOPO_ASM_RUN / TOPO_ASM_MIX above) are sections of the block.
 						uint32_t t0_, t1_, t2_, t3_, c_;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
 						{ TOPO_T0();
-						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32); }
+						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16, TOPO_RUN_FACE16, TOPO_MIX_FACE16, "1"); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32, TOPO_RUN_FACE32, TOPO_MIX_FACE32, "2"); }
 						TOPO_ACC(0); }
 						if(start >= end) break;
 						if(c_ == 0x200u) break;                                   // the block ended the chain (BOUNDARY / DELAY) and found no gate to go on with
-						if(c_ == 0x100u && ep <= MASK) {
-							// (VERTEX LEFT)^k ahead: up to 63 pairs in one pass of the whole wave (TOPO_RUN_STEP above).  Bounded by the
-							// vertex ids and ring slots left, the group's faces and the symbols in the LDS window.
-							uint32_t rk_, rkm1_, rswo_, rswno_, rxl_, rwl_, ral_, rbl_, rm0s_;
-							uint64_t rsv_, rm0_, rm1_;
-							const uint32_t rkmax_ = TOPO_S(min(min(budget_, 63u), min((end - start)/6u, (winbase + SYMW - cler) >> 1)));
-							TOPO_T0();
-							if constexpr(U16) { TOPO_RUN_STEP(TOPO_RUN_FACE16); } else { TOPO_RUN_STEP(TOPO_RUN_FACE32); }
-							if(rk_) {
-								nc_next = rk_ == 1 ? en : (nq + rk_ - 2u) & MASK;
-								v0 = rxl_; v2 = ral_; nc_v1 = rbl_; ep = rwl_ & 0xFFFFu;
-								v1 = vc + rk_ - 1u; en = (nq + rk_ - 1u) & MASK; nc = en;
-								vc += rk_; nq += rk_; start += 6u*rk_; cler += 2u*rk_; sw = rswo_; swn = rswno_;
-								TOPO_ACC(1);
-								if(start >= end) break;
-								continue;
-							}
-						}
-						if(c_ == 0x300u && ep <= MASK) {
-							// VERTEXes and LEFTs in any order ahead: up to 63 symbols in one pass of the whole wave (TOPO_MIX_STEP above)
-							uint32_t mk_, mtv_, mtl_, mswo_, mswno_, mepn_, mt_;
-							uint64_t msv_, mm0_, mm1_, mvm_, mlm_;
-							const uint32_t mkmax_ = TOPO_S(min(min(63u, (end - start)/3u), winbase + SYMW - cler));
-							TOPO_T0();
-							if constexpr(U16) { TOPO_MIX_STEP(TOPO_MIX_FACE16); } else { TOPO_MIX_STEP(TOPO_MIX_FACE32); }
-							if(!mk_) TOPO_ACC(2);
-							if(mk_) {
-								if(mtv_) en = (nq + mtv_ - 1u) & MASK;
-								ep = mepn_; nc = 0xFFFFFFFFu;                             // (every record is in LDS: a RIGHT reads e.next's)
-								vc += mtv_; nq += mtv_; start += 3u*mk_; cler += mk_; sw = mswo_; swn = mswno_;
-								TOPO_ACC(2);
-								if(start >= end) break;
-								continue;
-							}
-						}
+						// (anything else: the next symbol is one the block leaves to the C++ below - or it wants the window slid first, which
+						// the top of this loop does after that symbol)
 					}
 					TOPO_T0();
 					uint32_t c; TOPO_SYMBOL(c);
