@@ -1,5 +1,5 @@
 """Where the CLERS automaton's time goes (k_topology_lds): needs the library built with CORTO_BUILD_DEFINES=CORTO_TOPO_STAMPS
-(python -m corto_amd.build --force).  Shader clocks, steps and symbols per phase, averaged over the 256 blobs of a batch;
+(python -m corto_amd.build --force).  Shader clocks, entries and symbols per phase (the ISA block with its run and mix steps, the C++ symbols, the gate fetch), averaged over the 256 blobs of a batch;
 $FLIP > 0 takes the irregular blobs (bumpy_sphere_flipped)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -18,12 +18,13 @@ out = np.zeros(48*4096, dtype=np.uint32)
 L = ca.lib(); L.crthip_debug_topo_stamps.argtypes = [C.c_void_p]
 print("rc", L.crthip_debug_topo_stamps(out.ctypes.data_as(C.c_void_p)))
 o = out.reshape(4096, 48)[:256].astype(np.float64)
-names = ["ISA block", "run step", "mix step", "C++ symbol", "gate fetch", "prologue"]
+names = ["ISA block", None, None, "C++ symbol", "gate fetch", "prologue"]   # (1, 2: the run and mix steps when they were asm statements of their own; sections of the block now)
 tot = o[:, 15]
 print("flip %.2f  total clocks: mean %.0f  max %.0f  (blob %d)" % (flip, tot.mean(), tot.max(), int(tot.argmax())))
 for i, n in enumerate(names):
+    if n is None: continue
     clk, cnt, sym = o[:, i].mean(), o[:, 8 + i].mean(), o[:, 16 + i].mean()
     print("  %-11s clocks %8.0f (%4.1f %%)  steps %7.1f  symbols %7.1f  clocks/step %7.1f  clocks/symbol %7.1f" % (n, clk, 100*clk/tot.mean(), cnt, sym, clk/max(cnt, 1), clk/max(sym, 1)))
 print("  unaccounted %.1f %%" % (100*(1 - o[:, :6].sum(axis=1).mean()/tot.mean())))
 w = int(tot.argmax())
-print("  slowest blob:", {n: (int(o[w, i]), int(o[w, 8 + i]), int(o[w, 16 + i])) for i, n in enumerate(names)})
+print("  slowest blob:", {n: (int(o[w, i]), int(o[w, 8 + i]), int(o[w, 16 + i])) for i, n in enumerate(names) if n})
