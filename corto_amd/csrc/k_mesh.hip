@@ -502,6 +502,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_sub_u32 %[t2], %[nq], %[qpos]\n"   /* queued entries */ \
 							"  s_cmp_eq_u32 %[t2], 0\n" \
 							"  s_cbranch_scc1 Ldpop_%=\n" \
+							"  s_and_b32 %[t0], %[sw], 0xee\n"       /* the gate about to be popped is ended at once, and the one after it too (BOUNDARY 4 / DELAY 5 twice): the */ \
+							"  s_cmp_eq_u32 %[t0], 0x44\n"           /* chain-end step (TOPO_ASM_ENDS) - it costs what two ends cost one at a time, so a single pair goes the old way */ \
+							"  s_cbranch_scc1 Lends_%=\n" \
+							"Lpop1_%=:\n" \
 							"  s_mov_b64 exec, -1\n" \
 							"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
 							"  v_mbcnt_hi_u32_b32 v60, -1, v60\n" \
@@ -651,6 +655,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Llgo_%=\n" \
 							TOPO_ASM_MIX(MIXFACE, FSHIFT) \
 							TOPO_ASM_RUN(RUNFACE, FSHIFT) \
+							TOPO_ASM_ENDS \
 							   /* ---------------- after a step: the group may be done, the window may want sliding (both the C++'s business), else the next symbol */ \
 							"Lstepped_%=:\n" \
 							"  s_mov_b32 %[c], 0\n" \
@@ -1143,6 +1148,202 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_cbranch_scc0 Lvgo_%=\n" \
 	"  s_branch Llgo_%=\n"
 
+// The chain-end step.  BOUNDARY and DELAY end a chain: the current edge survives (it moves to a pool slot, its neighbours' links follow),
+// and the next live gate is popped from the ring - ~70 dependent scalar instructions and two LDS round trips, ~1 000 clocks, and half of a
+// regular blob's automaton (222 chain ends) or two thirds of a holey disc's (1 935).  They come in runs (BB, DDDD, DB: 188 of the regular
+// blob's 222, 1 637 of the disc's 1 935): the gate just popped is ended by the next symbol at once.  Nothing in such a run depends on the one
+// before except through the links of neighbouring gates, so after the current edge has been dealt with the usual way and the NEXT symbol is a
+// BOUNDARY / DELAY too, the whole wave looks at the next 64 queue entries (as the pop does anyway): the r-th live one is ended by the r-th
+// symbol - lane = queue entry, r = its rank among the live ones (v_mbcnt) - as long as symbols are BOUNDARY / DELAY, a further live gate is in
+// sight (the last one popped becomes the current edge), and the pool / DELAY stack have room.  A moving lane takes pool slot number r (free
+// list from the top, then the bump pointer), leaves a forwarding mark (0xF0000000 | new slot; vertex ids have 30 bits) in its ring record's
+// first word, and every lane follows the marks of its two neighbours: a neighbour that moves in the same step is addressed at its new slot
+// (and writes its own link), any other gets its link rewritten as the one-at-a-time code does.  DELAYs set their flag and push their slot at
+// (stack fill + DELAYs in front of them).  Checked against the oracle on the host model first (tools/topo_run_model.py).
+#define TOPO_ASM_ENDS \
+	"Lends_%=:\n"                                     /* t2 = queued entries (not 0) */ \
+	"  s_min_u32 %[t2], %[t2], 64\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_mbcnt_lo_u32_b32 v60, -1, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = lane */ \
+	"  v_add_u32 v40, %[cler], v60\n"                /* lane j: symbol cler + j */ \
+	"  v_lshrrev_b32 v41, 3, v40\n" \
+	"  v_add_u32 v41, %[wbias], v41\n" \
+	"  v_lshlrev_b32 v41, 2, v41\n" \
+	"  v_add_u32 v41, %[clbase], v41\n" \
+	"  v_add_u32 v41, -4, v41\n" \
+	"  ds_read2_b32 v[42:43], v41 offset1:1\n" \
+	"  v_add_u32 v61, %[qpos], v60\n"                /* lane i: queue entry qpos + i */ \
+	"  v_and_b32 v61, %[mask], v61\n" \
+	"  v_lshlrev_b32 v61, 4, v61\n" \
+	"  v_mov_b32 v58, -1\n"                          /* (entries past the queue's end: dead) */ \
+	"  v_cmp_gt_u32 vcc, %[t2], v60\n" \
+	"  s_mov_b64 exec, vcc\n" \
+	"  ds_read_b128 v[56:59], v61\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_and_b32 v53, 7, v40\n" \
+	"  v_lshlrev_b32 v53, 2, v53\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from the lane's on */ \
+	"  v_and_b32 v44, 14, v54\n" \
+	"  v_cmp_ne_u32 vcc, 4, v44\n"                   /* not BOUNDARY (4) / DELAY (5) */ \
+	"  s_ff1_i32_b64 %[t1], vcc\n"                   /* nb: chain-end symbols in a row (-1: 64) */ \
+	"  s_min_u32 %[t1], %[t1], 62\n" \
+	"  v_cmp_gt_i32 vcc, v58, -1\n"                  /* live entries (TOPO_DEAD is the sign bit) */ \
+	"  s_bcnt1_i32_b64 %[t0], vcc\n" \
+	"  s_cmp_lt_u32 %[t0], 2\n"                      /* fewer than two live gates in sight: the one-gate way */ \
+	"  s_cbranch_scc1 Lends0_%=\n" \
+	"  v_mov_b32 v37, 1\n" \
+	"  v_cndmask_b32 v39, 0, v37, vcc\n"             /* v39: live */ \
+	"  v_mbcnt_lo_u32_b32 v38, vcc_lo, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v38, vcc_hi, v38\n"        /* v38: rank among the live entries */ \
+	"  s_sub_u32 %[t0], %[t0], 1\n" \
+	"  s_min_u32 %[t0], %[t0], %[t1]\n"              /* k = min(symbols, live gates - 1, pool room, DELAY room) */ \
+	"  s_lshr_b32 %[t1], %[pk1], 16\n"               /* free-list fill */ \
+	"  s_and_b32 %[t3], %[pk1], 0xffff\n"            /* bump pointer */ \
+	"  s_add_u32 %[c], %[mask], 1\n" \
+	"  s_lshl_b32 %[c], %[c], 1\n" \
+	"  s_sub_u32 %[c], %[c], %[t3]\n" \
+	"  s_add_u32 %[c], %[c], %[t1]\n" \
+	"  s_min_u32 %[t0], %[t0], %[c]\n" \
+	"  s_lshr_b32 %[c], %[pk2], 16\n" \
+	"  s_and_b32 %[t2], %[pk2], 0xffff\n"            /* DELAY stack fill */ \
+	"  s_sub_u32 %[c], %[c], %[t2]\n" \
+	"  s_min_u32 %[t0], %[t0], %[c]\n" \
+	"  s_cmp_eq_u32 %[t0], 0\n" \
+	"  s_cbranch_scc1 Lends0_%=\n" \
+	"  v_and_b32 v44, 15, v54\n"                     /* the symbol lanes: symbol | DELAYs in front of it << 8 */ \
+	"  s_bfm_b64 exec, %[t0], 0\n" \
+	"  v_cmp_eq_u32 vcc, 5, v44\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  s_nop 1\n" \
+	"  v_mbcnt_lo_u32_b32 v45, vcc_lo, 0\n" \
+	"  v_mbcnt_hi_u32_b32 v45, vcc_hi, v45\n" \
+	"  v_lshl_or_b32 v45, v45, 8, v44\n" \
+	"  v_lshlrev_b32 v46, 2, v38\n" \
+	"  ds_bpermute_b32 v46, v46, v45\n"              /* v46: the symbol that ends the lane's gate (lane rank's) */ \
+	"  v_cmp_gt_u32 vcc, %[t1], v38\n"               /* rank < free-list fill: slot freel[fill - 1 - rank] */ \
+	"  v_sub_u32 v47, %[t1], v38\n" \
+	"  v_add_u32 v47, -1, v47\n" \
+	"  v_lshlrev_b32 v47, 1, v47\n" \
+	"  s_add_u32 %[c], %[mask], 1\n" \
+	"  s_lshl_b32 %[c], %[c], 5\n" \
+	"  v_add_u32 v47, %[c], v47\n" \
+	"  s_mov_b64 exec, vcc\n" \
+	"  ds_read_u16 v47, v47\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_add_u32 v48, %[t3], v38\n"                  /* else bump + rank - fill */ \
+	"  v_subrev_u32 v48, %[t1], v48\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_cndmask_b32 v47, v48, v47, vcc\n"           /* v47: the lane's pool slot */ \
+	"  v_cmp_ne_u32 vcc, 0, v39\n" \
+	"  s_mov_b64 exec, vcc\n"                        /* live lanes ... */ \
+	"  v_cmp_gt_u32 vcc, %[t0], v38\n" \
+	"  s_mov_b64 exec, vcc\n"                        /* ... that move (rank < k): the forwarding mark */ \
+	"  v_or_b32 v50, 0xf0000000, v47\n" \
+	"  ds_write_b32 v61, v50\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  s_add_u32 %[c], %[mask], 1\n" \
+	"  s_lshl_b32 %[c], %[c], 1\n" \
+	"  s_sub_u32 %[c], %[c], 1\n"                    /* (links are slot ids below ring + pool; a lazy 0xffff is clamped) */ \
+	"  v_and_b32 v48, 0xffff, v59\n" \
+	"  v_lshrrev_b32 v49, 16, v59\n" \
+	"  v_min_u32 v50, %[c], v48\n" \
+	"  v_min_u32 v51, %[c], v49\n" \
+	"  v_lshlrev_b32 v50, 4, v50\n" \
+	"  v_lshlrev_b32 v51, 4, v51\n" \
+	"  ds_read_b32 v50, v50\n" \
+	"  ds_read_b32 v51, v51\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_lshrrev_b32 v52, 28, v50\n" \
+	"  v_cmp_eq_u32 vcc, 15, v52\n" \
+	"  v_and_b32 v52, 0xffff, v50\n" \
+	"  v_cndmask_b32 v52, v48, v52, vcc\n"           /* v52: prev, forwarded */ \
+	"  v_cndmask_b32 v35, 0, v37, vcc\n"             /* v35: no write to prev's record: it moves too ... */ \
+	"  v_cmp_lt_u32 vcc, %[c], v48\n" \
+	"  v_cndmask_b32 v35, v35, v37, vcc\n"           /* ... or the link is no slot (a lazy 0xffff: kept as it is, like the one-at-a-time code's out-of-range write) */ \
+	"  v_cndmask_b32 v52, v52, v48, vcc\n" \
+	"  v_lshrrev_b32 v53, 28, v51\n" \
+	"  v_cmp_eq_u32 vcc, 15, v53\n" \
+	"  v_and_b32 v53, 0xffff, v51\n" \
+	"  v_cndmask_b32 v53, v49, v53, vcc\n"           /* v53: next, forwarded */ \
+	"  v_cndmask_b32 v36, 0, v37, vcc\n" \
+	"  v_cmp_lt_u32 vcc, %[c], v49\n" \
+	"  v_cndmask_b32 v36, v36, v37, vcc\n" \
+	"  v_cndmask_b32 v53, v53, v49, vcc\n" \
+	"  v_cmp_ne_u32 vcc, 0, v39\n" \
+	"  s_mov_b64 exec, vcc\n" \
+	"  v_cmp_eq_u32 vcc, %[t0], v38\n"               /* the live entry of rank k: the next current edge */ \
+	"  s_ff1_i32_b64 %[t1], vcc\n" \
+	"  v_cmp_gt_u32 vcc, %[t0], v38\n" \
+	"  s_mov_b64 exec, vcc\n"                        /* the movers: their records in the pool */ \
+	"  v_mov_b32 v34, 0\n"                           /* (and the mark wiped: a stale link that found it in a later step would be forwarded into a live record) */ \
+	"  ds_write_b32 v61, v34\n" \
+	"  v_and_b32 v34, 15, v46\n" \
+	"  v_and_b32 v58, 0x3fffffff, v58\n" \
+	"  v_or_b32 v33, 0x40000000, v58\n"              /* TOPO_DELAYED */ \
+	"  v_cmp_eq_u32 vcc, 5, v34\n" \
+	"  v_cndmask_b32 v58, v58, v33, vcc\n" \
+	"  v_lshl_or_b32 v59, v53, 16, v52\n" \
+	"  v_lshlrev_b32 v32, 4, v47\n" \
+	"  ds_write_b128 v32, v[56:59]\n" \
+	"  v_lshrrev_b32 v33, 8, v46\n"                  /* a DELAY's place on the stack */ \
+	"  v_add_u32 v33, %[t2], v33\n" \
+	"  v_lshlrev_b32 v33, 1, v33\n" \
+	"  s_add_u32 %[c], %[mask], 1\n" \
+	"  s_mul_i32 %[c], %[c], 34\n" \
+	"  v_add_u32 v33, %[c], v33\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  ds_write_b16 v33, v47\n" \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_cmp_ne_u32 vcc, 0, v39\n"                   /* the neighbours that stay where they are: their links */ \
+	"  s_mov_b64 exec, vcc\n" \
+	"  v_cmp_gt_u32 vcc, %[t0], v38\n" \
+	"  s_mov_b64 exec, vcc\n" \
+	"  v_cmp_eq_u32 vcc, 0, v35\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_lshlrev_b32 v32, 4, v52\n" \
+	"  ds_write_b16 v32, v47 offset:14\n"            /* front[prev].next = slot */ \
+	"  s_mov_b64 exec, -1\n" \
+	"  v_cmp_ne_u32 vcc, 0, v39\n" \
+	"  s_mov_b64 exec, vcc\n" \
+	"  v_cmp_gt_u32 vcc, %[t0], v38\n" \
+	"  s_mov_b64 exec, vcc\n" \
+	"  v_cmp_eq_u32 vcc, 0, v36\n" \
+	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_lshlrev_b32 v32, 4, v53\n" \
+	"  ds_write_b16 v32, v47 offset:12\n"            /* front[next].prev = slot */ \
+	"  s_mov_b64 exec, 1\n" \
+	"  v_readlane_b32 %[v0], v56, %[t1]\n"           /* the next current edge */ \
+	"  v_readlane_b32 %[v1], v57, %[t1]\n" \
+	"  v_readlane_b32 %[v2], v58, %[t1]\n" \
+	"  v_readlane_b32 %[ep], v52, %[t1]\n" \
+	"  v_readlane_b32 %[en], v53, %[t1]\n" \
+	"  v_readlane_b32 %[c], v45, %[t0]\n"            /* DELAYs of the step (lane k's count) */ \
+	"  v_readlane_b32 %[sw], v54, %[t0]\n" \
+	"  v_readlane_b32 %[swn], v43, %[t0]\n" \
+	"  s_and_b32 %[v2], %[v2], 0x3fffffff\n" \
+	"  s_add_u32 %[qpos], %[qpos], %[t1]\n" \
+	"  s_add_u32 %[qpos], %[qpos], 1\n" \
+	"  s_lshr_b32 %[c], %[c], 8\n" \
+	"  s_add_u32 %[pk2], %[pk2], %[c]\n" \
+	"  s_lshr_b32 %[t1], %[pk1], 16\n" \
+	"  s_min_u32 %[t1], %[t1], %[t0]\n"              /* slots taken from the free list; the rest from the bump pointer */ \
+	"  s_sub_u32 %[c], %[t0], %[t1]\n" \
+	"  s_add_u32 %[pk1], %[pk1], %[c]\n" \
+	"  s_lshl_b32 %[t1], %[t1], 16\n" \
+	"  s_sub_u32 %[pk1], %[pk1], %[t1]\n" \
+	"  s_add_u32 %[cler], %[cler], %[t0]\n" \
+	"  s_mov_b32 %[nc], -1\n" \
+	"  s_mov_b32 %[c], 0\n" \
+	"  s_cmp_ge_u32 %[cler], %[slideat]\n" \
+	"  s_cbranch_scc1 Lexit_%=\n" \
+	"  s_branch Ltop_%=\n" \
+	"Lends0_%=:\n" \
+	"  s_mov_b64 exec, 1\n" \
+	"  s_sub_u32 %[t2], %[nq], %[qpos]\n" \
+	"  s_branch Lpop1_%=\n"
+
 // -DCORTO_TOPO_STAMPS (CORTO_BUILD_DEFINES=CORTO_TOPO_STAMPS python -m corto_amd.build --force; tools/topo_stamp_probe.py): where the
 // automaton's time goes - shader clocks (s_memtime), steps and symbols per phase of workgroups 0..4095, read back with
 // crthip_debug_topo_stamps.  Phases: 0 ISA block (run and mix steps included), 3 C++ symbol, 4 gate fetch, 5 prologue; [15] = all of it.
@@ -1415,7 +1616,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	if(blockIdx.x < 4096) {
 		uint32_t *o_ = g_topo_stamps + blockIdx.x*48;
 		for(int i = 0; i < 6; i++) { o_[i] = st_clk[i]; o_[8 + i] = st_cnt[i]; o_[16 + i] = st_sym[i]; }
-		o_[15] = TOPO_CLK() - st_begin; o_[24] = cler; o_[25] = err;
+		o_[15] = TOPO_CLK() - st_begin; o_[24] = cler; o_[25] = err; o_[26] = nq; o_[27] = qpos; o_[28] = vc; o_[29] = start; o_[30] = RING; o_[31] = pk1; o_[32] = pk2; o_[33] = dcap;
 	}
 #endif
 	if(err == 2) return false;

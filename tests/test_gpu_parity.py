@@ -164,6 +164,27 @@ def test_irregular_connectivity_batch(ctx):
         b.close()
 
 
+def test_chain_end_runs_stay_in_lds(ctx):
+    """BOUNDARY / DELAY runs are the automaton's chain-end step (the next live gates of the ring each moved to the pool by its own lane,
+    links patched through forwarding marks): meshes full of them - discs with holes, ribbons, several groups, open grids - decode byte
+    for byte AND without the HBM redo (a wrong front that only runs out of slots falls back and still decodes right: the counter is the test)"""
+    from corto_amd import synth
+    meshes = [synth.holey_disc(40, seed=s) for s in range(12)] + [synth.holey_disc(24, seed=50 + s, hole_frac=0.05 + 0.03 * s) for s in range(6)]
+    meshes += [synth.strip(200 + 37 * s, seed=s) for s in range(4)] + [synth.bumpy_sphere(64, 32, seed=s) for s in range(4)]
+    blobs = [ca.encode(m, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER if k % 2 else ca.ESTIMATED) for k, m in enumerate(meshes)]
+    blobs += [load_golden(n)["crt"] for n in ("group_props", "two_groups", "multi_component", "holey_disc")]
+    c = ca.Context(0)
+    run_batch(c, blobs).close()                    # (a fresh context may plan too few slots for a disc full of holes: the first batch teaches it)
+    for u16 in (False, True):
+        b = run_batch(c, blobs, index16=u16, color_components=4)
+        for i, blob in enumerate(blobs):
+            r = oc.decode(blob, index16=u16, color_components=4)
+            assert_same(b.host_outputs(i), r, KEYS, "chain ends %d u16=%s" % (i, u16))
+        assert b.stats().topology_fallbacks == 0
+        b.close()
+    c.close()
+
+
 def test_single_stream_context_decodes_the_same(ctx):
     """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
     the hardware queues) - same bytes as the two-stream schedule"""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host model of k_topology_lds's data structure (ring of queued edges + pool of survivors + lazy current edge) with the
-(VERTEX LEFT)^k run step and the VERTEX / LEFT mix step done "in parallel" - the formulations the kernel uses (k_mesh.hip:
-TOPO_RUN_STEP, TOPO_MIX_STEP), checked here
+(VERTEX LEFT)^k run step, the VERTEX / LEFT mix step and the BOUNDARY / DELAY chain-end step done "in parallel" - the formulations
+the kernel uses (k_mesh.hip: TOPO_ASM_RUN, TOPO_ASM_MIX, TOPO_ASM_ENDS), checked here
 against the oracle's faces and prediction triples before it is written in ISA.  Development aid: not a product path and
 not a test (tests/ compare the real kernel with the oracle)."""
 import sys, os
@@ -13,7 +13,7 @@ LAZY = 0xFFFF
 
 
 class Model:
-    def __init__(self, clers, nvert, nface, group_end, ring=1 << 12, pool=1 << 12, use_runs=True, use_mix=True, ref_faces=None):
+    def __init__(self, clers, nvert, nface, group_end, ring=1 << 12, pool=1 << 12, use_runs=True, use_mix=True, use_ends=True, ref_faces=None):
         self.cl = list(clers) + [15] * 64
         self.nvert, self.nface = nvert, nface
         self.RING, self.MASK, self.POOL = ring, ring - 1, pool
@@ -22,10 +22,11 @@ class Model:
         self.pred = np.zeros((nvert, 3), dtype=np.int64)
         self.use_runs = use_runs
         self.use_mix = use_mix
+        self.use_ends = use_ends
         self.any_align = os.environ.get('MIX_ANY_ALIGN', '0') == '1'   # experiment: a trigger that peeks into the next window word too (more one-symbol steps: not taken)
         self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
         self.group_end = group_end
-        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0, mixes=0, mix_symbols=0, mix_hist={})
+        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0, mixes=0, mix_symbols=0, mix_hist={}, ends=0, end_symbols=0, end_hist={})
 
     def win_left(self, cler):
         return 1 << 30                      # (the model holds the whole stream; the kernel bounds a step by its LDS window)
@@ -167,6 +168,40 @@ class Model:
                             self.stats['mix_hist'][k] = self.stats['mix_hist'].get(k, 0) + 1
                             if k <= 2: self.stats.setdefault('short', {}); pat = ''.join('VLREBDS?'[min(c_, 7)] for c_ in cl[cler - k:cler - k + 8]); self.stats['short'][pat] = self.stats['short'].get(pat, 0) + 1
                             if start >= end: break
+                            continue
+                    # ---- the chain-end step: k BOUNDARY / DELAY symbols at once (TOPO_ASM_ENDS).  Symbol m materialises edge m and pops edge
+                    # m+1: edge 0 is the current one (scalar code, first: its link writes land in the ring records the lanes then read), edge
+                    # m >= 1 the m-th live entry of the next 64 queue entries, each on its own lane; the last one popped becomes current.
+                    if self.use_ends and cl[cler] in (B, D) and cl[cler + 1] in (B, D) and cl[cler + 2] in (B, D):   # (three in a row: the step costs what two ends cost one at a time)
+                        nb = 0
+                        while nb < 63 and cl[cler + nb] in (B, D): nb += 1
+                        avail = min(64, nq - qpos)
+                        live = [i for i in range(avail) if not rec[(qpos + i) & MASK][3]]
+                        k = min(nb, len(live))
+                        if k >= 1:
+                            def alloc():
+                                nonlocal mbump
+                                if free: return free.pop()
+                                f = mbump; mbump += 1; return f
+                            f0 = alloc()
+                            rec[f0] = [v0, v1, v2, 0, ep, en]; rec[ep][5] = f0; rec[en][4] = f0
+                            if cl[cler] == D: delayed.append(f0)
+                            G = [((qpos + i) & MASK, list(rec[(qpos + i) & MASK])) for i in live[:k]]      # read AFTER edge 0's link writes
+                            fs = [alloc() for m in range(1, k)]                                               # edge m -> fs[m - 1]
+                            fwd = {G[m - 1][0]: fs[m - 1] for m in range(1, k)}
+                            for m in range(1, k):
+                                slot, t = G[m - 1]; f = fs[m - 1]
+                                pv, nx = fwd.get(t[4], t[4]), fwd.get(t[5], t[5])
+                                rec[f] = [t[0], t[1], t[2], 0, pv, nx]
+                                if t[4] not in fwd: rec[pv][5] = f
+                                if t[5] not in fwd: rec[nx][4] = f
+                                if cl[cler + m] == D: delayed.append(f)
+                            slot, t = G[k - 1]
+                            v0, v1, v2, ep, en = t[0], t[1], t[2], fwd.get(t[4], t[4]), fwd.get(t[5], t[5])
+                            qpos += live[k - 1] + 1
+                            cler += k
+                            self.stats['ends'] += 1; self.stats['end_symbols'] += k
+                            self.stats['end_hist'][k] = self.stats['end_hist'].get(k, 0) + 1
                             continue
                     c = cl[cler]; cler += 1
                     self.stats['serial'] += 1
