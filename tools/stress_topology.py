@@ -1,0 +1,52 @@
+"""Random meshes of every synthetic family (sizes, flip rates, hole fractions, groups, shuffles, merges) through the GPU decoder against the
+oracle, byte for byte, and the HBM-redo counter beside it: the automaton's wave-wide steps (run, mix, chain ends) are hand-written ISA, a
+wrong front often only runs out of slots, falls back and still decodes right - so mismatches AND unexpected fallbacks are what to look at.
+    python tools/stress_topology.py [rounds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+import corto_amd as ca
+from corto_amd import synth
+from oracle import oracle as oc
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = ca.Context(0)
+KEYS = ("index", "position", "normal", "uv", "color")
+total = bad = 0
+fallbacks = []
+for rd in range(rounds):
+    meshes = []; kinds = []
+    for _ in range(24):
+        k = int(rng.integers(0, 8)); s = int(rng.integers(0, 1 << 30))
+        if k == 0: m = synth.bumpy_sphere(int(rng.integers(8, 90)), int(rng.integers(4, 45)), seed=s)
+        elif k == 1: m = synth.bumpy_sphere_flipped(int(rng.integers(8, 90)), int(rng.integers(4, 45)), seed=s, flip=float(rng.choice([0.01, 0.05, 0.2, 0.5, 0.9, 1.0])))
+        elif k == 2: m = synth.holey_disc(int(rng.integers(8, 48)), seed=s, hole_frac=float(rng.uniform(0.02, 0.3)))
+        elif k == 3: m = synth.torus(int(rng.integers(6, 60)), int(rng.integers(4, 30)), seed=s)
+        elif k == 4: m = synth.strip(int(rng.integers(10, 500)), seed=s)
+        elif k == 5: m = synth.closed_sphere(int(rng.integers(6, 40)), int(rng.integers(4, 20)), seed=s)
+        elif k == 6: m = synth.shuffled(synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=s, flip=0.3))
+        else: m = synth.merge([synth.bumpy_sphere(int(rng.integers(6, 24)), int(rng.integers(4, 12)), seed=s), synth.holey_disc(int(rng.integers(8, 20)), seed=s + 1, color_components=4), synth.torus(12, 6, seed=s + 2)])
+        meshes.append(m); kinds.append(k)
+    blobs = [ca.aligned_blob(ca.encode(m, position_bits=int(rng.integers(10, 18)), uv_bits=12, normal_bits=10,
+                                       normal_prediction=[ca.BORDER, ca.ESTIMATED, ca.DIFF][i % 3])) for i, m in enumerate(meshes)]
+    u16 = bool(rd & 1)
+    for attempt in range(2):                        # the second pass runs with the slots the first one taught the context
+        b = ca.Batch(ctx, blobs); b.allocate_outputs(fill=0, index16=u16, color_components=4); b.decode()
+        st = b.sync()
+        for i, blob in enumerate(blobs):
+            r = oc.decode(blob, index16=u16, color_components=4)
+            got = b.host_outputs(i)
+            for key in KEYS:
+                if key in r and got[key].tobytes() != r[key].tobytes():
+                    bad += 1; print("MISMATCH round", rd, "blob", i, key, "nface", r["nface"])
+            total += 1
+        fallbacks.append(int(b.stats().topology_fallbacks))
+        b.close()
+        if attempt == 1 and fallbacks[-1]:             # who still falls back with the slots learnt: each blob alone, twice
+            for i, blob in enumerate(blobs):
+                c1 = ca.Context(0); n = []
+                for _ in range(2):
+                    b1 = ca.Batch(c1, [blob]); b1.allocate_outputs(fill=0); b1.decode(); b1.sync(); n.append(int(b1.stats().topology_fallbacks)); b1.close()
+                c1.close()
+                if n[1]: print("  persistent fallback: round", rd, "blob", i, kinds[i], "nface", meshes[i].nface, "nvert", meshes[i].nvert, n)
+print("decodes", total, "mismatching arrays", bad, "fallbacks per batch (first pass, second pass ...)", fallbacks)
