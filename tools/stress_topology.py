@@ -1,4 +1,4 @@
-"""Random meshes of every synthetic family (sizes, flip rates, hole fractions, groups, shuffles, merges) through the GPU decoder against the
+"""Random meshes of every synthetic family (sizes, flip rates, hole fractions, random group cuts, shuffles, merges) through the GPU decoder against the
 oracle, byte for byte, and the HBM-redo counter beside it: the automaton's wave-wide steps (run, mix, chain ends) are hand-written ISA, a
 wrong front often only runs out of slots, falls back and still decodes right - so mismatches AND unexpected fallbacks are what to look at.
     python tools/stress_topology.py [rounds] [seed]"""
@@ -26,7 +26,14 @@ for rd in range(rounds):
         elif k == 5: m = synth.closed_sphere(int(rng.integers(6, 40)), int(rng.integers(4, 20)), seed=s)
         elif k == 6: m = synth.shuffled(synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=s, flip=0.3))
         else: m = synth.merge([synth.bumpy_sphere(int(rng.integers(6, 24)), int(rng.integers(4, 12)), seed=s), synth.holey_disc(int(rng.integers(8, 20)), seed=s + 1, color_components=4), synth.torus(12, 6, seed=s + 2)])
+        if rng.random() < 0.3 and m.nface > 8:           # several groups (each starts from an empty front): random cuts
+            cuts = sorted(set(int(c) for c in rng.integers(1, m.nface, int(rng.integers(1, 4)))))
+            m.groups = cuts + [m.nface]
         meshes.append(m); kinds.append(k)
+    if rd % 5 == 4:                                      # now and then something beyond the LDS symbol window (slides) and the 64-entry scans
+        meshes[0] = synth.bumpy_sphere_flipped(int(rng.integers(100, 180)), int(rng.integers(50, 90)), seed=rd, flip=float(rng.choice([0.02, 0.5])))
+        meshes[1] = synth.holey_disc(int(rng.integers(60, 100)), seed=rd, hole_frac=0.1)
+        kinds[0], kinds[1] = 1, 2
     blobs = [ca.aligned_blob(ca.encode(m, position_bits=int(rng.integers(10, 18)), uv_bits=12, normal_bits=10,
                                        normal_prediction=[ca.BORDER, ca.ESTIMATED, ca.DIFF][i % 3])) for i, m in enumerate(meshes)]
     u16 = bool(rd & 1)
