@@ -800,10 +800,12 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mad_u32_u24 v59, v60, 12, %[c]\n" \
 	"  global_store_dwordx3 v59, v[36:38], %[faceb]\n"
 // Both steps are sections of the ISA block (TOPO_FAST_PATH jumps here from its VERTEX / LEFT entries and dispatches the next symbol
-// afterwards): as asm statements of their own they cost ~400 clocks of compiler-made glue a step - the exit, forty scalar instructions
-// of state shuffling either side, the way back in - a sixth of a regular blob's automaton.  Inside they live on the block's five scalar
-// temporaries and vcc: conditions are chained by narrowing exec (each compare sees the lanes that passed the ones before), masks are
-// rebuilt from per-lane values where they are needed again, exec is known to be lane 0 on entry.  FSHIFT: log2 of an index's bytes.
+// afterwards).  As asm statements of their own each paid an exit, forty-odd scalar instructions of compiler-made state shuffling either
+// side and the way back in; measured, that was worth 7 % on irregular blobs and 5 % on the 128K-vertex mesh, nothing on the regular
+// blob (the stamps that had blamed the glue for a quarter of its time were mostly measuring themselves: DESIGN.md 3.1).  Inside they
+// live on the block's five scalar temporaries and vcc: conditions are chained by narrowing exec (each compare sees the lanes that passed
+// the ones before - and a mask rebuilt with v_cmp is only as wide as exec is at that moment: set exec to -1 first), masks are rebuilt
+// from per-lane values where they are needed again, exec is known to be lane 0 on entry.  FSHIFT: log2 of an index's bytes.
 #define TOPO_ASM_WINDOW_LEFT /* t2 = symbols the LDS window holds from cler on (63+ when it reaches the end of the stream) */ \
 	"  s_add_u32 %[t2], %[slideat], 2048\n" \
 	"  s_sub_u32 %[t2], %[t2], %[cler]\n" \
