@@ -177,20 +177,41 @@ def cpu_baseline(blobs, budget_s=12.0):
     return out
 
 
+def sources_sha256():
+    """one hash over everything libcorto_hip.so is built from (corto_amd/csrc/*, the public headers, the build flags): what ties a
+    committed PMC profile to the kernels that are running now.  tools/prof_run.sh stamps it into the profile it writes."""
+    import hashlib
+    from corto_amd import build as b
+    h = hashlib.sha256()
+    files = sorted(os.path.join(b.CSRC, f) for f in os.listdir(b.CSRC) if f.endswith((".hip", ".cpp", ".h")))
+    files += [os.path.join(ROOT, "include", "corto_hip.h"), os.path.join(ROOT, "include", "corto", "decoder.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    h.update(" ".join(b.FLAGS).encode())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/, separate
-    --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None when no profile is committed."""
+    --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Returns (bytes, note): bytes is None when no
+    profile is committed OR when the newest one was taken from other sources than the ones this library was built from (the
+    profile carries the hash of corto_amd/csrc at the time, sources_sha256()) - a number from another kernel is not reported."""
     import glob
     name = {"topology_lds": "corto_hip::k_topology_lds", "topology": "corto_hip::k_topology", "delta_mesh": "corto_hip::k_delta_mesh",
             "tunstall_tables": "corto_hip::k_tun_tables", "tunstall_decode": "corto_hip::k_tun_decode", "tunstall_stream": "corto_hip::k_tun_stream",
-            "delta_mesh": "corto_hip::k_delta_wave"}.get(kernel)
+            "delta_mesh": "corto_hip::k_delta_lds16"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_per_dispatch.json")))
     if not name or not files:
-        return None
-    d = json.load(open(files[-1])).get(name, {})
+        return None, "no PMC profile committed for this kernel"
+    prof = json.load(open(files[-1]))
+    tag = os.path.basename(files[-1])
+    stamp = prof.get("_sources_sha256")
+    if stamp != sources_sha256():
+        return None, "%s was taken from other sources (%s) than this build (%s): not reported" % (tag, (stamp or "unstamped")[:12], sources_sha256()[:12])
+    d = prof.get(name, {})
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
-        return None
-    return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
+        return None, "%s has no FETCH_SIZE / WRITE_SIZE for %s" % (tag, name)
+    return int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "%s (sources %s = this build): (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch" % (tag, stamp[:12])
 
 
 def tunstall_scaled(ctx, ca, z, table_ids=None):
@@ -343,6 +364,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (contexts) per host thread; 1 = unpipelined")
     ap.add_argument("--host-threads", type=int, default=4, help="native host threads per GPU feeding it (crthip_pool)")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the `sustained` leg (one long timed region on the same pool); 0 skips it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-object C2 / C3 decodes (tools/prof_run.sh: keeps the rocprofv3 kernel averages about the C4 batch)")
@@ -402,8 +424,9 @@ def main():
         items.append(blobs_g)
     blobs = items[0]
     depth, nthreads = max(1, args.depth), max(1, args.host_threads)
-    # compressed inputs resident in HBM before the timed region: every item on every pool device (the queue may hand any item to any GPU)
-    arenas = [[ca.upload_arena(it, d) for d in devices] for it in items]
+    # compressed inputs resident in HBM before the timed region: item j on ITS pool device (j % N: crthip_pool's home-shard-first policy) -
+    # sharding, not replication; a device asked to decode another's item would upload it inside the step
+    arenas = [[ca.upload_arena(it, d) if k == j % len(devices) else None for k, d in enumerate(devices)] for j, it in enumerate(items)]
     pool = ca.Pool(devices, threads=nthreads, depth=depth)
 
     ctx = ca.Context(devices[0])
@@ -498,6 +521,10 @@ def main():
     if rep.devices_used != nloc:
         raise SystemExit("bench.py: only %d of %d pool devices decoded anything: %s" % (rep.devices_used, nloc, list(rep.steps_per_device)[:nloc]))
     steps_per_device = list(rep.steps_per_device)[:nloc]
+    # every context's LAST step started from an output block the pool had just filled with 0xA5 (pool.cpp): the check below cannot pass on
+    # bytes a warm-up step left behind
+    if rep.poisoned_lanes != pool.lanes:
+        raise SystemExit("bench.py: only %d of %d contexts ended on a poisoned output block" % (rep.poisoned_lanes, pool.lanes))
 
     # untimed bit-exactness check: what EVERY context of EVERY device decoded last, sampled, against the CPU oracle ...
     import hashlib
@@ -514,6 +541,8 @@ def main():
                 got = pool.lane_read(lane, i, k, dt, cnt)
                 assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed", lane, slot, it, i, k)
             checked += 1
+        tail = pool.lane_read(lane, 0, "#tail", np.uint8, 256)       # behind every output array: still the poison
+        assert (tail == 0xA5).all(), ("output block was not poisoned before the lane's last step", lane)
     for i in range(0, NBLOBS, 17):                # ... the unpipelined context's outputs as well ...
         got, ref = b0.host_outputs(i), oc.decode(blobs[i])
         for k in ("position", "normal", "color", "uv", "index"):
@@ -533,6 +562,34 @@ def main():
     barrier()
     elapsed_h = shard.max_over_ranks(rep_h.elapsed_s, dist, red_dev)
 
+    # sustained: the same pool, the same steps, for at least --sustain seconds in ONE region (steady clocks and thermals; what a 2 ms region cannot show)
+    sustained = None
+    if args.sustain > 0:
+        est = max(elapsed / args.steps, 1e-6)
+        n_sus = int(min(max(args.sustain / est * 1.1, 200), 400000)) * nloc
+        barrier()
+        rep_s, stamps_s = pool.run(items, steps=n_sus, warmup=2 * pool.lanes, arenas=arenas)
+        barrier()
+        el_s = shard.max_over_ranks(rep_s.elapsed_s, dist, red_dev)
+        tris_s = shard.sum_over_ranks(float(rep_s.triangles), dist, red_dev)
+        if rep_s.failed_blobs or rep_s.poisoned_lanes != pool.lanes:
+            raise SystemExit("bench.py: sustained leg: %d failed blobs, %d of %d contexts poisoned" % (rep_s.failed_blobs, rep_s.poisoned_lanes, pool.lanes))
+        for lane in range(0, pool.lanes, 3):                                     # ... and what it left is the oracle's bytes too
+            it, _slot = pool.lane_item(lane)
+            ref = oc.decode(items[it][11 + lane])
+            for k, (dt, w) in dts.items():
+                got = pool.lane_read(lane, 11 + lane, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
+                assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (sustained)", lane, k)
+        # windows of ~0.1 s
+        ts = np.concatenate([[0.0], np.asarray(stamps_s, dtype=np.float64)])
+        nwin = max(1, int(ts[-1] / 0.1))
+        edges = [round(i * (len(ts) - 1) / nwin) for i in range(nwin + 1)]
+        per = [(ts[edges[i + 1]] - ts[edges[i]]) / (edges[i + 1] - edges[i]) * 1e3 for i in range(nwin) if edges[i + 1] > edges[i]]
+        sustained = {"seconds": round(el_s, 3), "steps": n_sus // nloc, "mtri_per_s": round(tris_s / el_s / 1e6, 2), "ms_per_step": round(el_s / (n_sus / nloc) * 1e3, 4),
+                     "windows": len(per), "best_window_ms_per_step": round(float(min(per)), 4), "median_window_ms_per_step": round(float(np.median(per)), 4),
+                     "worst_window_ms_per_step": round(float(max(per)), 4), "host_us_per_step_per_thread": round(float(rep_s.host_us_per_step), 1),
+                     "note": "one timed region of >= %.1f s on the same pool as `value` (same items, inputs resident in HBM), windows of ~0.1 s; outputs poisoned before the last round and checked against the oracle" % args.sustain}
+
     # beside `value`: the same pipelined steps with one Tunstall dictionary built PER STREAM ($CORTO_TUN_SHARE=0; read when a context is
     # made, so: a second pool).  By default the streams of a batch that carry the same probability table share one dictionary, and the
     # synthetic blobs - one generator, 256 seeds, the same connectivity - repeat tables far more than unrelated meshes would.
@@ -550,6 +607,7 @@ def main():
     # beside `value` too: the same batch shape with IRREGULAR connectivity (every grid quad's diagonal flipped per seed: valences 4-8, no two
     # blobs share a CLERS stream; shorter (VERTEX LEFT) runs, shorter scan blocks) - what the pipeline does when meshes are not lat-long grids
     irregular = None
+    realistic = None
     if rank == 0 and not args.no_other_configs:
         from corto_amd import synth
         iblobs = [ca.encode(synth.bumpy_sphere_flipped(64, 32, seed=i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(NBLOBS)]
@@ -567,6 +625,28 @@ def main():
                      "steps": fh_steps // nloc, "topology_fallbacks": int(rep_i.topology_fallbacks), "failed_blobs": int(rep_i.failed_blobs),
                      "note": "one GPU; 256 x bumpy_sphere_flipped(64, 32, seed): 2112 verts / 4096 tris each, every quad's diagonal flipped with probability 1/2"}
         pool_i.close()
+        # `realistic`: everything the headline's best case leaves out, at once - irregular connectivity, one dictionary PER STREAM (no two
+        # blobs of unrelated meshes share tables), and the compressed blobs uploaded from host memory inside every step (SURVEY 8d's primary region)
+        os.environ["CORTO_TUN_SHARE"] = "0"
+        pool_r = ca.Pool(devices[:1], threads=nthreads, depth=depth)
+        del os.environ["CORTO_TUN_SHARE"]
+        pool_r.run([iblobs], steps=4 * pool_r.lanes, warmup=0, arenas=None)
+        r_steps = max(fh_steps // nloc, 200)
+        rep_r, st_r = pool_r.run([iblobs], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
+        assert rep_r.poisoned_lanes == pool_r.lanes
+        for lane in range(1, pool_r.lanes, 4):
+            i = 5 * lane + 2
+            ref = oc.decode(iblobs[i])
+            for k, (dt, w) in dts.items():
+                got = pool_r.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
+                assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (realistic)", lane, i, k)
+        realistic = {"mtri_per_s": round(rep_r.triangles / rep_r.elapsed_s / 1e6, 2), "mverts_per_s": round(rep_r.vertices / rep_r.elapsed_s / 1e6, 2),
+                     "ms_per_step": round(rep_r.elapsed_s / r_steps * 1e3, 4), "steps": r_steps,
+                     "topology_fallbacks": int(rep_r.topology_fallbacks), "failed_blobs": int(rep_r.failed_blobs), **window_stats(st_r, pool_r.lanes),
+                     "h2d_bytes_per_step": int(sum(((len(x) + 15) & ~15) for x in iblobs)),
+                     "note": "one GPU; irregular connectivity (bumpy_sphere_flipped) + $CORTO_TUN_SHARE=0 (one dictionary per stream) + compressed blobs in HOST memory, uploaded "
+                             "over PCIe inside every step; outputs poisoned before the last round, bit-exact spot check against the oracle.  The number to expect from unrelated scanned meshes; `value` is the best case"}
+        pool_r.close()
 
     tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev) / R     # (per K-step region)
     verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev) / R
@@ -588,6 +668,7 @@ def main():
         dom_bytes = alg.get(dom) or whole_path_bytes
         dom_ms = kernels[dom]["ms_per_step"] / max(kernels[dom]["launches_per_step"], 1)
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_note = pmc_traffic(dom)
         out = {
             "metric": "Mtriangles/s + Mverts/s decode, 1M-tri batch; bit-exact vs CPU",
             "value": round(tris_total / elapsed / 1e6, 2), "unit": "Mtri/s",
@@ -614,8 +695,17 @@ def main():
             "without_dictionary_sharing": {"mtri_per_s": round(tris_ns / elapsed_ns / 1e6, 2), "ms_per_step": round(elapsed_ns / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
                                            "note": "same pipelined steps with $CORTO_TUN_SHARE=0: every stream builds its own dictionary (round 2's earlier figure)"},
             "irregular_connectivity": irregular,
-            "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
+            "realistic": realistic,
+            "sustained": sustained,
+            "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool.warning or None,
+            "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1),
+            "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "mverts_per_s": round(tris_h / elapsed_h / 1e6 * nvert / ntri, 2),
+                                    "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
                                     **window_stats(stamps_h, pool.lanes),
+                                    "roofline": {"bound": "hbm", "what": "whole path, SURVEY 8d primary region (pinned-host .crt -> HBM outputs)",
+                                                 "algorithmic_bytes_per_step": whole_path_bytes, "achieved": round(whole_path_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9, 2),
+                                                 "peak": 8000.0, "unit": "GB/s", "frac": round(whole_path_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9 / 8000.0, 6),
+                                                 "pcie_GBps": round(stats0.arena_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9, 2)},
                                     "note": "same pipelined steps, but every step uploads its %.1f MB of compressed blobs from host memory (PCIe H2D inside the step); "
                                             "reported beside `value`, never as it" % (stats0.arena_bytes / 1e6)},
             "single_batch": {"ms": round(solo_ms, 4), "mtri_per_s": round(ntri / solo_ms / 1e3, 2), "steps": solo_steps,
@@ -627,7 +717,7 @@ def main():
                              "to_host_memory": {"ms": round(d2h_ms, 4), "mtri_per_s": round(ntri / d2h_ms / 1e3, 2),
                                                 "note": "same step plus the %.1f MB of decoded outputs copied to pinned host memory" % (stats0.output_bytes / 1e6)}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(dom),
+                         "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_note, "sources_sha256": sources_sha256(),
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
             "whole_path": {"algorithmic_bytes": whole_path_bytes, "GBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9, 2),
                            "frac_of_8TBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9 / 8000.0, 6)},

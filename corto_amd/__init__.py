@@ -84,7 +84,8 @@ class PoolItem(C.Structure):
 class PoolReport(C.Structure):
     _fields_ = [("elapsed_s", C.c_double), ("steps", C.c_uint64), ("triangles", C.c_uint64), ("vertices", C.c_uint64),
                 ("failed_blobs", C.c_uint64), ("first_error", C.c_int32), ("devices_used", C.c_uint32),
-                ("steps_per_device", C.c_uint64 * 16), ("topology_fallbacks", C.c_uint64)]
+                ("steps_per_device", C.c_uint64 * 16), ("topology_fallbacks", C.c_uint64),
+                ("poisoned_lanes", C.c_uint32), ("pinned_devices", C.c_uint32), ("host_us_per_step", C.c_float), ("reserved", C.c_uint32)]
 
 
 class KernelTimes(C.Structure):
@@ -157,6 +158,8 @@ def lib():
         L.crthip_pool_destroy.argtypes = [C.c_void_p]
         L.crthip_pool_lanes.restype = C.c_uint32
         L.crthip_pool_lanes.argtypes = [C.c_void_p]
+        L.crthip_pool_warning.restype = C.c_char_p
+        L.crthip_pool_warning.argtypes = [C.c_void_p]
         L.crthip_pool_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(PoolReport), C.c_void_p]
         L.crthip_pool_lane_item.restype = C.c_int64
         L.crthip_pool_lane_item.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -530,6 +533,7 @@ class Pool:
         arr = np.array(self.devices, dtype=np.int32)
         _check(lib().crthip_pool_create(len(self.devices), _np_ptr(arr), threads, depth, C.byref(self.handle)))
         self.lanes = int(lib().crthip_pool_lanes(self.handle))
+        self.warning = lib().crthip_pool_warning(self.handle).decode()
         self._keep = None
 
     def run(self, items, steps: int, warmup: int = 0, arenas=None):

@@ -17,6 +17,7 @@
 
 #include "../../include/corto_hip.h"
 #include "crt_format.h"
+#include "debug_config.h"
 #include "device_plan.h"
 #include "encoder_internal.h"
 #include "kernels.h"
@@ -211,18 +212,11 @@ struct crthip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;  // attribute streams (Tunstall + bit-unpack) run here while the main stream does topology
-	hipStream_t stream3 = nullptr;  // long Tunstall streams: the three word-width classes of the staged decode run side by side (k_tunstall.hip)
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
-	// long streams: by default chunk sums, a scan per stream (k_tun_stream_scan), the decode; $CORTO_TUN_TWO_PASS=1: one device-wide scan kernel
-	// instead (round 1); $CORTO_TUN_SINGLE_PASS=1: the adding-up and a wait-free look-back inside the decode kernel (round 2's first half)
-	bool tun_two_pass = false, tun_single_pass = false;
-	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // experiments: $CORTO_EXP_NORMAL_FN_MAX
-	uint8_t exp_delta_walk = 0;                       // experiments: $CORTO_EXP_DELTA_WALK=1 - K-DELTA without the scan passes
-	uint8_t exp_no_deq_fold = 0;                      // experiments: $CORTO_EXP_NO_DEQ_FOLD=1 - every attribute through k_dequant
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	DebugConfig dbg;                // every environment switch, read once when the context is made (debug_config.h)
+	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // largest LDS request for which K-NRM keeps its face normals in LDS (dbg.normal_fn_max, or by single_stream)
 	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams
-	bool tun_side = false;          // $CORTO_TUN_SIDE_STREAMS=1: the three word-width classes side by side on three streams (measured: 3-4 % SLOWER than one after the other)
-	bool tun_three = false;         // $CORTO_TUN_THREE_LAUNCHES=1: one decode kernel per word-width class (A/B measurements)
-	TunLaunch tun_launch() const { return tun_side ? TunLaunch{stream, {stream2, stream3}, ev_fork, {ev_join, ev_join3}, false} : TunLaunch{stream, {nullptr, nullptr}, nullptr, {nullptr, nullptr}, !tun_three}; }
+	TunLaunch tun_launch() const { return TunLaunch{stream, !dbg.tun_three}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
 	PinnedBuf staging;        // host image of the job arrays
 	PinnedBuf status_host;
@@ -247,7 +241,8 @@ struct crthip_ctx {
 	struct DictKey { uint8_t n, bytes[32]; };
 	std::vector<DictKey> dict_keys;
 	std::vector<uint32_t> dict_slots, dict_used, dict_ids;
-	int tun_share = -1;                               // $CORTO_TUN_SHARE: 0 never, 1 whenever possible, unset: when at least half of a launch's streams repeat a table
+	bool delta_wide = false;                          // K-DELTA keeps 32-bit values in LDS: $CORTO_DELTA_WIDE=1, or learnt from a batch whose 16-bit relative values overflowed
+	uint32_t delta_calm = 0;
 };
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
@@ -330,17 +325,10 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
 	   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-	   hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
-	{ const char *e = getenv("CORTO_TUN_TWO_PASS"); c->tun_two_pass = e && e[0] == '1'; }
-	{ const char *e = getenv("CORTO_TUN_THREE_LAUNCHES"); c->tun_three = e && e[0] == '1'; }
-	{ const char *e = getenv("CORTO_TUN_SINGLE_PASS"); c->tun_single_pass = e && e[0] == '1' && !c->tun_two_pass; }
-	{ const char *e = getenv("CORTO_TUN_SIDE_STREAMS"); c->tun_side = e && e[0] == '1'; }
-	{ const char *e = getenv("CORTO_TUN_SHARE"); if(e && (e[0] == '0' || e[0] == '1')) c->tun_share = e[0] - '0'; }
-	if(c->tun_side && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE); }   // (a stream is a hardware queue: not made unless asked for)
-	{ const char *e = getenv("CORTO_EXP_NORMAL_FN_MAX"); if(e) c->exp_normal_fn_max = (uint32_t)atoi(e); }
-	{ const char *e = getenv("CORTO_EXP_DELTA_WALK"); c->exp_delta_walk = e && e[0] == '1'; }
-	{ const char *e = getenv("CORTO_EXP_NO_DEQ_FOLD"); c->exp_no_deq_fold = e && e[0] == '1'; }
+	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	c->dbg = debug_config_from_env();
+	if(c->dbg.has_normal_fn_max) c->exp_normal_fn_max = c->dbg.normal_fn_max;
+	c->delta_wide = c->dbg.delta_wide != 0;
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
@@ -360,9 +348,8 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	c->timer.release();
 	if(c->host_batch) { crthip_batch *hb = c->host_batch; c->host_batch = nullptr; crthip_batch_destroy(hb); }
 	c->scratch.release(); c->staging.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
-	(void)hipStreamSynchronize(c->stream2); if(c->stream3) (void)hipStreamSynchronize(c->stream3);
-	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_join3);
-	if(c->stream3) (void)hipStreamDestroy(c->stream3);
+	(void)hipStreamSynchronize(c->stream2);
+	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
 	(void)hipStreamDestroy(c->stream2);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -379,7 +366,7 @@ extern "C" int crthip_ctx_set_single_stream(crthip_ctx *c, int on) {
 	c->single_stream = on != 0;
 	// many batches in flight: kernels wait for LDS to come free, and a request of 41 KB finds room long before one of 91 KB does - the
 	// normals kernel without its face-normal array takes twice as long alone (79 vs 39 us per C4 batch) and the pipelined rate is 10 % higher
-	if(!getenv("CORTO_EXP_NORMAL_FN_MAX")) c->exp_normal_fn_max = on ? 0u : NORMAL_FN_LDS_MAX;
+	if(!c->dbg.has_normal_fn_max) c->exp_normal_fn_max = on ? 0u : NORMAL_FN_LDS_MAX;
 	return CRTHIP_OK;
 }
 
@@ -479,7 +466,8 @@ static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
 	if(a.codec == CRTHIP_CODEC_NORMAL) {
 		if(bd.format != CRTHIP_FMT_FLOAT && bd.format != CRTHIP_FMT_INT16) return CRTHIP_E_FORMAT;
 		const uint32_t el = bd.format == CRTHIP_FMT_INT16 ? 2u : 4u;
-		if(st && (st < 3*el || st % el || ((uintptr_t)bd.buffer) % el)) return CRTHIP_E_ARGUMENT;
+		if(((uintptr_t)bd.buffer) % el) return CRTHIP_E_ARGUMENT;            // a float* / int16_t* (decoder.h:52-53) is aligned by its type
+		if(st && (st < 3*el || st % el)) return CRTHIP_E_ARGUMENT;
 		return CRTHIP_OK;
 	}
 	if(a.codec == CRTHIP_CODEC_COLOR) {
@@ -491,7 +479,10 @@ static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
 	}
 	if(a.N < 1) return CRTHIP_E_FORMAT;
 	if(bd.format != CRTHIP_FMT_FLOAT) return CRTHIP_E_FORMAT;            // integer output formats: SURVEY a17, not on the device path
-	if(st && (st < 4*a.N || st % 4 || ((uintptr_t)bd.buffer) % 4)) return CRTHIP_E_ARGUMENT;
+	// a packed buffer doubles as the int32 workspace and K-DELTA turns it into floats with dword / 16-byte accesses: a float* that is
+	// not 4-byte aligned (never one a C++ caller's setPositions(float*) could pass) is refused, not decoded into integers
+	if(((uintptr_t)bd.buffer) % 4) return CRTHIP_E_ARGUMENT;
+	if(st && (st < 4*a.N || st % 4)) return CRTHIP_E_ARGUMENT;
 	return CRTHIP_OK;
 }
 
@@ -574,7 +565,23 @@ struct Launch {
 	}
 };
 
+static int build_and_launch_inner(crthip_batch *b);
+// A decode call that fails half-way (a HIP error between two launches) may have kernels queued that write per-blob status into the
+// context's pinned block and into its scratch; in_flight is not set on that path, so nothing downstream would wait for them before the
+// next call clears or moves those blocks.  Drain the context's streams before the error is returned.
 static int build_and_launch(crthip_batch *b) {
+	const int err = build_and_launch_inner(b);
+	if(err) {
+		crthip_ctx *ctx = b->ctx;
+		(void)hipStreamSynchronize(ctx->stream);
+		if(ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+		(void)hipGetLastError();
+		b->decoded = false;
+	}
+	return err;
+}
+
+static int build_and_launch_inner(crthip_batch *b) {
 	crthip_ctx *ctx = b->ctx;
 	const double t0 = now_us(); double t1 = 0, t2 = 0, t3 = 0;        // host-side cost of a decode call (crthip_batch_stats::host_*_us)
 	Plan &pl = ctx->plan;
@@ -726,7 +733,7 @@ static int build_and_launch(crthip_batch *b) {
 		TunStream t{};
 		t.src = arena + blob_off + s.payload_off; t.dst = SP(sym_off); t.probs = arena + blob_off + s.probs_off;
 		t.csize = s.csize; t.size = s.size; t.nsym = s.nsym; t.table = (uint32_t)pl.tun.v.size();
-		t.chunk0 = tun_chunks; tun_pick_geometry(t);
+		t.chunk0 = tun_chunks; tun_pick_geometry(t, ctx->dbg.tun_chunk_cap);
 		if(t.nchunks > 1) pl.tun_multi_chunk = true;
 		pl.tun_max_nchunks = std::max(pl.tun_max_nchunks, t.nchunks);
 		for(uint32_t c = 0; c < t.nchunks; c++) pl.tun_chunk_stream.v.push_back((uint32_t)pl.tun.v.size());
@@ -810,7 +817,7 @@ static int build_and_launch(crthip_batch *b) {
 			for(size_t k = 0; k < L.attrs.size(); k++)
 				if(mesh && L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && (L.attrs[k].normal_prediction == 1 || L.attrs[k].normal_prediction == 2)) readers++;
 			pos_ints_needed = readers > 0;
-			pos_by_normal = readers == 1 && !ctx->exp_no_deq_fold && normal_fused(nvert, nface);
+			pos_by_normal = readers == 1 && !ctx->dbg.no_deq_fold && normal_fused(nvert, nface);
 		}
 
 		for(size_t k = 0; k < L.attrs.size(); k++) {
@@ -860,9 +867,9 @@ static int build_and_launch(crthip_batch *b) {
 				if(mesh) {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
-					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->exp_delta_walk;   // pad[1]: experiments - the flag-driven walk only
+					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->dbg.delta_walk;   // pad[1]: experiments - the flag-driven walk only
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
-					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d) == 2 && !ctx->exp_no_deq_fold) {
+					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d) == 2 && !ctx->dbg.no_deq_fold) {
 						if(a.codec == CRTHIP_CODEC_COLOR) {
 							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;
 							for(int c = 0; c < 4; c++) d.qc[c] = as.qc[c];
@@ -951,7 +958,7 @@ static int build_and_launch(crthip_batch *b) {
 			const DeltaJob &d0 = pl.delta.v[j];
 			uint64_t lds = delta_wave_need(d0);
 			DeltaGroup g{(uint32_t)j, 1};
-			static const uint32_t gmax_ = [] { const char *e = getenv("CORTO_EXP_DELTA_GROUP"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 1 && v <= DELTA_GROUP_MAX ? v : DELTA_GROUP_MAX; }();
+			const uint32_t gmax_ = ctx->dbg.delta_group ? ctx->dbg.delta_group : DELTA_GROUP_MAX;
 			while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
 				const DeltaJob &d = pl.delta.v[j + g.count];
 				const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
@@ -1032,7 +1039,7 @@ static int build_and_launch(crthip_batch *b) {
 	const uint32_t nfill = (uint32_t)pl.fill.v.size();
 	const uint32_t ndict = (uint32_t)pl.tun_dict.v.size();
 	// a launch's streams share dictionaries when at least half of them repeat another one's table (and there are enough of them for it to matter)
-	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { return ctx->tun_share == 1 ? ndicts < nstreams : ctx->tun_share != 0 && nstreams >= 64 && 2*ndicts <= nstreams; };
+	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { return ctx->dbg.tun_share == 1 ? ndicts < nstreams : ctx->dbg.tun_share != 0 && nstreams >= 64 && 2*ndicts <= nstreams; };
 	const bool share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict), share_attrs = !pl.tun_multi_chunk && shares(ntun - clers_tun, ndict - clers_dict);
 	stat_dicts = (share_clers ? clers_dict : clers_tun) + (share_attrs ? ndict - clers_dict : ntun - clers_tun);
 	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
@@ -1071,13 +1078,13 @@ static int build_and_launch(crthip_batch *b) {
 	if(pl.tun_multi_chunk) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
 		uint64_t *tun_state = tun_partial;                                     // (single pass: the look-back's chunk state words, cleared by K-TAB)
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables, ctx->tun_single_pass ? tun_state : (uint64_t *)nullptr, tun_chunks); LT.end();
-		if(!ctx->tun_single_pass) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables, ctx->dbg.tun_single_pass ? tun_state : (uint64_t *)nullptr, tun_chunks); LT.end();
+		if(!ctx->dbg.tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
-			if(ctx->tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end(); }
+			if(ctx->dbg.tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end(); }
 			else if(pl.tun_max_nchunks > 256) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, D(pl.tun), ntun, tun_partial); LT.end(); }
 		}                                                                          // (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself)
-		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, ctx->tun_single_pass ? 1u : !ctx->tun_two_pass && pl.tun_max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); LT.end();
+		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, ctx->dbg.tun_single_pass ? 1u : !ctx->dbg.tun_two_pass && pl.tun_max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
@@ -1259,12 +1266,14 @@ extern "C" int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t l
 	const BlobLayout &L = b->blobs[0].L;
 	const uint32_t nvert = L.h.nvert, nface = L.h.nface;
 	const size_t na = L.h.attrs.size();
-	if(na && !attrs) return fail(CRTHIP_E_ARGUMENT);
 	crthip_attr_binding dev[CRTHIP_MAX_ATTRS];
 	size_t off[CRTHIP_MAX_ATTRS + 1], bytes[CRTHIP_MAX_ATTRS + 1];
 	size_t total = 0;
 	for(size_t k = 0; k < na; k++) {
-		dev[k] = attrs[k]; dev[k].stride = 0; dev[k].reserved = 0; bytes[k] = 0; off[k] = 0;   // (host buffers: upstream's packed layouts)
+		// attrs == NULL: nothing bound (an index-only decode); host buffers have upstream's packed layouts - a stride is refused, not ignored
+		if(attrs) dev[k] = attrs[k]; else { dev[k].buffer = nullptr; dev[k].format = CRTHIP_FMT_FLOAT; dev[k].out_components = 0; dev[k].stride = 0; }
+		if(dev[k].buffer && dev[k].stride) return fail(CRTHIP_E_ARGUMENT, "crthip_decode_host: host buffers are tightly packed (stride must be 0)");
+		dev[k].stride = 0; dev[k].reserved = 0; bytes[k] = 0; off[k] = 0;
 		if(!dev[k].buffer) continue;
 		const AttrHeader &a = L.h.attrs[k];
 		if(a.codec == CRTHIP_CODEC_NORMAL) bytes[k] = (size_t)nvert*3*(dev[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
@@ -1283,7 +1292,7 @@ extern "C" int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t l
 	const int serr = crthip_batch_sync(b, nullptr);          // waits for the copy too (same stream); keeps the context consistent on error
 	if(!err) err = serr;
 	if(!err) {
-		for(size_t k = 0; k < na; k++) if(bytes[k]) memcpy(attrs[k].buffer, hbase + off[k], bytes[k]);
+		for(size_t k = 0; k < na; k++) if(bytes[k]) memcpy(attrs[k].buffer, hbase + off[k], bytes[k]);      // (bytes[k] != 0 only with attrs)
 		if(bytes[na]) memcpy(index, hbase + off[na], bytes[na]);
 	}
 	return err;
@@ -1312,7 +1321,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		if(ns == 0 || csize == 0) return fail(CRTHIP_E_TRUNCATED);
 		TunStream t{};
 		t.src = dblk + 9 + 2*ns; t.dst = dst; t.probs = dblk + 1; t.csize = csize; t.size = size; t.nsym = ns; t.table = (uint32_t)tun.size();
-		t.chunk0 = chunks; tun_pick_geometry(t);
+		t.chunk0 = chunks; tun_pick_geometry(t, ctx->dbg.tun_chunk_cap);
 		if(t.nchunks > 1) multi = true;
 		max_nchunks = std::max(max_nchunks, t.nchunks);
 		for(uint32_t c = 0; c < t.nchunks; c++) chunk_stream.push_back((uint32_t)tun.size());
@@ -1338,14 +1347,14 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	uint64_t *state = part;                                                  // (single pass: the chunk state words of the look-back, cleared by K-TAB)
 	const uint32_t ntun = (uint32_t)tun.size();
 	if(ntun) {
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables, multi && ctx->tun_single_pass ? state : (uint64_t *)nullptr, chunks); LT.end();
-		if(multi && !ctx->tun_single_pass) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables, multi && ctx->dbg.tun_single_pass ? state : (uint64_t *)nullptr, chunks); LT.end();
+		if(multi && !ctx->dbg.tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
-			if(ctx->tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end(); }
+			if(ctx->dbg.tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end(); }
 			else if(max_nchunks > 256) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, dt, ntun, part); LT.end(); }
 		}                                                                   // (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself)
 		LT.begin("tunstall_decode");
-		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, ctx->tun_single_pass ? 1u : !ctx->tun_two_pass && max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); }
+		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, ctx->dbg.tun_single_pass ? 1u : !ctx->dbg.tun_two_pass && max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); }
 		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
 		LT.end();
 	}

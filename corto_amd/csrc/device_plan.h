@@ -38,18 +38,10 @@ struct TunStream {
 // balanced by OUTPUT bytes (a two-symbol dictionary expands 60x, a flat one 2x), and a wave's step of 64*cpl codewords
 // is sized so that its decoded bytes fit the wave's LDS window (k_tunstall.hip).
 constexpr uint32_t TUN_CHUNK_CODES = 32768;   // largest chunk
-#ifndef __HIP_DEVICE_COMPILE__
-inline uint32_t tun_chunk_cap() {                // $CORTO_EXP_TUN_CHUNK: experiments with the largest chunk (a power of two >= 2048)
-	static const uint32_t cap = [] { const char *e = getenv("CORTO_EXP_TUN_CHUNK"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 2048 && v <= TUN_CHUNK_CODES && !(v & (v - 1)) ? v : TUN_CHUNK_CODES; }();
-	return cap;
-}
-#else
-inline uint32_t tun_chunk_cap() { return TUN_CHUNK_CODES; }
-#endif
-inline void tun_pick_geometry(TunStream &t) {
+inline void tun_pick_geometry(TunStream &t, uint32_t chunk_cap = TUN_CHUNK_CODES) {   // chunk_cap: DebugConfig::tun_chunk_cap (debug_config.h)
 	const uint32_t avg = t.csize ? (uint32_t)(((uint64_t)t.size + t.csize - 1)/t.csize) : 1;
 	t.cpl = avg <= 8 ? 8 : avg <= 16 ? 4 : avg <= 32 ? 2 : 1;
-	uint32_t codes = tun_chunk_cap();
+	uint32_t codes = chunk_cap;
 	while(codes > 256*t.cpl && (uint64_t)codes*avg > 256*1024) codes >>= 1;   // a wave's quarter chunk stays whole steps of 64*cpl
 	t.chunk_codes = codes;
 	t.nchunks = (t.csize + codes - 1)/codes;

@@ -730,12 +730,7 @@ int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const
                              uint64_t *chunk_out, uint32_t single_pass) {
 #define TUN_LAUNCH(W_, S_) hipLaunchKernelGGL((k_tun_decode_staged<W_>), dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<W_, 8>()), S_, \
                                           streams, chunk_stream, nchunks, tables, chunk_out, single_pass)
-	const bool side = q.side[0] && q.side[1] && q.fork && q.join[0] && q.join[1];
-	if(side) {
-		if(hipEventRecord(q.fork, q.main) != hipSuccess || hipStreamWaitEvent(q.side[0], q.fork, 0) != hipSuccess || hipStreamWaitEvent(q.side[1], q.fork, 0) != hipSuccess) return -1;
-		TUN_LAUNCH(4, q.main); TUN_LAUNCH(1, q.side[0]); TUN_LAUNCH(2, q.side[1]);
-		for(int k = 0; k < 2; k++) if(hipEventRecord(q.join[k], q.side[k]) != hipSuccess || hipStreamWaitEvent(q.main, q.join[k], 0) != hipSuccess) return -1;
-	} else if(q.one_launch) hipLaunchKernelGGL(k_tun_decode_staged_any, dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<4, 8>()), q.main, streams, chunk_stream, nchunks, tables, chunk_out, single_pass);
+	if(q.one_launch) hipLaunchKernelGGL(k_tun_decode_staged_any, dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<4, 8>()), q.main, streams, chunk_stream, nchunks, tables, chunk_out, single_pass);
 	else { TUN_LAUNCH(1, q.main); TUN_LAUNCH(2, q.main); TUN_LAUNCH(4, q.main); }
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 #undef TUN_LAUNCH

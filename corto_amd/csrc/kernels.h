@@ -18,7 +18,7 @@ __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_str
 // Dwords of a word's zero-padded copy the staged decode composes from (k_tunstall.hip): by the dictionary's longest word;
 // steps of fewer than 8 codewords per lane (mean word length > 8) are only compiled for 4.
 __host__ __device__ inline uint32_t tun_width(uint32_t cpl, uint32_t maxlen) { return cpl < 8 || maxlen > 8 ? 4u : maxlen > 4 ? 2u : 1u; }
-struct TunLaunch { hipStream_t main, side[2]; hipEvent_t fork, join[2]; bool one_launch; };   // side streams / events may be null: everything on `main`; one_launch: all three classes in one kernel
+struct TunLaunch { hipStream_t main; bool one_launch; };   // one_launch: all three word-width classes in one kernel (the default); else one kernel per class
 int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                              uint64_t *chunk_out, uint32_t single_pass);    // words <= 4 bytes, <= 8 bytes, longer: one kernel, or three
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);

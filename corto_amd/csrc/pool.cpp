@@ -5,10 +5,14 @@
 // Reference anchor: independent crt::Decoder objects, src/decoder.cpp:126-196 (nothing shared between two decodes).
 #include <cstdlib>
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -37,7 +41,9 @@ struct Lane {                       // one context = one batch in flight
 	int64_t item = -1;              // item of the step in flight / last executed
 	uint64_t step = 0;              // its global step number
 	bool busy = false;
+	bool poisoned = false;          // the output block was filled with POISON on the context's stream right before the step in flight / last executed
 };
+constexpr int POISON = 0xA5;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -47,6 +53,8 @@ struct crthip_pool {
 	uint32_t ndevices = 0, threads_per_device = 0, depth = 0;
 	std::vector<int> devices;
 	std::vector<Lane> lanes;        // [device][thread][depth]
+	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
+	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
 	std::mutex m;
@@ -68,14 +76,50 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 	for(uint32_t d = 0; d < ndevices; d++) p->devices.push_back(devices ? devices[d] : (int)d);
 	p->lanes.resize((size_t)ndevices*threads_per_device*depth);
 	uint32_t hw_queues = 4;                                      // ROCm's default
-	{ const char *e = getenv("GPU_MAX_HW_QUEUES"); if(e && atoi(e) > 0) hw_queues = (uint32_t)atoi(e); }
+	bool hw_queues_set = false;
+	{ const char *e = getenv("GPU_MAX_HW_QUEUES"); if(e && atoi(e) > 0) { hw_queues = (uint32_t)atoi(e); hw_queues_set = true; } }
+	// contexts per PHYSICAL device: a device id may repeat (several pool devices on one GPU), and it is the GPU's hardware queues
+	// that the contexts' streams share
+	std::map<int, uint32_t> ctx_per_gpu;
+	for(uint32_t d = 0; d < ndevices; d++) ctx_per_gpu[p->devices[d]] += threads_per_device*depth;
 	for(size_t i = 0; i < p->lanes.size(); i++) {
 		Lane &L = p->lanes[i];
 		L.slot = (uint32_t)(i/((size_t)threads_per_device*depth)); L.device = p->devices[L.slot];
 		int err = crthip_ctx_create(L.device, &L.ctx);
-		// two HIP streams per context only while every stream of the device gets a hardware queue of its own (corto_hip.h)
-		if(!err && 2*threads_per_device*depth > hw_queues) err = crthip_ctx_set_single_stream(L.ctx, 1);
+		// two HIP streams per context only while every stream of the GPU gets a hardware queue of its own (corto_hip.h)
+		if(!err && 2*ctx_per_gpu[L.device] > hw_queues) err = crthip_ctx_set_single_stream(L.ctx, 1);
 		if(err) { for(auto &x : p->lanes) destroy_lane(x); delete p; return err; }
+	}
+	for(auto &kv : ctx_per_gpu)
+		if(kv.second > hw_queues && p->warning.empty()) {
+			char buf[320];
+			snprintf(buf, sizeof buf, "corto_hip pool: %u contexts on GPU %d but %u hardware queues (%s): streams that share a queue serialise each other's kernels; "
+			         "export GPU_MAX_HW_QUEUES=%u before the process first touches HIP", kv.second, kv.first, hw_queues,
+			         hw_queues_set ? "GPU_MAX_HW_QUEUES" : "ROCm's default; GPU_MAX_HW_QUEUES is not set", kv.second > 16 ? 16u : kv.second);
+			p->warning = buf;
+			fprintf(stderr, "%s\n", buf);
+		}
+	// the host CPUs next to each GPU: PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist
+	p->cpus.resize(ndevices);
+	for(uint32_t d = 0; d < ndevices; d++) {
+		char bus[64] = {0};
+		if(hipDeviceGetPCIBusId(bus, (int)sizeof bus, p->devices[d]) != hipSuccess) { (void)hipGetLastError(); continue; }
+		for(char *c = bus; *c; c++) if(*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+		char path[192]; int node = -1;
+		snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+		if(FILE *f = fopen(path, "r")) { if(fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+		if(node < 0) continue;
+		snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+		if(FILE *f = fopen(path, "r")) {
+			int a, b; char sep;
+			while(fscanf(f, "%d", &a) == 1) {
+				b = a;
+				if(fscanf(f, "%c", &sep) == 1 && sep == '-') { if(fscanf(f, "%d", &b) != 1) b = a; if(fscanf(f, "%c", &sep) != 1) sep = 0; }
+				for(int c = a; c <= b && c < CPU_SETSIZE; c++) p->cpus[d].push_back(c);
+				if(sep != ',') break;
+			}
+			fclose(f);
+		}
 	}
 	*out = p;
 	return CRTHIP_OK;
@@ -88,6 +132,7 @@ extern "C" void crthip_pool_destroy(crthip_pool *p) {
 }
 
 extern "C" uint32_t crthip_pool_lanes(const crthip_pool *p) { return p ? (uint32_t)p->lanes.size() : 0; }
+extern "C" const char *crthip_pool_warning(const crthip_pool *p) { return p ? p->warning.c_str() : ""; }
 
 // plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
 static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id) {
@@ -157,11 +202,25 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	std::vector<std::atomic<uint64_t>> per_dev(p->ndevices);
 	for(auto &x : per_dev) x = 0;
 	std::atomic<int32_t> first_error{0};
+	std::atomic<uint64_t> host_ns{0}, host_steps{0};
+	// home shard first: pool device d owns the items j with j % ndevices == d (its shard is resident there), and a device without a home
+	// item takes from the others' ("stealing" in a cyclic run: it is the work list that is shared, a faster GPU simply draws more tickets)
+	std::vector<std::vector<uint32_t>> home(p->ndevices);
+	for(uint32_t j = 0; j < nitems; j++) home[j % p->ndevices].push_back(j);
+	std::vector<std::atomic<uint64_t>> home_next(p->ndevices);
+	for(auto &x : home_next) x = 0;
+	std::atomic<uint64_t> stolen{0};
+	const uint64_t poison_from = timed_end > p->lanes.size() ? timed_end - p->lanes.size() : 0;   // the last round of timed steps and the tail behind them
 	const double t_launch = now_s();
 	stamps[0] = t_launch;
 
 	auto worker = [&](uint32_t slot, uint32_t t) {
 		(void)hipSetDevice(p->devices[slot]);
+		if(!p->cpus[slot].empty()) {                             // next to the GPU: plan + launch are ~200 us of host work per step and thread
+			cpu_set_t set; CPU_ZERO(&set);
+			for(int c : p->cpus[slot]) CPU_SET(c, &set);
+			(void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (a cpuset that forbids them: stay where we are)
+		}
 		Lane *mine = &p->lanes[((size_t)slot*p->threads_per_device + t)*p->depth];
 		auto finish = [&](Lane &L) -> int {
 			const int rc = crthip_batch_sync(L.batch, L.status.data());
@@ -198,9 +257,20 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(err) break;
 			const uint64_t step = p->next.fetch_add(1);
 			if(step >= total) break;
-			const uint32_t j = (uint32_t)(step % nitems);
+			uint32_t j;
+			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
+			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
+			const auto h0 = std::chrono::steady_clock::now();
 			err = lane_plan(p, L, items[j], (int64_t)j);
+			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
+			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
+			L.poisoned = false;
+			if(!err && step >= poison_from && L.out) {
+				if(hipMemsetAsync(L.out, POISON, L.out_cap, corto_hip::ctx_stream(L.ctx)) != hipSuccess) err = ctx_fail(CRTHIP_E_DEVICE, "hipMemsetAsync(poison)");
+				else L.poisoned = true;
+			}
 			if(!err) err = crthip_batch_decode(L.batch);
+			host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count(); host_steps++;
 			if(!err) { L.busy = true; L.step = step; }
 		}
 		for(uint32_t k = 0; k < p->depth; k++) if(mine[k].busy) { const int e2 = finish(mine[k]); if(!err) err = e2; }
@@ -219,6 +289,9 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	report->steps = steps; report->triangles = tris; report->vertices = verts;
 	report->failed_blobs = failed; report->first_error = first_error; report->topology_fallbacks = fallbacks;
 	for(uint32_t d = 0; d < p->ndevices; d++) { report->steps_per_device[d] = per_dev[d]; if(per_dev[d]) report->devices_used++; }
+	for(auto &L : p->lanes) if(L.item >= 0 && L.poisoned) report->poisoned_lanes++;
+	report->host_us_per_step = host_steps ? (float)((double)host_ns/1e3/(double)host_steps) : 0.f;
+	for(uint32_t d = 0; d < p->ndevices; d++) if(!p->cpus[d].empty()) report->pinned_devices++;
 	if(completion_s) for(uint64_t c = 0; c < steps; c++) completion_s[c] = stamps[warmup + 1 + c] - stamps[warmup];
 	return CRTHIP_OK;
 }
@@ -237,7 +310,8 @@ extern "C" int64_t crthip_pool_lane_read(crthip_pool *p, uint32_t lane, uint32_t
 	int err = crthip_batch_info(L.batch, blob, &info);
 	if(err) return err;
 	const uint8_t *src = nullptr; size_t n = 0;
-	if(!strcmp(what, "index")) { if(!info.nface) return 0; src = (const uint8_t *)L.index_ptr[blob]; n = (size_t)info.nface*12; }
+	if(!strcmp(what, "#tail")) { n = L.out_cap < 256 ? L.out_cap : 256; src = (const uint8_t *)L.out + (L.out_cap - n); }   // the block's last bytes: behind every output array
+	else if(!strcmp(what, "index")) { if(!info.nface) return 0; src = (const uint8_t *)L.index_ptr[blob]; n = (size_t)info.nface*12; }
 	else {
 		for(uint32_t k = 0; k < info.nattr; k++) if(!strcmp(info.attr[k].name, what)) {
 			const crthip_attr_info &a = info.attr[k];

@@ -9,7 +9,8 @@
  *
  * Differences from upstream, at the edges only:
  *   - exceptions do not cross the C boundary: newDecoder returns NULL for a blob the reference would throw on,
- *     decode() returns without writing for a decode error; crthip_last_error() (libcorto_hip.so) has the message.
+ *     decode() returns without writing for a decode error - and so that a failed decode is not mistaken for a successful
+ *     one, ONE symbol is added to upstream's eighteen: lastError() below.
  *   - every entry point tolerates a NULL decoder (returns 0 / false / does nothing).
  *   - setColors has no default argument in C; pass 4 for RGBA (upstream's C++ default, emcorto.cpp:67).
  */
@@ -45,6 +46,10 @@ void setIndex16(crt_decoder *decoder, uint16_t *buffer);          /* :75-77 */
 void setIndex32(crt_decoder *decoder, uint32_t *buffer);          /* :79-81 */
 void decode(crt_decoder *decoder);                                /* :83-85  one-shot, like upstream */
 void deleteDecoder(crt_decoder *decoder);                         /* :87-89 */
+/* Not upstream's: 0 if the decoder's last decode() succeeded (or none ran), else the CRTHIP_E_* code (include/corto_hip.h) of what
+ * upstream would have thrown - CRTHIP_E_TOPOLOGY for "Decoding topology failed", CRTHIP_E_DEVICE without a GPU ...;
+ * lastError(NULL) = why this thread's last newDecoder() returned NULL (CRTHIP_E_MAGIC for "Not a crt file." ...). */
+int lastError(crt_decoder *decoder);
 
 #ifdef __cplusplus
 }

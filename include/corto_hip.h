@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 2   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_* */
+#define CRTHIP_ABI_VERSION 3   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_*; 3: crthip_pool_report grew, crthip_pool_warning */
 
 /* VertexAttribute::Format, include/corto/vertex_attribute.h:32 */
 enum { CRTHIP_FMT_UINT32 = 0, CRTHIP_FMT_INT32 = 1, CRTHIP_FMT_UINT16 = 2, CRTHIP_FMT_INT16 = 3,
@@ -87,6 +87,7 @@ typedef struct {
  * buffer == NULL leaves the attribute unbound: its streams are skipped, like the reference does.
  * Buffers are DEVICE pointers for the batch API (crthip_batch_*) and HOST pointers for crthip_decode_host.
  *   generic (position, uv, radius, ...): FLOAT only; nvert*components*4 bytes (decoded in place as int32 first)
+ *   FLOAT buffers must be 4-byte aligned and INT16 ones 2-byte aligned (what a float* / int16_t* is), else CRTHIP_E_ARGUMENT
  *   normal : FLOAT (nvert*3 f32) or INT16 (nvert*3 i16)
  *   color  : UINT8, out_components = 3 or 4 (>= stored components); nvert*out_components bytes        */
 typedef struct {
@@ -164,7 +165,10 @@ int crthip_batch_sync(crthip_batch *b, int32_t *status);
 int crthip_batch_done(crthip_batch *b);
 
 /* One-blob convenience with HOST output buffers: probe + plan + device decode + copy back.
- * This is what the crt::Decoder facade (include/corto/decoder.h of this repo) calls. */
+ * This is what the crt::Decoder facade (include/corto/decoder.h of this repo) calls.
+ * attrs == NULL: no attribute is bound (an index-only decode, like a Decoder nobody called set*() on).  Host buffers have
+ * upstream's tightly packed layouts: a binding with a non-zero stride is refused with CRTHIP_E_ARGUMENT (strides are for
+ * DEVICE vertex buffers, crthip_batch_bind). */
 int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
                        void *index, uint32_t index_format);
 
@@ -173,14 +177,21 @@ int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const c
  * shared), so a list of blobs shards by blob with NO collective.  The pool is that, for the GPUs of one node: `ndevices`
  * devices, `depth` batches in flight per host thread and `threads_per_device` host threads per device, every batch on its
  * own context (crthip_ctx: own HIP streams, scratch, descriptors) with its own output block in that device's HBM.  All
- * threads of all devices pull work items from ONE queue - an atomic counter over the submitted list - so a faster or less
- * loaded GPU simply takes more items: no RCCL, no peer traffic, no static assignment.
+ * threads of all devices pull tickets from ONE queue - an atomic counter - so a faster or less loaded GPU simply takes more steps:
+ * no RCCL, no peer traffic.  Which item a ticket decodes is home-shard-first: pool device d prefers the items j with
+ * j % ndevices == d (the shard resident in ITS HBM: give device_arena[d] for those and NULL elsewhere), and a device without a home
+ * item takes the others' (and uploads them, since they are not resident there).  Worker threads are pinned to the CPUs of their GPU's
+ * NUMA node when sysfs names one.
  * devices == NULL: devices 0 .. ndevices-1.  A device id may repeat (several pool "devices" on one GPU: how the N > 1 path
  * is exercised on a one-GPU box). */
 typedef struct crthip_pool crthip_pool;
 int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_t threads_per_device, uint32_t depth, crthip_pool **out);
 void crthip_pool_destroy(crthip_pool *pool);
 uint32_t crthip_pool_lanes(const crthip_pool *pool);     /* ndevices * threads_per_device * depth contexts */
+/* "" or what crthip_pool_create found wrong with the hardware queues (also printed to stderr once): every context needs a queue of
+ * its own, ROCm hands out $GPU_MAX_HW_QUEUES (default 4) per process and reads it when HIP initialises - a pool of 16 contexts on
+ * the default runs at a fraction of its rate.  Contexts are counted per physical GPU (a device id may repeat). */
+const char *crthip_pool_warning(const crthip_pool *pool);
 
 /* One work item = one batch of blobs (HOST pointers, borrowed for the duration of crthip_pool_run).
  * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step;
@@ -203,10 +214,16 @@ typedef struct {
 	uint32_t devices_used;       /* pool devices that completed at least one timed step */
 	uint64_t steps_per_device[16];
 	uint64_t topology_fallbacks;
+	uint32_t poisoned_lanes;     /* contexts whose LAST executed step started from an output block the pool had just filled with 0xA5 on the
+	                                context's stream: the last round of timed steps and the tail behind them are run that way, so what
+	                                crthip_pool_lane_read returns afterwards was written by those steps and by nothing earlier */
+	uint32_t pinned_devices;     /* pool devices whose worker threads were pinned to the CPUs of the GPU's NUMA node */
+	float host_us_per_step;      /* host time per step and thread: plan (walk + bind) + enqueue, averaged over every executed step */
+	uint32_t reserved;
 } crthip_pool_report;
 
-/* Decode items[(first_step + i) % nitems] for i in [0, warmup + steps) (+ a few more to keep every context busy until the
- * last timed completion), outputs into the contexts' own device blocks: every attribute bound in its natural format
+/* Decode warmup + steps batches drawn cyclically from the items (each device from its home items, see above; + a few more steps to
+ * keep every context busy until the last timed completion), outputs into the contexts' own device blocks: every attribute bound in its natural format
  * (generic FLOAT, normal FLOAT, colour UINT8 x 4, index UINT32).  completion_s: NULL, or `steps` doubles that receive the
  * completion time of every timed step in seconds since the start of the timed region, in completion order.
  * Blocks until everything has drained.  Returns CRTHIP_OK or the first HIP / planning error (per-blob decode failures are
@@ -216,6 +233,7 @@ int crthip_pool_run(crthip_pool *pool, uint32_t nitems, const crthip_pool_item *
 
 /* After a run every lane (context) still holds the outputs of the last step it executed: which item that was, on which pool
  * device, and a copy of one output array of one of its blobs to the host ("position", "normal", "color", "uv", ... or "index").
+ * ("#tail": the last 256 bytes of the context's output block, behind every array - 0xA5 after a run, see poisoned_lanes.)
  * Returns bytes written / the item index, or <0.  This is how bench.py and the tests check what every GPU decoded. */
 int64_t crthip_pool_lane_item(const crthip_pool *pool, uint32_t lane, uint32_t *device_slot);
 int64_t crthip_pool_lane_read(crthip_pool *pool, uint32_t lane, uint32_t blob, const char *what, void *host_out, size_t cap);

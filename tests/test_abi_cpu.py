@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(L):
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(L, n), n
-    assert L.crthip_abi_version() == 2
+    assert L.crthip_abi_version() == 3
 
 
 def test_headers_are_plain_c(tmp_path):
@@ -154,7 +154,8 @@ def test_unity_veneer_exports_and_parses_on_the_host(L):
 
 
 EM_SYMBOLS = ("newDecoder ngroups groups nvert nface hasAttr hasNormal hasColor hasUv setPositions setNormals32 setNormals16 "
-              "setColors setUvs setIndex16 setIndex32 decode deleteDecoder").split()
+              "setColors setUvs setIndex16 setIndex32 decode deleteDecoder").split()     # upstream's eighteen
+EM_EXTRA = ("lastError",)       # this repo's one addition (a failed decode must not look like a successful one)
 
 
 def em_veneer():
@@ -164,7 +165,7 @@ def em_veneer():
     E = C.CDLL(build.EMVENEER)
     E.newDecoder.restype = C.c_void_p
     E.newDecoder.argtypes = [C.c_int, C.c_void_p]
-    for nm in ("ngroups", "nvert", "nface"):
+    for nm in ("ngroups", "nvert", "nface", "lastError"):
         getattr(E, nm).restype = C.c_int
         getattr(E, nm).argtypes = [C.c_void_p]
     for nm in ("hasNormal", "hasColor", "hasUv"):
@@ -188,7 +189,7 @@ def test_js_veneer_exports_and_parses_on_the_host(L):
     include/corto/emcorto.h; the header queries (nvert, nface, groups, has*) are host-side and need no GPU"""
     hdr = open(os.path.join(ROOT, "include", "corto", "emcorto.h")).read()
     E = em_veneer()
-    for nm in EM_SYMBOLS:
+    for nm in EM_SYMBOLS + list(EM_EXTRA):
         assert re.search(r"\b%s\(" % nm, hdr), nm
         assert hasattr(E, nm), nm
     for name in ("two_groups", "cloud_border", "nrm_estimated_rgb"):
@@ -203,5 +204,8 @@ def test_js_veneer_exports_and_parses_on_the_host(L):
         E.deleteDecoder(d)
     junk = aligned(np.zeros(64, dtype=np.uint8))
     assert not E.newDecoder(len(junk), junk.ctypes.data)
+    assert E.lastError(None) == -2            # CRTHIP_E_MAGIC: "Not a crt file." (src/decoder.cpp:51)
+    assert not E.newDecoder(len(junk) - 1, junk.ctypes.data + 1)
+    assert E.lastError(None) == -1            # CRTHIP_E_ALIGN (src/decoder.cpp:44)
     assert E.nvert(None) == 0 and E.ngroups(None) == 0 and not E.hasUv(None)
     E.decode(None); E.deleteDecoder(None)

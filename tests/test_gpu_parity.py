@@ -1164,3 +1164,122 @@ def test_config4_256_distinct_blobs(ctx):
     want = np.sort(np.trunc(meshes[77].position / np.float32(q)).astype(np.int64).view([("", np.int64)] * 3), axis=0)
     have = np.sort(np.rint(got["position"] / np.float32(q)).astype(np.int64).view([("", np.int64)] * 3), axis=0)
     assert np.array_equal(want, have)
+
+
+def test_misaligned_float_and_int16_buffers_are_refused(ctx):
+    """a packed generic buffer doubles as int32 workspace and leaves K-DELTA as floats through dword / 16-byte stores: a FLOAT binding
+    that is not 4-byte aligned (INT16 normals: 2) is refused at bind time - never decoded into something else"""
+    import ctypes as C
+    import torch
+    g = load_golden("c4_unit")
+    blob = aligned(g["crt"])
+    L = ca.lib()
+    b = ca.Batch(ctx, [blob])
+    b.allocate_outputs()
+    info = b.infos[0]
+    attrs = info.attrs()
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    for which, fmt, off, want in (("position", ca.FMT_FLOAT, 2, -8), ("uv", ca.FMT_FLOAT, 1, -8), ("normal", ca.FMT_FLOAT, 2, -8), ("normal", ca.FMT_INT16, 1, -8),
+                                  ("position", ca.FMT_FLOAT, 4, 0), ("normal", ca.FMT_INT16, 2, 0), ("color", ca.FMT_UINT8, 3, 0)):
+        binds = (ca.AttrBinding * len(attrs))()
+        for k, a in enumerate(attrs):
+            binds[k].buffer = buf.data_ptr() + 65536 * k + (off if a["name"] == which else 0)
+            binds[k].format = fmt if a["name"] == which else (ca.FMT_UINT8 if a["name"] == "color" else ca.FMT_FLOAT)
+            binds[k].out_components = 4 if a["name"] == "color" else 0
+        rc = L.crthip_batch_bind(b.handle, 0, binds, None, ca.FMT_UINT32)
+        assert rc == want, (which, fmt, off, rc)
+    b.close()
+
+
+def test_decode_host_without_bindings_and_with_a_stride(ctx):
+    """crthip_decode_host: attrs == NULL binds nothing (an index-only decode, like a Decoder nobody called set*() on); host buffers are
+    packed, so a stride is refused rather than silently ignored"""
+    import ctypes as C
+    g = load_golden("c4_unit")
+    blob = aligned(g["crt"])
+    L = ca.lib()
+    idx = np.zeros((len(g["index"]), 3), np.uint32)
+    assert L.crthip_decode_host(ctx.handle, blob.ctypes.data, len(blob), None, idx.ctypes.data, ca.FMT_UINT32) == 0
+    assert idx.tobytes() == g["index"].tobytes()
+    attrs = ca.probe(blob).attrs()
+    binds = (ca.AttrBinding * len(attrs))()
+    pos = np.zeros((len(g["position"]), 4), np.float32)
+    for k, a in enumerate(attrs):
+        if a["name"] == "position":
+            binds[k].buffer = pos.ctypes.data; binds[k].format = ca.FMT_FLOAT; binds[k].stride = 16
+    assert L.crthip_decode_host(ctx.handle, blob.ctypes.data, len(blob), binds, None, ca.FMT_UINT32) == -8
+    assert not pos.any()
+    for k, a in enumerate(attrs):
+        binds[k].stride = 0
+    pos3 = np.zeros((len(g["position"]), 3), np.float32)
+    for k, a in enumerate(attrs):
+        if a["name"] == "position":
+            binds[k].buffer = pos3.ctypes.data
+    assert L.crthip_decode_host(ctx.handle, blob.ctypes.data, len(blob), binds, None, ca.FMT_UINT32) == 0
+    assert pos3.tobytes() == g["position"].tobytes()
+
+
+def test_js_veneer_reports_a_failed_decode(ctx):
+    """upstream's decode() throws across the wasm boundary; here it returns, and lastError() (this repo's one addition to the eighteen
+    symbols) says what upstream would have thrown - a failed decode is not mistaken for a successful one"""
+    from test_abi_cpu import em_veneer
+    E = em_veneer()
+    g = load_golden("c4_unit")
+    good = aligned(g["crt"])
+    bad = aligned(g["crt"].copy())
+    probs = int(ca.probe(bad).body_offset) + 9 + 4 + 1            # the CLERS stream's probability table: symbols no automaton accepts
+    bad[probs:probs + 2] = (7, 255)
+    for blob, want in ((bad, -5), (good, 0), (bad, -5)):
+        d = E.newDecoder(len(blob), blob.ctypes.data)
+        assert d and E.lastError(d) == 0
+        nv, nf = E.nvert(d), E.nface(d)
+        pos = np.zeros((nv, 3), np.float32); idx = np.zeros((nf, 3), np.uint32)
+        E.setPositions(d, pos.ctypes.data); E.setIndex32(d, idx.ctypes.data)
+        E.decode(d)
+        assert E.lastError(d) == want, want
+        if want == 0:
+            assert pos.tobytes() == g["position"].tobytes() and idx.tobytes() == g["index"].tobytes()
+            E.decode(d)
+            assert E.lastError(d) == 0
+        E.deleteDecoder(d)
+
+
+def test_pool_poisons_outputs_before_the_last_steps(c5_blobs):
+    """what crthip_pool_lane_read returns after a run was written by the run's last steps: the pool fills every context's output block with
+    0xA5 (on the context's own stream) before each step of the last round, and says how many contexts ended that way; a byte between two
+    output arrays - never written by a decode - still holds the poison, the arrays hold the oracle's bytes"""
+    items = [c5_blobs[300:332], c5_blobs[900:932]]
+    pool = ca.Pool([0], threads=2, depth=2)
+    arenas = [[ca.upload_arena(it, 0)] for it in items]
+    rep, _ = pool.run(items, steps=24, warmup=4, arenas=arenas)
+    assert rep.failed_blobs == 0 and rep.poisoned_lanes == pool.lanes == 4
+    assert rep.host_us_per_step > 0
+    for lane in range(pool.lanes):
+        it, _slot = pool.lane_item(lane)
+        ref = oc.decode(items[it][5])
+        got = pool.lane_read(lane, 5, "position", np.float32, ref["nvert"] * 3)
+        assert got.tobytes() == ref["position"].tobytes()
+        assert (pool.lane_read(lane, 0, "#tail", np.uint8, 256) == 0xA5).all()
+    assert isinstance(pool.warning, str)
+    pool.close()
+
+
+@pytest.mark.timeout(600)
+def test_bench_eight_pool_devices_on_one_gpu():
+    """`python bench.py --gpus 8` end to end without eight GPUs ($BENCH_SHARE_GPU=1: eight pool devices on this box's one GPU): the
+    single-process launch form really runs eight devices - config C5's eight shards, each resident on its home device only, one
+    ticket queue - and every one of them decodes.  The line is the driver's contract: one JSON object, n_gpus 8."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--no-cpu", "--no-tunstall-scaled",
+                          "--no-other-configs", "--sustain", "0.3", "--host-threads", "1", "--depth", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 8 and j["shared_gpu"] is True and j["bit_exact"] is True
+    assert len(j["steps_per_device"]) == 8 and all(x > 0 for x in j["steps_per_device"]), j["steps_per_device"]
+    assert j["poisoned_lanes"] == 16 and j["config"]["launch"] == "single-process-queue"
+    assert j["host_us_per_step_per_thread"] > 0 and j["sustained"]["seconds"] >= 0.3

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash tools/prof_run.sh <tag>
 # writes rocprofv3 summaries under gpurun_out/prof_<tag>; the ones to be judged are copied into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -24,8 +24,10 @@ for tag in ("pmc1", "pmc_fetch", "pmc_write"):
             k = r["Kernel_Name"].split("(")[0]; acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
         for k, v in acc.items():
             out.setdefault(k, {}).update({c: x / len(n[k]) for c, x in v.items()}); out[k]["dispatches_" + tag] = len(n[k])
+import sys; sys.path.insert(0, "."); import bench
+out["_sources_sha256"] = bench.sources_sha256()          # ties the counters to the kernels they were taken from (bench.py refuses a mismatch)
 json.dump(out, open("$OUT/pmc_per_dispatch.json", "w"), indent=1)
 for k, v in out.items():
-    print(k, {c: round(x, 1) for c, x in v.items()})
+    if isinstance(v, dict): print(k, {c: round(x, 1) for c, x in v.items()})
 PY
 tail -1 $OUT/bench_trace.log | cut -c1-200

@@ -18,6 +18,8 @@ for tag in ("p1","p2","p3","p4"):
             if "tun" in k:
                 print(tag, k, len(n[k]), {c: round(x/len(n[k]),1) for c, x in v.items()})
                 out.setdefault(k, {}).update({c: x/len(n[k]) for c, x in v.items()}); out[k]["dispatches_" + tag] = len(n[k])
+import sys; sys.path.insert(0, "."); import bench
+out["_sources_sha256"] = bench.sources_sha256()          # ties the counters to the kernels they were taken from (bench.py refuses a mismatch)
 json.dump(out, open("$OUT/pmc_per_dispatch.json", "w"), indent=1)
 PY
 tail -1 $OUT/l1.log | cut -c1-300
