@@ -556,7 +556,9 @@ def main():
 
     # secondary (SURVEY 8d's host-resident variant; never `value`): the same pipelined steps with the compressed blobs starting in HOST
     # memory, uploaded over PCIe inside every step
-    fh_steps = max(20, min(args.steps, 120)) * nloc
+    # (the side legs run 600 steps whatever K is: a 120-step region of sixteen batches in flight lands anywhere within -40 / +5 % of the
+    # long-run rate - tools/leg_probe.py - and 600 steps of these take 0.1-0.15 s)
+    fh_steps = 600 * nloc
     barrier()
     rep_h, stamps_h = pool.run(items, steps=fh_steps, warmup=2 * pool.lanes, arenas=None)
     barrier()
@@ -566,7 +568,7 @@ def main():
     sustained = None
     if args.sustain > 0:
         est = max(elapsed / args.steps, 1e-6)
-        n_sus = int(min(max(args.sustain / est * 1.1, 200), 400000)) * nloc
+        n_sus = int(min(max(args.sustain / est * 1.3, 200), 400000)) * nloc
         barrier()
         rep_s, stamps_s = pool.run(items, steps=n_sus, warmup=2 * pool.lanes, arenas=arenas)
         barrier()
@@ -698,7 +700,7 @@ def main():
             "realistic": realistic,
             "sustained": sustained,
             "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool.warning or None,
-            "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1),
+            "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1), "numa_pinned_devices": int(rep.pinned_devices),
             "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "mverts_per_s": round(tris_h / elapsed_h / 1e6 * nvert / ntri, 2),
                                     "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
                                     **window_stats(stamps_h, pool.lanes),

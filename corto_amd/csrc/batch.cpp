@@ -174,6 +174,7 @@ struct BlobScratch {
 struct Plan {
 	// job arrays
 	HostArr<TunStream> tun, tun_dict; HostArr<uint32_t> tun_chunk_stream;   // tun_dict: one entry per DISTINCT probability table (shared dictionaries)
+	HostArr<uint32_t> tun_group_ids; HostArr<TunGroup> tun_groups; uint32_t clers_groups = 0;   // streams by dictionary, in groups of one dictionary each (k_tun_stream_grouped)
 	HostArr<FillJob> fill;
 	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
 	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
@@ -190,19 +191,19 @@ struct Plan {
 	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
 	uint64_t jobs_begin = 0, jobs_bytes = 0;
 	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
-	uint32_t delta_wave_lds = 0;
+	uint32_t delta_wave_lds = 0, delta16_lds = 0, delta16_groups = 0;   // (delta_groups: the k_delta_lds16 groups first, then k_delta_wave's)
 	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
 	uint32_t tun_max_nchunks = 0;
 	uint64_t total = 0;
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
 	void reset() {                                          // keep every vector's capacity
-		clr(tun); clr(tun_dict); clr(tun_chunk_stream); clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
+		clr(tun); clr(tun_dict); clr(tun_chunk_stream); clr(tun_group_ids); clr(tun_groups); clers_groups = 0; clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
 		clr(unpack); clr(unpack_chunk_job); clr(delta); clr(delta_groups); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
 		clr(nf_block_job); clr(nf_block_first); clr(normal_fused_ids); clr(dequant); clr(dequant_block_job);
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
 		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
-		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0;
+		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0; delta16_lds = 0; delta16_groups = 0;
 		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0; tun_max_nchunks = 0;
 	}
 };
@@ -240,9 +241,9 @@ struct crthip_ctx {
 	// to 16 symbols; bigger ones hardly ever repeat and are quick to build), open addressing on a hash of them
 	struct DictKey { uint8_t n, bytes[32]; };
 	std::vector<DictKey> dict_keys;
-	std::vector<uint32_t> dict_slots, dict_used, dict_ids;
+	std::vector<uint32_t> dict_slots, dict_used, dict_ids, dict_count;
 	bool delta_wide = false;                          // K-DELTA keeps 32-bit values in LDS: $CORTO_DELTA_WIDE=1, or learnt from a batch whose 16-bit relative values overflowed
-	uint32_t delta_calm = 0;
+	uint32_t delta_calm = 0, delta_patience = 256;
 };
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
@@ -269,6 +270,7 @@ struct crthip_batch {
 	crthip_batch_stats stats{};
 	std::vector<int32_t> status;
 	bool decoded = false;
+	bool planned_wide = false;          // the decode in flight was planned with K-DELTA's 32-bit layout
 };
 
 // Wait for the batch in flight on this context (if any) and move its per-blob status from the pinned landing zone into the
@@ -284,6 +286,19 @@ static int harvest(crthip_ctx *ctx) {
 	for(size_t i = 0; i < n; i++) b->status[i] = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
 	b->stats.topology_fallbacks = 0;
 	for(size_t i = 0; i < n; i++) b->stats.topology_fallbacks += (uint64_t)(hs[n + i] & 1);
+	// K-DELTA keeps values in LDS as int16 relative to vertex 0 and redoes an attribute that does not fit in HBM (slow, exact): a context
+	// that meets such blobs (positions quantised beyond 15 bits) plans its next batches with 32-bit values; a long run of batches later it
+	// tries the narrow layout again, with growing patience if that turns out wrong
+	b->stats.delta_redone = 0; b->stats.delta_walked = 0;
+	for(size_t i = 0; i < n; i++) b->stats.delta_walked += (uint32_t)(hs[2*n + 2*i + 1] != 0);
+	if(!b->planned_wide) {
+		for(size_t i = 0; i < n; i++) b->stats.delta_redone += (uint64_t)(hs[2*n + 2*i] != 0);
+		if(b->stats.delta_redone) {
+			ctx->delta_wide = true;
+			if(ctx->delta_calm == 0 && ctx->delta_patience < (1u << 20)) ctx->delta_patience *= 2;   // overflowed right after narrowing again
+			ctx->delta_calm = 0;
+		} else ctx->delta_calm = 1;                                          // (narrow and fine)
+	} else if(!ctx->dbg.delta_wide && ++ctx->delta_calm >= ctx->delta_patience) { ctx->delta_wide = false; ctx->delta_calm = 0; }
 	// more than one blob in twenty redone on the HBM front (5x slower): four times the edge slots from the next batch on;
 	// a long run without any: try half again, and be more patient the next time that turns out to be too little
 	if(b->stats.topology_fallbacks*20 > n) {
@@ -300,6 +315,12 @@ static int harvest(crthip_ctx *ctx) {
 namespace corto_hip {
 int ctx_device(crthip_ctx *ctx) { return ctx->device; }
 hipStream_t ctx_stream(crthip_ctx *ctx) { return ctx->stream; }
+int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value) {      // on the context's main stream, ordered before its next decode
+	if(!bytes) return CRTHIP_OK;
+	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+	hipLaunchKernelGGL(k_fill_block, dim3(2048), dim3(256), 0, ctx->stream, (uint8_t *)dst, (uint64_t)bytes, (uint32_t)(value & 255));
+	return hipGetLastError() == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE);
+}
 int ctx_quiesce(crthip_ctx *ctx) {
 	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
 	ctx->last_decoded = nullptr;                         // the encoder stages reuse the scratch block
@@ -333,6 +354,7 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_delta_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA_WAVE_LDS_MAX) != hipSuccess ||
+	   hipFuncSetAttribute((const void *)k_delta_lds16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA16_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_normal_blob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NORMAL_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_enc_tun_parse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_parse_lds(ENC_TRIE_LDS_MAX)) != hipSuccess) {
 		crthip_ctx_destroy(c); return fail(CRTHIP_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -539,12 +561,22 @@ static int32_t f2i_x86_host(float x) {
 } // namespace
 
 
-// launch classes of K-DELTA: 2 = values + prediction graph fit LDS, one wave (k_delta_wave); else the stretch walk over HBM (k_delta_mesh), 0 = large, 1 = small
+// launch classes of K-DELTA: values + prediction graph fit LDS, one wave per attribute - 2: as int16 relative to vertex 0 (k_delta_lds16, k_delta.hip),
+// 3: as int32 (k_delta_wave: contexts that met values beyond int16, attributes of more than four components); else the stretch walk over HBM
+// (k_delta_mesh), 0 = large, 1 = small
 static inline uint64_t delta_wave_need(const DeltaJob &d) {           // alone in a workgroup; ~0 wraps to "too big"
 	const uint64_t g = delta_wave_graph_lds(d.nvert), a = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
 	return g == ~0ull || a == ~0ull ? ~0ull : g + a;
 }
-static inline int delta_class(const DeltaJob &d) { return delta_wave_need(d) <= DELTA_WAVE_LDS_MAX ? 2 : d.nvert > DELTA_SMALL_NVERT ? 0 : 1; }
+static inline bool delta16_hosts_a(const DeltaJob &d) { return !d.is_u8 && d.N == 3; }
+static inline uint64_t delta16_need(const DeltaJob &d) {
+	if(d.nvert > DELTA16_NVERT_MAX || d.N < 1 || d.N > 4) return ~0ull;
+	return (uint64_t)delta16_vbytes(d.nvert, d.N, d.is_u8 != 0) + delta16_graph_lds(d.nvert, delta16_hosts_a(d));
+}
+static inline int delta_class(const DeltaJob &d, bool wide) {
+	if(!wide && delta16_need(d) <= DELTA16_LDS_MAX) return 2;
+	return delta_wave_need(d) <= DELTA_WAVE_LDS_MAX ? 3 : d.nvert > DELTA_SMALL_NVERT ? 0 : 1;
+}
 static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 32767 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
 struct Launch {
@@ -588,6 +620,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	pl.reset();
 	Carver cv;
 	const uint32_t nblobs = (uint32_t)b->blobs.size();
+	const bool wide = ctx->delta_wide;                                     // K-DELTA with 32-bit values in LDS (this context met values beyond int16)
 	const uint8_t *arena = b->d_arena;
 
 	// ---- pass 1: sizes & offsets (device addresses are scratch_base + offset, resolved in pass 2) ----
@@ -629,10 +662,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 		for(size_t k = 0; k < L.attrs.size(); k++) {
 			if(!P.bind[k].buffer) continue;
 			const AttrHeader &a = L.h.attrs[k];
-			const bool u8 = a.codec == CRTHIP_CODEC_COLOR;
-			const uint32_t n = a.codec == CRTHIP_CODEC_NORMAL ? 2u : a.N;
-			const uint64_t g = delta_wave_graph_lds(L.h.nvert), w = delta_wave_attr_lds(L.h.nvert, n, u8);
-			if(g == ~0ull || w == ~0ull || g + w > DELTA_WAVE_LDS_MAX)          // k_delta_mesh: fired flags (zeroed) + the list of stretch starts behind them
+			DeltaJob probe{};
+			probe.nvert = L.h.nvert; probe.N = a.codec == CRTHIP_CODEC_NORMAL ? 2u : a.N; probe.is_u8 = a.codec == CRTHIP_CODEC_COLOR;
+			if(delta_class(probe, wide) <= 1)                                     // k_delta_mesh: fired flags (zeroed) + the list of stretch starts behind them
 				bs[i].attr[k].fired = cv.take((((uint64_t)L.h.nvert + 15) & ~15ull) + 4ull*L.h.nvert + 16, 16);
 		}
 	}
@@ -693,8 +725,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 	// ---- pass 2: job structs with offsets stored in pointer fields (rebased after the block is reserved) ----
 	// To keep one pass, pointers are built as (uint8_t*)offset and fixed up by adding the scratch base.
 	auto SP = [](uint64_t off) { return (uint8_t *)(uintptr_t)off; };   // scratch-relative pseudo pointer
-	if((size_t)nblobs*8 + 16 > ctx->status_host.cap && harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);   // the block is about to move: the batch in flight writes to it
-	if(ctx->status_host.reserve((size_t)nblobs*8 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	// four words a blob: status | automaton flags (bit 0: redone on the HBM front) | K-DELTA: {an attribute's values left int16, an attribute took the walk}
+	if((size_t)nblobs*16 + 16 > ctx->status_host.cap && harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);   // the block is about to move: the batch in flight writes to it
+	if(ctx->status_host.reserve((size_t)nblobs*16 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 	int32_t *const hs_base = (int32_t *)ctx->status_host.p;
 	auto HS = [&](uint64_t k) { return (int32_t *)((uintptr_t)(hs_base + k) | (1ull << 63)); };   // real pointer (bit 63: R() leaves it alone)
 
@@ -869,7 +902,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->dbg.delta_walk;   // pad[1]: experiments - the flag-driven walk only
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
-					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d) == 2 && !ctx->dbg.no_deq_fold) {
+					d.flags = HS(2ull*nblobs + 2ull*i);
+					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2 && !ctx->dbg.no_deq_fold) {
 						if(a.codec == CRTHIP_CODEC_COLOR) {
 							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;
 							for(int c = 0; c < 4; c++) d.qc[c] = as.qc[c];
@@ -930,6 +964,28 @@ static int build_and_launch_inner(crthip_batch *b) {
 			}
 		}
 	}
+	// streams of a launch that share dictionaries: sorted by dictionary (counting sort), cut into groups of one dictionary each
+	const uint32_t ntun_all = (uint32_t)pl.tun.v.size(), ndict_all = (uint32_t)pl.tun_dict.v.size();
+	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { return ctx->dbg.tun_share == 1 ? ndicts < nstreams : ctx->dbg.tun_share != 0 && nstreams >= 64 && 2*ndicts <= nstreams; };
+	const bool share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict), share_attrs = !pl.tun_multi_chunk && shares(ntun_all - clers_tun, ndict_all - clers_dict);
+	{
+		std::vector<uint32_t> &cnt = ctx->dict_count;
+		auto group_range = [&](uint32_t t0, uint32_t t1, uint32_t d0, uint32_t d1) {
+			if(t1 <= t0) return;
+			cnt.assign((size_t)(d1 - d0) + 1, 0u);
+			for(uint32_t t = t0; t < t1; t++) cnt[pl.tun.v[t].dict - d0 + 1]++;
+			for(uint32_t d = 1; d <= d1 - d0; d++) cnt[d] += cnt[d - 1];
+			const uint32_t base = (uint32_t)pl.tun_group_ids.v.size();
+			pl.tun_group_ids.v.resize((size_t)base + (t1 - t0));
+			for(uint32_t d = 0; d < d1 - d0; d++)                                 // (cnt[d] .. cnt[d + 1]: the dictionary's slots; groups before the fill moves the cursors)
+				for(uint32_t k = cnt[d]; k < cnt[d + 1]; k += TUN_GROUP_MAX) pl.tun_groups.v.push_back(TunGroup{base + k, std::min(TUN_GROUP_MAX, cnt[d + 1] - k)});
+			for(uint32_t t = t0; t < t1; t++) pl.tun_group_ids.v[base + cnt[pl.tun.v[t].dict - d0]++] = t;
+		};
+		if(share_clers) group_range(0, clers_tun, 0, clers_dict);
+		pl.clers_groups = (uint32_t)pl.tun_groups.v.size();
+		if(share_attrs) group_range(clers_tun, ntun_all, clers_dict, ndict_all);
+	}
+
 	// block maps of the normal jobs (per vertex / per face, 256 per block)
 	for(uint32_t j = 0; j < pl.normal.v.size(); j++) {
 		const NormalJob &n = pl.normal.v[j];
@@ -946,26 +1002,43 @@ static int build_and_launch_inner(crthip_batch *b) {
 	pl.jobs_begin = cv.take(0);
 	pl.unpack_partial_off = cv.take(unpack_state_words*8, 16);           // (first thing in the uploaded block: zeros)
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
-	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
+	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.tun_group_ids); place(pl.tun_groups); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) == 0; });
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [](const DeltaJob &d) { return delta_class(d) <= 1; });
-	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph (k_delta_wave): consecutive
-		// class-2 jobs with the same prediction array, up to DELTA_GROUP_MAX
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) == 0; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 1; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 2; });
+	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph: consecutive jobs of one class with
+		// the same prediction array, up to DELTA_GROUP_MAX.  Class 2 groups first (k_delta_lds16), then class 3 (k_delta_wave).
 		size_t j = 0;
-		while(j < pl.delta.v.size() && delta_class(pl.delta.v[j]) != 2) j++;
+		while(j < pl.delta.v.size() && delta_class(pl.delta.v[j], wide) < 2) j++;
+		const uint32_t gmax_ = ctx->dbg.delta_group ? ctx->dbg.delta_group : DELTA_GROUP_MAX;
 		while(j < pl.delta.v.size()) {
 			const DeltaJob &d0 = pl.delta.v[j];
-			uint64_t lds = delta_wave_need(d0);
+			const int cls = delta_class(d0, wide);
 			DeltaGroup g{(uint32_t)j, 1};
-			const uint32_t gmax_ = ctx->dbg.delta_group ? ctx->dbg.delta_group : DELTA_GROUP_MAX;
-			while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
-				const DeltaJob &d = pl.delta.v[j + g.count];
-				const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
-				if(d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;
-				lds += more; g.count++;
+			if(cls == 2) {
+				uint64_t vals = delta16_vbytes(d0.nvert, d0.N, d0.is_u8 != 0);
+				bool hosted = delta16_hosts_a(d0);
+				while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
+					const DeltaJob &d = pl.delta.v[j + g.count];
+					if(delta_class(d, wide) != 2 || d.pred != d0.pred || d.nvert != d0.nvert) break;
+					const uint64_t more = delta16_vbytes(d.nvert, d.N, d.is_u8 != 0);
+					const bool h2 = hosted || delta16_hosts_a(d);
+					if(vals + more + delta16_graph_lds(d0.nvert, h2) > DELTA16_LDS_MAX) break;
+					vals += more; hosted = h2; g.count++;
+				}
+				pl.delta16_lds = std::max<uint32_t>(pl.delta16_lds, (uint32_t)(vals + delta16_graph_lds(d0.nvert, hosted)));
+				pl.delta16_groups++;
+			} else {
+				uint64_t lds = delta_wave_need(d0);
+				while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
+					const DeltaJob &d = pl.delta.v[j + g.count];
+					const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
+					if(d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;
+					lds += more; g.count++;
+				}
+				pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)lds);
 			}
-			pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)lds);
 			pl.delta_groups.v.push_back(g);
 			j += g.count;
 		}
@@ -1002,7 +1075,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		if(!(u.out_u8 & 0x80)) u.out = R(u.out);
 		u.out_u8 &= 0x7F;
 	}
-	for(auto &d : pl.delta.v) { if(!d.pad[0]) d.values = R(d.values); d.pad[0] = 0; d.pred = (const uint32_t *)R(d.pred); if(d.fired) d.fired = R(d.fired); }
+	for(auto &d : pl.delta.v) { if(!d.pad[0]) d.values = R(d.values); d.pad[0] = 0; d.pred = (const uint32_t *)R(d.pred); if(d.fired) d.fired = R(d.fired); d.flags = (int32_t *)R(d.flags); }
 	for(auto &c : pl.cloud.v) { if(!c.pad[0]) c.values = R(c.values); c.pad[0] = 0; }
 	for(auto &n : pl.normal.v) {
 		n.diffs = (int32_t *)R(n.diffs); n.status = (int32_t *)R(n.status);
@@ -1016,9 +1089,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 	// host image -> device (one copy)
 	uint8_t *stage = (uint8_t *)ctx->staging.p;
 	memset(stage + (pl.unpack_partial_off - pl.jobs_begin), 0, unpack_state_words*8);
-	memset(ctx->status_host.p, 0, (size_t)nblobs*8);                       // (after the harvest above: the previous batch's words have been read)
+	memset(ctx->status_host.p, 0, (size_t)nblobs*16);                       // (after the harvest above: the previous batch's words have been read)
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
-	put(pl.tun); put(pl.tun_dict); put(pl.tun_chunk_stream); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
+	put(pl.tun); put(pl.tun_dict); put(pl.tun_chunk_stream); put(pl.tun_group_ids); put(pl.tun_groups); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
 	put(pl.delta); put(pl.delta_groups); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
@@ -1038,9 +1111,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 	const uint32_t ntun = (uint32_t)pl.tun.v.size();
 	const uint32_t nfill = (uint32_t)pl.fill.v.size();
 	const uint32_t ndict = (uint32_t)pl.tun_dict.v.size();
-	// a launch's streams share dictionaries when at least half of them repeat another one's table (and there are enough of them for it to matter)
-	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { return ctx->dbg.tun_share == 1 ? ndicts < nstreams : ctx->dbg.tun_share != 0 && nstreams >= 64 && 2*ndicts <= nstreams; };
-	const bool share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict), share_attrs = !pl.tun_multi_chunk && shares(ntun - clers_tun, ndict - clers_dict);
+	// (a launch's streams share dictionaries when at least half of them repeat another one's table and there are enough of them for it to
+	// matter: share_clers / share_attrs, decided where the groups were made)
 	stat_dicts = (share_clers ? clers_dict : clers_tun) + (share_attrs ? ndict - clers_dict : ntun - clers_tun);
 	auto tunstall = [&](hipStream_t s, uint32_t t0, uint32_t t1, uint32_t c0, uint32_t c1, uint32_t f0, uint32_t f1) {
 		if(t1 > t0) {                                        // every stream here is one chunk: one wave per stream
@@ -1051,7 +1123,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 			if(share) {                                        // distinct tables first, then every stream decodes from its (shared) dictionary
 				const uint32_t d0 = has_clers ? 0u : clers_dict, d1 = has_attrs ? ndict : clers_dict;
 				LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(d1 - d0), dim3(64), 0, s, D(pl.tun_dict) + d0, d1 - d0, tables, (uint64_t *)nullptr, 0u); LT.end();
-				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream_shared, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0, tables); LT.end();
+				const uint32_t g0 = has_clers ? 0u : pl.clers_groups, g1 = has_attrs ? (uint32_t)pl.tun_groups.v.size() : pl.clers_groups;
+				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream_grouped, dim3(g1 - g0), dim3(256), 0, s, D(pl.tun), D(pl.tun_group_ids), D(pl.tun_groups) + g0, g1 - g0, tables); LT.end();
 			} else {                                           // dictionary + decode in one kernel
 				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream, dim3(t1 - t0), dim3(64), 0, s, D(pl.tun) + t0, t1 - t0); LT.end();
 			}
@@ -1066,7 +1139,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		if(!pl.topo_lds_ids.v.empty() || !pl.topo_big_ids.v.empty()) {
 			LT.begin("topology_lds");
 			if(!pl.topo_big_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_big_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_big_lds, st, D(pl.topo), D(pl.topo_big_ids), nj); }
-			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); }
+			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), std::min(pl.topo_lds + ctx->dbg.lds_pad_topo, TOPO_LDS_MAX), st, D(pl.topo), D(pl.topo_lds_ids), nj); }
 			LT.end();
 		}
 		if(!pl.topo_glob_ids.v.empty()) {
@@ -1105,12 +1178,14 @@ static int build_and_launch_inner(crthip_batch *b) {
 		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
-		uint32_t ncls[3] = {0, 0, 0};
-		for(auto &d : pl.delta.v) ncls[delta_class(d)]++;
+		uint32_t ncls[4] = {0, 0, 0, 0};
+		for(auto &d : pl.delta.v) ncls[delta_class(d, wide)]++;
+		const uint32_t ng16 = pl.delta16_groups, ng32 = (uint32_t)pl.delta_groups.v.size() - ng16;
 		LT.begin("delta_mesh");
 		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
 		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
-		if(ncls[2]) hipLaunchKernelGGL(k_delta_wave, dim3((uint32_t)pl.delta_groups.v.size()), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups), (uint32_t)pl.delta_groups.v.size());
+		if(ng16) hipLaunchKernelGGL(k_delta_lds16, dim3(ng16), dim3(256), std::min(pl.delta16_lds + ctx->dbg.lds_pad_delta, DELTA16_LDS_MAX), st, D(pl.delta), D(pl.delta_groups), ng16);
+		if(ng32) hipLaunchKernelGGL(k_delta_wave, dim3(ng32), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups) + ng16, ng32);
 		LT.end();
 	}
 	if(cloud_chunks) {
@@ -1121,7 +1196,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	const uint32_t nvb = (uint32_t)pl.nv_block_job.v.size(), nfb = (uint32_t)pl.nf_block_job.v.size();
 	if(!pl.normal_fused_ids.v.empty()) {
 		const uint32_t nj = (uint32_t)pl.normal_fused_ids.v.size();
-		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), pl.normal_fused_lds, st, D(pl.normal), D(pl.normal_fused_ids), nj, pl.normal_fused_lds); LT.end();
+		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), std::min(pl.normal_fused_lds + ctx->dbg.lds_pad_normal, NORMAL_LDS_MAX), st, D(pl.normal), D(pl.normal_fused_ids), nj, pl.normal_fused_lds); LT.end();
 	}
 	if(pl.any_est_normal) {
 		float *facen = (float *)(base + pl.facen_off);
@@ -1154,7 +1229,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	// stats
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
 	b->stats.scratch_bytes = pl.total;
-	b->stats.topology_scale = ctx->topo_scale;
+	b->stats.topology_scale = ctx->topo_scale; b->stats.delta_wide = wide ? 1u : 0u;
 	uint64_t ob = 0;
 	for(auto &P : b->blobs) {
 		const BlobLayout &L = P.L;
@@ -1169,7 +1244,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	}
 	b->stats.output_bytes = ob;
 	ctx->in_flight = b; ctx->last_decoded = b;
-	b->decoded = true;
+	b->decoded = true; b->planned_wide = wide;
 	b->dirty = false;
 	t3 = now_us();
 	b->stats.host_plan_us = (float)(t1 - t0); b->stats.host_stage_us = (float)(t2 - t1); b->stats.host_launch_us = (float)(t3 - t2);

@@ -47,6 +47,10 @@ inline void tun_pick_geometry(TunStream &t, uint32_t chunk_cap = TUN_CHUNK_CODES
 	t.nchunks = (t.csize + codes - 1)/codes;
 }
 
+// streams [first, first + count) of the launch's by-dictionary order (an index array): all of one dictionary, decoded by one workgroup
+struct TunGroup { uint32_t first, count; };
+constexpr uint32_t TUN_GROUP_MAX = 8;
+
 struct FillJob { uint8_t *dst; uint32_t size; uint32_t value; };
 
 // CLERS automaton input/output of one mesh blob (src/decoder.cpp:204-358)
@@ -102,6 +106,7 @@ struct DeltaJob {
 	uint32_t qc[4];
 	void *out;                     // colour destination
 	uint32_t out_components, out_stride;
+	int32_t *flags;                // k_delta_lds16: set to 1 when the attribute's values relative to vertex 0 left int16 and were redone in HBM
 };
 
 // point-cloud running sum, one job per (blob, attribute) (vertex_attribute.h:177-181, normal_attribute.cpp:202-207)

@@ -39,5 +39,6 @@ int ctx_fail(int code, const char *msg);
 int ctx_device(crthip_ctx *ctx);
 hipStream_t ctx_stream(crthip_ctx *ctx);
 int ctx_quiesce(crthip_ctx *ctx);       // wait for whatever batch is in flight on the context
+int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value);   // k_fill_block on the context's main stream
 
 } // namespace corto_hip

@@ -1,0 +1,575 @@
+// k_delta.hip — K-DELTA for blobs whose values and prediction graph fit LDS (round 3): v[i] += v[a] + v[b] - v[c] (or += v[a]) for
+// i = 1 .. nvert-1 in index order (include/corto/vertex_attribute.h:160-176, src/normal_attribute.cpp:193-201).
+//
+// One workgroup per blob, one wave per attribute (up to four) sharing the prediction graph, like k_delta_wave (k_mesh.hip), which
+// stays as the wide path.  What is different here:
+//
+// * Values live in LDS as 16-BIT integers RELATIVE TO VERTEX 0.  The recurrence is affine with weights +1 +1 -1, so subtracting
+//   vertex 0's value from every vertex leaves it unchanged: rel[i] = d[i] + rel[a] + rel[b] - rel[c].  A mesh quantised to n bits
+//   spans 2^n steps whatever its offset from the origin, so up to 15 bits the relative values fit an int16 - but the header does
+//   not say so (no bounds, no bit count), hence it is CHECKED, not assumed: every raw delta and every result must fit, all sums
+//   are formed in 32-bit registers from sign-extended operands (mod 2^32, the reference's int arithmetic), and by induction every
+//   stored value then IS v[i] - v[0] mod 2^32.  An attribute that does not fit (18-bit positions, a malformed stream) is redone by
+//   its wave on the 32-bit values in HBM with the same loop (slow, exact), the blob's flag word tells the host, and the context plans
+//   its next batches on the wide kernel.  A C4 blob's three attributes + graph: 42 KB of LDS instead of 64.
+//   Colours are bytes with the reference's mod-256 arithmetic: four to a dword, no base, nothing to check.
+// * The graph is 4 bytes a vertex: b | c << 15 | (a == i-1) << 30 | (value stays) << 31, and `a` as a u16 that rides in the spare
+//   halfword of a three-component attribute's 8-byte records when the group has one.
+// * ONE loop instead of scans + walk: an OUT-OF-ORDER WINDOW.  Lane l looks at vertex s + l, s = the lowest vertex not done.  A vertex
+//   can go when b, c (and a, unless it continues its predecessor's sum) are done - done = below s, or set in the 64-bit mask of the
+//   window, which is ALL the bookkeeping there is (two SGPRs: nothing above the window is ever done) - and when, if it continues its
+//   predecessor, that predecessor is done or goes in this same pass: a flood fill up the lanes, three scalar instructions.  The lanes
+//   that go form runs; each run is a prefix sum from its head (one DPP scan per component + a bpermute of the head's exclusive sum).
+//   A 4K-triangle grid takes 70 passes (the contiguous blocks of round 2: 110), a holey disc 80 (337), random diagonals 290 (572, or
+//   the walk's 174 cheaper ones) - tests/test_delta16_model_cpu.py restates the loop on the host and checks it against the oracle.
+// * The next window's graph words and raw values are fetched while the current pass gathers and scans.
+#include <hip/hip_runtime.h>
+
+#include "device_plan.h"
+#include "kernels.h"
+#include "kernels_common.h"
+
+namespace corto_hip {
+namespace {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int32_t sx16(uint32_t w) { return (int32_t)(int16_t)(uint16_t)w; }
+
+// ---- values in LDS: K = 1, 2, 3, 4 int16 components (records of 2, 4, 8, 8 bytes), K = 5: four bytes (colours) ----
+template <int K> struct LdsVal;
+template <> struct LdsVal<1> {
+	static constexpr int NC = 1; static constexpr bool CHECK = true; typedef uint32_t Raw;
+	CRT_LDS uint16_t *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[1]) { v[0] = sx16(w); }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[1], uint32_t) const { p[i] = (uint16_t)v[0]; }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return sx16((uint32_t)v); }      // what a stored value reads back as
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsVal<2> {
+	static constexpr int NC = 2; static constexpr bool CHECK = true; typedef uint32_t Raw;
+	CRT_LDS uint32_t *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[2]) { v[0] = sx16(w); v[1] = (int32_t)w >> 16; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[2], uint32_t) const { p[i] = ((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16); }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return sx16((uint32_t)v); }
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsVal<3> {                                // x | y << 16, z | a << 16: the spare halfword carries the graph's `a`
+	static constexpr int NC = 3; static constexpr bool CHECK = true; typedef u32x2 Raw;
+	CRT_LDS u32x2 *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[3]) { v[0] = sx16(w.x); v[1] = (int32_t)w.x >> 16; v[2] = sx16(w.y); }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[3], uint32_t a) const {
+		p[i] = u32x2{((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16), ((uint32_t)v[2] & 0xFFFFu) | (a << 16)};
+	}
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return sx16((uint32_t)v); }
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsVal<4> {
+	static constexpr int NC = 4; static constexpr bool CHECK = true; typedef u32x2 Raw;
+	CRT_LDS u32x2 *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[4]) { v[0] = sx16(w.x); v[1] = (int32_t)w.x >> 16; v[2] = sx16(w.y); v[3] = (int32_t)w.y >> 16; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[4], uint32_t) const {
+		p[i] = u32x2{((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16), ((uint32_t)v[2] & 0xFFFFu) | ((uint32_t)v[3] << 16)};
+	}
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return sx16((uint32_t)v); }
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsVal<5> {                                // bytes, mod 256 (ColorAttr: uchar arithmetic)
+	static constexpr int NC = 4; static constexpr bool CHECK = false; typedef uint32_t Raw;
+	CRT_LDS uint32_t *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[4]) { v[0] = (int32_t)(w & 255u); v[1] = (int32_t)((w >> 8) & 255u); v[2] = (int32_t)((w >> 16) & 255u); v[3] = (int32_t)(w >> 24); }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[4], uint32_t) const {
+		p[i] = ((uint32_t)v[0] & 255u) | (((uint32_t)v[1] & 255u) << 8) | (((uint32_t)v[2] & 255u) << 16) | ((uint32_t)v[3] << 24);
+	}
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return (int32_t)((uint32_t)v & 255u); }
+	__device__ __forceinline__ void sync() const {}
+};
+
+// ---- values in HBM, as the caller / the bit-unpack left them (the redo path of an attribute whose relative values left int16): any
+// N <= 4, int32 or bytes.  Loads bypass the CU's cache (agent scope) and a pass's stores are waited for before the next pass reads.
+template <typename T> struct GlobalVal {
+	static constexpr int NC = 4; static constexpr bool CHECK = false;
+	struct Raw { uint32_t v[4]; };
+	CRT_GLOBAL T *p; uint32_t N;
+	__device__ __forceinline__ Raw raw(uint32_t i) const {
+		Raw r;
+#pragma unroll
+		for(uint32_t q = 0; q < 4; q++) r.v[q] = q < N ? (uint32_t)__hip_atomic_load(p + (size_t)i*N + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		return r;
+	}
+	__device__ __forceinline__ static void unpack(const Raw &w, int32_t (&v)[4]) { v[0] = (int32_t)w.v[0]; v[1] = (int32_t)w.v[1]; v[2] = (int32_t)w.v[2]; v[3] = (int32_t)w.v[3]; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[4], uint32_t) const {
+#pragma unroll
+		for(uint32_t q = 0; q < 4; q++) if(q < N) __hip_atomic_store(p + (size_t)i*N + q, (T)v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return (int32_t)(T)v; }
+	__device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// where a vertex' `a` is: a u16 array of its own (shift 1), or the spare halfword of a three-component attribute's records (shift 3)
+struct GaRef {
+	uint32_t addr, shift;
+	__device__ __forceinline__ uint32_t get(uint32_t i) const { return *lds_at<const uint16_t>(addr + (i << shift)); }
+	__device__ __forceinline__ void put(uint32_t i, uint32_t a) const { *lds_at<uint16_t>(addr + (i << shift)) = (uint16_t)a; }
+};
+
+constexpr uint32_t GW_CHAINED = 1u << 30, GW_STAYS = 1u << 31, GW_NO_BC = 0x3FFFFFFFu;
+
+// The window loop.  `base`: what a vertex whose value stays (malformed triple) has to give up to become relative (0 for bytes / HBM).
+// Returns the OR over every stored component of (value + 0x8000): anything at or above bit 16 = a value left int16.
+// `hand`: null, or where to leave (s, window mask) when the loop gives up in favour of the walk below - decided ONCE, at pass 24, from what
+// passes 8 .. 23 looked like: the walk's parallelism is the number of stretches that can advance at the same time, which is what the
+// window sees as HEADS per pass; a pass of either loop costs about the same on the GPU (0.4-0.5 us: the walk's is straight-line but has
+// eleven LDS reads and its bookkeeping), so what counts is passes: the walk's are the DAG's depth (3.5 sqrt(n) on sphere-like meshes), the
+// window's are n / (lanes going per pass).  At least two heads a pass and at most fourteen lanes going a pass says walk: random diagonals
+// (three heads, 9-11 going: 292 window passes against 24 + 150) - not rings (one head), grids (25-29 going), or holey discs (five to nine
+// heads but 20 going: 80 passes against 24 + 68).  tests/test_delta16_model_cpu.py has the families this was read off.
+struct WindowHand { uint32_t s; uint64_t donew; };
+template <class V>
+__device__ __forceinline__ uint32_t delta_window_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, const uint32_t nvert, const bool para,
+                                                    const int32_t (&base)[V::NC], WindowHand *hand = nullptr) {
+	constexpr int NC = V::NC;
+	const uint32_t lane = lane_id();
+	const uint64_t lane_le = (2ull << lane) - 1ull;                          // lanes 0 .. mine
+	const uint32_t wmask = para ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);      // v += v[a] alone: b = c = vertex 0 cancel
+	uint32_t s = 1, bad = 0;
+	uint64_t donew = 0;                                                       // bit l: vertex s + l is done (everything below s is; nothing at or above s + 64 can be)
+	uint32_t W, A; typename V::Raw D;
+	{ const uint32_t ic = s + lane < nvert ? s + lane : nvert - 1u; W = gw[ic] & wmask; A = ga.get(ic); D = val.raw(ic); }
+	uint32_t passes = 0, nheads = 0, ngo = 0;
+	if(hand) { hand->s = nvert; hand->donew = 0; }
+	while(s < nvert) {
+		if(hand && passes == 24u && nheads >= 32u && ngo <= 224u && nvert - s >= 128u) { hand->s = s; hand->donew = donew; break; }
+		const uint32_t i = s + lane;
+		const bool in = i < nvert;
+		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
+		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (W & GW_NO_BC) == GW_NO_BC;
+		const uint64_t d1 = (donew << 1) | 1ull;                              // bit r: vertex s - 1 + r is done (r = 0 stands for everything below the window)
+		auto ready = [&](uint32_t x) -> uint32_t { const int32_t r = (int32_t)(x - s) + 1; return (uint32_t)(d1 >> (uint32_t)(r > 0 ? r : 0)) & 1u; };   // (x < i: r <= 63)
+		const bool done_i = __builtin_amdgcn_inverse_ballot_w64(donew), pred_done = __builtin_amdgcn_inverse_ballot_w64(d1);
+		const bool H = stays || !ch || pred_done;                             // starts a sum of its own: its v[a] is fetched, not scanned in
+		const uint32_t rdy = stays ? 1u : (ready(b) & ready(c) & (ch ? 1u : ready(A)));
+		const bool R = in && !done_i && rdy != 0;
+		const uint64_t Rm = __ballot(R), Sm = __ballot(R && H);
+		// the lanes that go: flood fill from the heads (Sm) up through consecutive ready lanes that continue their predecessor - adding the
+		// heads to the ready mask ripples a carry through exactly those
+		const uint64_t G = (((Rm + Sm) ^ Rm) & Rm) | Sm;
+		const bool go = __builtin_amdgcn_inverse_ballot_w64(G), head = __builtin_amdgcn_inverse_ballot_w64(Sm);
+		if(passes >= 8u && passes < 24u) { nheads += (uint32_t)__builtin_popcountll(Sm); ngo += (uint32_t)__builtin_popcountll(G); }
+		passes++;
+		const uint64_t dn = donew | G;
+		const uint32_t t = ~dn ? (uint32_t)__builtin_ctzll(~dn) : 64u;       // lane 0 always goes: t >= 1
+		const uint32_t s_next = s + t;
+		const uint64_t donew_next = t < 64 ? dn >> t : 0ull;
+		// this pass's gathers first, then the next window's words: the gathers are what the scans wait for
+		const bool use = go && !stays;
+		const uint32_t gb = use ? b : 0u, gc = use ? c : 0u, gp = use && head ? (ch ? i - 1u : A) : 0u;
+		const typename V::Raw Bw = val.raw(gb), Cw = val.raw(gc), Pw = val.raw(gp);
+		uint32_t W2, A2; typename V::Raw D2;
+		{ const uint32_t ic = s_next + lane < nvert ? s_next + lane : nvert - 1u; W2 = gw[ic] & wmask; A2 = ga.get(ic); D2 = val.raw(ic); }
+		int32_t dv[NC], bv[NC], cv[NC], pv[NC], x[NC];
+		V::unpack(D, dv); V::unpack(Bw, bv); V::unpack(Cw, cv); V::unpack(Pw, pv);
+		uint32_t incl[NC], eh[NC];
+#pragma unroll
+		for(int q = 0; q < NC; q++) {
+			int32_t v = dv[q] + (use ? bv[q] - cv[q] + (head ? pv[q] : 0) : -base[q]);
+			x[q] = go ? v : 0;
+		}
+#pragma unroll
+		for(int q = 0; q < NC; q++) incl[q] = wave_inclusive_scan_u32((uint32_t)x[q]);
+		// my run's head = the highest head lane at or below me
+		const uint64_t hm = Sm & lane_le;
+		const uint32_t hidx = hm ? 63u - (uint32_t)__builtin_clzll(hm) : 0u;
+#pragma unroll
+		for(int q = 0; q < NC; q++) eh[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hidx << 2), (int)(incl[q] - (uint32_t)x[q]));
+		int32_t r[NC];
+#pragma unroll
+		for(int q = 0; q < NC; q++) r[q] = (int32_t)(incl[q] - eh[q]);
+		if(go) {
+			if(V::CHECK) {
+#pragma unroll
+				for(int q = 0; q < NC; q++) bad |= (uint32_t)r[q] + 0x8000u;
+			}
+			val.store(i, r, A);
+		}
+		val.sync();
+		s = s_next; donew = donew_next; W = W2; A = A2; D = D2;
+	}
+	return bad;
+}
+
+// ---- the walk: meshes whose fronts break into MANY stretches (runs of vertices that each continue their predecessor's sum) ----
+// The window loop above is a scan machine: it finishes a whole run of such vertices per pass, which is what a mesh of a few long
+// rings wants (a torus: 24 stretches, a closed sphere: one).  A mesh with dozens of stretches alive at once - every open grid, any
+// irregular connectivity - has its parallelism ACROSS stretches instead: fans (c = i-2) and flipped diagonals cut the window's runs
+// to 7 vertices a pass where 40 stretches could each advance by one.  So, when the window's first passes look like that (WindowHand),
+// lane k walks stretches k, k + 64, ... in order from where the window stopped, one vertex a pass, a vertex firing when its parents' fired
+// bits are set; the vertex a lane has just finished stays in its registers (its successor's `a`); vertices the window had finished out of
+// order are stepped over.  Passes = the depth of the DAG (158 for the 4K-triangle
+// grid, 174 with every diagonal random, 106 for a holey disc) at about half a window pass's instructions and ONE LDS round trip each.
+// The lowest unfired vertex is always some lane's current one and its parents are lower, so every pass fires at least one vertex
+// (whatever the triples: malformed ones only cost passes).  One wave's LDS accesses execute in program order: no fences, no polling.
+// Stretches are handed out IN ORDER to whichever lanes are free (a scalar cursor over the start bitmap: the lanes test 64 vertices' start
+// bits, the free lanes take the first so many through 64 words of LDS) - so the lowest unfinished stretch always has a lane, whose current
+// vertex is then the lowest unfired one: progress.  A stretch ends where the next vertex does not continue the sum (its graph word says
+// so, and the word is fetched a pass ahead anyway): no end markers, no search.
+// The pass itself is branch-free up to its one predicated store (the compiler's version of `if(active) { if(ready) { ... if(last) ...`
+// was a dozen exec-masked regions and taken branches per pass, and a binary search whenever any lane's stretch ended - every pass, on a
+// mesh of 500 short stretches).
+struct WalkStarts { CRT_LDS const uint32_t *sbits; CRT_LDS uint32_t *tmp; uint32_t nw; };
+
+template <class V>
+__device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
+                                                  const uint32_t nvert, const bool para, const int32_t (&base)[V::NC], const WindowHand hand) {
+	constexpr int NC = V::NC;
+	const uint32_t lane = lane_id();
+	const uint64_t lane_lt = (1ull << lane) - 1ull;
+	const uint32_t wmask = para ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);
+	const uint32_t first = hand.s;                                          // everything below is done, and so are the window's set bits from there
+	for(uint32_t d = lane; d < G.nw; d += 64) {
+		const uint32_t b0 = d*32u;
+		uint32_t w = first >= b0 + 32u ? 0xFFFFFFFFu : first > b0 ? (1u << (first - b0)) - 1u : 0u;
+		if(b0 + 32u > first && b0 < first + 64u) {                             // the window mask's bits that fall into this dword
+			const int32_t sh = (int32_t)b0 - (int32_t)first;                   // bit 0 of the dword is bit `sh` of the mask
+			w |= sh >= 0 ? (uint32_t)(hand.donew >> (uint32_t)sh) : (uint32_t)(hand.donew << (uint32_t)(-sh));
+		}
+		fbits[d] = w;
+	}
+	// lane 0 resumes at `first` (a start, or the middle of the stretch the window was in); everybody else takes starts from first + 1 on
+	uint32_t bad = 0, i = first, cur = first + 1u;
+	bool active = lane == 0, need = lane != 0, at_start = true;
+	uint32_t W, A, F; typename V::Raw D;
+	{ const uint32_t ic = i < nvert ? i : nvert - 1u; W = gw[ic] & wmask; A = ga.get(ic); D = val.raw(ic); F = fbits[ic >> 5]; }
+	int32_t prev[NC];
+#pragma unroll
+	for(int q = 0; q < NC; q++) prev[q] = 0;
+	for(;;) {
+		const uint64_t nm = __ballot(need);
+		if(nm && cur < nvert) {                                                // (uniform) hand out the next starts
+			const uint32_t m = (uint32_t)__builtin_popcountll(nm);
+			const uint32_t v = cur + lane, vc = v < nvert ? v : nvert - 1u;
+			const uint32_t sw = G.sbits[vc >> 5];
+			const bool st = v < nvert && ((sw >> (v & 31u)) & 1u) != 0;
+			const uint64_t sm = __ballot(st);
+			const uint32_t avail = (uint32_t)__builtin_popcountll(sm);
+			const uint32_t srank = (uint32_t)__builtin_popcountll(sm & lane_lt), nrank = (uint32_t)__builtin_popcountll(nm & lane_lt);
+			if(st && srank < m) G.tmp[srank] = v;
+			const uint32_t got = G.tmp[nrank], lastv = G.tmp[m - 1u < 63u ? m - 1u : 63u];   // (one wave: the reads see the writes)
+			const bool gets = need && nrank < avail;
+			cur = avail <= m ? cur + 64u : (uint32_t)__builtin_amdgcn_readfirstlane((int)lastv) + 1u;
+			if(gets) { i = got; active = true; need = false; at_start = true; }
+			const uint32_t ic = i < nvert ? i : nvert - 1u;
+			const uint32_t Wn = gw[ic] & wmask, An = ga.get(ic), Fn = fbits[ic >> 5]; const typename V::Raw Dn = val.raw(ic);
+			if(gets) { W = Wn; A = An; F = Fn; D = Dn; }
+		}
+		const uint64_t am = __ballot(active);
+		if(!am) { if(cur >= nvert || !__ballot(need)) break; continue; }
+		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
+		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (W & GW_NO_BC) == GW_NO_BC;
+		const bool own = ch && !at_start;                                      // continues the vertex this lane finished last pass: in `prev`
+		const uint32_t ic = i < nvert ? i : nvert - 1u;
+		const uint32_t ap = stays || own ? 0u : ch ? ic - 1u : A, gb = stays ? 0u : b, gc = stays ? 0u : c;
+		const uint32_t inext = ic + 1u < nvert ? ic + 1u : ic;
+		// the parents' fired bits and values and the next vertex' words: one round trip
+		uint32_t fa = fbits[ap >> 5], fb = fbits[gb >> 5], fc = fbits[gc >> 5];
+		typename V::Raw Bw = val.raw(gb), Cw = val.raw(gc), Pw = val.raw(ap);
+		uint32_t W2 = gw[inext], A2 = ga.get(inext), F2 = fbits[inext >> 5]; typename V::Raw D2 = val.raw(inext);
+		asm volatile("" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(W2), "+v"(A2), "+v"(F2));
+		const bool mine_done = ((F >> (ic & 31u)) & 1u) != 0;                  // the window finished it out of order: stepped over (only this lane ever fires it otherwise)
+		const uint32_t ready = stays ? 1u : ((fa >> (ap & 31u)) & (fb >> (gb & 31u)) & (fc >> (gc & 31u)) & 1u);
+		int32_t dv[NC], bv[NC], cv[NC], pv[NC], r[NC];
+		V::unpack(D, dv); V::unpack(Bw, bv); V::unpack(Cw, cv); V::unpack(Pw, pv);
+#pragma unroll
+		for(int q = 0; q < NC; q++) r[q] = dv[q] + (stays ? -base[q] : bv[q] - cv[q] + (own ? prev[q] : pv[q]));
+		const bool fire = active && (ready != 0 || mine_done), store = fire && !mine_done;
+		if(store) {
+			val.store(ic, r, A);
+			(void)__hip_atomic_fetch_or(fbits + (ic >> 5), 1u << (ic & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_or_b32
+		}
+		uint32_t chk = 0;
+#pragma unroll
+		for(int q = 0; q < NC; q++) { chk |= (uint32_t)r[q] + 0x8000u; prev[q] = store ? r[q] : prev[q]; }
+		if(V::CHECK) bad |= store ? chk : 0u;
+		// on: the next vertex of my stretch, or - it starts another stretch, or there is none - a new stretch for me
+		const bool ends = ic + 1u >= nvert || (W2 & GW_CHAINED) == 0;
+		const bool on = fire && !ends;
+		at_start = fire ? mine_done : at_start;                                  // (behind a vertex that was stepped over: its value is in LDS, not in `prev`)
+		need = need || (fire && ends);
+		active = active && !(fire && ends);
+		i = on ? inext : i;
+		W = on ? (W2 & wmask) : W; A = on ? A2 : A; F = on ? F2 : F; D = on ? D2 : D;
+		val.sync();
+	}
+	return bad;
+}
+
+// ---- staging: raw int32 deltas in HBM -> int16 records (checked); results back as the int32 / float the caller wants ----
+template <int K>
+__device__ __forceinline__ uint32_t stage_in16(const LdsVal<K> &val, CRT_GLOBAL const int32_t *src, uint32_t nvert, bool ga_here) {
+	constexpr int NC = LdsVal<K>::NC;
+	uint32_t bad = 0;
+	constexpr uint32_t U = NC <= 2 ? 16u : 8u;                              // vertices per lane and round: every load of a round in flight together
+	for(uint32_t i0 = lane_id(); i0 < nvert; i0 += 64*U) {                   // (a 2 112-vertex blob: five rounds of 8 x 12 bytes, not nine of four)
+		int32_t d[U][NC];
+#pragma unroll
+		for(uint32_t u = 0; u < U; u++) {
+			const uint32_t i = i0 + u*64 < nvert ? i0 + u*64 : nvert - 1u;
+#pragma unroll
+			for(int q = 0; q < NC; q++) d[u][q] = src[(size_t)i*NC + q];
+		}
+#pragma unroll
+		for(uint32_t u = 0; u < U; u++)
+#pragma unroll
+			for(int q = 0; q < NC; q++) asm volatile("" : "+v"(d[u][q]));       // all loads of the round in flight before the first is used
+#pragma unroll
+		for(uint32_t u = 0; u < U; u++) {
+			const uint32_t i = i0 + u*64;
+			if(i >= nvert) continue;
+			if(i == 0) {
+#pragma unroll
+				for(int q = 0; q < NC; q++) d[u][q] = 0;                        // vertex 0 is the base: relative value 0
+			}
+#pragma unroll
+			for(int q = 0; q < NC; q++) bad |= (uint32_t)d[u][q] + 0x8000u;
+			// (K = 3: the spare halfword belongs to the graph builder, which may have written it already: x | y, then z alone)
+			if(K == 3 && ga_here) {
+				CRT_LDS uint32_t *p32 = (CRT_LDS uint32_t *)(val.p + i);
+				p32[0] = ((uint32_t)d[u][0] & 0xFFFFu) | ((uint32_t)d[u][1] << 16);
+				*(CRT_LDS uint16_t *)(p32 + 1) = (uint16_t)d[u][NC > 2 ? 2 : 0];
+			} else val.store(i, d[u], 0u);
+		}
+	}
+	return bad;
+}
+
+__device__ __forceinline__ void stage_in_bytes(const LdsVal<5> &val, CRT_GLOBAL const uint8_t *src, uint32_t nvert, uint32_t N) {
+	if(N == 4 && ((uintptr_t)src & 3) == 0) {
+		CRT_GLOBAL const uint32_t *s4 = (CRT_GLOBAL const uint32_t *)src;
+		for(uint32_t i0 = lane_id(); i0 < nvert; i0 += 64*8) {
+			uint32_t w[8];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) w[u] = s4[i0 + u*64 < nvert ? i0 + u*64 : nvert - 1u];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(w[u]));
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) if(i0 + u*64 < nvert) val.p[i0 + u*64] = w[u];
+		}
+		return;
+	}
+	for(uint32_t i = lane_id(); i < nvert; i += 64) {
+		uint32_t w = 0;
+		for(uint32_t q = 0; q < N && q < 4; q++) w |= (uint32_t)src[(size_t)i*N + q] << (8*q);
+		val.p[i] = w;
+	}
+}
+
+// generic attribute out: base + relative value, as int32 (in place of the deltas) or as (float)v*q (vertex_attribute.h:190-193)
+template <int K>
+__device__ __forceinline__ void stage_out16(const LdsVal<K> &val, CRT_GLOBAL int32_t *dst, uint32_t nvert, const int32_t (&base)[LdsVal<K>::NC], bool as_float, float q) {
+	constexpr int NC = LdsVal<K>::NC;
+	CRT_GLOBAL float *fdst = (CRT_GLOBAL float *)dst;
+	for(uint32_t i0 = lane_id(); i0 < nvert; i0 += 64*8) {
+		typename LdsVal<K>::Raw w[8];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) w[u] = val.raw(i0 + u*64 < nvert ? i0 + u*64 : nvert - 1u);
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) {
+			const uint32_t i = i0 + u*64;
+			if(i >= nvert) continue;
+			int32_t v[NC];
+			LdsVal<K>::unpack(w[u], v);
+#pragma unroll
+			for(int c = 0; c < NC; c++) v[c] += base[c];
+			if(as_float) {
+#pragma unroll
+				for(int c = 0; c < NC; c++) fdst[(size_t)i*NC + c] = (float)v[c]*q;
+			} else {
+#pragma unroll
+				for(int c = 0; c < NC; c++) dst[(size_t)i*NC + c] = v[c];
+			}
+		}
+	}
+}
+
+// a colour attribute leaves LDS as RGB(A): (r, g, b, a) = (v2 + v0, v0, v1 + v0, v3) x qc, u8 wrap (color_attribute.cpp:76-95, point.h:214),
+// or as the delta-decoded bytes when k_dequant does that later
+__device__ __forceinline__ void stage_out_bytes(const LdsVal<5> &val, const DeltaJob &J, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+	const uint32_t nvert = J.nvert, N = J.N;
+	if(J.deq != 2) {                                                          // bytes back where they came from
+		CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.values);
+		if(N == 4 && ((uintptr_t)dst & 3) == 0) { for(uint32_t i = lane_id(); i < nvert; i += 64) ((CRT_GLOBAL uint32_t *)dst)[i] = val.p[i]; return; }
+		for(uint32_t i = lane_id(); i < nvert; i += 64) { const uint32_t w = val.p[i]; for(uint32_t c = 0; c < N && c < 4; c++) dst[(size_t)i*N + c] = (uint8_t)(w >> (8*c)); }
+		return;
+	}
+	CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
+	const uint32_t oc = J.out_components, stride = J.out_stride ? J.out_stride : oc;
+	const uint32_t amask = N < 4 ? 0xFF000000u : 0u;                          // fewer than four stored components: alpha 255 (color_attribute.h: out_components > N)
+	auto px = [&](uint32_t w) -> uint32_t {                                   // bytes y, u, v, a -> r, g, b, a
+		w |= amask;
+		const uint32_t y = w & 255u, cu = (w >> 8) & 255u, cv = (w >> 16) & 255u, al = w >> 24;
+		return (((cv + y)*q0) & 255u) | ((y*q1) & 255u) << 8 | (((cu + y)*q2) & 255u) << 16 | ((al*q3) & 255u) << 24;
+	};
+	if(oc == 4 && stride == 4 && ((uintptr_t)dst & 15) == 0) {                // packed RGBA: four vertices per lane, 16-byte stores
+		CRT_LDS const u32x4 *v4 = (CRT_LDS const u32x4 *)val.p;               // (the record array starts on a 16-byte multiple)
+		CRT_GLOBAL u32x4 *d4 = (CRT_GLOBAL u32x4 *)dst;
+		const uint32_t nq = nvert >> 2;
+		for(uint32_t k = lane_id(); k < nq; k += 64) { const u32x4 w = v4[k]; d4[k] = u32x4{px(w.x), px(w.y), px(w.z), px(w.w)}; }
+		for(uint32_t i = (nq << 2) + lane_id(); i < nvert; i += 64) ((CRT_GLOBAL uint32_t *)dst)[i] = px(val.p[i]);
+		return;
+	}
+	for(uint32_t i = lane_id(); i < nvert; i += 64) {
+		const uint32_t w = px(val.p[i]);
+		CRT_GLOBAL uint8_t *o = dst + (size_t)i*stride;
+		if(oc == 4 && (((uintptr_t)o) & 3) == 0) *(CRT_GLOBAL uint32_t *)o = w;
+		else for(uint32_t c = 0; c < oc && c < 4; c++) o[c] = (uint8_t)(w >> (8*c));
+	}
+}
+
+// one int16 attribute by its wave, in two phases with the workgroup's barrier between them (the graph is another wave's work)
+template <int K>
+__device__ __forceinline__ uint32_t delta16_in(CRT_LDS uint8_t *rec, const DeltaJob &J, bool ga_here) {
+	LdsVal<K> val{(decltype(LdsVal<K>::p))rec};
+	return stage_in16<K>(val, as_global((const int32_t *)J.values), J.nvert, ga_here);
+}
+// returns true if the relative values left int16 (nothing was written back: the caller redoes the attribute in HBM)
+template <int K>
+__device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob &J, CRT_LDS const uint32_t *gw, const GaRef ga, uint32_t bad,
+                                            CRT_LDS uint32_t *fbits, const WalkStarts &starts) {
+	constexpr int NC = LdsVal<K>::NC;
+	LdsVal<K> val{(decltype(LdsVal<K>::p))rec};
+	CRT_GLOBAL const int32_t *src = as_global((const int32_t *)J.values);
+	int32_t base[NC];
+#pragma unroll
+	for(int q = 0; q < NC; q++) base[q] = src[q];                            // vertex 0 (every lane: one broadcast load each)
+	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert);
+	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
+	WindowHand hand;
+	bad |= delta_window_run(val, gw, ga, nvert, para, base, &hand);
+	if(hand.s < nvert) {
+		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
+		bad |= delta_walk_run(val, gw, ga, fbits, starts, nvert, para, base, hand);
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	if(__ballot((bad >> 16) != 0)) return true;
+	stage_out16<K>(val, as_global((int32_t *)J.values), J.nvert, base, J.deq == 1, J.q);
+	return false;
+}
+
+} // namespace
+
+// One workgroup per blob: up to four attributes, one wave each, share the prediction graph in LDS; the graph is made by the first wave
+// that has no attribute (by wave 0 in front of its own staging when all four have one).
+// LDS: records of attribute 0 | 1 | ... (each array a 16-byte multiple) | graph words (u32 x nvert) | a (u16 x nvert, unless it rides
+// in a three-component attribute's records): delta16_group_lds() in kernels.h is the same sum.
+__global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict__ jobs, const DeltaGroup *__restrict__ groups, uint32_t ngroups) {
+	if(blockIdx.x >= ngroups) return;
+	const DeltaGroup G = groups[blockIdx.x];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const uint32_t lane = lane_id(), w = wave_id();
+	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[G.first].nvert);   // (uniform: the window loop's control stays scalar)
+	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
+	uint32_t off = 0, myoff = 0, ga_addr = 0, ga_shift = 1;
+	bool ga_set = false;
+	for(uint32_t k = 0; k < G.count; k++) {
+		const uint32_t N = jobs[G.first + k].N; const bool u8 = jobs[G.first + k].is_u8 != 0;
+		if(k == w) myoff = off;
+		if(!ga_set && !u8 && N == 3) { ga_addr = (uint32_t)(uintptr_t)(l8 + off) + 6u; ga_shift = 3; ga_set = true; }
+		off += delta16_vbytes(nvert, N, u8);
+	}
+	CRT_LDS uint32_t *gw = (CRT_LDS uint32_t *)(l8 + off);
+	off += (4u*nvert + 15u) & ~15u;
+	if(!ga_set) { ga_addr = (uint32_t)(uintptr_t)(l8 + off); off += (2u*nvert + 15u) & ~15u; }
+	const GaRef ga{ga_addr, ga_shift};
+	// the walk's bookkeeping: stretch-start bits | per wave: 64 words the free lanes take their starts through, fired bits
+	const uint32_t nw = delta_wave_bit_words(nvert);
+	CRT_LDS uint32_t *sbits = (CRT_LDS uint32_t *)(l8 + off);
+	CRT_LDS uint32_t *wtmp = (CRT_LDS uint32_t *)(l8 + off + delta16_walk_shared(nvert)) + w*(64u + nw);
+	CRT_LDS uint32_t *fbits = wtmp + 64;
+	const uint32_t builder = G.count < 4 ? G.count : 0u;
+	if(w == builder) {
+		// prediction triples -> graph words + a.  Eight rounds of 64 vertices in flight (unconditional loads on clamped indices, pinned).
+		CRT_GLOBAL const uint32_t *pred = as_global(jobs[G.first].pred);
+		for(uint32_t base = 0; base < nvert; base += 512) {
+			uint32_t ta[8], tb[8], tc[8];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) {
+				const uint32_t i = base + u*64 + lane, ic = i < nvert ? i : nvert - 1u;
+				const u32x3 t = *(CRT_GLOBAL const u32x3 *)(pred + (size_t)ic*3);
+				ta[u] = t.x; tb[u] = t.y; tc[u] = t.z;
+			}
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(ta[u]), "+v"(tb[u]), "+v"(tc[u]));
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) {
+				const uint32_t i = base + u*64 + lane;
+				const bool start = i < nvert && !(ta[u] < i && ta[u] + 1u == i);   // does not continue its predecessor's sum: a stretch starts here
+				const uint64_t m = __ballot(start);                              // the round's 64 vertices: two dwords of the start bitmap
+				if(lane == 0 && base + u*64 < nvert) { const uint32_t d = (base + u*64) >> 5; sbits[d] = (uint32_t)m; sbits[d + 1] = (uint32_t)(m >> 32); }
+				if(i >= nvert) continue;
+				// well-formed streams always predict from earlier vertices.  A triple that does not: the value stays (vertex 0 is one) - for
+				// every attribute when it is `a`, for parallelogram attributes only when it is b or c (the others never look at them):
+				// GW_STAYS for the first, b = c = 0x7FFF (no vertex: nvert <= 32767) for the second
+				const bool va = ta[u] < i, vbc = tb[u] < i && tc[u] < i;
+				uint32_t word = !va ? GW_STAYS : vbc ? (tb[u] | (tc[u] << 15)) : GW_NO_BC;
+				if(va && ta[u] + 1u == i) word |= GW_CHAINED;
+				gw[i] = word;
+				ga.put(i, va ? ta[u] : 0u);
+			}
+		}
+	}
+	bool redo = false;
+	const DeltaJob &J = jobs[G.first + (w < G.count ? w : 0u)];
+	const bool mine = w < G.count, bytes = J.is_u8 != 0;
+	CRT_LDS uint8_t *rec = l8 + myoff;
+	const uint32_t N = J.N;
+	uint32_t bad = 0;
+	if(mine) {
+		const bool ga_here = ga_set && ga_shift == 3 && (uint32_t)(uintptr_t)rec + 6u == ga_addr;
+		if(bytes) stage_in_bytes(LdsVal<5>{(CRT_LDS uint32_t *)rec}, as_global((const uint8_t *)J.values), nvert, N);
+		else if(N == 1) bad = delta16_in<1>(rec, J, false);
+		else if(N == 2) bad = delta16_in<2>(rec, J, false);
+		else if(N == 3) bad = delta16_in<3>(rec, J, ga_here);
+		else bad = delta16_in<4>(rec, J, false);
+	}
+	__syncthreads();                                                           // the graph is there
+	if(!mine) return;
+	const WalkStarts starts{sbits, wtmp, nw};
+	if(bytes) {
+		const LdsVal<5> val{(CRT_LDS uint32_t *)rec};
+		const int32_t zero[4] = {0, 0, 0, 0};
+		WindowHand hand;
+		(void)delta_window_run(val, gw, ga, nvert, J.parallelogram != 0, zero, &hand);
+		if(hand.s < nvert) {
+			if(lane == 0) as_global(J.flags)[1] = 1;
+			(void)delta_walk_run(val, gw, ga, fbits, starts, nvert, J.parallelogram != 0, zero, hand);
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		stage_out_bytes(val, J, J.qc[0], J.qc[1], J.qc[2], J.qc[3]);
+	}
+	else if(N == 1) redo = delta16_run<1>(rec, J, gw, ga, bad, fbits, starts);
+	else if(N == 2) redo = delta16_run<2>(rec, J, gw, ga, bad, fbits, starts);
+	else if(N == 3) redo = delta16_run<3>(rec, J, gw, ga, bad, fbits, starts);
+	else redo = delta16_run<4>(rec, J, gw, ga, bad, fbits, starts);
+	if(redo) {
+		// the relative values left int16: the raw deltas are still in HBM (nothing was written back) - the same loop on them, 32 bits wide,
+		// and a word for the host: its next batches are planned on the wide kernel (batch.cpp: harvest)
+		if(lane == 0) *as_global(J.flags) = 1;
+		const int32_t zero[4] = {0, 0, 0, 0};
+		const GlobalVal<int32_t> gval{as_global((int32_t *)J.values), N};
+		(void)delta_window_run(gval, gw, ga, nvert, J.parallelogram != 0, zero);
+		if(J.deq == 1) {                                                        // floats in place of the integers (vertex_attribute.h:190-193)
+			CRT_GLOBAL int32_t *v = as_global((int32_t *)J.values);
+			const uint32_t n = nvert*N;
+			for(uint32_t k = lane; k < n; k += 64) { const int32_t x = v[k]; ((CRT_GLOBAL float *)v)[k] = (float)x*J.q; }
+		}
+	}
+}
+
+} // namespace corto_hip

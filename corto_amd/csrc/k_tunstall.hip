@@ -165,7 +165,7 @@ __device__ __forceinline__ void tun_tile_prepare(TunTile &t, const TunStream &st
 
 // the decode of one short stream by one wave from a dictionary in LDS (offsets, lengths, word bytes): four codewords per lane and step
 __device__ __forceinline__ void tun_stream_decode(const TunStream &st, const uint16_t *loff, const uint8_t *llen, const uint8_t *words) {
-	const uint32_t lane = threadIdx.x, csize = st.csize;
+	const uint32_t lane = lane_id(), csize = st.csize;
 	const uint64_t size = st.size;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	CRT_GLOBAL uint8_t *gdst = as_global(st.dst);
@@ -269,6 +269,35 @@ __global__ __launch_bounds__(64) void k_tun_stream_shared(const TunStream *__res
 	}
 	__syncthreads();
 	tun_stream_decode(st, loff, llen, words);
+}
+
+// ... and the streams that share a dictionary share its copy in LDS too (round 3): the planner sorts a launch's streams by dictionary
+// and hands groups of up to TUN_GROUP_MAX of them, all of ONE dictionary, to one workgroup of four waves - the dictionary is loaded
+// once by 256 threads and every wave decodes its streams from it, one after the other.  What this buys is LDS.time, which is what
+// bounds the pipelined decode: one wave per stream held 10 KB for its ~8 us each, 2 304 times a batch - more than any
+// other kernel of the path (1.1 of 4.0 GB.us in the steady-state trace); a group of eight holds the same 10 KB for ~20 us.
+__global__ __launch_bounds__(256) void k_tun_stream_grouped(const TunStream *__restrict__ streams, const uint32_t *__restrict__ ids, const TunGroup *__restrict__ groups,
+                                                            uint32_t ngroups, const TunTable *__restrict__ tables) {
+	if(blockIdx.x >= ngroups) return;
+	const TunGroup G = groups[blockIdx.x];
+	__shared__ uint16_t loff[256];
+	__shared__ uint8_t llen[256];
+	__shared__ __attribute__((aligned(16))) uint8_t words[TUN_TABLE_BYTES];
+	const uint32_t t = threadIdx.x;
+	const TunTable &T = tables[streams[ids[G.first]].dict];
+	{
+		CRT_GLOBAL const u32x4_t *o4 = (CRT_GLOBAL const u32x4_t *)as_global(T.off);
+		CRT_GLOBAL const u32x4_t *w4 = (CRT_GLOBAL const u32x4_t *)as_global(T.bytes);
+		u32x4_t hv = o4[t < 48 ? t : 47u], wv = w4[t];                          // (the table has 576 vectors of words: t < 256 is inside)
+		asm volatile("" : "+v"(hv), "+v"(wv));
+		if(t < 32) ((CRT_LDS u32x4_t *)as_lds(loff))[t] = hv;
+		else if(t < 48) ((CRT_LDS u32x4_t *)as_lds(llen))[t - 32] = hv;
+		((CRT_LDS u32x4_t *)as_lds(words))[t] = wv;
+		const uint32_t nv = (min(T.used, TUN_TABLE_BYTES) + 15u) >> 4;
+		for(uint32_t i = t + 256; i < nv; i += 256) ((CRT_LDS u32x4_t *)as_lds(words))[i] = w4[i];
+	}
+	__syncthreads();
+	for(uint32_t k = wave_id(); k < G.count; k += 4) tun_stream_decode(streams[ids[G.first + k]], loff, llen, words);
 }
 
 // pass B, short streams (the .crt case: one chunk, a few KiB): small LDS footprint so that it can run next to the
@@ -742,6 +771,21 @@ __global__ __launch_bounds__(256) void k_fill(const FillJob *__restrict__ jobs, 
 	if(j >= njobs) return;
 	const FillJob f = jobs[j];
 	for(uint32_t i = threadIdx.x; i < f.size; i += 256) f.dst[i] = (uint8_t)f.value;
+}
+
+// one block of memory filled with a byte, 16 bytes a thread and store (crthip_pool poisons a context's output block with it: one
+// launch on the context's stream, no host-side work beyond that - hipMemsetAsync of 32 MB cost the calling thread ~0.2 ms)
+__global__ __launch_bounds__(256) void k_fill_block(uint8_t *__restrict__ dst, uint64_t bytes, uint32_t value) {
+	typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+	const uint32_t w = value*0x01010101u;
+	const u32x4_t v = {w, w, w, w};
+	const uint64_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, nvec = bytes > head ? (bytes - head) >> 4 : 0;
+	u32x4_t *d4 = (u32x4_t *)(dst + head);
+	for(uint64_t i = (uint64_t)blockIdx.x*256 + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x*256) __builtin_nontemporal_store(v, d4 + i);
+	if(blockIdx.x == 0) {
+		for(uint64_t i = threadIdx.x; i < head && i < bytes; i += 256) dst[i] = (uint8_t)value;
+		for(uint64_t i = head + nvec*16 + threadIdx.x; i < bytes; i += 256) dst[i] = (uint8_t)value;
+	}
 }
 
 } // namespace corto_hip

@@ -10,6 +10,7 @@ namespace corto_hip {
 __global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables, uint64_t *lookback_state, uint32_t lookback_words);   // lookback_state: null, or the chunk state words to clear
 __global__ void k_tun_stream(const TunStream *streams, uint32_t nstreams);   // short streams: dictionary + decode by one wave, the dictionary never leaves LDS
 __global__ void k_tun_stream_shared(const TunStream *streams, uint32_t nstreams, const TunTable *tables);   // ... decode from a dictionary another wave built (k_tun_tables): streams of a batch that carry the same probability table
+__global__ void k_tun_stream_grouped(const TunStream *streams, const uint32_t *ids, const TunGroup *groups, uint32_t ngroups, const TunTable *tables);   // ... streams of ONE dictionary, up to TUN_GROUP_MAX per workgroup, from one copy of it in LDS
 __global__ void k_tun_stream_scan(const TunStream *streams, uint32_t nstreams, uint64_t *chunk_out);   // one stream's quarter sums -> its quarter offsets (one workgroup per stream)
 __global__ void k_tun_chunk_sums(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                                  uint64_t *chunk_out, uint32_t chunk_base);
@@ -22,6 +23,7 @@ struct TunLaunch { hipStream_t main; bool one_launch; };   // one_launch: all th
 int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                              uint64_t *chunk_out, uint32_t single_pass);    // words <= 4 bytes, <= 8 bytes, longer: one kernel, or three
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
+__global__ void k_fill_block(uint8_t *dst, uint64_t bytes, uint32_t value);
 
 // k_stream.hip
 __global__ void k_scan_u64(uint64_t *a, uint32_t n);
@@ -80,6 +82,19 @@ __host__ __device__ inline uint64_t delta_wave_attr_lds(uint32_t nvert, uint32_t
 }
 struct DeltaGroup { uint32_t first, count; };     // DeltaJob entries [first, first + count) of one blob
 __global__ void k_delta_wave(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
+// k_delta.hip: the same division of labour with 16-bit values relative to vertex 0 (bytes for colours), a 4-byte graph word and one
+// out-of-order window loop.  Records: 2 / 4 / 8 / 8 bytes for 1 / 2 / 3 / 4 int16 components, 4 bytes for up to four colour bytes.
+constexpr uint32_t DELTA16_LDS_MAX = 128*1024, DELTA16_NVERT_MAX = 32767;
+__host__ __device__ inline uint32_t delta16_rec(uint32_t N, bool is_u8) { return is_u8 ? 4u : N == 1 ? 2u : N == 2 ? 4u : 8u; }
+__host__ __device__ inline uint32_t delta16_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return (nvert*delta16_rec(N, is_u8) + 15u) & ~15u; }
+__host__ __device__ inline bool delta16_eligible(uint32_t nvert, uint32_t N, bool is_u8) { return nvert <= DELTA16_NVERT_MAX && N >= 1 && N <= 4 && (is_u8 || true); }
+// graph: 4 bytes a vertex + (unless a three-component int16 attribute of the group lends its spare halfwords) 2 bytes a vertex of `a`
+// ... + the walk's bookkeeping (k_delta.hip): stretch-start bits, then per wave (four) 64 words and a fired bitmap
+__host__ __device__ inline uint32_t delta16_walk_shared(uint32_t nvert) { return (4u*delta_wave_bit_words(nvert) + 15u) & ~15u; }
+__host__ __device__ inline uint32_t delta16_graph_lds(uint32_t nvert, bool a_embedded) {
+	return ((4u*nvert + 15u) & ~15u) + (a_embedded ? 0u : ((2u*nvert + 15u) & ~15u)) + delta16_walk_shared(nvert) + 4u*4u*(64u + delta_wave_bit_words(nvert)) + 16u;
+}
+__global__ void k_delta_lds16(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
 
 // k_normal.hip
 __global__ void k_normal_diff(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks);

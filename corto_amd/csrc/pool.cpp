@@ -202,7 +202,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	std::vector<std::atomic<uint64_t>> per_dev(p->ndevices);
 	for(auto &x : per_dev) x = 0;
 	std::atomic<int32_t> first_error{0};
-	std::atomic<uint64_t> host_ns{0}, host_steps{0};
+	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0};
 	// home shard first: pool device d owns the items j with j % ndevices == d (its shard is resident there), and a device without a home
 	// item takes from the others' ("stealing" in a cyclic run: it is the work list that is shared, a faster GPU simply draws more tickets)
 	std::vector<std::vector<uint32_t>> home(p->ndevices);
@@ -237,7 +237,10 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			return CRTHIP_OK;
 		};
 		int err = CRTHIP_OK;
+		auto tick = [] { return std::chrono::steady_clock::now(); };
+		auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
 		for(uint64_t n = 0; !err; n++) {
+			const auto w0 = tick();
 			// the next lane to refill: a free one, else whichever of the busy ones finishes first (they mostly finish in the order they
 			// were launched, but a thread that waited on the oldest while a younger one was done left that context idle)
 			uint32_t pick = p->depth;
@@ -252,8 +255,11 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 				if(pick == p->depth && !err) { if(spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(5)); }
 			}
 			if(err) break;
+			wait_ns += ns_since(w0);
 			Lane &L = mine[pick];
+			const auto f0 = tick();
 			if(L.busy) err = finish(L);
+			finish_ns += ns_since(f0);
 			if(err) break;
 			const uint64_t step = p->next.fetch_add(1);
 			if(step >= total) break;
@@ -262,12 +268,13 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
 			const auto h0 = std::chrono::steady_clock::now();
 			err = lane_plan(p, L, items[j], (int64_t)j);
+			plan_ns += ns_since(h0);
 			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
 			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
 			L.poisoned = false;
 			if(!err && step >= poison_from && L.out) {
-				if(hipMemsetAsync(L.out, POISON, L.out_cap, corto_hip::ctx_stream(L.ctx)) != hipSuccess) err = ctx_fail(CRTHIP_E_DEVICE, "hipMemsetAsync(poison)");
-				else L.poisoned = true;
+				err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+				if(!err) L.poisoned = true;
 			}
 			if(!err) err = crthip_batch_decode(L.batch);
 			host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count(); host_steps++;
@@ -291,6 +298,10 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	for(uint32_t d = 0; d < p->ndevices; d++) { report->steps_per_device[d] = per_dev[d]; if(per_dev[d]) report->devices_used++; }
 	for(auto &L : p->lanes) if(L.item >= 0 && L.poisoned) report->poisoned_lanes++;
 	report->host_us_per_step = host_steps ? (float)((double)host_ns/1e3/(double)host_steps) : 0.f;
+	if(host_steps) {
+		report->host_wait_us = (float)((double)wait_ns/1e3/(double)host_steps); report->host_finish_us = (float)((double)finish_ns/1e3/(double)host_steps);
+		report->host_plan_us = (float)((double)plan_ns/1e3/(double)host_steps);
+	}
 	for(uint32_t d = 0; d < p->ndevices; d++) if(!p->cpus[d].empty()) report->pinned_devices++;
 	if(completion_s) for(uint64_t c = 0; c < steps; c++) completion_s[c] = stamps[warmup + 1 + c] - stamps[warmup];
 	return CRTHIP_OK;

@@ -220,6 +220,9 @@ typedef struct {
 	uint32_t pinned_devices;     /* pool devices whose worker threads were pinned to the CPUs of the GPU's NUMA node */
 	float host_us_per_step;      /* host time per step and thread: plan (walk + bind) + enqueue, averaged over every executed step */
 	uint32_t reserved;
+	float host_wait_us, host_finish_us, host_plan_us;   /* of a worker thread's time per step: waiting for one of its contexts to finish; harvesting it
+	                                (sync, status); the walk + bind part of host_us_per_step */
+	uint32_t reserved2;
 } crthip_pool_report;
 
 /* Decode warmup + steps batches drawn cyclically from the items (each device from its home items, see above; + a few more steps to
@@ -295,6 +298,12 @@ typedef struct {
 	uint32_t tunstall_dictionaries; /* Tunstall dictionaries the last decode BUILT: streams of a batch that carry the same probability table
 	                               share one (the dictionary is a function of the table alone, src/tunstall.cpp:125-256), so this is
 	                               <= tunstall_streams; $CORTO_TUN_SHARE=0 builds one per stream */
+	uint32_t delta_redone;      /* after crthip_batch_sync: blobs with an attribute whose values, relative to vertex 0, left int16 (K-DELTA's LDS
+	                               layout) and were redone on the 32-bit values in HBM (same results, slower); the context plans its next
+	                               batches with 32-bit values in LDS when that happens */
+	uint32_t delta_walked;      /* after crthip_batch_sync: blobs of which K-DELTA finished an attribute with its walk (one lane per stretch of the
+	                               prediction graph) rather than its window of prefix sums: irregular connectivity (k_delta.hip) */
+	uint32_t delta_wide;        /* 1: this decode was planned with 32-bit values in K-DELTA's LDS (the context had met such blobs, or $CORTO_DELTA_WIDE=1) */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

@@ -1283,3 +1283,33 @@ def test_bench_eight_pool_devices_on_one_gpu():
     assert len(j["steps_per_device"]) == 8 and all(x > 0 for x in j["steps_per_device"]), j["steps_per_device"]
     assert j["poisoned_lanes"] == 16 and j["config"]["launch"] == "single-process-queue"
     assert j["host_us_per_step_per_thread"] > 0 and j["sustained"]["seconds"] >= 0.3
+
+
+def test_delta_values_beyond_int16_are_redone_and_the_context_learns():
+    """K-DELTA (k_delta.hip) keeps an attribute's values in LDS as int16 relative to vertex 0 - checked, not assumed: positions quantised
+    to 17 / 20 bits span more than that, the wave redoes them on the 32-bit values in HBM (bit-exact, counted in stats.delta_redone), and
+    the context plans its NEXT batches with 32-bit values in LDS (stats.delta_wide).  A mesh far from the origin (large absolute
+    coordinates, 14-bit span) does NOT overflow: the values are relative.  Blobs of both kinds share one batch."""
+    from corto_amd import synth
+    c = ca.Context(0)
+    far = synth.bumpy_sphere(40, 20, seed=5)
+    far.position = far.position + np.float32(900.0)                      # quantised coordinates around 900 / q: far beyond int16, span 2^14
+    meshes = [(synth.bumpy_sphere(48, 24, seed=1), 14), (synth.bumpy_sphere(24, 12, seed=2), 17), (far, 14), (synth.torus(24, 12, seed=3), 20),
+              (synth.bumpy_sphere_flipped(32, 16, seed=4), 15), (synth.holey_disc(20, seed=6), 16)]
+    blobs = [ca.encode(m, position_bits=bits, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER if k % 2 else ca.DIFF) for k, (m, bits) in enumerate(meshes)]
+    refs = [oc.decode(b_, color_components=4) for b_ in blobs]
+    b = run_batch(c, blobs, color_components=4)
+    st = b.stats()
+    assert st.delta_wide == 0 and 2 <= st.delta_redone <= 3, (st.delta_wide, st.delta_redone)     # 17 and 20 bits for sure; 16 bits by its extent
+    for i, r in enumerate(refs):
+        assert_same(b.host_outputs(i), r, KEYS, "blob %d, %d bits, narrow plan" % (i, meshes[i][1]))
+    b.decode(); b.sync()                                                     # the same batch again: planned wide now, nothing redone
+    st = b.stats()
+    assert st.delta_wide == 1 and st.delta_redone == 0
+    for i, r in enumerate(refs):
+        assert_same(b.host_outputs(i), r, KEYS, "blob %d, %d bits, wide plan" % (i, meshes[i][1]))
+    b.close()
+    # a context that only ever sees 14-bit meshes stays narrow
+    b2 = run_batch(ca.Context(0), blobs[:1] + blobs[2:3], color_components=4)
+    assert b2.stats().delta_wide == 0 and b2.stats().delta_redone == 0
+    b2.close(); c.close()

@@ -21,4 +21,4 @@ for i in range(N + 3):
         for k, v in b.kernel_times().items():
             a = acc.setdefault(k, [0.0, 0]); a[0] += v["ms"]; a[1] += v.get("launches", 1)
 st = b.stats()
-print(kind, "flip", flip, {k: (round(v[0] / N, 4), v[1] // N) for k, v in acc.items()}, "dicts", st.tunstall_dictionaries, "of", st.tunstall_streams, "fallbacks", st.topology_fallbacks, "clers", st.clers_symbols // 256)
+print(kind, "flip", flip, {k: (round(v[0] / N, 4), v[1] // N) for k, v in acc.items()}, "dicts", st.tunstall_dictionaries, "of", st.tunstall_streams, "fallbacks", st.topology_fallbacks, "delta walked", st.delta_walked, "redone", st.delta_redone, "clers", st.clers_symbols // 256)

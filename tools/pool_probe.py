@@ -14,6 +14,12 @@ shapes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.arg
 for th, dp in shapes:
     pool = ca.Pool([0], threads=th, depth=dp)
     pool.run([blobs], steps=pool.lanes * 2, warmup=0, arenas=[[arena]])
+    if os.environ.get("PROBE_LONG"):                       # one long run and nothing else (tools/prof_pipe.sh: the trace's steady state)
+        n = int(os.environ["PROBE_LONG"])
+        rep, st = pool.run([blobs], steps=n, warmup=48, arenas=[[arena]])
+        print("threads %d depth %d: %d steps %.4f ms/step (%.1f Mtri/s)" % (th, dp, n, rep.elapsed_s / n * 1e3, rep.triangles / rep.elapsed_s / 1e6), flush=True)
+        pool.close()
+        continue
     rep, st = pool.run([blobs], steps=480, warmup=48, arenas=[[arena]])
     long_ms = rep.elapsed_s / 480 * 1e3
     d = np.diff(np.concatenate([[0], st])) * 1e3

@@ -14,7 +14,7 @@ for n in (64, 128, 256, 512, 1024):
     arena = ca.upload_arena(blobs, 0)
     pool = ca.Pool([0], threads=th, depth=dp)
     pool.run([blobs], steps=pool.lanes * 4, warmup=0, arenas=[[arena]])
-    rep, st = pool.run([blobs], steps=240, warmup=24, arenas=[[arena]])
-    ms = rep.elapsed_s / 240 * 1e3
+    rep, st = pool.run([blobs], steps=1000, warmup=48, arenas=[[arena]])
+    ms = rep.elapsed_s / 1000 * 1e3
     print("%4d blobs/batch (%dx%d): %.4f ms/step  %.2f us/blob  %.0f Mtri/s" % (n, th, dp, ms, ms * 1e3 / n, n * 4096 / ms / 1e3), flush=True)
     pool.close()

@@ -2,7 +2,10 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pipe
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-rm -rf $OUT/t; GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tools/pool_probe.py ${SHAPE:-2 3} > $OUT/log.txt 2>&1
+# the same pool, un-profiled first: how much the profiler perturbs the operating point is part of the evidence
+PROBE_LONG=${STEPS:-2000} GPU_MAX_HW_QUEUES=16 python tools/pool_probe.py ${SHAPE:-4 4} 2>/dev/null | tail -1 | sed 's/^/un-profiled: /'
+rm -rf $OUT/t; PROBE_LONG=${STEPS:-2000} GPU_MAX_HW_QUEUES=16 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tools/pool_probe.py ${SHAPE:-4 4} > $OUT/log.txt 2>&1
+grep "ms/step" $OUT/log.txt | sed 's/^/under rocprofv3: /'
 python - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True)[0]
@@ -10,7 +13,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 topo = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_topology_lds" in r["Kernel_Name"]]
 # steady state = the last 40 topology launches
-ph = topo[-400:-200]                      # steady state: inside the 480-step run of tools/pool_probe.py (the 20-step runs follow it)
+ph = topo[len(topo) // 4: 3 * len(topo) // 4]                      # steady state: the middle half of the long run
 t0, t1 = ph[0][0], ph[-1][1]
 print("steady state: %d topology launches in %.2f ms -> %.3f ms/step" % (len(ph), (t1 - t0) / 1e6, (t1 - t0) / 1e6 / len(ph)))
 ev = sorted([(s, 1) for s, e in ph] + [(e, -1) for s, e in ph])

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""threads x depth shapes of the decode pool on the C4 batch (256 blobs), long runs: usage: python tools/shape_probe.py "4 4" "8 2" ..."""
+import os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+import corto_amd as ca
+blobs, _ = bench.load_blobs(0)
+arena = ca.upload_arena(blobs, 0)
+for sh in sys.argv[1:] or ["4 4", "8 2"]:
+    th, dp = (int(x) for x in sh.split())
+    pool = ca.Pool([0], threads=th, depth=dp)
+    pool.run([blobs], steps=pool.lanes * 4, warmup=0, arenas=[[arena]])
+    rep, st = pool.run([blobs], steps=1500, warmup=48, arenas=[[arena]])
+    print("%dx%d: %.4f ms/step %.0f Mtri/s host %.0f us/step/thread (plan %.0f) wait %.0f finish %.0f  wall/thread-step %.0f %s" % (th, dp, rep.elapsed_s / 1500 * 1e3, rep.triangles / rep.elapsed_s / 1e6, rep.host_us_per_step, rep.host_plan_us, rep.host_wait_us, rep.host_finish_us, rep.elapsed_s / 1500 * 1e6 * th, pool.warning[:40]), flush=True)
+    pool.close()
