@@ -159,8 +159,8 @@ template <typename T> struct HostArr {  // host image of a device array + where 
 };
 
 struct AttrScratch {
-	uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull, vals = ~0ull; std::vector<uint64_t> sym;   // vals: int32 workspace of a generic attribute bound with a stride
-	void reset() { color = diffs = fired = vals = ~0ull; sym.clear(); }
+	uint64_t color = ~0ull, diffs = ~0ull, fired = ~0ull, vals = ~0ull, facen = ~0ull; std::vector<uint64_t> sym;   // vals: int32 workspace of a generic attribute bound with a stride; facen: the fused normal kernel's face normals when not in LDS
+	void reset() { color = diffs = fired = vals = facen = ~0ull; sym.clear(); }
 };
 struct BlobScratch {
 	uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
@@ -712,6 +712,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 			if(a.codec != CRTHIP_CODEC_COLOR && a.codec != CRTHIP_CODEC_NORMAL && bd.stride) A.vals = cv.take((uint64_t)L.h.nvert*a.N*4 + 16, 16);
 			if(a.codec == CRTHIP_CODEC_NORMAL) {
 				A.diffs = cv.take((uint64_t)L.h.nvert*8 + 16, 16);
+				if(mesh && L.attrs[k].normal_prediction != 0 && normal_fused(L.h.nvert, L.h.nface) && normal_blob_lds_fn(L.h.nvert, L.h.nface) > ctx->exp_normal_fn_max)
+					A.facen = cv.take((uint64_t)L.h.nface*12 + 16, 16);
 			}
 		}
 	}
@@ -938,6 +940,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 						n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0) | (pos_scratch ? 0x40 : 0));   // bit7: faces is a real pointer, bit6: position is a scratch offset (both cleared at fixup)
 						if(normal_fused(nvert, nface)) {
 							n.fused = 1;
+							n.fn_scratch = A.facen != ~0ull ? (float *)SP(A.facen) : nullptr;
 							if(pos_by_normal) { n.pos_out = P.bind[pos_k].buffer; n.pos_stride = P.bind[pos_k].stride ? P.bind[pos_k].stride : 12u; n.pos_q = L.h.attrs[pos_k].q; }
 							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
 							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= ctx->exp_normal_fn_max ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
@@ -1081,6 +1084,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		n.diffs = (int32_t *)R(n.diffs); n.status = (int32_t *)R(n.status);
 		if(n.prediction != 0 && !(n.faces_u16 & 0x80)) n.faces = R(n.faces);
 		if(n.prediction != 0 && (n.faces_u16 & 0x40)) n.position = (const int32_t *)R(n.position);
+		if(n.fn_scratch) n.fn_scratch = (float *)R(n.fn_scratch);
 		n.faces_u16 &= 0x3F;
 	}
 	for(auto &q : pl.dequant.v) if(q.is_color || q.stride) q.src = R(q.src);
@@ -1122,7 +1126,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 			const bool share = (!has_clers || share_clers) && (!has_attrs || share_attrs) && (has_clers || has_attrs);
 			if(share) {                                        // distinct tables first, then every stream decodes from its (shared) dictionary
 				const uint32_t d0 = has_clers ? 0u : clers_dict, d1 = has_attrs ? ndict : clers_dict;
-				LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(d1 - d0), dim3(64), 0, s, D(pl.tun_dict) + d0, d1 - d0, tables, (uint64_t *)nullptr, 0u); LT.end();
+				uint32_t big = 0;                                  // (an alphabet of more than 64 symbols builds its words in LDS: tun_tables.h)
+				for(uint32_t d = d0; d < d1; d++) if(pl.tun_dict.v[d].nsym > 64) big = TUN_TABLE_BYTES;
+				LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(d1 - d0), dim3(64), big, s, D(pl.tun_dict) + d0, d1 - d0, tables, (uint64_t *)nullptr, 0u); LT.end();
 				const uint32_t g0 = has_clers ? 0u : pl.clers_groups, g1 = has_attrs ? (uint32_t)pl.tun_groups.v.size() : pl.clers_groups;
 				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream_grouped, dim3(g1 - g0), dim3(256), 0, s, D(pl.tun), D(pl.tun_group_ids), D(pl.tun_groups) + g0, g1 - g0, tables); LT.end();
 			} else {                                           // dictionary + decode in one kernel
@@ -1151,7 +1157,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 	if(pl.tun_multi_chunk) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
 		uint64_t *tun_state = tun_partial;                                     // (single pass: the look-back's chunk state words, cleared by K-TAB)
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, D(pl.tun), ntun, tables, ctx->dbg.tun_single_pass ? tun_state : (uint64_t *)nullptr, tun_chunks); LT.end();
+		uint32_t big = 0;
+		for(auto &t : pl.tun.v) if(t.nsym > 64) big = TUN_TABLE_BYTES;
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), big, st, D(pl.tun), ntun, tables, ctx->dbg.tun_single_pass ? tun_state : (uint64_t *)nullptr, tun_chunks); LT.end();
 		if(!ctx->dbg.tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
 			if(ctx->dbg.tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end(); }
@@ -1184,7 +1192,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 		LT.begin("delta_mesh");
 		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
 		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
-		if(ng16) hipLaunchKernelGGL(k_delta_lds16, dim3(ng16), dim3(256), std::min(pl.delta16_lds + ctx->dbg.lds_pad_delta, DELTA16_LDS_MAX), st, D(pl.delta), D(pl.delta_groups), ng16);
+		if(ng16 && ctx->dbg.delta_global) hipLaunchKernelGGL(k_delta_global, dim3(ncls[2]), dim3(64), 0, st, D(pl.delta) + ncls[0] + ncls[1], ncls[2]);
+		else if(ng16) hipLaunchKernelGGL(k_delta_lds16, dim3(ng16), dim3(256), std::min(pl.delta16_lds + ctx->dbg.lds_pad_delta, DELTA16_LDS_MAX), st, D(pl.delta), D(pl.delta_groups), ng16);
 		if(ng32) hipLaunchKernelGGL(k_delta_wave, dim3(ng32), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups) + ng16, ng32);
 		LT.end();
 	}
@@ -1422,7 +1431,9 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	uint64_t *state = part;                                                  // (single pass: the chunk state words of the look-back, cleared by K-TAB)
 	const uint32_t ntun = (uint32_t)tun.size();
 	if(ntun) {
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), 0, st, dt, ntun, tables, multi && ctx->dbg.tun_single_pass ? state : (uint64_t *)nullptr, chunks); LT.end();
+		uint32_t big = 0;
+		for(auto &t : tun) if(t.nsym > 64) big = TUN_TABLE_BYTES;
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), big, st, dt, ntun, tables, multi && ctx->dbg.tun_single_pass ? state : (uint64_t *)nullptr, chunks); LT.end();
 		if(multi && !ctx->dbg.tun_single_pass) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
 			if(ctx->dbg.tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end(); }

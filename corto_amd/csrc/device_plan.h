@@ -133,6 +133,7 @@ struct NormalJob {
 	void *pos_out;                 // null: leave the positions alone
 	float pos_q;
 	uint32_t pad;
+	float *fn_scratch;             // k_normal_blob without its face normals in LDS: 3 floats per face in HBM scratch (null: recompute them per incident vertex)
 };
 
 struct DequantJob {

@@ -93,7 +93,8 @@ template <> struct LdsVal<5> {                                // bytes, mod 256 
 };
 
 // ---- values in HBM, as the caller / the bit-unpack left them (the redo path of an attribute whose relative values left int16): any
-// N <= 4, int32 or bytes.  Loads bypass the CU's cache (agent scope) and a pass's stores are waited for before the next pass reads.
+// N <= 4, int32 or bytes.  One wave owns the attribute (workgroup-scope accesses: the CU's own cache is coherent for it) and a pass's
+// stores are waited for before the next pass reads.
 template <typename T> struct GlobalVal {
 	static constexpr int NC = 4; static constexpr bool CHECK = false;
 	struct Raw { uint32_t v[4]; };
@@ -101,13 +102,13 @@ template <typename T> struct GlobalVal {
 	__device__ __forceinline__ Raw raw(uint32_t i) const {
 		Raw r;
 #pragma unroll
-		for(uint32_t q = 0; q < 4; q++) r.v[q] = q < N ? (uint32_t)__hip_atomic_load(p + (size_t)i*N + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		for(uint32_t q = 0; q < 4; q++) r.v[q] = q < N ? (uint32_t)__hip_atomic_load(p + (size_t)i*N + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
 		return r;
 	}
 	__device__ __forceinline__ static void unpack(const Raw &w, int32_t (&v)[4]) { v[0] = (int32_t)w.v[0]; v[1] = (int32_t)w.v[1]; v[2] = (int32_t)w.v[2]; v[3] = (int32_t)w.v[3]; }
 	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[4], uint32_t) const {
 #pragma unroll
-		for(uint32_t q = 0; q < 4; q++) if(q < N) __hip_atomic_store(p + (size_t)i*N + q, (T)v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for(uint32_t q = 0; q < 4; q++) if(q < N) __hip_atomic_store(p + (size_t)i*N + q, (T)v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 	__device__ __forceinline__ static int32_t wrap(int32_t v) { return (int32_t)(T)v; }
 	__device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -122,6 +123,29 @@ struct GaRef {
 
 constexpr uint32_t GW_CHAINED = 1u << 30, GW_STAYS = 1u << 31, GW_NO_BC = 0x3FFFFFFFu;
 
+// a vertex' graph word and `a`: from LDS (made once by the builder wave), or - k_delta_global, no LDS at all - worked out of the
+// prediction triple in HBM where it is needed
+__device__ __forceinline__ uint32_t graph_word(uint32_t i, uint32_t a, uint32_t b, uint32_t c) {
+	// well-formed streams always predict from earlier vertices.  A triple that does not: the value stays (vertex 0 is one) - for
+	// every attribute when it is `a`, for parallelogram attributes only when it is b or c (the others never look at them):
+	// GW_STAYS for the first, b = c = 0x7FFF (no vertex: nvert <= 32767) for the second
+	const bool va = a < i, vbc = b < i && c < i;
+	uint32_t word = !va ? GW_STAYS : vbc ? (b | (c << 15)) : GW_NO_BC;
+	if(va && a + 1u == i) word |= GW_CHAINED;
+	return word;
+}
+struct GraphLds {
+	CRT_LDS const uint32_t *gw; GaRef ga;
+	__device__ __forceinline__ void fetch(uint32_t i, uint32_t &W, uint32_t &A) const { W = gw[i]; A = ga.get(i); }
+};
+struct GraphGlobal {
+	CRT_GLOBAL const uint32_t *pred;
+	__device__ __forceinline__ void fetch(uint32_t i, uint32_t &W, uint32_t &A) const {
+		const u32x3 t = *(CRT_GLOBAL const u32x3 *)(pred + (size_t)i*3);
+		W = graph_word(i, t.x, t.y, t.z); A = t.x < i ? t.x : 0u;
+	}
+};
+
 // The window loop.  `base`: what a vertex whose value stays (malformed triple) has to give up to become relative (0 for bytes / HBM).
 // Returns the OR over every stored component of (value + 0x8000): anything at or above bit 16 = a value left int16.
 // `hand`: null, or where to leave (s, window mask) when the loop gives up in favour of the walk below - decided ONCE, at pass 24, from what
@@ -132,8 +156,8 @@ constexpr uint32_t GW_CHAINED = 1u << 30, GW_STAYS = 1u << 31, GW_NO_BC = 0x3FFF
 // (three heads, 9-11 going: 292 window passes against 24 + 150) - not rings (one head), grids (25-29 going), or holey discs (five to nine
 // heads but 20 going: 80 passes against 24 + 68).  tests/test_delta16_model_cpu.py has the families this was read off.
 struct WindowHand { uint32_t s; uint64_t donew; };
-template <class V>
-__device__ __forceinline__ uint32_t delta_window_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, const uint32_t nvert, const bool para,
+template <class V, class GR>
+__device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &graph, const uint32_t nvert, const bool para,
                                                     const int32_t (&base)[V::NC], WindowHand *hand = nullptr) {
 	constexpr int NC = V::NC;
 	const uint32_t lane = lane_id();
@@ -142,7 +166,7 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, CRT_LDS const
 	uint32_t s = 1, bad = 0;
 	uint64_t donew = 0;                                                       // bit l: vertex s + l is done (everything below s is; nothing at or above s + 64 can be)
 	uint32_t W, A; typename V::Raw D;
-	{ const uint32_t ic = s + lane < nvert ? s + lane : nvert - 1u; W = gw[ic] & wmask; A = ga.get(ic); D = val.raw(ic); }
+	{ const uint32_t ic = s + lane < nvert ? s + lane : nvert - 1u; graph.fetch(ic, W, A); W &= wmask; D = val.raw(ic); }
 	uint32_t passes = 0, nheads = 0, ngo = 0;
 	if(hand) { hand->s = nvert; hand->donew = 0; }
 	while(s < nvert) {
@@ -173,7 +197,7 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, CRT_LDS const
 		const uint32_t gb = use ? b : 0u, gc = use ? c : 0u, gp = use && head ? (ch ? i - 1u : A) : 0u;
 		const typename V::Raw Bw = val.raw(gb), Cw = val.raw(gc), Pw = val.raw(gp);
 		uint32_t W2, A2; typename V::Raw D2;
-		{ const uint32_t ic = s_next + lane < nvert ? s_next + lane : nvert - 1u; W2 = gw[ic] & wmask; A2 = ga.get(ic); D2 = val.raw(ic); }
+		{ const uint32_t ic = s_next + lane < nvert ? s_next + lane : nvert - 1u; graph.fetch(ic, W2, A2); W2 &= wmask; D2 = val.raw(ic); }
 		int32_t dv[NC], bv[NC], cv[NC], pv[NC], x[NC];
 		V::unpack(D, dv); V::unpack(Bw, bv); V::unpack(Cw, cv); V::unpack(Pw, pv);
 		uint32_t incl[NC], eh[NC];
@@ -451,7 +475,7 @@ __device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob
 	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert);
 	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
 	WindowHand hand;
-	bad |= delta_window_run(val, gw, ga, nvert, para, base, &hand);
+	bad |= delta_window_run(val, GraphLds{gw, ga}, nvert, para, base, &hand);
 	if(hand.s < nvert) {
 		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
 		bad |= delta_walk_run(val, gw, ga, fbits, starts, nvert, para, base, hand);
@@ -513,14 +537,8 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 				const uint64_t m = __ballot(start);                              // the round's 64 vertices: two dwords of the start bitmap
 				if(lane == 0 && base + u*64 < nvert) { const uint32_t d = (base + u*64) >> 5; sbits[d] = (uint32_t)m; sbits[d + 1] = (uint32_t)(m >> 32); }
 				if(i >= nvert) continue;
-				// well-formed streams always predict from earlier vertices.  A triple that does not: the value stays (vertex 0 is one) - for
-				// every attribute when it is `a`, for parallelogram attributes only when it is b or c (the others never look at them):
-				// GW_STAYS for the first, b = c = 0x7FFF (no vertex: nvert <= 32767) for the second
-				const bool va = ta[u] < i, vbc = tb[u] < i && tc[u] < i;
-				uint32_t word = !va ? GW_STAYS : vbc ? (tb[u] | (tc[u] << 15)) : GW_NO_BC;
-				if(va && ta[u] + 1u == i) word |= GW_CHAINED;
-				gw[i] = word;
-				ga.put(i, va ? ta[u] : 0u);
+				gw[i] = graph_word(i, ta[u], tb[u], tc[u]);
+				ga.put(i, ta[u] < i ? ta[u] : 0u);
 			}
 		}
 	}
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 		const LdsVal<5> val{(CRT_LDS uint32_t *)rec};
 		const int32_t zero[4] = {0, 0, 0, 0};
 		WindowHand hand;
-		(void)delta_window_run(val, gw, ga, nvert, J.parallelogram != 0, zero, &hand);
+		(void)delta_window_run(val, GraphLds{gw, ga}, nvert, J.parallelogram != 0, zero, &hand);
 		if(hand.s < nvert) {
 			if(lane == 0) as_global(J.flags)[1] = 1;
 			(void)delta_walk_run(val, gw, ga, fbits, starts, nvert, J.parallelogram != 0, zero, hand);
@@ -563,11 +581,47 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 		if(lane == 0) *as_global(J.flags) = 1;
 		const int32_t zero[4] = {0, 0, 0, 0};
 		const GlobalVal<int32_t> gval{as_global((int32_t *)J.values), N};
-		(void)delta_window_run(gval, gw, ga, nvert, J.parallelogram != 0, zero);
+		(void)delta_window_run(gval, GraphLds{gw, ga}, nvert, J.parallelogram != 0, zero);
 		if(J.deq == 1) {                                                        // floats in place of the integers (vertex_attribute.h:190-193)
 			CRT_GLOBAL int32_t *v = as_global((int32_t *)J.values);
 			const uint32_t n = nvert*N;
 			for(uint32_t k = lane; k < n; k += 64) { const int32_t x = v[k]; ((CRT_GLOBAL float *)v)[k] = (float)x*J.q; }
+		}
+	}
+}
+
+// EXPERIMENT ($CORTO_EXP_DELTA_GLOBAL=1): the same window loop with NO LDS at all - one wave per attribute, values in place in HBM (they
+// stay in L2), graph words worked out of the prediction triples as the window reaches them.  A pass costs L2 round trips instead of LDS
+// ones; what it tests is whether a pipelined decode gains more from the 44 KB x 50 us of LDS per blob it gives back than the longer
+// kernel costs.
+__global__ __launch_bounds__(64) void k_delta_global(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const DeltaJob &J = jobs[blockIdx.x];
+	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert), N = J.N, lane = lane_id();
+	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
+	const GraphGlobal graph{as_global(J.pred)};
+	const int32_t zero[4] = {0, 0, 0, 0};
+	if(J.is_u8) {
+		const GlobalVal<uint8_t> v{as_global((uint8_t *)J.values), N};
+		(void)delta_window_run(v, graph, nvert, para, zero);
+		if(J.deq == 2) {                                                        // RGB(A) out (color_attribute.cpp:76-95)
+			CRT_GLOBAL const uint8_t *src = as_global((const uint8_t *)J.values);
+			CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
+			const uint32_t oc = J.out_components, stride = J.out_stride ? J.out_stride : oc;
+			for(uint32_t i = lane; i < nvert; i += 64) {
+				uint32_t col[4] = {0, 0, 0, 255};
+				for(uint32_t c = 0; c < N && c < 4; c++) col[c] = src[(size_t)i*N + c];
+				const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
+				for(uint32_t c = 0; c < oc && c < 4; c++) dst[(size_t)i*stride + c] = (uint8_t)(rgb[c]*J.qc[c]);
+			}
+		}
+	} else {
+		const GlobalVal<int32_t> v{as_global((int32_t *)J.values), N};
+		(void)delta_window_run(v, graph, nvert, para, zero);
+		if(J.deq == 1) {
+			CRT_GLOBAL int32_t *p = as_global((int32_t *)J.values);
+			const uint32_t n = nvert*N;
+			for(uint32_t k = lane; k < n; k += 64) { const int32_t x = p[k]; ((CRT_GLOBAL float *)p)[k] = (float)x*J.q; }
 		}
 	}
 }

@@ -212,6 +212,11 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	// to stay within a CU's LDS.
 	const bool fn_lds = normal_blob_lds_fn(nv, nf) <= lds_bytes;
 	CRT_LDS float *fn = (CRT_LDS float *)(as_lds(lds_raw) + ((normal_blob_lds(nv, nf) + 15u) & ~15u));
+	// ... or once into a scratch array in HBM (it never leaves L2: 48 KB for a 4K-triangle blob) - what a context gets when many batches are
+	// in flight: the LDS-lean layout without recomputing every face's normal for each of its three vertices (round 2's lean path: 72
+	// dependent loads and three cross products per vertex where 18 loads do; 50 -> 3x us per C4 batch, and LDS.time is what bounds the pipeline)
+	CRT_GLOBAL float *fng = !fn_lds && J.fn_scratch ? as_global(J.fn_scratch) : nullptr;
+	const bool fn_any = fn_lds || fng != nullptr;
 	__shared__ uint32_t scan_s[4];
 	CRT_GLOBAL const int32_t *pos = as_global(J.position);
 	CRT_GLOBAL const uint32_t *f32 = J.faces_u16 ? nullptr : as_global((const uint32_t *)J.faces);
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			bad |= in && !ok[u];
 		}
 		int32_t P[4][9];
-		if(fn_lds) {
+		if(fn_any) {
 #pragma unroll
 			for(uint32_t u = 0; u < 4; u++) {
 				CRT_GLOBAL const int32_t *p0 = pos + 3*(ok[u] ? A[u] : 0u), *p1 = pos + 3*(ok[u] ? B[u] : 0u), *p2 = pos + 3*(ok[u] ? C[u] : 0u);
@@ -251,17 +256,21 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		for(uint32_t u = 0; u < 4; u++) if(ok[u]) {
 			const uint32_t f = f0 + 256*u, a = A[u], b = B[u], c = C[u];
 			atomicAdd((uint32_t *)&cnt[a], 1u); atomicAdd((uint32_t *)&cnt[b], 1u); atomicAdd((uint32_t *)&cnt[c], 1u);
-			if(fn_lds) {
+			if(fn_any) {
 				const float x0 = (float)P[u][0], y0 = (float)P[u][1], z0 = (float)P[u][2];
 				const float ax = (float)P[u][3] - x0, ay = (float)P[u][4] - y0, az = (float)P[u][5] - z0;
 				const float bx = (float)P[u][6] - x0, by = (float)P[u][7] - y0, bz = (float)P[u][8] - z0;
-				fn[3*f] = ay*bz - az*by; fn[3*f + 1] = az*bx - ax*bz; fn[3*f + 2] = ax*by - ay*bx;   // point.h:113-115
+				const float nx = ay*bz - az*by, ny = az*bx - ax*bz, nz = ax*by - ay*bx;   // point.h:113-115
+				if(fn_lds) { fn[3*f] = nx; fn[3*f + 1] = ny; fn[3*f + 2] = nz; }
+				else { fng[3*(size_t)f] = nx; fng[3*(size_t)f + 1] = ny; fng[3*(size_t)f + 2] = nz; }
 			}
 			if(J.prediction == 2) { atomicXor((uint32_t *)&bnd[a], b ^ c); atomicXor((uint32_t *)&bnd[b], c ^ a); atomicXor((uint32_t *)&bnd[c], a ^ b); }
 		}
 	}
 	if(bad) *as_global(J.status) = -5;
+	if(fng) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // the face normals in HBM: written here, read by other waves of this workgroup below
 	__syncthreads();
+	if(fng) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	// the integer positions have been read for the last time when the face normals sit in LDS: they become floats now (in place, or
 	// into an interleaved vertex buffer), while the rest of the kernel works from LDS; otherwise at the very end (below)
 	auto positions_out = [&]() {                                           // (loads in groups, every one of a group in flight: one at a time this loop was a third of the kernel)
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			}
 		}
 	};
-	if(fn_lds) positions_out();
+	if(fn_any) positions_out();
 	// two block-wide exclusive scans over the vertices: CSR offsets of cnt, and correction slots of the flags
 	const uint32_t per = (nv + 255)/256;
 	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint16_t *out, bool flags) {
@@ -390,10 +399,15 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			CRT_CX(3, 4)
 #undef CRT_CX
 			const uint32_t id0 = id[0];                                      // a valid face: stands in for the unused slots' loads
-			if(fn_lds) {
+			if(fn_any) {
 				float n[8][3];
+				if(fn_lds) {
 #pragma unroll
-				for(uint32_t k = 0; k < 8; k++) { const uint32_t f = k < deg ? id[k] : id0; n[k][0] = fn[3*f]; n[k][1] = fn[3*f + 1]; n[k][2] = fn[3*f + 2]; }
+					for(uint32_t k = 0; k < 8; k++) { const uint32_t f = k < deg ? id[k] : id0; n[k][0] = fn[3*f]; n[k][1] = fn[3*f + 1]; n[k][2] = fn[3*f + 2]; }
+				} else {
+#pragma unroll
+					for(uint32_t k = 0; k < 8; k++) { const uint32_t f = k < deg ? id[k] : id0; CRT_GLOBAL const float *q = fng + 3*(size_t)f; n[k][0] = q[0]; n[k][1] = q[1]; n[k][2] = q[2]; }
+				}
 #pragma unroll
 				for(uint32_t k = 0; k < 8; k++) asm volatile("" : "+v"(n[k][0]), "+v"(n[k][1]), "+v"(n[k][2]));
 #pragma unroll
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			}
 			float nx, ny, nz;
 			if(fn_lds) { nx = fn[3*best]; ny = fn[3*best + 1]; nz = fn[3*best + 2]; }
+			else if(fng) { nx = fng[3*(size_t)best]; ny = fng[3*(size_t)best + 1]; nz = fng[3*(size_t)best + 2]; }
 			else {
 				uint32_t a, b, c; face(best, a, b, c);
 				CRT_GLOBAL const int32_t *p0 = pos + 3*a, *p1 = pos + 3*b, *p2 = pos + 3*c;
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
 		}
 	}
-	if(!fn_lds) { __syncthreads(); positions_out(); }
+	if(!fn_any) { __syncthreads(); positions_out(); }
 }
 
 } // namespace corto_hip

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	if(s >= nstreams) return;
 	const TunStream st = streams[s];
 	const uint32_t lane = threadIdx.x;
-	tun_tables_body(st, &tables[st.table], nullptr, nullptr);
+	extern __shared__ __attribute__((aligned(16))) uint8_t big_words[];        // TUN_TABLE_BYTES when the launch has an alphabet of more than 64 symbols, else nothing
+	tun_tables_body<true>(st, &tables[st.table], nullptr, nullptr, nullptr, big_words);
 	// a long stream's chunks find their output offsets by look-back (tun_lookback below): their state words start out empty
 	if(lookback_state && st.nchunks > 1) for(uint32_t i = lane; i < st.nchunks; i += 64) lookback_state[st.chunk0 + i] = 0;
 	if(lookback_state && s == 0 && lane == 0) lookback_state[lookback_words] = 0;        // the give-up counter behind them

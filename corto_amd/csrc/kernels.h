@@ -95,6 +95,7 @@ __host__ __device__ inline uint32_t delta16_graph_lds(uint32_t nvert, bool a_emb
 	return ((4u*nvert + 15u) & ~15u) + (a_embedded ? 0u : ((2u*nvert + 15u) & ~15u)) + delta16_walk_shared(nvert) + 4u*4u*(64u + delta_wave_bit_words(nvert)) + 16u;
 }
 __global__ void k_delta_lds16(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
+__global__ void k_delta_global(const DeltaJob *jobs, uint32_t njobs);      // experiment: the same loop with no LDS (values and graph in HBM / L2), one wave per attribute
 
 // k_normal.hip
 __global__ void k_normal_diff(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks);

@@ -16,10 +16,19 @@ __device__ uint64_t g_tun_stamps[8*4096];
 #define TUN_STAMP(k) do { } while(0)
 #endif
 __shared__ __attribute__((aligned(16))) uint8_t g_tun_words[TUN_TABLE_BYTES];        // (one definition: both kernels below are single-wave workgroups)
-__device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTable *Tg, uint16_t *loff, uint8_t *llen, const uint8_t *probs_override = nullptr) {
+// WORDS_TO_HBM (K-TAB only, Tg != null): up to 64 symbols - every stream an encoder really writes - the word bytes are only ever WRITTEN
+// while the dictionary is made (seed bytes, then the surviving words spelled out), so they go straight to the TunTable in HBM and the
+// kernel's LDS is the 6.4 KB of the growth bookkeeping instead of 15.6 KB (its LDS.time is what a batch's ~250 dictionaries cost the
+// pipelined decode).  Bigger alphabets copy parents' bytes: they use `big_words`, 9 KB of dynamic LDS the host adds to the
+// launch when a stream of the launch has more than 64 symbols.
+template <bool WORDS_TO_HBM = false>
+__device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTable *Tg, uint16_t *loff, uint8_t *llen, const uint8_t *probs_override = nullptr, uint8_t *big_words = nullptr) {
 	const uint8_t *probs = probs_override ? probs_override : st.probs;   // nsym x (symbol, probability), sorted as stored in the stream
 	TunTable &T = *Tg;                           // (only touched when Tg != null)
-	uint8_t *buf = g_tun_words;
+	const bool to_hbm = WORDS_TO_HBM && st.nsym <= 64;
+	uint8_t *buf = WORDS_TO_HBM ? big_words : g_tun_words;                 // (LDS: read and written; to_hbm: never touched)
+	CRT_GLOBAL uint8_t *gbuf = WORDS_TO_HBM ? as_global(Tg->bytes) : nullptr;
+	auto put = [&](uint32_t at, uint8_t v) { if(WORDS_TO_HBM && to_hbm) gbuf[at] = v; else buf[at] = v; };
 	const uint32_t n = st.nsym;                 // 2..255 (host guarantees)
 	const uint32_t lane = threadIdx.x;
 
@@ -50,7 +59,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		for(uint32_t b = lane; b < total; b += 64) {
 			uint8_t v = A;
 			if(b > 0) { uint32_t k = (b - 1)/count + 1, j = (b - 1) - (k - 1)*count; if(j == count - 1) v = sym[k]; }
-			buf[b] = v;
+			put(b, v);
 		}
 		if(lane == 0) {                         // P0^col, col = 1..count
 			uint32_t v = p0; pw[1] = v;
@@ -72,7 +81,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		pos = total;
 	} else {                                    // one-symbol words (tunstall.cpp:195-205)
 		for(uint32_t i = lane; i < n; i += 64) {
-			head[i] = (uint16_t)i; epl[i] = (uint32_t)P[i] | (1u | ((uint32_t)sym[i] << 8)) << 16; eoff[i] = (uint16_t)i; buf[i] = sym[i];
+			head[i] = (uint16_t)i; epl[i] = (uint32_t)P[i] | (1u | ((uint32_t)sym[i] << 8)) << 16; eoff[i] = (uint16_t)i; put(i, sym[i]);
 		}
 		nwords = n; end = n; pos = n;
 	}
@@ -220,10 +229,10 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		}
 		if(made && len) {
 			uint32_t cur = e, j = off + len;
-			while(cur >= seed_end && j > off + 1) { const uint32_t lr = epl[cur]; buf[--j] = (uint8_t)(lr >> 24); cur = eoff[cur]; }
+			while(cur >= seed_end && j > off + 1) { const uint32_t lr = epl[cur]; put(--j, (uint8_t)(lr >> 24)); cur = eoff[cur]; }
 			const uint32_t lr = epl[cur];
-			buf[--j] = (uint8_t)(lr >> 24);
-			while(j > off) buf[--j] = A;
+			put(--j, (uint8_t)(lr >> 24));
+			while(j > off) put(--j, A);
 		}
 		w += __popcll(mask);
 	}
@@ -233,6 +242,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 	__syncthreads();
 	if(Tg) {
 		if(lane == 0) { T.used = used; T.maxlen = maxlen; }
+		if(WORDS_TO_HBM && to_hbm) return TunBuilt{used, maxlen};           // the words are there already
 		typedef uint32_t v4_t __attribute__((ext_vector_type(4)));
 		const uint32_t nv = ((used < TUN_TABLE_BYTES ? used : TUN_TABLE_BYTES) + 15u) >> 4;       // 16-byte vectors (both sides are 16-aligned)
 		const v4_t *src4 = (const v4_t *)buf;

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bench
 import corto_amd as ca
 blobs, _ = bench.load_blobs(0)
+if os.environ.get("KIND") == "irregular":
+    from corto_amd import synth
+    blobs = [ca.encode(synth.bumpy_sphere_flipped(64, 32, seed=i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(256)]
 arena = ca.upload_arena(blobs, 0)
 for sh in sys.argv[1:] or ["4 4", "8 2"]:
     th, dp = (int(x) for x in sh.split())
