@@ -743,7 +743,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	auto dict_of = [&](const StreamRef &s, const TunStream &t) -> uint32_t {
 		const uint32_t fresh = (uint32_t)pl.tun_dict.v.size();
 		auto make = [&]() { TunStream d = t; d.table = fresh; d.dict = fresh; d.nchunks = 1; pl.tun_dict.v.push_back(d); return fresh; };
-		if(s.nsym > 16 || fresh - dict_group0 >= 4096) return make();
+		if(s.nsym > 16 || fresh - dict_group0 >= 4096 || ctx->dbg.tun_share == 0 || ctx->dbg.tun_share == 2) return make();   // (0 / 2: one dictionary per stream, whatever repeats)
 		uint64_t h = 0x9E3779B97F4A7C15ull ^ s.nsym;
 		for(uint32_t k = 0; k < 2*s.nsym; k += 8) { uint64_t w; memcpy(&w, s.probs16 + k, 8); h = (h ^ w)*0xFF51AFD7ED558CCDull; h ^= h >> 32; }
 		for(uint32_t pos = (uint32_t)h & 8191u;; pos = (pos + 1) & 8191u) {
@@ -969,7 +969,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 	}
 	// streams of a launch that share dictionaries: sorted by dictionary (counting sort), cut into groups of one dictionary each
 	const uint32_t ntun_all = (uint32_t)pl.tun.v.size(), ndict_all = (uint32_t)pl.tun_dict.v.size();
-	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { return ctx->dbg.tun_share == 1 ? ndicts < nstreams : ctx->dbg.tun_share != 0 && nstreams >= 64 && 2*ndicts <= nstreams; };
+	// dictionaries by one kernel (K-TAB, 6 KB of LDS per wave), decodes by another (10 KB for a few us), instead of both in one wave per stream
+	// (16 KB for ~37 us): a batch of many streams is bound by LDS.time, so the split pays even when NO two streams share a table
+	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { (void)ndicts; return ctx->dbg.tun_share == 0 ? false : ctx->dbg.tun_share == 1 ? true : nstreams >= 64; };
 	const bool share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict), share_attrs = !pl.tun_multi_chunk && shares(ntun_all - clers_tun, ndict_all - clers_dict);
 	{
 		std::vector<uint32_t> &cnt = ctx->dict_count;

@@ -17,7 +17,9 @@ namespace corto_hip {
 
 struct DebugConfig {
 	// deployment
-	int tun_share = -1;             // $CORTO_TUN_SHARE: 0 never share dictionaries, 1 whenever two streams carry one table, unset: when at least half of a launch's streams do
+	int tun_share = -1;             // $CORTO_TUN_SHARE: unset: launches of 64+ streams make every DISTINCT probability table's dictionary once (K-TAB) and decode
+	                                // the streams in groups of one dictionary; 2: the same two kernels but one dictionary PER STREAM, whatever repeats (what a
+	                                // batch of unrelated meshes looks like); 0: dictionary and decode by one wave per stream (rounds 1-2); 1: two kernels always
 	int delta_wide = 0;             // $CORTO_DELTA_WIDE=1: K-DELTA keeps 32-bit values in LDS from the start (a context otherwise learns it from its first overflowing batch)
 	// experiments (A/B measurements; all bit-exact)
 	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: long streams - one device-wide scan kernel over the chunk sums (round 1)
@@ -36,7 +38,7 @@ inline DebugConfig debug_config_from_env() {
 	{
 		DebugConfig c;
 		auto on = [](const char *name) { const char *e = getenv(name); return e && e[0] == '1'; };
-		if(const char *e = getenv("CORTO_TUN_SHARE")) if(e[0] == '0' || e[0] == '1') c.tun_share = e[0] - '0';
+		if(const char *e = getenv("CORTO_TUN_SHARE")) if(e[0] >= '0' && e[0] <= '2') c.tun_share = e[0] - '0';
 		c.delta_wide = on("CORTO_DELTA_WIDE");
 		c.tun_two_pass = on("CORTO_TUN_TWO_PASS");
 		c.tun_single_pass = on("CORTO_TUN_SINGLE_PASS") && !c.tun_two_pass;

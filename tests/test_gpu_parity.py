@@ -94,7 +94,7 @@ def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     gs = [load_golden(n) for n in ALL_CASES]
     blobs = [g["crt"] for g in gs] * 2 + [aligned(z["crt_%02d" % s]) for s in range(16)]
     seen = {}
-    for share in ("1", "0", None):
+    for share in ("1", "0", "2", None):
         if share is None:
             monkeypatch.delenv("CORTO_TUN_SHARE", raising=False)
         else:
@@ -110,7 +110,7 @@ def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
         st = b.stats()
         seen[share] = (st.tunstall_dictionaries, st.tunstall_streams)
         b.close(); c.close()
-    assert seen["0"][0] == seen["0"][1], seen                       # one dictionary per stream
+    assert seen["0"][0] == seen["0"][1] and seen["2"][0] == seen["2"][1], seen      # one dictionary per stream (one kernel / two kernels)
     assert seen["1"][0] < seen["1"][1] // 2, seen                   # every fixture is there twice
     assert seen[None][0] <= seen["0"][0], seen
 
