@@ -119,7 +119,29 @@ def facade_per_blob(ca, blobs, device):
     wall = time.perf_counter() - t0
     for c in ctxs:
         c.close()
-    return {"one_thread_us": round(one * 1e6, 1), "four_threads_us_per_blob": round(wall / (4 * 12 * len(sample)) * 1e6, 1),
+    # the C++ facade itself (crt::Decoder, decoder_facade.cpp): its decode() calls are coalesced across threads
+    cpp = {}
+    try:
+        import subprocess, tempfile
+        from corto_amd import build as bld
+        d = tempfile.mkdtemp(prefix="corto_facade_")
+        exe = os.path.join(d, "facade_threads")
+        subprocess.check_call(["g++", "-O2", "-std=c++11", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_threads.cpp"),
+                               "-L", bld.LIBDIR, "-lcorto_hip", "-Wl,-rpath," + bld.LIBDIR, "-o", exe])
+        files = []
+        for i, b in enumerate(sample):
+            f = os.path.join(d, "b%02d.crt" % i); np.asarray(b).tofile(f); files.append(f)
+        for nt in (1, 4, 16):
+            out = subprocess.run([exe, str(nt), "24" if nt == 1 else "16", "-", *files], capture_output=True, text=True, timeout=120, env=dict(os.environ, CORTO_HIP_DEVICE=str(device)))
+            if out.returncode == 0:
+                kv = dict(l.split() for l in out.stdout.strip().splitlines() if len(l.split()) == 2)
+                cpp["%d_threads" % nt] = {"us_per_blob": float(kv["wall_us_per_blob"]), "decode_call_us": float(kv["per_decode_us"])}
+        cpp["note"] = ("crt::Decoder::decode() on N threads, a fresh Decoder per blob (tests/cpp/facade_threads.cpp): us_per_blob = wall time over all decodes; concurrent calls are "
+                       "coalesced into one batch by the facade's combiner.  A blob's decode is one serial chain on the GPU (~0.3 ms whatever else runs), so N synchronous callers "
+                       "cannot get below (0.3 ms + host) / N per blob")
+    except Exception as e:                           # (no compiler on the box, ...: the ctypes numbers stand)
+        cpp["error"] = str(e)[:200]
+    return {"one_thread_us": round(one * 1e6, 1), "four_threads_us_per_blob": round(wall / (4 * 12 * len(sample)) * 1e6, 1), "crt_decoder_cpp": cpp,
             "mtri_per_s_one_thread": round(4096 / one / 1e6, 2),
             "note": "crthip_decode_host per C4-unit blob (host .crt -> host arrays: what crt::Decoder::decode() costs), contexts reused; "
                     "timed through ctypes (a few us of Python per call included).  Beside it: cpu_baseline's per-blob time = 4096 / (Mtri/s)"}

@@ -1334,54 +1334,96 @@ extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const ch
 }
 
 // ------------------------------------------------------------------------------------------------
-// one blob, host buffers: the crt::Decoder facade's decode().  The batch object, the device output block and its pinned landing
-// zone live in the context: in the steady state a call is one upload of the blob, one upload of the job descriptors, the kernels,
+// blobs with HOST output buffers: the crt::Decoder facade's decode() (one blob, crthip_decode_host) and its combiner (the blobs of
+// every thread that called decode() at about the same time, decoder_facade.cpp).  The batch object, the device output block and its
+// pinned landing zone live in the context: in the steady state a call is one upload of the blobs, one descriptor upload, the kernels,
 // and ONE download of all outputs - no allocation, no per-attribute copies.  Serialised per context (host_mutex).
+// A blob the walk rejects fails alone: the others are decoded without it.
+namespace corto_hip {
+int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy_out) {
+	if(!ctx || !reqs || n == 0) return fail(CRTHIP_E_ARGUMENT);
+	std::lock_guard<std::mutex> lock(ctx->host_mutex);
+	HIP_TRY(hipSetDevice(ctx->device));
+	// the blobs the walk accepts (a malformed one must not take its neighbours down)
+	std::vector<const uint8_t *> blobs; std::vector<uint32_t> lens; std::vector<uint32_t> who;
+	for(uint32_t i = 0; i < n; i++) {
+		HostDecodeReq &r = reqs[i];
+		r.status = CRTHIP_OK; r.nout = 0;
+		if(!r.blob || r.len > 0xFFFFFFFFull) { r.status = r.blob ? CRTHIP_E_LIMIT : CRTHIP_E_ARGUMENT; continue; }
+		if(n > 1) { BlobLayout L; const int e = walk_blob(r.blob, r.len, L); if(e) { r.status = fail(e); continue; } }
+		blobs.push_back(r.blob); lens.push_back((uint32_t)r.len); who.push_back(i);
+	}
+	const uint32_t m = (uint32_t)blobs.size();
+	if(m == 0) return reqs[0].status;
+	int err;
+	if(!ctx->host_batch) err = crthip_batch_create(ctx, m, blobs.data(), lens.data(), nullptr, &ctx->host_batch);
+	else err = crthip_batch_reset(ctx->host_batch, m, blobs.data(), lens.data(), nullptr);
+	if(err) { for(uint32_t k = 0; k < m; k++) reqs[who[k]].status = err; return err; }
+	crthip_batch *b = ctx->host_batch;
+	// outputs of every blob back to back in one device block (16-byte aligned pieces)
+	std::vector<crthip_attr_binding> dev; std::vector<void *> dindex(m, nullptr); std::vector<uint32_t> ifmt(m, CRTHIP_FMT_UINT32);
+	struct Piece { uint32_t req, slot; size_t off, bytes; void *host; };
+	std::vector<Piece> pieces;
+	size_t total = 0;
+	for(uint32_t k = 0; k < m; k++) {
+		HostDecodeReq &r = reqs[who[k]];
+		const BlobLayout &L = b->blobs[k].L;
+		const uint32_t nvert = L.h.nvert, nface = L.h.nface;
+		const size_t na = L.h.attrs.size();
+		for(size_t a = 0; a < na; a++) {
+			// attrs == NULL: nothing bound (an index-only decode); host buffers have upstream's packed layouts - a stride is refused, not ignored
+			crthip_attr_binding d;
+			if(r.attrs) d = r.attrs[a]; else { d.buffer = nullptr; d.format = CRTHIP_FMT_FLOAT; d.out_components = 0; d.stride = 0; }
+			if(d.buffer && d.stride) { r.status = fail(CRTHIP_E_ARGUMENT, "crthip_decode_host: host buffers are tightly packed (stride must be 0)"); d.buffer = nullptr; }
+			d.stride = 0; d.reserved = 0;
+			if(d.buffer && r.status == CRTHIP_OK) {
+				const AttrHeader &A = L.h.attrs[a];
+				size_t bytes;
+				if(A.codec == CRTHIP_CODEC_NORMAL) bytes = (size_t)nvert*3*(d.format == CRTHIP_FMT_INT16 ? 2 : 4);
+				else if(A.codec == CRTHIP_CODEC_COLOR) bytes = (size_t)nvert*(d.out_components ? d.out_components : 4);
+				else bytes = (size_t)nvert*A.N*4;
+				pieces.push_back(Piece{who[k], (uint32_t)a, total, bytes, d.buffer});
+				d.buffer = (void *)(uintptr_t)(total + 1);                    // (offset + 1: rebased below, once the block is there)
+				total += (bytes + 15) & ~(size_t)15;
+			} else d.buffer = nullptr;
+			dev.push_back(d);
+		}
+		if(r.index && nface && r.status == CRTHIP_OK) {
+			const size_t bytes = (size_t)nface*3*(r.index_format == CRTHIP_FMT_UINT16 ? 2 : 4);
+			pieces.push_back(Piece{who[k], CRTHIP_MAX_ATTRS, total, bytes, r.index});
+			dindex[k] = (void *)(uintptr_t)(total + 1); ifmt[k] = r.index_format;
+			total += (bytes + 15) & ~(size_t)15;
+		}
+	}
+	if(ctx->host_out.reserve(total + 16) != CRTHIP_OK || ctx->host_pin.reserve(total + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	uint8_t *dbase = (uint8_t *)ctx->host_out.p, *hbase = (uint8_t *)ctx->host_pin.p;
+	for(auto &d : dev) if(d.buffer) d.buffer = dbase + ((uintptr_t)d.buffer - 1);
+	for(auto &p : dindex) if(p) p = dbase + ((uintptr_t)p - 1);
+	err = crthip_batch_bind_all(b, dev.data(), dindex.data(), ifmt.data());
+	if(!err) err = crthip_batch_decode(b);
+	if(!err && total && hipMemcpyAsync(hbase, dbase, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
+	std::vector<int32_t> st(m, 0);
+	const int serr = crthip_batch_sync(b, st.data());      // waits for the copy too (same stream); keeps the context consistent on error
+	(void)serr;
+	for(uint32_t k = 0; k < m; k++) { HostDecodeReq &r = reqs[who[k]]; if(err) r.status = err; else if(r.status == CRTHIP_OK) r.status = st[k]; }
+	for(const Piece &p : pieces) {
+		HostDecodeReq &r = reqs[p.req];
+		if(r.status != CRTHIP_OK) continue;
+		if(copy_out) memcpy(p.host, hbase + p.off, p.bytes);
+		else if(r.nout < CRTHIP_MAX_ATTRS + 1) { r.out_src[r.nout] = hbase + p.off; r.out_dst[r.nout] = p.host; r.out_bytes[r.nout] = p.bytes; r.nout++; }
+	}
+	for(uint32_t i = 0; i < n; i++) if(reqs[i].status) return reqs[i].status;            // (the first failing blob's code - its message is the thread's last error; every status is in its request)
+	return CRTHIP_OK;
+}
+}
+
 extern "C" int crthip_decode_host(crthip_ctx *ctx, const uint8_t *blob, size_t len, const crthip_attr_binding *attrs,
                                   void *index, uint32_t index_format) {
 	if(!ctx || !blob) return fail(CRTHIP_E_ARGUMENT);
 	if(len > 0xFFFFFFFFull) return fail(CRTHIP_E_LIMIT, "blob larger than 4 GiB");
-	std::lock_guard<std::mutex> lock(ctx->host_mutex);
-	HIP_TRY(hipSetDevice(ctx->device));
-	uint32_t l32 = (uint32_t)len;
-	int err;
-	if(!ctx->host_batch) err = crthip_batch_create(ctx, 1, &blob, &l32, nullptr, &ctx->host_batch);
-	else err = crthip_batch_reset(ctx->host_batch, 1, &blob, &l32, nullptr);
-	if(err) return err;
-	crthip_batch *b = ctx->host_batch;
-	const BlobLayout &L = b->blobs[0].L;
-	const uint32_t nvert = L.h.nvert, nface = L.h.nface;
-	const size_t na = L.h.attrs.size();
-	crthip_attr_binding dev[CRTHIP_MAX_ATTRS];
-	size_t off[CRTHIP_MAX_ATTRS + 1], bytes[CRTHIP_MAX_ATTRS + 1];
-	size_t total = 0;
-	for(size_t k = 0; k < na; k++) {
-		// attrs == NULL: nothing bound (an index-only decode); host buffers have upstream's packed layouts - a stride is refused, not ignored
-		if(attrs) dev[k] = attrs[k]; else { dev[k].buffer = nullptr; dev[k].format = CRTHIP_FMT_FLOAT; dev[k].out_components = 0; dev[k].stride = 0; }
-		if(dev[k].buffer && dev[k].stride) return fail(CRTHIP_E_ARGUMENT, "crthip_decode_host: host buffers are tightly packed (stride must be 0)");
-		dev[k].stride = 0; dev[k].reserved = 0; bytes[k] = 0; off[k] = 0;
-		if(!dev[k].buffer) continue;
-		const AttrHeader &a = L.h.attrs[k];
-		if(a.codec == CRTHIP_CODEC_NORMAL) bytes[k] = (size_t)nvert*3*(dev[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
-		else if(a.codec == CRTHIP_CODEC_COLOR) bytes[k] = (size_t)nvert*(dev[k].out_components ? dev[k].out_components : 4);
-		else bytes[k] = (size_t)nvert*a.N*4;
-		off[k] = total; total += (bytes[k] + 15) & ~(size_t)15;
-	}
-	bytes[na] = 0; off[na] = total;
-	if(index && nface) { bytes[na] = (size_t)nface*3*(index_format == CRTHIP_FMT_UINT16 ? 2 : 4); total += (bytes[na] + 15) & ~(size_t)15; }
-	if(ctx->host_out.reserve(total + 16) != CRTHIP_OK || ctx->host_pin.reserve(total + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-	uint8_t *dbase = (uint8_t *)ctx->host_out.p, *hbase = (uint8_t *)ctx->host_pin.p;
-	for(size_t k = 0; k < na; k++) if(dev[k].buffer) dev[k].buffer = dbase + off[k];
-	err = crthip_batch_bind(b, 0, dev, bytes[na] ? dbase + off[na] : nullptr, index_format);
-	if(!err) err = crthip_batch_decode(b);
-	if(!err && total && hipMemcpyAsync(hbase, dbase, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
-	const int serr = crthip_batch_sync(b, nullptr);          // waits for the copy too (same stream); keeps the context consistent on error
-	if(!err) err = serr;
-	if(!err) {
-		for(size_t k = 0; k < na; k++) if(bytes[k]) memcpy(attrs[k].buffer, hbase + off[k], bytes[k]);      // (bytes[k] != 0 only with attrs)
-		if(bytes[na]) memcpy(index, hbase + off[na], bytes[na]);
-	}
-	return err;
+	HostDecodeReq r{};
+	r.blob = blob; r.len = len; r.attrs = attrs; r.index = index; r.index_format = index_format;
+	return decode_host_many(ctx, 1, &r, true);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@
 // uses, whether streams of a batch share dictionaries.  Experiment switches (CORTO_EXP_* / CORTO_TUN_*): alternative kernel paths kept
 // for A/B measurements (tools/) - each one is bit-exact and has a parity test that runs the GPU suite's cases through it
 // (tests/test_gpu_parity.py::test_experiment_switches_are_bit_exact); none changes results, only which kernels produce them.
-// Besides these: decoder_facade.cpp reads $CORTO_HIP_CONTEXTS / $CORTO_HIP_DEVICE / $CORTO_HIP_COMBINE_US once, pool.cpp reads ROCm's own
+// Besides these: decoder_facade.cpp reads $CORTO_HIP_CONTEXTS / $CORTO_HIP_DEVICE / $CORTO_HIP_COMBINE_US / $CORTO_HIP_LEADERS once, pool.cpp reads ROCm's own
 // $GPU_MAX_HW_QUEUES to size itself.
 #pragma once
 #include <cstdint>

@@ -7,9 +7,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/corto_hip.h"
+#include "encoder_internal.h"
+
+#include <atomic>
+#include <chrono>
 
 namespace crt {
 namespace {
@@ -84,6 +90,103 @@ struct Lease {
 	Lease(const Lease &) = delete;
 	Lease &operator=(const Lease &) = delete;
 };
+
+// The decode combiner.  A 4K-triangle blob alone is one serial chain on the GPU (its CLERS automaton takes as long as a whole batch's),
+// so N threads that each decode their own blob on their own context pay N launch sequences for N chains that one batch would run side by
+// side.  Concurrent decode() calls are therefore coalesced: a caller queues its request; whoever finds no leader at work becomes one,
+// waits a few microseconds when other callers are about (they are usually a step behind), takes what has queued up - its own request
+// included, up to COMBINE_MAX - and decodes it as ONE batch on a pool context (corto_hip::decode_host_many: one upload, one set of
+// launches, one download); every caller then copies its own outputs out of the pinned landing zone, the leader waits for them and
+// gives the context back.  A lone caller is its own leader and takes the one-blob path at its cost.  $CORTO_HIP_COMBINE_US: the gather
+// window (default 30; 0: never wait; negative: no combining, a context per caller); $CORTO_HIP_LEADERS: batches in flight (default 2).
+constexpr uint32_t COMBINE_MAX = 64;
+struct Request {
+	corto_hip::HostDecodeReq h{};
+	std::vector<crthip_attr_binding> binds;
+	bool taken = false, ready = false;      // picked up by a leader; decoded (outputs waiting in the landing zone, or status != OK)
+	std::atomic<int> *pending = nullptr;    // the leader's count of followers still copying
+	std::string message;                    // why it failed (the leader's thread-local last error)
+};
+struct Combiner {
+	std::mutex m;
+	std::condition_variable cv;
+	std::vector<Request *> q;
+	int leaders = 0, callers = 0;           // leaders at work; threads inside decode()
+	int window_us = -1, max_leaders = 0;
+} g_comb;
+
+void copy_out(const Request &r) {
+	for(uint32_t k = 0; k < r.h.nout; k++) memcpy(r.h.out_dst[k], r.h.out_src[k], r.h.out_bytes[k]);
+}
+
+int combined_decode(Request &r) {
+	std::unique_lock<std::mutex> lock(g_comb.m);
+	if(g_comb.window_us == -1) { const char *e = getenv("CORTO_HIP_COMBINE_US"); g_comb.window_us = e ? atoi(e) : 30; if(g_comb.window_us < 0) g_comb.window_us = -2; }   // (< 0: every caller decodes its own blob)
+	if(!g_pool.limit) g_pool.limit = pool_limit();
+	if(!g_comb.max_leaders) {
+		// TWO batches in flight (one being planned and copied out while the other's kernels run), however many threads call: what makes the
+		// batches big is that callers queue up behind busy leaders - with a leader per caller (8 contexts) sixteen threads got 97 us a blob,
+		// with two 38 (tests/cpp/facade_threads.cpp).  Combining off: as many as the pool has contexts.
+		const char *e = getenv("CORTO_HIP_LEADERS");
+		const int n = e ? atoi(e) : 2;
+		g_comb.max_leaders = g_comb.window_us < 0 ? g_pool.limit : n < 1 ? 1 : n > g_pool.limit ? g_pool.limit : n;
+	}
+	g_comb.callers++;
+	g_comb.q.push_back(&r);
+	for(;;) {
+		if(r.ready) break;
+		if(!r.taken && g_comb.leaders < g_comb.max_leaders) {
+			// lead: let the callers that are a step behind queue up, then take what is there
+			g_comb.leaders++;
+			if(g_comb.callers > 2 && g_comb.window_us > 0 && g_comb.q.size() < (size_t)g_comb.callers) {      // (two callers: a context each is as good)
+				lock.unlock();
+				const auto t0 = std::chrono::steady_clock::now();
+				while(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < g_comb.window_us) {
+#if defined(__x86_64__)
+					__builtin_ia32_pause();
+#endif
+				}
+				lock.lock();
+			}
+			if(r.taken) { g_comb.leaders--; g_comb.cv.notify_all(); continue; }   // another leader took mine while I gathered: follow it
+			std::vector<Request *> mine;
+			if(g_comb.window_us < 0) {                                  // combining off: mine alone
+				for(auto it = g_comb.q.begin(); it != g_comb.q.end(); ++it) if(*it == &r) { g_comb.q.erase(it); break; }
+				r.taken = true; mine.push_back(&r);
+			} else
+			for(auto it = g_comb.q.begin(); it != g_comb.q.end() && mine.size() < COMBINE_MAX;) { (*it)->taken = true; mine.push_back(*it); it = g_comb.q.erase(it); }
+			lock.unlock();
+			std::atomic<int> pending((int)mine.size() - 1);
+			std::vector<corto_hip::HostDecodeReq> reqs(mine.size());
+			for(size_t k = 0; k < mine.size(); k++) reqs[k] = mine[k]->h;
+			int lease_err = 0;
+			try {
+				Lease lease;                                          // a context of the pool for the duration of this batch
+				(void)corto_hip::decode_host_many(lease.ctx, (uint32_t)reqs.size(), reqs.data(), false);
+				const std::string msg = crthip_last_error();
+				lock.lock();
+				for(size_t k = 0; k < mine.size(); k++) { mine[k]->h = reqs[k]; mine[k]->pending = &pending; if(reqs[k].status) mine[k]->message = msg; mine[k]->ready = true; }
+				g_comb.cv.notify_all();
+				lock.unlock();
+				copy_out(r);                                          // mine, while the followers copy theirs
+				while(pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();   // the landing zone is the context's: keep it until they are done
+			} catch(const char *) { lease_err = CRTHIP_E_DEVICE; }
+			lock.lock();
+			if(lease_err) { for(Request *q : mine) if(!q->ready) { q->h.status = lease_err; q->h.nout = 0; q->message = crthip_strerror(lease_err); q->ready = true; } }
+			g_comb.leaders--;
+			g_comb.callers--;
+			g_comb.cv.notify_all();
+			return r.h.status;
+		}
+		g_comb.cv.wait(lock);
+	}
+	// a follower: copy my outputs, tell the leader
+	g_comb.callers--;
+	lock.unlock();
+	if(r.h.status == CRTHIP_OK) copy_out(r);
+	if(r.pending) r.pending->fetch_sub(1, std::memory_order_release);
+	return r.h.status;
+}
 
 } // namespace
 
@@ -171,22 +274,20 @@ void Decoder::decode() {
 			}
 		}
 	}
-	std::vector<crthip_attr_binding> binds;
+	Request r;
 	for(auto &it : data) {                                   // std::map order == the C ABI's attribute order (sorted by name)
 		crthip_attr_binding b;
 		b.buffer = it.second->buffer;
 		b.format = (uint32_t)it.second->format;
 		b.out_components = (uint32_t)it.second->out_components;
 		b.stride = 0; b.reserved = 0;
-		binds.push_back(b);
+		r.binds.push_back(b);
 	}
-	void *idx = index.faces16 ? (void *)index.faces16 : (void *)index.faces32;   // faces16 wins (src/decoder.cpp:246-249)
-	uint32_t ifmt = index.faces16 ? CRTHIP_FMT_UINT16 : CRTHIP_FMT_UINT32;
-	int err;
-	{
-		Lease lease;                                          // a context of the pool for the duration of this decode
-		err = crthip_decode_host(lease.ctx, input_, (size_t)len_, binds.data(), idx, ifmt);
-	}
+	r.h.blob = input_; r.h.len = (size_t)len_;
+	r.h.attrs = r.binds.empty() ? nullptr : r.binds.data();
+	r.h.index = index.faces16 ? (void *)index.faces16 : (void *)index.faces32;   // faces16 wins (src/decoder.cpp:246-249)
+	r.h.index_format = index.faces16 ? CRTHIP_FMT_UINT16 : CRTHIP_FMT_UINT32;
+	const int err = combined_decode(r);                       // alone: one blob on a pool context; with other threads decoding: one batch for all
 	if(err) raise(err);
 }
 

@@ -34,6 +34,20 @@ int encode_value_streams(crthip_ctx *ctx, uint32_t entropy, const std::vector<En
 struct QuantRequest { uint32_t kind = 0, count = 0, N = 1; const void *in = nullptr; void *out = nullptr; float q = 0; int32_t unit = 0; uint32_t qc[4] = {1, 1, 1, 1}; };
 int quantize_device(crthip_ctx *ctx, const std::vector<QuantRequest> &reqs);
 
+// several blobs with HOST output buffers in one batch (batch.cpp): what crthip_decode_host is one of, and what the crt::Decoder facade's
+// combiner hands over when several threads call decode() at once.  copy_out: copy every output into the caller's buffer before
+// returning; else leave them in the context's pinned landing zone and say where (out_src -> out_dst, out_bytes): valid until the next
+// call on this context - the facade lets every waiting thread copy its own.
+struct HostDecodeReq {
+	const uint8_t *blob; size_t len;
+	const crthip_attr_binding *attrs;       // info.nattr entries in attribute order, or null: nothing bound
+	void *index; uint32_t index_format;
+	int32_t status;                         // out: CRTHIP_OK or this blob's CRTHIP_E_*
+	uint32_t nout;                          // out (copy_out == false): pieces to copy
+	const uint8_t *out_src[CRTHIP_MAX_ATTRS + 1]; void *out_dst[CRTHIP_MAX_ATTRS + 1]; size_t out_bytes[CRTHIP_MAX_ATTRS + 1];
+};
+int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy_out);
+
 // context plumbing (batch.cpp)
 int ctx_fail(int code, const char *msg);
 int ctx_device(crthip_ctx *ctx);

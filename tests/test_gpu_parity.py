@@ -452,7 +452,7 @@ def test_pool_of_sixteen_contexts_on_one_gpu(c5_blobs):
 
 
 def test_cpp_decoder_threads(ctx, tmp_path):
-    """SURVEY §8b Threading: distinct crt::Decoder objects on 4 threads at once (tests/cpp/facade_threads.cpp), every decode
+    """SURVEY §8b Threading: distinct crt::Decoder objects on 4 and on 16 threads at once (tests/cpp/facade_threads.cpp), every decode
     repeated and compared with its first, thread 0's outputs compared with the oracle"""
     import subprocess
     from conftest import ROOT
@@ -476,6 +476,21 @@ def test_cpp_decoder_threads(ctx, tmp_path):
     # two pool contexts only: the other two threads wait their turn
     out = subprocess.run([exe, "4", "2", "-", *files], capture_output=True, text=True, env=dict(os.environ, CORTO_HIP_CONTEXTS="2"))
     assert out.returncode == 0, out.stderr + out.stdout
+    # sixteen threads: their decode() calls are coalesced into batches (the facade's combiner: one leader decodes what has queued up, every
+    # caller copies its own outputs); every decode of every thread equals its first and thread 0's; then without the gather window, and
+    # with one context for all sixteen
+    for env in ({}, {"CORTO_HIP_COMBINE_US": "0"}, {"CORTO_HIP_CONTEXTS": "1"}):
+        out = subprocess.run([exe, "16", "3", str(tmp_path / "w"), *files], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert out.returncode == 0, (env, out.stderr + out.stdout)
+        for i in range(len(names)):
+            assert (tmp_path / ("w%d.bin" % i)).read_bytes() == (tmp_path / ("out%d.bin" % i)).read_bytes(), (env, names[i])
+    # a blob that cannot be decoded fails alone: its thread gets upstream's exception, the threads decoding beside it their meshes
+    bad = load_golden("c4_unit")["crt"].copy()
+    probs = int(ca.probe(aligned(bad)).body_offset) + 9 + 4 + 1
+    bad[probs:probs + 2] = (7, 255)
+    badf = str(tmp_path / "bad.crt"); bad.tofile(badf)
+    out = subprocess.run([exe, "8", "2", "-", badf], capture_output=True, text=True)
+    assert out.returncode == 1 and "Decoding topology failed" in out.stderr, out.stderr + out.stdout
 
 
 def test_status_survives_other_batches(ctx):

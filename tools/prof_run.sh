@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 20 --warmup 3 --no-cpu --no-other-configs --depth 1 --host-threads 1"   # unpipelined: every kernel runs alone, as in bench.py's `kernels` phase
+BENCH="python bench.py --steps 20 --warmup 3 --no-cpu --no-other-configs --sustain 0 --depth 1 --host-threads 1"   # unpipelined: every kernel runs alone, as in bench.py's `kernels` phase
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1
 # PMC passes: counters only (no trace domains), one small group per pass
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o pmc1 -- $BENCH --no-tunstall-scaled > $OUT/bench_pmc1.log 2>&1
@@ -31,3 +31,6 @@ for k, v in out.items():
     if isinstance(v, dict): print(k, {c: round(x, 1) for c, x in v.items()})
 PY
 tail -1 $OUT/bench_trace.log | cut -c1-200
+# keep the summaries, drop the per-dispatch CSVs (tens of MB: gpurun copies back 64 MiB at most)
+find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc_fetch $OUT/pmc_write

@@ -23,3 +23,4 @@ out["_sources_sha256"] = bench.sources_sha256()          # ties the counters to 
 json.dump(out, open("$OUT/pmc_per_dispatch.json", "w"), indent=1)
 PY
 tail -1 $OUT/l1.log | cut -c1-300
+rm -rf $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4
