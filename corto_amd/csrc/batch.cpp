@@ -1142,6 +1142,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	auto unpack = [&](hipStream_t s) {
 		if(!unpack_chunks) return;
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
+		if(ctx->dbg.unpack_twice) hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial);
 	};
 	auto topology = [&]() -> int {
 		if(!pl.topo_lds_ids.v.empty() || !pl.topo_big_ids.v.empty()) {
