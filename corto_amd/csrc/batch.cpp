@@ -178,7 +178,7 @@ struct Plan {
 	HostArr<FillJob> fill;
 	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
 	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
-	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job;
+	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job, unpack_wave_ids;   // (unpack_wave_ids: the streams of small bit blocks, one wave each: k_unpack_wave)
 	HostArr<DeltaJob> delta;
 	HostArr<DeltaGroup> delta_groups;                       // blobs whose attributes share one k_delta_wave workgroup
 	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
@@ -198,7 +198,7 @@ struct Plan {
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
 	void reset() {                                          // keep every vector's capacity
 		clr(tun); clr(tun_dict); clr(tun_chunk_stream); clr(tun_group_ids); clr(tun_groups); clers_groups = 0; clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
-		clr(unpack); clr(unpack_chunk_job); clr(delta); clr(delta_groups); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
+		clr(unpack); clr(unpack_chunk_job); clr(unpack_wave_ids); clr(delta); clr(delta_groups); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
 		clr(nf_block_job); clr(nf_block_first); clr(normal_fused_ids); clr(dequant); clr(dequant_block_job);
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
@@ -863,15 +863,22 @@ static int build_and_launch_inner(crthip_batch *b) {
 			AttrScratch &A = S.attr[k];
 			const uint32_t *words = (const uint32_t *)(arena + bo + as.bits.words_off);
 			const uint32_t chain0 = unpack_chunks;
+			uint64_t attr_logs = 0;
+			for(const StreamRef &lg : as.logs) attr_logs += lg.size;
+			const bool by_wave = attr_logs <= UNPACK_WAVE_MAX_LOGS && !ctx->dbg.unpack_chunked;   // one wave per stream, no look-back
+			const uint32_t attr_first = (uint32_t)pl.unpack.v.size();
 			auto push_unpack = [&](const StreamRef &s, const uint8_t *logs, void *out, bool out_real, uint8_t mode, uint16_t fields, uint16_t stride, uint16_t comp, uint8_t u8) {
 				if(s.size == 0) return;
 				UnpackJob u{};
 				u.logs = logs; u.words = words; u.out = out; u.count = s.size; u.nwords = as.bits.nwords; u.out_limit = nvert;
 				u.chunk0 = unpack_chunks; u.chain_chunk0 = chain0; u.fields = fields; u.stride = stride; u.comp = comp; u.mode = mode;
 				u.out_u8 = (uint8_t)(u8 | (out_real ? 0x80 : 0));           // bit7: out is a real pointer (cleared at fixup)
-				const uint32_t nc = (s.size + CHUNK - 1)/CHUNK;
-				for(uint32_t c = 0; c < nc; c++) pl.unpack_chunk_job.v.push_back((uint32_t)pl.unpack.v.size());
-				unpack_chunks += nc;
+				if(by_wave) { u.chain_chunk0 = attr_first; pl.unpack_wave_ids.v.push_back((uint32_t)pl.unpack.v.size()); }
+				else {
+					const uint32_t nc = (s.size + CHUNK - 1)/CHUNK;
+					for(uint32_t c = 0; c < nc; c++) pl.unpack_chunk_job.v.push_back((uint32_t)pl.unpack.v.size());
+					unpack_chunks += nc;
+				}
 				pl.unpack.v.push_back(u);
 			};
 			std::vector<const uint8_t *> &logs = ctx->plan_logs;
@@ -1007,7 +1014,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	pl.jobs_begin = cv.take(0);
 	pl.unpack_partial_off = cv.take(unpack_state_words*8, 16);           // (first thing in the uploaded block: zeros)
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
-	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.tun_group_ids); place(pl.tun_groups); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job);
+	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.tun_group_ids); place(pl.tun_groups); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job); place(pl.unpack_wave_ids);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) == 0; });
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 1; });
@@ -1097,7 +1104,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	memset(stage + (pl.unpack_partial_off - pl.jobs_begin), 0, unpack_state_words*8);
 	memset(ctx->status_host.p, 0, (size_t)nblobs*16);                       // (after the harvest above: the previous batch's words have been read)
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
-	put(pl.tun); put(pl.tun_dict); put(pl.tun_chunk_stream); put(pl.tun_group_ids); put(pl.tun_groups); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job);
+	put(pl.tun); put(pl.tun_dict); put(pl.tun_chunk_stream); put(pl.tun_group_ids); put(pl.tun_groups); put(pl.fill); put(pl.topo); put(pl.aux_u32); put(pl.topo_lds_ids); put(pl.topo_big_ids); put(pl.topo_glob_ids); put(pl.unpack); put(pl.unpack_chunk_job); put(pl.unpack_wave_ids);
 	put(pl.delta); put(pl.delta_groups); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
@@ -1140,6 +1147,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 		if(f1 > f0) { LT.begin("fill", s); hipLaunchKernelGGL(k_fill, dim3(f1 - f0), dim3(256), 0, s, D(pl.fill) + f0, f1 - f0); LT.end(); }
 	};
 	auto unpack = [&](hipStream_t s) {
+		const uint32_t nuw = (uint32_t)pl.unpack_wave_ids.v.size();
+		if(nuw) { LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_wave, dim3(nuw), dim3(64), 0, s, D(pl.unpack), D(pl.unpack_wave_ids), nuw); LT.end(); }
 		if(!unpack_chunks) return;
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
 		if(ctx->dbg.unpack_twice) hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial);
@@ -1172,7 +1181,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
-	} else if(!pl.topo.v.empty() && (ntun > clers_tun || nfill > clers_fill || unpack_chunks) && !ctx->single_stream) {
+	} else if(!pl.topo.v.empty() && (ntun > clers_tun || nfill > clers_fill || unpack_chunks || !pl.unpack_wave_ids.v.empty()) && !ctx->single_stream) {
 		// fork: attribute streams on stream2, CLERS + topology on the main stream
 		hipStream_t s2 = ctx->stream2;
 		HIP_TRY(hipEventRecord(ctx->ev_fork, st));

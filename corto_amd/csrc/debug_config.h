@@ -30,6 +30,7 @@ struct DebugConfig {
 	bool delta_walk = false;        // $CORTO_EXP_DELTA_WALK=1: K-DELTA's 32-bit kernel without the scan passes (flag-driven walk only)
 	bool no_deq_fold = false;       // $CORTO_EXP_NO_DEQ_FOLD=1: every attribute through k_dequant instead of K-DELTA's / K-NRM's copy-out
 	uint32_t delta_group = 0;       // $CORTO_EXP_DELTA_GROUP: attributes of a blob per K-DELTA workgroup (1..4; 0 = as many as fit)
+	bool unpack_chunked = false;    // $CORTO_EXP_UNPACK_CHUNKED=1: every bit block through the chunked K-BIT with its look-back (rounds 1-2), however small
 	bool unpack_twice = false;      // $CORTO_EXP_UNPACK_TWICE=1: K-BIT launched twice (what the kernel costs a pipelined decode: tools/lds_pad_probe.sh)
 	bool delta_global = false;      // $CORTO_EXP_DELTA_GLOBAL=1: K-DELTA of LDS-sized blobs with no LDS at all (k_delta_global)
 	uint32_t lds_pad_delta = 0, lds_pad_topo = 0, lds_pad_normal = 0;   // $CORTO_EXP_LDS_PAD_{DELTA,TOPO,NORMAL}: KiB of LDS requested on top of what the kernel uses (what bounds the pipelined rate: tools/lds_pad_probe.sh)
@@ -50,6 +51,7 @@ inline DebugConfig debug_config_from_env() {
 		c.no_deq_fold = on("CORTO_EXP_NO_DEQ_FOLD");
 		c.delta_global = on("CORTO_EXP_DELTA_GLOBAL");
 		c.unpack_twice = on("CORTO_EXP_UNPACK_TWICE");
+		c.unpack_chunked = on("CORTO_EXP_UNPACK_CHUNKED");
 		if(const char *e = getenv("CORTO_EXP_DELTA_GROUP")) { const uint32_t v = (uint32_t)atoi(e); if(v >= 1 && v <= 4) c.delta_group = v; }
 		if(const char *e = getenv("CORTO_EXP_LDS_PAD_DELTA")) c.lds_pad_delta = (uint32_t)atoi(e)*1024u;
 		if(const char *e = getenv("CORTO_EXP_LDS_PAD_TOPO")) c.lds_pad_topo = (uint32_t)atoi(e)*1024u;

@@ -83,13 +83,15 @@ struct UnpackJob {
 	uint32_t nwords;
 	uint32_t out_limit;            // never write element index >= out_limit (nvert)
 	uint32_t chunk0;               // first chunk of this job in the chunk arrays
-	uint32_t chain_chunk0;         // first chunk of the bit block this job shares (component-major chaining)
+	uint32_t chain_chunk0;         // first chunk of the bit block this job shares (component-major chaining); k_unpack_wave: the first JOB of the bit block
 	uint16_t fields;               // ARRAY: N fields per log; VALUES: 1
 	uint16_t stride;               // output elements per vertex
 	uint16_t comp;                 // VALUES: component
 	uint8_t mode;                  // 0 ARRAY, 1 VALUES
 	uint8_t out_u8;
 };
+
+constexpr uint32_t UNPACK_WAVE_MAX_LOGS = 16384;   // bit blocks of at most this many logs (all streams together): one wave per stream (k_unpack_wave); else chunks of 1 024 with look-back
 
 // parallelogram / first-neighbour delta over a mesh (include/corto/vertex_attribute.h:160-176,
 // src/normal_attribute.cpp:193-201)

@@ -200,6 +200,139 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 	}
 }
 
+// K-BIT for the attributes of LDS-sized blobs (round 3): ONE WAVE PER LOG STREAM, lanes interleaved over the vertices.
+// The chunked kernel above gives every 1 024 logs a workgroup of four waves (a C4 batch: 5 632 workgroups, 22 528 waves, each living
+// ~6 us, two thirds of it waiting for its loads) and finds a chunk's bit offset by look-back through memory; launched twice it cost a
+// pipelined decode 11.8 us of its 89 us per batch (profiles/r03_what_bounds_the_pipeline.txt) - more than its 31 us alone would suggest,
+// because what it takes is wave slots and issue slots, 88 M wave-cycles a batch, more than every other kernel of the path together.
+// Here a stream is ONE wave's: lane l takes logs l, l + 64, ... (every load and store of a round is 64 consecutive elements), a round's
+// bit offsets are one DPP scan, the cursor is carried in a scalar - and the streams in front of it in the bit block (one per
+// component, component-major: cstream.h:300-317) are simply added up again from their logs (a few KB), so nobody waits for anybody:
+// no state words, no atomics.  A tenth of the waves, a sixth of the instructions.
+constexpr uint32_t UW_R = 8;                                                // rounds of 64 logs per block: their loads in flight together
+__global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const uint32_t jid = job_ids[blockIdx.x];
+	const UnpackJob J = jobs[jid];
+	const uint32_t lane = threadIdx.x, count = J.count, fields = J.fields;
+	CRT_GLOBAL const uint8_t *logs = as_global(J.logs);
+	auto width = [](uint32_t l) -> uint32_t { return l > 32u ? 32u : l; };   // >32 cannot be produced by the encoder (UB in the reference)
+	// the first block's logs, and everything in front of this stream in its bit block, in flight together
+	uint32_t lg[UW_R];
+#pragma unroll
+	for(uint32_t r = 0; r < UW_R; r++) { const uint32_t i = r*64u + lane; lg[r] = logs[i < count ? i : (count ? count - 1u : 0u)]; }
+	uint64_t running = 0;
+	for(uint32_t jp = J.chain_chunk0; jp < jid; jp++) {                        // (chain_chunk0: for this kernel, the first JOB of the bit block)
+		const UnpackJob &K = jobs[jp];
+		CRT_GLOBAL const uint8_t *kl = as_global(K.logs);
+		const uint32_t kc = K.count, kf = K.fields;
+		uint32_t t = 0;
+		for(uint32_t i0 = 4u*lane; i0 < kc; i0 += 4u*64u*4u) {                // four dwords per lane and pass
+			uint32_t w4[4], r4[4];
+#pragma unroll
+			for(uint32_t u = 0; u < 4; u++) w4[u] = unpack_logs4(kl, kc, i0 + 256u*u, r4[u]);
+#pragma unroll
+			for(uint32_t u = 0; u < 4; u++)
+#pragma unroll
+				for(uint32_t k = 0; k < 4; k++) if(k < r4[u]) t += width((w4[u] >> (8u*k)) & 255u);
+		}
+		t = wave_inclusive_scan_u32(t);
+		running += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)t, 63)*kf;
+	}
+	CRT_GLOBAL const uint32_t *words = as_global(J.words);
+	const uint32_t nwords = J.nwords, last_word = nwords ? nwords - 1u : 0u;
+	auto window = [&](uint64_t at, uint32_t &hi, uint32_t &lo) {              // two words of the bit block at bit offset `at` (clamped; masked by field())
+		const uint64_t wi = at >> 5;
+		hi = words[wi < nwords ? (uint32_t)wi : last_word];
+		lo = words[wi + 1 < nwords ? (uint32_t)wi + 1u : last_word];
+	};
+	auto field = [&](uint64_t at, uint32_t n, uint32_t hi, uint32_t lo) -> uint32_t {        // = bit_field(words, nwords, at, n)
+		if(n == 0) return 0u;
+		const uint64_t wi = at >> 5;
+		const uint32_t sh = (uint32_t)(at & 31);
+		const uint32_t h = wi < nwords ? hi : 0u, l = (sh + n > 32 && wi + 1 < nwords) ? lo : 0u;
+		return (uint32_t)(((((uint64_t)h << 32) | l) << sh) >> (64 - n));
+	};
+	const bool values = (J.mode & 1u) != 0;
+	for(uint32_t base = 0; base < count; base += UW_R*64u) {
+		// this block's widths and bit offsets (a scan per round, the cursor a scalar), then the next block's logs go out before the windows
+		uint32_t d[UW_R]; uint64_t at[UW_R];
+#pragma unroll
+		for(uint32_t r = 0; r < UW_R; r++) {
+			const uint32_t i = base + r*64u + lane;
+			d[r] = i < count ? width(lg[r]) : 0u;
+			const uint32_t bits = d[r]*fields, incl = wave_inclusive_scan_u32(bits);
+			at[r] = running + (incl - bits);
+			running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		}
+		if(base + UW_R*64u < count) {
+#pragma unroll
+			for(uint32_t r = 0; r < UW_R; r++) { const uint32_t i = base + (UW_R + r)*64u + lane; lg[r] = logs[i < count ? i : count - 1u]; }
+		}
+		if(values) {                                                           // decodeValues: sign folding (cstream.h:304-316); one field per log
+			uint32_t hi[UW_R], lo[UW_R];
+			if(nwords) {
+#pragma unroll
+				for(uint32_t r = 0; r < UW_R; r++) window(at[r], hi[r], lo[r]);
+#pragma unroll
+				for(uint32_t r = 0; r < UW_R; r++) asm volatile("" : "+v"(hi[r]), "+v"(lo[r]));
+			} else {
+#pragma unroll
+				for(uint32_t r = 0; r < UW_R; r++) hi[r] = lo[r] = 0;
+			}
+#pragma unroll
+			for(uint32_t r = 0; r < UW_R; r++) {
+				const uint32_t i = base + r*64u + lane, dd = d[r];
+				int32_t v = 0;
+				if(dd) {
+					v = (int32_t)field(at[r], dd, hi[r], lo[r]);
+					const int32_t mid = (int32_t)(1u << (dd - 1));
+					if(v < mid) v = -v - mid;
+				}
+				if(i < count && i < J.out_limit) {
+					if(J.out_u8) as_global((uint8_t *)J.out)[(size_t)i*J.stride + J.comp] = (uint8_t)v;
+					else as_global((int32_t *)J.out)[(size_t)i*J.stride + J.comp] = v;
+				}
+			}
+		} else {                                                                 // decodeArray: v = raw - 2^(d-1); d == 0 -> zeros (cstream.h:337-357); `fields` values per log
+#pragma unroll
+			for(uint32_t g = 0; g < UW_R; g += 2) {                               // two rounds at a time: up to eight fields' windows in flight
+				uint32_t hi[2][4], lo[2][4];
+				const bool fast = fields <= 4 && nwords;                         // (uniform)
+				if(fast) {
+#pragma unroll
+					for(uint32_t k = 0; k < 2; k++)
+#pragma unroll
+						for(uint32_t f = 0; f < 4; f++) window(at[g + k] + (uint64_t)(f < fields ? f : 0u)*d[g + k], hi[k][f], lo[k][f]);
+#pragma unroll
+					for(uint32_t k = 0; k < 2; k++) asm volatile("" : "+v"(hi[k][0]), "+v"(lo[k][0]), "+v"(hi[k][1]), "+v"(lo[k][1]), "+v"(hi[k][2]), "+v"(lo[k][2]), "+v"(hi[k][3]), "+v"(lo[k][3]));
+				}
+#pragma unroll
+				for(uint32_t k = 0; k < 2; k++) {
+					const uint32_t i = base + (g + k)*64u + lane, dd = d[g + k];
+					const bool store = i < count && i < J.out_limit;
+					CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + (size_t)i*J.stride;
+					const uint32_t half = dd ? (uint32_t)((1ull << dd) >> 1) : 0u;
+					if(fast) {
+#pragma unroll
+						for(uint32_t f = 0; f < 4; f++) if(f < fields) {
+							const int32_t v = dd ? (int32_t)(field(at[g + k] + (uint64_t)f*dd, dd, hi[k][f], lo[k][f]) - half) : 0;
+							if(store) out[f] = v;
+						}
+					} else {
+						uint64_t oo = at[g + k];
+						for(uint32_t f = 0; f < fields; f++) {
+							const int32_t v = dd ? (int32_t)(bit_field(words, nwords, oo, dd) - half) : 0;
+							oo += dd;
+							if(store) out[f] = v;
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // point-cloud delta: v[i] += v[i-N] over the flat array == per-component inclusive scan (wrap-around)
 __device__ __forceinline__ uint32_t cloud_load(const CloudJob &J, uint32_t i, uint32_t comp) {

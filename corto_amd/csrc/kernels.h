@@ -30,6 +30,7 @@ __global__ void k_scan_u64(uint64_t *a, uint32_t n);
 __global__ void k_u32_chunk_sums(const uint32_t *a, uint32_t n, uint64_t *partial);
 __global__ void k_u32_chunk_apply(const uint32_t *a, uint32_t *out, uint32_t n, const uint64_t *partial);
 __global__ void k_unpack_extract(const UnpackJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, uint64_t *state);   // state: nchunks + 1 zeroed words (look-back)
+__global__ void k_unpack_wave(const UnpackJob *jobs, const uint32_t *job_ids, uint32_t njobs);   // ... the log streams of small bit blocks: one wave per stream, lanes interleaved, no look-back
 __global__ void k_cloud_sums(const CloudJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, uint64_t *partial);
 __global__ void k_cloud_apply(const CloudJob *jobs, const uint32_t *chunk_job, uint32_t nchunks, const uint64_t *partial);
 __global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uint32_t nblocks);

@@ -281,6 +281,16 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(!err) { L.busy = true; L.step = step; }
 		}
 		for(uint32_t k = 0; k < p->depth; k++) if(mine[k].busy) { const int e2 = finish(mine[k]); if(!err) err = e2; }
+		// a context whose thread drew none of the last 2 x lanes tickets (descheduled while the others emptied the queue: seen with
+		// 32-blob items) repeats its last step from a poisoned block, behind the timed region: what lane_read returns is then ALWAYS
+		// a poisoned step's output, not only almost always
+		for(uint32_t k = 0; k < p->depth && !err; k++) {
+			Lane &L = mine[k];
+			if(L.item < 0 || L.poisoned || !L.out) continue;
+			err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+			if(!err) err = crthip_batch_decode(L.batch);
+			if(!err) { L.busy = true; L.poisoned = true; err = finish(L); }
+		}
 		if(err) {
 			std::lock_guard<std::mutex> lock(p->m);
 			if(!p->error) { p->error = err; p->error_msg = crthip_last_error(); }

@@ -86,6 +86,28 @@ def test_heterogeneous_batch(ctx):
         assert_same(b.host_outputs(i), g, KEYS, ALL_CASES[i])
 
 
+def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
+    """K-BIT has two kernels: the log streams of a small bit block (<= 16 384 logs) take one wave each, lanes interleaved over the
+    vertices, the bits in front of a stream re-added from the earlier streams' logs (k_unpack_wave); larger blocks go in chunks of
+    1 024 with look-back (k_unpack_scan/_extract; $CORTO_EXP_UNPACK_CHUNKED=1 sends everything there).  Same bytes from both, and the
+    oracle's: ragged sizes around the 64-lane round and the 512-log block, 1..4 fields per log, u8 and int32 outputs, a cloud."""
+    from corto_amd import synth
+    meshes = [synth.bumpy_sphere(nu, nv, seed=nu) for nu, nv in ((3, 2), (7, 3), (8, 7), (9, 7), (21, 3), (32, 15), (32, 16), (33, 16), (64, 32), (70, 60), (127, 120))]
+    meshes += [synth.holey_disc(12, seed=2), synth.strip(130, seed=3), synth.torus(20, 9, seed=4), synth.point_cloud(40, 13, seed=5), synth.point_cloud(150, 120, seed=6)]
+    blobs = []
+    for i, m in enumerate(meshes):
+        kw = dict(position_bits=(10, 14, 18)[i % 3], uv_bits=12, normal_bits=10, normal_prediction=(ca.BORDER, ca.ESTIMATED, ca.DIFF)[i % 3])
+        blobs.append(ca.encode(m, **kw))
+    refs = [oc.decode(b, color_components=4) for b in blobs]
+    for chunked in ("0", "1"):
+        monkeypatch.setenv("CORTO_EXP_UNPACK_CHUNKED", chunked)
+        c = ca.Context(0)
+        b = run_batch(c, blobs, color_components=4)
+        for i, r in enumerate(refs):
+            assert_same(b.host_outputs(i), r, KEYS, "mesh %d chunked=%s" % (i, chunked))
+        b.close(); c.close()
+
+
 def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
     table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_shared); $CORTO_TUN_SHARE=0
