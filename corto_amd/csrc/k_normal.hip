@@ -195,18 +195,28 @@ __global__ __launch_bounds__(256) void k_normal_vertex(const NormalJob *__restri
 // read from HBM/L2 (25 KB for a 2K-vertex blob: it stays in the CU's L1) rather than staged, and offsets are 16-bit
 // (3*nface <= 65535), so that the workgroup's LDS (50 KB for the 4K-triangle blob) fits beside the CLERS automata of
 // the batches behind it in a pipelined decode (k_mesh.hip: three 49 KB fronts per CU leave little).
-// Dynamic LDS layout: cnt[nvert+1] u32 | start[nvert+1] u16 | slot[nvert+1] u16 | bnd[nvert] u32, later adj[3*nface] u16
-// (the boundary flag moves into slot's top bit - nvert <= 32767 - once the slots are scanned, and the adjacency takes bnd's place)
+// Dynamic LDS layout (round 3: 41.5 -> 28.6 KB for the 4K-triangle blob; LDS.time is what bounds a pipelined decode):
+//   cur[nvert+2] u16 | fbits[2*ceil(nvert/64)] u32 | fpre[same] u16 | bnd[nvert] u32, later adj[3*nface] u16
+// cur is, in turn, the incidence counts (two vertices share a dword: ds_add_u32 of 1 or 1<<16; no half can overflow, 3*nface <= 65535),
+// their exclusive scan IN PLACE, the fill cursors - and, after the fill, cur[i] is where vertex i's list ENDS, i.e. where vertex i+1's
+// starts: no separate offset array.  The vertices that take a correction (ESTIMATED: all; BORDER: the boundary) are a bitmap with a
+// prefix count per dword; a vertex' slot in the diff stream is a popcount away.  The adjacency takes the boundary XORs' place.
 __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs, uint32_t lds_bytes) {
 	if(blockIdx.x >= njobs) return;
 	const NormalJob J = jobs[job_ids[blockIdx.x]];
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 	const uint32_t nv = J.nvert, nf = J.nface, tid = threadIdx.x;
-	CRT_LDS uint32_t *cnt = (CRT_LDS uint32_t *)as_lds(lds_raw);
-	CRT_LDS uint16_t *start = (CRT_LDS uint16_t *)(cnt + nv + 1);
-	CRT_LDS uint16_t *slot = start + ((nv + 2) & ~1u);
-	CRT_LDS uint32_t *bnd = (CRT_LDS uint32_t *)(slot + ((nv + 2) & ~1u));
+	const uint32_t ncur = (nv + 2) & ~1u, ndw = 2*((nv + 63)/64);
+	CRT_LDS uint16_t *cur = (CRT_LDS uint16_t *)as_lds(lds_raw);
+	CRT_LDS uint32_t *cur32 = (CRT_LDS uint32_t *)cur;
+	CRT_LDS uint32_t *fbits = (CRT_LDS uint32_t *)(cur + ncur);
+	CRT_LDS uint16_t *fpre = (CRT_LDS uint16_t *)(fbits + ndw);
+	CRT_LDS uint32_t *bnd = (CRT_LDS uint32_t *)(as_lds(lds_raw) + normal_blob_lds_head(nv));
 	CRT_LDS uint16_t *adj = (CRT_LDS uint16_t *)bnd;
+	auto bump = [&](uint32_t v) -> uint32_t {                              // cur[v]++ ; returns the old value
+		const uint32_t sh = (v & 1u)*16u;
+		return (atomicAdd((uint32_t *)&cur32[v >> 1], 1u << sh) >> sh) & 0xFFFFu;
+	};
 	// small blobs: every face's normal is computed once, while the incidence is counted, and kept in LDS; the ordered accumulation
 	// then never leaves LDS.  Bigger blobs recompute it per incident vertex from HBM/L2 (two dependent loads per face and vertex)
 	// to stay within a CU's LDS.
@@ -225,7 +235,8 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		if(f16) { a = f16[3*(size_t)f]; b = f16[3*(size_t)f + 1]; c = f16[3*(size_t)f + 2]; }
 		else { a = f32[3*(size_t)f]; b = f32[3*(size_t)f + 1]; c = f32[3*(size_t)f + 2]; }
 	};
-	for(uint32_t i = tid; i <= nv; i += 256) { cnt[i] = 0; if(i < nv) bnd[i] = 0; }
+	for(uint32_t i = tid; i < nv; i += 256) bnd[i] = 0;
+	for(uint32_t i = tid; i < ncur/2; i += 256) cur32[i] = 0;
 	__syncthreads();
 	// incidence counts + boundary XOR (markBoundary, normal_attribute.cpp:24-37)
 	bool bad = false;
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 #pragma unroll
 		for(uint32_t u = 0; u < 4; u++) if(ok[u]) {
 			const uint32_t f = f0 + 256*u, a = A[u], b = B[u], c = C[u];
-			atomicAdd((uint32_t *)&cnt[a], 1u); atomicAdd((uint32_t *)&cnt[b], 1u); atomicAdd((uint32_t *)&cnt[c], 1u);
+			(void)bump(a); (void)bump(b); (void)bump(c);
 			if(fn_any) {
 				const float x0 = (float)P[u][0], y0 = (float)P[u][1], z0 = (float)P[u][2];
 				const float ax = (float)P[u][3] - x0, ay = (float)P[u][4] - y0, az = (float)P[u][5] - z0;
@@ -313,40 +324,44 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		}
 	};
 	if(fn_any) positions_out();
-	// two block-wide exclusive scans over the vertices: CSR offsets of cnt, and correction slots of the flags
+	// the counts become CSR offsets (block-wide exclusive scan, in place); the vertices that take a correction become a bitmap + prefix counts
 	const uint32_t per = (nv + 255)/256;
-	auto block_scan = [&](CRT_LDS const uint32_t *in, CRT_LDS uint16_t *out, bool flags) {
+	{
 		const uint32_t i0 = tid*per;
 		uint32_t s = 0, total;
 		if(per <= 16) {                                                    // (uniform) the thread's elements read once, all reads in flight, kept in registers
 			uint32_t x[16];
 #pragma unroll
-			for(uint32_t k = 0; k < 16; k++) x[k] = in[i0 + k < nv ? i0 + k : 0u];
+			for(uint32_t k = 0; k < 16; k++) x[k] = cur[i0 + k < nv ? i0 + k : 0u];
 			asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
 			asm volatile("" : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
 #pragma unroll
-			for(uint32_t k = 0; k < 16; k++) {
-				const bool on = k < per && i0 + k < nv;
-				x[k] = on ? (flags ? (uint32_t)(J.prediction == 1 || x[k] != 0) : x[k]) : 0u;
-				s += x[k];
-			}
+			for(uint32_t k = 0; k < 16; k++) { x[k] = k < per && i0 + k < nv ? x[k] : 0u; s += x[k]; }
 			uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
 #pragma unroll
-			for(uint32_t k = 0; k < 16; k++) if(k < per && i0 + k < nv) { out[i0 + k] = (uint16_t)(flags ? o | x[k] << 15 : o); o += x[k]; }
+			for(uint32_t k = 0; k < 16; k++) if(k < per && i0 + k < nv) { cur[i0 + k] = (uint16_t)o; o += x[k]; }
 		} else {
-			for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; }
+			for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) s += cur[i]; }
 			uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
-			for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { const uint32_t x = flags ? (uint32_t)(J.prediction == 1 || in[i] != 0) : in[i]; out[i] = (uint16_t)(flags ? o | x << 15 : o); o += x; } }
+			for(uint32_t k = 0; k < per; k++) { const uint32_t i = i0 + k; if(i < nv) { const uint32_t x = cur[i]; cur[i] = (uint16_t)o; o += x; } }
 		}
-		if(tid == 0) out[nv] = (uint16_t)total;
-	};
-	block_scan(cnt, start, false);
-	block_scan(bnd, slot, true);
+	}
+	for(uint32_t b0 = 0; b0 < nv; b0 += 256) {                               // (uniform trip count) 64 vertices' flags are one ballot
+		const uint32_t i = b0 + tid;
+		const uint64_t m = __ballot(i < nv && (J.prediction == 1 || bnd[i] != 0));
+		if((tid & 63u) == 0 && i < nv) { fbits[(b0 + tid) >> 5] = (uint32_t)m; fbits[((b0 + tid) >> 5) + 1] = (uint32_t)(m >> 32); }
+	}
 	__syncthreads();
-	for(uint32_t i = tid; i < nv; i += 256) cnt[i] = start[i];           // cnt becomes the fill cursor
-	__syncthreads();
+	{
+		const uint32_t pd = (ndw + 255)/256, d0 = tid*pd;                      // <= 4 dwords a thread (nvert <= 32767)
+		uint32_t s = 0, total;
+		for(uint32_t k = 0; k < pd; k++) if(d0 + k < ndw && 32u*(d0 + k) < nv) s += (uint32_t)__popc(fbits[d0 + k]);
+		uint32_t o = block256_exclusive_scan<uint32_t>(s, scan_s, &total);
+		for(uint32_t k = 0; k < pd; k++) if(d0 + k < ndw) { fpre[d0 + k] = (uint16_t)o; if(32u*(d0 + k) < nv) o += (uint32_t)__popc(fbits[d0 + k]); }
+	}
+	__syncthreads();                                                       // (bnd has been read for the last time: the adjacency takes its place)
 	for(uint32_t f0 = tid; f0 < nf; f0 += 1024) {                           // four faces per thread and pass, as above; the twelve cursor bumps in flight together
-		uint32_t V[4][3], at[4][3];                                          // (a face that is out or malformed bumps the spare counter cnt[nv] and stores nothing)
+		uint32_t V[4][3], at[4][3];                                          // (a face that is out or malformed bumps the spare counter cur[nv] and stores nothing)
 #pragma unroll
 		for(uint32_t u = 0; u < 4; u++) face(f0 + 256*u < nf ? f0 + 256*u : nf - 1u, V[u][0], V[u][1], V[u][2]);
 #pragma unroll
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		for(uint32_t u = 0; u < 4; u++) {
 			ok[u] = f0 + 256*u < nf && V[u][0] < nv && V[u][1] < nv && V[u][2] < nv;
 #pragma unroll
-			for(int k = 0; k < 3; k++) at[u][k] = atomicAdd((uint32_t *)&cnt[ok[u] ? V[u][k] : nv], 1u);
+			for(int k = 0; k < 3; k++) at[u][k] = bump(ok[u] ? V[u][k] : nv);
 		}
 #pragma unroll
 		for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(at[u][0]), "+v"(at[u][1]), "+v"(at[u][2]));
@@ -369,12 +384,17 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	__syncthreads();
 	// per vertex: ordered accumulation (estimateNormals :40-59) + computeNormals (:281-325)
 	for(uint32_t i = tid; i < nv; i += 256) {
-		const uint32_t s0 = start[i], deg = (uint32_t)start[i + 1] - s0;
+		uint32_t s0 = cur[i ? i - 1u : 0u], fw = fbits[i >> 5], fp = fpre[i >> 5];
+		const uint32_t e0 = cur[i];
+		asm volatile("" : "+v"(s0), "+v"(fw), "+v"(fp));
+		s0 = i ? s0 : 0u;
+		const uint32_t deg = e0 - s0;
 		// the vertex' correction is fetched NOW (its slot is known), so that the load is back by the time the sum of face normals is
-		const uint32_t slw = slot[i];
-		const bool has_diff = (slw & 0x8000u) && (slw & 0x7FFFu) < J.ndiffs;
+		const bool flagged = (fw >> (i & 31u)) & 1u;
+		const uint32_t rank = fp + (uint32_t)__popc(fw & ((1u << (i & 31u)) - 1u));
+		const bool has_diff = flagged && rank < J.ndiffs;
 		int32_t pdx = 0, pdy = 0;
-		if(J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)(has_diff ? slw & 0x7FFFu : 0u); pdx = dp[0]; pdy = dp[1]; }
+		if(J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)(has_diff ? rank : 0u); pdx = dp[0]; pdy = dp[1]; }
 		float ex = 0.f, ey = 0.f, ez = 0.f;
 		if(deg <= 8 && deg > 0) {
 			// the usual vertex: its (at most eight) incident faces sorted by id with a branch-free network and their normals added in that
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			last = (int32_t)best; done += mult;
 		}
 		}
-		if(slw & 0x8000u) {                                              // ESTIMATED: every vertex; BORDER: boundary vertices
+		if(flagged) {                                                    // ESTIMATED: every vertex; BORDER: boundary vertices
 			int32_t qx, qy;
 			to_octa(ex, ey, ez, J.unit, qx, qy);
 			asm volatile("" : "+v"(pdx), "+v"(pdy));

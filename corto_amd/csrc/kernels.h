@@ -111,7 +111,9 @@ __global__ void k_normal_vertex(const NormalJob *jobs, const uint32_t *block_job
                                 const uint32_t *flag, const uint32_t *slot);
 
 __global__ void k_normal_blob(const NormalJob *jobs, const uint32_t *job_ids, uint32_t njobs, uint32_t lds_bytes);
-__host__ __device__ inline uint32_t normal_blob_lds(uint32_t nvert, uint32_t nface) { const uint32_t adj = (3*nface*2 + 15) & ~15u, bnd = nvert*4; return (nvert + 1)*4 + 2*((nvert + 2) & ~1u)*2 + (adj > bnd ? adj : bnd) + 64; }
+// (head: cursors u16 | flag bitmap u32 | its prefix counts u16; then the boundary XORs u32 per vertex, later the adjacency u16 per corner)
+__host__ __device__ inline uint32_t normal_blob_lds_head(uint32_t nvert) { const uint32_t ndw = 2*((nvert + 63)/64); return (((nvert + 2) & ~1u)*2 + ndw*4 + ndw*2 + 15u) & ~15u; }
+__host__ __device__ inline uint32_t normal_blob_lds(uint32_t nvert, uint32_t nface) { const uint32_t adj = (3*nface*2 + 15) & ~15u, bnd = nvert*4; return normal_blob_lds_head(nvert) + (adj > bnd ? adj : bnd) + 64; }
 constexpr uint32_t NORMAL_LDS_MAX = 150*1024;
 // with the blob's face normals kept in LDS too (3 x f32 per face, behind the layout above): small blobs only
 __host__ __device__ inline uint32_t normal_blob_lds_fn(uint32_t nvert, uint32_t nface) { return ((normal_blob_lds(nvert, nface) + 15u) & ~15u) + 12u*nface; }
