@@ -251,7 +251,8 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 		const uint64_t wi = at >> 5;
 		const uint32_t sh = (uint32_t)(at & 31);
 		const uint32_t h = wi < nwords ? hi : 0u, l = (sh + n > 32 && wi + 1 < nwords) ? lo : 0u;
-		return (uint32_t)(((((uint64_t)h << 32) | l) << sh) >> (64 - n));
+		const uint32_t top = sh ? __builtin_amdgcn_alignbit(h, l, 32u - sh) : h;   // the 32 bits from bit `sh` on: a funnel shift, not a 64-bit one (quarter rate)
+		return top >> (32u - n);
 	};
 	const bool values = (J.mode & 1u) != 0;
 	for(uint32_t base = 0; base < count; base += UW_R*64u) {

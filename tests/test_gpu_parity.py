@@ -108,9 +108,35 @@ def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
         b.close(); c.close()
 
 
+@pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_EXP_DELTA_GLOBAL": "1"}, {"CORTO_EXP_NO_DEQ_FOLD": "1"}, {"CORTO_EXP_DELTA_GROUP": "1"},
+                                 {"CORTO_EXP_NORMAL_FN_MAX": "0"}, {"CORTO_EXP_NORMAL_FN_MAX": "150000"}, {"CORTO_EXP_UNPACK_TWICE": "1"},
+                                 {"CORTO_EXP_LDS_PAD_DELTA": "8", "CORTO_EXP_LDS_PAD_TOPO": "8", "CORTO_EXP_LDS_PAD_NORMAL": "8"}],
+                         ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+def test_experiment_switches_are_bit_exact(monkeypatch, env):
+    """csrc/debug_config.h: every experiment switch selects other kernels or other launch geometry for the same bytes - every fixture and
+    the 16 C4 blobs through each of them (the Tunstall and unpack switches have their own tests above and below)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
+    gs = [load_golden(n) for n in ALL_CASES]
+    blobs = [g["crt"] for g in gs] + [aligned(z["crt_%02d" % s]) for s in range(16)]
+    for single in (False, True):
+        c = ca.Context(0)                                  # (the switches are read when a context is made)
+        if single:
+            c.set_single_stream(True)
+        b = run_batch(c, blobs)
+        for i, g in enumerate(gs):
+            assert_same(b.host_outputs(i), g, KEYS, "%s %s single=%s" % (ALL_CASES[i], env, single))
+        for s_ in range(16):
+            got = b.host_outputs(len(gs) + s_)
+            for k in ("position", "normal", "color", "uv", "index"):
+                assert sha(got[k]) == z["%s_sha256_%02d" % (k, s_)].tobytes().decode(), (s_, k, env, single)
+        b.close(); c.close()
+
+
 def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
-    table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_shared); $CORTO_TUN_SHARE=0
+    table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_grouped); $CORTO_TUN_SHARE=0
     builds one per stream (k_tun_stream).  Same bytes either way: every fixture twice + the 16 C4 blobs, in one batch."""
     z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
     gs = [load_golden(n) for n in ALL_CASES]
