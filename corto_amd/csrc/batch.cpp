@@ -191,7 +191,7 @@ struct Plan {
 	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
 	uint64_t jobs_begin = 0, jobs_bytes = 0;
 	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
-	uint32_t delta_wave_lds = 0, delta16_lds = 0, delta16_groups = 0;   // (delta_groups: the k_delta_lds16 groups first, then k_delta_wave's)
+	uint32_t delta_wave_lds = 0, delta16_lds = 0, delta16_groups = 0, delta_tree_lds = 0;   // (delta_groups: the k_delta_lds16 groups first, then k_delta_wave's)
 	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
 	uint32_t tun_max_nchunks = 0;
 	uint64_t total = 0;
@@ -203,7 +203,7 @@ struct Plan {
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
 		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
-		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0; delta16_lds = 0; delta16_groups = 0;
+		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0; delta16_lds = 0; delta16_groups = 0; delta_tree_lds = 0;
 		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0; tun_max_nchunks = 0;
 	}
 };
@@ -573,7 +573,10 @@ static inline uint64_t delta16_need(const DeltaJob &d) {
 	if(d.nvert > DELTA16_NVERT_MAX || d.N < 1 || d.N > 4) return ~0ull;
 	return (uint64_t)delta16_vbytes(d.nvert, d.N, d.is_u8 != 0) + delta16_graph_lds(d.nvert, delta16_hosts_a(d));
 }
+// 0 / 1: k_delta_mesh (HBM), 2: k_delta_lds16, 3: k_delta_wave, 4: k_delta_tree (v += v[a] alone: pointer jumping; DeltaJob::tree is
+// set by the planner where the context allows it)
 static inline int delta_class(const DeltaJob &d, bool wide) {
+	if(d.tree) return 4;
 	if(!wide && delta16_need(d) <= DELTA16_LDS_MAX) return 2;
 	return delta_wave_need(d) <= DELTA_WAVE_LDS_MAX ? 3 : d.nvert > DELTA_SMALL_NVERT ? 0 : 1;
 }
@@ -912,6 +915,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->dbg.delta_walk;   // pad[1]: experiments - the flag-driven walk only
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
 					d.flags = HS(2ull*nblobs + 2ull*i);
+					// EXPERIMENT: v += v[a] alone (no parallelogram) is a tree - pointer jumping in a workgroup of its own (k_delta_tree), whatever
+					// the other attributes of the blob take
+					d.tree = !para && ctx->dbg.delta_tree && N >= 1 && N <= 4 && nvert <= DELTA_TREE_NVERT_MAX && delta_tree_lds(nvert, N, is_u8) <= DELTA_TREE_LDS_MAX;
 					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2 && !ctx->dbg.no_deq_fold) {
 						if(a.codec == CRTHIP_CODEC_COLOR) {
 							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;
@@ -1019,6 +1025,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) == 0; });
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 1; });
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 2; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 3; });
 	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph: consecutive jobs of one class with
 		// the same prediction array, up to DELTA_GROUP_MAX.  Class 2 groups first (k_delta_lds16), then class 3 (k_delta_wave).
 		size_t j = 0;
@@ -1027,13 +1034,14 @@ static int build_and_launch_inner(crthip_batch *b) {
 		while(j < pl.delta.v.size()) {
 			const DeltaJob &d0 = pl.delta.v[j];
 			const int cls = delta_class(d0, wide);
+			if(cls == 4) { pl.delta_tree_lds = std::max(pl.delta_tree_lds, delta_tree_lds(d0.nvert, d0.N, d0.is_u8 != 0)); j++; continue; }   // (the tail: a workgroup each)
 			DeltaGroup g{(uint32_t)j, 1};
 			if(cls == 2) {
 				uint64_t vals = delta16_vbytes(d0.nvert, d0.N, d0.is_u8 != 0);
 				bool hosted = delta16_hosts_a(d0);
 				while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
 					const DeltaJob &d = pl.delta.v[j + g.count];
-					if(delta_class(d, wide) != 2 || d.pred != d0.pred || d.nvert != d0.nvert) break;
+					if(delta_class(d, wide) != 2 || d.pred != d0.pred || d.nvert != d0.nvert) break;   // (class 4 sits behind every group's candidates)
 					const uint64_t more = delta16_vbytes(d.nvert, d.N, d.is_u8 != 0);
 					const bool h2 = hosted || delta16_hosts_a(d);
 					if(vals + more + delta16_graph_lds(d0.nvert, h2) > DELTA16_LDS_MAX) break;
@@ -1046,7 +1054,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 				while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
 					const DeltaJob &d = pl.delta.v[j + g.count];
 					const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
-					if(d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;
+					if(delta_class(d, wide) != 3 || d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;
 					lds += more; g.count++;
 				}
 				pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)lds);
@@ -1198,7 +1206,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
-		uint32_t ncls[4] = {0, 0, 0, 0};
+		uint32_t ncls[5] = {0, 0, 0, 0, 0};
 		for(auto &d : pl.delta.v) ncls[delta_class(d, wide)]++;
 		const uint32_t ng16 = pl.delta16_groups, ng32 = (uint32_t)pl.delta_groups.v.size() - ng16;
 		LT.begin("delta_mesh");
@@ -1208,6 +1216,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		else if(ng16) hipLaunchKernelGGL(k_delta_lds16, dim3(ng16), dim3(256), std::min(pl.delta16_lds + ctx->dbg.lds_pad_delta, DELTA16_LDS_MAX), st, D(pl.delta), D(pl.delta_groups), ng16);
 		if(ng32) hipLaunchKernelGGL(k_delta_wave, dim3(ng32), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups) + ng16, ng32);
 		LT.end();
+		if(ncls[4]) { LT.begin("delta_tree"); hipLaunchKernelGGL(k_delta_tree, dim3(ncls[4]), dim3(256), pl.delta_tree_lds, st, D(pl.delta) + ncls[0] + ncls[1] + ncls[2] + ncls[3], ncls[4]); LT.end(); }
 	}
 	if(cloud_chunks) {
 		LT.begin("cloud_sums"); hipLaunchKernelGGL(k_cloud_sums, dim3(cloud_chunks), dim3(256), 0, st, D(pl.cloud), D(pl.cloud_chunk_job), cloud_chunks, cloud_partial); LT.end();

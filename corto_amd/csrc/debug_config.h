@@ -32,6 +32,7 @@ struct DebugConfig {
 	uint32_t delta_group = 0;       // $CORTO_EXP_DELTA_GROUP: attributes of a blob per K-DELTA workgroup (1..4; 0 = as many as fit)
 	bool unpack_chunked = false;    // $CORTO_EXP_UNPACK_CHUNKED=1: every bit block through the chunked K-BIT with its look-back (rounds 1-2), however small
 	bool unpack_twice = false;      // $CORTO_EXP_UNPACK_TWICE=1: K-BIT launched twice (what the kernel costs a pipelined decode: tools/lds_pad_probe.sh)
+	bool delta_tree = false;        // $CORTO_EXP_DELTA_TREE=1: attributes without parallelogram prediction (v += v[a]: a tree) by pointer jumping in a workgroup of their own (k_delta_tree) instead of a wave of K-DELTA's window kernel: measured level
 	bool delta_global = false;      // $CORTO_EXP_DELTA_GLOBAL=1: K-DELTA of LDS-sized blobs with no LDS at all (k_delta_global)
 	uint32_t lds_pad_delta = 0, lds_pad_topo = 0, lds_pad_normal = 0;   // $CORTO_EXP_LDS_PAD_{DELTA,TOPO,NORMAL}: KiB of LDS requested on top of what the kernel uses (what bounds the pipelined rate: tools/lds_pad_probe.sh)
 };
@@ -50,6 +51,7 @@ inline DebugConfig debug_config_from_env() {
 		c.delta_walk = on("CORTO_EXP_DELTA_WALK");
 		c.no_deq_fold = on("CORTO_EXP_NO_DEQ_FOLD");
 		c.delta_global = on("CORTO_EXP_DELTA_GLOBAL");
+		c.delta_tree = on("CORTO_EXP_DELTA_TREE");
 		c.unpack_twice = on("CORTO_EXP_UNPACK_TWICE");
 		c.unpack_chunked = on("CORTO_EXP_UNPACK_CHUNKED");
 		if(const char *e = getenv("CORTO_EXP_DELTA_GROUP")) { const uint32_t v = (uint32_t)atoi(e); if(v >= 1 && v <= 4) c.delta_group = v; }

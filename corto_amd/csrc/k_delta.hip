@@ -373,21 +373,21 @@ __device__ __forceinline__ uint32_t stage_in16(const LdsVal<K> &val, CRT_GLOBAL 
 	return bad;
 }
 
-__device__ __forceinline__ void stage_in_bytes(const LdsVal<5> &val, CRT_GLOBAL const uint8_t *src, uint32_t nvert, uint32_t N) {
+__device__ __forceinline__ void stage_in_bytes(const LdsVal<5> &val, CRT_GLOBAL const uint8_t *src, uint32_t nvert, uint32_t N, uint32_t first = lane_id(), uint32_t step = 64u) {
 	if(N == 4 && ((uintptr_t)src & 3) == 0) {
 		CRT_GLOBAL const uint32_t *s4 = (CRT_GLOBAL const uint32_t *)src;
-		for(uint32_t i0 = lane_id(); i0 < nvert; i0 += 64*8) {
+		for(uint32_t i0 = first; i0 < nvert; i0 += step*8) {
 			uint32_t w[8];
 #pragma unroll
-			for(uint32_t u = 0; u < 8; u++) w[u] = s4[i0 + u*64 < nvert ? i0 + u*64 : nvert - 1u];
+			for(uint32_t u = 0; u < 8; u++) w[u] = s4[i0 + u*step < nvert ? i0 + u*step : nvert - 1u];
 #pragma unroll
 			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(w[u]));
 #pragma unroll
-			for(uint32_t u = 0; u < 8; u++) if(i0 + u*64 < nvert) val.p[i0 + u*64] = w[u];
+			for(uint32_t u = 0; u < 8; u++) if(i0 + u*step < nvert) val.p[i0 + u*step] = w[u];
 		}
 		return;
 	}
-	for(uint32_t i = lane_id(); i < nvert; i += 64) {
+	for(uint32_t i = first; i < nvert; i += step) {
 		uint32_t w = 0;
 		for(uint32_t q = 0; q < N && q < 4; q++) w |= (uint32_t)src[(size_t)i*N + q] << (8*q);
 		val.p[i] = w;
@@ -424,12 +424,12 @@ __device__ __forceinline__ void stage_out16(const LdsVal<K> &val, CRT_GLOBAL int
 
 // a colour attribute leaves LDS as RGB(A): (r, g, b, a) = (v2 + v0, v0, v1 + v0, v3) x qc, u8 wrap (color_attribute.cpp:76-95, point.h:214),
 // or as the delta-decoded bytes when k_dequant does that later
-__device__ __forceinline__ void stage_out_bytes(const LdsVal<5> &val, const DeltaJob &J, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+__device__ __forceinline__ void stage_out_bytes(const LdsVal<5> &val, const DeltaJob &J, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t first = lane_id(), uint32_t step = 64u) {
 	const uint32_t nvert = J.nvert, N = J.N;
 	if(J.deq != 2) {                                                          // bytes back where they came from
 		CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.values);
-		if(N == 4 && ((uintptr_t)dst & 3) == 0) { for(uint32_t i = lane_id(); i < nvert; i += 64) ((CRT_GLOBAL uint32_t *)dst)[i] = val.p[i]; return; }
-		for(uint32_t i = lane_id(); i < nvert; i += 64) { const uint32_t w = val.p[i]; for(uint32_t c = 0; c < N && c < 4; c++) dst[(size_t)i*N + c] = (uint8_t)(w >> (8*c)); }
+		if(N == 4 && ((uintptr_t)dst & 3) == 0) { for(uint32_t i = first; i < nvert; i += step) ((CRT_GLOBAL uint32_t *)dst)[i] = val.p[i]; return; }
+		for(uint32_t i = first; i < nvert; i += step) { const uint32_t w = val.p[i]; for(uint32_t c = 0; c < N && c < 4; c++) dst[(size_t)i*N + c] = (uint8_t)(w >> (8*c)); }
 		return;
 	}
 	CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
@@ -444,11 +444,11 @@ __device__ __forceinline__ void stage_out_bytes(const LdsVal<5> &val, const Delt
 		CRT_LDS const u32x4 *v4 = (CRT_LDS const u32x4 *)val.p;               // (the record array starts on a 16-byte multiple)
 		CRT_GLOBAL u32x4 *d4 = (CRT_GLOBAL u32x4 *)dst;
 		const uint32_t nq = nvert >> 2;
-		for(uint32_t k = lane_id(); k < nq; k += 64) { const u32x4 w = v4[k]; d4[k] = u32x4{px(w.x), px(w.y), px(w.z), px(w.w)}; }
-		for(uint32_t i = (nq << 2) + lane_id(); i < nvert; i += 64) ((CRT_GLOBAL uint32_t *)dst)[i] = px(val.p[i]);
+		for(uint32_t k = first; k < nq; k += step) { const u32x4 w = v4[k]; d4[k] = u32x4{px(w.x), px(w.y), px(w.z), px(w.w)}; }
+		for(uint32_t i = (nq << 2) + first; i < nvert; i += step) ((CRT_GLOBAL uint32_t *)dst)[i] = px(val.p[i]);
 		return;
 	}
-	for(uint32_t i = lane_id(); i < nvert; i += 64) {
+	for(uint32_t i = first; i < nvert; i += step) {
 		const uint32_t w = px(val.p[i]);
 		CRT_GLOBAL uint8_t *o = dst + (size_t)i*stride;
 		if(oc == 4 && (((uintptr_t)o) & 3) == 0) *(CRT_GLOBAL uint32_t *)o = w;
@@ -587,6 +587,119 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 			const uint32_t n = nvert*N;
 			for(uint32_t k = lane; k < n; k += 64) { const int32_t x = v[k]; ((CRT_GLOBAL float *)v)[k] = (float)x*J.q; }
 		}
+	}
+}
+
+// ---- EXPERIMENT ($CORTO_EXP_DELTA_TREE=1): the attributes that only use `a` (strategy without PARALLEL: v[i] += v[a],
+// vertex_attribute.h:170-176; uv and colours of the usual encoder settings) by POINTER JUMPING.  That recurrence is a TREE: v[i] = the
+// sum of the deltas on i's path to a root, and integer sums (mod 2^32, or mod 256 for colours) can be taken in any order.  Every vertex
+// keeps (partial sum, the ancestor whose partial sum is still missing); a round adds the ancestor's pair to it: val[i] += val[anc],
+// anc[i] = anc[anc].  The distance covered doubles each round: ~log2(depth) rounds over all vertices (a 2 112-vertex blob: twelve)
+// instead of ~150 dependent window passes, in a workgroup of its own - and the parallelogram attributes' workgroup holds 26 KB, not 43.
+// A round is read phase | barrier | write phase | barrier per chunk of 256 x 8 vertices (every pair is read as the barrier left it,
+// chunks see the chunks before them already advanced).  32-bit values (no int16 bookkeeping: nothing to check, nothing to redo).
+// LDS: val[nvert x N] int32 (colours: one dword of four bytes) | anc[nvert] u16.
+// MEASURED (C4 batch): 24 us alone - 9.5 us of launch + staging, twelve rounds of 1.25 us (two barriers and two dependent LDS round
+// trips per chunk) - while the position-only window kernel goes from 49 to 45 us; pipelined the two are level (12.0 vs 12.2 Gtri/s,
+// irregular 6.69 vs 6.57): the 17 KB x 90 us it frees are spent again on 2 048 more waves for 24 us.  Off by default.
+constexpr uint32_t TREE_NONE = 0xFFFFu;
+template <int NW, bool BYTES>
+__device__ __forceinline__ void delta_tree_rounds(CRT_LDS uint32_t *val, CRT_LDS uint16_t *anc, uint32_t nvert, uint32_t tid) {
+	constexpr uint32_t U = 8;
+	const uint32_t nchunks = (nvert + 256u*U - 1u)/(256u*U);
+	const uint32_t csize = (((nvert + nchunks - 1u)/nchunks) + 255u) & ~255u;  // chunks of equal size, a multiple of the workgroup
+	for(uint32_t round = 0; round < 20; round++) {                            // (2^16 > any depth: the loop ends by itself)
+		uint32_t any = 0;
+		for(uint32_t c0 = 0; c0 < nvert; c0 += csize) {
+			const uint32_t cend = c0 + csize < nvert ? c0 + csize : nvert;
+			uint32_t k[U], ak[U], vi[U][NW], vk[U][NW];
+#pragma unroll
+			for(uint32_t u = 0; u < U; u++) { const uint32_t i = c0 + tid + 256u*u; k[u] = anc[i < cend ? i : c0]; }
+#pragma unroll
+			for(uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(k[u]));
+#pragma unroll
+			for(uint32_t u = 0; u < U; u++) {
+				const uint32_t i = c0 + tid + 256u*u, ic = i < cend ? i : c0;
+				if(i >= cend) k[u] = TREE_NONE;
+				const uint32_t kk = k[u] != TREE_NONE ? k[u] : 0u;
+				ak[u] = anc[kk];
+#pragma unroll
+				for(int q = 0; q < NW; q++) { vk[u][q] = val[kk*NW + q]; vi[u][q] = val[ic*NW + q]; }
+			}
+#pragma unroll
+			for(uint32_t u = 0; u < U; u++) {
+				asm volatile("" : "+v"(ak[u]));
+#pragma unroll
+				for(int q = 0; q < NW; q++) asm volatile("" : "+v"(vk[u][q]), "+v"(vi[u][q]));
+			}
+			__syncthreads();
+#pragma unroll
+			for(uint32_t u = 0; u < U; u++) if(k[u] != TREE_NONE) {
+				const uint32_t i = c0 + tid + 256u*u;
+#pragma unroll
+				for(int q = 0; q < NW; q++) {
+					const uint32_t x = vi[u][q], y = vk[u][q];
+					val[i*NW + q] = BYTES ? (((x & 0x7F7F7F7Fu) + (y & 0x7F7F7F7Fu)) ^ ((x ^ y) & 0x80808080u)) : x + y;   // four byte sums, no carry across
+				}
+				anc[i] = (uint16_t)ak[u];
+				any |= (uint32_t)(ak[u] != TREE_NONE);
+			}
+			__syncthreads();
+		}
+		if(!__syncthreads_or((int)any)) break;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_delta_tree(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
+	if(blockIdx.x >= njobs) return;
+	const DeltaJob &J = jobs[blockIdx.x];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const uint32_t tid = threadIdx.x, nvert = J.nvert, N = J.N;
+	const bool bytes = J.is_u8 != 0;
+	CRT_LDS uint32_t *val = (CRT_LDS uint32_t *)as_lds(lds);
+	CRT_LDS uint16_t *anc = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)as_lds(lds) + delta_tree_vbytes(nvert, N, bytes));
+	// stage in: the raw deltas (a flat copy, eight loads a thread in flight) and `a` out of the prediction triples
+	if(bytes) {
+		stage_in_bytes(LdsVal<5>{val}, as_global((const uint8_t *)J.values), nvert, N, tid, 256u);
+	} else {
+		CRT_GLOBAL const uint32_t *src = as_global((const uint32_t *)J.values);
+		const uint32_t n = nvert*N;
+		for(uint32_t e0 = tid; e0 < n; e0 += 256u*8u) {
+			uint32_t w[8];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) w[u] = src[e0 + 256u*u < n ? e0 + 256u*u : n - 1u];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(w[u]));
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) if(e0 + 256u*u < n) val[e0 + 256u*u] = w[u];
+		}
+	}
+	{
+		CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
+		for(uint32_t i0 = tid; i0 < nvert; i0 += 256u*8u) {
+			uint32_t a[8];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) a[u] = pred[3*(size_t)(i0 + 256u*u < nvert ? i0 + 256u*u : nvert - 1u)];
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(a[u]));
+#pragma unroll
+			for(uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + 256u*u; if(i < nvert) anc[i] = (uint16_t)(a[u] < i ? a[u] : TREE_NONE); }   // (a >= i: the value stays, as graph_word())
+		}
+	}
+	__syncthreads();
+	if(bytes) delta_tree_rounds<1, true>(val, anc, nvert, tid);
+	else if(N == 1) delta_tree_rounds<1, false>(val, anc, nvert, tid);
+	else if(N == 2) delta_tree_rounds<2, false>(val, anc, nvert, tid);
+	else if(N == 3) delta_tree_rounds<3, false>(val, anc, nvert, tid);
+	else delta_tree_rounds<4, false>(val, anc, nvert, tid);
+	// out: as the caller wants them (the same folds as k_delta_lds16's copy-out)
+	if(bytes) { stage_out_bytes(LdsVal<5>{val}, J, J.qc[0], J.qc[1], J.qc[2], J.qc[3], tid, 256u); return; }
+	CRT_GLOBAL int32_t *dst = as_global((int32_t *)J.values);
+	const uint32_t n = nvert*N;
+	const bool as_float = J.deq == 1; const float q = J.q;
+	for(uint32_t e = tid; e < n; e += 256u) {
+		const int32_t v = (int32_t)val[e];
+		if(as_float) ((CRT_GLOBAL float *)dst)[e] = (float)v*q; else dst[e] = v;
 	}
 }
 

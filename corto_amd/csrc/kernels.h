@@ -96,6 +96,11 @@ __host__ __device__ inline uint32_t delta16_graph_lds(uint32_t nvert, bool a_emb
 	return ((4u*nvert + 15u) & ~15u) + (a_embedded ? 0u : ((2u*nvert + 15u) & ~15u)) + delta16_walk_shared(nvert) + 4u*4u*(64u + delta_wave_bit_words(nvert)) + 16u;
 }
 __global__ void k_delta_lds16(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
+// ... attributes that only use `a` (no parallelogram: a tree): pointer jumping, 32-bit values (or four bytes) + a u16 ancestor per vertex in LDS
+constexpr uint32_t DELTA_TREE_LDS_MAX = 64*1024, DELTA_TREE_NVERT_MAX = 32767;
+__host__ __device__ inline uint32_t delta_tree_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return (nvert*4u*(is_u8 ? 1u : N) + 15u) & ~15u; }
+__host__ __device__ inline uint32_t delta_tree_lds(uint32_t nvert, uint32_t N, bool is_u8) { return delta_tree_vbytes(nvert, N, is_u8) + ((2u*nvert + 15u) & ~15u) + 16u; }
+__global__ void k_delta_tree(const DeltaJob *jobs, uint32_t njobs);
 __global__ void k_delta_global(const DeltaJob *jobs, uint32_t njobs);      // experiment: the same loop with no LDS (values and graph in HBM / L2), one wave per attribute
 
 // k_normal.hip

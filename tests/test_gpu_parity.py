@@ -109,7 +109,7 @@ def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_EXP_DELTA_GLOBAL": "1"}, {"CORTO_EXP_NO_DEQ_FOLD": "1"}, {"CORTO_EXP_DELTA_GROUP": "1"},
-                                 {"CORTO_EXP_NORMAL_FN_MAX": "0"}, {"CORTO_EXP_NORMAL_FN_MAX": "150000"}, {"CORTO_EXP_UNPACK_TWICE": "1"},
+                                 {"CORTO_EXP_NORMAL_FN_MAX": "0"}, {"CORTO_EXP_NORMAL_FN_MAX": "150000"}, {"CORTO_EXP_UNPACK_TWICE": "1"}, {"CORTO_EXP_DELTA_TREE": "1"},
                                  {"CORTO_EXP_LDS_PAD_DELTA": "8", "CORTO_EXP_LDS_PAD_TOPO": "8", "CORTO_EXP_LDS_PAD_NORMAL": "8"}],
                          ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
 def test_experiment_switches_are_bit_exact(monkeypatch, env):
