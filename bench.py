@@ -617,6 +617,10 @@ def main():
     # beside `value`: the same pipelined steps with one Tunstall dictionary built PER STREAM ($CORTO_TUN_SHARE=2; read when a context is
     # made, so: a second pool).  By default the streams of a batch that carry the same probability table share one dictionary, and the
     # synthetic blobs - one generator, 256 seeds, the same connectivity - repeat tables far more than unrelated meshes would.
+    # (the main pool is closed first: its sixteen contexts' streams would share the sixteen hardware queues with the side pools' - round 3's
+    # first side-leg numbers were taken that way and came out 10-30 % under what the same pool does alone, tools/shape_probe.py)
+    pool_lanes, pool_warning = pool.lanes, pool.warning
+    pool.close()
     os.environ["CORTO_TUN_SHARE"] = "2"            # one dictionary per stream whatever repeats (still two kernels: dictionaries, then decodes)
     pool_ns = ca.Pool(devices, threads=nthreads, depth=depth)
     del os.environ["CORTO_TUN_SHARE"]
@@ -712,7 +716,7 @@ def main():
                            n_gpus, "one process, one work queue over all GPUs" if world == 1 else "one process per GPU, RCCL only for barrier/max", nthreads, depth)},
             "bit_exact": True, "bit_exact_blobs_checked": checked, "topology_fallbacks": int(rep.topology_fallbacks),
             "steps_per_device": steps_per_device,
-            "steady_state": window_stats(stamps, pool.lanes),
+            "steady_state": window_stats(stamps, pool_lanes),
             "tunstall_dictionaries": {"streams": int(stats0.tunstall_streams), "built": int(stats0.tunstall_dictionaries),
                                       "note": "per batch (rebuilt every step): streams of a batch with the same probability table share one dictionary; "
                                               "one generator with 256 seeds repeats tables more than unrelated meshes would - see without_dictionary_sharing"},
@@ -721,11 +725,11 @@ def main():
             "irregular_connectivity": irregular,
             "realistic": realistic,
             "sustained": sustained,
-            "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool.warning or None,
+            "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool_warning or None,
             "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1), "numa_pinned_devices": int(rep.pinned_devices),
             "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "mverts_per_s": round(tris_h / elapsed_h / 1e6 * nvert / ntri, 2),
                                     "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
-                                    **window_stats(stamps_h, pool.lanes),
+                                    **window_stats(stamps_h, pool_lanes),
                                     "roofline": {"bound": "hbm", "what": "whole path, SURVEY 8d primary region (pinned-host .crt -> HBM outputs)",
                                                  "algorithmic_bytes_per_step": whole_path_bytes, "achieved": round(whole_path_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9, 2),
                                                  "peak": 8000.0, "unit": "GB/s", "frac": round(whole_path_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9 / 8000.0, 6),
@@ -762,7 +766,6 @@ def main():
             if "facade_per_blob" in out:
                 out["facade_per_blob"]["cpu_reference_us"] = round(4096 / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    pool.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
