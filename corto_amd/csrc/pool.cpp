@@ -286,7 +286,12 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 		// a poisoned step's output, not only almost always
 		for(uint32_t k = 0; k < p->depth && !err; k++) {
 			Lane &L = mine[k];
-			if(L.item < 0 || L.poisoned || !L.out) continue;
+			if(L.item < 0) {                                     // ... and one that drew no ticket at all (a 28-step run on a cold box) decodes its device's first item
+				const uint32_t j = home[slot].empty() ? 0u : home[slot][0];
+				err = lane_plan(p, L, items[j], (int64_t)j);
+				if(err) break;
+			}
+			if(L.poisoned || !L.out) continue;
 			err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
 			if(!err) err = crthip_batch_decode(L.batch);
 			if(!err) { L.busy = true; L.poisoned = true; err = finish(L); }
