@@ -526,7 +526,8 @@ def main():
     # ---- the timed region (see the module docstring): the pool runs W warm-up steps straight into exactly K timed steps per GPU
     nloc = len(devices)
     # whatever W is: every context used (scratch pools are allocated on first use) and the GPU at its working clocks before the clock starts
-    pool.run(items, steps=8 * pool.lanes, warmup=0, arenas=arenas)
+    prewarm_steps = int(os.environ.get("BENCH_PREWARM_STEPS", "0")) or 8 * pool.lanes
+    pool.run(items, steps=prewarm_steps * nloc, warmup=0, arenas=arenas)
     barrier()
     # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
