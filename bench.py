@@ -16,7 +16,7 @@ Timing: barrier + device sync, then W warm-up steps flow straight into the K tim
 between); the clock runs from the completion of the last warm-up step to the completion of the K-th timed step, a few more
 steps are queued behind so that every context is still busy when the clock stops, then everything drains, barrier + sync.
 So `--steps 20` measures the same steady state as `--steps 480`.  value = K batches / that time (max over ranks).
-With K < 100 the K-step region is timed five times back to back (no drain in between) and the MEDIAN region is reported, every
+With K < 100 the K-step region is timed R = ~500/K times back to back (no drain in between) and the MEDIAN region is reported, every
 region's time in `timed_regions`: completions of sixteen batches in flight come in bursts, and one region of 20 steps lands
 anywhere within -15 / +30 % of the long-run rate (tools/pool_probe.py).
 `python bench.py --gpus N` without a launcher runs the N GPUs from this one process (one pool, shared queue, N x K steps);
@@ -532,7 +532,7 @@ def main():
     # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
     # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: one region.
-    R = 1 if args.steps >= 100 else 5
+    R = 1 if args.steps >= 100 else max(5, -(-500 // args.steps) | 1)      # (an odd number of regions, ~500 steps in all: round 3 - five regions' median still moved +-8 % run to run)
     rep, stamps = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
     barrier()
     kk = args.steps * nloc
@@ -711,7 +711,7 @@ def main():
                        "blobs_per_gpu": NBLOBS, "tris_per_gpu": ntri, "verts_per_gpu": nvert,
                        "timed_region": "K x [plan(host walk)+bind+kernels+sync] per GPU, compressed inputs resident in HBM, outputs left in HBM; clock from the "
                                        "completion of the last of W warm-up steps to the completion of the K-th timed step, pipeline full at both ends "
-                                       "(barrier + device sync before the warm-up and after the drain); K < 100: five such regions back to back, the median one reported (timed_regions)",
+                                       "(barrier + device sync before the warm-up and after the drain); K < 100: ~500/K such regions back to back, the median one reported (timed_regions)",
                        "pipeline_depth": depth, "host_threads": nthreads, "launch": mode,
                        "parallelism": "blob-sharded x%d, no collective; %s; %d native host threads x %d batches in flight per GPU" % (
                            n_gpus, "one process, one work queue over all GPUs" if world == 1 else "one process per GPU, RCCL only for barrier/max", nthreads, depth)},

@@ -1,7 +1,7 @@
 #!/bin/bash
 # how long the untimed pre-warm has to be for a 20-step timed region to see the steady-state rate (bench.py: BENCH_PREWARM_STEPS)
 cd $GRAFT_REPO_ROOT
-for pw in ${PW:-128 4000 128 4000 20000}; do
+for pw in ${PW:-128 128 128 4000 128}; do
   echo -n "prewarm $pw: "
   BENCH_PREWARM_STEPS=$pw python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu --no-other-configs --no-tunstall-scaled --sustain 0 2>/dev/null | python -c "
 import sys, json
