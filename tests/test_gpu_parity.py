@@ -89,7 +89,7 @@ def test_heterogeneous_batch(ctx):
 def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
     """K-BIT has two kernels: the log streams of a small bit block (<= 16 384 logs) take one wave each, lanes interleaved over the
     vertices, the bits in front of a stream re-added from the earlier streams' logs (k_unpack_wave); larger blocks go in chunks of
-    1 024 with look-back (k_unpack_scan/_extract; $CORTO_EXP_UNPACK_CHUNKED=1 sends everything there).  Same bytes from both, and the
+    1 024 with look-back (k_unpack_extract; $CORTO_EXP_UNPACK_CHUNKED=1 sends everything there).  Same bytes from both, and the
     oracle's: ragged sizes around the 64-lane round and the 512-log block, 1..4 fields per log, u8 and int32 outputs, a cloud."""
     from corto_amd import synth
     meshes = [synth.bumpy_sphere(nu, nv, seed=nu) for nu, nv in ((3, 2), (7, 3), (8, 7), (9, 7), (21, 3), (32, 15), (32, 16), (33, 16), (64, 32), (70, 60), (127, 120))]
