@@ -582,10 +582,24 @@ def main():
     # (the side legs run 600 steps whatever K is: a 120-step region of sixteen batches in flight lands anywhere within -40 / +5 % of the
     # long-run rate - tools/leg_probe.py - and 600 steps of these take 0.1-0.15 s)
     fh_steps = 600 * nloc
+    pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=None)      # (untimed: every context's pinned image of an arena is allocated on first use)
     barrier()
-    rep_h, stamps_h = pool.run(items, steps=fh_steps, warmup=2 * pool.lanes, arenas=None)
+    fhh_steps = 2000 * nloc       # (the from-host legs run longer: they meet an occasional 7-8 ms stall - tools/fromhost_gaps.py - that a 60 ms leg cannot average out)
+    rep_h, stamps_h = pool.run(items, steps=fhh_steps, warmup=2 * pool.lanes, arenas=None)
     barrier()
     elapsed_h = shard.max_over_ranks(rep_h.elapsed_s, dist, red_dev)
+    # ... and the same with every item's blobs in ONE pinned host buffer, laid out as an arena (crthip_ctx_set_packed_host_blobs): the upload
+    # is one DMA copy straight from the caller's memory, without the library gathering 256 scattered blobs into its own pinned image first
+    pins = [ca.pinned_host_arena(it) for it in items]
+    pool.set_packed_host_blobs(True)
+    barrier()
+    rep_hp, stamps_hp = pool.run([v for _, v in pins], steps=fhh_steps, warmup=2 * pool.lanes, arenas=None)
+    barrier()
+    pool.set_packed_host_blobs(False)
+    elapsed_hp = shard.max_over_ranks(rep_hp.elapsed_s, dist, red_dev)
+    tris_hp = shard.sum_over_ranks(float(rep_hp.triangles), dist, red_dev)
+    if rep_hp.failed_blobs:
+        raise SystemExit("bench.py: from-host (packed) leg: %d failed blobs" % rep_hp.failed_blobs)
 
     # sustained: the same pool, the same steps, for at least --sustain seconds in ONE region (steady clocks and thermals; what a 2 ms region cannot show)
     sustained = None
@@ -669,10 +683,15 @@ def main():
             for k, (dt, w) in dts.items():
                 got = pool_r.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
                 assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (realistic)", lane, i, k)
+        pin_r, iviews = ca.pinned_host_arena(iblobs)
+        pool_r.set_packed_host_blobs(True)
+        rep_rp, _ = pool_r.run([iviews], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
+        pool_r.set_packed_host_blobs(False)
         realistic = {"mtri_per_s": round(rep_r.triangles / rep_r.elapsed_s / 1e6, 2), "mverts_per_s": round(rep_r.vertices / rep_r.elapsed_s / 1e6, 2),
                      "ms_per_step": round(rep_r.elapsed_s / r_steps * 1e3, 4), "steps": r_steps,
                      "topology_fallbacks": int(rep_r.topology_fallbacks), "failed_blobs": int(rep_r.failed_blobs), **window_stats(st_r, pool_r.lanes),
                      "h2d_bytes_per_step": int(sum(((len(x) + 15) & ~15) for x in iblobs)),
+                     "packed_pinned_mtri_per_s": round(rep_rp.triangles / rep_rp.elapsed_s / 1e6, 2) if not rep_rp.failed_blobs else None,
                      "note": "one GPU; irregular connectivity (bumpy_sphere_flipped) + $CORTO_TUN_SHARE=2 (one dictionary per stream) + compressed blobs in HOST memory, uploaded "
                              "over PCIe inside every step; outputs poisoned before the last round, bit-exact spot check against the oracle.  The number to expect from unrelated scanned meshes; `value` is the best case"}
         pool_r.close()
@@ -729,12 +748,16 @@ def main():
             "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool_warning or None,
             "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1), "numa_pinned_devices": int(rep.pinned_devices),
             "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "mverts_per_s": round(tris_h / elapsed_h / 1e6 * nvert / ntri, 2),
-                                    "ms_per_step": round(elapsed_h / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
+                                    "ms_per_step": round(elapsed_h / (fhh_steps / nloc) * 1e3, 4), "steps": fhh_steps // nloc,
                                     **window_stats(stamps_h, pool_lanes),
                                     "roofline": {"bound": "hbm", "what": "whole path, SURVEY 8d primary region (pinned-host .crt -> HBM outputs)",
-                                                 "algorithmic_bytes_per_step": whole_path_bytes, "achieved": round(whole_path_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9, 2),
-                                                 "peak": 8000.0, "unit": "GB/s", "frac": round(whole_path_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9 / 8000.0, 6),
-                                                 "pcie_GBps": round(stats0.arena_bytes / (elapsed_h / (fh_steps / nloc)) / 1e9, 2)},
+                                                 "algorithmic_bytes_per_step": whole_path_bytes, "achieved": round(whole_path_bytes / (elapsed_h / (fhh_steps / nloc)) / 1e9, 2),
+                                                 "peak": 8000.0, "unit": "GB/s", "frac": round(whole_path_bytes / (elapsed_h / (fhh_steps / nloc)) / 1e9 / 8000.0, 6),
+                                                 "pcie_GBps": round(stats0.arena_bytes / (elapsed_h / (fhh_steps / nloc)) / 1e9, 2)},
+                                    "packed_pinned": {"mtri_per_s": round(tris_hp / elapsed_hp / 1e6, 2), "ms_per_step": round(elapsed_hp / (fhh_steps / nloc) * 1e3, 4),
+                                                      **window_stats(stamps_hp, pool_lanes), "pcie_GBps": round(stats0.arena_bytes / (elapsed_hp / (fhh_steps / nloc)) / 1e9, 2),
+                                                      "note": "the same, the item's blobs laid out as an arena in ONE pinned host buffer (crthip_ctx_set_packed_host_blobs): "
+                                                              "one DMA copy from the caller's memory, no gathering of 256 scattered (pageable) blobs on the host thread first"},
                                     "note": "same pipelined steps, but every step uploads its %.1f MB of compressed blobs from host memory (PCIe H2D inside the step); "
                                             "reported beside `value`, never as it" % (stats0.arena_bytes / 1e6)},
             "single_batch": {"ms": round(solo_ms, 4), "mtri_per_s": round(ntri / solo_ms / 1e3, 2), "steps": solo_steps,

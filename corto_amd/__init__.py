@@ -161,6 +161,8 @@ def lib():
         L.crthip_pool_lanes.argtypes = [C.c_void_p]
         L.crthip_pool_warning.restype = C.c_char_p
         L.crthip_pool_warning.argtypes = [C.c_void_p]
+        L.crthip_pool_set_packed_host_blobs.argtypes = [C.c_void_p, C.c_int]
+        L.crthip_ctx_set_packed_host_blobs.argtypes = [C.c_void_p, C.c_int]
         L.crthip_pool_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(PoolReport), C.c_void_p]
         L.crthip_pool_lane_item.restype = C.c_int64
         L.crthip_pool_lane_item.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -290,6 +292,10 @@ class Context:
     def set_single_stream(self, on: bool = True):
         """one HIP stream per context instead of two: faster from about $GPU_MAX_HW_QUEUES / 2 contexts per GPU up (corto_hip.h)"""
         _check(lib().crthip_ctx_set_single_stream(self.handle, int(on)))
+
+    def set_packed_host_blobs(self, on: bool = True):
+        """blobs laid out as an arena in ONE pinned host buffer (pinned_host_arena) are uploaded straight from there (corto_hip.h)"""
+        _check(lib().crthip_ctx_set_packed_host_blobs(self.handle, int(on)))
 
     def sync(self):
         _check(lib().crthip_ctx_sync(self.handle))
@@ -537,6 +543,10 @@ class Pool:
         self.warning = lib().crthip_pool_warning(self.handle).decode()
         self._keep = None
 
+    def set_packed_host_blobs(self, on: bool = True):
+        """items run without device arenas whose blobs are views of ONE pinned host buffer (pinned_host_arena) go up straight from it"""
+        _check(lib().crthip_pool_set_packed_host_blobs(self.handle, int(on)))
+
     def run(self, items, steps: int, warmup: int = 0, arenas=None):
         """items: list of batches (each a list of aligned uint8 blobs).  arenas: None (every step uploads its blobs) or, per item, a
         list with one device tensor per pool device (the item's blobs resident there in arena_layout order).
@@ -603,6 +613,21 @@ def upload_arena(blobs: Sequence[np.ndarray], device: int = 0):
     arena = torch.from_numpy(host).to(torch.device("cuda", device))
     _torch_ready(arena.device)
     return arena
+
+
+def pinned_host_arena(blobs: Sequence[np.ndarray]):
+    """The blobs back to back (crthip_arena_layout) in ONE pinned host buffer: returns (the pinned torch tensor - keep it alive -, the
+    list of numpy views of the blobs inside it).  Handed to a context / pool with set_packed_host_blobs(True), the views are uploaded
+    with one DMA copy straight from the buffer."""
+    import torch
+    offs, total = arena_layout([len(b) for b in blobs])
+    pin = torch.zeros(max(total, 16), dtype=torch.uint8).pin_memory()
+    host = pin.numpy()
+    views = []
+    for b, o in zip(blobs, offs):
+        host[int(o):int(o) + len(b)] = b
+        views.append(host[int(o):int(o) + len(b)])
+    return pin, views
 
 
 class Decoder:

@@ -220,10 +220,13 @@ struct crthip_ctx {
 	TunLaunch tun_launch() const { return TunLaunch{stream, !dbg.tun_three}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
 	PinnedBuf staging;        // host image of the job arrays
+	PinnedBuf arena_pin;      // host image of a batch's blobs on their way to the device (batch_fill: one H2D copy, not waited for)
 	PinnedBuf status_host;
 	bool profiling = false;
 	KernelTimer timer;
 	crthip_batch *in_flight = nullptr;   // decode enqueued, status not harvested yet
+	bool packed_host = false;            // crthip_ctx_set_packed_host_blobs: blobs laid out as an arena in the caller's pinned memory go up from there
+	bool arena_upload_pending = false;   // a batch's blobs are (perhaps still) on their way from arena_pin: cleared by whoever synchronises the stream
 	crthip_batch *last_decoded = nullptr;// whose intermediates the scratch block holds (crthip_batch_debug_read)
 	// crthip_decode_host: everything a one-blob decode with host buffers needs, kept from call to call (no hipMalloc / create in the
 	// steady state) and guarded by a mutex so that callers may share a context between threads
@@ -281,6 +284,7 @@ static int harvest(crthip_ctx *ctx) {
 	crthip_batch *b = ctx->in_flight;
 	if(!b) return CRTHIP_OK;
 	if(hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->in_flight = nullptr; return CRTHIP_E_DEVICE; }
+	ctx->arena_upload_pending = false;
 	const int32_t *hs = (const int32_t *)ctx->status_host.p;
 	const size_t n = b->blobs.size();
 	for(size_t i = 0; i < n; i++) b->status[i] = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
@@ -369,7 +373,7 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	(void)hipStreamSynchronize(c->stream);
 	c->timer.release();
 	if(c->host_batch) { crthip_batch *hb = c->host_batch; c->host_batch = nullptr; crthip_batch_destroy(hb); }
-	c->scratch.release(); c->staging.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
+	c->scratch.release(); c->staging.release(); c->arena_pin.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
 	(void)hipStreamSynchronize(c->stream2);
 	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
 	(void)hipStreamDestroy(c->stream2);
@@ -380,6 +384,12 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 extern "C" int crthip_ctx_set_profiling(crthip_ctx *c, int enable) {
 	if(!c) return fail(CRTHIP_E_ARGUMENT);
 	c->profiling = enable != 0;
+	return CRTHIP_OK;
+}
+
+extern "C" int crthip_ctx_set_packed_host_blobs(crthip_ctx *c, int on) {
+	if(!c) return fail(CRTHIP_E_ARGUMENT);
+	c->packed_host = on != 0;
 	return CRTHIP_OK;
 }
 
@@ -429,12 +439,26 @@ static int batch_fill(crthip_ctx *ctx, crthip_batch *b, uint32_t nblobs, const u
 	if(device_arena) b->d_arena = (const uint8_t *)device_arena;
 	else if(off) {
 		if(b->own_arena.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-		if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);      // the staging buffer may still feed the batch in flight
-		if(ctx->staging.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-		uint8_t *h = (uint8_t *)ctx->staging.p;
+		// the blobs are gathered in a pinned image of the arena and go up in ONE copy on the context's stream, in front of the kernels that
+		// read them - and nobody waits for it (round 3: the hipStreamSynchronize that stood here was 100 us of every from-host step, on the
+		// host thread): the image is this context's own buffer, reused only after harvest() has seen the batch it fed complete
+		if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
+		bool in_place = ctx->packed_host && nblobs > 0;                        // the caller's buffer IS the arena's image (corto_hip.h)
+		for(uint32_t i = 0; in_place && i < nblobs; i++) in_place = blobs[i] == blobs[0] + b->blobs[i].arena_off;
+		if(in_place) {
+			const uint64_t bytes = b->blobs[nblobs - 1].arena_off + lens[nblobs - 1];
+			if(hipMemcpyAsync(b->own_arena.p, blobs[0], bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+		} else {
+		if(ctx->arena_upload_pending) {                                      // (a batch that was created and not decoded yet: its upload has to be through before the image is reused)
+			if(hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+			ctx->arena_upload_pending = false;
+		}
+		if(ctx->arena_pin.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+		uint8_t *h = (uint8_t *)ctx->arena_pin.p;
 		for(uint32_t i = 0; i < nblobs; i++) memcpy(h + b->blobs[i].arena_off, blobs[i], lens[i]);
-		if(hipMemcpyAsync(b->own_arena.p, h, off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-		   hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+		if(hipMemcpyAsync(b->own_arena.p, h, off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+		ctx->arena_upload_pending = true;
+		}
 		b->d_arena = (const uint8_t *)b->own_arena.p;
 	}
 	b->status.assign(nblobs, 0);

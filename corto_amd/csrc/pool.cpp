@@ -133,6 +133,11 @@ extern "C" void crthip_pool_destroy(crthip_pool *p) {
 
 extern "C" uint32_t crthip_pool_lanes(const crthip_pool *p) { return p ? (uint32_t)p->lanes.size() : 0; }
 extern "C" const char *crthip_pool_warning(const crthip_pool *p) { return p ? p->warning.c_str() : ""; }
+extern "C" int crthip_pool_set_packed_host_blobs(crthip_pool *p, int on) {
+	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	for(auto &L : p->lanes) { const int err = crthip_ctx_set_packed_host_blobs(L.ctx, on); if(err) return err; }
+	return CRTHIP_OK;
+}
 
 // plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
 static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id) {

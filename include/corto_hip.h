@@ -129,6 +129,13 @@ void crthip_ctx_destroy(crthip_ctx *ctx);
  * The same switch selects the LDS-lean layout of the normals kernel (41 KB instead of 91 KB per blob: slower alone, but with many
  * batches in flight a kernel's wait for LDS is what its latency is made of: +10 %). */
 int crthip_ctx_set_single_stream(crthip_ctx *ctx, int on);
+/* Blobs that already sit in ONE pinned host buffer (hipHostMalloc / hipHostRegister / torch pin_memory), laid out as
+ * crthip_arena_layout says (blob i at blobs[0] + offset i): with this switch on, crthip_batch_create / _reset upload them with one
+ * DMA copy straight from there - no gathering into the library's own pinned image first (3.7 MB of memcpy per C4 batch: 150 us of a
+ * from-host step's host time).  The caller's promise: the buffer stays valid and unchanged until the batch has been synced.  Blob
+ * pointers that are NOT laid out that way take the gathering path as before, whatever the switch says.  (No reference counterpart:
+ * crt::Decoder reads its one blob from the caller's memory in place, src/decoder.cpp:41-48.) */
+int crthip_ctx_set_packed_host_blobs(crthip_ctx *ctx, int on);
 int crthip_device_count(void);
 
 /* Plan a batch: parse every header, walk every body (validating all extents against lens[i]),
@@ -192,6 +199,8 @@ uint32_t crthip_pool_lanes(const crthip_pool *pool);     /* ndevices * threads_p
  * its own, ROCm hands out $GPU_MAX_HW_QUEUES (default 4) per process and reads it when HIP initialises - a pool of 16 contexts on
  * the default runs at a fraction of its rate.  Contexts are counted per physical GPU (a device id may repeat). */
 const char *crthip_pool_warning(const crthip_pool *pool);
+/* crthip_ctx_set_packed_host_blobs for every context of the pool (items handed to crthip_pool_run without device arenas). */
+int crthip_pool_set_packed_host_blobs(crthip_pool *pool, int on);
 
 /* One work item = one batch of blobs (HOST pointers, borrowed for the duration of crthip_pool_run).
  * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step;

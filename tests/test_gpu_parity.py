@@ -134,6 +134,46 @@ def test_experiment_switches_are_bit_exact(monkeypatch, env):
         b.close(); c.close()
 
 
+def test_host_blobs_upload_is_not_waited_for_and_packed_pinned_blobs_go_up_in_place():
+    """crthip_batch_create / _reset with host blobs (round 3): the blobs are gathered into the context's pinned image and go up in one
+    copy that nobody waits for - so a second batch made on the same context before the first is decoded must not disturb the first's
+    bytes (the image is reused only once the upload is through) - and with crthip_ctx_set_packed_host_blobs a batch whose blobs are
+    views of ONE pinned buffer (corto_amd.pinned_host_arena) is uploaded straight from it; blobs that are not laid out that way take
+    the gathering path whatever the switch says.  Every output against the golden fixtures."""
+    names = list(ALL_CASES)
+    gs = [load_golden(n) for n in names]
+    blobs = [g["crt"] for g in gs]
+    rev = blobs[::-1]
+    c = ca.Context(0)
+    a = ca.Batch(c, blobs)                                   # two uploads queued on one context, nothing decoded yet
+    b = ca.Batch(c, rev)
+    for bt in (a, b):
+        bt.allocate_outputs(fill=0)
+    a.decode(); assert (a.sync() == 0).all()
+    b.decode(); assert (b.sync() == 0).all()
+    for i, g in enumerate(gs):
+        assert_same(a.host_outputs(i), g, KEYS, "first batch " + names[i])
+        assert_same(b.host_outputs(len(gs) - 1 - i), g, KEYS, "second batch " + names[i])
+    a.close(); b.close()
+    pin, views = ca.pinned_host_arena(blobs)
+    c.set_packed_host_blobs(True)
+    for round_ in range(3):                                  # in place, three times over (reset re-uses the batch object)
+        bt = ca.Batch(c, views) if round_ == 0 else bt
+        if round_:
+            bt.reset(views)
+        bt.allocate_outputs(fill=0)
+        bt.decode(); assert (bt.sync() == 0).all()
+        for i, g in enumerate(gs):
+            assert_same(bt.host_outputs(i), g, KEYS, "packed " + names[i])
+    bt.close()
+    sc = ca.Batch(c, rev)                                    # scattered blobs with the switch on: gathered as before
+    sc.allocate_outputs(fill=0)
+    sc.decode(); assert (sc.sync() == 0).all()
+    for i, g in enumerate(gs):
+        assert_same(sc.host_outputs(len(gs) - 1 - i), g, KEYS, "scattered " + names[i])
+    sc.close(); c.close()
+
+
 def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
     table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_grouped); $CORTO_TUN_SHARE=0
