@@ -396,8 +396,9 @@ extern "C" int crthip_ctx_set_packed_host_blobs(crthip_ctx *c, int on) {
 extern "C" int crthip_ctx_set_single_stream(crthip_ctx *c, int on) {
 	if(!c) return fail(CRTHIP_E_ARGUMENT);
 	c->single_stream = on != 0;
-	// many batches in flight: kernels wait for LDS to come free, and a request of 41 KB finds room long before one of 91 KB does - the
-	// normals kernel without its face-normal array takes twice as long alone (79 vs 39 us per C4 batch) and the pipelined rate is 10 % higher
+	// many batches in flight: kernels wait for LDS to come free, and a request of 29 KB finds room long before one of 78 KB does - the
+	// normals kernel with its face normals in an L2-resident scratch array instead of LDS is slower alone (38 vs 34 us per C4 batch) and
+	// the pipelined rate higher (round 2, 41 against 91 KB: +10 %)
 	if(!c->dbg.has_normal_fn_max) c->exp_normal_fn_max = on ? 0u : NORMAL_FN_LDS_MAX;
 	return CRTHIP_OK;
 }

@@ -30,7 +30,7 @@ struct TunStream {
 	uint32_t nchunks;
 	uint32_t chunk_codes;          // codewords per chunk (= per K-TUN workgroup), a multiple of 256*cpl
 	uint32_t cpl;                  // staged decode: codewords per lane per step (8, 4, 2 or 1)
-	uint32_t dict;                 // k_tun_stream_shared: TunTable slot of the dictionary this stream shares
+	uint32_t dict;                 // k_tun_stream_grouped: TunTable slot of the dictionary this stream decodes from
 	uint32_t pad_;
 };
 

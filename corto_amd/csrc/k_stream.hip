@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 // Here a stream is ONE wave's: lane l takes logs l, l + 64, ... (every load and store of a round is 64 consecutive elements), a round's
 // bit offsets are one DPP scan, the cursor is carried in a scalar - and the streams in front of it in the bit block (one per
 // component, component-major: cstream.h:300-317) are simply added up again from their logs (a few KB), so nobody waits for anybody:
-// no state words, no atomics.  A tenth of the waves, a sixth of the instructions.
+// no state words, no atomics.  A tenth of the waves, a quarter of the wave-cycles (the instruction count is the same).
 constexpr uint32_t UW_R = 4;                                                // rounds of 64 logs per block: their loads in flight together
 __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;

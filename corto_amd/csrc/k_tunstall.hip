@@ -245,32 +245,8 @@ __global__ __launch_bounds__(64) void k_tun_stream(const TunStream *__restrict__
 
 // K-STREAM, shared dictionaries: the streams of a batch repeat one another's probability tables - an alphabet of two symbols has
 // ~127 possible tables - and the dictionary is a function of the table alone, so the planner (batch.cpp) has every DISTINCT table
-// built once (k_tun_tables, into its TunTable in HBM) and each stream's wave only loads it: 768 bytes of offsets / lengths and the
-// `used` bytes of words, from L2.  10 KB of LDS for ~8 us instead of 16 KB for ~37.
-__global__ __launch_bounds__(64) void k_tun_stream_shared(const TunStream *__restrict__ streams, uint32_t nstreams, const TunTable *__restrict__ tables) {
-	const uint32_t s = blockIdx.x;
-	if(s >= nstreams) return;
-	const TunStream st = streams[s];
-	__shared__ uint16_t loff[256];
-	__shared__ uint8_t llen[256];
-	__shared__ __attribute__((aligned(16))) uint8_t words[TUN_TABLE_BYTES];
-	const TunTable &T = tables[st.dict];
-	const uint32_t lane = threadIdx.x;
-	{	// offsets | lengths (48 16-byte vectors, contiguous in the TunTable) and the first KiB of words: both loads issued before the first
-		// wait, the table's `used` read beside them; longer dictionaries loop on
-		CRT_GLOBAL const u32x4_t *o4 = (CRT_GLOBAL const u32x4_t *)as_global(T.off);
-		CRT_GLOBAL const u32x4_t *w4 = (CRT_GLOBAL const u32x4_t *)as_global(T.bytes);
-		u32x4_t hv = o4[lane < 48 ? lane : 47u], wv = w4[lane];
-		asm volatile("" : "+v"(hv), "+v"(wv));
-		if(lane < 32) ((CRT_LDS u32x4_t *)as_lds(loff))[lane] = hv;
-		else if(lane < 48) ((CRT_LDS u32x4_t *)as_lds(llen))[lane - 32] = hv;
-		((CRT_LDS u32x4_t *)as_lds(words))[lane] = wv;
-		const uint32_t nv = (min(T.used, TUN_TABLE_BYTES) + 15u) >> 4;
-		for(uint32_t i = lane + 64; i < nv; i += 64) ((CRT_LDS u32x4_t *)as_lds(words))[i] = w4[i];
-	}
-	__syncthreads();
-	tun_stream_decode(st, loff, llen, words);
-}
+// built once (k_tun_tables, into its TunTable in HBM) and the streams only load it: 768 bytes of offsets / lengths and the `used` bytes
+// of words, from L2 (round 2 did that with one wave per stream, k_tun_stream_shared; round 3 by groups of one dictionary:)
 
 // ... and the streams that share a dictionary share its copy in LDS too (round 3): the planner sorts a launch's streams by dictionary
 // and hands groups of up to TUN_GROUP_MAX of them, all of ONE dictionary, to one workgroup of four waves - the dictionary is loaded

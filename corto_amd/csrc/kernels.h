@@ -9,7 +9,6 @@ namespace corto_hip {
 // k_tunstall.hip
 __global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables, uint64_t *lookback_state, uint32_t lookback_words);   // lookback_state: null, or the chunk state words to clear
 __global__ void k_tun_stream(const TunStream *streams, uint32_t nstreams);   // short streams: dictionary + decode by one wave, the dictionary never leaves LDS
-__global__ void k_tun_stream_shared(const TunStream *streams, uint32_t nstreams, const TunTable *tables);   // ... decode from a dictionary another wave built (k_tun_tables): streams of a batch that carry the same probability table
 __global__ void k_tun_stream_grouped(const TunStream *streams, const uint32_t *ids, const TunGroup *groups, uint32_t ngroups, const TunTable *tables);   // ... streams of ONE dictionary, up to TUN_GROUP_MAX per workgroup, from one copy of it in LDS
 __global__ void k_tun_stream_scan(const TunStream *streams, uint32_t nstreams, uint64_t *chunk_out);   // one stream's quarter sums -> its quarter offsets (one workgroup per stream)
 __global__ void k_tun_chunk_sums(const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,

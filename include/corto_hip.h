@@ -126,7 +126,7 @@ void crthip_ctx_destroy(crthip_ctx *ctx);
  * on the other, joined before the delta stage): the shortest latency for one batch.  With many contexts on one GPU the streams
  * outnumber the hardware queues ($GPU_MAX_HW_QUEUES, ROCm default 4) and streams that share a queue serialise each other's kernels:
  * from about queues/2 contexts up, one stream per context is faster (12 contexts, 16 queues: +15 %; crthip_pool chooses by itself).
- * The same switch selects the LDS-lean layout of the normals kernel (41 KB instead of 91 KB per blob: slower alone, but with many
+ * The same switch selects the LDS-lean layout of the normals kernel (29 KB instead of 78 KB per blob: slower alone, but with many
  * batches in flight a kernel's wait for LDS is what its latency is made of: +10 %). */
 int crthip_ctx_set_single_stream(crthip_ctx *ctx, int on);
 /* Blobs that already sit in ONE pinned host buffer (hipHostMalloc / hipHostRegister / torch pin_memory), laid out as
