@@ -531,8 +531,8 @@ def main():
     barrier()
     # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
-    # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: one region.
-    R = 1 if args.steps >= 100 else max(5, -(-500 // args.steps) | 1)      # (an odd number of regions, ~500 steps in all: round 3 - five regions' median still moved +-8 % run to run)
+    # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: five regions (one 480-step region that meets a multi-ms stall reads 25 % low).
+    R = 5 if args.steps >= 100 else max(5, -(-500 // args.steps) | 1)      # (an odd number of regions, ~500 steps in all: round 3 - five regions' median still moved +-8 % run to run)
     rep, stamps = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
     barrier()
     kk = args.steps * nloc
