@@ -174,6 +174,44 @@ def test_host_blobs_upload_is_not_waited_for_and_packed_pinned_blobs_go_up_in_pl
     sc.close(); c.close()
 
 
+@pytest.mark.parametrize("nu,nv", [(127, 63), (128, 63), (128, 64), (129, 64), (180, 90), (181, 90)])
+def test_bit_unpack_kernel_choice_around_the_threshold(ctx, nu, nv):
+    """K-BIT picks its kernel per bit block (UNPACK_WAVE_MAX_LOGS = 16 384 logs: one wave per stream below, chunks with look-back above):
+    meshes whose uv block (two logs a vertex) and position block (one) sit just under, on and just over it - one blob then has blocks of
+    both kinds - against the oracle"""
+    from corto_amd import synth
+    m = synth.bumpy_sphere(nu, nv, seed=nu + nv)
+    blob = ca.encode(m, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
+    r = oc.decode(blob, color_components=4)
+    assert 8000 < r["nvert"] < 17000, r["nvert"]
+    b = run_batch(ctx, [blob], color_components=4)
+    assert_same(b.host_outputs(0), r, KEYS, "%dx%d (%d vertices)" % (nu, nv, r["nvert"]))
+    b.close()
+
+
+def test_pool_takes_packed_pinned_items_in_place(c5_blobs):
+    """crthip_pool_set_packed_host_blobs: items whose blobs are views of one pinned buffer in arena layout are uploaded straight from it
+    (no device arena, no gathering); every context's last outputs against the oracle, poison behind the arrays"""
+    items = [c5_blobs[100:148], c5_blobs[700:748]]
+    pins = [ca.pinned_host_arena(it) for it in items]
+    pool = ca.Pool([0], threads=2, depth=2)
+    pool.set_packed_host_blobs(True)
+    rep, _ = pool.run([v for _, v in pins], steps=40, warmup=4, arenas=None)
+    assert rep.failed_blobs == 0 and rep.poisoned_lanes == pool.lanes
+    for lane in range(pool.lanes):
+        it, _slot = pool.lane_item(lane)
+        for i in (0, 17, 47):
+            ref = oc.decode(items[it][i])
+            for k, dt, w in (("position", np.float32, 3), ("uv", np.float32, 2), ("normal", np.float32, 3), ("index", np.uint32, 3)):
+                cnt = (ref["nface"] if k == "index" else ref["nvert"]) * w
+                assert pool.lane_read(lane, i, k, dt, cnt).tobytes() == ref[k].tobytes(), (lane, i, k)
+        assert (pool.lane_read(lane, 0, "#tail", np.uint8, 256) == 0xA5).all()
+    pool.set_packed_host_blobs(False)
+    rep, _ = pool.run(items, steps=16, warmup=2, arenas=None)      # ... and the same pool back on scattered blobs
+    assert rep.failed_blobs == 0
+    pool.close()
+
+
 def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
     table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_grouped); $CORTO_TUN_SHARE=0
