@@ -618,7 +618,13 @@ def upload_arena(blobs: Sequence[np.ndarray], device: int = 0):
 def pinned_host_arena(blobs: Sequence[np.ndarray]):
     """The blobs back to back (crthip_arena_layout) in ONE pinned host buffer: returns (the pinned torch tensor - keep it alive -, the
     list of numpy views of the blobs inside it).  Handed to a context / pool with set_packed_host_blobs(True), the views are uploaded
-    with one DMA copy straight from the buffer."""
+    with one DMA copy straight from the buffer.
+
+    REUSE HAZARD: the copy is only enqueued when a batch is created / reset - the library neither snapshots the buffer nor waits for the
+    copy.  The buffer must stay alive AND UNCHANGED until the batch that reads it has been synced (Batch.sync / the pool run's return);
+    writing the next batch's blobs into the same buffer before that corrupts the decode in flight silently.  Rotate as many buffers as
+    there are batches in flight.  $CORTO_HIP_CHECK_PINNED=1 makes the library verify (hipPointerGetAttributes) that a buffer handed over
+    this way really is pinned host memory and refuse it (CRTHIP_E_ARGUMENT) otherwise."""
     import torch
     offs, total = arena_layout([len(b) for b in blobs])
     pin = torch.zeros(max(total, 16), dtype=torch.uint8).pin_memory()

@@ -247,6 +247,7 @@ struct crthip_ctx {
 	std::vector<uint32_t> dict_slots, dict_used, dict_ids, dict_count;
 	bool delta_wide = false;                          // K-DELTA keeps 32-bit values in LDS: $CORTO_DELTA_WIDE=1, or learnt from a batch whose 16-bit relative values overflowed
 	uint32_t delta_calm = 0, delta_patience = 256;
+	bool delta_just_narrowed = false;                  // the narrow layout is on trial again after a wide spell (an overflow now doubles the patience)
 };
 
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
@@ -299,10 +300,11 @@ static int harvest(crthip_ctx *ctx) {
 		for(size_t i = 0; i < n; i++) b->stats.delta_redone += (uint64_t)(hs[2*n + 2*i] != 0);
 		if(b->stats.delta_redone) {
 			ctx->delta_wide = true;
-			if(ctx->delta_calm == 0 && ctx->delta_patience < (1u << 20)) ctx->delta_patience *= 2;   // overflowed right after narrowing again
+			if(ctx->delta_just_narrowed && ctx->delta_patience < (1u << 20)) ctx->delta_patience *= 2;   // overflowed right after narrowing again (never on a context's first overflow)
 			ctx->delta_calm = 0;
-		} else ctx->delta_calm = 1;                                          // (narrow and fine)
-	} else if(!ctx->dbg.delta_wide && ++ctx->delta_calm >= ctx->delta_patience) { ctx->delta_wide = false; ctx->delta_calm = 0; }
+		}
+		ctx->delta_just_narrowed = false;                                   // (narrow and fine, or wide from here on)
+	} else if(!ctx->dbg.delta_wide && ++ctx->delta_calm >= ctx->delta_patience) { ctx->delta_wide = false; ctx->delta_calm = 0; ctx->delta_just_narrowed = true; }
 	// more than one blob in twenty redone on the HBM front (5x slower): four times the edge slots from the next batch on;
 	// a long run without any: try half again, and be more patient the next time that turns out to be too little
 	if(b->stats.topology_fallbacks*20 > n) {
@@ -448,6 +450,13 @@ static int batch_fill(crthip_ctx *ctx, crthip_batch *b, uint32_t nblobs, const u
 		for(uint32_t i = 0; in_place && i < nblobs; i++) in_place = blobs[i] == blobs[0] + b->blobs[i].arena_off;
 		if(in_place) {
 			const uint64_t bytes = b->blobs[nblobs - 1].arena_off + lens[nblobs - 1];
+			// the copy below reads the caller's buffer whenever the DMA engine gets to it: nothing here snapshots it or waits (corto_hip.h: the
+			// caller keeps it alive and unchanged until the batch is synced).  A pageable buffer would still work (HIP stages it), a pinned one
+			// is what the switch promises: on request, check
+			if(ctx->dbg.check_pinned) {
+				hipPointerAttribute_t pa;
+				if(hipPointerGetAttributes(&pa, blobs[0]) != hipSuccess || pa.type != hipMemoryTypeHost) { (void)hipGetLastError(); return fail(CRTHIP_E_ARGUMENT, "packed host blobs: the buffer is not pinned host memory ($CORTO_HIP_CHECK_PINNED)"); }
+			}
 			if(hipMemcpyAsync(b->own_arena.p, blobs[0], bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
 		} else {
 		if(ctx->arena_upload_pending) {                                      // (a batch that was created and not decoded yet: its upload has to be through before the image is reused)
@@ -1383,16 +1392,23 @@ extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const ch
 // pinned landing zone live in the context: in the steady state a call is one upload of the blobs, one descriptor upload, the kernels,
 // and ONE download of all outputs - no allocation, no per-attribute copies.  Serialised per context (host_mutex).
 // A blob the walk rejects fails alone: the others are decoded without it.
+// bytes per component of a generic attribute's caller buffer: upstream decodes in place as int32 whatever the format and DOUBLE widens
+// in place (include/corto/vertex_attribute.h:184-228), so every format's buffer is nvert*N*4 bytes but DOUBLE's
+static inline size_t generic_work_bytes(uint32_t format) { return format == CRTHIP_FMT_DOUBLE ? 8u : 4u; }
+
 namespace corto_hip {
 int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy_out) {
 	if(!ctx || !reqs || n == 0) return fail(CRTHIP_E_ARGUMENT);
 	std::lock_guard<std::mutex> lock(ctx->host_mutex);
-	HIP_TRY(hipSetDevice(ctx->device));
+	// whatever way this call ends, no request may be left saying "OK, nothing to copy": a request's status is CRTHIP_OK only once its
+	// blob has been through the kernels (the facade's combiner publishes these words to other threads, decoder_facade.cpp)
+	auto fail_all = [&](int code) { for(uint32_t i = 0; i < n; i++) if(reqs[i].status == CRTHIP_OK) { reqs[i].status = code; reqs[i].nout = 0; } return code; };
+	for(uint32_t i = 0; i < n; i++) { reqs[i].status = CRTHIP_OK; reqs[i].nout = 0; }
+	if(hipSetDevice(ctx->device) != hipSuccess) return fail_all(fail(CRTHIP_E_DEVICE, "hipSetDevice"));
 	// the blobs the walk accepts (a malformed one must not take its neighbours down)
 	std::vector<const uint8_t *> blobs; std::vector<uint32_t> lens; std::vector<uint32_t> who;
 	for(uint32_t i = 0; i < n; i++) {
 		HostDecodeReq &r = reqs[i];
-		r.status = CRTHIP_OK; r.nout = 0;
 		if(!r.blob || r.len > 0xFFFFFFFFull) { r.status = r.blob ? CRTHIP_E_LIMIT : CRTHIP_E_ARGUMENT; continue; }
 		if(n > 1) { BlobLayout L; const int e = walk_blob(r.blob, r.len, L); if(e) { r.status = fail(e); continue; } }
 		blobs.push_back(r.blob); lens.push_back((uint32_t)r.len); who.push_back(i);
@@ -1402,10 +1418,10 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 	int err;
 	if(!ctx->host_batch) err = crthip_batch_create(ctx, m, blobs.data(), lens.data(), nullptr, &ctx->host_batch);
 	else err = crthip_batch_reset(ctx->host_batch, m, blobs.data(), lens.data(), nullptr);
-	if(err) { for(uint32_t k = 0; k < m; k++) reqs[who[k]].status = err; return err; }
+	if(err) return fail_all(err);
 	crthip_batch *b = ctx->host_batch;
 	// outputs of every blob back to back in one device block (16-byte aligned pieces)
-	std::vector<crthip_attr_binding> dev; std::vector<void *> dindex(m, nullptr); std::vector<uint32_t> ifmt(m, CRTHIP_FMT_UINT32);
+	std::vector<crthip_attr_binding> dev; std::vector<size_t> dev_first(m, 0); std::vector<void *> dindex(m, nullptr); std::vector<uint32_t> ifmt(m, CRTHIP_FMT_UINT32);
 	struct Piece { uint32_t req, slot; size_t off, bytes; void *host; };
 	std::vector<Piece> pieces;
 	size_t total = 0;
@@ -1414,6 +1430,7 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 		const BlobLayout &L = b->blobs[k].L;
 		const uint32_t nvert = L.h.nvert, nface = L.h.nface;
 		const size_t na = L.h.attrs.size();
+		dev_first[k] = dev.size();
 		for(size_t a = 0; a < na; a++) {
 			// attrs == NULL: nothing bound (an index-only decode); host buffers have upstream's packed layouts - a stride is refused, not ignored
 			crthip_attr_binding d;
@@ -1425,7 +1442,7 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 				size_t bytes;
 				if(A.codec == CRTHIP_CODEC_NORMAL) bytes = (size_t)nvert*3*(d.format == CRTHIP_FMT_INT16 ? 2 : 4);
 				else if(A.codec == CRTHIP_CODEC_COLOR) bytes = (size_t)nvert*(d.out_components ? d.out_components : 4);
-				else bytes = (size_t)nvert*A.N*4;
+				else bytes = (size_t)nvert*A.N*generic_work_bytes(d.format);   // (the decode works in int32 / int64 records whatever the output format: DESIGN.md 1)
 				pieces.push_back(Piece{who[k], (uint32_t)a, total, bytes, d.buffer});
 				d.buffer = (void *)(uintptr_t)(total + 1);                    // (offset + 1: rebased below, once the block is there)
 				total += (bytes + 15) & ~(size_t)15;
@@ -1439,23 +1456,37 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 			total += (bytes + 15) & ~(size_t)15;
 		}
 	}
-	if(ctx->host_out.reserve(total + 16) != CRTHIP_OK || ctx->host_pin.reserve(total + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
+	if(ctx->host_out.reserve(total + 16) != CRTHIP_OK || ctx->host_pin.reserve(total + 16) != CRTHIP_OK) return fail_all(fail(CRTHIP_E_NOMEM));
 	uint8_t *dbase = (uint8_t *)ctx->host_out.p, *hbase = (uint8_t *)ctx->host_pin.p;
 	for(auto &d : dev) if(d.buffer) d.buffer = dbase + ((uintptr_t)d.buffer - 1);
 	for(auto &p : dindex) if(p) p = dbase + ((uintptr_t)p - 1);
-	err = crthip_batch_bind_all(b, dev.data(), dindex.data(), ifmt.data());
+	// bound blob by blob: a binding the device path refuses (a format, an alignment) fails ITS blob - which is then decoded with nothing
+	// bound - and nobody else's (upstream's Decoder objects share nothing, src/decoder.cpp:126-196)
+	err = CRTHIP_OK;
+	for(uint32_t k = 0; k < m && !err; k++) {
+		HostDecodeReq &r = reqs[who[k]];
+		const size_t na = b->blobs[k].L.h.attrs.size();
+		int e = r.status != CRTHIP_OK ? r.status : crthip_batch_bind(b, k, na ? dev.data() + dev_first[k] : nullptr, dindex[k], ifmt[k]);
+		if(e) {
+			if(r.status == CRTHIP_OK) r.status = e;
+			for(size_t a = 0; a < na; a++) dev[dev_first[k] + a].buffer = nullptr;
+			e = crthip_batch_bind(b, k, na ? dev.data() + dev_first[k] : nullptr, nullptr, CRTHIP_FMT_UINT32);
+			if(e) err = e;                                                 // (cannot happen: nothing is bound)
+		}
+	}
 	if(!err) err = crthip_batch_decode(b);
 	if(!err && total && hipMemcpyAsync(hbase, dbase, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
 	std::vector<int32_t> st(m, 0);
 	const int serr = crthip_batch_sync(b, st.data());      // waits for the copy too (same stream); keeps the context consistent on error
-	(void)serr;
-	for(uint32_t k = 0; k < m; k++) { HostDecodeReq &r = reqs[who[k]]; if(err) r.status = err; else if(r.status == CRTHIP_OK) r.status = st[k]; }
+	if(!err && (serr == CRTHIP_E_DEVICE || serr == CRTHIP_E_NOMEM)) err = serr;
+	for(uint32_t k = 0; k < m; k++) { HostDecodeReq &r = reqs[who[k]]; if(r.status != CRTHIP_OK) continue; r.status = err ? err : st[k]; }
 	for(const Piece &p : pieces) {
 		HostDecodeReq &r = reqs[p.req];
 		if(r.status != CRTHIP_OK) continue;
 		if(copy_out) memcpy(p.host, hbase + p.off, p.bytes);
 		else if(r.nout < CRTHIP_MAX_ATTRS + 1) { r.out_src[r.nout] = hbase + p.off; r.out_dst[r.nout] = p.host; r.out_bytes[r.nout] = p.bytes; r.nout++; }
 	}
+	if(err) return err;
 	for(uint32_t i = 0; i < n; i++) if(reqs[i].status) return reqs[i].status;            // (the first failing blob's code - its message is the thread's last error; every status is in its request)
 	return CRTHIP_OK;
 }

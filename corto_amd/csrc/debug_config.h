@@ -21,6 +21,7 @@ struct DebugConfig {
 	                                // the streams in groups of one dictionary; 2: the same two kernels but one dictionary PER STREAM, whatever repeats (what a
 	                                // batch of unrelated meshes looks like); 0: dictionary and decode by one wave per stream (rounds 1-2); 1: two kernels always
 	int delta_wide = 0;             // $CORTO_DELTA_WIDE=1: K-DELTA keeps 32-bit values in LDS from the start (a context otherwise learns it from its first overflowing batch)
+	bool check_pinned = false;      // $CORTO_HIP_CHECK_PINNED=1: a buffer handed over as a packed pinned arena (crthip_ctx_set_packed_host_blobs) is verified to be pinned host memory
 	// experiments (A/B measurements; all bit-exact)
 	bool tun_two_pass = false;      // $CORTO_TUN_TWO_PASS=1: long streams - one device-wide scan kernel over the chunk sums (round 1)
 	bool tun_single_pass = false;   // $CORTO_TUN_SINGLE_PASS=1: long streams - adding-up and a wait-free look-back inside the decode kernel
@@ -43,6 +44,7 @@ inline DebugConfig debug_config_from_env() {
 		auto on = [](const char *name) { const char *e = getenv(name); return e && e[0] == '1'; };
 		if(const char *e = getenv("CORTO_TUN_SHARE")) if(e[0] >= '0' && e[0] <= '2') c.tun_share = e[0] - '0';
 		c.delta_wide = on("CORTO_DELTA_WIDE");
+		c.check_pinned = on("CORTO_HIP_CHECK_PINNED");
 		c.tun_two_pass = on("CORTO_TUN_TWO_PASS");
 		c.tun_single_pass = on("CORTO_TUN_SINGLE_PASS") && !c.tun_two_pass;
 		c.tun_three = on("CORTO_TUN_THREE_LAUNCHES");

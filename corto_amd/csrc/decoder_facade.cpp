@@ -6,7 +6,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -54,12 +56,14 @@ int pool_limit() {
 	return n < 1 ? 1 : n > 64 ? 64 : n;
 }
 
+void read_settings();
+
 struct Lease {
 	crthip_ctx *ctx = nullptr;
 	uint64_t generation = 0;
 	Lease() {
+		read_settings();
 		std::unique_lock<std::mutex> lock(g_pool.m);
-		if(!g_pool.limit) g_pool.limit = pool_limit();
 		for(;;) {
 			if(!g_pool.idle.empty()) { ctx = g_pool.idle.back(); g_pool.idle.pop_back(); break; }
 			if(g_pool.live < g_pool.limit) {
@@ -119,18 +123,27 @@ void copy_out(const Request &r) {
 	for(uint32_t k = 0; k < r.h.nout; k++) memcpy(r.h.out_dst[k], r.h.out_src[k], r.h.out_bytes[k]);
 }
 
-int combined_decode(Request &r) {
-	std::unique_lock<std::mutex> lock(g_comb.m);
-	if(g_comb.window_us == -1) { const char *e = getenv("CORTO_HIP_COMBINE_US"); g_comb.window_us = e ? atoi(e) : 30; if(g_comb.window_us < 0) g_comb.window_us = -2; }   // (< 0: every caller decodes its own blob)
-	if(!g_pool.limit) g_pool.limit = pool_limit();
-	if(!g_comb.max_leaders) {
+// the pool's size and the combiner's settings: read once, before any thread can race on them (g_pool.limit is read under g_pool.m by
+// Lease and under g_comb.m by the combiner: it must not be written under either alone)
+std::once_flag g_settings_once;
+void read_settings() {
+	std::call_once(g_settings_once, [] {
+		g_pool.limit = pool_limit();
+		const char *e = getenv("CORTO_HIP_COMBINE_US");
+		g_comb.window_us = e ? atoi(e) : 30;
+		if(g_comb.window_us < 0) g_comb.window_us = -2;                    // (< 0: every caller decodes its own blob)
 		// TWO batches in flight (one being planned and copied out while the other's kernels run), however many threads call: what makes the
 		// batches big is that callers queue up behind busy leaders - with a leader per caller (8 contexts) sixteen threads got 97 us a blob,
 		// with two 38 (tests/cpp/facade_threads.cpp).  Combining off: as many as the pool has contexts.
-		const char *e = getenv("CORTO_HIP_LEADERS");
+		e = getenv("CORTO_HIP_LEADERS");
 		const int n = e ? atoi(e) : 2;
 		g_comb.max_leaders = g_comb.window_us < 0 ? g_pool.limit : n < 1 ? 1 : n > g_pool.limit ? g_pool.limit : n;
-	}
+	});
+}
+
+int combined_decode(Request &r) {
+	read_settings();
+	std::unique_lock<std::mutex> lock(g_comb.m);
 	g_comb.callers++;
 	g_comb.q.push_back(&r);
 	for(;;) {
@@ -149,33 +162,54 @@ int combined_decode(Request &r) {
 				lock.lock();
 			}
 			if(r.taken) { g_comb.leaders--; g_comb.cv.notify_all(); continue; }   // another leader took mine while I gathered: follow it
+			// MY request first, wherever it stands in the queue (with 65+ callers queued behind two busy leaders the thread that wakes as the
+			// next leader may sit beyond the first COMBINE_MAX entries: it must never return without its own blob decoded), then the oldest others
 			std::vector<Request *> mine;
-			if(g_comb.window_us < 0) {                                  // combining off: mine alone
-				for(auto it = g_comb.q.begin(); it != g_comb.q.end(); ++it) if(*it == &r) { g_comb.q.erase(it); break; }
-				r.taken = true; mine.push_back(&r);
-			} else
-			for(auto it = g_comb.q.begin(); it != g_comb.q.end() && mine.size() < COMBINE_MAX;) { (*it)->taken = true; mine.push_back(*it); it = g_comb.q.erase(it); }
+			for(auto it = g_comb.q.begin(); it != g_comb.q.end(); ++it) if(*it == &r) { g_comb.q.erase(it); break; }
+			r.taken = true; mine.push_back(&r);
+			if(g_comb.window_us >= 0)                                    // (combining off: mine alone)
+				for(auto it = g_comb.q.begin(); it != g_comb.q.end() && mine.size() < COMBINE_MAX;) { (*it)->taken = true; mine.push_back(*it); it = g_comb.q.erase(it); }
 			lock.unlock();
-			std::atomic<int> pending((int)mine.size() - 1);
-			std::vector<corto_hip::HostDecodeReq> reqs(mine.size());
-			for(size_t k = 0; k < mine.size(); k++) reqs[k] = mine[k]->h;
-			int lease_err = 0;
-			try {
-				Lease lease;                                          // a context of the pool for the duration of this batch
-				(void)corto_hip::decode_host_many(lease.ctx, (uint32_t)reqs.size(), reqs.data(), false);
+			std::atomic<int> pending((int)mine.size() - 1);           // the followers (everyone in `mine` but me) still copying out of the landing zone
+			int batch_err = 0; std::string batch_msg;
+			bool published = false;
+			std::unique_ptr<Lease> lease;                             // a context of the pool for the duration of this batch: given back only when
+			try {                                                     // every follower has copied its outputs out of its landing zone
+				std::vector<corto_hip::HostDecodeReq> reqs(mine.size());
+				for(size_t k = 0; k < mine.size(); k++) reqs[k] = mine[k]->h;
+				lease.reset(new Lease());
+				const int rc = corto_hip::decode_host_many(lease->ctx, (uint32_t)reqs.size(), reqs.data(), false);
 				const std::string msg = crthip_last_error();
+				// a call that failed as a whole (device, memory) must not leave any request looking decoded: every request that still says OK
+				// without having been through the kernels takes the call's code
+				if(rc == CRTHIP_E_DEVICE || rc == CRTHIP_E_NOMEM) for(auto &q : reqs) if(q.status == CRTHIP_OK) { q.status = rc; q.nout = 0; }
 				lock.lock();
 				for(size_t k = 0; k < mine.size(); k++) { mine[k]->h = reqs[k]; mine[k]->pending = &pending; if(reqs[k].status) mine[k]->message = msg; mine[k]->ready = true; }
+				published = true;
 				g_comb.cv.notify_all();
 				lock.unlock();
-				copy_out(r);                                          // mine, while the followers copy theirs
+				if(r.h.status == CRTHIP_OK) copy_out(r);              // mine, while the followers copy theirs
 				while(pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();   // the landing zone is the context's: keep it until they are done
-			} catch(const char *) { lease_err = CRTHIP_E_DEVICE; }
-			lock.lock();
-			if(lease_err) { for(Request *q : mine) if(!q->ready) { q->h.status = lease_err; q->h.nout = 0; q->message = crthip_strerror(lease_err); q->ready = true; } }
+			} catch(const char *m) { batch_err = CRTHIP_E_DEVICE; batch_msg = m ? m : ""; }
+			catch(const std::bad_alloc &) { batch_err = CRTHIP_E_NOMEM; batch_msg = crthip_strerror(CRTHIP_E_NOMEM); }
+			catch(...) { batch_err = CRTHIP_E_DEVICE; batch_msg = "corto_hip: decode failed"; }
+			if(!lock.owns_lock()) lock.lock();
+			if(batch_err && !published) {
+				// nobody has been told anything yet: every request of this batch fails with the batch's error, and nobody copies
+				for(Request *q : mine) { q->h.status = batch_err; q->h.nout = 0; q->pending = nullptr; q->message = batch_msg.empty() ? crthip_strerror(batch_err) : batch_msg; q->ready = true; }
+			} else if(batch_err) {
+				// (an exception behind the publication can only come from my own copy_out / the wait: the followers have their results;
+				// wait for their copies before the landing zone's context goes back)
+				lock.unlock();
+				while(pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+				lock.lock();
+				r.h.status = batch_err; r.message = batch_msg;
+			}
 			g_comb.leaders--;
 			g_comb.callers--;
 			g_comb.cv.notify_all();
+			lock.unlock();
+			lease.reset();
 			return r.h.status;
 		}
 		g_comb.cv.wait(lock);

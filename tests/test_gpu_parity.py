@@ -610,6 +610,18 @@ def test_cpp_decoder_threads(ctx, tmp_path):
         assert out.returncode == 0, (env, out.stderr + out.stdout)
         for i in range(len(names)):
             assert (tmp_path / ("w%d.bin" % i)).read_bytes() == (tmp_path / ("out%d.bin" % i)).read_bytes(), (env, names[i])
+    # 72 threads - more callers queued behind the two leaders than one batch takes (COMBINE_MAX 64): the thread that wakes
+    # as the next leader must decode ITS OWN blob whatever its place in the queue (it used to return "ok" with its buffers untouched)
+    for env in ({}, {"CORTO_HIP_LEADERS": "1"}):
+        out = subprocess.run([exe, "72", "3", str(tmp_path / "x"), *files], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert out.returncode == 0, (env, out.stderr + out.stdout)
+        for i in range(len(names)):
+            assert (tmp_path / ("x%d.bin" % i)).read_bytes() == (tmp_path / ("out%d.bin" % i)).read_bytes(), (env, names[i])
+    # a binding the device path refuses fails ITS caller (on every decode), not the callers co-batched with it
+    out = subprocess.run([exe, "16", "3", str(tmp_path / "y"), *files], capture_output=True, text=True, env=dict(os.environ, FACADE_BAD_BIND_THREAD="5"))
+    assert out.returncode == 0, out.stderr + out.stdout
+    for i in range(len(names)):
+        assert (tmp_path / ("y%d.bin" % i)).read_bytes() == (tmp_path / ("out%d.bin" % i)).read_bytes(), names[i]
     # a blob that cannot be decoded fails alone: its thread gets upstream's exception, the threads decoding beside it their meshes
     bad = load_golden("c4_unit")["crt"].copy()
     probs = int(ca.probe(aligned(bad)).body_offset) + 9 + 4 + 1
