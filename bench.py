@@ -7,8 +7,11 @@
 Workload (config C4 of BASELINE.json): a batch of 256 independent ~4K-triangle .crt blobs
 (2 112 verts / 4 096 tris each; position 14 bit + uv 12 bit + normal 10 bit BORDER + rgba 6/7/6/5)
 = 1 048 576 triangles / 540 672 vertices PER GPU (weak scaling: config C5 = 8 GPUs x 256 blobs).
-A "step" = one pass of the hot path over that batch with the compressed blobs already resident in HBM:
-re-plan (crthip_batch_reset: host walk of every blob) + bind + decode (descriptor upload, all kernels) + sync; outputs stay in HBM.
+A "step" = one pass of the hot path over that batch on SURVEY.md 8d's PRIMARY timed region: the compressed blobs start in pinned HOST memory
+(one buffer per batch, arena layout) and the decoded outputs end in device HBM - upload of the 3.7 MB of .crt bytes over PCIe, re-plan
+(crthip_batch_reset: host walk of every blob) + bind + decode (descriptor upload, all kernels) + sync.  (Rounds 1-3 quoted the rate with the
+compressed inputs already resident in HBM as `value`; VERDICT r3 asked for 8d's primary region instead.  The resident-input rate - no
+PCIe inside the step - is measured in the same run and reported beside it as `resident_inputs`, with its own regions and roofline.)
 Steps run on the library's decode pool (crthip_pool, csrc/pool.cpp): per GPU --host-threads (default 4) native host threads
 each keep --depth (default 4) batches in flight, every batch on its own context (own HIP streams, scratch and output
 block), all threads of all GPUs pulling batches from ONE work queue (an atomic counter) - no collective anywhere.
@@ -525,20 +528,42 @@ def main():
 
     # ---- the timed region (see the module docstring): the pool runs W warm-up steps straight into exactly K timed steps per GPU
     nloc = len(devices)
+    # SURVEY 8d's primary region: every item's blobs in ONE pinned host buffer (arena layout), uploaded over PCIe inside every step
+    # ... allocated (and so first touched and pinned) on a CPU of the GPU's own NUMA node: with eight GPUs on two sockets a buffer on the
+    # far socket's memory is read across the inter-socket link on every step
+    pins = []
+    numa_local_inputs = 0
+    for j, it in enumerate(items):
+        cpus = pool.device_cpus(j % nloc)
+        old_aff = os.sched_getaffinity(0)
+        moved = False
+        if cpus:
+            try:
+                os.sched_setaffinity(0, set(cpus) & old_aff or set(cpus)); moved = True
+            except OSError:
+                pass
+        try:
+            pins.append(ca.pinned_host_arena(it))
+        finally:
+            if moved:
+                os.sched_setaffinity(0, old_aff); numa_local_inputs += 1
+    host_items = [v for _, v in pins]
+    pool.set_packed_host_blobs(True)
     # whatever W is: every context used (scratch pools are allocated on first use) and the GPU at its working clocks before the clock starts
     prewarm_steps = int(os.environ.get("BENCH_PREWARM_STEPS", "0")) or 8 * pool.lanes
-    pool.run(items, steps=prewarm_steps * nloc, warmup=0, arenas=arenas)
+    pool.run(host_items, steps=prewarm_steps * nloc, warmup=0, arenas=None)
     barrier()
     # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
     # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: five regions (one 480-step region that meets a multi-ms stall reads 25 % low).
     R = 5 if args.steps >= 100 else max(5, -(-500 // args.steps) | 1)      # (an odd number of regions, ~500 steps in all: round 3 - five regions' median still moved +-8 % run to run)
-    rep, stamps = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
+    rep, stamps = pool.run(host_items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=None)
     barrier()
     kk = args.steps * nloc
     tt = np.concatenate([[0.0], np.asarray(stamps, dtype=np.float64)])             # completion times of the timed steps, from the last warm-up step's
     regions = [shard.max_over_ranks(float(tt[(j + 1) * kk] - tt[j * kk]), dist, red_dev) for j in range(R)]
     elapsed = float(np.median(regions))
+    elapsed_mean = shard.max_over_ranks(rep.elapsed_s, dist, red_dev) / R          # (all R regions together: a stall anywhere shows here)
     if rep.failed_blobs or rep.first_error:
         raise SystemExit("bench.py: %d blobs failed to decode (first status %d)" % (rep.failed_blobs, rep.first_error))
     if rep.devices_used != nloc:
@@ -577,29 +602,31 @@ def main():
                 d = hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest()
                 assert d == z["%s_sha256_%02d" % (k, i)].tobytes().decode(), ("bit-exact check failed (golden)", i, k)
 
-    # secondary (SURVEY 8d's host-resident variant; never `value`): the same pipelined steps with the compressed blobs starting in HOST
-    # memory, uploaded over PCIe inside every step
+    # beside `value`: the same pipelined steps with the compressed inputs ALREADY RESIDENT in HBM (what rounds 1-3 quoted as `value`): no PCIe
+    # inside the step.  Same R regions of K steps, median reported.
     # (the side legs run 600 steps whatever K is: a 120-step region of sixteen batches in flight lands anywhere within -40 / +5 % of the
     # long-run rate - tools/leg_probe.py - and 600 steps of these take 0.1-0.15 s)
     fh_steps = 600 * nloc
-    pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=None)      # (untimed: every context's pinned image of an arena is allocated on first use)
+    pool.set_packed_host_blobs(False)
+    pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=arenas)
     barrier()
-    fhh_steps = 2000 * nloc       # (the from-host legs run longer: they meet an occasional 7-8 ms stall - tools/fromhost_gaps.py - that a 60 ms leg cannot average out)
+    rep_res, stamps_res = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
+    barrier()
+    tr = np.concatenate([[0.0], np.asarray(stamps_res, dtype=np.float64)])
+    regions_res = [shard.max_over_ranks(float(tr[(j + 1) * kk] - tr[j * kk]), dist, red_dev) for j in range(R)]
+    elapsed_res = float(np.median(regions_res))
+    tris_res = shard.sum_over_ranks(float(rep_res.triangles), dist, red_dev) / R
+    if rep_res.failed_blobs:
+        raise SystemExit("bench.py: resident-input leg: %d failed blobs" % rep_res.failed_blobs)
+    # ... and with the blobs scattered over PAGEABLE host memory (256 separate numpy arrays): the worker thread gathers them into a pinned
+    # image first (3.7 MB of memcpy per step on the host thread)
+    fhh_steps = 2000 * nloc       # (the from-host legs run longer: round 3 met an occasional 7-8 ms stall - tools/fromhost_gaps.py - that a 60 ms leg cannot average out)
+    pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=None)      # (untimed: every feeder's pinned image of an arena is allocated on first use)
+    barrier()
     rep_h, stamps_h = pool.run(items, steps=fhh_steps, warmup=2 * pool.lanes, arenas=None)
     barrier()
     elapsed_h = shard.max_over_ranks(rep_h.elapsed_s, dist, red_dev)
-    # ... and the same with every item's blobs in ONE pinned host buffer, laid out as an arena (crthip_ctx_set_packed_host_blobs): the upload
-    # is one DMA copy straight from the caller's memory, without the library gathering 256 scattered blobs into its own pinned image first
-    pins = [ca.pinned_host_arena(it) for it in items]
     pool.set_packed_host_blobs(True)
-    barrier()
-    rep_hp, stamps_hp = pool.run([v for _, v in pins], steps=fhh_steps, warmup=2 * pool.lanes, arenas=None)
-    barrier()
-    pool.set_packed_host_blobs(False)
-    elapsed_hp = shard.max_over_ranks(rep_hp.elapsed_s, dist, red_dev)
-    tris_hp = shard.sum_over_ranks(float(rep_hp.triangles), dist, red_dev)
-    if rep_hp.failed_blobs:
-        raise SystemExit("bench.py: from-host (packed) leg: %d failed blobs" % rep_hp.failed_blobs)
 
     # sustained: the same pool, the same steps, for at least --sustain seconds in ONE region (steady clocks and thermals; what a 2 ms region cannot show)
     sustained = None
@@ -607,7 +634,7 @@ def main():
         est = max(elapsed / args.steps, 1e-6)
         n_sus = int(min(max(args.sustain / est * 1.3, 200), 400000)) * nloc
         barrier()
-        rep_s, stamps_s = pool.run(items, steps=n_sus, warmup=2 * pool.lanes, arenas=arenas)
+        rep_s, stamps_s = pool.run(host_items, steps=n_sus, warmup=2 * pool.lanes, arenas=None)
         barrier()
         el_s = shard.max_over_ranks(rep_s.elapsed_s, dist, red_dev)
         tris_s = shard.sum_over_ranks(float(rep_s.triangles), dist, red_dev)
@@ -627,7 +654,7 @@ def main():
         sustained = {"seconds": round(el_s, 3), "steps": n_sus // nloc, "mtri_per_s": round(tris_s / el_s / 1e6, 2), "ms_per_step": round(el_s / (n_sus / nloc) * 1e3, 4),
                      "windows": len(per), "best_window_ms_per_step": round(float(min(per)), 4), "median_window_ms_per_step": round(float(np.median(per)), 4),
                      "worst_window_ms_per_step": round(float(max(per)), 4), "host_us_per_step_per_thread": round(float(rep_s.host_us_per_step), 1),
-                     "note": "one timed region of >= %.1f s on the same pool as `value` (same items, inputs resident in HBM), windows of ~0.1 s; outputs poisoned before the last round and checked against the oracle" % args.sustain}
+                     "note": "one timed region of >= %.1f s on the same pool and region as `value` (same items, uploaded from pinned host memory inside every step), windows of ~0.1 s; outputs poisoned before the last round and checked against the oracle" % args.sustain}
 
     # beside `value`: the same pipelined steps with one Tunstall dictionary built PER STREAM ($CORTO_TUN_SHARE=2; read when a context is
     # made, so: a second pool).  By default the streams of a batch that carry the same probability table share one dictionary, and the
@@ -639,9 +666,10 @@ def main():
     os.environ["CORTO_TUN_SHARE"] = "2"            # one dictionary per stream whatever repeats (still two kernels: dictionaries, then decodes)
     pool_ns = ca.Pool(devices, threads=nthreads, depth=depth)
     del os.environ["CORTO_TUN_SHARE"]
-    pool_ns.run(items, steps=4 * pool_ns.lanes, warmup=0, arenas=arenas)
+    pool_ns.set_packed_host_blobs(True)
+    pool_ns.run(host_items, steps=4 * pool_ns.lanes, warmup=0, arenas=None)
     barrier()
-    rep_ns, _ = pool_ns.run(items, steps=fh_steps, warmup=2 * pool_ns.lanes, arenas=arenas)
+    rep_ns, _ = pool_ns.run(host_items, steps=fh_steps, warmup=2 * pool_ns.lanes, arenas=None)
     barrier()
     elapsed_ns = shard.max_over_ranks(rep_ns.elapsed_s, dist, red_dev)
     tris_ns = shard.sum_over_ranks(float(rep_ns.triangles), dist, red_dev)
@@ -654,10 +682,11 @@ def main():
     if rank == 0 and not args.no_other_configs:
         from corto_amd import synth
         iblobs = [ca.encode(synth.bumpy_sphere_flipped(64, 32, seed=i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(NBLOBS)]
-        iarena = [[ca.upload_arena(iblobs, devices[0])]]
+        pin_i, iviews = ca.pinned_host_arena(iblobs)
         pool_i = ca.Pool(devices[:1], threads=nthreads, depth=depth)
-        pool_i.run([iblobs], steps=4 * pool_i.lanes, warmup=0, arenas=iarena)
-        rep_i, st_i = pool_i.run([iblobs], steps=fh_steps // nloc, warmup=2 * pool_i.lanes, arenas=iarena)
+        pool_i.set_packed_host_blobs(True)
+        pool_i.run([iviews], steps=4 * pool_i.lanes, warmup=0, arenas=None)
+        rep_i, st_i = pool_i.run([iviews], steps=fh_steps // nloc, warmup=2 * pool_i.lanes, arenas=None)
         for lane in range(0, pool_i.lanes, 5):                                  # bit-exact spot check against the oracle
             i = 7 * lane + 3
             ref = oc.decode(iblobs[i])
@@ -666,7 +695,7 @@ def main():
                 assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (irregular)", lane, i, k)
         irregular = {"mtri_per_s": round(rep_i.triangles / rep_i.elapsed_s / 1e6, 2), "ms_per_step": round(rep_i.elapsed_s / (fh_steps // nloc) * 1e3, 4),
                      "steps": fh_steps // nloc, "topology_fallbacks": int(rep_i.topology_fallbacks), "failed_blobs": int(rep_i.failed_blobs),
-                     "note": "one GPU; 256 x bumpy_sphere_flipped(64, 32, seed): 2112 verts / 4096 tris each, every quad's diagonal flipped with probability 1/2"}
+                     "note": "one GPU, same timed region as `value` (pinned host -> HBM); 256 x bumpy_sphere_flipped(64, 32, seed): 2112 verts / 4096 tris each, every quad's diagonal flipped with probability 1/2"}
         pool_i.close()
         # `realistic`: everything the headline's best case leaves out, at once - irregular connectivity, one dictionary PER STREAM (no two
         # blobs of unrelated meshes share tables), and the compressed blobs uploaded from host memory inside every step (SURVEY 8d's primary region)
@@ -683,7 +712,6 @@ def main():
             for k, (dt, w) in dts.items():
                 got = pool_r.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
                 assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (realistic)", lane, i, k)
-        pin_r, iviews = ca.pinned_host_arena(iblobs)
         pool_r.set_packed_host_blobs(True)
         rep_rp, _ = pool_r.run([iviews], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
         pool_r.set_packed_host_blobs(False)
@@ -692,10 +720,35 @@ def main():
                      "topology_fallbacks": int(rep_r.topology_fallbacks), "failed_blobs": int(rep_r.failed_blobs), **window_stats(st_r, pool_r.lanes),
                      "h2d_bytes_per_step": int(sum(((len(x) + 15) & ~15) for x in iblobs)),
                      "packed_pinned_mtri_per_s": round(rep_rp.triangles / rep_rp.elapsed_s / 1e6, 2) if not rep_rp.failed_blobs else None,
-                     "note": "one GPU; irregular connectivity (bumpy_sphere_flipped) + $CORTO_TUN_SHARE=2 (one dictionary per stream) + compressed blobs in HOST memory, uploaded "
-                             "over PCIe inside every step; outputs poisoned before the last round, bit-exact spot check against the oracle.  The number to expect from unrelated scanned meshes; `value` is the best case"}
+                     "note": "one GPU; irregular connectivity (bumpy_sphere_flipped) + $CORTO_TUN_SHARE=2 (one dictionary per stream) + compressed blobs scattered over pageable HOST memory, gathered and uploaded "
+                             "over PCIe inside every step (packed_pinned_mtri_per_s: from one pinned buffer, the region of `value`); outputs poisoned before the last round, bit-exact spot check against the oracle.  The number to expect from unrelated scanned meshes; `value` is the best case"}
         pool_r.close()
 
+    # SURVEY 8e's scaling report when N > 1: per-GPU rate, what ONE of the GPUs does alone on the same box right now (same pool shape, the
+    # other GPUs idle: every rank but 0 waits at the barrier), efficiency = value / (N x that), and the host-side cost per step
+    scaling_block = None
+    tri_step = float(sum(ca.probe(x).nface for x in items[0]))
+    if world > 1:
+        import torch as _t
+        mine = _t.zeros(world, dtype=_t.float64, device=red_dev); mine[rank] = float(rep.triangles) / max(rep.elapsed_s, 1e-9) / 1e6
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_gpu = [round(float(x), 2) for x in mine.tolist()]
+    else:
+        per_gpu = [round(c * tri_step / max(rep.elapsed_s, 1e-9) / 1e6, 2) for c in list(rep.steps_per_device)[:nloc]]
+    if n_gpus > 1:
+        alone = None
+        barrier()
+        if rank == 0:
+            pool_1 = ca.Pool(devices[:1], threads=nthreads, depth=depth)
+            pool_1.set_packed_host_blobs(True)
+            pool_1.run(host_items[:1], steps=4 * pool_1.lanes, warmup=0, arenas=None)
+            rep_1, _ = pool_1.run(host_items[:1], steps=max(600, 2 * args.steps), warmup=2 * pool_1.lanes, arenas=None)
+            alone = rep_1.triangles / rep_1.elapsed_s / 1e6
+            pool_1.close()
+        barrier()
+        scaling_block = {"per_gpu_mtri_per_s": per_gpu, "one_gpu_alone_mtri_per_s": round(alone, 2) if alone else None,
+                         "note": "per-GPU rate of the timed steps; one_gpu_alone: GPU 0 with the same pool shape and timed region while the other GPUs idle "
+                                 "(measured behind the main run, the main pool closed); efficiency_vs_1gpu = value / (n_gpus x one_gpu_alone)"}
     tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev) / R     # (per K-step region)
     verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev) / R
     tris_h = shard.sum_over_ranks(float(rep_h.triangles), dist, red_dev)
@@ -723,43 +776,48 @@ def main():
             "mverts_per_s": round(verts_total / elapsed / 1e6, 2),
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "timed_regions": {"count": R, "ms_per_step": [round(e / args.steps * 1e3, 4) for e in regions],
-                              "note": "consecutive regions of exactly K steps each, pipeline full throughout; `value` and `ms_per_step` are the median region's"},
+                              "mean_ms_per_step": round(elapsed_mean / args.steps * 1e3, 4), "median_over_mean": round(elapsed / elapsed_mean, 4),
+                              "note": "consecutive regions of exactly K steps each, pipeline full throughout; `value` and `ms_per_step` are the median region's; "
+                                      "mean_ms_per_step is all R regions together (a stall anywhere shows there)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 integer + f32 normals",
             "data": "synthetic: 256 distinct bumpy-sphere meshes per GPU (seeds 256*g ..), encoded by the repo's byte-identical .crt writer",
             "config": {"workload": "C4: 256 x (2112 verts / 4096 tris), pos14+uv12+normal10(BORDER)+rgba, per GPU; C5 when n_gpus=8",
                        "blobs_per_gpu": NBLOBS, "tris_per_gpu": ntri, "verts_per_gpu": nvert,
-                       "timed_region": "K x [plan(host walk)+bind+kernels+sync] per GPU, compressed inputs resident in HBM, outputs left in HBM; clock from the "
+                       "timed_region": "SURVEY 8d primary: K x [H2D of the batch's .crt bytes from ONE pinned host buffer + plan(host walk)+bind+kernels+sync] per GPU, "
+                                       "outputs left in HBM; clock from the "
                                        "completion of the last of W warm-up steps to the completion of the K-th timed step, pipeline full at both ends "
-                                       "(barrier + device sync before the warm-up and after the drain); K < 100: ~500/K such regions back to back, the median one reported (timed_regions)",
+                                       "(barrier + device sync before the warm-up and after the drain); K < 100: ~500/K such regions back to back, the median one reported (timed_regions); "
+                                       "the rate with the compressed inputs already resident in HBM (rounds 1-3's `value`) is `resident_inputs`",
+                       "h2d_bytes_per_step": int(stats0.arena_bytes), "pcie_GBps": round(stats0.arena_bytes / (ms_step * 1e-3) / 1e9, 2),
                        "pipeline_depth": depth, "host_threads": nthreads, "launch": mode,
                        "parallelism": "blob-sharded x%d, no collective; %s; %d native host threads x %d batches in flight per GPU" % (
                            n_gpus, "one process, one work queue over all GPUs" if world == 1 else "one process per GPU, RCCL only for barrier/max", nthreads, depth)},
             "bit_exact": True, "bit_exact_blobs_checked": checked, "topology_fallbacks": int(rep.topology_fallbacks),
-            "steps_per_device": steps_per_device,
+            "steps_per_device": steps_per_device, "per_gpu_mtri_per_s": per_gpu, "numa_local_input_buffers": numa_local_inputs,
+            "scaling_report": scaling_block,
             "steady_state": window_stats(stamps, pool_lanes),
+            "resident_inputs": {"mtri_per_s": round(tris_res / elapsed_res / 1e6, 2), "mverts_per_s": round(tris_res / elapsed_res / 1e6 * nvert / ntri, 2),
+                                "ms_per_step": round(elapsed_res / args.steps * 1e3, 4), "regions_ms_per_step": [round(e / args.steps * 1e3, 4) for e in regions_res],
+                                "whole_path_GBps": round(whole_path_bytes / (elapsed_res / args.steps) / 1e9, 2),
+                                "whole_path_frac_of_8TBps": round(whole_path_bytes / (elapsed_res / args.steps) / 1e9 / 8000.0, 6),
+                                **window_stats(stamps_res, pool_lanes),
+                                "note": "the same pool and steps with the compressed arena already resident in HBM (no PCIe inside the step): what rounds 1-3 reported as `value`"},
             "tunstall_dictionaries": {"streams": int(stats0.tunstall_streams), "built": int(stats0.tunstall_dictionaries),
                                       "note": "per batch (rebuilt every step): streams of a batch with the same probability table share one dictionary; "
                                               "one generator with 256 seeds repeats tables more than unrelated meshes would - see without_dictionary_sharing"},
             "without_dictionary_sharing": {"mtri_per_s": round(tris_ns / elapsed_ns / 1e6, 2), "ms_per_step": round(elapsed_ns / (fh_steps / nloc) * 1e3, 4), "steps": fh_steps // nloc,
-                                           "note": "same pipelined steps with $CORTO_TUN_SHARE=2: a dictionary is built for EVERY stream, whatever tables repeat (2 304 per batch instead of ~255) - what a batch of unrelated meshes costs"},
+                                           "note": "same pipelined steps and timed region as `value` with $CORTO_TUN_SHARE=2: a dictionary is built for EVERY stream, whatever tables repeat (2 304 per batch instead of ~255) - what a batch of unrelated meshes costs"},
             "irregular_connectivity": irregular,
             "realistic": realistic,
             "sustained": sustained,
             "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool_warning or None,
             "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1), "numa_pinned_devices": int(rep.pinned_devices),
-            "from_host_pipelined": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "mverts_per_s": round(tris_h / elapsed_h / 1e6 * nvert / ntri, 2),
-                                    "ms_per_step": round(elapsed_h / (fhh_steps / nloc) * 1e3, 4), "steps": fhh_steps // nloc,
-                                    **window_stats(stamps_h, pool_lanes),
-                                    "roofline": {"bound": "hbm", "what": "whole path, SURVEY 8d primary region (pinned-host .crt -> HBM outputs)",
-                                                 "algorithmic_bytes_per_step": whole_path_bytes, "achieved": round(whole_path_bytes / (elapsed_h / (fhh_steps / nloc)) / 1e9, 2),
-                                                 "peak": 8000.0, "unit": "GB/s", "frac": round(whole_path_bytes / (elapsed_h / (fhh_steps / nloc)) / 1e9 / 8000.0, 6),
-                                                 "pcie_GBps": round(stats0.arena_bytes / (elapsed_h / (fhh_steps / nloc)) / 1e9, 2)},
-                                    "packed_pinned": {"mtri_per_s": round(tris_hp / elapsed_hp / 1e6, 2), "ms_per_step": round(elapsed_hp / (fhh_steps / nloc) * 1e3, 4),
-                                                      **window_stats(stamps_hp, pool_lanes), "pcie_GBps": round(stats0.arena_bytes / (elapsed_hp / (fhh_steps / nloc)) / 1e9, 2),
-                                                      "note": "the same, the item's blobs laid out as an arena in ONE pinned host buffer (crthip_ctx_set_packed_host_blobs): "
-                                                              "one DMA copy from the caller's memory, no gathering of 256 scattered (pageable) blobs on the host thread first"},
-                                    "note": "same pipelined steps, but every step uploads its %.1f MB of compressed blobs from host memory (PCIe H2D inside the step); "
-                                            "reported beside `value`, never as it" % (stats0.arena_bytes / 1e6)},
+            "host_us": {"per_step_per_thread": round(float(rep.host_us_per_step), 1), "upload_enqueue": round(float(rep.host_upload_us), 1), "plan_walk_bind": round(float(rep.host_plan_us), 1),
+                        "wait_for_a_context": round(float(rep.host_wait_us), 1), "harvest": round(float(rep.host_finish_us), 1)},
+            "scattered_pageable_blobs": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "ms_per_step": round(elapsed_h / (fhh_steps / nloc) * 1e3, 4), "steps": fhh_steps // nloc,
+                                         **window_stats(stamps_h, pool_lanes), "host_us_per_step_per_thread": round(float(rep_h.host_us_per_step), 1),
+                                         "note": "the timed region of `value` with the batch's 256 blobs in 256 separate PAGEABLE host arrays: the worker thread gathers them into "
+                                                 "its pinned image (%.1f MB of memcpy) before the DMA copy" % (stats0.arena_bytes / 1e6)},
             "single_batch": {"ms": round(solo_ms, 4), "mtri_per_s": round(ntri / solo_ms / 1e3, 2), "steps": solo_steps,
                              "note": "one batch at a time on one context (latency); `kernels` and `roofline` are measured in this phase",
                              "host_us": {"create_walk": round(stats0.host_create_us, 1), "plan": round(stats0.host_plan_us, 1),
@@ -771,11 +829,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_note, "sources_sha256": sources_sha256(),
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
-            "whole_path": {"algorithmic_bytes": whole_path_bytes, "GBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9, 2),
-                           "frac_of_8TBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9 / 8000.0, 6)},
+            "whole_path": {"bound": "hbm", "what": "whole path on the timed region of `value` (pinned-host .crt -> HBM outputs)", "algorithmic_bytes": whole_path_bytes,
+                           "GBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": 8000.0, "frac_of_8TBps": round(whole_path_bytes / (ms_step * 1e-3) / 1e9 / 8000.0, 6)},
             "kernels": kernels,
             "hbm_ceiling": hbm_ceiling(torch),
         }
+        if scaling_block and scaling_block["one_gpu_alone_mtri_per_s"]:
+            scaling_block["efficiency_vs_1gpu"] = round(out["value"] / (n_gpus * scaling_block["one_gpu_alone_mtri_per_s"]), 4)
+            scaling_block["host_us_per_step_per_thread"] = out["host_us_per_step_per_thread"]
         if share:
             out["shared_gpu"] = True
         if not args.no_tunstall_scaled:

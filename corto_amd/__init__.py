@@ -86,7 +86,7 @@ class PoolReport(C.Structure):
                 ("failed_blobs", C.c_uint64), ("first_error", C.c_int32), ("devices_used", C.c_uint32),
                 ("steps_per_device", C.c_uint64 * 16), ("topology_fallbacks", C.c_uint64),
                 ("poisoned_lanes", C.c_uint32), ("pinned_devices", C.c_uint32), ("host_us_per_step", C.c_float), ("reserved", C.c_uint32),
-                ("host_wait_us", C.c_float), ("host_finish_us", C.c_float), ("host_plan_us", C.c_float), ("reserved2", C.c_uint32)]
+                ("host_wait_us", C.c_float), ("host_finish_us", C.c_float), ("host_plan_us", C.c_float), ("host_upload_us", C.c_float)]
 
 
 class KernelTimes(C.Structure):
@@ -542,6 +542,17 @@ class Pool:
         self.lanes = int(lib().crthip_pool_lanes(self.handle))
         self.warning = lib().crthip_pool_warning(self.handle).decode()
         self._keep = None
+
+    def device_cpus(self, slot: int) -> List[int]:
+        """host CPUs of pool device `slot`'s NUMA node (what its worker threads are pinned to); [] when sysfs names none"""
+        buf = np.zeros(4096, dtype=np.int32)
+        L = lib()
+        L.crthip_pool_device_cpus.restype = C.c_int64
+        L.crthip_pool_device_cpus.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+        n = int(L.crthip_pool_device_cpus(self.handle, slot, _np_ptr(buf), buf.size))
+        if n < 0:
+            _check(n)
+        return [int(x) for x in buf[:min(n, buf.size)]]
 
     def set_packed_host_blobs(self, on: bool = True):
         """items run without device arenas whose blobs are views of ONE pinned host buffer (pinned_host_arena) go up straight from it"""

@@ -42,8 +42,26 @@ struct Lane {                       // one context = one batch in flight
 	uint64_t step = 0;              // its global step number
 	bool busy = false;
 	bool poisoned = false;          // the output block was filled with POISON on the context's stream right before the step in flight / last executed
+	int upload = -1;                // the feeder slot whose arena the step in flight reads (-1: the item was resident, or the library uploaded it)
 };
 constexpr int POISON = 0xA5;
+
+// Host-resident items (SURVEY.md 8d's primary region: .crt blobs in pinned host memory -> decoded outputs in HBM).  Every worker thread owns
+// a COPY stream and depth + 1 arena buffers in its GPU's HBM: the blobs of the step a thread is about to run go up on the copy stream while
+// the thread still waits for one of its contexts to finish the step before, and the context that takes the step only waits for the upload's
+// event - the 3.7 MB of a C4 batch cross PCIe under other batches' kernels instead of at the head of their own context's stream (round 3:
+// the upload sat in front of the context's kernels and cost a from-host step 15-30 us).  A buffer is reused once the step that read it has
+// been harvested.
+struct Upload {
+	void *dev = nullptr; size_t cap = 0;       // arena in HBM
+	void *pin = nullptr; size_t pin_cap = 0;   // pinned image, for blobs that are scattered over (pageable) host memory
+	hipEvent_t ready = nullptr;                // recorded behind the copy
+	bool in_use = false;                       // being uploaded to, or read by a step in flight
+};
+struct Feeder {                                // one per worker thread
+	hipStream_t copy = nullptr;
+	std::vector<Upload> slots;
+};
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -55,6 +73,9 @@ struct crthip_pool {
 	std::vector<Lane> lanes;        // [device][thread][depth]
 	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
 	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
+	std::vector<Feeder> feeders;    // [device][thread]
+	bool packed_host = false;       // crthip_pool_set_packed_host_blobs: items whose blobs lie in one pinned buffer in arena layout go up from there
+	bool prefetch = true;           // $CORTO_POOL_PREFETCH=0: uploads at the head of the context's own stream, by the library (round 3's path)
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
 	std::mutex m;
@@ -68,6 +89,8 @@ static void destroy_lane(Lane &L) {
 	if(L.out) (void)hipFree(L.out);
 	L.batch = nullptr; L.ctx = nullptr; L.out = nullptr; L.out_cap = 0;
 }
+
+static void destroy_feeders(crthip_pool *p);
 
 extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_t threads_per_device, uint32_t depth, crthip_pool **out) {
 	if(!out || ndevices == 0 || ndevices > 16 || threads_per_device == 0 || depth == 0 || threads_per_device*depth > 64) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
@@ -99,6 +122,15 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 			p->warning = buf;
 			fprintf(stderr, "%s\n", buf);
 		}
+	{ const char *e = getenv("CORTO_POOL_PREFETCH"); p->prefetch = !(e && e[0] == '0'); }
+	p->feeders.resize((size_t)ndevices*threads_per_device);
+	for(size_t f = 0; f < p->feeders.size(); f++) {
+		Feeder &F = p->feeders[f];
+		bool ok = hipSetDevice(p->devices[f/threads_per_device]) == hipSuccess && hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking) == hipSuccess;
+		F.slots.resize(depth + 1);
+		for(Upload &U : F.slots) ok = ok && hipEventCreateWithFlags(&U.ready, hipEventDisableTiming) == hipSuccess;
+		if(!ok) { for(auto &x : p->lanes) destroy_lane(x); destroy_feeders(p); delete p; return ctx_fail(CRTHIP_E_DEVICE, "crthip_pool_create: copy stream / events"); }
+	}
 	// the host CPUs next to each GPU: PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist
 	p->cpus.resize(ndevices);
 	for(uint32_t d = 0; d < ndevices; d++) {
@@ -125,23 +157,85 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 	return CRTHIP_OK;
 }
 
+static void destroy_feeders(crthip_pool *p) {
+	for(size_t f = 0; f < p->feeders.size(); f++) {
+		Feeder &F = p->feeders[f];
+		(void)hipSetDevice(p->devices[f/p->threads_per_device]);
+		if(F.copy) (void)hipStreamSynchronize(F.copy);
+		for(Upload &U : F.slots) {
+			if(U.dev) (void)hipFree(U.dev);
+			if(U.pin) (void)hipHostFree(U.pin);
+			if(U.ready) (void)hipEventDestroy(U.ready);
+		}
+		if(F.copy) (void)hipStreamDestroy(F.copy);
+	}
+	p->feeders.clear();
+}
+
 extern "C" void crthip_pool_destroy(crthip_pool *p) {
 	if(!p) return;
 	for(auto &L : p->lanes) destroy_lane(L);
+	destroy_feeders(p);
 	delete p;
 }
 
 extern "C" uint32_t crthip_pool_lanes(const crthip_pool *p) { return p ? (uint32_t)p->lanes.size() : 0; }
 extern "C" const char *crthip_pool_warning(const crthip_pool *p) { return p ? p->warning.c_str() : ""; }
+extern "C" int64_t crthip_pool_device_cpus(const crthip_pool *p, uint32_t device_slot, int32_t *cpus, size_t cap) {
+	if(!p || device_slot >= p->ndevices) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	const std::vector<int> &c = p->cpus[device_slot];
+	for(size_t i = 0; i < c.size() && i < cap && cpus; i++) cpus[i] = c[i];
+	return (int64_t)c.size();
+}
 extern "C" int crthip_pool_set_packed_host_blobs(crthip_pool *p, int on) {
 	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	p->packed_host = on != 0;
 	for(auto &L : p->lanes) { const int err = crthip_ctx_set_packed_host_blobs(L.ctx, on); if(err) return err; }
 	return CRTHIP_OK;
 }
 
 // plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
-static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id) {
-	const void *arena = it.device_arena ? it.device_arena[L.slot] : nullptr;
+// enqueue the upload of an item's blobs into a free slot of the thread's feeder (on its copy stream, nobody waits); returns the slot or < 0
+static int feeder_upload(crthip_pool *p, Feeder &F, const crthip_pool_item &it, std::vector<uint64_t> &offs, int *slot_out) {
+	int k = -1;
+	for(size_t i = 0; i < F.slots.size(); i++) if(!F.slots[i].in_use) { k = (int)i; break; }
+	if(k < 0) return ctx_fail(CRTHIP_E_ARGUMENT, "pool: no free upload slot");       // (cannot happen: depth + 1 slots, depth steps in flight)
+	Upload &U = F.slots[(size_t)k];
+	offs.resize(it.nblobs);
+	const uint64_t total = crthip_arena_layout(it.nblobs, it.lens, offs.data());
+	if(total + 16 > U.cap) {
+		if(U.dev) (void)hipFree(U.dev);
+		U.dev = nullptr; U.cap = 0;
+		const size_t want = (size_t)(total + total/4 + 4096);
+		if(hipMalloc(&U.dev, want) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
+		U.cap = want;
+	}
+	bool in_place = p->packed_host && it.nblobs > 0;                                 // the caller's buffer IS the arena's image (corto_hip.h)
+	for(uint32_t i = 0; in_place && i < it.nblobs; i++) in_place = it.blobs[i] == it.blobs[0] + offs[i];
+	const void *src;
+	size_t bytes = (size_t)total;
+	if(in_place) { src = it.blobs[0]; bytes = (size_t)(offs[it.nblobs - 1] + it.lens[it.nblobs - 1]); }
+	else {
+		// (the slot's previous upload from this image has completed: its reader was harvested before the slot came free)
+		if(total + 16 > U.pin_cap) {
+			if(U.pin) (void)hipHostFree(U.pin);
+			U.pin = nullptr; U.pin_cap = 0;
+			const size_t want = (size_t)(total + total/4 + 4096);
+			if(hipHostMalloc(&U.pin, want, hipHostMallocDefault) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
+			U.pin_cap = want;
+		}
+		for(uint32_t i = 0; i < it.nblobs; i++) memcpy((uint8_t *)U.pin + offs[i], it.blobs[i], it.lens[i]);
+		src = U.pin;
+	}
+	if(bytes && hipMemcpyAsync(U.dev, src, bytes, hipMemcpyHostToDevice, F.copy) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, "pool: hipMemcpyAsync(H2D)");
+	if(hipEventRecord(U.ready, F.copy) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, "pool: hipEventRecord");
+	U.in_use = true;
+	*slot_out = k;
+	return CRTHIP_OK;
+}
+
+static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id, const void *uploaded = nullptr) {
+	const void *arena = uploaded ? uploaded : it.device_arena ? it.device_arena[L.slot] : nullptr;
 	int err = L.batch ? crthip_batch_reset(L.batch, it.nblobs, it.blobs, it.lens, arena)
 	                  : crthip_batch_create(L.ctx, it.nblobs, it.blobs, it.lens, arena, &L.batch);
 	if(err) return err;
@@ -207,7 +301,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	std::vector<std::atomic<uint64_t>> per_dev(p->ndevices);
 	for(auto &x : per_dev) x = 0;
 	std::atomic<int32_t> first_error{0};
-	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0};
+	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0}, upload_ns{0};
 	// home shard first: pool device d owns the items j with j % ndevices == d (its shard is resident there), and a device without a home
 	// item takes from the others' ("stealing" in a cyclic run: it is the work list that is shared, a faster GPU simply draws more tickets)
 	std::vector<std::vector<uint32_t>> home(p->ndevices);
@@ -227,9 +321,15 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			(void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (a cpuset that forbids them: stay where we are)
 		}
 		Lane *mine = &p->lanes[((size_t)slot*p->threads_per_device + t)*p->depth];
+		Feeder &F = p->feeders[(size_t)slot*p->threads_per_device + t];
+		for(Upload &U : F.slots) U.in_use = false;
+		std::vector<uint64_t> offs;
+		auto tick = [] { return std::chrono::steady_clock::now(); };
+		auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
 		auto finish = [&](Lane &L) -> int {
 			const int rc = crthip_batch_sync(L.batch, L.status.data());
 			L.busy = false;
+			if(L.upload >= 0) { F.slots[(size_t)L.upload].in_use = false; L.upload = -1; }   // its arena has been read
 			const uint64_t c = ++p->completed;                   // completion order
 			if(c <= timed_end) stamps[c] = now_s();
 			uint64_t bad = 0;
@@ -241,10 +341,41 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(rc == CRTHIP_E_DEVICE || rc == CRTHIP_E_NOMEM) return rc;
 			return CRTHIP_OK;
 		};
+		// an item that is not resident on this device goes up on the thread's copy stream; the context that decodes it waits for the event
+		auto needs_upload = [&](uint32_t j) { return p->prefetch && !(items[j].device_arena && items[j].device_arena[slot]); };
+		auto start = [&](Lane &L, uint32_t j, int up, bool poison) -> int {       // plan item j on the lane and enqueue its decode
+			const auto p0 = tick();
+			int e = lane_plan(p, L, items[j], (int64_t)j, up >= 0 ? F.slots[(size_t)up].dev : nullptr);
+			plan_ns += ns_since(p0);
+			if(!e && up >= 0 && hipStreamWaitEvent(corto_hip::ctx_stream(L.ctx), F.slots[(size_t)up].ready, 0) != hipSuccess) e = ctx_fail(CRTHIP_E_DEVICE, "pool: hipStreamWaitEvent");
+			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
+			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
+			L.poisoned = false;
+			if(!e && poison && L.out) {
+				e = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+				if(!e) L.poisoned = true;
+			}
+			if(!e) e = crthip_batch_decode(L.batch);
+			if(!e) { L.busy = true; L.upload = up; }
+			else if(up >= 0) { (void)hipStreamSynchronize(F.copy); F.slots[(size_t)up].in_use = false; }
+			return e;
+		};
 		int err = CRTHIP_OK;
-		auto tick = [] { return std::chrono::steady_clock::now(); };
-		auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
 		for(uint64_t n = 0; !err; n++) {
+			// the ticket first: its blobs cross PCIe while this thread waits for one of its contexts
+			const uint64_t step = p->next.fetch_add(1);
+			if(step >= total) break;
+			uint32_t j;
+			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
+			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
+			int up = -1;
+			if(needs_upload(j)) {
+				const auto u0 = tick();
+				err = feeder_upload(p, F, items[j], offs, &up);
+				const uint64_t ns = ns_since(u0);
+				upload_ns += ns; host_ns += ns;
+				if(err) break;
+			}
 			const auto w0 = tick();
 			// the next lane to refill: a free one, else whichever of the busy ones finishes first (they mostly finish in the order they
 			// were launched, but a thread that waited on the oldest while a younger one was done left that context idle)
@@ -266,40 +397,26 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(L.busy) err = finish(L);
 			finish_ns += ns_since(f0);
 			if(err) break;
-			const uint64_t step = p->next.fetch_add(1);
-			if(step >= total) break;
-			uint32_t j;
-			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
-			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
-			const auto h0 = std::chrono::steady_clock::now();
-			err = lane_plan(p, L, items[j], (int64_t)j);
-			plan_ns += ns_since(h0);
-			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
-			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
-			L.poisoned = false;
-			if(!err && step >= poison_from && L.out) {
-				err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
-				if(!err) L.poisoned = true;
-			}
-			if(!err) err = crthip_batch_decode(L.batch);
-			host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count(); host_steps++;
-			if(!err) { L.busy = true; L.step = step; }
+			const auto h0 = tick();
+			err = start(L, j, up, step >= poison_from);
+			host_ns += ns_since(h0); host_steps++;
+			if(!err) L.step = step;
 		}
+		if(err) (void)hipStreamSynchronize(F.copy);
 		for(uint32_t k = 0; k < p->depth; k++) if(mine[k].busy) { const int e2 = finish(mine[k]); if(!err) err = e2; }
 		// a context whose thread drew none of the last 2 x lanes tickets (descheduled while the others emptied the queue: seen with
 		// 32-blob items) repeats its last step from a poisoned block, behind the timed region: what lane_read returns is then ALWAYS
 		// a poisoned step's output, not only almost always
 		for(uint32_t k = 0; k < p->depth && !err; k++) {
 			Lane &L = mine[k];
-			if(L.item < 0) {                                     // ... and one that drew no ticket at all (a 28-step run on a cold box) decodes its device's first item
-				const uint32_t j = home[slot].empty() ? 0u : home[slot][0];
-				err = lane_plan(p, L, items[j], (int64_t)j);
-				if(err) break;
-			}
-			if(L.poisoned || !L.out) continue;
-			err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
-			if(!err) err = crthip_batch_decode(L.batch);
-			if(!err) { L.busy = true; L.poisoned = true; err = finish(L); }
+			if(L.poisoned && L.item >= 0) continue;
+			if(!L.out && L.item >= 0) continue;
+			// ... and one that drew no ticket at all (a 28-step run on a cold box) decodes its device's first item
+			const uint32_t j = L.item >= 0 ? (uint32_t)L.item : home[slot].empty() ? 0u : home[slot][0];
+			int up = -1;
+			if(needs_upload(j)) err = feeder_upload(p, F, items[j], offs, &up);     // (the arena its last step read may have been reused since)
+			if(!err) err = start(L, j, up, true);
+			if(!err) err = finish(L);
 		}
 		if(err) {
 			std::lock_guard<std::mutex> lock(p->m);
@@ -321,6 +438,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	if(host_steps) {
 		report->host_wait_us = (float)((double)wait_ns/1e3/(double)host_steps); report->host_finish_us = (float)((double)finish_ns/1e3/(double)host_steps);
 		report->host_plan_us = (float)((double)plan_ns/1e3/(double)host_steps);
+		report->host_upload_us = (float)((double)upload_ns/1e3/(double)host_steps);
 	}
 	for(uint32_t d = 0; d < p->ndevices; d++) if(!p->cpus[d].empty()) report->pinned_devices++;
 	if(completion_s) for(uint64_t c = 0; c < steps; c++) completion_s[c] = stamps[warmup + 1 + c] - stamps[warmup];
