@@ -180,7 +180,7 @@ struct Plan {
 	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
 	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job, unpack_wave_ids;   // (unpack_wave_ids: the streams of small bit blocks, one wave each: k_unpack_wave)
 	HostArr<DeltaJob> delta;
-	HostArr<DeltaGroup> delta_groups;                       // blobs whose attributes share one k_delta_wave workgroup
+	HostArr<DeltaGroup> delta_groups;                       // blobs whose attributes share one k_delta_lds16 workgroup
 	HostArr<CloudJob> cloud; HostArr<uint32_t> cloud_chunk_job;
 	HostArr<NormalJob> normal; HostArr<uint32_t> nv_block_job, nv_block_first, nf_block_job, nf_block_first, normal_fused_ids;
 	uint32_t normal_fused_lds = 0;
@@ -191,7 +191,7 @@ struct Plan {
 	uint64_t facen_off = 0, cnt_off = 0, cursor_off = 0, bnd_off = 0, start_off = 0, flag_off = 0, slot_off = 0, adj_off = 0, nscan_partial_off = 0;
 	uint64_t jobs_begin = 0, jobs_bytes = 0;
 	uint32_t est_nvert = 0, est_nface = 0;                // totals over ESTIMATED/BORDER jobs
-	uint32_t delta_wave_lds = 0, delta16_lds = 0, delta16_groups = 0, delta_tree_lds = 0;   // (delta_groups: the k_delta_lds16 groups first, then k_delta_wave's)
+	uint32_t delta16_lds = 0;                              // largest LDS request among the k_delta_lds16 groups
 	bool tun_multi_chunk = false, any_diff_normal = false, any_est_normal = false;
 	uint32_t tun_max_nchunks = 0;
 	uint64_t total = 0;
@@ -203,7 +203,7 @@ struct Plan {
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
 		zero_begin = zero_end = status_off = tables_off = tun_partial_off = unpack_partial_off = cloud_partial_off = 0;
 		facen_off = cnt_off = cursor_off = bnd_off = start_off = flag_off = slot_off = adj_off = nscan_partial_off = 0;
-		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta_wave_lds = 0; delta16_lds = 0; delta16_groups = 0; delta_tree_lds = 0;
+		jobs_begin = jobs_bytes = 0; est_nvert = est_nface = 0; delta16_lds = 0;
 		tun_multi_chunk = any_diff_normal = any_est_normal = false; total = 0; tun_max_nchunks = 0;
 	}
 };
@@ -214,10 +214,11 @@ struct crthip_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;  // attribute streams (Tunstall + bit-unpack) run here while the main stream does topology
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipEvent_t ev_done = nullptr;   // recorded behind a decode's last kernel: what sync / done wait for, so that work a caller queues on the stream BEHIND a decode
+	                                // (crthip_pool: the next batch's upload) does not delay the harvest of this one
 	DebugConfig dbg;                // every environment switch, read once when the context is made (debug_config.h)
-	uint32_t exp_normal_fn_max = NORMAL_FN_LDS_MAX;   // largest LDS request for which K-NRM keeps its face normals in LDS (dbg.normal_fn_max, or by single_stream)
+	uint32_t normal_fn_max = NORMAL_FN_LDS_MAX;       // largest LDS request for which K-NRM keeps its face normals in LDS (0 for a context that is one of many: crthip_ctx_set_single_stream)
 	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams
-	TunLaunch tun_launch() const { return TunLaunch{stream, !dbg.tun_three}; }
 	DeviceBuf scratch;        // symbols, tables, fronts, predictions, job arrays ... (one batch in flight at a time)
 	PinnedBuf staging;        // host image of the job arrays
 	PinnedBuf arena_pin;      // host image of a batch's blobs on their way to the device (batch_fill: one H2D copy, not waited for)
@@ -284,8 +285,8 @@ struct crthip_batch {
 static int harvest(crthip_ctx *ctx) {
 	crthip_batch *b = ctx->in_flight;
 	if(!b) return CRTHIP_OK;
-	if(hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->in_flight = nullptr; return CRTHIP_E_DEVICE; }
-	ctx->arena_upload_pending = false;
+	if(hipEventSynchronize(ctx->ev_done) != hipSuccess) { ctx->in_flight = nullptr; return CRTHIP_E_DEVICE; }
+	ctx->arena_upload_pending = false;                                     // (the library's own upload sits in front of the kernels)
 	const int32_t *hs = (const int32_t *)ctx->status_host.p;
 	const size_t n = b->blobs.size();
 	for(size_t i = 0; i < n; i++) b->status[i] = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
@@ -352,14 +353,13 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
 	   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
 	   hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
+	   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+	   hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { delete c; return fail(CRTHIP_E_DEVICE); }
 	c->dbg = debug_config_from_env();
-	if(c->dbg.has_normal_fn_max) c->exp_normal_fn_max = c->dbg.normal_fn_max;
 	c->delta_wide = c->dbg.delta_wide != 0;
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
-	   hipFuncSetAttribute((const void *)k_delta_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA_WAVE_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_delta_lds16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA16_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_normal_blob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NORMAL_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_enc_tun_parse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_parse_lds(ENC_TRIE_LDS_MAX)) != hipSuccess) {
@@ -377,7 +377,7 @@ extern "C" void crthip_ctx_destroy(crthip_ctx *c) {
 	if(c->host_batch) { crthip_batch *hb = c->host_batch; c->host_batch = nullptr; crthip_batch_destroy(hb); }
 	c->scratch.release(); c->staging.release(); c->arena_pin.release(); c->status_host.release(); c->host_out.release(); c->host_pin.release();
 	(void)hipStreamSynchronize(c->stream2);
-	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
+	(void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_done);
 	(void)hipStreamDestroy(c->stream2);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -401,7 +401,7 @@ extern "C" int crthip_ctx_set_single_stream(crthip_ctx *c, int on) {
 	// many batches in flight: kernels wait for LDS to come free, and a request of 29 KB finds room long before one of 78 KB does - the
 	// normals kernel with its face normals in an L2-resident scratch array instead of LDS is slower alone (38 vs 34 us per C4 batch) and
 	// the pipelined rate higher (round 2, 41 against 91 KB: +10 %)
-	if(!c->dbg.has_normal_fn_max) c->exp_normal_fn_max = on ? 0u : NORMAL_FN_LDS_MAX;
+	c->normal_fn_max = on ? 0u : NORMAL_FN_LDS_MAX;
 	return CRTHIP_OK;
 }
 
@@ -595,24 +595,17 @@ static int32_t f2i_x86_host(float x) {
 } // namespace
 
 
-// launch classes of K-DELTA: values + prediction graph fit LDS, one wave per attribute - 2: as int16 relative to vertex 0 (k_delta_lds16, k_delta.hip),
-// 3: as int32 (k_delta_wave: contexts that met values beyond int16, attributes of more than four components); else the stretch walk over HBM
-// (k_delta_mesh), 0 = large, 1 = small
-static inline uint64_t delta_wave_need(const DeltaJob &d) {           // alone in a workgroup; ~0 wraps to "too big"
-	const uint64_t g = delta_wave_graph_lds(d.nvert), a = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
-	return g == ~0ull || a == ~0ull ? ~0ull : g + a;
-}
-static inline bool delta16_hosts_a(const DeltaJob &d) { return !d.is_u8 && d.N == 3; }
-static inline uint64_t delta16_need(const DeltaJob &d) {
+// launch classes of K-DELTA: 2 - values + prediction graph fit LDS, one wave per attribute (k_delta_lds16, k_delta.hip): as int16 relative to
+// vertex 0, or - `wide`: a context that met values beyond int16 - as int32; else the stretch walk over HBM (k_delta_mesh): 0 = large, 1 = small
+// (meshes beyond LDS, attributes of more than four components)
+static inline bool delta_hosts_a(const DeltaJob &d) { return !d.is_u8 && d.N == 3; }
+static inline uint64_t delta_lds_need(const DeltaJob &d, bool wide) {          // alone in a workgroup; ~0: not eligible
 	if(d.nvert > DELTA16_NVERT_MAX || d.N < 1 || d.N > 4) return ~0ull;
-	return (uint64_t)delta16_vbytes(d.nvert, d.N, d.is_u8 != 0) + delta16_graph_lds(d.nvert, delta16_hosts_a(d));
+	return (uint64_t)delta_vbytes(d.nvert, d.N, d.is_u8 != 0, wide) + delta16_graph_lds(d.nvert, delta_hosts_a(d));
 }
-// 0 / 1: k_delta_mesh (HBM), 2: k_delta_lds16, 3: k_delta_wave, 4: k_delta_tree (v += v[a] alone: pointer jumping; DeltaJob::tree is
-// set by the planner where the context allows it)
 static inline int delta_class(const DeltaJob &d, bool wide) {
-	if(d.tree) return 4;
-	if(!wide && delta16_need(d) <= DELTA16_LDS_MAX) return 2;
-	return delta_wave_need(d) <= DELTA_WAVE_LDS_MAX ? 3 : d.nvert > DELTA_SMALL_NVERT ? 0 : 1;
+	if(delta_lds_need(d, wide) <= DELTA16_LDS_MAX) return 2;
+	return d.nvert > DELTA_SMALL_NVERT ? 0 : 1;
 }
 static bool normal_fused(uint32_t nvert, uint32_t nface) { return nvert <= 32767 && (uint64_t)3*nface <= 65535 && normal_blob_lds(nvert, nface) <= NORMAL_LDS_MAX; }
 
@@ -749,7 +742,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 			if(a.codec != CRTHIP_CODEC_COLOR && a.codec != CRTHIP_CODEC_NORMAL && bd.stride) A.vals = cv.take((uint64_t)L.h.nvert*a.N*4 + 16, 16);
 			if(a.codec == CRTHIP_CODEC_NORMAL) {
 				A.diffs = cv.take((uint64_t)L.h.nvert*8 + 16, 16);
-				if(mesh && L.attrs[k].normal_prediction != 0 && normal_fused(L.h.nvert, L.h.nface) && normal_blob_lds_fn(L.h.nvert, L.h.nface) > ctx->exp_normal_fn_max)
+				if(mesh && L.attrs[k].normal_prediction != 0 && normal_fused(L.h.nvert, L.h.nface) && normal_blob_lds_fn(L.h.nvert, L.h.nface) > ctx->normal_fn_max)
 					A.facen = cv.take((uint64_t)L.h.nface*12 + 16, 16);
 			}
 		}
@@ -805,7 +798,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		TunStream t{};
 		t.src = arena + blob_off + s.payload_off; t.dst = SP(sym_off); t.probs = arena + blob_off + s.probs_off;
 		t.csize = s.csize; t.size = s.size; t.nsym = s.nsym; t.table = (uint32_t)pl.tun.v.size();
-		t.chunk0 = tun_chunks; tun_pick_geometry(t, ctx->dbg.tun_chunk_cap);
+		t.chunk0 = tun_chunks; tun_pick_geometry(t);
 		if(t.nchunks > 1) pl.tun_multi_chunk = true;
 		pl.tun_max_nchunks = std::max(pl.tun_max_nchunks, t.nchunks);
 		for(uint32_t c = 0; c < t.nchunks; c++) pl.tun_chunk_stream.v.push_back((uint32_t)pl.tun.v.size());
@@ -889,7 +882,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 			for(size_t k = 0; k < L.attrs.size(); k++)
 				if(mesh && L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && (L.attrs[k].normal_prediction == 1 || L.attrs[k].normal_prediction == 2)) readers++;
 			pos_ints_needed = readers > 0;
-			pos_by_normal = readers == 1 && !ctx->dbg.no_deq_fold && normal_fused(nvert, nface);
+			pos_by_normal = readers == 1 && normal_fused(nvert, nface);
 		}
 
 		for(size_t k = 0; k < L.attrs.size(); k++) {
@@ -946,13 +939,10 @@ static int build_and_launch_inner(crthip_batch *b) {
 				if(mesh) {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
-					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = ctx->dbg.delta_walk;   // pad[1]: experiments - the flag-driven walk only
+					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = wide;                   // pad[1]: 32-bit records in LDS (k_delta_lds16)
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
 					d.flags = HS(2ull*nblobs + 2ull*i);
-					// EXPERIMENT: v += v[a] alone (no parallelogram) is a tree - pointer jumping in a workgroup of its own (k_delta_tree), whatever
-					// the other attributes of the blob take
-					d.tree = !para && ctx->dbg.delta_tree && N >= 1 && N <= 4 && nvert <= DELTA_TREE_NVERT_MAX && delta_tree_lds(nvert, N, is_u8) <= DELTA_TREE_LDS_MAX;
-					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2 && !ctx->dbg.no_deq_fold) {
+					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2) {
 						if(a.codec == CRTHIP_CODEC_COLOR) {
 							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;
 							for(int c = 0; c < 4; c++) d.qc[c] = as.qc[c];
@@ -990,7 +980,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 							n.fn_scratch = A.facen != ~0ull ? (float *)SP(A.facen) : nullptr;
 							if(pos_by_normal) { n.pos_out = P.bind[pos_k].buffer; n.pos_stride = P.bind[pos_k].stride ? P.bind[pos_k].stride : 12u; n.pos_q = L.h.attrs[pos_k].q; }
 							pl.normal_fused_ids.v.push_back((uint32_t)pl.normal.v.size());
-							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= ctx->exp_normal_fn_max ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
+							pl.normal_fused_lds = std::max(pl.normal_fused_lds, normal_blob_lds_fn(nvert, nface) <= ctx->normal_fn_max ? normal_blob_lds_fn(nvert, nface) : normal_blob_lds(nvert, nface));
 						} else {
 							n.vbase = est_vbase; n.fbase = est_fbase; est_vbase += nvert; est_fbase += nface;
 							pl.any_est_normal = true;
@@ -1058,41 +1048,24 @@ static int build_and_launch_inner(crthip_batch *b) {
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) == 0; });
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 1; });
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 2; });
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 3; });
-	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph: consecutive jobs of one class with
-		// the same prediction array, up to DELTA_GROUP_MAX.  Class 2 groups first (k_delta_lds16), then class 3 (k_delta_wave).
+	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph: consecutive jobs of class 2 with the same
+		// prediction array, up to DELTA_GROUP_MAX
 		size_t j = 0;
 		while(j < pl.delta.v.size() && delta_class(pl.delta.v[j], wide) < 2) j++;
-		const uint32_t gmax_ = ctx->dbg.delta_group ? ctx->dbg.delta_group : DELTA_GROUP_MAX;
 		while(j < pl.delta.v.size()) {
 			const DeltaJob &d0 = pl.delta.v[j];
-			const int cls = delta_class(d0, wide);
-			if(cls == 4) { pl.delta_tree_lds = std::max(pl.delta_tree_lds, delta_tree_lds(d0.nvert, d0.N, d0.is_u8 != 0)); j++; continue; }   // (the tail: a workgroup each)
 			DeltaGroup g{(uint32_t)j, 1};
-			if(cls == 2) {
-				uint64_t vals = delta16_vbytes(d0.nvert, d0.N, d0.is_u8 != 0);
-				bool hosted = delta16_hosts_a(d0);
-				while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
-					const DeltaJob &d = pl.delta.v[j + g.count];
-					if(delta_class(d, wide) != 2 || d.pred != d0.pred || d.nvert != d0.nvert) break;   // (class 4 sits behind every group's candidates)
-					const uint64_t more = delta16_vbytes(d.nvert, d.N, d.is_u8 != 0);
-					const bool h2 = hosted || delta16_hosts_a(d);
-					if(vals + more + delta16_graph_lds(d0.nvert, h2) > DELTA16_LDS_MAX) break;
-					vals += more; hosted = h2; g.count++;
-				}
-				pl.delta16_lds = std::max<uint32_t>(pl.delta16_lds, (uint32_t)(vals + delta16_graph_lds(d0.nvert, hosted)));
-				pl.delta16_groups++;
-			} else {
-				uint64_t lds = delta_wave_need(d0);
-				while(j + g.count < pl.delta.v.size() && g.count < gmax_) {
-					const DeltaJob &d = pl.delta.v[j + g.count];
-					const uint64_t more = delta_wave_attr_lds(d.nvert, d.N, d.is_u8 != 0);
-					if(delta_class(d, wide) != 3 || d.pred != d0.pred || d.nvert != d0.nvert || lds + more > DELTA_WAVE_LDS_MAX) break;
-					lds += more; g.count++;
-				}
-				pl.delta_wave_lds = std::max<uint32_t>(pl.delta_wave_lds, (uint32_t)lds);
+			uint64_t vals = delta_vbytes(d0.nvert, d0.N, d0.is_u8 != 0, wide);
+			bool hosted = delta_hosts_a(d0);
+			while(j + g.count < pl.delta.v.size() && g.count < DELTA_GROUP_MAX) {
+				const DeltaJob &d = pl.delta.v[j + g.count];
+				if(d.pred != d0.pred || d.nvert != d0.nvert) break;
+				const uint64_t more = delta_vbytes(d.nvert, d.N, d.is_u8 != 0, wide);
+				const bool h2 = hosted || delta_hosts_a(d);
+				if(vals + more + delta16_graph_lds(d0.nvert, h2) > DELTA16_LDS_MAX) break;
+				vals += more; hosted = h2; g.count++;
 			}
+			pl.delta16_lds = std::max<uint32_t>(pl.delta16_lds, (uint32_t)(vals + delta16_graph_lds(d0.nvert, hosted)));
 			pl.delta_groups.v.push_back(g);
 			j += g.count;
 		}
@@ -1179,7 +1152,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 				const uint32_t d0 = has_clers ? 0u : clers_dict, d1 = has_attrs ? ndict : clers_dict;
 				uint32_t big = 0;                                  // (an alphabet of more than 64 symbols builds its words in LDS: tun_tables.h)
 				for(uint32_t d = d0; d < d1; d++) if(pl.tun_dict.v[d].nsym > 64) big = TUN_TABLE_BYTES;
-				LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(d1 - d0), dim3(64), big, s, D(pl.tun_dict) + d0, d1 - d0, tables, (uint64_t *)nullptr, 0u); LT.end();
+				LT.begin("tunstall_tables", s); hipLaunchKernelGGL(k_tun_tables, dim3(d1 - d0), dim3(64), big, s, D(pl.tun_dict) + d0, d1 - d0, tables); LT.end();
 				const uint32_t g0 = has_clers ? 0u : pl.clers_groups, g1 = has_attrs ? (uint32_t)pl.tun_groups.v.size() : pl.clers_groups;
 				LT.begin("tunstall_stream", s); hipLaunchKernelGGL(k_tun_stream_grouped, dim3(g1 - g0), dim3(256), 0, s, D(pl.tun), D(pl.tun_group_ids), D(pl.tun_groups) + g0, g1 - g0, tables); LT.end();
 			} else {                                           // dictionary + decode in one kernel
@@ -1193,13 +1166,12 @@ static int build_and_launch_inner(crthip_batch *b) {
 		if(nuw) { LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_wave, dim3(nuw), dim3(64), 0, s, D(pl.unpack), D(pl.unpack_wave_ids), nuw); LT.end(); }
 		if(!unpack_chunks) return;
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
-		if(ctx->dbg.unpack_twice) hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack), D(pl.unpack_chunk_job), unpack_chunks, unpack_partial);
 	};
 	auto topology = [&]() -> int {
 		if(!pl.topo_lds_ids.v.empty() || !pl.topo_big_ids.v.empty()) {
 			LT.begin("topology_lds");
 			if(!pl.topo_big_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_big_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_big_lds, st, D(pl.topo), D(pl.topo_big_ids), nj); }
-			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), std::min(pl.topo_lds + ctx->dbg.lds_pad_topo, TOPO_LDS_MAX), st, D(pl.topo), D(pl.topo_lds_ids), nj); }
+			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds, dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); }
 			LT.end();
 		}
 		if(!pl.topo_glob_ids.v.empty()) {
@@ -1210,16 +1182,14 @@ static int build_and_launch_inner(crthip_batch *b) {
 	};
 	if(pl.tun_multi_chunk) {
 		// long streams (scaled Tunstall runs, very large meshes): chunk offsets need one scan over all chunks; single stream
-		uint64_t *tun_state = tun_partial;                                     // (single pass: the look-back's chunk state words, cleared by K-TAB)
 		uint32_t big = 0;
 		for(auto &t : pl.tun.v) if(t.nsym > 64) big = TUN_TABLE_BYTES;
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), big, st, D(pl.tun), ntun, tables, ctx->dbg.tun_single_pass ? tun_state : (uint64_t *)nullptr, tun_chunks); LT.end();
-		if(!ctx->dbg.tun_single_pass) {
-			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
-			if(ctx->dbg.tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, tun_partial, tun_chunks*4); LT.end(); }
-			else if(pl.tun_max_nchunks > 256) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, D(pl.tun), ntun, tun_partial); LT.end(); }
-		}                                                                          // (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself)
-		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(ctx->tun_launch(), D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, ctx->dbg.tun_single_pass ? 1u : !ctx->dbg.tun_two_pass && pl.tun_max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); LT.end();
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), big, st, D(pl.tun), ntun, tables); LT.end();
+		LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(tun_chunks), dim3(256), 0, st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, 0u); LT.end();
+		// (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself; longer streams: one workgroup per stream scans them)
+		const bool scanned = pl.tun_max_nchunks > 256;
+		if(scanned) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, D(pl.tun), ntun, tun_partial); LT.end(); }
+		LT.begin("tunstall_decode"); if(launch_tun_decode_staged(st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, scanned ? 0u : 1u)) return fail(CRTHIP_E_DEVICE); LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
 		{ int e_ = topology(); if(e_) return e_; }
 		unpack(st);
@@ -1240,17 +1210,14 @@ static int build_and_launch_inner(crthip_batch *b) {
 		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
-		uint32_t ncls[5] = {0, 0, 0, 0, 0};
+		uint32_t ncls[3] = {0, 0, 0};
 		for(auto &d : pl.delta.v) ncls[delta_class(d, wide)]++;
-		const uint32_t ng16 = pl.delta16_groups, ng32 = (uint32_t)pl.delta_groups.v.size() - ng16;
+		const uint32_t ngroups = (uint32_t)pl.delta_groups.v.size();
 		LT.begin("delta_mesh");
 		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
 		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
-		if(ng16 && ctx->dbg.delta_global) hipLaunchKernelGGL(k_delta_global, dim3(ncls[2]), dim3(64), 0, st, D(pl.delta) + ncls[0] + ncls[1], ncls[2]);
-		else if(ng16) hipLaunchKernelGGL(k_delta_lds16, dim3(ng16), dim3(256), std::min(pl.delta16_lds + ctx->dbg.lds_pad_delta, DELTA16_LDS_MAX), st, D(pl.delta), D(pl.delta_groups), ng16);
-		if(ng32) hipLaunchKernelGGL(k_delta_wave, dim3(ng32), dim3(256), pl.delta_wave_lds, st, D(pl.delta), D(pl.delta_groups) + ng16, ng32);
+		if(ngroups) hipLaunchKernelGGL(k_delta_lds16, dim3(ngroups), dim3(256), pl.delta16_lds, st, D(pl.delta), D(pl.delta_groups), ngroups);
 		LT.end();
-		if(ncls[4]) { LT.begin("delta_tree"); hipLaunchKernelGGL(k_delta_tree, dim3(ncls[4]), dim3(256), pl.delta_tree_lds, st, D(pl.delta) + ncls[0] + ncls[1] + ncls[2] + ncls[3], ncls[4]); LT.end(); }
 	}
 	if(cloud_chunks) {
 		LT.begin("cloud_sums"); hipLaunchKernelGGL(k_cloud_sums, dim3(cloud_chunks), dim3(256), 0, st, D(pl.cloud), D(pl.cloud_chunk_job), cloud_chunks, cloud_partial); LT.end();
@@ -1260,7 +1227,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	const uint32_t nvb = (uint32_t)pl.nv_block_job.v.size(), nfb = (uint32_t)pl.nf_block_job.v.size();
 	if(!pl.normal_fused_ids.v.empty()) {
 		const uint32_t nj = (uint32_t)pl.normal_fused_ids.v.size();
-		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), std::min(pl.normal_fused_lds + ctx->dbg.lds_pad_normal, NORMAL_LDS_MAX), st, D(pl.normal), D(pl.normal_fused_ids), nj, pl.normal_fused_lds); LT.end();
+		LT.begin("normal_blob"); hipLaunchKernelGGL(k_normal_blob, dim3(nj), dim3(256), pl.normal_fused_lds, st, D(pl.normal), D(pl.normal_fused_ids), nj, pl.normal_fused_lds); LT.end();
 	}
 	if(pl.any_est_normal) {
 		float *facen = (float *)(base + pl.facen_off);
@@ -1289,6 +1256,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 	if(ndq) { LT.begin("dequantize"); hipLaunchKernelGGL(k_dequant, dim3(ndq), dim3(256), 0, st, D(pl.dequant), D(pl.dequant_block_job), ndq); LT.end(); }
 
 	HIP_TRY(hipGetLastError());                                            // (status: written by the kernels straight into the pinned block)
+	HIP_TRY(hipEventRecord(ctx->ev_done, st));
 
 	// stats
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
@@ -1339,7 +1307,7 @@ extern "C" int crthip_batch_done(crthip_batch *b) {
 	crthip_ctx *ctx = b->ctx;
 	if(ctx->in_flight != b) return 1;                                  // harvested already, or never decoded
 	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
-	const hipError_t e = hipStreamQuery(ctx->stream);
+	const hipError_t e = hipEventQuery(ctx->ev_done);
 	if(e == hipSuccess) return 1;
 	if(e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
 	return fail(CRTHIP_E_DEVICE);
@@ -1477,7 +1445,8 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 	if(!err) err = crthip_batch_decode(b);
 	if(!err && total && hipMemcpyAsync(hbase, dbase, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
 	std::vector<int32_t> st(m, 0);
-	const int serr = crthip_batch_sync(b, st.data());      // waits for the copy too (same stream); keeps the context consistent on error
+	const int serr = crthip_batch_sync(b, st.data());      // (waits for the kernels: the event behind them; keeps the context consistent on error)
+	if(hipStreamSynchronize(ctx->stream) != hipSuccess && !err) err = fail(CRTHIP_E_DEVICE);   // ... and this for the copy behind them
 	if(!err && (serr == CRTHIP_E_DEVICE || serr == CRTHIP_E_NOMEM)) err = serr;
 	for(uint32_t k = 0; k < m; k++) { HostDecodeReq &r = reqs[who[k]]; if(r.status != CRTHIP_OK) continue; r.status = err ? err : st[k]; }
 	for(const Piece &p : pieces) {
@@ -1524,7 +1493,7 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 		if(ns == 0 || csize == 0) return fail(CRTHIP_E_TRUNCATED);
 		TunStream t{};
 		t.src = dblk + 9 + 2*ns; t.dst = dst; t.probs = dblk + 1; t.csize = csize; t.size = size; t.nsym = ns; t.table = (uint32_t)tun.size();
-		t.chunk0 = chunks; tun_pick_geometry(t, ctx->dbg.tun_chunk_cap);
+		t.chunk0 = chunks; tun_pick_geometry(t);
 		if(t.nchunks > 1) multi = true;
 		max_nchunks = std::max(max_nchunks, t.nchunks);
 		for(uint32_t c = 0; c < t.nchunks; c++) chunk_stream.push_back((uint32_t)tun.size());
@@ -1547,19 +1516,18 @@ extern "C" int crthip_tunstall_decode_blocks(crthip_ctx *ctx, uint32_t n, const 
 	Launch LT{ctx};
 	TunStream *dt = (TunStream *)(base + o_tun); uint32_t *dcs = (uint32_t *)(base + o_cs);
 	TunTable *tables = (TunTable *)(base + o_tab); uint64_t *part = (uint64_t *)(base + o_part);
-	uint64_t *state = part;                                                  // (single pass: the chunk state words of the look-back, cleared by K-TAB)
 	const uint32_t ntun = (uint32_t)tun.size();
 	if(ntun) {
 		uint32_t big = 0;
 		for(auto &t : tun) if(t.nsym > 64) big = TUN_TABLE_BYTES;
-		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), big, st, dt, ntun, tables, multi && ctx->dbg.tun_single_pass ? state : (uint64_t *)nullptr, chunks); LT.end();
-		if(multi && !ctx->dbg.tun_single_pass) {
+		LT.begin("tunstall_tables"); hipLaunchKernelGGL(k_tun_tables, dim3(ntun), dim3(64), big, st, dt, ntun, tables); LT.end();
+		const bool scanned = max_nchunks > 256;
+		if(multi) {
 			LT.begin("tunstall_chunk_sums"); hipLaunchKernelGGL(k_tun_chunk_sums, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u); LT.end();
-			if(ctx->dbg.tun_two_pass) { LT.begin("scan"); hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, part, chunks*4); LT.end(); }
-			else if(max_nchunks > 256) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, dt, ntun, part); LT.end(); }
+			if(scanned) { LT.begin("tunstall_stream_scan"); hipLaunchKernelGGL(k_tun_stream_scan, dim3(ntun), dim3(256), 0, st, dt, ntun, part); LT.end(); }
 		}                                                                   // (up to 256 chunks a stream: every decode wave adds up the sums in front of it itself)
 		LT.begin("tunstall_decode");
-		if(multi) { if(launch_tun_decode_staged(ctx->tun_launch(), dt, dcs, chunks, tables, part, ctx->dbg.tun_single_pass ? 1u : !ctx->dbg.tun_two_pass && max_nchunks <= 256 ? 2u : 0u)) return fail(CRTHIP_E_DEVICE); }
+		if(multi) { if(launch_tun_decode_staged(st, dt, dcs, chunks, tables, part, scanned ? 0u : 1u)) return fail(CRTHIP_E_DEVICE); }
 		else hipLaunchKernelGGL(k_tun_decode, dim3(chunks), dim3(256), 0, st, dt, dcs, chunks, tables, part, 0u);
 		LT.end();
 	}

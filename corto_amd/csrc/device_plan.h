@@ -100,8 +100,8 @@ struct DeltaJob {
 	const uint32_t *pred;
 	uint8_t *fired;                // nvert zeroed flags in HBM, used only when values + flags do not fit LDS
 	uint32_t nvert, N;
-	uint8_t parallelogram, is_u8, pad[2];
-	// k_delta_wave can finish the attribute on its way out of LDS (no k_dequant launch, no second trip through HBM):
+	uint8_t parallelogram, is_u8, pad[2];   // pad[1]: k_delta_lds16 keeps 32-bit records in LDS (the whole group says the same)
+	// k_delta_lds16 finishes the attribute on its way out of LDS (no k_dequant launch, no second trip through HBM):
 	uint32_t deq;                  // 0: write the integers back; 1: generic, packed: (float)v*q in place (vertex_attribute.h:190-193);
 	                               // 2: colour: YCC -> RGB x qc into `out` (color_attribute.cpp:76-95)
 	float q;
@@ -109,7 +109,7 @@ struct DeltaJob {
 	void *out;                     // colour destination
 	uint32_t out_components, out_stride;
 	int32_t *flags;                // k_delta_lds16: set to 1 when the attribute's values relative to vertex 0 left int16 and were redone in HBM
-	uint32_t tree, pad2;           // tree: v += v[a] alone, solved by k_delta_tree (pointer jumping) instead of the window kernels
+	uint32_t pad2[2];
 };
 
 // point-cloud running sum, one job per (blob, attribute) (vertex_attribute.h:177-181, normal_attribute.cpp:202-207)

@@ -92,23 +92,66 @@ template <> struct LdsVal<5> {                                // bytes, mod 256 
 	__device__ __forceinline__ void sync() const {}
 };
 
+// ---- the same records with 32-BIT components (round 4: a context that met values beyond int16 - positions quantised to 16+ bits - plans
+// its batches this way; rounds 2-3 kept a second kernel, k_delta_wave, for them).  Records of 4 / 8 / 16 / 16 bytes; absolute values (no
+// base, nothing to check); a three-component record's fourth dword carries the graph's `a`.
+template <int K> struct LdsW;
+template <> struct LdsW<1> {
+	static constexpr int NC = 1; static constexpr bool CHECK = false; typedef uint32_t Raw;
+	CRT_LDS uint32_t *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[1]) { v[0] = (int32_t)w; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[1], uint32_t) const { p[i] = (uint32_t)v[0]; }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return v; }
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsW<2> {
+	static constexpr int NC = 2; static constexpr bool CHECK = false; typedef u32x2 Raw;
+	CRT_LDS u32x2 *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[2]) { v[0] = (int32_t)w.x; v[1] = (int32_t)w.y; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[2], uint32_t) const { p[i] = u32x2{(uint32_t)v[0], (uint32_t)v[1]}; }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return v; }
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsW<3> {                                  // x, y, z, a
+	static constexpr int NC = 3; static constexpr bool CHECK = false; typedef u32x4 Raw;
+	CRT_LDS u32x4 *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[3]) { v[0] = (int32_t)w.x; v[1] = (int32_t)w.y; v[2] = (int32_t)w.z; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[3], uint32_t a) const { p[i] = u32x4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], a}; }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return v; }
+	__device__ __forceinline__ void sync() const {}
+};
+template <> struct LdsW<4> {
+	static constexpr int NC = 4; static constexpr bool CHECK = false; typedef u32x4 Raw;
+	CRT_LDS u32x4 *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[4]) { v[0] = (int32_t)w.x; v[1] = (int32_t)w.y; v[2] = (int32_t)w.z; v[3] = (int32_t)w.w; }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[4], uint32_t) const { p[i] = u32x4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]}; }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return v; }
+	__device__ __forceinline__ void sync() const {}
+};
+
 // ---- values in HBM, as the caller / the bit-unpack left them (the redo path of an attribute whose relative values left int16): any
 // N <= 4, int32 or bytes.  One wave owns the attribute (workgroup-scope accesses: the CU's own cache is coherent for it) and a pass's
 // stores are waited for before the next pass reads.
 template <typename T> struct GlobalVal {
 	static constexpr int NC = 4; static constexpr bool CHECK = false;
 	struct Raw { uint32_t v[4]; };
-	CRT_GLOBAL T *p; uint32_t N;
+	CRT_GLOBAL T *p; uint32_t N;                              // N: components of this run (<= 4)
+	uint32_t stride = 0;                                      // elements from one vertex to the next (0: N); p points at the run's first component
+	__device__ __forceinline__ uint32_t st() const { return stride ? stride : N; }
 	__device__ __forceinline__ Raw raw(uint32_t i) const {
 		Raw r;
 #pragma unroll
-		for(uint32_t q = 0; q < 4; q++) r.v[q] = q < N ? (uint32_t)__hip_atomic_load(p + (size_t)i*N + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+		for(uint32_t q = 0; q < 4; q++) r.v[q] = q < N ? (uint32_t)__hip_atomic_load(p + (size_t)i*st() + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
 		return r;
 	}
 	__device__ __forceinline__ static void unpack(const Raw &w, int32_t (&v)[4]) { v[0] = (int32_t)w.v[0]; v[1] = (int32_t)w.v[1]; v[2] = (int32_t)w.v[2]; v[3] = (int32_t)w.v[3]; }
 	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[4], uint32_t) const {
 #pragma unroll
-		for(uint32_t q = 0; q < 4; q++) if(q < N) __hip_atomic_store(p + (size_t)i*N + q, (T)v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		for(uint32_t q = 0; q < 4; q++) if(q < N) __hip_atomic_store(p + (size_t)i*st() + q, (T)v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 	__device__ __forceinline__ static int32_t wrap(int32_t v) { return (int32_t)(T)v; }
 	__device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -123,8 +166,7 @@ struct GaRef {
 
 constexpr uint32_t GW_CHAINED = 1u << 30, GW_STAYS = 1u << 31, GW_NO_BC = 0x3FFFFFFFu;
 
-// a vertex' graph word and `a`: from LDS (made once by the builder wave), or - k_delta_global, no LDS at all - worked out of the
-// prediction triple in HBM where it is needed
+// a vertex' graph word and `a`, made once by the builder wave and kept in LDS
 __device__ __forceinline__ uint32_t graph_word(uint32_t i, uint32_t a, uint32_t b, uint32_t c) {
 	// well-formed streams always predict from earlier vertices.  A triple that does not: the value stays (vertex 0 is one) - for
 	// every attribute when it is `a`, for parallelogram attributes only when it is b or c (the others never look at them):
@@ -137,13 +179,6 @@ __device__ __forceinline__ uint32_t graph_word(uint32_t i, uint32_t a, uint32_t 
 struct GraphLds {
 	CRT_LDS const uint32_t *gw; GaRef ga;
 	__device__ __forceinline__ void fetch(uint32_t i, uint32_t &W, uint32_t &A) const { W = gw[i]; A = ga.get(i); }
-};
-struct GraphGlobal {
-	CRT_GLOBAL const uint32_t *pred;
-	__device__ __forceinline__ void fetch(uint32_t i, uint32_t &W, uint32_t &A) const {
-		const u32x3 t = *(CRT_GLOBAL const u32x3 *)(pred + (size_t)i*3);
-		W = graph_word(i, t.x, t.y, t.z); A = t.x < i ? t.x : 0u;
-	}
 };
 
 // The window loop.  `base`: what a vertex whose value stays (malformed triple) has to give up to become relative (0 for bytes / HBM).
@@ -373,6 +408,60 @@ __device__ __forceinline__ uint32_t stage_in16(const LdsVal<K> &val, CRT_GLOBAL 
 	return bad;
 }
 
+// 32-bit records: the raw deltas as they are (absolute values, nothing to check); K = 3 leaves the record's fourth dword to the graph builder
+template <int K>
+__device__ __forceinline__ void stage_in32(const LdsW<K> &val, CRT_GLOBAL const int32_t *src, uint32_t nvert) {
+	constexpr int NC = LdsW<K>::NC;
+	constexpr uint32_t U = NC <= 2 ? 16u : 8u;
+	for(uint32_t i0 = lane_id(); i0 < nvert; i0 += 64*U) {
+		int32_t d[U][NC];
+#pragma unroll
+		for(uint32_t u = 0; u < U; u++) {
+			const uint32_t i = i0 + u*64 < nvert ? i0 + u*64 : nvert - 1u;
+#pragma unroll
+			for(int q = 0; q < NC; q++) d[u][q] = src[(size_t)i*NC + q];
+		}
+#pragma unroll
+		for(uint32_t u = 0; u < U; u++)
+#pragma unroll
+			for(int q = 0; q < NC; q++) asm volatile("" : "+v"(d[u][q]));
+#pragma unroll
+		for(uint32_t u = 0; u < U; u++) {
+			const uint32_t i = i0 + u*64;
+			if(i >= nvert) continue;
+			if(K == 3) {
+				CRT_LDS uint32_t *p32 = (CRT_LDS uint32_t *)(val.p + i);
+				*(CRT_LDS u32x2 *)p32 = u32x2{(uint32_t)d[u][0], (uint32_t)d[u][1]};
+				p32[2] = (uint32_t)d[u][NC > 2 ? 2 : 0];
+			} else val.store(i, d[u], 0u);
+		}
+	}
+}
+template <int K>
+__device__ __forceinline__ void stage_out32(const LdsW<K> &val, CRT_GLOBAL int32_t *dst, uint32_t nvert, bool as_float, float q) {
+	constexpr int NC = LdsW<K>::NC;
+	CRT_GLOBAL float *fdst = (CRT_GLOBAL float *)dst;
+	for(uint32_t i0 = lane_id(); i0 < nvert; i0 += 64*8) {
+		typename LdsW<K>::Raw w[8];
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) w[u] = val.raw(i0 + u*64 < nvert ? i0 + u*64 : nvert - 1u);
+#pragma unroll
+		for(uint32_t u = 0; u < 8; u++) {
+			const uint32_t i = i0 + u*64;
+			if(i >= nvert) continue;
+			int32_t v[NC];
+			LdsW<K>::unpack(w[u], v);
+			if(as_float) {
+#pragma unroll
+				for(int c = 0; c < NC; c++) fdst[(size_t)i*NC + c] = (float)v[c]*q;
+			} else {
+#pragma unroll
+				for(int c = 0; c < NC; c++) dst[(size_t)i*NC + c] = v[c];
+			}
+		}
+	}
+}
+
 __device__ __forceinline__ void stage_in_bytes(const LdsVal<5> &val, CRT_GLOBAL const uint8_t *src, uint32_t nvert, uint32_t N, uint32_t first = lane_id(), uint32_t step = 64u) {
 	if(N == 4 && ((uintptr_t)src & 3) == 0) {
 		CRT_GLOBAL const uint32_t *s4 = (CRT_GLOBAL const uint32_t *)src;
@@ -486,6 +575,24 @@ __device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob
 	return false;
 }
 
+// the same attribute with 32-bit records (the context met values beyond int16): window, walk, copy-out; nothing can overflow
+template <int K>
+__device__ __forceinline__ void delta32_run(CRT_LDS uint8_t *rec, const DeltaJob &J, CRT_LDS const uint32_t *gw, const GaRef ga,
+                                            CRT_LDS uint32_t *fbits, const WalkStarts &starts) {
+	LdsW<K> val{(decltype(LdsW<K>::p))rec};
+	const int32_t zero[LdsW<K>::NC] = {};
+	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert);
+	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
+	WindowHand hand;
+	(void)delta_window_run(val, GraphLds{gw, ga}, nvert, para, zero, &hand);
+	if(hand.s < nvert) {
+		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
+		(void)delta_walk_run(val, gw, ga, fbits, starts, nvert, para, zero, hand);
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	stage_out32<K>(val, as_global((int32_t *)J.values), J.nvert, J.deq == 1, J.q);
+}
+
 } // namespace
 
 // One workgroup per blob: up to four attributes, one wave each, share the prediction graph in LDS; the graph is made by the first wave
@@ -498,14 +605,15 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const uint32_t lane = lane_id(), w = wave_id();
 	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[G.first].nvert);   // (uniform: the window loop's control stays scalar)
+	const bool wide = __builtin_amdgcn_readfirstlane((int)jobs[G.first].pad[1]) != 0;            // 32-bit records (every job of the group says the same)
 	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
 	uint32_t off = 0, myoff = 0, ga_addr = 0, ga_shift = 1;
 	bool ga_set = false;
 	for(uint32_t k = 0; k < G.count; k++) {
 		const uint32_t N = jobs[G.first + k].N; const bool u8 = jobs[G.first + k].is_u8 != 0;
 		if(k == w) myoff = off;
-		if(!ga_set && !u8 && N == 3) { ga_addr = (uint32_t)(uintptr_t)(l8 + off) + 6u; ga_shift = 3; ga_set = true; }
-		off += delta16_vbytes(nvert, N, u8);
+		if(!ga_set && !u8 && N == 3) { ga_addr = (uint32_t)(uintptr_t)(l8 + off) + (wide ? 12u : 6u); ga_shift = wide ? 4 : 3; ga_set = true; }
+		off += delta_vbytes(nvert, N, u8, wide);
 	}
 	CRT_LDS uint32_t *gw = (CRT_LDS uint32_t *)(l8 + off);
 	off += (4u*nvert + 15u) & ~15u;
@@ -551,6 +659,13 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 	if(mine) {
 		const bool ga_here = ga_set && ga_shift == 3 && (uint32_t)(uintptr_t)rec + 6u == ga_addr;
 		if(bytes) stage_in_bytes(LdsVal<5>{(CRT_LDS uint32_t *)rec}, as_global((const uint8_t *)J.values), nvert, N);
+		else if(wide) {
+			CRT_GLOBAL const int32_t *src = as_global((const int32_t *)J.values);
+			if(N == 1) stage_in32<1>(LdsW<1>{(CRT_LDS uint32_t *)rec}, src, nvert);
+			else if(N == 2) stage_in32<2>(LdsW<2>{(CRT_LDS u32x2 *)rec}, src, nvert);
+			else if(N == 3) stage_in32<3>(LdsW<3>{(CRT_LDS u32x4 *)rec}, src, nvert);
+			else stage_in32<4>(LdsW<4>{(CRT_LDS u32x4 *)rec}, src, nvert);
+		}
 		else if(N == 1) bad = delta16_in<1>(rec, J, false);
 		else if(N == 2) bad = delta16_in<2>(rec, J, false);
 		else if(N == 3) bad = delta16_in<3>(rec, J, ga_here);
@@ -571,6 +686,12 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		stage_out_bytes(val, J, J.qc[0], J.qc[1], J.qc[2], J.qc[3]);
 	}
+	else if(wide) {
+		if(N == 1) delta32_run<1>(rec, J, gw, ga, fbits, starts);
+		else if(N == 2) delta32_run<2>(rec, J, gw, ga, fbits, starts);
+		else if(N == 3) delta32_run<3>(rec, J, gw, ga, fbits, starts);
+		else delta32_run<4>(rec, J, gw, ga, fbits, starts);
+	}
 	else if(N == 1) redo = delta16_run<1>(rec, J, gw, ga, bad, fbits, starts);
 	else if(N == 2) redo = delta16_run<2>(rec, J, gw, ga, bad, fbits, starts);
 	else if(N == 3) redo = delta16_run<3>(rec, J, gw, ga, bad, fbits, starts);
@@ -586,155 +707,6 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 			CRT_GLOBAL int32_t *v = as_global((int32_t *)J.values);
 			const uint32_t n = nvert*N;
 			for(uint32_t k = lane; k < n; k += 64) { const int32_t x = v[k]; ((CRT_GLOBAL float *)v)[k] = (float)x*J.q; }
-		}
-	}
-}
-
-// ---- EXPERIMENT ($CORTO_EXP_DELTA_TREE=1): the attributes that only use `a` (strategy without PARALLEL: v[i] += v[a],
-// vertex_attribute.h:170-176; uv and colours of the usual encoder settings) by POINTER JUMPING.  That recurrence is a TREE: v[i] = the
-// sum of the deltas on i's path to a root, and integer sums (mod 2^32, or mod 256 for colours) can be taken in any order.  Every vertex
-// keeps (partial sum, the ancestor whose partial sum is still missing); a round adds the ancestor's pair to it: val[i] += val[anc],
-// anc[i] = anc[anc].  The distance covered doubles each round: ~log2(depth) rounds over all vertices (a 2 112-vertex blob: twelve)
-// instead of ~150 dependent window passes, in a workgroup of its own - and the parallelogram attributes' workgroup holds 26 KB, not 43.
-// A round is read phase | barrier | write phase | barrier per chunk of 256 x 8 vertices (every pair is read as the barrier left it,
-// chunks see the chunks before them already advanced).  32-bit values (no int16 bookkeeping: nothing to check, nothing to redo).
-// LDS: val[nvert x N] int32 (colours: one dword of four bytes) | anc[nvert] u16.
-// MEASURED (C4 batch): 24 us alone - 9.5 us of launch + staging, twelve rounds of 1.25 us (two barriers and two dependent LDS round
-// trips per chunk) - while the position-only window kernel goes from 49 to 45 us; pipelined the two are level (12.0 vs 12.2 Gtri/s,
-// irregular 6.69 vs 6.57): the 17 KB x 90 us it frees are spent again on 2 048 more waves for 24 us.  Off by default.
-constexpr uint32_t TREE_NONE = 0xFFFFu;
-template <int NW, bool BYTES>
-__device__ __forceinline__ void delta_tree_rounds(CRT_LDS uint32_t *val, CRT_LDS uint16_t *anc, uint32_t nvert, uint32_t tid) {
-	constexpr uint32_t U = 8;
-	const uint32_t nchunks = (nvert + 256u*U - 1u)/(256u*U);
-	const uint32_t csize = (((nvert + nchunks - 1u)/nchunks) + 255u) & ~255u;  // chunks of equal size, a multiple of the workgroup
-	for(uint32_t round = 0; round < 20; round++) {                            // (2^16 > any depth: the loop ends by itself)
-		uint32_t any = 0;
-		for(uint32_t c0 = 0; c0 < nvert; c0 += csize) {
-			const uint32_t cend = c0 + csize < nvert ? c0 + csize : nvert;
-			uint32_t k[U], ak[U], vi[U][NW], vk[U][NW];
-#pragma unroll
-			for(uint32_t u = 0; u < U; u++) { const uint32_t i = c0 + tid + 256u*u; k[u] = anc[i < cend ? i : c0]; }
-#pragma unroll
-			for(uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(k[u]));
-#pragma unroll
-			for(uint32_t u = 0; u < U; u++) {
-				const uint32_t i = c0 + tid + 256u*u, ic = i < cend ? i : c0;
-				if(i >= cend) k[u] = TREE_NONE;
-				const uint32_t kk = k[u] != TREE_NONE ? k[u] : 0u;
-				ak[u] = anc[kk];
-#pragma unroll
-				for(int q = 0; q < NW; q++) { vk[u][q] = val[kk*NW + q]; vi[u][q] = val[ic*NW + q]; }
-			}
-#pragma unroll
-			for(uint32_t u = 0; u < U; u++) {
-				asm volatile("" : "+v"(ak[u]));
-#pragma unroll
-				for(int q = 0; q < NW; q++) asm volatile("" : "+v"(vk[u][q]), "+v"(vi[u][q]));
-			}
-			__syncthreads();
-#pragma unroll
-			for(uint32_t u = 0; u < U; u++) if(k[u] != TREE_NONE) {
-				const uint32_t i = c0 + tid + 256u*u;
-#pragma unroll
-				for(int q = 0; q < NW; q++) {
-					const uint32_t x = vi[u][q], y = vk[u][q];
-					val[i*NW + q] = BYTES ? (((x & 0x7F7F7F7Fu) + (y & 0x7F7F7F7Fu)) ^ ((x ^ y) & 0x80808080u)) : x + y;   // four byte sums, no carry across
-				}
-				anc[i] = (uint16_t)ak[u];
-				any |= (uint32_t)(ak[u] != TREE_NONE);
-			}
-			__syncthreads();
-		}
-		if(!__syncthreads_or((int)any)) break;
-	}
-}
-
-__global__ __launch_bounds__(256) void k_delta_tree(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;
-	const DeltaJob &J = jobs[blockIdx.x];
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const uint32_t tid = threadIdx.x, nvert = J.nvert, N = J.N;
-	const bool bytes = J.is_u8 != 0;
-	CRT_LDS uint32_t *val = (CRT_LDS uint32_t *)as_lds(lds);
-	CRT_LDS uint16_t *anc = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)as_lds(lds) + delta_tree_vbytes(nvert, N, bytes));
-	// stage in: the raw deltas (a flat copy, eight loads a thread in flight) and `a` out of the prediction triples
-	if(bytes) {
-		stage_in_bytes(LdsVal<5>{val}, as_global((const uint8_t *)J.values), nvert, N, tid, 256u);
-	} else {
-		CRT_GLOBAL const uint32_t *src = as_global((const uint32_t *)J.values);
-		const uint32_t n = nvert*N;
-		for(uint32_t e0 = tid; e0 < n; e0 += 256u*8u) {
-			uint32_t w[8];
-#pragma unroll
-			for(uint32_t u = 0; u < 8; u++) w[u] = src[e0 + 256u*u < n ? e0 + 256u*u : n - 1u];
-#pragma unroll
-			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(w[u]));
-#pragma unroll
-			for(uint32_t u = 0; u < 8; u++) if(e0 + 256u*u < n) val[e0 + 256u*u] = w[u];
-		}
-	}
-	{
-		CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
-		for(uint32_t i0 = tid; i0 < nvert; i0 += 256u*8u) {
-			uint32_t a[8];
-#pragma unroll
-			for(uint32_t u = 0; u < 8; u++) a[u] = pred[3*(size_t)(i0 + 256u*u < nvert ? i0 + 256u*u : nvert - 1u)];
-#pragma unroll
-			for(uint32_t u = 0; u < 8; u++) asm volatile("" : "+v"(a[u]));
-#pragma unroll
-			for(uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + 256u*u; if(i < nvert) anc[i] = (uint16_t)(a[u] < i ? a[u] : TREE_NONE); }   // (a >= i: the value stays, as graph_word())
-		}
-	}
-	__syncthreads();
-	if(bytes) delta_tree_rounds<1, true>(val, anc, nvert, tid);
-	else if(N == 1) delta_tree_rounds<1, false>(val, anc, nvert, tid);
-	else if(N == 2) delta_tree_rounds<2, false>(val, anc, nvert, tid);
-	else if(N == 3) delta_tree_rounds<3, false>(val, anc, nvert, tid);
-	else delta_tree_rounds<4, false>(val, anc, nvert, tid);
-	// out: as the caller wants them (the same folds as k_delta_lds16's copy-out)
-	if(bytes) { stage_out_bytes(LdsVal<5>{val}, J, J.qc[0], J.qc[1], J.qc[2], J.qc[3], tid, 256u); return; }
-	CRT_GLOBAL int32_t *dst = as_global((int32_t *)J.values);
-	const uint32_t n = nvert*N;
-	const bool as_float = J.deq == 1; const float q = J.q;
-	for(uint32_t e = tid; e < n; e += 256u) {
-		const int32_t v = (int32_t)val[e];
-		if(as_float) ((CRT_GLOBAL float *)dst)[e] = (float)v*q; else dst[e] = v;
-	}
-}
-
-// EXPERIMENT ($CORTO_EXP_DELTA_GLOBAL=1): the same window loop with NO LDS at all - one wave per attribute, values in place in HBM (they
-// stay in L2), graph words worked out of the prediction triples as the window reaches them.  A pass costs L2 round trips instead of LDS
-// ones; what it tests is whether a pipelined decode gains more from the 44 KB x 50 us of LDS per blob it gives back than the longer
-// kernel costs.
-__global__ __launch_bounds__(64) void k_delta_global(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;
-	const DeltaJob &J = jobs[blockIdx.x];
-	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert), N = J.N, lane = lane_id();
-	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
-	const GraphGlobal graph{as_global(J.pred)};
-	const int32_t zero[4] = {0, 0, 0, 0};
-	if(J.is_u8) {
-		const GlobalVal<uint8_t> v{as_global((uint8_t *)J.values), N};
-		(void)delta_window_run(v, graph, nvert, para, zero);
-		if(J.deq == 2) {                                                        // RGB(A) out (color_attribute.cpp:76-95)
-			CRT_GLOBAL const uint8_t *src = as_global((const uint8_t *)J.values);
-			CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
-			const uint32_t oc = J.out_components, stride = J.out_stride ? J.out_stride : oc;
-			for(uint32_t i = lane; i < nvert; i += 64) {
-				uint32_t col[4] = {0, 0, 0, 255};
-				for(uint32_t c = 0; c < N && c < 4; c++) col[c] = src[(size_t)i*N + c];
-				const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
-				for(uint32_t c = 0; c < oc && c < 4; c++) dst[(size_t)i*stride + c] = (uint8_t)(rgb[c]*J.qc[c]);
-			}
-		}
-	} else {
-		const GlobalVal<int32_t> v{as_global((int32_t *)J.values), N};
-		(void)delta_window_run(v, graph, nvert, para, zero);
-		if(J.deq == 1) {
-			CRT_GLOBAL int32_t *p = as_global((int32_t *)J.values);
-			const uint32_t n = nvert*N;
-			for(uint32_t k = lane; k < n; k += 64) { const int32_t x = p[k]; ((CRT_GLOBAL float *)p)[k] = (float)x*J.q; }
 		}
 	}
 }

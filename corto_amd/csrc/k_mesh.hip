@@ -1645,9 +1645,9 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 // every vertex predicts from the vertex made just before it (a = i-1) and two vertices one ring of the front back.
 // So the graph is a set of "stretches" - runs of consecutive vertices, each run a serial chain - skewed against each
 // other by two steps, and the parallelism is ACROSS stretches.  Both kernels below give each lane / thread whole
-// stretches to walk; they differ in where the values live (LDS: k_delta_wave, HBM: k_delta_mesh).
+// stretches to walk (k_delta_mesh, values in HBM); blobs whose values fit LDS take the window loop of k_delta.hip.
 
-// Attributes too big for LDS (meshes of tens of thousands of vertices): the same stretch walk as k_delta_wave below, over
+// Attributes too big for LDS (meshes of tens of thousands of vertices, attributes of more than four components): a stretch walk over
 // HBM/L2 by one workgroup.  Thread k walks stretches k, k+T, ... in order and carries the value of the vertex it has just
 // finished in registers (a = i-1 inside a stretch), so the only waiting is for the two parents one ring back - which the
 // neighbouring stretch, two steps ahead, has normally published already.  Flags and values cross waves through L2 with
@@ -1768,345 +1768,6 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 		case 3: delta_stretch_global<uint32_t, 3>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
 		default: delta_stretch_global<uint32_t, 0>(v, fired, starts, ns, pred, nvert, J.N, para, THREADS); break;
 		}
-	}
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// K-DELTA for an attribute that fits LDS: ONE wave.  In the breadth-first CLERS order nearly every vertex predicts from
-// the vertex made just before it (a = i-1) and two vertices one ring of the front back, so the dependency graph is a
-// set of "stretches" - runs of consecutive vertices, each run a serial chain - skewed against each other by two steps:
-// the parallelism (about 13 wide on a 4K-triangle blob) is ACROSS stretches.  Lane k walks stretch k, k+64, ... in
-// order; a vertex fires when the fired flags of its three parents are set.  One wave executes its LDS accesses in
-// program order, so a flag or value written in one pass is what the next pass reads: no fences, no barriers, no
-// polling waves (a strided assignment - thread t owns vertices t, t+T, ... - keeps 8-16 waves per attribute spinning on
-// flags for the same 13-wide work).
-// The lowest unfired vertex always is the current vertex of its lane and its parents are lower, so every pass fires
-// at least one vertex.  Any triple set is handled (a malformed or adversarial one only costs passes).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// The walk's bookkeeping is bit-packed (it is the fallback of the scans below, and a byte per vertex and attribute of fired flags plus
-// two of stretch starts were 10.5 KB of a C4 blob's 74 KB of LDS): `fbits` one bit per vertex, set with ds_or; `sbits` one bit per
-// vertex that starts a stretch, `spre[j]` the number of starts in the dwords below j, so that lane k finds its stretches k, k+64, ...
-// with a binary search over spre and a select inside one dword.
-struct DeltaStarts { CRT_LDS const uint32_t *sbits; CRT_LDS const uint16_t *spre; uint32_t nw, ns; };
-
-__device__ __forceinline__ bool delta_take_stretch(const DeltaStarts &G, uint32_t k, uint32_t nvert, uint32_t &i, uint32_t &end) {
-	if(k >= G.ns) return false;
-	uint32_t lo = 0, hi = G.nw;                                           // largest j with spre[j] <= k
-	while(hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if((uint32_t)G.spre[mid] <= k) lo = mid; else hi = mid; }
-	uint32_t word = G.sbits[lo];
-	for(uint32_t r = k - G.spre[lo]; r; r--) word &= word - 1u;            // drop the starts in front of mine
-	const uint32_t bit = (uint32_t)__builtin_ctz(word | 0x80000000u);
-	i = lo*32u + bit;
-	word &= word - 1u;                                                     // the next start: where this stretch ends
-	uint32_t j = lo;
-	while(!word && ++j < G.nw) word = G.sbits[j];
-	end = word ? j*32u + (uint32_t)__builtin_ctz(word) : nvert;
-	if(end > nvert) end = nvert;
-	return true;
-}
-
-template <typename T, int NC>
-__device__ __forceinline__ void delta_wave_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, CRT_LDS uint32_t *fbits,
-                                               const DeltaStarts &G, uint32_t nvert, uint32_t Nrt, bool para, uint32_t first) {
-	const uint32_t n = NC ? (uint32_t)NC : Nrt;
-	for(uint32_t d = lane_id(); d < G.nw; d += 64) {                       // vertices below `first` are final already (delta_scan_run)
-		const uint32_t b0 = d*32u;
-		fbits[d] = first >= b0 + 32u ? 0xFFFFFFFFu : first > b0 ? (1u << (first - b0)) - 1u : 0u;
-	}
-	auto is_fired = [&](uint32_t x) -> uint32_t { return (fbits[x >> 5] >> (x & 31u)) & 1u; };
-	uint32_t k = lane_id();
-	bool active = true;
-	uint32_t i = 0, end = 0;
-	auto take = [&]() {                                                    // stretch k, from `first` on; stretches that end below it are done
-		while(active) {
-			active = delta_take_stretch(G, k, nvert, i, end);
-			if(!active) break;
-			if(i < first) i = first;
-			if(i < end) break;
-			k += 64;
-		}
-	};
-	take();
-	uint32_t a = active ? pa[i] : 0u, bc = active ? pbc[i] : 0u;
-	while(__any(active)) {
-		if(active) {
-			// malformed triple (and vertex 0): the value stays.  v += v[a] alone: b = c = vertex 0 cancel
-			const bool inv = a == 0xFFFFu || (para && bc == 0xFFFFFFFFu);
-			const uint32_t aa = inv ? 0u : a, b = inv || !para ? 0u : bc & 0xFFFFu, c = inv || !para ? 0u : bc >> 16;
-			const uint32_t ready = is_fired(aa) & is_fired(b) & is_fired(c);
-			if(NC) {                                                         // values are fetched with the flags: one LDS round trip per pass
-				T x[NC ? NC : 1];
-#pragma unroll
-				for(uint32_t q = 0; q < (uint32_t)NC; q++) x[q] = (T)(v[i*n + q] + v[aa*n + q] + v[b*n + q] - v[c*n + q]);
-				if(ready && !inv) {
-#pragma unroll
-					for(uint32_t q = 0; q < (uint32_t)NC; q++) v[i*n + q] = x[q];
-				}
-			} else if(ready && !inv) {
-				for(uint32_t q = 0; q < n; q++) v[i*n + q] = (T)(v[i*n + q] + v[aa*n + q] + v[b*n + q] - v[c*n + q]);
-			}
-			if(ready) {
-				(void)__hip_atomic_fetch_or(fbits + (i >> 5), 1u << (i & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_or_b32
-				i++;
-				if(i == end) { k += 64; take(); }
-				if(active) { a = pa[i]; bc = pbc[i]; }
-			}
-		}
-		asm volatile("" ::: "memory");
-	}
-}
-
-// K-DELTA as SCANS (round 2).  v[i] += v[a] + v[b] - v[c] with a = i-1 is a prefix sum: v[i] = v[s-1] + sum_{k=s..i} (d[k] + v[b_k] - v[c_k])
-// as long as every b, c lies below s.  In the CLERS order that is the common case - the vertices of a (VERTEX LEFT) run predict from
-// their predecessor and from two vertices of the previous ring of the front - so the wave takes the next up-to-64 vertices [s, s+64),
-// cuts the block at the first vertex with a parent inside the block that is not its predecessor, and finishes the rest in one pass:
-// gathers of v[b], v[c] (and v[a] for the heads: vertices whose a is not i-1; a < s then), one DPP wave scan per component, and,
-// because a block may hold several heads, each lane subtracts the exclusive sum at its own segment's head (a max-scan of head lanes
-// + one bpermute per component) - all sums wrap mod 2^32 (mod 2^8 for colours), like the reference's int / uchar arithmetic.
-// The first vertex of a block always qualifies (its parents are below it), so every pass advances; a 4K-triangle blob with its
-// growing rings needs ~110 passes (the 34K- and 128K-vertex meshes average 47 and 54 vertices a pass) where the flag-driven walk
-// below needs at least one round of dependent LDS trips per level of the DAG (158 levels there, 480 on a small torus).  Meshes whose blocks
-// stay short (irregular connectivity) are handed to that walk, from where the scans stopped.
-// Returns the first vertex not done (nvert: finished).
-template <typename T, int NC>
-__device__ __forceinline__ uint32_t delta_scan_run(CRT_LDS T *v, CRT_LDS const uint16_t *pa, CRT_LDS const uint32_t *pbc, uint32_t nvert, bool para) {
-	const uint32_t lane = lane_id();
-	uint32_t s = 1, passes = 0, sp0 = 1, sp1 = 1;
-	while(s < nvert) {
-		for(uint32_t pass16 = 0; pass16 < 16 && s < nvert; pass16++) {       // (sixteen passes, then the checks below: nothing but the block in the loop)
-		const uint32_t i = s + lane;
-		const bool in = i < nvert;
-		// (loads are unconditional, on clamped addresses, and pinned by empty asm statements: written as `in ? pa[i] : ...` the compiler sinks
-		// every load into its own exec-masked branch with its own wait - six LDS round trips a pass instead of three)
-		const uint32_t ic = in ? i : nvert - 1u;
-		uint32_t a = pa[ic], bc = pbc[ic];
-		asm volatile("" : "+v"(a), "+v"(bc));
-		a = in ? a : 0xFFFFu; bc = in ? bc : 0xFFFFFFFFu;
-		const bool inv = a == 0xFFFFu || (para && bc == 0xFFFFFFFFu);           // malformed triple: the value stays (a head with base 0)
-		const uint32_t b = bc & 0xFFFFu, c = bc >> 16;
-		const bool chained = !inv && a + 1 == i && lane != 0;                   // continues its predecessor's sum
-		const bool ok = in && (inv || ((chained || a < s) && (!para || (b < s && c < s))));
-		const uint64_t bad = ~__ballot(ok);
-		const uint32_t L = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;           // lanes [0, L) go now (L >= 1)
-		const bool mine = lane < L;
-		const bool head = mine && !chained;
-		// the lane's own head = the highest head lane at or below it (lane 0 is always one): from the ballot, no cross-lane traffic
-		const uint64_t heads = __ballot(head) | 1ull;
-		const uint32_t hidx = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63u - lane)));
-		// the components side by side, phase by phase: every gather of the pass in flight at once, then the scans, the bpermutes, the
-		// stores (written as a loop over components the stores of one fenced in the loads of the next: three LDS round trips each)
-		uint32_t x[NC], incl[NC], eh[NC];
-		const uint32_t ri = mine ? i : 0u, rb = mine && !inv && para ? b : 0u, rc = mine && !inv && para ? c : 0u, ra = head && !inv ? a : 0u;
-		uint32_t g[NC][4];
-#pragma unroll
-		for(uint32_t q = 0; q < (uint32_t)NC; q++) { g[q][0] = (uint32_t)v[ri*NC + q]; g[q][1] = (uint32_t)v[rb*NC + q]; g[q][2] = (uint32_t)v[rc*NC + q]; g[q][3] = (uint32_t)v[ra*NC + q]; }
-#pragma unroll
-		for(uint32_t q = 0; q < (uint32_t)NC; q++) asm volatile("" : "+v"(g[q][0]), "+v"(g[q][1]), "+v"(g[q][2]), "+v"(g[q][3]));   // every gather in flight, one wait
-#pragma unroll
-		for(uint32_t q = 0; q < (uint32_t)NC; q++) x[q] = mine ? g[q][0] + (!inv && para ? g[q][1] - g[q][2] : 0u) + (head && !inv ? g[q][3] : 0u) : 0u;
-#pragma unroll
-		for(uint32_t q = 0; q < (uint32_t)NC; q++) incl[q] = wave_inclusive_scan_u32(x[q]);
-#pragma unroll
-		for(uint32_t q = 0; q < (uint32_t)NC; q++) eh[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hidx << 2), (int)(incl[q] - x[q]));
-		if(mine) {
-#pragma unroll
-			for(uint32_t q = 0; q < (uint32_t)NC; q++) v[i*NC + q] = (T)(incl[q] - eh[q]);
-		}
-		s += L;
-		}
-		// a front grows from its seed triangle, so the first blocks are short whatever the mesh; by pass 96 a mesh with rings to speak
-		// of has done well over a thousand vertices (a 4K-triangle grid: 1 700) and one that has not yet done 576 (a holey disc, a
-		// ribbon: ~5 a pass) has a shallower DAG than it has blocks - the walk takes over from s.  Most of those show it earlier:
-		// passes 33..48 take 230 vertices on a grid (123 on a torus, 140 on a grid with one quad in fifty split the other way), 60-85
-		// where the diagonals are random or the mesh is full of holes - fewer than 6 a pass there ends the scans at pass 48.
-		// And a mesh that is regular only in patches (one quad in fifty split the other way: 266 passes, 0.148 ms where the walk
-		// takes 0.073) shows in how its blocks grow: with whole rings a pass takes ~1.35x more vertices in passes 49..64 than in
-		// 33..48 (grid, torus), with patches 1.1x or less - under 1.2x with more than a hundred such passes to go ends the scans too.
-		// (Checked every 16 passes from the 64th on, while a pass takes fewer than 16 vertices.)
-		passes += 16;
-		const uint32_t g = s - sp1, g0 = sp1 - sp0;                            // vertices of the last 16 passes, and of the 16 before
-		if(passes == 48 && g < 16*6) break;
-		if(passes >= 64 && g < 16*16 && g*5 < g0*6 && (nvert - s)*16 > g*100) break;
-		if(passes == 96 && s < 96*6) break;
-		sp0 = sp1; sp1 = s;
-	}
-	return s < nvert ? s : nvert;
-}
-
-// values of one attribute <-> LDS by one wave: 16-byte vectors, eight in flight per lane (a lone wave that waited for each load
-// before issuing the next would spend ~1 us per KB).  LDS mirrors the caller's alignment phase so that both sides of the
-// body are 16-aligned; unaligned heads/tails (3-component colours, odd caller buffers) go bytewise.
-struct DeltaStage { CRT_LDS uint8_t *l8; CRT_GLOBAL uint8_t *g8; uint32_t bytes, head, nvec; };
-
-__device__ __forceinline__ DeltaStage delta_stage_plan(CRT_LDS uint8_t *lds, void *values, uint32_t bytes) {
-	DeltaStage S;
-	const uint32_t phase = (uint32_t)((uintptr_t)values & 15);
-	const bool vec = bytes >= 64;
-	S.g8 = as_global((uint8_t *)values); S.bytes = bytes;
-	S.head = vec ? (16 - phase) & 15 : 0u;
-	S.nvec = vec ? (bytes - S.head) >> 4 : 0u;
-	S.l8 = lds + (vec ? phase : 0u);                                     // (l8 + head) is 16-aligned; phase % 4 == 0 whenever the caller's ints are aligned
-	return S;
-}
-
-template <bool IN>
-__device__ __forceinline__ void delta_stage_copy(const DeltaStage &S) {
-	const uint32_t lane = lane_id();
-	CRT_GLOBAL u32x4 *g4 = (CRT_GLOBAL u32x4 *)(S.g8 + S.head);
-	CRT_LDS u32x4 *l4 = (CRT_LDS u32x4 *)(S.l8 + S.head);
-	for(uint32_t i = lane; i < S.nvec; i += 64*8) {
-		u32x4 t[8];
-#pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) t[u] = IN ? g4[i + u*64] : l4[i + u*64];
-#pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) { if(IN) l4[i + u*64] = t[u]; else g4[i + u*64] = t[u]; }
-	}
-	for(uint32_t i = lane; i < S.head; i += 64) { if(IN) S.l8[i] = S.g8[i]; else S.g8[i] = S.l8[i]; }
-	for(uint32_t i = S.head + S.nvec*16 + lane; i < S.bytes; i += 64) { if(IN) S.l8[i] = S.g8[i]; else S.g8[i] = S.l8[i]; }
-}
-
-// a generic attribute leaves LDS as floats: (float)v*q, in place of the integers (vertex_attribute.h:190-193)
-__device__ __forceinline__ void delta_stage_out_float(const DeltaStage &S, float q) {
-	const uint32_t lane = lane_id();
-	typedef float f32x4_t __attribute__((ext_vector_type(4)));
-	CRT_GLOBAL f32x4_t *g4 = (CRT_GLOBAL f32x4_t *)(S.g8 + S.head);
-	CRT_LDS u32x4 *l4 = (CRT_LDS u32x4 *)(S.l8 + S.head);
-	for(uint32_t i = lane; i < S.nvec; i += 64*8) {
-		u32x4 t[8];
-#pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) t[u] = l4[i + u*64];
-#pragma unroll
-		for(uint32_t u = 0; u < 8; u++) if(i + u*64 < S.nvec) {
-			f32x4_t f;
-			f.x = (float)(int32_t)t[u].x*q; f.y = (float)(int32_t)t[u].y*q; f.z = (float)(int32_t)t[u].z*q; f.w = (float)(int32_t)t[u].w*q;
-			g4[i + u*64] = f;
-		}
-	}
-	// heads and tails are whole dwords (the caller's ints are 4-byte aligned)
-	for(uint32_t i = lane*4; i + 3 < S.head; i += 256) *(CRT_GLOBAL float *)(S.g8 + i) = (float)*(CRT_LDS const int32_t *)(S.l8 + i)*q;
-	for(uint32_t i = S.head + S.nvec*16 + lane*4; i + 3 < S.bytes; i += 256) *(CRT_GLOBAL float *)(S.g8 + i) = (float)*(CRT_LDS const int32_t *)(S.l8 + i)*q;
-}
-
-// a colour attribute leaves LDS as RGB(A): (r, g, b, a) = (v2 + v0, v0, v1 + v0, v3) x qc, u8 wrap (color_attribute.cpp:76-95, point.h:214)
-__device__ __forceinline__ void delta_stage_out_color(CRT_LDS const uint8_t *v, const DeltaJob &J) {
-	CRT_GLOBAL uint8_t *dst = as_global((uint8_t *)J.out);
-	const uint32_t N = J.N, oc = J.out_components, stride = J.out_stride ? J.out_stride : oc;
-	uint32_t done = 0;
-	if(N == 4 && oc == 4 && stride == 4 && (((uintptr_t)dst | (uintptr_t)v) & 15) == 0) {      // packed RGBA: four vertices per lane, 16-byte loads and stores
-		const uint32_t q0 = J.qc[0], q1 = J.qc[1], q2 = J.qc[2], q3 = J.qc[3];
-		CRT_LDS const u32x4 *v4 = (CRT_LDS const u32x4 *)v;
-		CRT_GLOBAL u32x4 *d4 = (CRT_GLOBAL u32x4 *)dst;
-		const uint32_t nq = J.nvert >> 2;
-		auto px = [&](uint32_t w) -> uint32_t {                                                   // bytes y, u, v, a -> r, g, b, a
-			const uint32_t y = w & 255u, cu = (w >> 8) & 255u, cv = (w >> 16) & 255u, al = w >> 24;
-			return (((cv + y)*q0) & 255u) | ((y*q1) & 255u) << 8 | (((cu + y)*q2) & 255u) << 16 | ((al*q3) & 255u) << 24;
-		};
-		for(uint32_t k = lane_id(); k < nq; k += 64) { const u32x4 w = v4[k]; d4[k] = u32x4{px(w.x), px(w.y), px(w.z), px(w.w)}; }
-		done = nq << 2;
-	}
-	for(uint32_t i = done + lane_id(); i < J.nvert; i += 64) {
-		uint32_t col[4] = {0, 0, 0, 255};
-		for(uint32_t c = 0; c < N && c < 4; c++) col[c] = v[i*N + c];
-		const uint32_t rgb[4] = {(col[2] + col[0]) & 255u, col[0], (col[1] + col[0]) & 255u, col[3]};
-		CRT_GLOBAL uint8_t *o = dst + (size_t)i*stride;
-		if(oc == 4 && (((uintptr_t)o) & 3) == 0)
-			*(CRT_GLOBAL uint32_t *)o = ((rgb[0]*J.qc[0]) & 255u) | ((rgb[1]*J.qc[1]) & 255u) << 8 | ((rgb[2]*J.qc[2]) & 255u) << 16 | ((rgb[3]*J.qc[3]) & 255u) << 24;
-		else for(uint32_t c = 0; c < oc && c < 4; c++) o[c] = (uint8_t)(rgb[c]*J.qc[c]);
-	}
-}
-
-// One workgroup per blob: up to four attributes share the prediction graph in LDS (a | b,c | stretch starts), one wave each walks
-// it with its own fired flags; the graph is made by the first wave that has no attribute (or by wave 0 before its own staging).
-__global__ __launch_bounds__(256) void k_delta_wave(const DeltaJob *__restrict__ jobs, const DeltaGroup *__restrict__ groups, uint32_t ngroups) {
-	if(blockIdx.x >= ngroups) return;
-	const DeltaGroup G = groups[blockIdx.x];
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	__shared__ uint32_t ns_shared;
-	const uint32_t lane = lane_id(), w = wave_id();
-	const DeltaJob J0 = jobs[G.first];
-	const uint32_t nvert = J0.nvert;
-	// LDS: values of every attribute | a u16 | b,c u32 | stretch-start bits, prefix counts | fired bits x count
-	CRT_LDS uint8_t *l8 = (CRT_LDS uint8_t *)as_lds(lds);
-	uint32_t myoff = 0, vtot = 0;
-	for(uint32_t k = 0; k < G.count; k++) { const uint32_t vb = delta_wave_vbytes(nvert, jobs[G.first + k].N, jobs[G.first + k].is_u8 != 0); if(k < w) myoff += vb; vtot += vb; }
-	CRT_LDS uint16_t *pa = (CRT_LDS uint16_t *)(l8 + vtot);
-	CRT_LDS uint32_t *pbc = (CRT_LDS uint32_t *)((CRT_LDS uint8_t *)pa + delta_wave_a_bytes(nvert));
-	const uint32_t nw = delta_wave_bit_words(nvert);
-	CRT_LDS uint32_t *sbits = pbc + nvert;
-	CRT_LDS uint16_t *spre = (CRT_LDS uint16_t *)((CRT_LDS uint8_t *)sbits + delta_wave_fired_bytes(nvert));
-	CRT_LDS uint8_t *fired_all = (CRT_LDS uint8_t *)sbits + delta_wave_starts_bytes(nvert);
-	const uint32_t builder = G.count < 4 ? G.count : 0u;
-	if(w == builder) {
-		// prediction triples -> a | (b, c) | stretch starts.  Four rounds of 64 vertices in flight.
-		CRT_GLOBAL const uint32_t *pred = as_global(J0.pred);
-		uint32_t ns = 0;
-		for(uint32_t base = 0; base < nvert; base += 256) {
-			uint32_t ta[4], tb[4], tc[4];
-#pragma unroll
-			for(uint32_t u = 0; u < 4; u++) {                                   // (unconditional on a clamped index and pinned: as `if(i < nvert) load` the four
-				const uint32_t i = base + u*64 + lane, ic = i < nvert ? i : nvert - 1u;   //  rounds were four dependent round trips, 36 for a C4 blob)
-				ta[u] = pred[(size_t)ic*3]; tb[u] = pred[(size_t)ic*3 + 1]; tc[u] = pred[(size_t)ic*3 + 2];
-			}
-#pragma unroll
-			for(uint32_t u = 0; u < 4; u++) asm volatile("" : "+v"(ta[u]), "+v"(tb[u]), "+v"(tc[u]));
-#pragma unroll
-			for(uint32_t u = 0; u < 4; u++) {
-				const uint32_t i = base + u*64 + lane;
-				const bool in = i < nvert;
-				const bool va = in && ta[u] < i;                                // well-formed streams always predict from earlier vertices
-				const bool start = in && !(va && ta[u] + 1 == i);
-				if(in) {
-					pa[i] = (uint16_t)(va ? ta[u] : 0xFFFFu);
-					pbc[i] = tb[u] < i && tc[u] < i ? tb[u] | (tc[u] << 16) : 0xFFFFFFFFu;
-				}
-				const uint64_t m = __ballot(start);                              // the round's 64 vertices: two dwords of the start bitmap
-				if(lane == 0 && base + u*64 < nvert) {
-					const uint32_t d = (base + u*64) >> 5, lo32 = (uint32_t)m, hi32 = (uint32_t)(m >> 32);
-					sbits[d] = lo32; sbits[d + 1] = hi32;
-					spre[d] = (uint16_t)ns; spre[d + 1] = (uint16_t)(ns + __popc(lo32));
-				}
-				ns += __popcll(m);
-			}
-		}
-		if(lane == 0) ns_shared = ns;
-	}
-	DeltaJob J = J0;
-	DeltaStage S{};
-	CRT_LDS uint32_t *fbits = (CRT_LDS uint32_t *)(fired_all + w*delta_wave_fired_bytes(nvert));
-	if(w < G.count) {
-		J = jobs[G.first + w];
-		S = delta_stage_plan(l8 + myoff, J.values, nvert*J.N*(J.is_u8 ? 1u : 4u));
-		delta_stage_copy<true>(S);
-	}
-	__syncthreads();
-	if(w < G.count) {
-		const uint32_t ns = ns_shared, N = J.N;
-		const bool para = J.parallelogram != 0;
-		// scans first (delta_scan_run); what they leave - short blocks: irregular connectivity - to the flag-driven walk
-#define CRT_DELTA(T_, NC_, V_) do { uint32_t first_ = 1; if(NC_ && !J.pad[1]) first_ = delta_scan_run<T_, (NC_) ? (NC_) : 1>(V_, pa, pbc, nvert, para); \
-		if(first_ < nvert) delta_wave_run<T_, NC_>(V_, pa, pbc, fbits, DeltaStarts{sbits, spre, nw, ns}, nvert, N, para, first_); } while(0)
-		if(J.is_u8) {
-			CRT_LDS uint8_t *v = S.l8;
-			switch(N) {
-			case 3: CRT_DELTA(uint8_t, 3, v); break;
-			case 4: CRT_DELTA(uint8_t, 4, v); break;
-			default: CRT_DELTA(uint8_t, 0, v); break;
-			}
-		} else {
-			CRT_LDS uint32_t *v = (CRT_LDS uint32_t *)S.l8;
-			switch(N) {
-			case 1: CRT_DELTA(uint32_t, 1, v); break;
-			case 2: CRT_DELTA(uint32_t, 2, v); break;
-			case 3: CRT_DELTA(uint32_t, 3, v); break;
-			default: CRT_DELTA(uint32_t, 0, v); break;
-			}
-		}
-#undef CRT_DELTA
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		if(J.deq == 1 && !J.is_u8 && ((S.head | (uint32_t)(uintptr_t)S.g8) & 3u) == 0) delta_stage_out_float(S, J.q);
-		else if(J.deq == 2 && J.is_u8) delta_stage_out_color(S.l8, J);
-		else delta_stage_copy<false>(S);
 	}
 }
 

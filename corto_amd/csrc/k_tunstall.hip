@@ -27,16 +27,12 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #include "tun_tables.h"
 
 __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__ streams, uint32_t nstreams,
-                                                    TunTable *__restrict__ tables, uint64_t *lookback_state, uint32_t lookback_words) {
+                                                    TunTable *__restrict__ tables) {
 	const uint32_t s = blockIdx.x;
 	if(s >= nstreams) return;
 	const TunStream st = streams[s];
-	const uint32_t lane = threadIdx.x;
 	extern __shared__ __attribute__((aligned(16))) uint8_t big_words[];        // TUN_TABLE_BYTES when the launch has an alphabet of more than 64 symbols, else nothing
 	tun_tables_body<true>(st, &tables[st.table], nullptr, nullptr, nullptr, big_words);
-	// a long stream's chunks find their output offsets by look-back (tun_lookback below): their state words start out empty
-	if(lookback_state && st.nchunks > 1) for(uint32_t i = lane; i < st.nchunks; i += 64) lookback_state[st.chunk0 + i] = 0;
-	if(lookback_state && s == 0 && lane == 0) lookback_state[lookback_words] = 0;        // the give-up counter behind them
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,34 +367,6 @@ __device__ __forceinline__ void tun_drain_long(uint32_t win0, CRT_LDS const uint
 	}
 }
 
-// Decoded bytes of codewords [first, last) of a stream, by one wave; the total in every lane.  Four dwords in flight per lane: the
-// loop is a chain of HBM load -> four LDS byte reads per dword, and one dword at a time ran at a tenth of what the CU can do.
-__device__ __forceinline__ uint32_t tun_wave_bytes(CRT_GLOBAL const uint8_t *src, uint32_t first, uint32_t last, CRT_LDS const uint8_t *len8) {
-	const uint32_t lane = lane_id();
-	uint32_t sum = 0;
-	const uint32_t head = min((uint32_t)((0u - (uint32_t)(uintptr_t)(src + first)) & 3u), last - first);   // aligned dword body, byte head/tail
-	if(lane < head) sum += len8[src[first + lane]];
-	const uint32_t body0 = first + head, ndw = (last - body0) >> 2;
-	CRT_GLOBAL const uint32_t *src32 = (CRT_GLOBAL const uint32_t *)(src + body0);
-	auto four = [&](uint32_t x) { return (uint32_t)len8[x & 255u] + len8[(x >> 8) & 255u] + len8[(x >> 16) & 255u] + len8[x >> 24]; };
-	uint32_t i = lane;
-	for(; i + 15*64 < ndw; i += 16*64) {                                // sixteen loads in flight: under the decode kernels' write traffic a read takes microseconds
-		uint32_t x[16];
-#pragma unroll
-		for(int k = 0; k < 16; k++) x[k] = src32[i + 64*k];
-#pragma unroll
-		for(int k = 0; k < 16; k++) sum += four(x[k]);
-	}
-	for(; i + 192 < ndw; i += 256) {
-		const uint32_t x0 = src32[i], x1 = src32[i + 64], x2 = src32[i + 128], x3 = src32[i + 192];
-		sum += four(x0) + four(x1) + four(x2) + four(x3);
-	}
-	for(; i < ndw; i += 64) sum += four(src32[i]);
-	const uint32_t tail0 = body0 + ndw*4;
-	if(tail0 + lane < last) sum += len8[src[tail0 + lane]];
-	sum = wave_inclusive_scan_u32(sum);
-	return (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
-}
 
 // Between pass A and the decode (the default for long streams): the quarter sums of ONE stream turned into that stream's quarter offsets
 // by one workgroup - streams are independent, so there is no device-wide scan (k_scan_u64: one workgroup over every chunk of every
@@ -434,14 +402,9 @@ __global__ __launch_bounds__(256) void k_tun_stream_scan(const TunStream *__rest
 	}
 }
 
-// SINGLE PASS over a long stream (decoupled look-back): a chunk's output offset is the decoded size of every earlier chunk of its
-// stream.  Instead of a kernel that adds up every chunk, a device-wide scan and a second read of all codewords, each workgroup
-// adds up its own chunk (its four waves their quarters), publishes the total in the chunk's state word, and walks back over its
-// predecessors' words - "total of this chunk" (keep walking) or "total of everything up to here" (done) - spinning only on a
-// predecessor that has not published yet.  Workgroups start in chunk order (MI355X_MICROARCH.md: observed, not promised - so the
-// spin is bounded and a chunk that gives up flags the error word behind the state array), chunk 0 of every stream publishes an
-// inclusive total at once, so a walk never leaves its stream.  The state word IS the payload: 8-byte agent-scope atomics on both
-// sides, no fences (the per-XCD L2s are not coherent; sc1 accesses go to memory).
+// (Rounds 2-3 also carried a SINGLE-PASS form - every decode workgroup adding up its own chunk and finding its offset by decoupled
+// look-back over its predecessors' state words - as a switch: it measured 0.674 ms against 0.57-0.59 for sums + per-stream scan + decode,
+// DESIGN.md 3.2 has the table, and it was removed in round 4.  chain_lookback itself lives on in K-BIT's chunked kernel.)
 // the decoded bytes leave through non-temporal stores: six bytes are written for every byte read, and as ordinary stores they
 // pushed the chunk's codewords out of the XCD's L2 between the look-back's adding-up pass and the decode pass
 #ifndef TUN_FLUSH_PLAIN
@@ -453,8 +416,8 @@ template <int W, int CPL> constexpr uint32_t tun_win_bytes() { return W == 1 ? 2
 constexpr uint32_t tun_staged_lds(uint32_t win) { return 4*(win + 64); }                // dynamic LDS: the four waves' windows
 
 template <int W, int CPL>
-__device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTable &T, uint32_t c, uint64_t *chunk_out, uint32_t single_pass, uint32_t nchunks_all,
-                                                TunLds &L, uint32_t *t16, uint32_t (*longbuf)[TUN_LONGQ], uint32_t *winbuf, uint64_t *share) {
+__device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTable &T, uint32_t c, uint64_t *chunk_out, uint32_t sums_only,
+                                                TunLds &L, uint32_t *t16, uint32_t (*longbuf)[TUN_LONGQ], uint32_t *winbuf) {
 	constexpr uint32_t TUN_WIN = tun_win_bytes<W, CPL>();
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	tun_load_table(L, T, T.used);
@@ -479,24 +442,7 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 	const uint32_t csize = st.csize;
 	CRT_GLOBAL const uint8_t *src = as_global(st.src);
 	uint64_t base;
-	if(single_pass == 1) {                                                // (tun_lookback above)
-		const uint32_t mine = tun_wave_bytes(src, first, last, as_lds(L.len));
-		if(lane == 0) share[1 + w] = mine;
-		__syncthreads();
-		const uint64_t q0 = share[1], q1 = share[2], q2 = share[3], q3 = share[4];
-		auto chunk_bytes = [&](uint32_t ci) -> uint64_t {                  // the decoded size of another chunk of this stream: same dictionary, its codewords
-			const uint32_t cf = (ci - st.chunk0)*chunk_codes;
-			const uint32_t f_ = min(cf + w*quarter, st.csize), l_ = min(f_ + quarter, min(cf + chunk_codes, st.csize));
-			const uint32_t t = tun_wave_bytes(src, f_, l_, as_lds(L.len));
-			__syncthreads();
-			if(lane == 0) share[5 + w] = t;
-			__syncthreads();
-			return share[5] + share[6] + share[7] + share[8];
-		};
-		(void)nchunks_all;
-		base = chain_lookback(chunk_out, c, st.chunk0, q0 + q1 + q2 + q3, 512u, &share[0], chunk_bytes);
-		base += w > 0 ? q0 : 0; base += w > 1 ? q1 : 0; base += w > 2 ? q2 : 0;
-	} else if(single_pass == 2) {                                          // k_tun_chunk_sums ran before: the stream's quarter SUMS, not yet offsets - add up
+	if(sums_only) {                                          // k_tun_chunk_sums ran before: the stream's quarter SUMS, not yet offsets - add up
 		CRT_GLOBAL const uint64_t *qs = as_global(chunk_out) + (size_t)st.chunk0*4;   // the ones in front of this wave's quarter (<= 1 024 of them: the
 		const uint32_t nq = (c - st.chunk0)*4u + w;                          // planner sends longer streams through k_tun_stream_scan)
 		uint64_t acc = 0;
@@ -677,40 +623,13 @@ __device__ __forceinline__ void tun_staged_body(const TunStream &st, const TunTa
 	if(pending) write_pending();
 }
 
-// Three kernels, each launched over all chunks (a workgroup whose stream belongs to another kernel leaves at once): words of at
-// most 4 bytes, of at most 8, and the rest (which picks its step size by the stream).  Separate kernels, not branches of one,
-// because they want different resources: the 4-byte kernel (most log streams) needs a 2 KB window per wave and 67 VGPRs, so
-// eight of its workgroups fit a CU where the long-word kernel (6 KB windows, up to 128 VGPRs) fits four - and this kernel is
-// latency-bound, waves in flight are what it runs on.
-template <int W>
-__global__ __launch_bounds__(256) void k_tun_decode_staged(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
-                                                           uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                           uint64_t *chunk_out, uint32_t single_pass) {
-	const uint32_t c = blockIdx.x;
-	if(blockIdx.x >= nchunks) return;
-	const TunStream st = streams[chunk_stream[c]];
-	const TunTable &T = tables[st.table];
-	if(tun_width(st.cpl, T.maxlen) != (uint32_t)W) return;
-	__shared__ TunLds L;
-	__shared__ __attribute__((aligned(16))) uint32_t t16[256*(W == 1 ? 2 : W)];
-	__shared__ uint32_t longbuf[W == 4 ? 4 : 1][TUN_LONGQ];
-	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];                   // [4][(TUN_WIN + 64)/4]: 16 bytes of slack in front, 48 behind
-	__shared__ uint64_t share[9];                                                       // single pass: look-back scratch, the four quarters' bytes, a recomputed predecessor's
-	if constexpr(W != 4) tun_staged_body<W, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-	else {
-		if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-		else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-		else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-		else tun_staged_body<4, 1>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-	}
-}
-
-// all three word-width classes in ONE launch: a workgroup runs the body of its stream's class.  Registers and LDS are the long-word
-// class's (the others' are within a few registers of it), and the launch has neither the two extra grids of workgroups that leave at
-// once nor the two under-filled tails between the classes.
+// Words of at most 4 bytes, of at most 8, and the rest (which picks its step size by the stream) are three bodies of ONE kernel: a
+// workgroup runs the body of its stream's class.  Registers and LDS are the long-word class's (the others' are within a few registers of
+// it); round 1's three launches - one kernel per class over all chunks, workgroups of another class leaving at once - had two extra grids
+// of workgroups and two under-filled tails between the classes (removed in round 4).
 __global__ __launch_bounds__(256) void k_tun_decode_staged_any(const TunStream *__restrict__ streams, const uint32_t *__restrict__ chunk_stream,
                                                                uint32_t nchunks, const TunTable *__restrict__ tables,
-                                                               uint64_t *chunk_out, uint32_t single_pass) {
+                                                               uint64_t *chunk_out, uint32_t sums_only) {
 	const uint32_t c = blockIdx.x;
 	if(blockIdx.x >= nchunks) return;
 	const TunStream st = streams[chunk_stream[c]];
@@ -720,26 +639,20 @@ __global__ __launch_bounds__(256) void k_tun_decode_staged_any(const TunStream *
 	__shared__ __attribute__((aligned(16))) uint32_t t16[256*4];
 	__shared__ uint32_t longbuf[4][TUN_LONGQ];
 	extern __shared__ __attribute__((aligned(16))) uint32_t winbuf[];
-	__shared__ uint64_t share[9];
-	if(W == 1) tun_staged_body<1, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, (uint32_t (*)[TUN_LONGQ])longbuf, winbuf, share);
-	else if(W == 2) tun_staged_body<2, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, (uint32_t (*)[TUN_LONGQ])longbuf, winbuf, share);
-	else if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-	else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-	else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
-	else tun_staged_body<4, 1>(st, T, c, chunk_out, single_pass, nchunks, L, t16, longbuf, winbuf, share);
+	if(W == 1) tun_staged_body<1, 8>(st, T, c, chunk_out, sums_only, L, t16, (uint32_t (*)[TUN_LONGQ])longbuf, winbuf);
+	else if(W == 2) tun_staged_body<2, 8>(st, T, c, chunk_out, sums_only, L, t16, (uint32_t (*)[TUN_LONGQ])longbuf, winbuf);
+	else if(st.cpl == 8) tun_staged_body<4, 8>(st, T, c, chunk_out, sums_only, L, t16, longbuf, winbuf);
+	else if(st.cpl == 4) tun_staged_body<4, 4>(st, T, c, chunk_out, sums_only, L, t16, longbuf, winbuf);
+	else if(st.cpl == 2) tun_staged_body<4, 2>(st, T, c, chunk_out, sums_only, L, t16, longbuf, winbuf);
+	else tun_staged_body<4, 1>(st, T, c, chunk_out, sums_only, L, t16, longbuf, winbuf);
 }
 
-// host side: the three launches.  They touch disjoint chunks, so they run side by side on three HIP streams (fork / join with
-// events around them): the tail of one class's chunks overlaps the body of the next.  single_pass 1: the chunk state words
-// (chunk_out[0 .. nchunks], zeroed by the caller) carry the look-back; otherwise chunk_out holds the scanned quarter offsets.
-int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                             uint64_t *chunk_out, uint32_t single_pass) {
-#define TUN_LAUNCH(W_, S_) hipLaunchKernelGGL((k_tun_decode_staged<W_>), dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<W_, 8>()), S_, \
-                                          streams, chunk_stream, nchunks, tables, chunk_out, single_pass)
-	if(q.one_launch) hipLaunchKernelGGL(k_tun_decode_staged_any, dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<4, 8>()), q.main, streams, chunk_stream, nchunks, tables, chunk_out, single_pass);
-	else { TUN_LAUNCH(1, q.main); TUN_LAUNCH(2, q.main); TUN_LAUNCH(4, q.main); }
+// sums_only != 0: chunk_out holds every quarter's decoded SIZE (k_tun_chunk_sums) and a wave adds up the ones in front of its own (streams
+// of at most 256 chunks); 0: chunk_out holds the scanned offsets (k_tun_stream_scan ran in between)
+int launch_tun_decode_staged(hipStream_t stream, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                             uint64_t *chunk_out, uint32_t sums_only) {
+	hipLaunchKernelGGL(k_tun_decode_staged_any, dim3(nchunks), dim3(256), tun_staged_lds(tun_win_bytes<4, 8>()), stream, streams, chunk_stream, nchunks, tables, chunk_out, sums_only);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
-#undef TUN_LAUNCH
 }
 
 // memset path: single-symbol streams (tunstall.cpp:433-436)

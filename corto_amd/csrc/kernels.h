@@ -7,7 +7,7 @@
 namespace corto_hip {
 
 // k_tunstall.hip
-__global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables, uint64_t *lookback_state, uint32_t lookback_words);   // lookback_state: null, or the chunk state words to clear
+__global__ void k_tun_tables(const TunStream *streams, uint32_t nstreams, TunTable *tables);
 __global__ void k_tun_stream(const TunStream *streams, uint32_t nstreams);   // short streams: dictionary + decode by one wave, the dictionary never leaves LDS
 __global__ void k_tun_stream_grouped(const TunStream *streams, const uint32_t *ids, const TunGroup *groups, uint32_t ngroups, const TunTable *tables);   // ... streams of ONE dictionary, up to TUN_GROUP_MAX per workgroup, from one copy of it in LDS
 __global__ void k_tun_stream_scan(const TunStream *streams, uint32_t nstreams, uint64_t *chunk_out);   // one stream's quarter sums -> its quarter offsets (one workgroup per stream)
@@ -18,9 +18,8 @@ __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_str
 // Dwords of a word's zero-padded copy the staged decode composes from (k_tunstall.hip): by the dictionary's longest word;
 // steps of fewer than 8 codewords per lane (mean word length > 8) are only compiled for 4.
 __host__ __device__ inline uint32_t tun_width(uint32_t cpl, uint32_t maxlen) { return cpl < 8 || maxlen > 8 ? 4u : maxlen > 4 ? 2u : 1u; }
-struct TunLaunch { hipStream_t main; bool one_launch; };   // one_launch: all three word-width classes in one kernel (the default); else one kernel per class
-int launch_tun_decode_staged(const TunLaunch &q, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
-                             uint64_t *chunk_out, uint32_t single_pass);    // words <= 4 bytes, <= 8 bytes, longer: one kernel, or three
+int launch_tun_decode_staged(hipStream_t stream, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
+                             uint64_t *chunk_out, uint32_t sums_only);    // words <= 4 bytes, <= 8 bytes, longer: three bodies of one kernel
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
 __global__ void k_fill_block(uint8_t *dst, uint64_t bytes, uint32_t value);
 
@@ -64,29 +63,17 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of k_delta_mesh's workgroup for one (blob, attribute) too big for LDS; half of them up to DELTA_SMALL_NVERT vertices
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs);
-// one workgroup per blob, one wave per attribute (up to four), when the attributes' values + the prediction graph fit LDS (k_mesh.hip):
-// values of every attribute | a u16 | b,c u32 | stretch-start bits + their prefix counts | fired bits per attribute.  (The stretch list and
-// the fired flags serve the walk that takes over where the scans give up; as 2 + 1 bytes per vertex they were 10.5 KB of a C4 blob's 74 KB
-// for a path regular meshes never take - as bitmaps they are 1.2 KB, and 14 % less LDS per workgroup is 4 % more pipelined throughput.)
-constexpr uint32_t DELTA_WAVE_LDS_MAX = 128*1024, DELTA_GROUP_MAX = 4;
-__host__ __device__ inline uint32_t delta_wave_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return ((nvert*N*(is_u8 ? 1u : 4u) + 15u) & ~15u) + 32u; }
-__host__ __device__ inline uint32_t delta_wave_a_bytes(uint32_t nvert) { return (2u*nvert + 15u) & ~15u; }
+constexpr uint32_t DELTA_GROUP_MAX = 4;
 __host__ __device__ inline uint32_t delta_wave_bit_words(uint32_t nvert) { return ((nvert + 63u) >> 6) << 1; }                   // whole 64-vertex rounds
-__host__ __device__ inline uint32_t delta_wave_fired_bytes(uint32_t nvert) { return (delta_wave_bit_words(nvert)*4u + 15u) & ~15u; }
-__host__ __device__ inline uint32_t delta_wave_starts_bytes(uint32_t nvert) { return delta_wave_fired_bytes(nvert) + (((delta_wave_bit_words(nvert) + 1u)*2u + 15u) & ~15u); }   // bits + u16 prefix counts
-// LDS of the shared graph (+64 slack) and of one attribute riding on it; ~0 when the vertex ids do not fit 16 bits
-__host__ __device__ inline uint64_t delta_wave_graph_lds(uint32_t nvert) { return nvert > 65534u ? ~0ull : (uint64_t)delta_wave_a_bytes(nvert) + delta_wave_starts_bytes(nvert) + 4ull*nvert + 64; }
-__host__ __device__ inline uint64_t delta_wave_attr_lds(uint32_t nvert, uint32_t N, bool is_u8) {
-	if(nvert > 65534u || (uint64_t)nvert*N > (1u << 24)) return ~0ull;
-	return (uint64_t)delta_wave_vbytes(nvert, N, is_u8) + delta_wave_fired_bytes(nvert);
-}
 struct DeltaGroup { uint32_t first, count; };     // DeltaJob entries [first, first + count) of one blob
-__global__ void k_delta_wave(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
-// k_delta.hip: the same division of labour with 16-bit values relative to vertex 0 (bytes for colours), a 4-byte graph word and one
-// out-of-order window loop.  Records: 2 / 4 / 8 / 8 bytes for 1 / 2 / 3 / 4 int16 components, 4 bytes for up to four colour bytes.
+// k_delta.hip: one workgroup per blob, one wave per attribute (up to four) + one that builds the prediction graph they share: 16-bit values
+// relative to vertex 0 (bytes for colours), a 4-byte graph word and one out-of-order window loop.  Records: 2 / 4 / 8 / 8 bytes for 1 / 2 / 3 / 4 int16 components, 4 bytes for up to four colour bytes.
 constexpr uint32_t DELTA16_LDS_MAX = 128*1024, DELTA16_NVERT_MAX = 32767;
 __host__ __device__ inline uint32_t delta16_rec(uint32_t N, bool is_u8) { return is_u8 ? 4u : N == 1 ? 2u : N == 2 ? 4u : 8u; }
 __host__ __device__ inline uint32_t delta16_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return (nvert*delta16_rec(N, is_u8) + 15u) & ~15u; }
+// ... or 32-bit components (a context that met values beyond int16): records of 4 / 8 / 16 / 16 bytes; colours stay four bytes
+__host__ __device__ inline uint32_t delta_rec(uint32_t N, bool is_u8, bool wide) { return !wide || is_u8 ? delta16_rec(N, is_u8) : N == 1 ? 4u : N == 2 ? 8u : 16u; }
+__host__ __device__ inline uint32_t delta_vbytes(uint32_t nvert, uint32_t N, bool is_u8, bool wide) { return (nvert*delta_rec(N, is_u8, wide) + 15u) & ~15u; }
 __host__ __device__ inline bool delta16_eligible(uint32_t nvert, uint32_t N, bool is_u8) { return nvert <= DELTA16_NVERT_MAX && N >= 1 && N <= 4 && (is_u8 || true); }
 // graph: 4 bytes a vertex + (unless a three-component int16 attribute of the group lends its spare halfwords) 2 bytes a vertex of `a`
 // ... + the walk's bookkeeping (k_delta.hip): stretch-start bits, then per wave (four) 64 words and a fired bitmap
@@ -95,12 +82,6 @@ __host__ __device__ inline uint32_t delta16_graph_lds(uint32_t nvert, bool a_emb
 	return ((4u*nvert + 15u) & ~15u) + (a_embedded ? 0u : ((2u*nvert + 15u) & ~15u)) + delta16_walk_shared(nvert) + 4u*4u*(64u + delta_wave_bit_words(nvert)) + 16u;
 }
 __global__ void k_delta_lds16(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
-// ... attributes that only use `a` (no parallelogram: a tree): pointer jumping, 32-bit values (or four bytes) + a u16 ancestor per vertex in LDS
-constexpr uint32_t DELTA_TREE_LDS_MAX = 64*1024, DELTA_TREE_NVERT_MAX = 32767;
-__host__ __device__ inline uint32_t delta_tree_vbytes(uint32_t nvert, uint32_t N, bool is_u8) { return (nvert*4u*(is_u8 ? 1u : N) + 15u) & ~15u; }
-__host__ __device__ inline uint32_t delta_tree_lds(uint32_t nvert, uint32_t N, bool is_u8) { return delta_tree_vbytes(nvert, N, is_u8) + ((2u*nvert + 15u) & ~15u) + 16u; }
-__global__ void k_delta_tree(const DeltaJob *jobs, uint32_t njobs);
-__global__ void k_delta_global(const DeltaJob *jobs, uint32_t njobs);      // experiment: the same loop with no LDS (values and graph in HBM / L2), one wave per attribute
 
 // k_normal.hip
 __global__ void k_normal_diff(const NormalJob *jobs, const uint32_t *block_job, const uint32_t *block_first, uint32_t nblocks);

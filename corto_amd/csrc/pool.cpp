@@ -42,26 +42,18 @@ struct Lane {                       // one context = one batch in flight
 	uint64_t step = 0;              // its global step number
 	bool busy = false;
 	bool poisoned = false;          // the output block was filled with POISON on the context's stream right before the step in flight / last executed
-	int upload = -1;                // the feeder slot whose arena the step in flight reads (-1: the item was resident, or the library uploaded it)
+	// host-resident items (SURVEY.md 8d's primary region: .crt blobs in pinned host memory -> decoded outputs in HBM): two arenas in HBM that
+	// take turns, and the lane's NEXT ticket.  The blobs of the next step are queued for upload on the lane's OWN stream right behind the
+	// kernels of the step just launched: they cross PCIe while the lane would otherwise sit idle waiting for its host thread to come round
+	// again (a thread serves `depth` lanes, ~200 us of host work each), the step's kernels find them resident, and no second stream or event
+	// is involved (round 4 measured a copy stream per thread with events: 0.125 ms a step instead of 0.096 - cross-stream waits on sixteen
+	// busy queues - and the copy at the head of the step itself, round 3's way: 0.096 against 0.080 with resident inputs).
+	struct Upload { void *dev = nullptr; size_t cap = 0; void *pin = nullptr; size_t pin_cap = 0; } up[2];   // pin: gathering image for blobs scattered over host memory
+	int cur = -1;                   // the arena the step in flight / last executed reads (-1: resident item, or uploaded by the library itself)
+	bool has_next = false;          // a ticket drawn ahead for this lane: its upload is queued (or it needs none)
+	uint64_t next_step = 0; uint32_t next_item = 0; int next_buf = -1;
 };
 constexpr int POISON = 0xA5;
-
-// Host-resident items (SURVEY.md 8d's primary region: .crt blobs in pinned host memory -> decoded outputs in HBM).  Every worker thread owns
-// a COPY stream and depth + 1 arena buffers in its GPU's HBM: the blobs of the step a thread is about to run go up on the copy stream while
-// the thread still waits for one of its contexts to finish the step before, and the context that takes the step only waits for the upload's
-// event - the 3.7 MB of a C4 batch cross PCIe under other batches' kernels instead of at the head of their own context's stream (round 3:
-// the upload sat in front of the context's kernels and cost a from-host step 15-30 us).  A buffer is reused once the step that read it has
-// been harvested.
-struct Upload {
-	void *dev = nullptr; size_t cap = 0;       // arena in HBM
-	void *pin = nullptr; size_t pin_cap = 0;   // pinned image, for blobs that are scattered over (pageable) host memory
-	hipEvent_t ready = nullptr;                // recorded behind the copy
-	bool in_use = false;                       // being uploaded to, or read by a step in flight
-};
-struct Feeder {                                // one per worker thread
-	hipStream_t copy = nullptr;
-	std::vector<Upload> slots;
-};
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -73,9 +65,8 @@ struct crthip_pool {
 	std::vector<Lane> lanes;        // [device][thread][depth]
 	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
 	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
-	std::vector<Feeder> feeders;    // [device][thread]
 	bool packed_host = false;       // crthip_pool_set_packed_host_blobs: items whose blobs lie in one pinned buffer in arena layout go up from there
-	bool prefetch = true;           // $CORTO_POOL_PREFETCH=0: uploads at the head of the context's own stream, by the library (round 3's path)
+	bool prefetch = true;           // $CORTO_POOL_PREFETCH=0: a step's blobs go up at the head of the step itself (crthip_batch_reset's own upload: round 3's path)
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
 	std::mutex m;
@@ -87,10 +78,9 @@ static void destroy_lane(Lane &L) {
 	if(L.batch) crthip_batch_destroy(L.batch);
 	if(L.ctx) crthip_ctx_destroy(L.ctx);
 	if(L.out) (void)hipFree(L.out);
+	for(auto &U : L.up) { if(U.dev) (void)hipFree(U.dev); if(U.pin) (void)hipHostFree(U.pin); U = Lane::Upload{}; }
 	L.batch = nullptr; L.ctx = nullptr; L.out = nullptr; L.out_cap = 0;
 }
-
-static void destroy_feeders(crthip_pool *p);
 
 extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_t threads_per_device, uint32_t depth, crthip_pool **out) {
 	if(!out || ndevices == 0 || ndevices > 16 || threads_per_device == 0 || depth == 0 || threads_per_device*depth > 64) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
@@ -123,14 +113,6 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 			fprintf(stderr, "%s\n", buf);
 		}
 	{ const char *e = getenv("CORTO_POOL_PREFETCH"); p->prefetch = !(e && e[0] == '0'); }
-	p->feeders.resize((size_t)ndevices*threads_per_device);
-	for(size_t f = 0; f < p->feeders.size(); f++) {
-		Feeder &F = p->feeders[f];
-		bool ok = hipSetDevice(p->devices[f/threads_per_device]) == hipSuccess && hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking) == hipSuccess;
-		F.slots.resize(depth + 1);
-		for(Upload &U : F.slots) ok = ok && hipEventCreateWithFlags(&U.ready, hipEventDisableTiming) == hipSuccess;
-		if(!ok) { for(auto &x : p->lanes) destroy_lane(x); destroy_feeders(p); delete p; return ctx_fail(CRTHIP_E_DEVICE, "crthip_pool_create: copy stream / events"); }
-	}
 	// the host CPUs next to each GPU: PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist
 	p->cpus.resize(ndevices);
 	for(uint32_t d = 0; d < ndevices; d++) {
@@ -157,25 +139,9 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 	return CRTHIP_OK;
 }
 
-static void destroy_feeders(crthip_pool *p) {
-	for(size_t f = 0; f < p->feeders.size(); f++) {
-		Feeder &F = p->feeders[f];
-		(void)hipSetDevice(p->devices[f/p->threads_per_device]);
-		if(F.copy) (void)hipStreamSynchronize(F.copy);
-		for(Upload &U : F.slots) {
-			if(U.dev) (void)hipFree(U.dev);
-			if(U.pin) (void)hipHostFree(U.pin);
-			if(U.ready) (void)hipEventDestroy(U.ready);
-		}
-		if(F.copy) (void)hipStreamDestroy(F.copy);
-	}
-	p->feeders.clear();
-}
-
 extern "C" void crthip_pool_destroy(crthip_pool *p) {
 	if(!p) return;
 	for(auto &L : p->lanes) destroy_lane(L);
-	destroy_feeders(p);
 	delete p;
 }
 
@@ -194,17 +160,14 @@ extern "C" int crthip_pool_set_packed_host_blobs(crthip_pool *p, int on) {
 	return CRTHIP_OK;
 }
 
-// plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
-// enqueue the upload of an item's blobs into a free slot of the thread's feeder (on its copy stream, nobody waits); returns the slot or < 0
-static int feeder_upload(crthip_pool *p, Feeder &F, const crthip_pool_item &it, std::vector<uint64_t> &offs, int *slot_out) {
-	int k = -1;
-	for(size_t i = 0; i < F.slots.size(); i++) if(!F.slots[i].in_use) { k = (int)i; break; }
-	if(k < 0) return ctx_fail(CRTHIP_E_ARGUMENT, "pool: no free upload slot");       // (cannot happen: depth + 1 slots, depth steps in flight)
-	Upload &U = F.slots[(size_t)k];
+// queue the upload of an item's blobs into arena `buf` of the lane, on the lane's own stream (nobody waits: what is queued behind it on
+// that stream is ordered after it)
+static int lane_upload(crthip_pool *p, Lane &L, const crthip_pool_item &it, int buf, std::vector<uint64_t> &offs) {
+	Lane::Upload &U = L.up[buf];
 	offs.resize(it.nblobs);
 	const uint64_t total = crthip_arena_layout(it.nblobs, it.lens, offs.data());
 	if(total + 16 > U.cap) {
-		if(U.dev) (void)hipFree(U.dev);
+		if(U.dev) { (void)hipStreamSynchronize(corto_hip::ctx_stream(L.ctx)); (void)hipFree(U.dev); }
 		U.dev = nullptr; U.cap = 0;
 		const size_t want = (size_t)(total + total/4 + 4096);
 		if(hipMalloc(&U.dev, want) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
@@ -216,9 +179,9 @@ static int feeder_upload(crthip_pool *p, Feeder &F, const crthip_pool_item &it, 
 	size_t bytes = (size_t)total;
 	if(in_place) { src = it.blobs[0]; bytes = (size_t)(offs[it.nblobs - 1] + it.lens[it.nblobs - 1]); }
 	else {
-		// (the slot's previous upload from this image has completed: its reader was harvested before the slot came free)
+		// (this image's previous upload is through: it fed the lane's step before last, which was harvested before the last one started)
 		if(total + 16 > U.pin_cap) {
-			if(U.pin) (void)hipHostFree(U.pin);
+			if(U.pin) { (void)hipStreamSynchronize(corto_hip::ctx_stream(L.ctx)); (void)hipHostFree(U.pin); }
 			U.pin = nullptr; U.pin_cap = 0;
 			const size_t want = (size_t)(total + total/4 + 4096);
 			if(hipHostMalloc(&U.pin, want, hipHostMallocDefault) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
@@ -227,13 +190,11 @@ static int feeder_upload(crthip_pool *p, Feeder &F, const crthip_pool_item &it, 
 		for(uint32_t i = 0; i < it.nblobs; i++) memcpy((uint8_t *)U.pin + offs[i], it.blobs[i], it.lens[i]);
 		src = U.pin;
 	}
-	if(bytes && hipMemcpyAsync(U.dev, src, bytes, hipMemcpyHostToDevice, F.copy) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, "pool: hipMemcpyAsync(H2D)");
-	if(hipEventRecord(U.ready, F.copy) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, "pool: hipEventRecord");
-	U.in_use = true;
-	*slot_out = k;
+	if(bytes && hipMemcpyAsync(U.dev, src, bytes, hipMemcpyHostToDevice, corto_hip::ctx_stream(L.ctx)) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, "pool: hipMemcpyAsync(H2D)");
 	return CRTHIP_OK;
 }
 
+// plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
 static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id, const void *uploaded = nullptr) {
 	const void *arena = uploaded ? uploaded : it.device_arena ? it.device_arena[L.slot] : nullptr;
 	int err = L.batch ? crthip_batch_reset(L.batch, it.nblobs, it.blobs, it.lens, arena)
@@ -321,15 +282,13 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			(void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (a cpuset that forbids them: stay where we are)
 		}
 		Lane *mine = &p->lanes[((size_t)slot*p->threads_per_device + t)*p->depth];
-		Feeder &F = p->feeders[(size_t)slot*p->threads_per_device + t];
-		for(Upload &U : F.slots) U.in_use = false;
+		for(uint32_t k = 0; k < p->depth; k++) { mine[k].has_next = false; mine[k].cur = -1; }
 		std::vector<uint64_t> offs;
 		auto tick = [] { return std::chrono::steady_clock::now(); };
 		auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
 		auto finish = [&](Lane &L) -> int {
 			const int rc = crthip_batch_sync(L.batch, L.status.data());
 			L.busy = false;
-			if(L.upload >= 0) { F.slots[(size_t)L.upload].in_use = false; L.upload = -1; }   // its arena has been read
 			const uint64_t c = ++p->completed;                   // completion order
 			if(c <= timed_end) stamps[c] = now_s();
 			uint64_t bad = 0;
@@ -341,13 +300,26 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(rc == CRTHIP_E_DEVICE || rc == CRTHIP_E_NOMEM) return rc;
 			return CRTHIP_OK;
 		};
-		// an item that is not resident on this device goes up on the thread's copy stream; the context that decodes it waits for the event
+		// an item that is not resident on this device goes up into one of the lane's two arenas
 		auto needs_upload = [&](uint32_t j) { return p->prefetch && !(items[j].device_arena && items[j].device_arena[slot]); };
-		auto start = [&](Lane &L, uint32_t j, int up, bool poison) -> int {       // plan item j on the lane and enqueue its decode
+		auto upload = [&](Lane &L, uint32_t j, int buf) -> int {
+			const auto u0 = tick();
+			const int e = lane_upload(p, L, items[j], buf, offs);
+			const uint64_t ns = ns_since(u0);
+			upload_ns += ns; host_ns += ns;
+			return e;
+		};
+		auto draw = [&](uint64_t &step, uint32_t &j) -> bool {
+			step = p->next.fetch_add(1);
+			if(step >= total) return false;
+			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
+			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
+			return true;
+		};
+		auto start = [&](Lane &L, uint32_t j, int buf, bool poison) -> int {       // plan item j on the lane (its blobs: arena `buf`, or resident) and enqueue its decode
 			const auto p0 = tick();
-			int e = lane_plan(p, L, items[j], (int64_t)j, up >= 0 ? F.slots[(size_t)up].dev : nullptr);
+			int e = lane_plan(p, L, items[j], (int64_t)j, buf >= 0 ? L.up[buf].dev : nullptr);
 			plan_ns += ns_since(p0);
-			if(!e && up >= 0 && hipStreamWaitEvent(corto_hip::ctx_stream(L.ctx), F.slots[(size_t)up].ready, 0) != hipSuccess) e = ctx_fail(CRTHIP_E_DEVICE, "pool: hipStreamWaitEvent");
 			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
 			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
 			L.poisoned = false;
@@ -356,34 +328,27 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 				if(!e) L.poisoned = true;
 			}
 			if(!e) e = crthip_batch_decode(L.batch);
-			if(!e) { L.busy = true; L.upload = up; }
-			else if(up >= 0) { (void)hipStreamSynchronize(F.copy); F.slots[(size_t)up].in_use = false; }
+			if(!e) { L.busy = true; L.cur = buf; }
 			return e;
 		};
 		int err = CRTHIP_OK;
+		bool exhausted = false;                                  // no tickets left to draw
 		for(uint64_t n = 0; !err; n++) {
-			// the ticket first: its blobs cross PCIe while this thread waits for one of its contexts
-			const uint64_t step = p->next.fetch_add(1);
-			if(step >= total) break;
-			uint32_t j;
-			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
-			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
-			int up = -1;
-			if(needs_upload(j)) {
-				const auto u0 = tick();
-				err = feeder_upload(p, F, items[j], offs, &up);
-				const uint64_t ns = ns_since(u0);
-				upload_ns += ns; host_ns += ns;
-				if(err) break;
-			}
 			const auto w0 = tick();
-			// the next lane to refill: a free one, else whichever of the busy ones finishes first (they mostly finish in the order they
-			// were launched, but a thread that waited on the oldest while a younger one was done left that context idle)
-			uint32_t pick = p->depth;
-			for(uint32_t k = 0; k < p->depth && pick == p->depth; k++) if(!mine[(n + k) % p->depth].busy) pick = (uint32_t)((n + k) % p->depth);
+			// the next lane to (re)fill: a free one that has work (its own ticket waiting, or tickets left to draw), else whichever of the
+			// busy ones finishes first (they mostly finish in the order they were launched, but a thread that waited on the oldest while a
+			// younger one was done left that context idle)
+			uint32_t pick = p->depth, nbusy = 0;
+			for(uint32_t k = 0; k < p->depth; k++) {
+				Lane &C = mine[(n + k) % p->depth];
+				if(C.busy) nbusy++;
+				else if(pick == p->depth && (C.has_next || !exhausted)) pick = (uint32_t)((n + k) % p->depth);
+			}
+			if(pick == p->depth && !nbusy) break;                   // nothing in flight, nothing to start
 			for(uint32_t spins = 0; pick == p->depth && !err; spins++) {
 				for(uint32_t k = 0; k < p->depth; k++) {
 					Lane &C = mine[(n + k) % p->depth];
+					if(!C.busy) continue;
 					const int d = crthip_batch_done(C.batch);
 					if(d < 0) { err = d; break; }
 					if(d) { pick = (uint32_t)((n + k) % p->depth); break; }
@@ -397,12 +362,28 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(L.busy) err = finish(L);
 			finish_ns += ns_since(f0);
 			if(err) break;
+			// the lane's own ticket (its blobs went up behind its last step's kernels), else a fresh one
+			uint64_t step; uint32_t j; int buf = -1;
 			const auto h0 = tick();
-			err = start(L, j, up, step >= poison_from);
-			host_ns += ns_since(h0); host_steps++;
+			if(L.has_next) { step = L.next_step; j = L.next_item; buf = L.next_buf; L.has_next = false; }
+			else {
+				if(exhausted || !draw(step, j)) { exhausted = true; continue; }
+				if(needs_upload(j)) { buf = L.cur == 0 ? 1 : 0; err = upload(L, j, buf); if(err) break; }
+			}
+			err = start(L, j, buf, step >= poison_from);
 			if(!err) L.step = step;
+			// ... and the ticket behind it: its upload is queued behind this step's kernels, on the lane's own stream
+			if(!err && p->prefetch && !exhausted) {
+				uint64_t step2; uint32_t j2;
+				if(!draw(step2, j2)) exhausted = true;
+				else {
+					int b2 = -1;
+					if(needs_upload(j2)) { b2 = buf == 0 ? 1 : 0; err = upload(L, j2, b2); }
+					if(!err) { L.has_next = true; L.next_step = step2; L.next_item = j2; L.next_buf = b2; }
+				}
+			}
+			host_ns += ns_since(h0); host_steps++;
 		}
-		if(err) (void)hipStreamSynchronize(F.copy);
 		for(uint32_t k = 0; k < p->depth; k++) if(mine[k].busy) { const int e2 = finish(mine[k]); if(!err) err = e2; }
 		// a context whose thread drew none of the last 2 x lanes tickets (descheduled while the others emptied the queue: seen with
 		// 32-blob items) repeats its last step from a poisoned block, behind the timed region: what lane_read returns is then ALWAYS
@@ -413,9 +394,12 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(!L.out && L.item >= 0) continue;
 			// ... and one that drew no ticket at all (a 28-step run on a cold box) decodes its device's first item
 			const uint32_t j = L.item >= 0 ? (uint32_t)L.item : home[slot].empty() ? 0u : home[slot][0];
-			int up = -1;
-			if(needs_upload(j)) err = feeder_upload(p, F, items[j], offs, &up);     // (the arena its last step read may have been reused since)
-			if(!err) err = start(L, j, up, true);
+			int buf = -1;
+			if(needs_upload(j)) {
+				if(L.item >= 0 && L.cur >= 0) buf = L.cur;           // (its last step's arena: untouched since)
+				else { buf = 0; err = upload(L, j, buf); }
+			}
+			if(!err) err = start(L, j, buf, true);
 			if(!err) err = finish(L);
 		}
 		if(err) {

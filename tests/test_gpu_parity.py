@@ -89,7 +89,7 @@ def test_heterogeneous_batch(ctx):
 def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
     """K-BIT has two kernels: the log streams of a small bit block (<= 16 384 logs) take one wave each, lanes interleaved over the
     vertices, the bits in front of a stream re-added from the earlier streams' logs (k_unpack_wave); larger blocks go in chunks of
-    1 024 with look-back (k_unpack_extract; $CORTO_EXP_UNPACK_CHUNKED=1 sends everything there).  Same bytes from both, and the
+    1 024 with look-back (k_unpack_extract; $CORTO_UNPACK_CHUNKED=1 sends everything there).  Same bytes from both, and the
     oracle's: ragged sizes around the 64-lane round and the 512-log block, 1..4 fields per log, u8 and int32 outputs, a cloud."""
     from corto_amd import synth
     meshes = [synth.bumpy_sphere(nu, nv, seed=nu) for nu, nv in ((3, 2), (7, 3), (8, 7), (9, 7), (21, 3), (32, 15), (32, 16), (33, 16), (64, 32), (70, 60), (127, 120))]
@@ -100,7 +100,7 @@ def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
         blobs.append(ca.encode(m, **kw))
     refs = [oc.decode(b, color_components=4) for b in blobs]
     for chunked in ("0", "1"):
-        monkeypatch.setenv("CORTO_EXP_UNPACK_CHUNKED", chunked)
+        monkeypatch.setenv("CORTO_UNPACK_CHUNKED", chunked)
         c = ca.Context(0)
         b = run_batch(c, blobs, color_components=4)
         for i, r in enumerate(refs):
@@ -108,13 +108,12 @@ def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
         b.close(); c.close()
 
 
-@pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_EXP_DELTA_GLOBAL": "1"}, {"CORTO_EXP_NO_DEQ_FOLD": "1"}, {"CORTO_EXP_DELTA_GROUP": "1"},
-                                 {"CORTO_EXP_NORMAL_FN_MAX": "0"}, {"CORTO_EXP_NORMAL_FN_MAX": "150000"}, {"CORTO_EXP_UNPACK_TWICE": "1"}, {"CORTO_EXP_DELTA_TREE": "1"},
-                                 {"CORTO_EXP_LDS_PAD_DELTA": "8", "CORTO_EXP_LDS_PAD_TOPO": "8", "CORTO_EXP_LDS_PAD_NORMAL": "8"}],
+@pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_UNPACK_CHUNKED": "1"}, {"CORTO_DELTA_WIDE": "1", "CORTO_TUN_SHARE": "2"}],
                          ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
-def test_experiment_switches_are_bit_exact(monkeypatch, env):
-    """csrc/debug_config.h: every experiment switch selects other kernels or other launch geometry for the same bytes - every fixture and
-    the 16 C4 blobs through each of them (the Tunstall and unpack switches have their own tests above and below)"""
+def test_context_settings_are_bit_exact(monkeypatch, env):
+    """csrc/debug_config.h: the settings a context reads select other kernel paths for the same bytes (32-bit records in K-DELTA's LDS -
+    what a context learns from values beyond int16 -, the chunked K-BIT, one dictionary per stream) - every fixture and the 16 C4 blobs
+    through each, on a two-stream and on a single-stream context.  (The experiment switches of rounds 2-3 were removed with their kernels.)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     z = np.load(os.path.join(GOLDEN, "c4_blobs16.npz"))
@@ -243,21 +242,21 @@ def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
 
 def test_vertex_counts_around_the_bitmap_words(monkeypatch):
     """K-DELTA's fallback walk keeps its fired flags and stretch starts as bitmaps (one dword per 32 vertices, written 64 vertices a round):
-    vertex counts on and around the word boundaries, tiny meshes, a long thin strip (2 049 vertices: 683 stretches) - with the walk
-    forced ($CORTO_EXP_DELTA_WALK=1), with the scans, and on a single-stream context (the LDS-lean normals path)"""
+    vertex counts on and around the word boundaries, tiny meshes, a long thin strip (2 049 vertices: 683 stretches) - with 16-bit and with
+    32-bit records in LDS ($CORTO_DELTA_WIDE=1), and on a single-stream context (the LDS-lean normals path)"""
     from corto_amd import synth
     meshes = [synth.bumpy_sphere(w, h, seed=w * h) for w, h in ((3, 2), (4, 3), (9, 6), (8, 7), (13, 4), (16, 7), (43, 2), (31, 32), (64, 31), (683, 2))]
     assert [m.nvert for m in meshes] == [9, 16, 63, 64, 65, 128, 129, 1023, 2048, 2049]
     blobs = [ca.encode(m, normal_prediction=ca.ESTIMATED if k % 2 else ca.BORDER) for k, m in enumerate(meshes)]
     refs = [oc.decode(b) for b in blobs]
     for walk, single in (("1", False), ("0", False), ("1", True), ("0", True)):
-        monkeypatch.setenv("CORTO_EXP_DELTA_WALK", walk)
+        monkeypatch.setenv("CORTO_DELTA_WIDE", walk)
         c = ca.Context(0)
         if single:
             c.set_single_stream(True)
         b = run_batch(c, blobs)
         for i, r in enumerate(refs):
-            assert_same(b.host_outputs(i), r, KEYS, "nvert %d walk=%s single=%s" % (meshes[i].nvert, walk, single))
+            assert_same(b.host_outputs(i), r, KEYS, "nvert %d wide=%s single=%s" % (meshes[i].nvert, walk, single))
         b.close(); c.close()
 
 
@@ -919,16 +918,12 @@ def test_tunstall_long_streams_on_four_contexts_at_once(ctx):
     for j in jobs: j[0].close()
 
 
-@pytest.mark.parametrize("env", [{}, {"CORTO_TUN_TWO_PASS": "1"}, {"CORTO_TUN_SINGLE_PASS": "1"}, {"CORTO_TUN_THREE_LAUNCHES": "1"}],
-                         ids=["sums+stream-scan", "sums+device-scan", "single-pass-lookback", "three-decode-launches"])
-def test_tunstall_long_stream_pipelines(monkeypatch, env):
-    """every way the long-stream path can find a chunk's output offset (k_tunstall.hip): quarter sums + a scan per stream (streams of more
-    than 256 chunks) or the decode waves adding up the sums in front of them (fewer), round 1's device-wide scan, the single pass with
-    wait-free look-back; one decode launch for all word-width classes or three.  A two-symbol dictionary with words up to 255 bytes
-    (hundreds of small chunks), a flat one, a short stream beside them."""
-    for k_, v in env.items():
-        monkeypatch.setenv(k_, v)
-    c = ca.Context(0)                                    # (the switches are read when a context is made)
+def test_tunstall_long_stream_pipelines():
+    """both ways the long-stream path finds a chunk's output offset (k_tunstall.hip): quarter sums + a scan per stream (streams of more
+    than 256 chunks) or the decode waves adding up the sums in front of them (fewer); one decode launch for all word-width classes.
+    A two-symbol dictionary with words up to 255 bytes (hundreds of small chunks), a flat one, a short stream beside them."""
+    env = {}
+    c = ca.Context(0)
     rng = np.random.default_rng(23)
     k = _kat()
     blocks, sizes, expect = [], [], []
