@@ -251,6 +251,10 @@ struct crthip_ctx {
 	bool delta_just_narrowed = false;                  // the narrow layout is on trial again after a wide spell (an overflow now doubles the patience)
 };
 
+// bytes per component of a generic attribute's caller buffer: upstream decodes in place as int32 whatever the format and DOUBLE widens
+// in place (include/corto/vertex_attribute.h:184-228), so every format's buffer is nvert*N*4 bytes but DOUBLE's
+static inline size_t generic_work_bytes(uint32_t format) { return format == CRTHIP_FMT_DOUBLE ? 8u : 4u; }
+
 struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
 
 struct BlobPlan {
@@ -327,6 +331,15 @@ int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value) {      /
 	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
 	hipLaunchKernelGGL(k_fill_block, dim3(2048), dim3(256), 0, ctx->stream, (uint8_t *)dst, (uint64_t)bytes, (uint32_t)(value & 255));
 	return hipGetLastError() == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE);
+}
+int ctx_copy_async(crthip_ctx *ctx, void *dst, const void *host_src, size_t bytes, int by_kernel) {   // pinned host memory -> HBM on the context's main stream
+	if(!bytes) return CRTHIP_OK;
+	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+	if(by_kernel && (((uintptr_t)dst | (uintptr_t)host_src) & 15) == 0) {
+		hipLaunchKernelGGL(k_copy_block, dim3(128), dim3(256), 0, ctx->stream, (const uint8_t *)host_src, (uint8_t *)dst, (uint64_t)bytes);
+		return hipGetLastError() == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE);
+	}
+	return hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE, "hipMemcpyAsync(H2D)");
 }
 int ctx_quiesce(crthip_ctx *ctx) {
 	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
@@ -533,11 +546,12 @@ static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
 		if(st && st < oc) return CRTHIP_E_ARGUMENT;
 		return CRTHIP_OK;
 	}
-	if(a.N < 1) return CRTHIP_E_FORMAT;
-	if(bd.format != CRTHIP_FMT_FLOAT) return CRTHIP_E_FORMAT;            // integer output formats: SURVEY a17, not on the device path
+	if(a.N < 1 || bd.format > CRTHIP_FMT_DOUBLE) return CRTHIP_E_FORMAT;
 	// a packed buffer doubles as the int32 workspace and K-DELTA turns it into floats with dword / 16-byte accesses: a float* that is
 	// not 4-byte aligned (never one a C++ caller's setPositions(float*) could pass) is refused, not decoded into integers
-	if(((uintptr_t)bd.buffer) % 4) return CRTHIP_E_ARGUMENT;
+	if(((uintptr_t)bd.buffer) % (bd.format == CRTHIP_FMT_DOUBLE ? 8 : 4)) return CRTHIP_E_ARGUMENT;
+	// the integer formats and DOUBLE (setAttribute(name, buffer, format): vertex_attribute.h:195-228) are upstream's in-place layouts: packed only
+	if(bd.format != CRTHIP_FMT_FLOAT) return st ? CRTHIP_E_ARGUMENT : CRTHIP_OK;
 	if(st && (st < 4*a.N || st % 4)) return CRTHIP_E_ARGUMENT;
 	return CRTHIP_OK;
 }
@@ -739,7 +753,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 			A.sym.resize(L.attrs[k].logs.size());
 			for(size_t j = 0; j < A.sym.size(); j++) need_stream(L.attrs[k].logs[j], A.sym[j]);
 			if(a.codec == CRTHIP_CODEC_COLOR) A.color = cv.take((uint64_t)L.h.nvert*a.N + 16, 16);
-			if(a.codec != CRTHIP_CODEC_COLOR && a.codec != CRTHIP_CODEC_NORMAL && bd.stride) A.vals = cv.take((uint64_t)L.h.nvert*a.N*4 + 16, 16);
+			if(a.codec != CRTHIP_CODEC_COLOR && a.codec != CRTHIP_CODEC_NORMAL && (bd.stride || bd.format == CRTHIP_FMT_DOUBLE)) A.vals = cv.take((uint64_t)L.h.nvert*a.N*4 + 16, 16);
 			if(a.codec == CRTHIP_CODEC_NORMAL) {
 				A.diffs = cv.take((uint64_t)L.h.nvert*8 + 16, 16);
 				if(mesh && L.attrs[k].normal_prediction != 0 && normal_fused(L.h.nvert, L.h.nface) && normal_blob_lds_fn(L.h.nvert, L.h.nface) > ctx->normal_fn_max)
@@ -882,7 +896,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 			for(size_t k = 0; k < L.attrs.size(); k++)
 				if(mesh && L.h.attrs[k].codec == CRTHIP_CODEC_NORMAL && P.bind[k].buffer && (L.attrs[k].normal_prediction == 1 || L.attrs[k].normal_prediction == 2)) readers++;
 			pos_ints_needed = readers > 0;
-			pos_by_normal = readers == 1 && normal_fused(nvert, nface);
+			pos_by_normal = readers == 1 && normal_fused(nvert, nface) && pos_k >= 0 && P.bind[pos_k].format == CRTHIP_FMT_FLOAT;
 		}
 
 		for(size_t k = 0; k < L.attrs.size(); k++) {
@@ -927,9 +941,11 @@ static int build_and_launch_inner(crthip_batch *b) {
 				for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], SP(A.color), false, 1, 1, (uint16_t)a.N, (uint16_t)c, 1);
 				values = SP(A.color); is_u8 = 1; para = (a.strategy & CRTHIP_PARALLEL) != 0;
 			} else {
-				// packed output: the caller's buffer is the int32 workspace (like upstream, vertex_attribute.h:190-193); with a stride: scratch
-				void *work = bd.stride ? (void *)SP(A.vals) : bd.buffer;
-				const bool work_real = !bd.stride;
+				// packed output: the caller's buffer is the int32 workspace (like upstream, vertex_attribute.h:190-193); with a stride, or as
+				// DOUBLE (eight bytes a value: upstream widens in place, front to back): scratch
+				const bool in_scratch = bd.stride || bd.format == CRTHIP_FMT_DOUBLE;
+				void *work = in_scratch ? (void *)SP(A.vals) : bd.buffer;
+				const bool work_real = !in_scratch;
 				if(a.strategy & CRTHIP_CORRELATED) push_unpack(as.logs[0], logs[0], work, work_real, 0, (uint16_t)a.N, (uint16_t)a.N, 0, 0);
 				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], work, work_real, 1, 1, (uint16_t)a.N, (uint16_t)c, 0);
 				values = work; values_real = work_real; para = (a.strategy & CRTHIP_PARALLEL) != 0;
@@ -947,7 +963,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;
 							for(int c = 0; c < 4; c++) d.qc[c] = as.qc[c];
 							dequantised = true;
-						} else if(!bd.stride && !((int)k == pos_k && pos_ints_needed)) { d.deq = 1; d.q = a.q; dequantised = true; }
+						} else if(!bd.stride && bd.format == CRTHIP_FMT_FLOAT && !((int)k == pos_k && pos_ints_needed)) { d.deq = 1; d.q = a.q; dequantised = true; }
 					}
 					pl.delta.v.push_back(d);
 				} else {
@@ -971,7 +987,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 					if(pr != 0) {
 						const bool pos_ok = pos_k >= 0 && L.h.attrs[pos_k].codec == CRTHIP_CODEC_GENERIC && L.h.attrs[pos_k].N == 3 && P.bind[pos_k].buffer;
 						if(!pos_ok) { P.host_status = CRTHIP_E_NORMAL_NEEDS_POSITION; continue; }
-						const bool pos_scratch = P.bind[pos_k].stride != 0;               // the integer positions: in the caller's packed buffer, or in scratch
+						const bool pos_scratch = P.bind[pos_k].stride != 0 || P.bind[pos_k].format == CRTHIP_FMT_DOUBLE;   // the integer positions: in the caller's packed buffer, or in scratch
 						n.position = pos_scratch ? (const int32_t *)SP(S.attr[pos_k].vals) : (const int32_t *)P.bind[pos_k].buffer;
 						n.faces = P.index ? P.index : (void *)SP(S.faces);
 						n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0) | (pos_scratch ? 0x40 : 0));   // bit7: faces is a real pointer, bit6: position is a scratch offset (both cleared at fixup)
@@ -994,9 +1010,10 @@ static int build_and_launch_inner(crthip_batch *b) {
 				for(int c = 0; c < 4; c++) q.qc[c] = as.qc[c];
 				q.block0 = (uint32_t)pl.dequant_block_job.v.size();
 				q.is_color = a.codec == CRTHIP_CODEC_COLOR;
+				q.format = q.is_color ? (uint8_t)CRTHIP_FMT_FLOAT : (uint8_t)bd.format;
 				q.stride = bd.stride;
 				if(q.is_color) q.src = SP(A.color);
-				else if(bd.stride) q.src = SP(A.vals);
+				else if(bd.stride || bd.format == CRTHIP_FMT_DOUBLE) q.src = SP(A.vals);
 				const uint64_t elems = q.is_color ? nvert : (uint64_t)nvert*a.N;
 				const uint32_t nb = (uint32_t)((elems + CHUNK - 1)/CHUNK);
 				for(uint32_t c = 0; c < nb; c++) pl.dequant_block_job.v.push_back((uint32_t)pl.dequant.v.size());
@@ -1111,7 +1128,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 		if(n.fn_scratch) n.fn_scratch = (float *)R(n.fn_scratch);
 		n.faces_u16 &= 0x3F;
 	}
-	for(auto &q : pl.dequant.v) if(q.is_color || q.stride) q.src = R(q.src);
+	for(auto &q : pl.dequant.v) if(q.is_color || q.stride || q.format == CRTHIP_FMT_DOUBLE) q.src = R(q.src);
 	for(auto &P : b->blobs) { (void)P; }
 
 	// host image -> device (one copy)
@@ -1271,7 +1288,7 @@ static int build_and_launch_inner(crthip_batch *b) {
 			const AttrHeader &a = L.h.attrs[k];
 			if(a.codec == CRTHIP_CODEC_NORMAL) ob += (uint64_t)L.h.nvert*3*(P.bind[k].format == CRTHIP_FMT_INT16 ? 2 : 4);
 			else if(a.codec == CRTHIP_CODEC_COLOR) ob += (uint64_t)L.h.nvert*P.bind[k].out_components;
-			else ob += (uint64_t)L.h.nvert*a.N*4;
+			else ob += (uint64_t)L.h.nvert*a.N*generic_work_bytes(P.bind[k].format);
 		}
 	}
 	b->stats.output_bytes = ob;
@@ -1360,10 +1377,6 @@ extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const ch
 // pinned landing zone live in the context: in the steady state a call is one upload of the blobs, one descriptor upload, the kernels,
 // and ONE download of all outputs - no allocation, no per-attribute copies.  Serialised per context (host_mutex).
 // A blob the walk rejects fails alone: the others are decoded without it.
-// bytes per component of a generic attribute's caller buffer: upstream decodes in place as int32 whatever the format and DOUBLE widens
-// in place (include/corto/vertex_attribute.h:184-228), so every format's buffer is nvert*N*4 bytes but DOUBLE's
-static inline size_t generic_work_bytes(uint32_t format) { return format == CRTHIP_FMT_DOUBLE ? 8u : 4u; }
-
 namespace corto_hip {
 int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy_out) {
 	if(!ctx || !reqs || n == 0) return fail(CRTHIP_E_ARGUMENT);

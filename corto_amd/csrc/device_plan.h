@@ -146,7 +146,10 @@ struct DequantJob {
 	uint32_t nvert, N, out_components;
 	uint32_t qc[4];
 	uint32_t block0;               // first block of this job in the block->job map
-	uint8_t is_color, pad[3];
+	uint8_t is_color;
+	uint8_t format;                // generic attributes: the CRTHIP_FMT_* of `buffer` (FLOAT: (float)v*q; the integer formats and DOUBLE: upstream's
+	                               // in-place "*= q" through a pointer of that type, vertex_attribute.h:195-228 - k_dequant restates what the compiled reference does)
+	uint8_t pad[2];
 	uint32_t stride;               // bytes from one vertex to the next in `buffer`; 0 = packed
 	uint32_t pad2;
 };

@@ -387,6 +387,60 @@ __global__ __launch_bounds__(256) void k_dequant(const DequantJob *__restrict__ 
 	if(b >= nblocks) return;
 	const DequantJob J = jobs[block_job[b]];
 	const uint32_t e0 = (b - J.block0)*CHUNK + 4*threadIdx.x;
+	if(!J.is_color && J.format != 6u) {
+		// GenericAttr<int>::dequantize with an integer or DOUBLE output format (vertex_attribute.h:195-228): "buffer[i] *= q" through a pointer
+		// of the OUTPUT type over the first n = nvert*N elements OF THAT TYPE - the first 2n (n) bytes of the int32 array for the 16-bit (8-bit)
+		// formats - and DOUBLE widening in place front to back.  Restated as the reference library behaves when compiled for x86-64 (g++ -O2:
+		// scalar loops, cvttss2si conversions); pinned by tests/golden/generic_formats.npz, which the reference itself produced.
+		const uint32_t n = J.nvert*J.N;
+		const float q = J.q;
+		if(J.format == 7u) {                                      // DOUBLE: element i >= 1 is computed from the bytes double[i >> 1] left where coords[i] was:
+			CRT_GLOBAL const int32_t *vs = as_global((const int32_t *)J.src);   // D(0) = f(v[0]), D(i) = f(half (i & 1) of D(i >> 1)), f(c) = (double)((float)c*q)
+			CRT_GLOBAL double *out = as_global((double *)J.buffer);
+			const int32_t v0 = vs[0];
+#pragma unroll
+			for(int k = 0; k < 4; k++) if(e0 + k < n) {
+				const uint32_t i = e0 + k;
+				double d = (double)((float)v0*q);
+				for(int bit = 31 - (int)__builtin_clz(i | 1u); i && bit >= 0; bit--) {
+					const uint64_t w = (uint64_t)__double_as_longlong(d);
+					const int32_t c = (int32_t)(uint32_t)(((i >> bit) & 1u) ? w >> 32 : w);
+					d = (double)((float)c*q);
+				}
+				out[i] = d;
+			}
+			return;
+		}
+		// integer formats: one thread per dword of the int32 array that holds elements with index < n
+		CRT_GLOBAL uint32_t *w32 = as_global((uint32_t *)J.buffer);
+		const uint32_t per = J.format <= 1u ? 1u : J.format <= 3u ? 2u : 4u;   // elements of the output type per dword
+		const uint32_t ndw = (n + per - 1u)/per;
+#pragma unroll
+		for(int k = 0; k < 4; k++) if(e0 + k < ndw) {
+			const uint32_t d = e0 + k;
+			uint32_t w = w32[d];
+			if(per == 1u) {                                         // ((uint32_t *)buffer)[i] *= q: u32 -> float -> x q -> cvttss2si (64-bit) -> low 32 bits
+				const float f = (float)w*q;
+				const int64_t t = (f >= -9223372036854775808.0f && f < 9223372036854775808.0f) ? (int64_t)f : (int64_t)0x8000000000000000ull;
+				w = (uint32_t)(uint64_t)t;
+			} else if(per == 2u) {                                  // ((uint16_t *)buffer)[i] *= q: u16 -> int -> float -> x q -> cvttss2si -> low 16 bits
+				uint32_t r = w;
+				if(2u*d < n) r = (r & 0xFFFF0000u) | ((uint32_t)f2i_x86((float)(int32_t)(w & 0xFFFFu)*q) & 0xFFFFu);
+				if(2u*d + 1u < n) r = (r & 0x0000FFFFu) | ((uint32_t)f2i_x86((float)(int32_t)(w >> 16)*q) << 16);
+				w = r;
+			} else {                                                // ((char *)buffer)[i] *= q: char is signed on x86
+				uint32_t r = w;
+#pragma unroll
+				for(uint32_t b = 0; b < 4; b++) if(4u*d + b < n) {
+					const int32_t c = (int32_t)(int8_t)(uint8_t)(w >> (8u*b));
+					r = (r & ~(255u << (8u*b))) | (((uint32_t)f2i_x86((float)c*q) & 255u) << (8u*b));
+				}
+				w = r;
+			}
+			w32[d] = w;
+		}
+		return;
+	}
 	if(!J.is_color) {                                          // out = (float)v * q, in place (vertex_attribute.h:190-193)
 		const uint32_t n = J.nvert*J.N;
 		CRT_GLOBAL int32_t *vi = as_global((int32_t *)J.buffer);

@@ -66,7 +66,8 @@ struct crthip_pool {
 	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
 	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
 	bool packed_host = false;       // crthip_pool_set_packed_host_blobs: items whose blobs lie in one pinned buffer in arena layout go up from there
-	bool prefetch = true;           // $CORTO_POOL_PREFETCH=0: a step's blobs go up at the head of the step itself (crthip_batch_reset's own upload: round 3's path)
+	int upload_mode = 0;            // $CORTO_POOL_UPLOAD: 0 = a step's blobs go up at the head of the step itself, by crthip_batch_reset (DMA engine); 1 = the lane's NEXT
+	                                // step's blobs queued behind this step's kernels, DMA engine; 2 = the same by a copy kernel; 3 = at the head of the step, by a copy kernel
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
 	std::mutex m;
@@ -112,7 +113,7 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 			p->warning = buf;
 			fprintf(stderr, "%s\n", buf);
 		}
-	{ const char *e = getenv("CORTO_POOL_PREFETCH"); p->prefetch = !(e && e[0] == '0'); }
+	{ const char *e = getenv("CORTO_POOL_UPLOAD"); p->upload_mode = e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : 0; }
 	// the host CPUs next to each GPU: PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist
 	p->cpus.resize(ndevices);
 	for(uint32_t d = 0; d < ndevices; d++) {
@@ -190,8 +191,7 @@ static int lane_upload(crthip_pool *p, Lane &L, const crthip_pool_item &it, int 
 		for(uint32_t i = 0; i < it.nblobs; i++) memcpy((uint8_t *)U.pin + offs[i], it.blobs[i], it.lens[i]);
 		src = U.pin;
 	}
-	if(bytes && hipMemcpyAsync(U.dev, src, bytes, hipMemcpyHostToDevice, corto_hip::ctx_stream(L.ctx)) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, "pool: hipMemcpyAsync(H2D)");
-	return CRTHIP_OK;
+	return corto_hip::ctx_copy_async(L.ctx, U.dev, src, bytes, p->upload_mode >= 2);
 }
 
 // plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
@@ -301,7 +301,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			return CRTHIP_OK;
 		};
 		// an item that is not resident on this device goes up into one of the lane's two arenas
-		auto needs_upload = [&](uint32_t j) { return p->prefetch && !(items[j].device_arena && items[j].device_arena[slot]); };
+		auto needs_upload = [&](uint32_t j) { return p->upload_mode != 0 && !(items[j].device_arena && items[j].device_arena[slot]); };
 		auto upload = [&](Lane &L, uint32_t j, int buf) -> int {
 			const auto u0 = tick();
 			const int e = lane_upload(p, L, items[j], buf, offs);
@@ -373,7 +373,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			err = start(L, j, buf, step >= poison_from);
 			if(!err) L.step = step;
 			// ... and the ticket behind it: its upload is queued behind this step's kernels, on the lane's own stream
-			if(!err && p->prefetch && !exhausted) {
+			if(!err && (p->upload_mode == 1 || p->upload_mode == 2) && !exhausted) {
 				uint64_t step2; uint32_t j2;
 				if(!draw(step2, j2)) exhausted = true;
 				else {

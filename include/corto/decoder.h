@@ -9,8 +9,10 @@
 //   * there is no CPU path: without a usable HIP device decode() throws;
 //   * VertexAttribute here is a plain descriptor, not upstream's codec base class: custom codec objects
 //     (setAttribute(name, buffer, VertexAttribute*)) cannot run on the device and are rejected;
-//   * generic attributes decode to FLOAT only, colours to UINT8, normals to FLOAT or INT16 (the formats
-//     upstream's own callers use; SURVEY.md a17 lists the rest as never executed by Decoder).
+//   * generic attributes take every VertexAttribute::Format through setAttribute(name, buffer, format): FLOAT is the format upstream's own
+//     callers use; the integer formats and DOUBLE leave in the buffer what the compiled reference leaves there (its "*= q" through a pointer
+//     of the output type over the int32 array, vertex_attribute.h:195-228 - buffers of nvert*N*4 bytes, nvert*N*8 for DOUBLE, as upstream);
+//     colours decode to UINT8 (FLOAT colour output is broken upstream, color_attribute.cpp:96-110), normals to FLOAT or INT16.
 // Errors are thrown as `const char *` with upstream's own messages (src/decoder.cpp:44,51,274 ...).
 //
 // Threading: as upstream (whose only global is the read-only bmask[], src/bitstream.cpp:29-33) - distinct Decoder objects may

@@ -602,10 +602,46 @@ static int attr_dequantize(attr_t *a, uint32_t nvert) {
 		}
 		return 0;
 	}
-	if(a->bind->format != CO_FMT_FLOAT) return E_FORMAT;
-	int32_t *v = (int32_t *)a->bind->buffer; float *f = (float *)a->bind->buffer;
-	for(size_t i = 0; i < (size_t)nvert*a->info.N; i++) f[i] = (float)v[i]*a->info.q;
-	return 0;
+	/* GenericAttr<int>::dequantize, vertex_attribute.h:184-230.  The values sit in the buffer as n = nvert*N int32.  FLOAT is the
+	 * only format upstream's own callers use; the others are restated as the reference library BEHAVES when built as oracle/Makefile
+	 * builds it (g++ x86-64 -O2: scalar loops, cvttss2si conversions) - "buffer[i] *= q" through a pointer of the OUTPUT type over the
+	 * first n elements OF THAT TYPE, i.e. over the first 2n (n) bytes of the int32 array for the 16-bit (8-bit) formats, and DOUBLE
+	 * widening in place front to back, so that element i >= 1 is computed from bytes an earlier store of the same loop wrote.
+	 * (Accessing the int array through these pointer types is undefined behaviour upstream; this is what the compiled code does,
+	 * pinned by tests/golden/generic_formats.npz, which the reference itself produced.) */
+	const size_t n = (size_t)nvert*a->info.N;
+	const float q = a->info.q;
+	uint8_t *b8 = (uint8_t *)a->bind->buffer;
+	switch(a->bind->format) {
+	case CO_FMT_FLOAT: {
+		int32_t *v = (int32_t *)a->bind->buffer; float *f = (float *)a->bind->buffer;
+		for(size_t i = 0; i < n; i++) f[i] = (float)v[i]*q;
+		return 0; }
+	case CO_FMT_INT32: case CO_FMT_UINT32:                           /* ((uint32_t *)buffer)[i] *= q : u32 -> float -> x q -> cvttss2si (64-bit) -> low 32 bits */
+		for(size_t i = 0; i < n; i++) {
+			uint32_t u; memcpy(&u, b8 + 4*i, 4);
+			const float f = (float)u*q;
+			const int64_t w = (f >= -9223372036854775808.0f && f < 9223372036854775808.0f) ? (int64_t)f : INT64_MIN;
+			u = (uint32_t)(uint64_t)w; memcpy(b8 + 4*i, &u, 4);
+		}
+		return 0;
+	case CO_FMT_INT16: case CO_FMT_UINT16:                           /* ((uint16_t *)buffer)[i] *= q : u16 -> int -> float -> x q -> cvttss2si (32-bit) -> low 16 bits */
+		for(size_t i = 0; i < n; i++) {
+			uint16_t u; memcpy(&u, b8 + 2*i, 2);
+			u = (uint16_t)(uint32_t)f2i((float)(int32_t)u*q); memcpy(b8 + 2*i, &u, 2);
+		}
+		return 0;
+	case CO_FMT_INT8: case CO_FMT_UINT8:                             /* ((char *)buffer)[i] *= q : char is signed on x86 */
+		for(size_t i = 0; i < n; i++) b8[i] = (uint8_t)(uint32_t)f2i((float)(int32_t)(int8_t)b8[i]*q);
+		return 0;
+	case CO_FMT_DOUBLE:                                              /* ((double *)buffer)[i] = coords[i]*q, i ascending, in place */
+		for(size_t i = 0; i < n; i++) {
+			int32_t c; memcpy(&c, b8 + 4*i, 4);
+			const double d = (double)((float)c*q); memcpy(b8 + 8*i, &d, 8);
+		}
+		return 0;
+	}
+	return E_FORMAT;
 }
 
 int co_decode(const uint8_t *blob, size_t len, const co_outputs *o, co_trace *tr) {

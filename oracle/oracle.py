@@ -106,6 +106,23 @@ def bits(words: np.ndarray, bitoff: int, n: int) -> int:
     return lib().co_bits(_ptr(words), bitoff, n)
 
 
+def decode_attr_format(blob: np.ndarray, name: str, fmt: int, fill=0xCD) -> np.ndarray:
+    """ONE generic attribute bound with output format `fmt` (crt::Decoder::setAttribute(name, buffer, format)): the nvert*N*8 bytes of its
+    buffer after the decode, prefilled with `fill` - what refcodec.decode_attr_format returns for the reference."""
+    h = parse_header(blob)
+    a = [x for x in h["attrs"] if x["name"] == name][0]
+    buf = np.full(h["nvert"] * a["N"] * 8, fill, dtype=np.uint8)
+    b = (Binding * 1)(Binding(name.encode(), _ptr(buf), fmt, 0))
+    o = Outputs(b, 1, None, None)
+    idx = np.zeros((max(h["nface"], 1), 3), dtype=np.uint32)
+    if h["nface"]:
+        o.index32 = _ptr(idx)
+    r = lib().co_decode(_ptr(blob), C.c_size_t(len(blob)), C.byref(o), None)
+    if r != 0:
+        raise RuntimeError(lib().co_strerror(r).decode())
+    return buf
+
+
 def decode(blob: np.ndarray, normal_format=FMT_FLOAT, color_components=4, index16=False, trace=False,
            bind=None, fill=0):
     """Whole decode by the C restatement -> dict of numpy arrays (same keys as refcodec.decode).

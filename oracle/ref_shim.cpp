@@ -187,6 +187,22 @@ int ref_decode(const uint8_t *blob, int len, const ref_out_t *o) {
 	}
 }
 
+// ONE generic attribute bound with an arbitrary output format through Decoder::setAttribute(name, buffer, format) (src/decoder.cpp:96-102;
+// the format only matters in GenericAttr::dequantize, include/corto/vertex_attribute.h:184-230).  buffer: nvert*N*8 bytes (the decode works
+// in place on int32 values whatever the format, DOUBLE widens in place).  index32: nface*3, or NULL for clouds.
+int ref_decode_attr_format(const uint8_t *blob, int len, const char *name, int format, uint8_t *buffer, uint32_t *index32) {
+	try {
+		Decoder dec(len, blob);
+		if(!dec.setAttribute(name, (char *)buffer, (VertexAttribute::Format)format)) { g_err = "no such attribute"; return -1; }
+		if(dec.nface && index32) dec.setIndex(index32);
+		dec.decode();
+		return 0;
+	} catch(const char *e) {
+		g_err = e;
+		return -1;
+	}
+}
+
 // Full decode + the topology intermediates the reference keeps in its public IndexAttribute
 // (include/corto/index_attribute.h:48-60): decoded CLERS symbols and per-vertex prediction triples.
 int ref_decode_trace(const uint8_t *blob, int len, const ref_out_t *o,

@@ -188,6 +188,18 @@ def decode(blob: np.ndarray, normal_format=FLOAT, color_components=4, index16=Fa
     return outs
 
 
+def decode_attr_format(blob: np.ndarray, name: str, fmt: int, n_components: int, fill=0xCD) -> np.ndarray:
+    """The reference Decoder with ONE generic attribute bound through setAttribute(name, buffer, format): the nvert*N*8 bytes of the buffer
+    afterwards (the decode works in place on int32 values; only DOUBLE uses the second half), prefilled with `fill`."""
+    info = probe(blob)
+    buf = np.full(info["nvert"] * n_components * 8, fill, dtype=np.uint8)
+    idx = np.zeros((max(info["nface"], 1), 3), dtype=np.uint32)
+    r = lib().ref_decode_attr_format(_ptr(blob), len(blob), name.encode(), int(fmt), _ptr(buf), _ptr(idx) if info["nface"] else None)
+    if r != 0:
+        raise RuntimeError("ref_decode_attr_format: " + lib().ref_last_error().decode())
+    return buf
+
+
 def decode_trace(blob: np.ndarray, normal_format=FLOAT, color_components=4, index16=False):
     """decode() + the reference's own topology intermediates (CLERS symbols, prediction triples)."""
     info = probe(blob)

@@ -630,6 +630,43 @@ def test_cpp_decoder_threads(ctx, tmp_path):
     assert out.returncode == 1 and "Decoding topology failed" in out.stderr, out.stderr + out.stdout
 
 
+def test_generic_attribute_output_formats(tmp_path):
+    """Decoder::setAttribute(name, buffer, format) with the integer formats and DOUBLE (src/decoder.cpp:96-102, GenericAttr::dequantize
+    include/corto/vertex_attribute.h:195-228): the device path leaves in the caller's nvert*N*8-byte buffer what the compiled reference left
+    (tests/golden/generic_formats.npz) - every format, through crthip_decode_host (the facade's path) one attribute at a time, and with every
+    attribute of a blob bound at once (positions as INT32 under estimated normals: the normals still read the integers)"""
+    z = np.load(os.path.join(GOLDEN, "generic_formats.npz"))
+    for name in z["cases"].tobytes().decode().split(","):
+        blob = aligned(z["crt_" + name])
+        info = ca.probe(blob)
+        for key in [k for k in z.files if k.startswith(name + ".")]:
+            _, attr, fmt = key.split(".")
+            want = z[key]
+            buf = np.full(len(want), 0xCD, dtype=np.uint8)
+            d = ca.Decoder(blob)
+            assert d.setAttribute(attr, buf, int(fmt))
+            idx = np.zeros((max(info.nface, 1), 3), dtype=np.uint32)
+            if info.nface:
+                d.setIndex(idx)
+            d.decode()
+            n4 = len(want) // 2
+            used = len(want) if int(fmt) == ca.FMT_DOUBLE else n4            # (the facade copies back the bytes the format uses: the int32 array, or the doubles)
+            assert buf[:used].tobytes() == want[:used].tobytes(), key
+            assert (buf[used:] == 0xCD).all(), key
+    # positions as INT32 beside float normals (estimated from the integer positions) and uvs as UINT16: one decode
+    blob = aligned(z["crt_sphere_q0p75"])
+    info = ca.probe(blob)
+    ref = oc.decode(blob)
+    pos = np.full(info.nvert * 3 * 4, 0xCD, dtype=np.uint8)
+    nrm = np.zeros((info.nvert, 3), dtype=np.float32)
+    idx = np.zeros((info.nface, 3), dtype=np.uint32)
+    d = ca.Decoder(blob)
+    d.setAttribute("position", pos, ca.FMT_INT32); d.setNormals(nrm); d.setIndex(idx)
+    d.decode()
+    assert pos.tobytes() == z["sphere_q0p75.position.%d" % ca.FMT_INT32][:len(pos)].tobytes()
+    assert nrm.tobytes() == ref["normal"].tobytes() and idx.tobytes() == ref["index"].tobytes()
+
+
 def test_status_survives_other_batches(ctx):
     """decode(A); decode(B) on one context; sync(A) must still report A's per-blob failures (they used to be lost when
     another call synchronised the stream first)"""

@@ -5,7 +5,9 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import ALL_CASES, load_golden
+import os
+
+from conftest import ALL_CASES, GOLDEN, aligned, load_golden
 from oracle import oracle as oc
 
 
@@ -112,3 +114,16 @@ def test_header_errors():
     h = oc.parse_header(g["crt"])
     assert [a["name"] for a in h["attrs"]] == ["color", "normal", "position", "uv"]
     assert h["nvert"] == 2112 and h["nface"] == 4096
+
+
+def test_generic_attribute_output_formats_match_the_reference():
+    """GenericAttr::dequantize's integer and DOUBLE branches (include/corto/vertex_attribute.h:195-228; reached through
+    Decoder::setAttribute(name, buffer, format)): the C restatement leaves the same bytes in the caller's buffer as the compiled reference
+    did (tests/golden/generic_formats.npz, made by make_generic_formats.py), every format, every byte of the nvert*N*8-byte buffer"""
+    z = np.load(os.path.join(GOLDEN, "generic_formats.npz"))
+    for name in z["cases"].tobytes().decode().split(","):
+        blob = aligned(z["crt_" + name])
+        for key in [k for k in z.files if k.startswith(name + ".")]:
+            _, attr, fmt = key.split(".")
+            got = oc.decode_attr_format(blob, attr, int(fmt))
+            assert got.tobytes() == z[key].tobytes(), key

@@ -14,13 +14,13 @@ depth = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 blobs, _ = bench.load_blobs(0)
 pin, views = ca.pinned_host_arena(blobs)
 arena = [[ca.upload_arena(blobs, 0)]]
-modes = {"resident": ("1", blobs, arena, False), "pinned-prefetch": ("1", views, None, True), "pinned": ("0", views, None, True),
-         "scattered-prefetch": ("1", blobs, None, False), "scattered": ("0", blobs, None, False)}
-want = sys.argv[4].split(",") if len(sys.argv) > 4 else ["resident", "pinned-prefetch", "pinned", "scattered", "resident"]
+modes = {"resident": ("0", blobs, arena, False), "pinned": ("0", views, None, True), "pinned-next-dma": ("1", views, None, True), "pinned-next-kernel": ("2", views, None, True),
+         "pinned-head-kernel": ("3", views, None, True), "scattered": ("0", blobs, None, False), "scattered-next-kernel": ("2", blobs, None, False)}
+want = sys.argv[4].split(",") if len(sys.argv) > 4 else ["resident", "pinned", "pinned-next-kernel", "pinned-head-kernel", "scattered", "resident"]
 print("GPU_MAX_HW_QUEUES=%s threads=%d depth=%d" % (os.environ.get("GPU_MAX_HW_QUEUES"), threads, depth), flush=True)
 for name in want:
     prefetch, items, arenas, packed = modes[name]
-    os.environ["CORTO_POOL_PREFETCH"] = prefetch
+    os.environ["CORTO_POOL_UPLOAD"] = prefetch
     pool = ca.Pool([0], threads=threads, depth=depth)
     pool.set_packed_host_blobs(packed)
     pool.run([items], steps=pool.lanes * 8, warmup=0, arenas=arenas)
