@@ -817,7 +817,7 @@ def main():
             "sustained": sustained,
             "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool_warning or None,
             "host_us_per_step_per_thread": round(float(rep.host_us_per_step), 1), "numa_pinned_devices": int(rep.pinned_devices),
-            "host_us": {"per_step_per_thread": round(float(rep.host_us_per_step), 1), "upload_enqueue": round(float(rep.host_upload_us), 1), "plan_walk_bind": round(float(rep.host_plan_us), 1),
+            "host_us": {"per_step_per_thread": round(float(rep.host_us_per_step), 1), "plan_walk_bind": round(float(rep.host_plan_us), 1),
                         "wait_for_a_context": round(float(rep.host_wait_us), 1), "harvest": round(float(rep.host_finish_us), 1)},
             "scattered_pageable_blobs": {"mtri_per_s": round(tris_h / elapsed_h / 1e6, 2), "ms_per_step": round(elapsed_h / (fhh_steps / nloc) * 1e3, 4), "steps": fhh_steps // nloc,
                                          **window_stats(stamps_h, pool_lanes), "host_us_per_step_per_thread": round(float(rep_h.host_us_per_step), 1),

@@ -332,15 +332,6 @@ int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value) {      /
 	hipLaunchKernelGGL(k_fill_block, dim3(2048), dim3(256), 0, ctx->stream, (uint8_t *)dst, (uint64_t)bytes, (uint32_t)(value & 255));
 	return hipGetLastError() == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE);
 }
-int ctx_copy_async(crthip_ctx *ctx, void *dst, const void *host_src, size_t bytes, int by_kernel) {   // pinned host memory -> HBM on the context's main stream
-	if(!bytes) return CRTHIP_OK;
-	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
-	if(by_kernel && (((uintptr_t)dst | (uintptr_t)host_src) & 15) == 0) {
-		hipLaunchKernelGGL(k_copy_block, dim3(128), dim3(256), 0, ctx->stream, (const uint8_t *)host_src, (uint8_t *)dst, (uint64_t)bytes);
-		return hipGetLastError() == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE);
-	}
-	return hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE, "hipMemcpyAsync(H2D)");
-}
 int ctx_quiesce(crthip_ctx *ctx) {
 	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
 	ctx->last_decoded = nullptr;                         // the encoder stages reuse the scratch block

@@ -7,7 +7,7 @@
 // twice ...).  Each was measured level or slower (profiles/r03_what_bounds_the_pipeline.txt has the numbers) and they were
 // REMOVED in round 4, kernels included: the library has one kernel per stage and size class.
 // Besides these: decoder_facade.cpp reads $CORTO_HIP_CONTEXTS / $CORTO_HIP_DEVICE / $CORTO_HIP_COMBINE_US / $CORTO_HIP_LEADERS once, pool.cpp reads
-// ROCm's own $GPU_MAX_HW_QUEUES to size itself and $CORTO_POOL_PREFETCH.
+// ROCm's own $GPU_MAX_HW_QUEUES to size itself.
 #pragma once
 #include <cstdint>
 #include <cstdlib>

@@ -54,6 +54,5 @@ int ctx_device(crthip_ctx *ctx);
 hipStream_t ctx_stream(crthip_ctx *ctx);
 int ctx_quiesce(crthip_ctx *ctx);       // wait for whatever batch is in flight on the context
 int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value);   // k_fill_block on the context's main stream
-int ctx_copy_async(crthip_ctx *ctx, void *dst, const void *host_src, size_t bytes, int by_kernel);   // pinned host -> HBM on the context's main stream: DMA engine, or k_copy_block
 
 } // namespace corto_hip

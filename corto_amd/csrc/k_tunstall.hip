@@ -678,24 +678,6 @@ __global__ __launch_bounds__(256) void k_fill_block(uint8_t *__restrict__ dst, u
 	}
 }
 
-// a block of bytes from (pinned, device-visible) HOST memory into HBM by a kernel: 16 bytes a thread and load, four loads in flight a thread.
-// crthip_pool's alternative to the DMA engine for a batch's compressed blobs: an ordinary packet on the context's own queue, no hand-over
-// between the compute queue and the copy engine (both pointers 16-byte aligned; the tail goes bytewise)
-__global__ __launch_bounds__(256) void k_copy_block(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t bytes) {
-	typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-	const uint64_t nvec = bytes >> 4;
-	const u32x4_t *s4 = (const u32x4_t *)src;
-	u32x4_t *d4 = (u32x4_t *)dst;
-	const uint64_t stride = (uint64_t)gridDim.x*256;
-	uint64_t i = (uint64_t)blockIdx.x*256 + threadIdx.x;
-	for(; i + 3*stride < nvec; i += 4*stride) {
-		const u32x4_t a = __builtin_nontemporal_load(s4 + i), b = __builtin_nontemporal_load(s4 + i + stride), c = __builtin_nontemporal_load(s4 + i + 2*stride), d = __builtin_nontemporal_load(s4 + i + 3*stride);
-		d4[i] = a; d4[i + stride] = b; d4[i + 2*stride] = c; d4[i + 3*stride] = d;
-	}
-	for(; i < nvec; i += stride) d4[i] = __builtin_nontemporal_load(s4 + i);
-	if(blockIdx.x == 0) for(uint64_t k = (nvec << 4) + threadIdx.x; k < bytes; k += 256) dst[k] = src[k];
-}
-
 } // namespace corto_hip
 
 #ifdef CORTO_TUN_STAMPS

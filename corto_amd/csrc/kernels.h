@@ -22,7 +22,6 @@ int launch_tun_decode_staged(hipStream_t stream, const TunStream *streams, const
                              uint64_t *chunk_out, uint32_t sums_only);    // words <= 4 bytes, <= 8 bytes, longer: three bodies of one kernel
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
 __global__ void k_fill_block(uint8_t *dst, uint64_t bytes, uint32_t value);
-__global__ void k_copy_block(const uint8_t *src, uint8_t *dst, uint64_t bytes);   // pinned host memory -> HBM by a kernel (both 16-byte aligned)
 
 // k_stream.hip
 __global__ void k_scan_u64(uint64_t *a, uint32_t n);

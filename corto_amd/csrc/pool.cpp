@@ -42,16 +42,6 @@ struct Lane {                       // one context = one batch in flight
 	uint64_t step = 0;              // its global step number
 	bool busy = false;
 	bool poisoned = false;          // the output block was filled with POISON on the context's stream right before the step in flight / last executed
-	// host-resident items (SURVEY.md 8d's primary region: .crt blobs in pinned host memory -> decoded outputs in HBM): two arenas in HBM that
-	// take turns, and the lane's NEXT ticket.  The blobs of the next step are queued for upload on the lane's OWN stream right behind the
-	// kernels of the step just launched: they cross PCIe while the lane would otherwise sit idle waiting for its host thread to come round
-	// again (a thread serves `depth` lanes, ~200 us of host work each), the step's kernels find them resident, and no second stream or event
-	// is involved (round 4 measured a copy stream per thread with events: 0.125 ms a step instead of 0.096 - cross-stream waits on sixteen
-	// busy queues - and the copy at the head of the step itself, round 3's way: 0.096 against 0.080 with resident inputs).
-	struct Upload { void *dev = nullptr; size_t cap = 0; void *pin = nullptr; size_t pin_cap = 0; } up[2];   // pin: gathering image for blobs scattered over host memory
-	int cur = -1;                   // the arena the step in flight / last executed reads (-1: resident item, or uploaded by the library itself)
-	bool has_next = false;          // a ticket drawn ahead for this lane: its upload is queued (or it needs none)
-	uint64_t next_step = 0; uint32_t next_item = 0; int next_buf = -1;
 };
 constexpr int POISON = 0xA5;
 
@@ -65,9 +55,6 @@ struct crthip_pool {
 	std::vector<Lane> lanes;        // [device][thread][depth]
 	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
 	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
-	bool packed_host = false;       // crthip_pool_set_packed_host_blobs: items whose blobs lie in one pinned buffer in arena layout go up from there
-	int upload_mode = 0;            // $CORTO_POOL_UPLOAD: 0 = a step's blobs go up at the head of the step itself, by crthip_batch_reset (DMA engine); 1 = the lane's NEXT
-	                                // step's blobs queued behind this step's kernels, DMA engine; 2 = the same by a copy kernel; 3 = at the head of the step, by a copy kernel
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
 	std::mutex m;
@@ -79,7 +66,6 @@ static void destroy_lane(Lane &L) {
 	if(L.batch) crthip_batch_destroy(L.batch);
 	if(L.ctx) crthip_ctx_destroy(L.ctx);
 	if(L.out) (void)hipFree(L.out);
-	for(auto &U : L.up) { if(U.dev) (void)hipFree(U.dev); if(U.pin) (void)hipHostFree(U.pin); U = Lane::Upload{}; }
 	L.batch = nullptr; L.ctx = nullptr; L.out = nullptr; L.out_cap = 0;
 }
 
@@ -113,7 +99,6 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 			p->warning = buf;
 			fprintf(stderr, "%s\n", buf);
 		}
-	{ const char *e = getenv("CORTO_POOL_UPLOAD"); p->upload_mode = e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : 0; }
 	// the host CPUs next to each GPU: PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist
 	p->cpus.resize(ndevices);
 	for(uint32_t d = 0; d < ndevices; d++) {
@@ -156,47 +141,20 @@ extern "C" int64_t crthip_pool_device_cpus(const crthip_pool *p, uint32_t device
 }
 extern "C" int crthip_pool_set_packed_host_blobs(crthip_pool *p, int on) {
 	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
-	p->packed_host = on != 0;
 	for(auto &L : p->lanes) { const int err = crthip_ctx_set_packed_host_blobs(L.ctx, on); if(err) return err; }
 	return CRTHIP_OK;
 }
 
-// queue the upload of an item's blobs into arena `buf` of the lane, on the lane's own stream (nobody waits: what is queued behind it on
-// that stream is ordered after it)
-static int lane_upload(crthip_pool *p, Lane &L, const crthip_pool_item &it, int buf, std::vector<uint64_t> &offs) {
-	Lane::Upload &U = L.up[buf];
-	offs.resize(it.nblobs);
-	const uint64_t total = crthip_arena_layout(it.nblobs, it.lens, offs.data());
-	if(total + 16 > U.cap) {
-		if(U.dev) { (void)hipStreamSynchronize(corto_hip::ctx_stream(L.ctx)); (void)hipFree(U.dev); }
-		U.dev = nullptr; U.cap = 0;
-		const size_t want = (size_t)(total + total/4 + 4096);
-		if(hipMalloc(&U.dev, want) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
-		U.cap = want;
-	}
-	bool in_place = p->packed_host && it.nblobs > 0;                                 // the caller's buffer IS the arena's image (corto_hip.h)
-	for(uint32_t i = 0; in_place && i < it.nblobs; i++) in_place = it.blobs[i] == it.blobs[0] + offs[i];
-	const void *src;
-	size_t bytes = (size_t)total;
-	if(in_place) { src = it.blobs[0]; bytes = (size_t)(offs[it.nblobs - 1] + it.lens[it.nblobs - 1]); }
-	else {
-		// (this image's previous upload is through: it fed the lane's step before last, which was harvested before the last one started)
-		if(total + 16 > U.pin_cap) {
-			if(U.pin) { (void)hipStreamSynchronize(corto_hip::ctx_stream(L.ctx)); (void)hipHostFree(U.pin); }
-			U.pin = nullptr; U.pin_cap = 0;
-			const size_t want = (size_t)(total + total/4 + 4096);
-			if(hipHostMalloc(&U.pin, want, hipHostMallocDefault) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
-			U.pin_cap = want;
-		}
-		for(uint32_t i = 0; i < it.nblobs; i++) memcpy((uint8_t *)U.pin + offs[i], it.blobs[i], it.lens[i]);
-		src = U.pin;
-	}
-	return corto_hip::ctx_copy_async(L.ctx, U.dev, src, bytes, p->upload_mode >= 2);
-}
-
+// Host-resident items (SURVEY.md 8d's primary region: .crt blobs in pinned host memory -> decoded outputs in HBM): crthip_batch_reset uploads
+// a step's blobs itself, with ONE DMA copy at the head of the context's own stream.  Round 4 built and measured four ways of taking that
+// copy off the step (C4 batch, 4 x 4 contexts; resident inputs 0.080 ms a step, this path 0.093, PCIe alone 0.075: tools/h2d_probe.py):
+// a copy stream per worker thread with an event the context waits for (0.125, and 7 ms stalls), the lane's NEXT batch queued behind the
+// running batch's kernels on the lane's own stream (0.15-0.20: a DMA copy queued behind kernels is started late), the same two with a
+// copy KERNEL reading the pinned buffer over PCIe (0.13 / 0.156).  All slower; removed.  What does help a little is one more lane per
+// thread's worth of contexts (5 x 4: 0.091): the lane whose blobs are on their way is idle for the GPU.
 // plan `item` on the lane's batch object, lay its outputs out in the lane's device block and bind them
-static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id, const void *uploaded = nullptr) {
-	const void *arena = uploaded ? uploaded : it.device_arena ? it.device_arena[L.slot] : nullptr;
+static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_t item_id) {
+	const void *arena = it.device_arena ? it.device_arena[L.slot] : nullptr;
 	int err = L.batch ? crthip_batch_reset(L.batch, it.nblobs, it.blobs, it.lens, arena)
 	                  : crthip_batch_create(L.ctx, it.nblobs, it.blobs, it.lens, arena, &L.batch);
 	if(err) return err;
@@ -262,7 +220,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	std::vector<std::atomic<uint64_t>> per_dev(p->ndevices);
 	for(auto &x : per_dev) x = 0;
 	std::atomic<int32_t> first_error{0};
-	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0}, upload_ns{0};
+	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0};
 	// home shard first: pool device d owns the items j with j % ndevices == d (its shard is resident there), and a device without a home
 	// item takes from the others' ("stealing" in a cyclic run: it is the work list that is shared, a faster GPU simply draws more tickets)
 	std::vector<std::vector<uint32_t>> home(p->ndevices);
@@ -282,10 +240,6 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			(void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (a cpuset that forbids them: stay where we are)
 		}
 		Lane *mine = &p->lanes[((size_t)slot*p->threads_per_device + t)*p->depth];
-		for(uint32_t k = 0; k < p->depth; k++) { mine[k].has_next = false; mine[k].cur = -1; }
-		std::vector<uint64_t> offs;
-		auto tick = [] { return std::chrono::steady_clock::now(); };
-		auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
 		auto finish = [&](Lane &L) -> int {
 			const int rc = crthip_batch_sync(L.batch, L.status.data());
 			L.busy = false;
@@ -300,55 +254,18 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(rc == CRTHIP_E_DEVICE || rc == CRTHIP_E_NOMEM) return rc;
 			return CRTHIP_OK;
 		};
-		// an item that is not resident on this device goes up into one of the lane's two arenas
-		auto needs_upload = [&](uint32_t j) { return p->upload_mode != 0 && !(items[j].device_arena && items[j].device_arena[slot]); };
-		auto upload = [&](Lane &L, uint32_t j, int buf) -> int {
-			const auto u0 = tick();
-			const int e = lane_upload(p, L, items[j], buf, offs);
-			const uint64_t ns = ns_since(u0);
-			upload_ns += ns; host_ns += ns;
-			return e;
-		};
-		auto draw = [&](uint64_t &step, uint32_t &j) -> bool {
-			step = p->next.fetch_add(1);
-			if(step >= total) return false;
-			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
-			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
-			return true;
-		};
-		auto start = [&](Lane &L, uint32_t j, int buf, bool poison) -> int {       // plan item j on the lane (its blobs: arena `buf`, or resident) and enqueue its decode
-			const auto p0 = tick();
-			int e = lane_plan(p, L, items[j], (int64_t)j, buf >= 0 ? L.up[buf].dev : nullptr);
-			plan_ns += ns_since(p0);
-			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
-			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
-			L.poisoned = false;
-			if(!e && poison && L.out) {
-				e = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
-				if(!e) L.poisoned = true;
-			}
-			if(!e) e = crthip_batch_decode(L.batch);
-			if(!e) { L.busy = true; L.cur = buf; }
-			return e;
-		};
 		int err = CRTHIP_OK;
-		bool exhausted = false;                                  // no tickets left to draw
+		auto tick = [] { return std::chrono::steady_clock::now(); };
+		auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
 		for(uint64_t n = 0; !err; n++) {
 			const auto w0 = tick();
-			// the next lane to (re)fill: a free one that has work (its own ticket waiting, or tickets left to draw), else whichever of the
-			// busy ones finishes first (they mostly finish in the order they were launched, but a thread that waited on the oldest while a
-			// younger one was done left that context idle)
-			uint32_t pick = p->depth, nbusy = 0;
-			for(uint32_t k = 0; k < p->depth; k++) {
-				Lane &C = mine[(n + k) % p->depth];
-				if(C.busy) nbusy++;
-				else if(pick == p->depth && (C.has_next || !exhausted)) pick = (uint32_t)((n + k) % p->depth);
-			}
-			if(pick == p->depth && !nbusy) break;                   // nothing in flight, nothing to start
+			// the next lane to refill: a free one, else whichever of the busy ones finishes first (they mostly finish in the order they
+			// were launched, but a thread that waited on the oldest while a younger one was done left that context idle)
+			uint32_t pick = p->depth;
+			for(uint32_t k = 0; k < p->depth && pick == p->depth; k++) if(!mine[(n + k) % p->depth].busy) pick = (uint32_t)((n + k) % p->depth);
 			for(uint32_t spins = 0; pick == p->depth && !err; spins++) {
 				for(uint32_t k = 0; k < p->depth; k++) {
 					Lane &C = mine[(n + k) % p->depth];
-					if(!C.busy) continue;
 					const int d = crthip_batch_done(C.batch);
 					if(d < 0) { err = d; break; }
 					if(d) { pick = (uint32_t)((n + k) % p->depth); break; }
@@ -362,27 +279,24 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			if(L.busy) err = finish(L);
 			finish_ns += ns_since(f0);
 			if(err) break;
-			// the lane's own ticket (its blobs went up behind its last step's kernels), else a fresh one
-			uint64_t step; uint32_t j; int buf = -1;
-			const auto h0 = tick();
-			if(L.has_next) { step = L.next_step; j = L.next_item; buf = L.next_buf; L.has_next = false; }
-			else {
-				if(exhausted || !draw(step, j)) { exhausted = true; continue; }
-				if(needs_upload(j)) { buf = L.cur == 0 ? 1 : 0; err = upload(L, j, buf); if(err) break; }
+			const uint64_t step = p->next.fetch_add(1);
+			if(step >= total) break;
+			uint32_t j;
+			if(!home[slot].empty()) j = home[slot][home_next[slot].fetch_add(1) % home[slot].size()];
+			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
+			const auto h0 = std::chrono::steady_clock::now();
+			err = lane_plan(p, L, items[j], (int64_t)j);
+			plan_ns += ns_since(h0);
+			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
+			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
+			L.poisoned = false;
+			if(!err && step >= poison_from && L.out) {
+				err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+				if(!err) L.poisoned = true;
 			}
-			err = start(L, j, buf, step >= poison_from);
-			if(!err) L.step = step;
-			// ... and the ticket behind it: its upload is queued behind this step's kernels, on the lane's own stream
-			if(!err && (p->upload_mode == 1 || p->upload_mode == 2) && !exhausted) {
-				uint64_t step2; uint32_t j2;
-				if(!draw(step2, j2)) exhausted = true;
-				else {
-					int b2 = -1;
-					if(needs_upload(j2)) { b2 = buf == 0 ? 1 : 0; err = upload(L, j2, b2); }
-					if(!err) { L.has_next = true; L.next_step = step2; L.next_item = j2; L.next_buf = b2; }
-				}
-			}
-			host_ns += ns_since(h0); host_steps++;
+			if(!err) err = crthip_batch_decode(L.batch);
+			host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count(); host_steps++;
+			if(!err) { L.busy = true; L.step = step; }
 		}
 		for(uint32_t k = 0; k < p->depth; k++) if(mine[k].busy) { const int e2 = finish(mine[k]); if(!err) err = e2; }
 		// a context whose thread drew none of the last 2 x lanes tickets (descheduled while the others emptied the queue: seen with
@@ -390,17 +304,15 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 		// a poisoned step's output, not only almost always
 		for(uint32_t k = 0; k < p->depth && !err; k++) {
 			Lane &L = mine[k];
-			if(L.poisoned && L.item >= 0) continue;
-			if(!L.out && L.item >= 0) continue;
-			// ... and one that drew no ticket at all (a 28-step run on a cold box) decodes its device's first item
-			const uint32_t j = L.item >= 0 ? (uint32_t)L.item : home[slot].empty() ? 0u : home[slot][0];
-			int buf = -1;
-			if(needs_upload(j)) {
-				if(L.item >= 0 && L.cur >= 0) buf = L.cur;           // (its last step's arena: untouched since)
-				else { buf = 0; err = upload(L, j, buf); }
+			if(L.item < 0) {                                     // ... and one that drew no ticket at all (a 28-step run on a cold box) decodes its device's first item
+				const uint32_t j = home[slot].empty() ? 0u : home[slot][0];
+				err = lane_plan(p, L, items[j], (int64_t)j);
+				if(err) break;
 			}
-			if(!err) err = start(L, j, buf, true);
-			if(!err) err = finish(L);
+			if(L.poisoned || !L.out) continue;
+			err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+			if(!err) err = crthip_batch_decode(L.batch);
+			if(!err) { L.busy = true; L.poisoned = true; err = finish(L); }
 		}
 		if(err) {
 			std::lock_guard<std::mutex> lock(p->m);
@@ -422,7 +334,6 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	if(host_steps) {
 		report->host_wait_us = (float)((double)wait_ns/1e3/(double)host_steps); report->host_finish_us = (float)((double)finish_ns/1e3/(double)host_steps);
 		report->host_plan_us = (float)((double)plan_ns/1e3/(double)host_steps);
-		report->host_upload_us = (float)((double)upload_ns/1e3/(double)host_steps);
 	}
 	for(uint32_t d = 0; d < p->ndevices; d++) if(!p->cpus[d].empty()) report->pinned_devices++;
 	if(completion_s) for(uint64_t c = 0; c < steps; c++) completion_s[c] = stamps[warmup + 1 + c] - stamps[warmup];

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define CRTHIP_ABI_VERSION 4   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_*; 3: crthip_pool_report grew, crthip_pool_warning;
-                                  4: crthip_pool_report.host_upload_us (was reserved), integer / DOUBLE output formats of generic attributes */
+                                  4: integer / DOUBLE output formats of generic attributes, crthip_pool_device_cpus */
 
 /* VertexAttribute::Format, include/corto/vertex_attribute.h:32 */
 enum { CRTHIP_FMT_UINT32 = 0, CRTHIP_FMT_INT32 = 1, CRTHIP_FMT_UINT16 = 2, CRTHIP_FMT_INT16 = 3,
@@ -208,10 +208,8 @@ int64_t crthip_pool_device_cpus(const crthip_pool *pool, uint32_t device_slot, i
 int crthip_pool_set_packed_host_blobs(crthip_pool *pool, int on);
 
 /* One work item = one batch of blobs (HOST pointers, borrowed for the duration of crthip_pool_run).
- * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step: each worker thread
- *                       has a copy stream and depth + 1 arena buffers, the blobs of its NEXT step go up while it waits for one of its
- *                       contexts to finish, and the context that takes the step waits for the copy's event only (SURVEY.md 8d's primary
- *                       region; $CORTO_POOL_PREFETCH=0: the upload at the head of the context's own stream, as crthip_batch_create does);
+ * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step (SURVEY.md 8d's primary
+ *                       region): one DMA copy at the head of the context's own stream, as crthip_batch_create does;
  *               else ndevices DEVICE pointers, entry d = the item's blobs already resident on pool device d in
  *               crthip_arena_layout order (an entry may be NULL: that device uploads). */
 typedef struct {
@@ -239,7 +237,7 @@ typedef struct {
 	uint32_t reserved;
 	float host_wait_us, host_finish_us, host_plan_us;   /* of a worker thread's time per step: waiting for one of its contexts to finish; harvesting it
 	                                (sync, status); the walk + bind part of host_us_per_step */
-	float host_upload_us;        /* ... and gathering + enqueueing the upload of a step's blobs on the thread's copy stream (host-resident items; part of host_us_per_step) */
+	uint32_t reserved2;
 } crthip_pool_report;
 
 /* Decode warmup + steps batches drawn cyclically from the items (each device from its home items, see above; + a few more steps to

@@ -806,9 +806,21 @@ def test_unsupported_format_fails_loudly(ctx):
     b = ca.Batch(ctx, [g["crt"]])
     info = b.infos[0].attrs()
     binds = [ca.AttrBinding() for _ in info]
+    # what the device path refuses: a colour as FLOAT (broken upstream, color_attribute.cpp:96-110), a normal as anything but FLOAT / INT16
+    for name, fmt in (("color", ca.FMT_FLOAT), ("normal", ca.FMT_UINT8), ("normal", ca.FMT_DOUBLE)):
+        binds = [ca.AttrBinding() for _ in info]
+        k = [a["name"] for a in info].index(name)
+        binds[k].buffer = 4096; binds[k].format = fmt
+        with pytest.raises(ca.CortoError, match="Format not supported"):
+            b.bind(0, binds)
+    # a generic attribute takes every format (test_generic_attribute_output_formats) - packed only, and aligned for its type
+    binds = [ca.AttrBinding() for _ in info]
     k = [a["name"] for a in info].index("position")
-    binds[k].buffer = 4096; binds[k].format = ca.FMT_INT16
-    with pytest.raises(ca.CortoError, match="Format not supported"):
+    binds[k].buffer = 4096; binds[k].format = ca.FMT_INT16; binds[k].stride = 32
+    with pytest.raises(ca.CortoError, match="Invalid argument"):
+        b.bind(0, binds)
+    binds[k].stride = 0; binds[k].buffer = 4100; binds[k].format = ca.FMT_DOUBLE
+    with pytest.raises(ca.CortoError, match="Invalid argument"):
         b.bind(0, binds)
 
 
