@@ -12,7 +12,7 @@ A "step" = one pass of the hot path over that batch on SURVEY.md 8d's PRIMARY ti
 (crthip_batch_reset: host walk of every blob) + bind + decode (descriptor upload, all kernels) + sync.  (Rounds 1-3 quoted the rate with the
 compressed inputs already resident in HBM as `value`; VERDICT r3 asked for 8d's primary region instead.  The resident-input rate - no
 PCIe inside the step - is measured in the same run and reported beside it as `resident_inputs`, with its own regions and roofline.)
-Steps run on the library's decode pool (crthip_pool, csrc/pool.cpp): per GPU --host-threads (default 4) native host threads
+Steps run on the library's decode pool (crthip_pool, csrc/pool.cpp): per GPU --host-threads (default 5) native host threads
 each keep --depth (default 4) batches in flight, every batch on its own context (own HIP streams, scratch and output
 block), all threads of all GPUs pulling batches from ONE work queue (an atomic counter) - no collective anywhere.
 Timing: barrier + device sync, then W warm-up steps flow straight into the K timed steps (the pipeline is NOT drained in
@@ -36,8 +36,9 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one HW queue per HIP stream of the pipelined contexts (the ROCm default of 4
-                                                   # makes streams share queues, and a shared queue serialises its kernels)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")   # one HW queue per HIP stream of the pipelined contexts (the ROCm default of 4 makes streams
+                                                   # share queues, and a shared queue serialises its kernels).  Round 4: 20 contexts on 20 queues
+                                                   # (5 x 4; 4 x 5 and 11 x 2 on 22 are the same) are 3 % faster than 16 on 16; 24 is slower again
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -388,7 +389,7 @@ def main():
     ap.add_argument("--steps", type=int, default=480)
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (contexts) per host thread; 1 = unpipelined")
-    ap.add_argument("--host-threads", type=int, default=4, help="native host threads per GPU feeding it (crthip_pool)")
+    ap.add_argument("--host-threads", type=int, default=5, help="native host threads per GPU feeding it (crthip_pool)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the `sustained` leg (one long timed region on the same pool); 0 skips it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-tunstall-scaled", action="store_true")

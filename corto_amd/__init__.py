@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcorto_hip.so")
+LIB_PATH = os.environ.get("CORTO_HIP_LIB_PATH") or os.path.join(_HERE, "lib", "libcorto_hip.so")   # (the override: A/B probes with a variant build, tools/)
 
 FMT_UINT32, FMT_INT32, FMT_UINT16, FMT_INT16, FMT_UINT8, FMT_INT8, FMT_FLOAT, FMT_DOUBLE = range(8)
 CODEC_GENERIC, CODEC_NORMAL, CODEC_COLOR = 1, 2, 3

@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("CORTO_BUILD_LIBDIR") or os.path.join(HERE, "lib")   # (probes: a variant library beside the product, tools/ab_build.sh)
 LIB = os.path.join(LIBDIR, "libcorto_hip.so")
 VENEER = os.path.join(LIBDIR, "libcortocodec_hip.so")
 EMVENEER = os.path.join(LIBDIR, "libcorto_em_hip.so")    # upstream's wasm/JS C ABI (include/corto/emcorto.h) over the facade

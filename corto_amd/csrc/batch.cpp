@@ -648,21 +648,34 @@ static int build_and_launch(crthip_batch *b) {
 	return err;
 }
 
-static int build_and_launch_inner(crthip_batch *b) {
-	crthip_ctx *ctx = b->ctx;
-	const double t0 = now_us(); double t1 = 0, t2 = 0, t3 = 0;        // host-side cost of a decode call (crthip_batch_stats::host_*_us)
-	Plan &pl = ctx->plan;
-	pl.reset();
+// The planner of one decode call, stage by stage (round 4: this was one function of 660 lines).  carve() lays the batch's scratch out
+// (pass 1: sizes and offsets only), jobs() writes the job descriptors of every stage with scratch-relative pseudo pointers (pass 2),
+// group() sorts streams by dictionary and attributes into K-DELTA workgroups and places the job arrays, upload() reserves the blocks,
+// rebases the pointers and stages the arrays, launch() enqueues the kernels in the order of crt::Decoder::decodeMesh / decodePointCloud
+// (src/decoder.cpp:133-196), account() fills crthip_batch_stats.
+namespace {
+struct Planner {
+	crthip_batch *b; crthip_ctx *ctx; Plan &pl; std::vector<BlobScratch> &bs;
+	const uint32_t nblobs; const bool wide; const uint8_t *arena;            // wide: K-DELTA with 32-bit values in LDS (this context met values beyond int16)
 	Carver cv;
-	const uint32_t nblobs = (uint32_t)b->blobs.size();
-	const bool wide = ctx->delta_wide;                                     // K-DELTA with 32-bit values in LDS (this context met values beyond int16)
-	const uint8_t *arena = b->d_arena;
+	uint64_t unpack_state_words = 1, n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0, stat_dicts = 0;
+	uint32_t tun_chunks = 0, unpack_chunks = 0, cloud_chunks = 0;
+	uint32_t clers_tun = 0, clers_chunks = 0, clers_fill = 0, clers_dict = 0;   // the CLERS streams come first in every stream / chunk / fill / dictionary array
+	bool share_clers = false, share_attrs = false;
+	int32_t *hs_base = nullptr;                                              // per-blob status words in pinned host memory
+	uint8_t *base = nullptr, *stage = nullptr;                               // the scratch block; the host image of the job arrays
 
+	Planner(crthip_batch *b_) : b(b_), ctx(b_->ctx), pl(b_->ctx->plan), bs(b_->ctx->plan_scratch), nblobs((uint32_t)b_->blobs.size()), wide(b_->ctx->delta_wide), arena(b_->d_arena) {}
+	static uint8_t *SP(uint64_t off) { return (uint8_t *)(uintptr_t)off; }   // scratch-relative pseudo pointer
+	int32_t *HS(uint64_t k) const { return (int32_t *)((uintptr_t)(hs_base + k) | (1ull << 63)); }   // real pointer (bit 63: R() leaves it alone)
+	int carve(); int jobs(); void group(); int upload(); int launch(); void account();
+};
+
+int Planner::carve() {
 	// ---- pass 1: sizes & offsets (device addresses are scratch_base + offset, resolved in pass 2) ----
 	// We first carve all scratch, then reserve the block, then fill job structs with real pointers.
 	// per-blob scratch offsets live in the context and are reset, not reallocated: a decode call used to spend a third of its host
 	// time in malloc/free of these small vectors
-	std::vector<BlobScratch> &bs = ctx->plan_scratch;
 	if(bs.size() < nblobs) bs.resize(nblobs);
 	for(uint32_t i = 0; i < nblobs; i++) bs[i].reset();
 
@@ -704,12 +717,11 @@ static int build_and_launch_inner(crthip_batch *b) {
 		}
 	}
 	pl.zero_end = cv.take(0);
-	uint64_t unpack_state_words = 1;                                      // look-back state words of the bit-unpack chunks (k_unpack_extract): one per
+	unpack_state_words = 1;                                               // look-back state words of the bit-unpack chunks (k_unpack_extract): one per
 	for(uint32_t i = 0; i < nblobs; i++) {                              // 1 024 logs of every bound stream, + a spare; uploaded as zeros with the jobs
 		const BlobPlan &P = b->blobs[i];
 		for(size_t k = 0; k < P.L.attrs.size(); k++) if(P.bind[k].buffer) for(const StreamRef &lg : P.L.attrs[k].logs) unpack_state_words += ((uint64_t)lg.size + CHUNK - 1)/CHUNK;
 	}
-	uint64_t n_tun = 0, stat_tin = 0, stat_tout = 0, stat_tt = 0, stat_dicts = 0;
 
 	auto need_stream = [&](const StreamRef &s, uint64_t &sym_off) {
 		sym_off = ~0ull;
@@ -759,16 +771,17 @@ static int build_and_launch_inner(crthip_batch *b) {
 	}
 	pl.tables_off = cv.take(n_tun*sizeof(TunTable));
 
+	return CRTHIP_OK;
+}
+
+int Planner::jobs() {
 	// ---- pass 2: job structs with offsets stored in pointer fields (rebased after the block is reserved) ----
 	// To keep one pass, pointers are built as (uint8_t*)offset and fixed up by adding the scratch base.
-	auto SP = [](uint64_t off) { return (uint8_t *)(uintptr_t)off; };   // scratch-relative pseudo pointer
 	// four words a blob: status | automaton flags (bit 0: redone on the HBM front) | K-DELTA: {an attribute's values left int16, an attribute took the walk}
 	if((size_t)nblobs*16 + 16 > ctx->status_host.cap && harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);   // the block is about to move: the batch in flight writes to it
 	if(ctx->status_host.reserve((size_t)nblobs*16 + 16) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-	int32_t *const hs_base = (int32_t *)ctx->status_host.p;
-	auto HS = [&](uint64_t k) { return (int32_t *)((uintptr_t)(hs_base + k) | (1ull << 63)); };   // real pointer (bit 63: R() leaves it alone)
+	hs_base = (int32_t *)ctx->status_host.p;
 
-	uint32_t tun_chunks = 0, unpack_chunks = 0, cloud_chunks = 0;
 	// the dictionary (TunTable slot) of a stream: a new one, or the one an earlier stream of this launch group with the same table got
 	if(ctx->dict_slots.size() != 8192) ctx->dict_slots.assign(8192, 0u);
 	for(uint32_t u : ctx->dict_used) ctx->dict_slots[u] = 0;
@@ -821,8 +834,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 		const BlobLayout &L = b->blobs[i].L;
 		if(L.h.nface > 0) clers_ptrs[i] = add_stream(L.clers, bs[i].clers, b->blobs[i].arena_off);
 	}
-	const uint32_t clers_tun = (uint32_t)pl.tun.v.size(), clers_chunks = tun_chunks, clers_fill = (uint32_t)pl.fill.v.size();
-	const uint32_t clers_dict = (uint32_t)pl.tun_dict.v.size();
+	clers_tun = (uint32_t)pl.tun.v.size(); clers_chunks = tun_chunks; clers_fill = (uint32_t)pl.fill.v.size();
+	clers_dict = (uint32_t)pl.tun_dict.v.size();
 	// the attribute streams are a launch of their own: their dictionaries are not shared with the CLERS streams' (different HIP streams)
 	for(uint32_t u : ctx->dict_used) ctx->dict_slots[u] = 0;
 	ctx->dict_used.clear(); ctx->dict_keys.clear(); dict_ids.clear();
@@ -1012,12 +1025,16 @@ static int build_and_launch_inner(crthip_batch *b) {
 			}
 		}
 	}
+	return CRTHIP_OK;
+}
+
+void Planner::group() {
 	// streams of a launch that share dictionaries: sorted by dictionary (counting sort), cut into groups of one dictionary each
 	const uint32_t ntun_all = (uint32_t)pl.tun.v.size(), ndict_all = (uint32_t)pl.tun_dict.v.size();
 	// dictionaries by one kernel (K-TAB, 6 KB of LDS per wave), decodes by another (10 KB for a few us), instead of both in one wave per stream
 	// (16 KB for ~37 us): a batch of many streams is bound by LDS.time, so the split pays even when NO two streams share a table
 	auto shares = [&](uint32_t nstreams, uint32_t ndicts) { (void)ndicts; return ctx->dbg.tun_share == 0 ? false : ctx->dbg.tun_share == 1 ? true : nstreams >= 64; };
-	const bool share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict), share_attrs = !pl.tun_multi_chunk && shares(ntun_all - clers_tun, ndict_all - clers_dict);
+	share_clers = !pl.tun_multi_chunk && shares(clers_tun, clers_dict); share_attrs = !pl.tun_multi_chunk && shares(ntun_all - clers_tun, ndict_all - clers_dict);
 	{
 		std::vector<uint32_t> &cnt = ctx->dict_count;
 		auto group_range = [&](uint32_t t0, uint32_t t1, uint32_t d0, uint32_t d1) {
@@ -1054,8 +1071,8 @@ static int build_and_launch_inner(crthip_batch *b) {
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
 	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.tun_group_ids); place(pl.tun_groups); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job); place(pl.unpack_wave_ids);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) == 0; });
-	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide](const DeltaJob &d) { return delta_class(d, wide) <= 1; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide_ = wide](const DeltaJob &d) { return delta_class(d, wide_) == 0; });
+	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide_ = wide](const DeltaJob &d) { return delta_class(d, wide_) <= 1; });
 	{	// attributes of one blob that fit LDS together share a workgroup and the prediction graph: consecutive jobs of class 2 with the same
 		// prediction array, up to DELTA_GROUP_MAX
 		size_t j = 0;
@@ -1083,12 +1100,14 @@ static int build_and_launch_inner(crthip_batch *b) {
 	pl.jobs_bytes = cv.take(0) - pl.jobs_begin;
 	pl.total = cv.take(0);
 
-	t1 = now_us();
+}
+
+int Planner::upload() {
 	// ---- reserve device + pinned memory; one batch in flight per context ----
 	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);        // one batch in flight per context: the previous one's status is kept in its object
 	if(ctx->scratch.reserve(pl.total + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 	if(ctx->staging.reserve(pl.jobs_bytes + 256) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
-	uint8_t *base = (uint8_t *)ctx->scratch.p;
+	base = (uint8_t *)ctx->scratch.p;
 	auto R = [&](const void *pseudo) -> uint8_t * {          // rebase a scratch-relative pseudo pointer
 		uintptr_t v = (uintptr_t)pseudo;
 		if(v >> 63) return (uint8_t *)(v & ~(1ull << 63));     // already real (arena)
@@ -1120,10 +1139,9 @@ static int build_and_launch_inner(crthip_batch *b) {
 		n.faces_u16 &= 0x3F;
 	}
 	for(auto &q : pl.dequant.v) if(q.is_color || q.stride || q.format == CRTHIP_FMT_DOUBLE) q.src = R(q.src);
-	for(auto &P : b->blobs) { (void)P; }
 
 	// host image -> device (one copy)
-	uint8_t *stage = (uint8_t *)ctx->staging.p;
+	stage = (uint8_t *)ctx->staging.p;
 	memset(stage + (pl.unpack_partial_off - pl.jobs_begin), 0, unpack_state_words*8);
 	memset(ctx->status_host.p, 0, (size_t)nblobs*16);                       // (after the harvest above: the previous batch's words have been read)
 	auto put = [&](auto &arr) { if(!arr.v.empty()) memcpy(stage + (arr.dev_off - pl.jobs_begin), arr.v.data(), arr.v.size()*sizeof(arr.v[0])); };
@@ -1131,7 +1149,10 @@ static int build_and_launch_inner(crthip_batch *b) {
 	put(pl.delta); put(pl.delta_groups); put(pl.cloud); put(pl.cloud_chunk_job); put(pl.normal); put(pl.nv_block_job); put(pl.nv_block_first);
 	put(pl.nf_block_job); put(pl.nf_block_first); put(pl.normal_fused_ids); put(pl.dequant); put(pl.dequant_block_job);
 
-	t2 = now_us();
+	return CRTHIP_OK;
+}
+
+int Planner::launch() {
 	hipStream_t st = ctx->stream;
 	ctx->timer.reset();
 	Launch LT{ctx};
@@ -1266,6 +1287,11 @@ static int build_and_launch_inner(crthip_batch *b) {
 	HIP_TRY(hipGetLastError());                                            // (status: written by the kernels straight into the pinned block)
 	HIP_TRY(hipEventRecord(ctx->ev_done, st));
 
+	return CRTHIP_OK;
+}
+
+void Planner::account() {
+	const uint32_t ntun = (uint32_t)pl.tun.v.size();
 	// stats
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
 	b->stats.scratch_bytes = pl.total;
@@ -1286,7 +1312,23 @@ static int build_and_launch_inner(crthip_batch *b) {
 	ctx->in_flight = b; ctx->last_decoded = b;
 	b->decoded = true; b->planned_wide = wide;
 	b->dirty = false;
-	t3 = now_us();
+}
+} // namespace
+
+static int build_and_launch_inner(crthip_batch *b) {
+	const double t0 = now_us();                                            // host-side cost of a decode call (crthip_batch_stats::host_*_us)
+	b->ctx->plan.reset();
+	Planner P(b);
+	int err = P.carve();
+	if(!err) err = P.jobs();
+	if(err) return err;
+	P.group();
+	const double t1 = now_us();
+	if((err = P.upload()) != CRTHIP_OK) return err;
+	const double t2 = now_us();
+	if((err = P.launch()) != CRTHIP_OK) return err;
+	P.account();
+	const double t3 = now_us();
 	b->stats.host_plan_us = (float)(t1 - t0); b->stats.host_stage_us = (float)(t2 - t1); b->stats.host_launch_us = (float)(t3 - t2);
 	return CRTHIP_OK;
 }

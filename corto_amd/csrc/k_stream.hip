@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 // no state words, no atomics.  A tenth of the waves, a quarter of the wave-cycles (the instruction count is the same).
 constexpr uint32_t UW_R = 4;                                                // rounds of 64 logs per block: their loads in flight together
 __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;
+	if(blockIdx.x >= njobs) return;                                             // (four streams a workgroup, a wave each - 512 workgroups a C4 batch instead of 2 048 - measured level: round 4)
 	const uint32_t jid = job_ids[blockIdx.x];
 	const UnpackJob J = jobs[jid];
 	const uint32_t lane = threadIdx.x, count = J.count, fields = J.fields;

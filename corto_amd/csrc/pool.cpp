@@ -95,7 +95,7 @@ extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_
 			char buf[320];
 			snprintf(buf, sizeof buf, "corto_hip pool: %u contexts on GPU %d but %u hardware queues (%s): streams that share a queue serialise each other's kernels; "
 			         "export GPU_MAX_HW_QUEUES=%u before the process first touches HIP", kv.second, kv.first, hw_queues,
-			         hw_queues_set ? "GPU_MAX_HW_QUEUES" : "ROCm's default; GPU_MAX_HW_QUEUES is not set", kv.second > 16 ? 16u : kv.second);
+			         hw_queues_set ? "GPU_MAX_HW_QUEUES" : "ROCm's default; GPU_MAX_HW_QUEUES is not set", kv.second > 20 ? 20u : kv.second);   // (20 contexts on 20 queues measured best; 24 on 24 is slower)
 			p->warning = buf;
 			fprintf(stderr, "%s\n", buf);
 		}

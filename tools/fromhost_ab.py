@@ -3,7 +3,7 @@
 ms per step (mean / median window), the largest gaps between consecutive completions and the host's share per step.
   python tools/fromhost_ab.py [steps] [threads] [depth]"""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import bench

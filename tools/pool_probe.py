@@ -3,7 +3,7 @@
 region: usage (GPU box): python tools/pool_probe.py [threads depth]..."""
 import os, sys, time
 import numpy as np
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 import corto_amd as ca

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """threads x depth shapes of the decode pool on the C4 batch (256 blobs), long runs: usage: python tools/shape_probe.py "4 4" "8 2" ..."""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 import corto_amd as ca
