@@ -558,7 +558,10 @@ def main():
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
     # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: five regions (one 480-step region that meets a multi-ms stall reads 25 % low).
     R = 5 if args.steps >= 100 else max(5, -(-500 // args.steps) | 1)      # (an odd number of regions, ~500 steps in all: round 3 - five regions' median still moved +-8 % run to run)
-    rep, stamps = pool.run(host_items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=None)
+    # (the W warm-up steps the caller asked for, plus two rounds of the pool's contexts: with twenty batches in flight a pipeline that was empty
+    # when the run began is not full after five steps, and the first regions would time its filling)
+    ramp = 2 * pool.lanes
+    rep, stamps = pool.run(host_items, steps=R * args.steps * nloc, warmup=args.warmup * nloc + ramp, arenas=None)
     barrier()
     kk = args.steps * nloc
     tt = np.concatenate([[0.0], np.asarray(stamps, dtype=np.float64)])             # completion times of the timed steps, from the last warm-up step's
@@ -611,7 +614,7 @@ def main():
     pool.set_packed_host_blobs(False)
     pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=arenas)
     barrier()
-    rep_res, stamps_res = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc, arenas=arenas)
+    rep_res, stamps_res = pool.run(items, steps=R * args.steps * nloc, warmup=args.warmup * nloc + ramp, arenas=arenas)
     barrier()
     tr = np.concatenate([[0.0], np.asarray(stamps_res, dtype=np.float64)])
     regions_res = [shard.max_over_ranks(float(tr[(j + 1) * kk] - tr[j * kk]), dist, red_dev) for j in range(R)]

@@ -6,6 +6,8 @@
 //
 // Every stage is "scan + gather" over chunks of CHUNK elements; a chunk->job map built by the host
 // lets one launch cover every blob of the batch.
+#include <type_traits>
+
 #include "kernels_common.h"
 
 namespace corto_hip {
@@ -210,6 +212,9 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 // component, component-major: cstream.h:300-317) are simply added up again from their logs (a few KB), so nobody waits for anybody:
 // no state words, no atomics.  A tenth of the waves, a quarter of the wave-cycles (the instruction count is the same).
 constexpr uint32_t UW_R = 4;                                                // rounds of 64 logs per block: their loads in flight together
+// Bit offsets are 32-bit here (the planner sends a bit block this way only when it has fewer than 2^26 words): round 3's 64-bit cursors made
+// every window two 64-bit compares, a 64-bit shift and two 64-bit address computations - a third of the kernel's vector instructions, and
+// the pipelined rate is within 2x of the chip's VALU issue rate.
 __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;                                             // (four streams a workgroup, a wave each - 512 workgroups a C4 batch instead of 2 048 - measured level: round 4)
 	const uint32_t jid = job_ids[blockIdx.x];
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 	uint32_t lg[UW_R];
 #pragma unroll
 	for(uint32_t r = 0; r < UW_R; r++) { const uint32_t i = r*64u + lane; lg[r] = logs[i < count ? i : (count ? count - 1u : 0u)]; }
-	uint64_t running = 0;
+	uint32_t running = 0;
 	for(uint32_t jp = J.chain_chunk0; jp < jid; jp++) {                        // (chain_chunk0: for this kernel, the first JOB of the bit block)
 		const UnpackJob &K = jobs[jp];
 		CRT_GLOBAL const uint8_t *kl = as_global(K.logs);
@@ -237,44 +242,55 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 				for(uint32_t k = 0; k < 4; k++) if(k < r4[u]) t += width((w4[u] >> (8u*k)) & 255u);
 		}
 		t = wave_inclusive_scan_u32(t);
-		running += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)t, 63)*kf;
+		running += (uint32_t)__builtin_amdgcn_readlane((int)t, 63)*kf;
 	}
 	CRT_GLOBAL const uint32_t *words = as_global(J.words);
-	const uint32_t nwords = J.nwords, last_word = nwords ? nwords - 1u : 0u;
-	auto window = [&](uint64_t at, uint32_t &hi, uint32_t &lo) {              // two words of the bit block at bit offset `at` (clamped; masked by field())
-		const uint64_t wi = at >> 5;
-		hi = words[wi < nwords ? (uint32_t)wi : last_word];
-		lo = words[wi + 1 < nwords ? (uint32_t)wi + 1u : last_word];
+	const uint32_t nwords = J.nwords, last_word = nwords ? nwords - 1u : 0u, nbits = nwords << 5;   // (nwords < 2^26: the planner)
+	// two words of the bit block at bit offset `at`.  INSIDE: the field lies inside the bit block - every field of a well-formed stream -
+	// so only the second word's index can run one past the end (a field that ends on a word boundary) and nothing needs masking;
+	// otherwise clamped loads, and field() masks what bit_field() would not have read
+	auto window = [&](auto INSIDE, uint32_t at, uint32_t &hi, uint32_t &lo) {
+		const uint32_t wi = at >> 5;
+		if constexpr(decltype(INSIDE)::value) hi = words[wi]; else hi = words[min(wi, last_word)];
+		lo = words[min(wi + 1u, last_word)];
 	};
-	auto field = [&](uint64_t at, uint32_t n, uint32_t hi, uint32_t lo) -> uint32_t {        // = bit_field(words, nwords, at, n)
-		if(n == 0) return 0u;
-		const uint64_t wi = at >> 5;
-		const uint32_t sh = (uint32_t)(at & 31);
-		const uint32_t h = wi < nwords ? hi : 0u, l = (sh + n > 32 && wi + 1 < nwords) ? lo : 0u;
-		const uint32_t top = sh ? __builtin_amdgcn_alignbit(h, l, 32u - sh) : h;   // the 32 bits from bit `sh` on: a funnel shift, not a 64-bit one (quarter rate)
-		return top >> (32u - n);
+	auto field = [&](auto INSIDE, uint32_t at, uint32_t n, uint32_t hi, uint32_t lo) -> uint32_t {   // = bit_field(words, nwords, at, n); n == 0 -> 0
+		const uint32_t sh = at & 31u;
+		uint32_t h = hi, l = lo;
+		if constexpr(!decltype(INSIDE)::value) {
+			const uint32_t wi = at >> 5;
+			h = wi < nwords ? hi : 0u; l = (sh + n > 32 && wi + 1 < nwords) ? lo : 0u;
+		}
+		const uint32_t top = sh ? __builtin_amdgcn_alignbit(h, l, 32u - sh) : h;   // the 32 bits from bit `sh` on: a funnel shift, not a 64-bit one (sh = 0: the shift count 32 would wrap to 0 and give l)
+		return (top >> 1) >> (31u - n);                                       // top >> (32 - n) without the shift by 32 at n = 0
 	};
 	const bool values = (J.mode & 1u) != 0;
+	const uint32_t stride = J.stride, comp = J.comp, out_limit = J.out_limit;
+	const bool out_u8 = J.out_u8 != 0;
 	for(uint32_t base = 0; base < count; base += UW_R*64u) {
 		// this block's widths and bit offsets (a scan per round, the cursor a scalar), then the next block's logs go out before the windows
-		uint32_t d[UW_R]; uint64_t at[UW_R];
+		uint32_t d[UW_R], at[UW_R];
+		bool ok = true;
 #pragma unroll
 		for(uint32_t r = 0; r < UW_R; r++) {
 			const uint32_t i = base + r*64u + lane;
 			d[r] = i < count ? width(lg[r]) : 0u;
 			const uint32_t bits = d[r]*fields, incl = wave_inclusive_scan_u32(bits);
 			at[r] = running + (incl - bits);
+			ok = ok && running + incl <= nbits;
 			running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		}
+		const bool inside = __all(ok) && nwords != 0;                            // (uniform) the whole block's fields inside the bit block
 		if(base + UW_R*64u < count) {
 #pragma unroll
 			for(uint32_t r = 0; r < UW_R; r++) { const uint32_t i = base + (UW_R + r)*64u + lane; lg[r] = logs[i < count ? i : count - 1u]; }
 		}
+		auto body = [&](auto INSIDE) {
 		if(values) {                                                           // decodeValues: sign folding (cstream.h:304-316); one field per log
 			uint32_t hi[UW_R], lo[UW_R];
 			if(nwords) {
 #pragma unroll
-				for(uint32_t r = 0; r < UW_R; r++) window(at[r], hi[r], lo[r]);
+				for(uint32_t r = 0; r < UW_R; r++) window(INSIDE, at[r], hi[r], lo[r]);
 #pragma unroll
 				for(uint32_t r = 0; r < UW_R; r++) asm volatile("" : "+v"(hi[r]), "+v"(lo[r]));
 			} else {
@@ -284,15 +300,12 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 #pragma unroll
 			for(uint32_t r = 0; r < UW_R; r++) {
 				const uint32_t i = base + r*64u + lane, dd = d[r];
-				int32_t v = 0;
-				if(dd) {
-					v = (int32_t)field(at[r], dd, hi[r], lo[r]);
-					const int32_t mid = (int32_t)(1u << (dd - 1));
-					if(v < mid) v = -v - mid;
-				}
-				if(i < count && i < J.out_limit) {
-					if(J.out_u8) as_global((uint8_t *)J.out)[(size_t)i*J.stride + J.comp] = (uint8_t)v;
-					else as_global((int32_t *)J.out)[(size_t)i*J.stride + J.comp] = v;
+				int32_t v = (int32_t)field(INSIDE, at[r], dd, hi[r], lo[r]);
+				const int32_t mid = (int32_t)((1u << dd) >> 1);                  // (dd == 0: v = 0, mid = 0: stays 0)
+				v = v < mid ? -v - mid : v;
+				if(i < count && i < out_limit) {
+					if(out_u8) as_global((uint8_t *)J.out)[i*stride + comp] = (uint8_t)v;
+					else as_global((int32_t *)J.out)[i*stride + comp] = v;
 				}
 			}
 		} else {                                                                 // decodeArray: v = raw - 2^(d-1); d == 0 -> zeros (cstream.h:337-357); `fields` values per log
@@ -304,26 +317,34 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 #pragma unroll
 					for(uint32_t k = 0; k < 2; k++)
 #pragma unroll
-						for(uint32_t f = 0; f < 4; f++) window(at[g + k] + (uint64_t)(f < fields ? f : 0u)*d[g + k], hi[k][f], lo[k][f]);
+						for(uint32_t f = 0; f < 4; f++) window(INSIDE, at[g + k] + (f < fields ? f : 0u)*d[g + k], hi[k][f], lo[k][f]);
 #pragma unroll
 					for(uint32_t k = 0; k < 2; k++) asm volatile("" : "+v"(hi[k][0]), "+v"(lo[k][0]), "+v"(hi[k][1]), "+v"(lo[k][1]), "+v"(hi[k][2]), "+v"(lo[k][2]), "+v"(hi[k][3]), "+v"(lo[k][3]));
 				}
 #pragma unroll
 				for(uint32_t k = 0; k < 2; k++) {
 					const uint32_t i = base + (g + k)*64u + lane, dd = d[g + k];
-					const bool store = i < count && i < J.out_limit;
-					CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + (size_t)i*J.stride;
-					const uint32_t half = dd ? (uint32_t)((1ull << dd) >> 1) : 0u;
+					const bool store = i < count && i < out_limit;
+					CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + i*stride;
+					const uint32_t half = (1u << dd) >> 1;
 					if(fast) {
+						int32_t v[4];
 #pragma unroll
-						for(uint32_t f = 0; f < 4; f++) if(f < fields) {
-							const int32_t v = dd ? (int32_t)(field(at[g + k] + (uint64_t)f*dd, dd, hi[k][f], lo[k][f]) - half) : 0;
-							if(store) out[f] = v;
+						for(uint32_t f = 0; f < 4; f++) v[f] = (int32_t)(field(INSIDE, at[g + k] + (f < fields ? f : 0u)*dd, dd, hi[k][f], lo[k][f]) - half);
+						if(store) {                                                  // one vector store a vertex (the caller's ints are 4-byte aligned)
+							typedef int32_t i32x2_t __attribute__((ext_vector_type(2)));
+							typedef int32_t i32x3_t __attribute__((ext_vector_type(3)));
+							typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+							typedef i32x2_t __attribute__((aligned(4))) i32x2u; typedef i32x3_t __attribute__((aligned(4))) i32x3u; typedef i32x4_t __attribute__((aligned(4))) i32x4u;
+							if(fields == 3) *(CRT_GLOBAL i32x3u *)out = i32x3_t{v[0], v[1], v[2]};
+							else if(fields == 2) *(CRT_GLOBAL i32x2u *)out = i32x2_t{v[0], v[1]};
+							else if(fields == 4) *(CRT_GLOBAL i32x4u *)out = i32x4_t{v[0], v[1], v[2], v[3]};
+							else out[0] = v[0];
 						}
 					} else {
-						uint64_t oo = at[g + k];
+						uint32_t oo = at[g + k];
 						for(uint32_t f = 0; f < fields; f++) {
-							const int32_t v = dd ? (int32_t)(bit_field(words, nwords, oo, dd) - half) : 0;
+							const int32_t v = dd ? (int32_t)(bit_field(words, nwords, (uint64_t)oo, dd) - half) : 0;
 							oo += dd;
 							if(store) out[f] = v;
 						}
@@ -331,6 +352,8 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 				}
 			}
 		}
+		};
+		if(inside) body(std::true_type{}); else body(std::false_type{});
 	}
 }
 

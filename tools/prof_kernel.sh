@@ -17,3 +17,4 @@ for f in sorted(glob.glob("$OUT/p/**/*counter_collection.csv", recursive=True)):
     for k, v in acc.items():
         if "$K" in k: print(k, len(n[k]), {c: round(x/len(n[k])) for c, x in v.items()})
 PY
+rm -rf $OUT/p
