@@ -92,6 +92,19 @@ template <> struct LdsVal<5> {                                // bytes, mod 256 
 	__device__ __forceinline__ void sync() const {}
 };
 
+// the same four bytes as TWO registers of two 16-bit fields each (b0 | b2 << 16, b1 | b3 << 16), for colours WITHOUT parallelogram prediction
+// (v += v[a]: additions only): a pass adds at most 65 bytes into a field, which cannot carry into its neighbour, so two wave scans do the
+// work of four, and nothing is unpacked (mod 256 is taken when the record is stored)
+template <> struct LdsVal<6> {
+	static constexpr int NC = 2; static constexpr bool CHECK = false; typedef uint32_t Raw;
+	CRT_LDS uint32_t *p;
+	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
+	__device__ __forceinline__ static void unpack(Raw w, int32_t (&v)[2]) { v[0] = (int32_t)(w & 0x00FF00FFu); v[1] = (int32_t)((w >> 8) & 0x00FF00FFu); }
+	__device__ __forceinline__ void store(uint32_t i, const int32_t (&v)[2], uint32_t) const { p[i] = ((uint32_t)v[0] & 0x00FF00FFu) | (((uint32_t)v[1] & 0x00FF00FFu) << 8); }
+	__device__ __forceinline__ static int32_t wrap(int32_t v) { return (int32_t)((uint32_t)v & 0x00FF00FFu); }
+	__device__ __forceinline__ void sync() const {}
+};
+
 // ---- the same records with 32-BIT components (round 4: a context that met values beyond int16 - positions quantised to 16+ bits - plans
 // its batches this way; rounds 2-3 kept a second kernel, k_delta_wave, for them).  Records of 4 / 8 / 16 / 16 bytes; absolute values (no
 // base, nothing to check); a three-component record's fourth dword carries the graph's `a`.
@@ -191,13 +204,16 @@ struct GraphLds {
 // (three heads, 9-11 going: 292 window passes against 24 + 150) - not rings (one head), grids (25-29 going), or holey discs (five to nine
 // heads but 20 going: 80 passes against 24 + 68).  tests/test_delta16_model_cpu.py has the families this was read off.
 struct WindowHand { uint32_t s; uint64_t donew; };
-template <class V, class GR>
-__device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &graph, const uint32_t nvert, const bool para,
-                                                    const int32_t (&base)[V::NC], WindowHand *hand = nullptr) {
+// PARA: parallelogram prediction (b, c are gathered); else v += v[a] alone - the same loop without the two gathers, their unpacking and
+// their ready tests (a third of a pass's vector instructions, for two of a C4 blob's three attributes: the pipelined rate is within 2x of
+// the chip's VALU issue rate)
+template <bool PARA, class V, class GR>
+__device__ __forceinline__ uint32_t delta_window_loop(const V &val, const GR &graph, const uint32_t nvert,
+                                                     const int32_t (&base)[V::NC], WindowHand *hand) {
 	constexpr int NC = V::NC;
 	const uint32_t lane = lane_id();
 	const uint64_t lane_le = (2ull << lane) - 1ull;                          // lanes 0 .. mine
-	const uint32_t wmask = para ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);      // v += v[a] alone: b = c = vertex 0 cancel
+	constexpr uint32_t wmask = PARA ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);  // v += v[a] alone: b, c are not looked at
 	uint32_t s = 1, bad = 0;
 	uint64_t donew = 0;                                                       // bit l: vertex s + l is done (everything below s is; nothing at or above s + 64 can be)
 	uint32_t W, A; typename V::Raw D;
@@ -209,12 +225,12 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &gra
 		const uint32_t i = s + lane;
 		const bool in = i < nvert;
 		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
-		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (W & GW_NO_BC) == GW_NO_BC;
+		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (PARA && (W & GW_NO_BC) == GW_NO_BC);
 		const uint64_t d1 = (donew << 1) | 1ull;                              // bit r: vertex s - 1 + r is done (r = 0 stands for everything below the window)
 		auto ready = [&](uint32_t x) -> uint32_t { const int32_t r = (int32_t)(x - s) + 1; return (uint32_t)(d1 >> (uint32_t)(r > 0 ? r : 0)) & 1u; };   // (x < i: r <= 63)
 		const bool done_i = __builtin_amdgcn_inverse_ballot_w64(donew), pred_done = __builtin_amdgcn_inverse_ballot_w64(d1);
 		const bool H = stays || !ch || pred_done;                             // starts a sum of its own: its v[a] is fetched, not scanned in
-		const uint32_t rdy = stays ? 1u : (ready(b) & ready(c) & (ch ? 1u : ready(A)));
+		const uint32_t rdy = stays ? 1u : ((PARA ? ready(b) & ready(c) : 1u) & (ch ? 1u : ready(A)));
 		const bool R = in && !done_i && rdy != 0;
 		const uint64_t Rm = __ballot(R), Sm = __ballot(R && H);
 		// the lanes that go: flood fill from the heads (Sm) up through consecutive ready lanes that continue their predecessor - adding the
@@ -230,15 +246,20 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &gra
 		// this pass's gathers first, then the next window's words: the gathers are what the scans wait for
 		const bool use = go && !stays;
 		const uint32_t gb = use ? b : 0u, gc = use ? c : 0u, gp = use && head ? (ch ? i - 1u : A) : 0u;
-		const typename V::Raw Bw = val.raw(gb), Cw = val.raw(gc), Pw = val.raw(gp);
+		typename V::Raw Bw, Cw;
+		if constexpr(PARA) { Bw = val.raw(gb); Cw = val.raw(gc); }
+		const typename V::Raw Pw = val.raw(gp);
 		uint32_t W2, A2; typename V::Raw D2;
 		{ const uint32_t ic = s_next + lane < nvert ? s_next + lane : nvert - 1u; graph.fetch(ic, W2, A2); W2 &= wmask; D2 = val.raw(ic); }
 		int32_t dv[NC], bv[NC], cv[NC], pv[NC], x[NC];
-		V::unpack(D, dv); V::unpack(Bw, bv); V::unpack(Cw, cv); V::unpack(Pw, pv);
+		V::unpack(D, dv); V::unpack(Pw, pv);
+		if constexpr(PARA) { V::unpack(Bw, bv); V::unpack(Cw, cv); }
 		uint32_t incl[NC], eh[NC];
 #pragma unroll
 		for(int q = 0; q < NC; q++) {
-			int32_t v = dv[q] + (use ? bv[q] - cv[q] + (head ? pv[q] : 0) : -base[q]);
+			int32_t v;
+			if constexpr(PARA) v = dv[q] + (use ? bv[q] - cv[q] + (head ? pv[q] : 0) : -base[q]);
+			else v = dv[q] + (use ? (head ? pv[q] : 0) : -base[q]);
 			x[q] = go ? v : 0;
 		}
 #pragma unroll
@@ -263,6 +284,11 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &gra
 	}
 	return bad;
 }
+template <class V, class GR>
+__device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &graph, const uint32_t nvert, const bool para,
+                                                    const int32_t (&base)[V::NC], WindowHand *hand = nullptr) {
+	return para ? delta_window_loop<true>(val, graph, nvert, base, hand) : delta_window_loop<false>(val, graph, nvert, base, hand);
+}
 
 // ---- the walk: meshes whose fronts break into MANY stretches (runs of vertices that each continue their predecessor's sum) ----
 // The window loop above is a scan machine: it finishes a whole run of such vertices per pass, which is what a mesh of a few long
@@ -284,13 +310,13 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &gra
 // mesh of 500 short stretches).
 struct WalkStarts { CRT_LDS const uint32_t *sbits; CRT_LDS uint32_t *tmp; uint32_t nw; };
 
-template <class V>
-__device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
-                                                  const uint32_t nvert, const bool para, const int32_t (&base)[V::NC], const WindowHand hand) {
+template <bool PARA, class V>
+__device__ __forceinline__ uint32_t delta_walk_loop(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
+                                                   const uint32_t nvert, const int32_t (&base)[V::NC], const WindowHand hand) {
 	constexpr int NC = V::NC;
 	const uint32_t lane = lane_id();
 	const uint64_t lane_lt = (1ull << lane) - 1ull;
-	const uint32_t wmask = para ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);
+	constexpr uint32_t wmask = PARA ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);
 	const uint32_t first = hand.s;                                          // everything below is done, and so are the window's set bits from there
 	for(uint32_t d = lane; d < G.nw; d += 64) {
 		const uint32_t b0 = d*32u;
@@ -331,22 +357,28 @@ __device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const u
 		const uint64_t am = __ballot(active);
 		if(!am) { if(cur >= nvert || !__ballot(need)) break; continue; }
 		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
-		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (W & GW_NO_BC) == GW_NO_BC;
+		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (PARA && (W & GW_NO_BC) == GW_NO_BC);
 		const bool own = ch && !at_start;                                      // continues the vertex this lane finished last pass: in `prev`
 		const uint32_t ic = i < nvert ? i : nvert - 1u;
 		const uint32_t ap = stays || own ? 0u : ch ? ic - 1u : A, gb = stays ? 0u : b, gc = stays ? 0u : c;
 		const uint32_t inext = ic + 1u < nvert ? ic + 1u : ic;
 		// the parents' fired bits and values and the next vertex' words: one round trip
-		uint32_t fa = fbits[ap >> 5], fb = fbits[gb >> 5], fc = fbits[gc >> 5];
-		typename V::Raw Bw = val.raw(gb), Cw = val.raw(gc), Pw = val.raw(ap);
+		uint32_t fa = fbits[ap >> 5], fb = 0xFFFFFFFFu, fc = 0xFFFFFFFFu;
+		typename V::Raw Bw, Cw;
+		if constexpr(PARA) { fb = fbits[gb >> 5]; fc = fbits[gc >> 5]; Bw = val.raw(gb); Cw = val.raw(gc); }
+		typename V::Raw Pw = val.raw(ap);
 		uint32_t W2 = gw[inext], A2 = ga.get(inext), F2 = fbits[inext >> 5]; typename V::Raw D2 = val.raw(inext);
 		asm volatile("" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(W2), "+v"(A2), "+v"(F2));
 		const bool mine_done = ((F >> (ic & 31u)) & 1u) != 0;                  // the window finished it out of order: stepped over (only this lane ever fires it otherwise)
-		const uint32_t ready = stays ? 1u : ((fa >> (ap & 31u)) & (fb >> (gb & 31u)) & (fc >> (gc & 31u)) & 1u);
+		const uint32_t ready = stays ? 1u : ((fa >> (ap & 31u)) & (PARA ? (fb >> (gb & 31u)) & (fc >> (gc & 31u)) : 1u) & 1u);
 		int32_t dv[NC], bv[NC], cv[NC], pv[NC], r[NC];
-		V::unpack(D, dv); V::unpack(Bw, bv); V::unpack(Cw, cv); V::unpack(Pw, pv);
+		V::unpack(D, dv); V::unpack(Pw, pv);
+		if constexpr(PARA) { V::unpack(Bw, bv); V::unpack(Cw, cv); }
 #pragma unroll
-		for(int q = 0; q < NC; q++) r[q] = dv[q] + (stays ? -base[q] : bv[q] - cv[q] + (own ? prev[q] : pv[q]));
+		for(int q = 0; q < NC; q++) {
+			if constexpr(PARA) r[q] = dv[q] + (stays ? -base[q] : bv[q] - cv[q] + (own ? prev[q] : pv[q]));
+			else r[q] = dv[q] + (stays ? -base[q] : (own ? prev[q] : pv[q]));
+		}
 		const bool fire = active && (ready != 0 || mine_done), store = fire && !mine_done;
 		if(store) {
 			val.store(ic, r, A);
@@ -354,7 +386,7 @@ __device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const u
 		}
 		uint32_t chk = 0;
 #pragma unroll
-		for(int q = 0; q < NC; q++) { chk |= (uint32_t)r[q] + 0x8000u; prev[q] = store ? r[q] : prev[q]; }
+		for(int q = 0; q < NC; q++) { chk |= (uint32_t)r[q] + 0x8000u; prev[q] = store ? V::wrap(r[q]) : prev[q]; }   // (wrap: what the stored record reads back as - packed byte fields must not grow along a stretch)
 		if(V::CHECK) bad |= store ? chk : 0u;
 		// on: the next vertex of my stretch, or - it starts another stretch, or there is none - a new stretch for me
 		const bool ends = ic + 1u >= nvert || (W2 & GW_CHAINED) == 0;
@@ -367,6 +399,11 @@ __device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const u
 		val.sync();
 	}
 	return bad;
+}
+template <class V>
+__device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
+                                                  const uint32_t nvert, const bool para, const int32_t (&base)[V::NC], const WindowHand hand) {
+	return para ? delta_walk_loop<true>(val, gw, ga, fbits, G, nvert, base, hand) : delta_walk_loop<false>(val, gw, ga, fbits, G, nvert, base, hand);
 }
 
 // ---- staging: raw int32 deltas in HBM -> int16 records (checked); results back as the int32 / float the caller wants ----
@@ -676,12 +713,22 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 	const WalkStarts starts{sbits, wtmp, nw};
 	if(bytes) {
 		const LdsVal<5> val{(CRT_LDS uint32_t *)rec};
-		const int32_t zero[4] = {0, 0, 0, 0};
 		WindowHand hand;
-		(void)delta_window_run(val, GraphLds{gw, ga}, nvert, J.parallelogram != 0, zero, &hand);
-		if(hand.s < nvert) {
-			if(lane == 0) as_global(J.flags)[1] = 1;
-			(void)delta_walk_run(val, gw, ga, fbits, starts, nvert, J.parallelogram != 0, zero, hand);
+		if(J.parallelogram) {
+			const int32_t zero[4] = {0, 0, 0, 0};
+			(void)delta_window_loop<true>(val, GraphLds{gw, ga}, nvert, zero, &hand);
+			if(hand.s < nvert) {
+				if(lane == 0) as_global(J.flags)[1] = 1;
+				(void)delta_walk_loop<true>(val, gw, ga, fbits, starts, nvert, zero, hand);
+			}
+		} else {                                                               // additions only: two packed registers instead of four components
+			const LdsVal<6> val2{(CRT_LDS uint32_t *)rec};
+			const int32_t zero[2] = {0, 0};
+			(void)delta_window_loop<false>(val2, GraphLds{gw, ga}, nvert, zero, &hand);
+			if(hand.s < nvert) {
+				if(lane == 0) as_global(J.flags)[1] = 1;
+				(void)delta_walk_loop<false>(val2, gw, ga, fbits, starts, nvert, zero, hand);
+			}
 		}
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		stage_out_bytes(val, J, J.qc[0], J.qc[1], J.qc[2], J.qc[3]);
