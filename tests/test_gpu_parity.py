@@ -1480,6 +1480,33 @@ def test_bench_eight_pool_devices_on_one_gpu():
     assert len(j["steps_per_device"]) == 8 and all(x > 0 for x in j["steps_per_device"]), j["steps_per_device"]
     assert j["poisoned_lanes"] == 16 and j["config"]["launch"] == "single-process-queue"
     assert j["host_us_per_step_per_thread"] > 0 and j["sustained"]["seconds"] >= 0.3
+    assert len(j["per_gpu_mtri_per_s"]) == 8 and j["scaling_report"]["one_gpu_alone_mtri_per_s"] > 0 and j["scaling_report"]["efficiency_vs_1gpu"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_under_torch_distributed_run():
+    """the driver's launch form for N > 1 - `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` - with two ranks sharing this
+    box's one GPU ($BENCH_SHARE_GPU=1: gloo carries the barrier and the reductions): rank 0 prints ONE JSON line with n_gpus 2, both ranks'
+    rates in per_gpu_mtri_per_s and the scaling report SURVEY 8e asks for"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu", "--no-tunstall-scaled", "--no-other-configs",
+                          "--sustain", "0.2", "--host-threads", "2", "--depth", "3"], env=env, cwd=root, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["bit_exact"] is True and j["config"]["launch"] == "process-per-gpu"
+    assert len(j["per_gpu_mtri_per_s"]) == 2 and all(x > 0 for x in j["per_gpu_mtri_per_s"]), j["per_gpu_mtri_per_s"]
+    sr = j["scaling_report"]
+    assert sr["one_gpu_alone_mtri_per_s"] > 0 and 0 < sr["efficiency_vs_1gpu"] < 2.0 and sr["host_us_per_step_per_thread"] > 0
 
 
 def test_delta_values_beyond_int16_are_redone_and_the_context_learns():
