@@ -87,7 +87,11 @@ typedef struct {
 /* Per-attribute output binding (Decoder::setAttribute, src/decoder.cpp:96-123).
  * buffer == NULL leaves the attribute unbound: its streams are skipped, like the reference does.
  * Buffers are DEVICE pointers for the batch API (crthip_batch_*) and HOST pointers for crthip_decode_host.
- *   generic (position, uv, radius, ...): FLOAT only; nvert*components*4 bytes (decoded in place as int32 first)
+ *   generic (position, uv, radius, ...): FLOAT - nvert*components*4 bytes (decoded in place as int32 first) - is what upstream's callers use;
+ *            the other formats of Decoder::setAttribute(name, buffer, format) (src/decoder.cpp:96-102) are taken too (ABI v4): the integer
+ *            formats leave upstream's in-place "*= q" over the int32 array (nvert*components*4 bytes), DOUBLE widens it (nvert*components*8
+ *            bytes) - what the compiled reference leaves there, include/corto/vertex_attribute.h:195-228; packed only (stride 0), 4-byte
+ *            aligned (DOUBLE: 8)
  *   FLOAT buffers must be 4-byte aligned and INT16 ones 2-byte aligned (what a float* / int16_t* is), else CRTHIP_E_ARGUMENT
  *   normal : FLOAT (nvert*3 f32) or INT16 (nvert*3 i16)
  *   color  : UINT8, out_components = 3 or 4 (>= stored components); nvert*out_components bytes        */
