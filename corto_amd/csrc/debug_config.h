@@ -33,7 +33,7 @@ inline DebugConfig debug_config_from_env() {
 	if(const char *e = getenv("CORTO_TUN_SHARE")) if(e[0] >= '0' && e[0] <= '2') c.tun_share = e[0] - '0';
 	c.delta_wide = on("CORTO_DELTA_WIDE");
 	c.check_pinned = on("CORTO_HIP_CHECK_PINNED");
-	c.unpack_chunked = on("CORTO_UNPACK_CHUNKED") || on("CORTO_EXP_UNPACK_CHUNKED");
+	c.unpack_chunked = on("CORTO_UNPACK_CHUNKED");
 	return c;
 }
 

@@ -1,8 +1,8 @@
 // k_delta.hip — K-DELTA for blobs whose values and prediction graph fit LDS (round 3): v[i] += v[a] + v[b] - v[c] (or += v[a]) for
 // i = 1 .. nvert-1 in index order (include/corto/vertex_attribute.h:160-176, src/normal_attribute.cpp:193-201).
 //
-// One workgroup per blob, one wave per attribute (up to four) sharing the prediction graph, like k_delta_wave (k_mesh.hip), which
-// stays as the wide path.  What is different here:
+// One workgroup per blob, one wave per attribute (up to four) sharing the prediction graph (round 2's k_delta_wave did the same with 32-bit
+// values and in-order scans; round 4 retired it: the 32-bit records live here too, LdsW below).  What this kernel does:
 //
 // * Values live in LDS as 16-BIT integers RELATIVE TO VERTEX 0.  The recurrence is affine with weights +1 +1 -1, so subtracting
 //   vertex 0's value from every vertex leaves it unchanged: rel[i] = d[i] + rel[a] + rel[b] - rel[c].  A mesh quantised to n bits

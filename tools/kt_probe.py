@@ -1,4 +1,4 @@
-"""Probe: per-kernel HIP-event times of one C4 batch decoded unpipelined, no verification (for $CORTO_EXP_* experiments)."""
+"""Probe: per-kernel HIP-event times of one C4 batch decoded unpipelined, no verification (the A/B instrument of kernel changes: two builds, tools/ab_build.sh)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,4 +16,4 @@ for i in range(N + 3):
     if i >= 3:
         for k, v in b.kernel_times().items():
             a = acc.setdefault(k, [0.0, 0]); a[0] += v["ms"]; a[1] += v.get("launches", 1)
-print(os.environ.get("CORTO_EXP_TUN", "-"), {k: (round(v[0] / N, 4), v[1] // N) for k, v in acc.items()})
+print(os.environ.get("CORTO_HIP_LIB_PATH", "-"), {k: (round(v[0] / N, 4), v[1] // N) for k, v in acc.items()})
