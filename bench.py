@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=5, help="native host threads per GPU feeding it (crthip_pool)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the `sustained` leg (one long timed region on the same pool); 0 skips it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: also run the single-GPU characterisation legs (CPU baseline, Tunstall at roofline scale, single objects, irregular batches) that belong to the N = 1 line")
     ap.add_argument("--no-tunstall-scaled", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the single-object C2 / C3 decodes (tools/prof_run.sh: keeps the rocprofv3 kernel averages about the C4 batch)")
     args = ap.parse_args()
@@ -438,6 +439,13 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=red_dev)
 
+    # the single-GPU characterisations - reference decoder on the host's cores, Tunstall at roofline scale, the single-object configs, the
+    # drop-in class, irregular / realistic batches - belong to the N = 1 line (the task: `cpu_baseline` on rank 0 at N = 1 only); an N > 1
+    # run is the scaling measurement and skips them unless asked (--all-legs): the other ranks would only wait at a barrier meanwhile
+    n1_only_skipped = False
+    if n_gpus > 1 and not args.all_legs:
+        args.no_cpu = args.no_tunstall_scaled = args.no_other_configs = True
+        n1_only_skipped = True
     from corto_amd import shard
     # C5 = n_gpus x 256 blobs cut into contiguous work-balanced ranges (one work item each); seeds 256*g .. 256*g+255 for range g
     ranges = shard.balanced_ranges([4096 + 2112] * (NBLOBS * n_gpus), n_gpus)
@@ -846,6 +854,8 @@ def main():
         if scaling_block and scaling_block["one_gpu_alone_mtri_per_s"]:
             scaling_block["efficiency_vs_1gpu"] = round(out["value"] / (n_gpus * scaling_block["one_gpu_alone_mtri_per_s"]), 4)
             scaling_block["host_us_per_step_per_thread"] = out["host_us_per_step_per_thread"]
+        if n1_only_skipped:
+            out["n1_only_legs"] = "skipped (cpu_baseline, tunstall_scaled, other_configs, irregular / realistic: see the N = 1 line; --all-legs runs them)"
         if share:
             out["shared_gpu"] = True
         if not args.no_tunstall_scaled:
