@@ -85,8 +85,8 @@ class PoolReport(C.Structure):
     _fields_ = [("elapsed_s", C.c_double), ("steps", C.c_uint64), ("triangles", C.c_uint64), ("vertices", C.c_uint64),
                 ("failed_blobs", C.c_uint64), ("first_error", C.c_int32), ("devices_used", C.c_uint32),
                 ("steps_per_device", C.c_uint64 * 16), ("topology_fallbacks", C.c_uint64),
-                ("poisoned_lanes", C.c_uint32), ("pinned_devices", C.c_uint32), ("host_us_per_step", C.c_float), ("reserved", C.c_uint32),
-                ("host_wait_us", C.c_float), ("host_finish_us", C.c_float), ("host_plan_us", C.c_float), ("reserved2", C.c_uint32)]
+                ("poisoned_lanes", C.c_uint32), ("pinned_devices", C.c_uint32), ("host_us_per_step", C.c_float), ("host_plan_max_us", C.c_float),
+                ("host_wait_us", C.c_float), ("host_finish_us", C.c_float), ("host_plan_us", C.c_float), ("host_launch_max_us", C.c_float)]
 
 
 class KernelTimes(C.Structure):

@@ -876,6 +876,9 @@ int Planner::jobs() {
 				for(;;) {                                                                // as much of the context's scale as fits a CU
 					topo_lds_geometry(nface, L.clers.size, 4096, scale, nblobs >= 32 ? 4u : 8u, ring, pool, symwin);
 					need = topo_lds_bytes(ring, pool, pool, symwin);                     // every delayed edge is a pool record: same capacity
+#ifdef CORTO_TOPO_STAMPS
+					if(need <= 32768 && L.clers.size < 8190) need = 65536;              // (the dispatch trace: k_mesh.hip TOPO_ASM_STAMP)
+#endif
 					if(need <= TOPO_LDS_MAX || scale == 1) break;
 					scale >>= 1;
 				}

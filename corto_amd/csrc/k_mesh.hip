@@ -285,6 +285,21 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // after a consumed symbol: advance the nibble window (every eighth symbol takes the out-of-line refill), test the end of the
 // group, and dispatch the NEXT symbol right here - "threaded": one taken branch per symbol instead of four (a taken branch
 // restarts the lone wave's instruction fetch, ~20 clocks each)
+// -DCORTO_TOPO_STAMPS: every dispatch leaves the shader clock in an LDS trace word of its own (32 KB up, indexed by the symbol it is about to
+// take): tools/topo_trace_probe.py turns the differences into what each kind of step costs.  Nothing in the product build.
+#ifdef CORTO_TOPO_STAMPS
+#define TOPO_ASM_STAMP \
+							"  s_memtime s[96:97]\n" \
+							"  s_mul_i32 s98, %[cler], 4\n" \
+							"  v_mov_b32 v63, s98\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_mov_b32 v62, s96\n" \
+							"  ds_write_b32 v63, v62 offset:32768\n"
+#define TOPO_ASM_STAMP_CLOBBERS , "s96", "s97", "s98"
+#else
+#define TOPO_ASM_STAMP
+#define TOPO_ASM_STAMP_CLOBBERS
+#endif
 #define TOPO_ASM_TAIL \
 							"  s_lshr_b32 %[sw], %[sw], 4\n" \
 							"  s_add_u32 %[cler], %[cler], 1\n" \
@@ -292,6 +307,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc0 Lrefill_%=\n" \
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc0 Lexit_%=\n" \
+							TOPO_ASM_STAMP \
 							"  s_and_b32 %[c], %[sw], 15\n" \
 							"  s_cbranch_scc0 Lvertex_%=\n" \
 							"  s_cmp_eq_u32 %[c], 1\n" \
@@ -302,6 +318,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 #define TOPO_FAST_PATH(FACE, RUNFACE, MIXFACE, FSHIFT) \
 						asm volatile( \
 							"Ltop_%=:\n" \
+							TOPO_ASM_STAMP \
 							"  s_and_b32 %[c], %[sw], 15\n"   /* (SCC = result != 0) */ \
 							"  s_cbranch_scc0 Lvertex_%=\n" \
 							"  s_cmp_eq_u32 %[c], 1\n" \
@@ -353,7 +370,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
    /* ---------------- LEFT (decoder.cpp:311-317), neighbour in the ring */ \
 							"Lleft_%=:\n" \
 							"  s_cmp_gt_u32 %[ep], %[mask]\n" \
-							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_cbranch_scc1 Lleftp_%=\n" \
 							"  s_and_b32 %[t0], %[sw], 0xeeee\n" \
 							"  s_cbranch_scc0 Llmix_%=\n" \
 							"Llgo_%=:\n" \
@@ -379,7 +396,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_eq_u32 %[en], %[nc]\n" \
 							"  s_cbranch_scc1 Lrightc_%=\n" \
 							"  s_cmp_gt_u32 %[en], %[mask]\n" \
-							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_cbranch_scc1 Lrightp_%=\n" \
 							"  ds_read_b128 v[56:59], v52\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
 							"  v_readfirstlane_b32 %[t1], v57\n"   /* opp = next.v1 */ \
@@ -392,6 +409,66 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lrightd_%=:\n" \
 							"  v_mov_b32 v53, 0x8000\n" \
 							"  ds_write_b16 v52, v53 offset:10\n"   /* next.deleted = true */ \
+							FACE("%[t1]") \
+							"  s_add_u32 %[start], %[start], 3\n" \
+							"  s_mov_b32 %[nc], -1\n" \
+							"  s_mov_b32 %[v2], %[v1]\n" \
+							"  s_mov_b32 %[v1], %[t1]\n" \
+							"  s_mov_b32 %[en], %[t2]\n" \
+							TOPO_ASM_TAIL \
+   /* ---------------- LEFT / RIGHT against a survivor (a pool slot: the neighbour is a chain end - after a DELAY, along a boundary, where a \
+      mesh zips up): the same step, and the slot goes back to the free list unless it still sits in the DELAY stack (whose pop returns it). \
+      Free list at (mask+1)*32 + 2*fill, fill = pk1 >> 16. */ \
+							"Lleftp_%=:\n" \
+							"  s_lshl_b32 %[t0], %[ep], 4\n" \
+							"  v_mov_b32 v52, %[t0]\n" \
+							"  ds_read_b128 v[56:59], v52\n" \
+							"  v_mov_b32 v53, 0x8000\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[t1], v56\n"   /* opp = prev.v0 */ \
+							"  v_readfirstlane_b32 %[t2], v59\n" \
+							"  v_readfirstlane_b32 %[t3], v58\n"   /* its flags */ \
+							"  ds_write_b16 v52, v53 offset:10\n"   /* prev.deleted = true */ \
+							"  s_and_b32 %[t2], %[t2], 0xffff\n"   /* pp = prev.prev */ \
+							"  s_bitcmp1_b32 %[t3], 30\n"           /* TOPO_DELAYED */ \
+							"  s_cbranch_scc1 Lleftq_%=\n" \
+							"  s_lshr_b32 %[t0], %[pk1], 16\n" \
+							"  s_lshl_b32 %[t0], %[t0], 1\n" \
+							"  s_add_u32 %[t3], %[mask], 1\n" \
+							"  s_lshl_b32 %[t3], %[t3], 5\n" \
+							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
+							"  v_mov_b32 v54, %[t0]\n" \
+							"  v_mov_b32 v55, %[ep]\n" \
+							"  ds_write_b16 v54, v55\n" \
+							"  s_add_u32 %[pk1], %[pk1], 0x10000\n" \
+							"Lleftq_%=:\n" \
+							FACE("%[t1]") \
+							"  s_add_u32 %[start], %[start], 3\n" \
+							"  s_mov_b32 %[v2], %[v0]\n" \
+							"  s_mov_b32 %[v0], %[t1]\n" \
+							"  s_mov_b32 %[ep], %[t2]\n" \
+							TOPO_ASM_TAIL \
+							"Lrightp_%=:\n" \
+							"  ds_read_b128 v[56:59], v52\n"        /* (v52 = en*16 from Lright) */ \
+							"  v_mov_b32 v53, 0x8000\n" \
+							"  s_waitcnt lgkmcnt(0)\n" \
+							"  v_readfirstlane_b32 %[t1], v57\n"   /* opp = next.v1 */ \
+							"  v_readfirstlane_b32 %[t2], v59\n" \
+							"  v_readfirstlane_b32 %[t3], v58\n" \
+							"  ds_write_b16 v52, v53 offset:10\n"   /* next.deleted = true */ \
+							"  s_lshr_b32 %[t2], %[t2], 16\n"       /* nn = next.next */ \
+							"  s_bitcmp1_b32 %[t3], 30\n" \
+							"  s_cbranch_scc1 Lrightq_%=\n" \
+							"  s_lshr_b32 %[t0], %[pk1], 16\n" \
+							"  s_lshl_b32 %[t0], %[t0], 1\n" \
+							"  s_add_u32 %[t3], %[mask], 1\n" \
+							"  s_lshl_b32 %[t3], %[t3], 5\n" \
+							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
+							"  v_mov_b32 v54, %[t0]\n" \
+							"  v_mov_b32 v55, %[en]\n" \
+							"  ds_write_b16 v54, v55\n" \
+							"  s_add_u32 %[pk1], %[pk1], 0x10000\n" \
+							"Lrightq_%=:\n" \
 							FACE("%[t1]") \
 							"  s_add_u32 %[start], %[start], 3\n" \
 							"  s_mov_b32 %[nc], -1\n" \
@@ -577,8 +654,12 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
       not lie inside the staged words is left to the C++ (which also reports a stream that runs out of bits).  vcc is scratch here: \
       the two words as a 64-bit value, then the vertex id. */ \
 							"Lsplit_%=:\n" \
-							"  s_sub_u32 %[budget], %[budget], 1\n"   /* a ring slot (SCC = borrow: none) */ \
+							"  s_sub_u32 %[t0], %[nq], %[qpos]\n"    /* a ring slot - NOT a vertex id: the SPLITs of a mesh that zips up come when every vertex has been made */ \
+							"  s_cmp_gt_u32 %[t0], %[mask]\n" \
 							"  s_cbranch_scc1 Lexit_%=\n" \
+							"  s_cmp_lg_u32 %[budget], 0\n"          /* (the VERTEXes' budget counts ring slots too) */ \
+							"  s_cselect_b32 %[t0], 1, 0\n" \
+							"  s_sub_u32 %[budget], %[budget], %[t0]\n" \
 							"  s_sub_u32 %[t0], %[clbase], 1056\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
 							"  ds_read2_b32 v[56:57], v52 offset0:3 offset1:4\n" \
@@ -673,7 +754,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63" TOPO_ASM_STAMP_CLOBBERS);
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -1351,6 +1432,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // crthip_debug_topo_stamps.  Phases: 0 ISA block (run and mix steps included), 3 C++ symbol, 4 gate fetch, 5 prologue; [15] = all of it.
 #ifdef CORTO_TOPO_STAMPS
 __device__ uint32_t g_topo_stamps[48*4096];
+__device__ uint32_t g_topo_trace[16*8192];
 #define TOPO_CLK() ((uint32_t)__builtin_amdgcn_s_memtime())
 #define TOPO_T0() const uint32_t tt0_ = TOPO_CLK(), tc0_ = cler
 #define TOPO_ACC(i) do { st_clk[i] += TOPO_CLK() - tt0_; st_cnt[i]++; st_sym[i] += cler - tc0_; } while(0)
@@ -1395,6 +1477,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #ifdef CORTO_TOPO_STAMPS
 	uint32_t st_clk[6] = {0, 0, 0, 0, 0, 0}, st_cnt[6] = {0, 0, 0, 0, 0, 0}, st_sym[6] = {0, 0, 0, 0, 0, 0};
 	const uint32_t st_begin = TOPO_CLK();
+#endif
+#ifdef CORTO_TOPO_STAMPS
+	for(uint32_t i = threadIdx.x; i < 8192; i += 64) ((CRT_LDS uint32_t *)as_lds(lds))[8192 + i] = 0;
 #endif
 	TOPO_FILL_WINDOW(0u);
 	if(nspl) {                                                            // (<= 256 words: four loads per lane, in flight together)
@@ -1618,6 +1703,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	if(blockIdx.x < 4096) {
 		uint32_t *o_ = g_topo_stamps + blockIdx.x*48;
 		for(int i = 0; i < 6; i++) { o_[i] = st_clk[i]; o_[8 + i] = st_cnt[i]; o_[16 + i] = st_sym[i]; }
+		if(blockIdx.x < 16) { const uint32_t tn_ = cler + 1 < 8192 ? cler + 1 : 8192; for(uint32_t i = 0; i < 8192; i++) g_topo_trace[blockIdx.x*8192 + i] = i < tn_ ? ((CRT_LDS uint32_t *)as_lds(lds))[8192 + i] : 0u; g_topo_trace[blockIdx.x*8192 + 8191] = TOPO_CLK(); }
 		o_[15] = TOPO_CLK() - st_begin; o_[24] = cler; o_[25] = err; o_[26] = nq; o_[27] = qpos; o_[28] = vc; o_[29] = start; o_[30] = RING; o_[31] = pk1; o_[32] = pk2; o_[33] = dcap;
 	}
 #endif
@@ -1774,5 +1860,6 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 } // namespace corto_hip
 
 #ifdef CORTO_TOPO_STAMPS
+extern "C" int crthip_debug_topo_trace(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_topo_trace), sizeof(uint32_t)*16*8192); }
 extern "C" int crthip_debug_topo_stamps(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_topo_stamps), sizeof(uint32_t)*48*4096); }
 #endif

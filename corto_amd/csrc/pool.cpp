@@ -220,7 +220,8 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	std::vector<std::atomic<uint64_t>> per_dev(p->ndevices);
 	for(auto &x : per_dev) x = 0;
 	std::atomic<int32_t> first_error{0};
-	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0};
+	std::atomic<uint64_t> host_ns{0}, host_steps{0}, wait_ns{0}, finish_ns{0}, plan_ns{0}, plan_max_ns{0}, launch_max_ns{0};
+	auto raise_max = [](std::atomic<uint64_t> &m, uint64_t v) { uint64_t cur = m.load(); while(v > cur && !m.compare_exchange_weak(cur, v)) { } };
 	// home shard first: pool device d owns the items j with j % ndevices == d (its shard is resident there), and a device without a home
 	// item takes from the others' ("stealing" in a cyclic run: it is the work list that is shared, a faster GPU simply draws more tickets)
 	std::vector<std::vector<uint32_t>> home(p->ndevices);
@@ -286,7 +287,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			else j = (uint32_t)(stolen.fetch_add(1) % nitems);
 			const auto h0 = std::chrono::steady_clock::now();
 			err = lane_plan(p, L, items[j], (int64_t)j);
-			plan_ns += ns_since(h0);
+			{ const uint64_t ns_ = ns_since(h0); plan_ns += ns_; raise_max(plan_max_ns, ns_); }
 			// the outputs every lane holds after the run were written by a step that STARTED from a poisoned block: the post-run bit-exact
 			// check cannot pass on bytes an earlier step left behind (on the context's own stream: ordered before the step's kernels)
 			L.poisoned = false;
@@ -294,7 +295,9 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 				err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
 				if(!err) L.poisoned = true;
 			}
+			const auto d0 = std::chrono::steady_clock::now();
 			if(!err) err = crthip_batch_decode(L.batch);
+			raise_max(launch_max_ns, ns_since(d0));
 			host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count(); host_steps++;
 			if(!err) { L.busy = true; L.step = step; }
 		}
@@ -334,6 +337,7 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	if(host_steps) {
 		report->host_wait_us = (float)((double)wait_ns/1e3/(double)host_steps); report->host_finish_us = (float)((double)finish_ns/1e3/(double)host_steps);
 		report->host_plan_us = (float)((double)plan_ns/1e3/(double)host_steps);
+		report->host_plan_max_us = (float)((double)plan_max_ns/1e3); report->host_launch_max_us = (float)((double)launch_max_ns/1e3);
 	}
 	for(uint32_t d = 0; d < p->ndevices; d++) if(!p->cpus[d].empty()) report->pinned_devices++;
 	if(completion_s) for(uint64_t c = 0; c < steps; c++) completion_s[c] = stamps[warmup + 1 + c] - stamps[warmup];

@@ -238,10 +238,10 @@ typedef struct {
 	                                crthip_pool_lane_read returns afterwards was written by those steps and by nothing earlier */
 	uint32_t pinned_devices;     /* pool devices whose worker threads were pinned to the CPUs of the GPU's NUMA node */
 	float host_us_per_step;      /* host time per step and thread: plan (walk + bind) + enqueue, averaged over every executed step */
-	uint32_t reserved;
+	float host_plan_max_us;      /* the LONGEST single plan call (walk + the upload's enqueue + bind) of the run ... */
 	float host_wait_us, host_finish_us, host_plan_us;   /* of a worker thread's time per step: waiting for one of its contexts to finish; harvesting it
 	                                (sync, status); the walk + bind part of host_us_per_step */
-	uint32_t reserved2;
+	float host_launch_max_us;    /* ... and the longest single crthip_batch_decode call: a host thread that blocks inside the runtime shows here */
 } crthip_pool_report;
 
 /* Decode warmup + steps batches drawn cyclically from the items (each device from its home items, see above; + a few more steps to

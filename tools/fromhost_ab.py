@@ -28,7 +28,7 @@ for name in want:
         d = np.diff(t)
         order = np.argsort(d)[::-1][:4]
         w = bench.window_stats(st, pool.lanes)
-        print("%-22s %.4f ms/step mean, %.4f median window, %.4f best | host %.0f us/step/thread (plan %.0f wait %.0f harvest %.0f) | largest gaps (us@step): %s" % (
-            name, rep.elapsed_s / steps * 1e3, w["median_ms_per_step"], w["best_ms_per_step"], rep.host_us_per_step, rep.host_plan_us, rep.host_wait_us, rep.host_finish_us,
+        print("%-22s %.4f ms/step mean, %.4f median window, %.4f best | host %.0f us/step/thread (plan %.0f wait %.0f harvest %.0f; longest plan %.0f launch %.0f) | largest gaps (us@step): %s" % (
+            name, rep.elapsed_s / steps * 1e3, w["median_ms_per_step"], w["best_ms_per_step"], rep.host_us_per_step, rep.host_plan_us, rep.host_wait_us, rep.host_finish_us, rep.host_plan_max_us, rep.host_launch_max_us,
             ", ".join("%.0f@%d" % (d[i] * 1e6, i) for i in order)), flush=True)
     pool.close()

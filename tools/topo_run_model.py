@@ -26,7 +26,9 @@ class Model:
         self.any_align = os.environ.get('MIX_ANY_ALIGN', '0') == '1'   # experiment: a trigger that peeks into the next window word too (more one-symbol steps: not taken)
         self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
         self.group_end = group_end
-        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0, mixes=0, mix_symbols=0, mix_hist={}, ends=0, end_symbols=0, end_hist={})
+        self.events = []                  # (symbol index, kind, symbols taken / entries skipped): what tools/topo_trace_probe.py labels the kernel's dispatch trace with
+        self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0, mixes=0, mix_symbols=0, mix_hist={}, ends=0, end_symbols=0, end_hist={},
+                          pops=0, dead=0, dpops=0, seeds=0, ser={k: 0 for k in 'VLREBDS'}, lone_v_before_run=0, run0=0, mix0=0)
 
     def win_left(self, cler):
         return 1 << 30                      # (the model holds the whole stream; the kernel bounds a step by its LDS window)
@@ -43,15 +45,18 @@ class Model:
                 # fetch next edge
                 if qpos != nq:
                     t = rec[qpos & MASK]; qpos += 1
-                    if t[3]: continue
+                    if t[3]: self.stats['dead'] += 1; self.events.append((cler, 'dead', 1)); continue
+                    self.stats['pops'] += 1; self.events.append((cler, 'pop', 1))
                     cur = list(t)
                 elif delayed:
                     f = delayed.pop(); t = rec[f]; free.append(f)
                     if t[3]: continue
+                    self.stats['dpops'] += 1; self.events.append((cler, 'dpop', 1))
                     cur = list(t)
                 else:
                     c = cl[cler]; cler += 1
                     assert c in (V, S)
+                    self.stats['seeds'] += 1; self.events.append((cler - 1, 'seed', 1))
                     last = vc - 1; vi = []
                     for k in range(3):
                         rv = int(self.ref_faces[start // 3][k])
@@ -103,9 +108,10 @@ class Model:
                             epn = w[k - 1]; enn = (nq + k - 1) & MASK
                             v0, v1, v2, ep, en = v0n, v1n, v2n, epn, enn
                             vc += k; nq += k; start += 6 * k; cler += 2 * k
-                            self.stats['runs'] += 1; self.stats['run_pairs'] += k
+                            self.stats['runs'] += 1; self.stats['run_pairs'] += k; self.events.append((cler - 2*k, 'run', 2*k))
                             if start >= end: break
                             continue
+                        self.stats['run0'] += 1
                     # ---- the mix step: k symbols of any VERTEX / LEFT sequence at once, one symbol per lane (TOPO_MIX_STEP)
                     if self.use_mix and ((cler & 7) <= 4 or self.any_align) and all(cl[cler + d] in (V, L) for d in range(4)) and ep <= MASK \
                             and [cl[cler + d] for d in range(4)] not in ([V, L, V, L], [L, V, L, V], [V, V, L, V]):
@@ -164,11 +170,12 @@ class Model:
                             enn = (nq + TV - 1) & MASK if TV else en
                             v0, v1, v2, ep, en = a, b, c, epn, enn
                             vc += TV; nq += TV; start += 3 * k; cler += k
-                            self.stats['mixes'] += 1; self.stats['mix_symbols'] += k
+                            self.stats['mixes'] += 1; self.stats['mix_symbols'] += k; self.events.append((cler - k, 'mix', k))
                             self.stats['mix_hist'][k] = self.stats['mix_hist'].get(k, 0) + 1
                             if k <= 2: self.stats.setdefault('short', {}); pat = ''.join('VLREBDS?'[min(c_, 7)] for c_ in cl[cler - k:cler - k + 8]); self.stats['short'][pat] = self.stats['short'].get(pat, 0) + 1
                             if start >= end: break
                             continue
+                        self.stats['mix0'] += 1
                     # ---- the chain-end step: k BOUNDARY / DELAY symbols at once (TOPO_ASM_ENDS).  Symbol m materialises edge m and pops edge
                     # m+1: edge 0 is the current one (scalar code, first: its link writes land in the ring records the lanes then read), edge
                     # m >= 1 the m-th live entry of the next 64 queue entries, each on its own lane; the last one popped becomes current.
@@ -200,11 +207,14 @@ class Model:
                             v0, v1, v2, ep, en = t[0], t[1], t[2], fwd.get(t[4], t[4]), fwd.get(t[5], t[5])
                             qpos += live[k - 1] + 1
                             cler += k
-                            self.stats['ends'] += 1; self.stats['end_symbols'] += k
+                            self.stats['ends'] += 1; self.stats['end_symbols'] += k; self.events.append((cler - k, 'ends', k)); self.events.append((cler, 'pop', live[k - 1] + 1))
                             self.stats['end_hist'][k] = self.stats['end_hist'].get(k, 0) + 1
                             continue
                     c = cl[cler]; cler += 1
                     self.stats['serial'] += 1
+                    self.stats['ser']['VLREBDS'[c]] += 1
+                    self.events.append((cler - 1, 'VLREBDS'[c] + ('p' if (c == L and ep > MASK) or (c == R and en > MASK) else ''), 1))
+                    if c == V and [cl[cler + d] for d in range(4)] == [V, L, V, L]: self.stats['lone_v_before_run'] += 1
                     if c == V or c == S:
                         if c == S: opp = int(self.ref_faces[start // 3][2])
                         else:
