@@ -289,13 +289,13 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // take): tools/topo_trace_probe.py turns the differences into what each kind of step costs.  Nothing in the product build.
 #ifdef CORTO_TOPO_STAMPS
 #define TOPO_ASM_STAMP \
-							"  s_memtime s[96:97]\n" \
-							"  s_mul_i32 s98, %[cler], 4\n" \
-							"  v_mov_b32 v63, s98\n" \
+							"  s_memtime s[94:95]\n" \
+							"  s_mul_i32 s96, %[cler], 4\n" \
+							"  v_mov_b32 v63, s96\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_mov_b32 v62, s96\n" \
+							"  v_mov_b32 v62, s94\n" \
 							"  ds_write_b32 v63, v62 offset:32768\n"
-#define TOPO_ASM_STAMP_CLOBBERS , "s96", "s97", "s98"
+#define TOPO_ASM_STAMP_CLOBBERS , "s94", "s95", "s96"
 #else
 #define TOPO_ASM_STAMP
 #define TOPO_ASM_STAMP_CLOBBERS
@@ -330,7 +330,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lvertex_%=:\n" \
 							"  s_and_b32 %[t0], %[sw], 0xffff\n"   /* VERTEX LEFT VERTEX LEFT ahead: leave for the run step (TOPO_RUN_STEP) */ \
 							"  s_cmp_eq_u32 %[t0], 0x1010\n" \
-							"  s_cbranch_scc1 Lrun_%=\n" \
+							"  s_cbranch_scc1 Lvrun_%=\n" \
 							"  s_and_b32 %[t1], %[t0], 0xeeee\n"   /* four symbols of VERTEX / LEFT ahead: maybe the mix step (checked out of line) */ \
 							"  s_cbranch_scc0 Lvmix_%=\n" \
 							"Lvgo_%=:\n" \
@@ -720,6 +720,15 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lexit_%=\n" \
 							   /* ---------------- four symbols of VERTEX / LEFT ahead: the mix step (TOPO_MIX_STEP) takes them, unless they are the head of a regular \
 							      run one symbol on (V VLV.., L VLV..: that symbol here, then the run step) or the window register holds fewer than four */ \
+							"Lvrun_%=:\n"                          /* VERTEX LEFT VERTEX LEFT: the run step if EVERY symbol the window register shows (4 .. 8) goes */ \
+							"  s_cmp_eq_u32 %[sw], 0x10101010\n"   /* on like that - a shorter run is the mix step's, which takes what follows it too.  All eight: */ \
+							"  s_cbranch_scc1 Lrun_%=\n"           /* the usual case; else the 8 - (cler & 7) nibbles that are certainly symbols (after a step the */ \
+							"  s_and_b32 %[t1], %[cler], 7\n"      /* register holds lane k's eight whatever the alignment, after a one-at-a-time symbol zeros) */ \
+							"  s_lshl_b32 %[t1], %[t1], 2\n" \
+							"  s_xor_b32 %[t0], %[sw], 0x10101010\n" \
+							"  s_lshl_b32 %[t0], %[t0], %[t1]\n"   /* (SCC = result != 0: one of them breaks the pattern) */ \
+							"  s_cbranch_scc0 Lrun_%=\n" \
+							"  s_branch Lmix_%=\n" \
 							"Lvmix_%=:\n" \
 							"  s_cmp_eq_u32 %[t0], 0x0100\n" \
 							"  s_cbranch_scc1 Lvgo_%=\n" \
@@ -754,7 +763,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63" TOPO_ASM_STAMP_CLOBBERS);
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s98", "s99" TOPO_ASM_STAMP_CLOBBERS);
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -1087,8 +1096,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_and_b64 exec, exec, vcc\n" \
 	"  v_cmp_gt_u32 vcc, %[t3], v60\n"               /* ... within kmax ... */ \
 	"  s_and_b64 exec, exec, vcc\n" \
-	"  v_cmp_ne_u32 vcc, 0x10101010, v35\n"          /* ... and no regular run from here on */ \
-	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_eq_u32 vcc, 0x10101010, v35\n"          /* ... and no regular run of SIXTEEN symbols from here on (lane j + 8 sees its second half; a */ \
+	"  s_lshr_b64 s[98:99], vcc, 8\n"                /* shorter one costs the run step what it costs this one to take it along, and a step less) */ \
+	"  s_and_b64 s[98:99], s[98:99], vcc\n" \
+	"  s_andn2_b64 exec, exec, s[98:99]\n" \
 	"  s_not_b64 vcc, exec\n" \
 	"  s_ff1_i32_b64 %[t0], vcc\n"                   /* the first lane out as far as its own symbol goes (kmax < 64: there is one) */ \
 	"  s_mov_b64 exec, -1\n" \

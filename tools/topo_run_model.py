@@ -14,7 +14,7 @@ LAZY = 0xFFFF
 
 class Model:
     def __init__(self, clers, nvert, nface, group_end, ring=1 << 12, pool=1 << 12, use_runs=True, use_mix=True, use_ends=True, ref_faces=None):
-        self.cl = list(clers) + [15] * 64
+        self.cl = list(clers) + [15] * 160
         self.nvert, self.nface = nvert, nface
         self.RING, self.MASK, self.POOL = ring, ring - 1, pool
         self.rec = [[0, 0, 0, 0, 0, 0] for _ in range(ring + pool)]   # v0 v1 v2 flags(0 live,1 dead) prev next
@@ -75,7 +75,8 @@ class Model:
                 v0, v1, v2, _, ep, en = cur
                 while True:
                     # ---- the run step: k pairs of (VERTEX, LEFT) at once
-                    if self.use_runs and cl[cler] == V and cl[cler + 1] == L and cl[cler + 2] == V and cl[cler + 3] == L:
+                    vis = 8 - (cler & 7) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' else 4    # the run step only when ALL the symbols the window register shows alternate (the kernel since round 4; 0: the first four)
+                    if self.use_runs and cl[cler] == V and cl[cler + 1] == L and cl[cler + 2] == V and cl[cler + 3] == L and all(cl[cler + d] == (V, L)[d & 1] for d in range(4, vis)):
                         kmax = min(64, self.nvert - vc, self.RING - (nq - qpos), (end - start) // 6)
                         ok = []
                         for j in range(64):
@@ -114,7 +115,7 @@ class Model:
                         self.stats['run0'] += 1
                     # ---- the mix step: k symbols of any VERTEX / LEFT sequence at once, one symbol per lane (TOPO_MIX_STEP)
                     if self.use_mix and ((cler & 7) <= 4 or self.any_align) and all(cl[cler + d] in (V, L) for d in range(4)) and ep <= MASK \
-                            and [cl[cler + d] for d in range(4)] not in ([V, L, V, L], [L, V, L, V], [V, V, L, V]):
+                            and [cl[cler + d] for d in range(4)] not in (([L, V, L, V], [V, V, L, V]) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' else ([V, L, V, L], [L, V, L, V], [V, V, L, V])):
                         kmax = min(63, (end - start) // 3, self.win_left(cler))
                         budget = min(self.nvert - vc, self.RING - (nq - qpos))
                         sym = [cl[cler + j] for j in range(64)]
@@ -134,8 +135,9 @@ class Model:
                         C = 0
                         while C < 64 and chain_ok[C]: C += 1
                         bad = [not (isV[j] or isL[j]) or (isL[j] and nL[j] >= C) or (isV[j] and nV[j] >= budget) for j in range(64)]
+                        T = int(os.environ.get('MIX_RUN_AHEAD', '16'))   # how long a regular run ahead must be to end the mix step (16: what the kernel does; 8 until round 4)
                         for j in range(1, 64):              # a regular run ahead: the run step does two symbols a lane
-                            if [cl[cler + j + d] for d in range(8)] == [V, L] * 4: bad[j] = True
+                            if [cl[cler + j + d] for d in range(T)] == [V, L] * (T // 2) and (T == 8 or j + T <= 64 + 7): bad[j] = True
                         k = 0
                         while k < 64 and not bad[k]: k += 1
                         assert k <= 63
