@@ -289,13 +289,13 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // take): tools/topo_trace_probe.py turns the differences into what each kind of step costs.  Nothing in the product build.
 #ifdef CORTO_TOPO_STAMPS
 #define TOPO_ASM_STAMP \
-							"  s_memtime s[94:95]\n" \
-							"  s_mul_i32 s96, %[cler], 4\n" \
-							"  v_mov_b32 v63, s96\n" \
+							"  s_memtime s[88:89]\n" \
+							"  s_mul_i32 s90, %[cler], 4\n" \
+							"  v_mov_b32 v63, s90\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_mov_b32 v62, s94\n" \
+							"  v_mov_b32 v62, s88\n" \
 							"  ds_write_b32 v63, v62 offset:32768\n"
-#define TOPO_ASM_STAMP_CLOBBERS , "s94", "s95", "s96"
+#define TOPO_ASM_STAMP_CLOBBERS , "s88", "s89", "s90"
 #else
 #define TOPO_ASM_STAMP
 #define TOPO_ASM_STAMP_CLOBBERS
@@ -315,7 +315,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_eq_u32 %[c], 2\n" \
 							"  s_cbranch_scc1 Lright_%=\n" \
 							"  s_branch Lcold_%=\n"
-#define TOPO_FAST_PATH(FACE, RUNFACE, MIXFACE, FSHIFT) \
+#define TOPO_FAST_PATH(FACE, RUNFACE, LEADFACE, MIXFACE, FSHIFT) \
 						asm volatile( \
 							"Ltop_%=:\n" \
 							TOPO_ASM_STAMP \
@@ -720,6 +720,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lexit_%=\n" \
 							   /* ---------------- four symbols of VERTEX / LEFT ahead: the mix step (TOPO_MIX_STEP) takes them, unless they are the head of a regular \
 							      run one symbol on (V VLV.., L VLV..: that symbol here, then the run step) or the window register holds fewer than four */ \
+							"Lvlead_%=:\n"                         /* V VLVLVL V, all eight certain (an L in the top nibble): the lone VERTEX in front of a regular run rides */ \
+							"  s_cmp_eq_u32 %[sw], 0x01010100\n"   /* along with the run step (TOPO_ASM_RUN's lead lane); else it goes one at a time as before */ \
+							"  s_cbranch_scc1 Lrunv_%=\n" \
+							"  s_branch Lvgo_%=\n" \
 							"Lvrun_%=:\n"                          /* VERTEX LEFT VERTEX LEFT: the run step if EVERY symbol the window register shows (4 .. 8) goes */ \
 							"  s_cmp_eq_u32 %[sw], 0x10101010\n"   /* on like that - a shorter run is the mix step's, which takes what follows it too.  All eight: */ \
 							"  s_cbranch_scc1 Lrun_%=\n"           /* the usual case; else the 8 - (cler & 7) nibbles that are certainly symbols (after a step the */ \
@@ -731,7 +735,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lmix_%=\n" \
 							"Lvmix_%=:\n" \
 							"  s_cmp_eq_u32 %[t0], 0x0100\n" \
-							"  s_cbranch_scc1 Lvgo_%=\n" \
+							"  s_cbranch_scc1 Lvlead_%=\n" \
 							"  s_and_b32 %[t1], %[cler], 7\n" \
 							"  s_cmp_gt_u32 %[t1], 4\n" \
 							"  s_cbranch_scc1 Lvgo_%=\n" \
@@ -744,7 +748,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_gt_u32 %[t1], 4\n" \
 							"  s_cbranch_scc1 Llgo_%=\n" \
 							TOPO_ASM_MIX(MIXFACE, FSHIFT) \
-							TOPO_ASM_RUN(RUNFACE, FSHIFT) \
+							TOPO_ASM_RUN(RUNFACE, LEADFACE, FSHIFT) \
 							TOPO_ASM_ENDS \
 							   /* ---------------- after a step: the group may be done, the window may want sliding (both the C++'s business), else the next symbol */ \
 							"Lstepped_%=:\n" \
@@ -763,7 +767,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s98", "s99" TOPO_ASM_STAMP_CLOBBERS);
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s92", "s93", "s94", "s96", "s97", "s98", "s99" TOPO_ASM_STAMP_CLOBBERS);
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -880,6 +884,17 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mad_u32_u24 v59, v60, 24, %[c]\n" \
 	"  global_store_dwordx4 v59, v[32:35], %[faceb]\n" \
 	"  global_store_dwordx2 v59, v[36:37], %[faceb] offset:16\n"
+#define TOPO_LEAD_FACE32 \
+	"  v_mov_b32 v59, -12\n" \
+	"  v_add_u32 v59, %[c], v59\n" \
+	"  global_store_dwordx3 v59, v[32:34], %[faceb]\n"
+#define TOPO_LEAD_FACE16 \
+	"  v_and_b32 v36, 0xffff, v32\n" \
+	"  v_lshl_or_b32 v36, v33, 16, v36\n" \
+	"  v_mov_b32 v59, -6\n" \
+	"  v_add_u32 v59, %[c], v59\n" \
+	"  global_store_dword v59, v36, %[faceb]\n" \
+	"  global_store_short v59, v34, %[faceb] offset:4\n"
 #define TOPO_RUN_FACE16 \
 	"  v_and_b32 v36, 0xffff, v32\n" \
 	"  v_lshl_or_b32 v36, v33, 16, v36\n" \
@@ -902,10 +917,31 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_max_i32 %[t2], %[t2], 0\n" \
 	"  s_cmp_eq_u32 %[slideat], -1\n" \
 	"  s_cselect_b32 %[t2], 126, %[t2]\n"
-#define TOPO_ASM_RUN(FACE, FSHIFT) \
+#define TOPO_ASM_RUN(FACE, LEADFACE, FSHIFT) \
+	"Lrunv_%=:\n"                                   /* a lone VERTEX, then the run: the state moves on as the VERTEX leaves it (what it was: s92 - s94), and */ \
+	"  s_cmp_eq_u32 %[budget], 0\n"                  /* lane 63 - never a pair's: kmax <= 63 - writes what the VERTEX writes, in the pairs' own stores */ \
+	"  s_cbranch_scc1 Lvgo_%=\n" \
+	"  s_cmp_gt_u32 %[ep], %[mask]\n" \
+	"  s_cbranch_scc1 Lvgo_%=\n" \
+	"  s_mov_b32 s92, %[v1]\n" \
+	"  s_mov_b32 s93, %[v2]\n" \
+	"  s_mov_b32 s94, %[en]\n" \
+	"  s_mov_b32 %[v2], %[v1]\n" \
+	"  s_mov_b32 %[v1], %[vc]\n" \
+	"  s_and_b32 %[en], %[nq], %[mask]\n" \
+	"  s_add_u32 %[vc], %[vc], 1\n" \
+	"  s_add_u32 %[nq], %[nq], 1\n" \
+	"  s_add_u32 %[start], %[start], 3\n" \
+	"  s_add_u32 %[cler], %[cler], 1\n" \
+	"  s_sub_u32 %[budget], %[budget], 1\n" \
+	"  s_mov_b32 s96, 0\n"                           /* s[96:97]: the lead lane's exec bit, or nothing */ \
+	"  s_brev_b32 s97, 1\n" \
+	"  s_branch Lrunb_%=\n" \
 	"Lrun_%=:\n" \
 	"  s_cmp_gt_u32 %[ep], %[mask]\n"                 /* e.prev in the pool: one symbol at a time */ \
 	"  s_cbranch_scc1 Lvgo_%=\n" \
+	"  s_mov_b64 s[96:97], 0\n" \
+	"Lrunb_%=:\n" \
 	"  s_sub_u32 %[t3], %[end], %[start]\n"           /* kmax = min(63, vertex ids / ring slots left, pairs the group and the window hold) */ \
 	"  s_mul_hi_u32 %[t3], %[t3], 0xaaaaaaab\n" \
 	"  s_lshr_b32 %[t3], %[t3], 2\n" \
@@ -960,6 +996,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_sub_u32 %[t1], %[t0], 1\n" \
 	"  s_lshl_b32 %[c], %[start], " FSHIFT "\n"      /* byte offset of the step's first index */ \
 	"  s_bfm_b64 exec, %[t0], 0\n"                   /* lanes 0 .. k-1 */ \
+	"  s_or_b64 exec, exec, s[96:97]\n"              /* ... and the lead lane */ \
 	"  v_mov_b32 v38, %[v0]\n" \
 	"  v_mov_b32 v39, %[v1]\n" \
 	"  v_add_u32 v34, %[vc], v60\n"                  /* the new vertex vc+j */ \
@@ -971,11 +1008,23 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_cndmask_b32 v58, v39, v38, vcc\n" \
 	"  v_cmp_lt_u32 vcc, 1, v60\n" \
 	"  v_cndmask_b32 v58, v58, v52, vcc\n"           /* c_j */ \
+	"  s_sub_u32 %[t2], %[vc], 1\n"                  /* the lead lane: the edge as the lone VERTEX found it, and the vertex it made */ \
+	"  v_writelane_b32 v32, s92, 63\n" \
+	"  v_writelane_b32 v33, %[v0], 63\n" \
+	"  v_writelane_b32 v58, s93, 63\n" \
+	"  v_writelane_b32 v34, %[t2], 63\n" \
 	"  v_mov_b32 v56, v32\n" \
 	"  v_mov_b32 v57, v33\n" \
 	"  v_mul_lo_u32 v59, v34, 12\n" \
 	"  global_store_dwordx3 v59, v[56:58], %[predb]\n" \
+	"  s_andn2_b64 exec, exec, s[96:97]\n" \
 	FACE \
+	"  s_mov_b64 exec, s[96:97]\n"                   /* the lone VERTEX' one face, in front of the pairs' */ \
+	"  s_cbranch_execz Lrunf_%=\n" \
+	LEADFACE \
+	"Lrunf_%=:\n" \
+	"  s_bfm_b64 exec, %[t0], 0\n" \
+	"  s_or_b64 exec, exec, s[96:97]\n" \
 	"  v_add_u32 v40, %[nq], v60\n" \
 	"  v_add_u32 v53, 1, v40\n" \
 	"  v_add_u32 v55, -1, v40\n" \
@@ -993,7 +1042,16 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mov_b32 v49, v32\n" \
 	"  v_mov_b32 v50, v33\n" \
 	"  v_lshlrev_b32 v41, 4, v41\n" \
+	"  s_sub_u32 %[t2], %[nq], 1\n"                  /* the lead lane's record: the slot before the pairs', next = e.next as it was, prev = the first pair's slot */ \
+	"  s_and_b32 %[t2], %[t2], %[mask]\n" \
+	"  s_lshl_b32 %[t2], %[t2], 4\n" \
+	"  v_writelane_b32 v41, %[t2], 63\n" \
+	"  s_and_b32 %[t3], %[nq], %[mask]\n" \
+	"  s_lshl_b32 %[c], s94, 16\n" \
+	"  s_or_b32 %[t3], %[t3], %[c]\n" \
+	"  v_writelane_b32 v51, %[t3], 63\n" \
 	"  ds_write_b128 v41, v[48:51]\n" \
+	"  s_andn2_b64 exec, exec, s[96:97]\n" \
 	"  v_mov_b32 v61, 0x8000\n" \
 	"  ds_write_b16 v45, v61 offset:10\n"            /* slot ep+j: deleted */ \
 	"  v_readlane_b32 %[sw], v54, %[t0]\n"           /* the window registers: lane k's (the words it read are the ones the loop goes on with) */ \
@@ -1008,6 +1066,13 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mov_b32 v40, %[t3]\n" \
 	"  v_mov_b32 v41, %[c]\n" \
 	"  ds_write_b16 v41, v40 offset:12\n" \
+	"  s_cmp_eq_u32 s97, 0\n"                        /* the lone VERTEX' own link: what was e.next now has its queued edge for prev */ \
+	"  s_cbranch_scc1 Lrunl_%=\n" \
+	"  s_lshl_b32 %[c], s94, 4\n" \
+	"  v_mov_b32 v42, %[en]\n" \
+	"  v_mov_b32 v43, %[c]\n" \
+	"  ds_write_b16 v43, v42 offset:12\n" \
+	"Lrunl_%=:\n" \
 	"  s_and_b32 %[ep], %[t2], 0xffff\n" \
 	"  s_add_u32 %[t3], %[nq], %[t0]\n" \
 	"  s_sub_u32 %[c], %[t3], 2\n" \
@@ -1026,8 +1091,18 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_lshl_b32 %[c], %[t0], 1\n" \
 	"  s_add_u32 %[cler], %[cler], %[c]\n" \
 	"  s_branch Lstepped_%=\n" \
-	"Lrun0_%=:\n"                                    /* not even one pair: the VERTEX goes the one-at-a-time way */ \
+	"Lrun0_%=:\n"                                    /* not even one pair: the VERTEX goes the one-at-a-time way (a lead VERTEX: the state as it was) */ \
 	"  s_mov_b64 exec, 1\n" \
+	"  s_cmp_eq_u32 s97, 0\n" \
+	"  s_cbranch_scc1 Lvgo_%=\n" \
+	"  s_mov_b32 %[v1], s92\n" \
+	"  s_mov_b32 %[v2], s93\n" \
+	"  s_mov_b32 %[en], s94\n" \
+	"  s_sub_u32 %[vc], %[vc], 1\n" \
+	"  s_sub_u32 %[nq], %[nq], 1\n" \
+	"  s_sub_u32 %[start], %[start], 3\n" \
+	"  s_sub_u32 %[cler], %[cler], 1\n" \
+	"  s_add_u32 %[budget], %[budget], 1\n" \
 	"  s_branch Lvgo_%=\n"
 
 // The mix step.  Meshes whose quads are not split the same way everywhere (anything that is not a regular grid) do not give (VERTEX LEFT)
@@ -1623,7 +1698,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 						uint32_t t0_, t1_, t2_, t3_, c_;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
 						{ TOPO_T0();
-						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16, TOPO_RUN_FACE16, TOPO_MIX_FACE16, "1"); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32, TOPO_RUN_FACE32, TOPO_MIX_FACE32, "2"); }
+						if constexpr(U16) { TOPO_FAST_PATH(TOPO_ASM_FACE16, TOPO_RUN_FACE16, TOPO_LEAD_FACE16, TOPO_MIX_FACE16, "1"); } else { TOPO_FAST_PATH(TOPO_ASM_FACE32, TOPO_RUN_FACE32, TOPO_LEAD_FACE32, TOPO_MIX_FACE32, "2"); }
 						TOPO_ACC(0); }
 						if(start >= end) break;
 						if(c_ == 0x200u) break;                                   // the block ended the chain (BOUNDARY / DELAY) and found no gate to go on with

@@ -26,6 +26,7 @@ class Model:
         self.any_align = os.environ.get('MIX_ANY_ALIGN', '0') == '1'   # experiment: a trigger that peeks into the next window word too (more one-symbol steps: not taken)
         self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
         self.group_end = group_end
+        self.last_step = None
         self.events = []                  # (symbol index, kind, symbols taken / entries skipped): what tools/topo_trace_probe.py labels the kernel's dispatch trace with
         self.stats = dict(runs=0, run_pairs=0, serial=0, cut_chain=0, cut_en=0, mixes=0, mix_symbols=0, mix_hist={}, ends=0, end_symbols=0, end_hist={},
                           pops=0, dead=0, dpops=0, seeds=0, ser={k: 0 for k in 'VLREBDS'}, lone_v_before_run=0, run0=0, mix0=0)
@@ -75,7 +76,22 @@ class Model:
                 v0, v1, v2, _, ep, en = cur
                 while True:
                     # ---- the run step: k pairs of (VERTEX, LEFT) at once
-                    vis = 8 - (cler & 7) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' else 4    # the run step only when ALL the symbols the window register shows alternate (the kernel since round 4; 0: the first four)
+                    # the symbols the kernel's window register certainly holds: what is left of the aligned word, or of the eight a step left behind
+                    certain = max(8 - (cler & 7), 8 - (cler - self.last_step) if self.last_step is not None else 0)
+                    lead = False
+                    if self.use_runs and os.environ.get('RUN_LEAD', '1') == '1' and certain >= 8 and [cl[cler + d] for d in range(8)] == [V, V, L, V, L, V, L, V] \
+                            and ep <= MASK and min(self.nvert - vc, self.RING - (nq - qpos)) >= 1:
+                        # the lone VERTEX in front of a regular run rides along with the run step (TOPO_ASM_RUN's lead lane): the VERTEX as the
+                        # one-at-a-time code does it, then the run from the state it leaves; undone if not even one pair follows
+                        saved = (v0, v1, v2, ep, en, vc, nq, start, cler, list(rec[en]), list(rec[nq & MASK]), len(self.faces), self.pred[vc].copy())
+                        self.pred[vc] = (v1, v0, v2); opp = vc; vc += 1
+                        s_ = nq & MASK; nq += 1
+                        self.faces += [v1, v0, opp]; start += 3
+                        rec[en][4] = s_
+                        rec[s_] = [opp, v1, v0, 0, LAZY, en]
+                        v2 = v1; v1 = opp; en = s_; cler += 1
+                        lead = True
+                    vis = 8 - (cler & 7) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' and not lead else 4    # the run step only when ALL the symbols the window register shows alternate (the kernel since round 4; 0: the first four)
                     if self.use_runs and cl[cler] == V and cl[cler + 1] == L and cl[cler + 2] == V and cl[cler + 3] == L and all(cl[cler + d] == (V, L)[d & 1] for d in range(4, vis)):
                         kmax = min(64, self.nvert - vc, self.RING - (nq - qpos), (end - start) // 6)
                         ok = []
@@ -109,10 +125,14 @@ class Model:
                             epn = w[k - 1]; enn = (nq + k - 1) & MASK
                             v0, v1, v2, ep, en = v0n, v1n, v2n, epn, enn
                             vc += k; nq += k; start += 6 * k; cler += 2 * k
-                            self.stats['runs'] += 1; self.stats['run_pairs'] += k; self.events.append((cler - 2*k, 'run', 2*k))
+                            self.stats['runs'] += 1; self.stats['run_pairs'] += k; self.events.append((cler - 2*k - int(lead), 'run', 2*k + int(lead)))
+                            self.stats['leads'] = self.stats.get('leads', 0) + int(lead); self.last_step = cler
                             if start >= end: break
                             continue
                         self.stats['run0'] += 1
+                    if lead:                                 # (no pair joined: as if nothing had happened)
+                        v0, v1, v2, ep, en, vc, nq, start, cler, r_en, r_s, nf, pv = saved
+                        rec[en][:] = r_en; rec[nq & MASK][:] = r_s; del self.faces[nf:]; self.pred[vc] = pv
                     # ---- the mix step: k symbols of any VERTEX / LEFT sequence at once, one symbol per lane (TOPO_MIX_STEP)
                     if self.use_mix and ((cler & 7) <= 4 or self.any_align) and all(cl[cler + d] in (V, L) for d in range(4)) and ep <= MASK \
                             and [cl[cler + d] for d in range(4)] not in (([L, V, L, V], [V, V, L, V]) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' else ([V, L, V, L], [L, V, L, V], [V, V, L, V])):
@@ -172,7 +192,7 @@ class Model:
                             enn = (nq + TV - 1) & MASK if TV else en
                             v0, v1, v2, ep, en = a, b, c, epn, enn
                             vc += TV; nq += TV; start += 3 * k; cler += k
-                            self.stats['mixes'] += 1; self.stats['mix_symbols'] += k; self.events.append((cler - k, 'mix', k))
+                            self.stats['mixes'] += 1; self.stats['mix_symbols'] += k; self.events.append((cler - k, 'mix', k)); self.last_step = cler
                             self.stats['mix_hist'][k] = self.stats['mix_hist'].get(k, 0) + 1
                             if k <= 2: self.stats.setdefault('short', {}); pat = ''.join('VLREBDS?'[min(c_, 7)] for c_ in cl[cler - k:cler - k + 8]); self.stats['short'][pat] = self.stats['short'].get(pat, 0) + 1
                             if start >= end: break
