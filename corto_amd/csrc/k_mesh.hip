@@ -936,6 +936,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_sub_u32 %[budget], %[budget], 1\n" \
 	"  s_mov_b32 s96, 0\n"                           /* s[96:97]: the lead lane's exec bit, or nothing */ \
 	"  s_brev_b32 s97, 1\n" \
+	"  s_lshl_b32 %[t0], s94, 4\n"                   /* the lone VERTEX' own link NOW, not with the step's other writes: what was e.next gets the queued edge for */ \
+	"  v_mov_b32 v42, %[en]\n"                       /* prev, and a run that closes the previous layer's slots right up to that edge reads this very link (small */ \
+	"  v_mov_b32 v43, %[t0]\n"                       /* closed meshes: tools/stress_topology.py found it).  Not undone if no pair joins: the one-at-a-time */ \
+	"  ds_write_b16 v43, v42 offset:12\n"            /* VERTEX that follows writes the same slot there */ \
 	"  s_branch Lrunb_%=\n" \
 	"Lrun_%=:\n" \
 	"  s_cmp_gt_u32 %[ep], %[mask]\n"                 /* e.prev in the pool: one symbol at a time */ \
@@ -1066,13 +1070,6 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mov_b32 v40, %[t3]\n" \
 	"  v_mov_b32 v41, %[c]\n" \
 	"  ds_write_b16 v41, v40 offset:12\n" \
-	"  s_cmp_eq_u32 s97, 0\n"                        /* the lone VERTEX' own link: what was e.next now has its queued edge for prev */ \
-	"  s_cbranch_scc1 Lrunl_%=\n" \
-	"  s_lshl_b32 %[c], s94, 4\n" \
-	"  v_mov_b32 v42, %[en]\n" \
-	"  v_mov_b32 v43, %[c]\n" \
-	"  ds_write_b16 v43, v42 offset:12\n" \
-	"Lrunl_%=:\n" \
 	"  s_and_b32 %[ep], %[t2], 0xffff\n" \
 	"  s_add_u32 %[t3], %[nq], %[t0]\n" \
 	"  s_sub_u32 %[c], %[t3], 2\n" \

@@ -310,6 +310,33 @@ def test_chain_end_runs_stay_in_lds(ctx):
     c.close()
 
 
+def test_small_closed_meshes_whose_runs_reach_the_current_edge(ctx):
+    """A regular run that closes the previous layer's slots right up to the current edge's own `next` reads the link a VERTEX in front of it
+    has just written: closed spheres of a few dozen vertices do that at every ring (a grid of thousands never does).  Round 4's lead lane
+    (the lone VERTEX riding along with the run step) wrote that link with the step's other writes, after the lanes had read it - the test
+    suite was green, tools/stress_topology.py was not; these are its two blobs and the family around them.  Also small tori, closed
+    meshes with flipped diagonals and every second one cut into groups."""
+    from corto_amd import synth
+    meshes = [synth.closed_sphere(nu, nv, seed=nu * 31 + nv) for nu in range(6, 41, 2) for nv in (4, 5, 7, 10, 13, 19)]
+    meshes += [synth.closed_sphere(15, 10, seed=1), synth.closed_sphere(9, 7, seed=2)]                     # (270 and 108 faces: the stress run's)
+    meshes += [synth.torus(nu, nv, seed=nu + nv) for nu in (6, 9, 14, 23) for nv in (4, 6, 11)]
+    meshes += [synth.bumpy_sphere_flipped(nu, nv, seed=nu, flip=f) for nu in (8, 13, 21) for nv in (4, 9) for f in (0.05, 0.5)]
+    for k, m in enumerate(meshes):
+        if k % 2 and m.nface > 24:
+            m.groups = [m.nface // 3, m.nface // 2 + 1, m.nface]
+    blobs = [ca.encode(m, position_bits=10 + k % 7, uv_bits=12, normal_bits=10, normal_prediction=[ca.BORDER, ca.ESTIMATED, ca.DIFF][k % 3]) for k, m in enumerate(meshes)]
+    c = ca.Context(0)
+    run_batch(c, blobs).close()
+    for u16 in (False, True):
+        b = run_batch(c, blobs, index16=u16, color_components=4)
+        for i, blob in enumerate(blobs):
+            r = oc.decode(blob, index16=u16, color_components=4)
+            assert_same(b.host_outputs(i), r, KEYS, "small closed mesh %d (%d faces) u16=%s" % (i, r["nface"], u16))
+        assert b.stats().topology_fallbacks == 0
+        b.close()
+    c.close()
+
+
 def test_single_stream_context_decodes_the_same(ctx):
     """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
     the hardware queues) - same bytes as the two-stream schedule"""
