@@ -337,6 +337,18 @@ def test_small_closed_meshes_whose_runs_reach_the_current_edge(ctx):
     c.close()
 
 
+def test_random_mesh_stress_run(ctx):
+    """tools/stress_topology.py as a test: eight rounds of 24 random meshes of every synthetic family (sizes, flip rates, hole fractions, random
+    group cuts, shuffles, merges; seed 5: the run that caught round 4's lead-lane bug with everything else green), byte for byte against the
+    oracle, u16 and u32 indices, twice (the second pass with the slots the first one taught the context)"""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([_sys.executable, os.path.join(root, "tools", "stress_topology.py"), "8", "5"], capture_output=True, text=True, timeout=600)
+    tail = [l for l in out.stdout.splitlines() if l.startswith("decodes")]
+    assert out.returncode == 0 and tail, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " mismatching arrays 0 " in tail[-1], "\n".join(l for l in out.stdout.splitlines() if "MISMATCH" in l)[:4000]
+
+
 def test_single_stream_context_decodes_the_same(ctx):
     """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
     the hardware queues) - same bytes as the two-stream schedule"""
