@@ -289,26 +289,26 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // take): tools/topo_trace_probe.py turns the differences into what each kind of step costs.  Nothing in the product build.
 #ifdef CORTO_TOPO_STAMPS
 #define TOPO_ASM_STAMP \
-							"  s_memtime s[88:89]\n" \
-							"  s_mul_i32 s90, %[cler], 4\n" \
-							"  v_mov_b32 v63, s90\n" \
+							"  s_memtime s[86:87]\n" \
+							"  s_mul_i32 s88, %[cler], 4\n" \
+							"  v_mov_b32 v63, s88\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_mov_b32 v62, s88\n" \
+							"  v_mov_b32 v62, s86\n" \
 							"  ds_write_b32 v63, v62 offset:32768\n"
-#define TOPO_ASM_STAMP_CLOBBERS , "s88", "s89", "s90"
+#define TOPO_ASM_STAMP_CLOBBERS , "s86", "s87", "s88"
 #else
 #define TOPO_ASM_STAMP
 #define TOPO_ASM_STAMP_CLOBBERS
 #endif
 #define TOPO_ASM_TAIL \
-							"  s_lshr_b32 %[sw], %[sw], 4\n" \
+							"  s_lshr_b64 s[90:91], s[90:91], 4\n" \
 							"  s_add_u32 %[cler], %[cler], 1\n" \
 							"  s_and_b32 %[t0], %[cler], 7\n"   /* SCC = result != 0 */ \
 							"  s_cbranch_scc0 Lrefill_%=\n" \
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc0 Lexit_%=\n" \
 							TOPO_ASM_STAMP \
-							"  s_and_b32 %[c], %[sw], 15\n" \
+							"  s_and_b32 %[c], s90, 15\n" \
 							"  s_cbranch_scc0 Lvertex_%=\n" \
 							"  s_cmp_eq_u32 %[c], 1\n" \
 							"  s_cbranch_scc1 Lleft_%=\n" \
@@ -317,9 +317,11 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lcold_%=\n"
 #define TOPO_FAST_PATH(FACE, RUNFACE, LEADFACE, MIXFACE, FSHIFT) \
 						asm volatile( \
+							"  s_mov_b32 s90, %[sw]\n"             /* the window registers live in s[90:91] inside the block: one 64-bit shift per symbol keeps EIGHT symbols */ \
+							"  s_mov_b32 s91, %[swn]\n"            /* in s90 whatever the alignment (s91: what is left of the next word), so every trigger sees eight */ \
 							"Ltop_%=:\n" \
 							TOPO_ASM_STAMP \
-							"  s_and_b32 %[c], %[sw], 15\n"   /* (SCC = result != 0) */ \
+							"  s_and_b32 %[c], s90, 15\n"   /* (SCC = result != 0) */ \
 							"  s_cbranch_scc0 Lvertex_%=\n" \
 							"  s_cmp_eq_u32 %[c], 1\n" \
 							"  s_cbranch_scc1 Lleft_%=\n" \
@@ -328,7 +330,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lcold_%=\n" \
    /* ---------------- VERTEX (decoder.cpp:294-309) */ \
 							"Lvertex_%=:\n" \
-							"  s_and_b32 %[t0], %[sw], 0xffff\n"   /* VERTEX LEFT VERTEX LEFT ahead: leave for the run step (TOPO_RUN_STEP) */ \
+							"  s_and_b32 %[t0], s90, 0xffff\n"   /* VERTEX LEFT VERTEX LEFT ahead: leave for the run step (TOPO_RUN_STEP) */ \
 							"  s_cmp_eq_u32 %[t0], 0x1010\n" \
 							"  s_cbranch_scc1 Lvrun_%=\n" \
 							"  s_and_b32 %[t1], %[t0], 0xeeee\n"   /* four symbols of VERTEX / LEFT ahead: maybe the mix step (checked out of line) */ \
@@ -371,7 +373,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lleft_%=:\n" \
 							"  s_cmp_gt_u32 %[ep], %[mask]\n" \
 							"  s_cbranch_scc1 Lleftp_%=\n" \
-							"  s_and_b32 %[t0], %[sw], 0xeeee\n" \
+							"  s_and_b32 %[t0], s90, 0xeeee\n" \
 							"  s_cbranch_scc0 Llmix_%=\n" \
 							"Llgo_%=:\n" \
 							"  s_lshl_b32 %[t0], %[ep], 4\n" \
@@ -478,7 +480,6 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							TOPO_ASM_TAIL \
    /* ---------------- every eighth symbol: the next word of the window, then the loop test and the dispatch at the top */ \
 							"Lrefill_%=:\n" \
-							"  s_mov_b32 %[sw], %[swn]\n" \
 							"  s_lshr_b32 %[t0], %[cler], 3\n" \
 							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
 							"  s_lshl_b32 %[t0], %[t0], 2\n" \
@@ -486,7 +487,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  v_mov_b32 v55, %[t0]\n" \
 							"  ds_read_b32 v55, v55\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_readfirstlane_b32 %[swn], v55\n" \
+							"  v_readfirstlane_b32 s91, v55\n" \
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc1 Ltop_%=\n" \
 							"  s_branch Lexit_%=\n" \
@@ -560,11 +561,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_lshl_b32 %[t0], %[en], 4\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
 							"  ds_write_b16 v52, v53 offset:12\n"   /* front[e.next].prev = slot */ \
-							"  s_lshr_b32 %[sw], %[sw], 4\n"        /* the symbol is consumed */ \
+							"  s_lshr_b64 s[90:91], s[90:91], 4\n"   /* the symbol is consumed */ \
 							"  s_add_u32 %[cler], %[cler], 1\n" \
 							"  s_and_b32 %[t0], %[cler], 7\n" \
 							"  s_cbranch_scc1 Lpop_%=\n" \
-							"  s_mov_b32 %[sw], %[swn]\n" \
 							"  s_lshr_b32 %[t0], %[cler], 3\n" \
 							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
 							"  s_lshl_b32 %[t0], %[t0], 2\n" \
@@ -572,14 +572,14 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  v_mov_b32 v55, %[t0]\n" \
 							"  ds_read_b32 v55, v55\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
-							"  v_readfirstlane_b32 %[swn], v55\n" \
+							"  v_readfirstlane_b32 s91, v55\n" \
 							"Lpop_%=:\n" \
 							"  s_cmp_ge_u32 %[cler], %[slideat]\n" \
 							"  s_cbranch_scc1 Lended_%=\n" \
 							"  s_sub_u32 %[t2], %[nq], %[qpos]\n"   /* queued entries */ \
 							"  s_cmp_eq_u32 %[t2], 0\n" \
 							"  s_cbranch_scc1 Ldpop_%=\n" \
-							"  s_and_b32 %[t0], %[sw], 0xee\n"       /* the gate about to be popped is ended at once, and the one after it too (BOUNDARY 4 / DELAY 5 twice): the */ \
+							"  s_and_b32 %[t0], s90, 0xee\n"       /* the gate about to be popped is ended at once, and the one after it too (BOUNDARY 4 / DELAY 5 twice): the */ \
 							"  s_cmp_eq_u32 %[t0], 0x44\n"           /* chain-end step (TOPO_ASM_ENDS) - it costs what two ends cost one at a time, so a single pair goes the old way */ \
 							"  s_cbranch_scc1 Lends_%=\n" \
 							"Lpop1_%=:\n" \
@@ -720,38 +720,30 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lexit_%=\n" \
 							   /* ---------------- four symbols of VERTEX / LEFT ahead: the mix step (TOPO_MIX_STEP) takes them, unless they are the head of a regular \
 							      run one symbol on (V VLV.., L VLV..: that symbol here, then the run step) or the window register holds fewer than four */ \
-							"Lvlead_%=:\n"                         /* V VLVLVL V, all eight certain (an L in the top nibble): the lone VERTEX in front of a regular run rides */ \
-							"  s_cmp_eq_u32 %[sw], 0x01010100\n"   /* along with the run step (TOPO_ASM_RUN's lead lane); else it goes one at a time as before */ \
+							"Lvlead_%=:\n"                         /* V VLVLVL V: the lone VERTEX in front of a regular run rides along with the run step (TOPO_ASM_RUN's */ \
+							"  s_cmp_eq_u32 s90, 0x01010100\n"    /* lead lane); else it goes one at a time */ \
 							"  s_cbranch_scc1 Lrunv_%=\n" \
 							"  s_branch Lvgo_%=\n" \
-							"Lvrun_%=:\n"                          /* VERTEX LEFT VERTEX LEFT: the run step if EVERY symbol the window register shows (4 .. 8) goes */ \
-							"  s_cmp_eq_u32 %[sw], 0x10101010\n"   /* on like that - a shorter run is the mix step's, which takes what follows it too.  All eight: */ \
-							"  s_cbranch_scc1 Lrun_%=\n"           /* the usual case; else the 8 - (cler & 7) nibbles that are certainly symbols (after a step the */ \
-							"  s_and_b32 %[t1], %[cler], 7\n"      /* register holds lane k's eight whatever the alignment, after a one-at-a-time symbol zeros) */ \
-							"  s_lshl_b32 %[t1], %[t1], 2\n" \
-							"  s_xor_b32 %[t0], %[sw], 0x10101010\n" \
-							"  s_lshl_b32 %[t0], %[t0], %[t1]\n"   /* (SCC = result != 0: one of them breaks the pattern) */ \
-							"  s_cbranch_scc0 Lrun_%=\n" \
+							"Lvrun_%=:\n"                          /* VERTEX LEFT VERTEX LEFT: the run step if all eight symbols of the window register go on like that - */ \
+							"  s_cmp_eq_u32 s90, 0x10101010\n"    /* a shorter run is the mix step's, which takes what follows it too */ \
+							"  s_cbranch_scc1 Lrun_%=\n" \
 							"  s_branch Lmix_%=\n" \
 							"Lvmix_%=:\n" \
 							"  s_cmp_eq_u32 %[t0], 0x0100\n" \
 							"  s_cbranch_scc1 Lvlead_%=\n" \
-							"  s_and_b32 %[t1], %[cler], 7\n" \
-							"  s_cmp_gt_u32 %[t1], 4\n" \
-							"  s_cbranch_scc1 Lvgo_%=\n" \
 							"  s_branch Lmix_%=\n" \
 							"Llmix_%=:\n" \
-							"  s_and_b32 %[t0], %[sw], 0xffff\n" \
+							"  s_and_b32 %[t0], s90, 0xffff\n" \
 							"  s_cmp_eq_u32 %[t0], 0x0101\n" \
-							"  s_cbranch_scc1 Llgo_%=\n" \
-							"  s_and_b32 %[t1], %[cler], 7\n" \
-							"  s_cmp_gt_u32 %[t1], 4\n" \
 							"  s_cbranch_scc1 Llgo_%=\n" \
 							TOPO_ASM_MIX(MIXFACE, FSHIFT) \
 							TOPO_ASM_RUN(RUNFACE, LEADFACE, FSHIFT) \
 							TOPO_ASM_ENDS \
 							   /* ---------------- after a step: the group may be done, the window may want sliding (both the C++'s business), else the next symbol */ \
 							"Lstepped_%=:\n" \
+							"  s_and_b32 %[c], %[cler], 7\n"        /* s91 came back as lane k's whole next word: shifted like s90 */ \
+							"  s_lshl_b32 %[c], %[c], 2\n" \
+							"  s_lshr_b32 s91, s91, %[c]\n" \
 							"  s_mov_b32 %[c], 0\n" \
 							"  s_cmp_lt_u32 %[start], %[end]\n" \
 							"  s_cbranch_scc0 Lexit_%=\n" \
@@ -759,6 +751,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Lexit_%=\n" \
 							"  s_branch Ltop_%=\n" \
 							"Lexit_%=:\n" \
+							"  s_mov_b32 %[sw], s90\n" \
+							"  s_mov_b32 %[swn], s91\n" \
 							: [sw] "+s"(sw), [swn] "+s"(swn), [cler] "+s"(cler), [vc] "+s"(vc), [nq] "+s"(nq), [start] "+s"(start), \
 							  [v0] "+s"(v0), [v1] "+s"(v1), [v2] "+s"(v2), [ep] "+s"(ep), [en] "+s"(en), \
 							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1), \
@@ -767,7 +761,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s92", "s93", "s94", "s96", "s97", "s98", "s99" TOPO_ASM_STAMP_CLOBBERS);
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s92", "s93", "s94", "s96", "s97", "s98", "s99", "s90", "s91" TOPO_ASM_STAMP_CLOBBERS);
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -1058,8 +1052,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_andn2_b64 exec, exec, s[96:97]\n" \
 	"  v_mov_b32 v61, 0x8000\n" \
 	"  ds_write_b16 v45, v61 offset:10\n"            /* slot ep+j: deleted */ \
-	"  v_readlane_b32 %[sw], v54, %[t0]\n"           /* the window registers: lane k's (the words it read are the ones the loop goes on with) */ \
-	"  v_readlane_b32 %[swn], v43, %[t0]\n" \
+	"  v_readlane_b32 s90, v54, %[t0]\n"            /* the window registers: lane k's eight symbols, and what is left of the word behind them (TOPO_ASM_PAIR below) */ \
+	"  v_readlane_b32 s91, v43, %[t0]\n" \
 	"  v_readlane_b32 %[t2], v47, %[t1]\n"           /* the state after the run: lane k-1's */ \
 	"  v_readlane_b32 %[v0], v46, %[t1]\n" \
 	"  v_readlane_b32 %[v2], v33, %[t1]\n" \
@@ -1244,8 +1238,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_cndmask_b32 v37, v37, v58, vcc\n"           /* c_j */ \
 	"  v_readlane_b32 %[t1], v38, %[t0]\n"           /* VERTEXes and LEFTs of the step: lane k's counts */ \
 	"  v_readlane_b32 %[t2], v39, %[t0]\n" \
-	"  v_readlane_b32 %[sw], v54, %[t0]\n"           /* the state after the step: lane k's */ \
-	"  v_readlane_b32 %[swn], v43, %[t0]\n" \
+	"  v_readlane_b32 s90, v54, %[t0]\n"            /* the window registers: lane k's eight symbols, and what is left of the word behind them (TOPO_ASM_PAIR below) */ \
+	"  v_readlane_b32 s91, v43, %[t0]\n" \
 	"  v_readlane_b32 %[v0], v33, %[t0]\n" \
 	"  v_readlane_b32 %[v1], v32, %[t0]\n" \
 	"  v_readlane_b32 %[v2], v37, %[t0]\n" \
@@ -1310,7 +1304,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_branch Lstepped_%=\n" \
 	"Lmix0_%=:\n"                                    /* nothing done: the symbol goes the one-at-a-time way */ \
 	"  s_mov_b64 exec, 1\n" \
-	"  s_and_b32 %[c], %[sw], 15\n" \
+	"  s_and_b32 %[c], s90, 15\n" \
 	"  s_cbranch_scc0 Lvgo_%=\n" \
 	"  s_branch Llgo_%=\n"
 
@@ -1486,8 +1480,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_readlane_b32 %[ep], v52, %[t1]\n" \
 	"  v_readlane_b32 %[en], v53, %[t1]\n" \
 	"  v_readlane_b32 %[c], v45, %[t0]\n"            /* DELAYs of the step (lane k's count) */ \
-	"  v_readlane_b32 %[sw], v54, %[t0]\n" \
-	"  v_readlane_b32 %[swn], v43, %[t0]\n" \
+	"  v_readlane_b32 s90, v54, %[t0]\n"            /* the window registers: lane k's eight symbols, and what is left of the word behind them (TOPO_ASM_PAIR below) */ \
+	"  v_readlane_b32 s91, v43, %[t0]\n" \
 	"  s_and_b32 %[v2], %[v2], 0x3fffffff\n" \
 	"  s_add_u32 %[qpos], %[qpos], %[t1]\n" \
 	"  s_add_u32 %[qpos], %[qpos], 1\n" \
@@ -1501,6 +1495,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_sub_u32 %[pk1], %[pk1], %[t1]\n" \
 	"  s_add_u32 %[cler], %[cler], %[t0]\n" \
 	"  s_mov_b32 %[nc], -1\n" \
+	"  s_and_b32 %[c], %[cler], 7\n"                 /* (s91 came back as lane k's whole next word: shifted like s90, as at Lstepped) */ \
+	"  s_lshl_b32 %[c], %[c], 2\n" \
+	"  s_lshr_b32 s91, s91, %[c]\n" \
 	"  s_mov_b32 %[c], 0\n" \
 	"  s_cmp_ge_u32 %[cler], %[slideat]\n" \
 	"  s_cbranch_scc1 Lexit_%=\n" \
@@ -1599,9 +1596,10 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
 	// slide the symbol window up to the current symbol (whole wave, TOPO_FILL_WINDOW) and reload the two window registers
 #define TOPO_SLIDE() do { winbase = cler & ~31u; TOPO_FILL_WINDOW(winbase); \
-	{ const uint32_t wi_ = (cler - winbase) >> 3; sw = TOPO_S(cl32[wi_]) >> (4*(cler & 7u)); swn = TOPO_S(cl32[wi_ + 1]); } \
+	{ const uint32_t wi_ = (cler - winbase) >> 3; const uint64_t w2_ = ((uint64_t)TOPO_S(cl32[wi_]) | (uint64_t)TOPO_S(cl32[wi_ + 1]) << 32) >> (4*(cler & 7u)); sw = (uint32_t)w2_; swn = (uint32_t)(w2_ >> 32); } \
 	wbias = 1u - (winbase >> 3); slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu; } while(0)
-#define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw >>= 4; cler++; if((cler & 7u) == 0) { sw = swn; swn = TOPO_S(cl32[(cler >> 3) + wbias]); } } while(0)
+// (sw, swn) = the 64 bits of the current symbol word and the next one, shifted down to the current symbol: sw always holds EIGHT symbols
+#define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw = sw >> 4 | swn << 28; swn >>= 4; cler++; if((cler & 7u) == 0) swn = TOPO_S(cl32[(cler >> 3) + wbias]); } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
 #define TOPO_RELEASE(id, z) do { if((id) > MASK && !(TOPO_S(z) & TOPO_DELAYED)) { freel[TOPO_NFREE()] = (uint16_t)(id); pk1 += 0x10000u; } } while(0)
 	// give the surviving current edge a pool slot, its record, and its neighbours their links to it

@@ -23,7 +23,7 @@ class Model:
         self.use_runs = use_runs
         self.use_mix = use_mix
         self.use_ends = use_ends
-        self.any_align = os.environ.get('MIX_ANY_ALIGN', '0') == '1'   # experiment: a trigger that peeks into the next window word too (more one-symbol steps: not taken)
+        self.any_align = os.environ.get('MIX_ANY_ALIGN', '1') == '1'   # the kernel's window register holds eight symbols whatever the alignment (round 4; 0: what rounds 2-3 did - four certain symbols only with cler & 7 <= 4)
         self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
         self.group_end = group_end
         self.last_step = None
@@ -77,7 +77,7 @@ class Model:
                 while True:
                     # ---- the run step: k pairs of (VERTEX, LEFT) at once
                     # the symbols the kernel's window register certainly holds: what is left of the aligned word, or of the eight a step left behind
-                    certain = max(8 - (cler & 7), 8 - (cler - self.last_step) if self.last_step is not None else 0)
+                    certain = 8 if self.any_align else max(8 - (cler & 7), 8 - (cler - self.last_step) if self.last_step is not None else 0)
                     lead = False
                     if self.use_runs and os.environ.get('RUN_LEAD', '1') == '1' and certain >= 8 and [cl[cler + d] for d in range(8)] == [V, V, L, V, L, V, L, V] \
                             and ep <= MASK and min(self.nvert - vc, self.RING - (nq - qpos)) >= 1:
@@ -91,7 +91,7 @@ class Model:
                         rec[s_] = [opp, v1, v0, 0, LAZY, en]
                         v2 = v1; v1 = opp; en = s_; cler += 1
                         lead = True
-                    vis = 8 - (cler & 7) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' and not lead else 4    # the run step only when ALL the symbols the window register shows alternate (the kernel since round 4; 0: the first four)
+                    vis = (8 if self.any_align else 8 - (cler & 7)) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' and not lead else 4    # the run step only when ALL the symbols the window register shows alternate (the kernel since round 4; 0: the first four)
                     if self.use_runs and cl[cler] == V and cl[cler + 1] == L and cl[cler + 2] == V and cl[cler + 3] == L and all(cl[cler + d] == (V, L)[d & 1] for d in range(4, vis)):
                         kmax = min(64, self.nvert - vc, self.RING - (nq - qpos), (end - start) // 6)
                         ok = []
