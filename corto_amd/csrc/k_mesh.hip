@@ -375,6 +375,12 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Lleftp_%=\n" \
 							"  s_and_b32 %[t0], s90, 0xeeee\n" \
 							"  s_cbranch_scc0 Llmix_%=\n" \
+							"  s_and_b32 %[t1], s90, 0xeeff\n"      /* LEFT RIGHT and two of VERTEX / LEFT, or LEFT LEFT RIGHT and one: the mix step takes ONE RIGHT */ \
+							"  s_cmp_eq_u32 %[t1], 0x0021\n"        /* that has no VERTEX in front of it (after a DELAY the next gate goes L R V V ..) */ \
+							"  s_cbranch_scc1 Lmix_%=\n" \
+							"  s_and_b32 %[t1], s90, 0xefff\n" \
+							"  s_cmp_eq_u32 %[t1], 0x0211\n" \
+							"  s_cbranch_scc1 Lmix_%=\n" \
 							"Llgo_%=:\n" \
 							"  s_lshl_b32 %[t0], %[ep], 4\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
@@ -761,7 +767,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
 							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
-							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s92", "s93", "s94", "s96", "s97", "s98", "s99", "s90", "s91" TOPO_ASM_STAMP_CLOBBERS);
+							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99" TOPO_ASM_STAMP_CLOBBERS);
 
 // The symbol window, filled by the whole wave: 32 symbols per lane and pass (two 16-byte loads), each byte checked (anything that
 // is not one of the seven CLERS symbols, and everything behind the stream, becomes the invalid nibble 15) and squeezed to a nibble
@@ -1150,15 +1156,31 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_lshlrev_b32 v48, 4, v48\n" \
 	"  ds_read_b32 v47, v45 offset:12\n"             /* w[j]: the links of slot ep+j */ \
 	"  ds_read_b32 v51, v48 offset:12\n"             /* w[j-1] */ \
+	"  s_lshl_b32 %[t0], %[en], 4\n"                 /* e.next's record (every lane the same address: a broadcast), for the step's one RIGHT */ \
+	"  v_mov_b32 v52, %[t0]\n" \
+	"  ds_read_b128 v[56:59], v52\n" \
 	"  v_and_b32 v53, 7, v40\n" \
 	"  v_lshlrev_b32 v53, 2, v53\n" \
 	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_readfirstlane_b32 s93, v57\n"               /* s93: its v1 (the RIGHT's opposite vertex, v1 behind it), s94: its next (e.next behind it), s95: its flags */ \
+	"  v_readfirstlane_b32 s94, v59\n" \
+	"  v_readfirstlane_b32 s95, v58\n" \
 	"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
 	"  v_and_b32 v56, 15, v54\n"                     /* v56: the lane's symbol */ \
 	"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
 	"  v_cmp_ne_u32 vcc, 0, v60\n" \
 	"  v_cndmask_b32 v35, 0, v54, vcc\n"             /* (lane 0 may be the head of a regular run: the run step had its chance) */ \
-	"  v_cmp_gt_u32 vcc, 2, v56\n"                   /* VERTEX or LEFT ... */ \
+	"  v_cmp_eq_u32 vcc, 2, v56\n"                   /* the step's one RIGHT: the first, and only with no VERTEX in front of it (it closes against e.next */ \
+	"  s_ff1_i32_b64 s92, vcc\n"                     /* as the step finds it: nothing before it has touched that side).  s92: its lane, 64: none; */ \
+	"  v_cmp_eq_u32 vcc, 0, v56\n"                   /* s[96:97]: its exec bit */ \
+	"  s_ff1_i32_b64 %[t1], vcc\n" \
+	"  s_lshr_b32 s94, s94, 16\n" \
+	"  s_cmp_lt_u32 s92, %[t1]\n"                    /* (none: -1 = 0xffffffff, never below) */ \
+	"  s_cselect_b32 s92, s92, 64\n" \
+	"  s_cselect_b32 %[t1], 1, 0\n" \
+	"  s_bfm_b64 s[96:97], %[t1], s92\n" \
+	"  v_cmp_gt_u32 vcc, 2, v56\n"                   /* VERTEX or LEFT (or that RIGHT) ... */ \
+	"  s_or_b64 vcc, vcc, s[96:97]\n" \
 	"  s_and_b64 exec, exec, vcc\n" \
 	"  v_cmp_gt_u32 vcc, %[t3], v60\n"               /* ... within kmax ... */ \
 	"  s_and_b64 exec, exec, vcc\n" \
@@ -1171,6 +1193,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_mov_b64 exec, -1\n" \
 	"  s_cmp_eq_u32 %[t0], 0\n" \
 	"  s_cbranch_scc1 Lmix0_%=\n" \
+	"  s_cmp_lt_u32 s92, %[t0]\n"                    /* (a RIGHT behind the first lane out is not this step's) */ \
+	"  s_cselect_b32 s92, s92, 64\n" \
+	"  s_cselect_b32 %[t1], 1, 0\n" \
+	"  s_bfm_b64 s[96:97], %[t1], s92\n" \
 	"  v_cmp_gt_u32 vcc, %[t0], v60\n" \
 	"  v_cndmask_b32 v56, 15, v56, vcc\n"            /* (from it on: no symbol) */ \
 	"  v_cmp_eq_u32 vcc, 0, v60\n" \
@@ -1179,6 +1205,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_and_b64 exec, exec, vcc\n" \
 	"  v_cmp_ne_u32 vcc, %[en], v44\n" \
 	"  s_and_b64 exec, exec, vcc\n" \
+	"  v_cmp_ne_u32 vcc, s94, v44\n"                 /* (nor what is e.next behind a RIGHT: the first VERTEX behind it rewrites that slot's prev link, and a lane */ \
+	"  s_and_b64 exec, exec, vcc\n"                  /* closing it has read the link already - a small closed front comes round to it; cutting the chain is always safe) */ \
 	"  s_not_b64 vcc, exec\n" \
 	"  s_ff1_i32_b64 %[t1], vcc\n"                   /* C: chain slots ep .. ep+C-1 are usable (-1: all 64) */ \
 	"  s_mov_b64 exec, -1\n" \
@@ -1195,14 +1223,22 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mbcnt_hi_u32_b32 v39, vcc_hi, v39\n"        /* nL_j */ \
 	"  v_cndmask_b32 v36, v38, v39, vcc\n"           /* ... and the number it would take */ \
 	"  v_cmp_gt_u32 vcc, 2, v56\n" \
+	"  s_or_b64 vcc, vcc, s[96:97]\n"                /* (the RIGHT takes neither a chain slot nor a vertex id) */ \
 	"  s_and_b64 exec, exec, vcc\n" \
 	"  v_cmp_lt_u32 vcc, v36, v35\n" \
+	"  s_or_b64 vcc, vcc, s[96:97]\n" \
 	"  s_and_b64 exec, exec, vcc\n" \
 	"  s_not_b64 vcc, exec\n" \
 	"  s_ff1_i32_b64 %[t0], vcc\n"                   /* k: the symbols of this step */ \
 	"  s_mov_b64 exec, -1\n" \
 	"  s_cmp_eq_u32 %[t0], 0\n" \
 	"  s_cbranch_scc1 Lmix0_%=\n" \
+	"  s_cmp_lt_u32 s92, %[t0]\n"                    /* the RIGHT is one of them: e.next moves on for everything behind it (s96: what it was, for the RIGHT's own writes) */ \
+	"  s_cselect_b32 s92, s92, 64\n" \
+	"  s_cbranch_scc0 Lmixr1_%=\n" \
+	"  s_mov_b32 s96, %[en]\n" \
+	"  s_mov_b32 %[en], s94\n" \
+	"Lmixr1_%=:\n" \
 	"  v_add_u32 v49, %[ep], v39\n"                  /* x[nL_j], x[nL_j - 1], x[nL_j - 2] */ \
 	"  v_add_u32 v50, -1, v49\n" \
 	"  v_add_u32 v52, -2, v49\n" \
@@ -1219,6 +1255,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_add_u32 v32, -1, v34\n" \
 	"  v_add_u32 v36, -2, v34\n" \
 	"  v_mov_b32 v58, %[v1]\n" \
+	"  v_mov_b32 v62, s93\n" \
+	"  v_cmp_lt_u32 vcc, s92, v60\n"                 /* behind the RIGHT: v1 is the vertex it closed against */ \
+	"  v_cndmask_b32 v58, v58, v62, vcc\n" \
 	"  v_cmp_lt_u32 vcc, 0, v38\n" \
 	"  v_cndmask_b32 v32, v58, v32, vcc\n"           /* b_j */ \
 	"  v_cmp_lt_u32 vcc, 1, v38\n" \
@@ -1233,6 +1272,12 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_cndmask_b32 v34, v46, v34, vcc\n"           /* opp_j */ \
 	"  s_lshl_b64 vcc, vcc, 1\n"                     /* lane j: symbol j-1 was a VERTEX */ \
 	"  v_cndmask_b32 v37, v37, v36, vcc\n" \
+	"  v_cmp_eq_u32 vcc, s92, v60\n"                 /* the RIGHT's own opposite vertex ... */ \
+	"  v_cndmask_b32 v34, v34, v62, vcc\n" \
+	"  s_add_u32 %[t1], s92, 1\n"                    /* ... and right behind it v2 is the v1 it found */ \
+	"  v_mov_b32 v63, %[v1]\n" \
+	"  v_cmp_eq_u32 vcc, %[t1], v60\n" \
+	"  v_cndmask_b32 v37, v37, v63, vcc\n" \
 	"  v_mov_b32 v58, %[v2]\n" \
 	"  v_cmp_eq_u32 vcc, 0, v60\n" \
 	"  v_cndmask_b32 v37, v37, v58, vcc\n"           /* c_j */ \
@@ -1284,6 +1329,26 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mov_b32 v42, 0x8000\n" \
 	"  ds_write_b16 v49, v42 offset:10\n" \
 	"  s_mov_b64 exec, 1\n" \
+	"  s_cmp_eq_u32 s92, 64\n"                       /* the RIGHT's own writes: what was e.next is deleted, and its slot - a survivor's - goes back to the free list */ \
+	"  s_cbranch_scc1 Lmixr2_%=\n"                   /* unless the DELAY stack still owns it (Lrightp's, above) */ \
+	"  s_lshl_b32 %[c], s96, 4\n" \
+	"  v_mov_b32 v40, %[c]\n" \
+	"  v_mov_b32 v41, 0x8000\n" \
+	"  ds_write_b16 v40, v41 offset:10\n" \
+	"  s_cmp_gt_u32 s96, %[mask]\n" \
+	"  s_cbranch_scc0 Lmixr2_%=\n" \
+	"  s_bitcmp1_b32 s95, 30\n" \
+	"  s_cbranch_scc1 Lmixr2_%=\n" \
+	"  s_lshr_b32 %[c], %[pk1], 16\n" \
+	"  s_lshl_b32 %[c], %[c], 1\n" \
+	"  s_add_u32 %[t3], %[mask], 1\n" \
+	"  s_lshl_b32 %[t3], %[t3], 5\n" \
+	"  s_add_u32 %[c], %[c], %[t3]\n" \
+	"  v_mov_b32 v40, %[c]\n" \
+	"  v_mov_b32 v41, s96\n" \
+	"  ds_write_b16 v40, v41\n" \
+	"  s_add_u32 %[pk1], %[pk1], 0x10000\n" \
+	"Lmixr2_%=:\n" \
 	"  s_cmp_eq_u32 %[t1], 0\n" \
 	"  s_cbranch_scc1 Lmixnov_%=\n" \
 	"  s_and_b32 %[t3], %[nq], %[mask]\n"            /* e.next.prev = the first new slot */ \

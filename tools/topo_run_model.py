@@ -134,13 +134,19 @@ class Model:
                         v0, v1, v2, ep, en, vc, nq, start, cler, r_en, r_s, nf, pv = saved
                         rec[en][:] = r_en; rec[nq & MASK][:] = r_s; del self.faces[nf:]; self.pred[vc] = pv
                     # ---- the mix step: k symbols of any VERTEX / LEFT sequence at once, one symbol per lane (TOPO_MIX_STEP)
-                    if self.use_mix and ((cler & 7) <= 4 or self.any_align) and all(cl[cler + d] in (V, L) for d in range(4)) and ep <= MASK \
+                    use_r = os.environ.get('MIX_RIGHT', '1') == '1'    # one RIGHT in the step, in front of every VERTEX of it (the kernel since round 4)
+                    first4 = [cl[cler + d] for d in range(4)]
+                    r4 = first4.index(R) if R in first4 else 4
+                    trig_r = use_r and 1 <= r4 <= 2 and all(c_ == L for c_ in first4[:r4]) and all(c_ in (V, L) for c_ in first4[r4 + 1:])   # (L R x x, L L R x: what the LEFT handler tests)
+                    if self.use_mix and ((cler & 7) <= 4 or self.any_align) and (all(c_ in (V, L) for c_ in first4) or trig_r) and ep <= MASK \
                             and [cl[cler + d] for d in range(4)] not in (([L, V, L, V], [V, V, L, V]) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' else ([V, L, V, L], [L, V, L, V], [V, V, L, V])):
                         kmax = min(63, (end - start) // 3, self.win_left(cler))
                         budget = min(self.nvert - vc, self.RING - (nq - qpos))
                         sym = [cl[cler + j] for j in range(64)]
-                        k0 = 0
-                        while k0 < kmax and sym[k0] in (V, L): k0 += 1
+                        k0 = 0; rpos = 64                   # rpos: the step's RIGHT (64: none) - the first one, and only with no VERTEX in front of it
+                        while k0 < kmax and (sym[k0] in (V, L) or (use_r and sym[k0] == R and rpos == 64 and V not in sym[:k0])):
+                            if sym[k0] == R: rpos = k0
+                            k0 += 1
                         isV = [j < k0 and sym[j] == V for j in range(64)]
                         isL = [j < k0 and sym[j] == L for j in range(64)]
                         nV = [sum(isV[:j]) for j in range(64)]
@@ -149,12 +155,12 @@ class Model:
                         chain_ok = []
                         for i in range(64):
                             slot = (ep + i) & MASK
-                            o = slot != en
+                            o = slot != en and (not use_r or slot != rec[en][5])   # (nor what is e.next behind a RIGHT: the first VERTEX behind it rewrites that slot's prev link, which a lane closing it would have read already)
                             if i >= 1: o = o and rec[(ep + i - 1) & MASK][4] == slot
                             chain_ok.append(o)
                         C = 0
                         while C < 64 and chain_ok[C]: C += 1
-                        bad = [not (isV[j] or isL[j]) or (isL[j] and nL[j] >= C) or (isV[j] and nV[j] >= budget) for j in range(64)]
+                        bad = [not (isV[j] or isL[j] or j == rpos) or (isL[j] and nL[j] >= C) or (isV[j] and nV[j] >= budget) for j in range(64)]
                         T = int(os.environ.get('MIX_RUN_AHEAD', '16'))   # how long a regular run ahead must be to end the mix step (16: what the kernel does; 8 until round 4)
                         for j in range(1, 64):              # a regular run ahead: the run step does two symbols a lane
                             if [cl[cler + j + d] for d in range(T)] == [V, L] * (T // 2) and (T == 8 or j + T <= 64 + 7): bad[j] = True
@@ -165,16 +171,22 @@ class Model:
                             x = [rec[(ep + i) & MASK][0] for i in range(64)]
                             w = [rec[(ep + i) & MASK][4] for i in range(64)]
                             TV, TL = nV[k], nL[k]
+                            hasR = rpos < k                  # the RIGHT closes against e.next as it is when the step begins (nothing in front of it touches that side)
+                            tR = list(rec[en]) if hasR else None
+                            v1b = tR[1] if hasR else v1       # v1 and e.next behind the RIGHT
+                            enb = tR[5] if hasR else en
                             nV = [sum(isV[:min(j, k)]) for j in range(64)]      # masks cut at k (lane k reads the state after the step)
                             nL = [sum(isL[:min(j, k)]) for j in range(64)]
                             def abc(j):
+                                base = v1b if j > rpos else v1
                                 a = x[nL[j] - 1] if nL[j] else v0
-                                b = vc + nV[j] - 1 if nV[j] else v1
+                                b = vc + nV[j] - 1 if nV[j] else base
                                 if j == 0: c = v2
-                                elif sym[j - 1] == V: c = vc + nV[j] - 2 if nV[j] >= 2 else v1
+                                elif j - 1 == rpos: c = v1
+                                elif sym[j - 1] == V: c = vc + nV[j] - 2 if nV[j] >= 2 else base
                                 else: c = x[nL[j] - 2] if nL[j] >= 2 else v0
                                 return a, b, c
-                            en0 = en
+                            en0 = enb
                             for j in range(k):
                                 a, b, c = abc(j)
                                 if isV[j]:
@@ -182,6 +194,10 @@ class Model:
                                     self.pred[opp] = (b, a, c)
                                     s_ = (nq + nV[j]) & MASK
                                     rec[s_] = [opp, b, a, 0, ((nq + nV[j] + 1) & MASK) if nV[j] + 1 < TV else LAZY, ((nq + nV[j] - 1) & MASK) if nV[j] else en0]
+                                elif j == rpos:
+                                    opp = v1b
+                                    rec[en][3] = 1
+                                    if en > MASK and en not in delayed: free.append(en)
                                 else:
                                     opp = x[nL[j]]
                                     rec[(ep + nL[j]) & MASK][3] = 1
@@ -189,8 +205,9 @@ class Model:
                             if TV: rec[en0][4] = nq & MASK
                             a, b, c = abc(k)
                             epn = w[TL - 1] if TL else ep
-                            enn = (nq + TV - 1) & MASK if TV else en
+                            enn = (nq + TV - 1) & MASK if TV else enb
                             v0, v1, v2, ep, en = a, b, c, epn, enn
+                            self.stats['mix_rights'] = self.stats.get('mix_rights', 0) + int(hasR)
                             vc += TV; nq += TV; start += 3 * k; cler += k
                             self.stats['mixes'] += 1; self.stats['mix_symbols'] += k; self.events.append((cler - k, 'mix', k)); self.last_step = cler
                             self.stats['mix_hist'][k] = self.stats['mix_hist'].get(k, 0) + 1
@@ -297,8 +314,37 @@ def check(mesh, name, **kw):
     assert okf and okp
 
 
+def wide(n=400, seed=7):
+    """hundreds of small random meshes of every family, every second one cut into groups: the dozen meshes below did not show a rule that was
+    wrong on small closed fronts (round 4: a RIGHT in the mix step).  Run this BEFORE writing a formulation in ISA: python tools/topo_run_model.py wide"""
+    import corto_amd as ca
+    from corto_amd import synth
+    from oracle import oracle as oc
+    rng = np.random.default_rng(seed)
+    bad = 0; tot = {}
+    for k in range(n):
+        f = k % 6
+        if f == 0: m = synth.closed_sphere(int(rng.integers(6, 40)), int(rng.integers(4, 20)), seed=k)
+        elif f == 1: m = synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=k, flip=float(rng.choice([0.05, 0.2, 0.5, 0.9])))
+        elif f == 2: m = synth.torus(int(rng.integers(6, 30)), int(rng.integers(4, 14)), seed=k)
+        elif f == 3: m = synth.holey_disc(int(rng.integers(8, 30)), seed=k, hole_frac=float(rng.uniform(0.02, 0.3)))
+        elif f == 4: m = synth.shuffled(synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=k, flip=0.3))
+        else: m = synth.bumpy_sphere(int(rng.integers(8, 60)), int(rng.integers(4, 30)), seed=k)
+        if k % 2 and m.nface > 24: m.groups = [m.nface // 3, m.nface // 2 + 1, m.nface]
+        blob = ca.aligned_blob(ca.encode(m)); r = oc.decode(blob, trace=True)
+        mm = Model(r["_clers"], r["nvert"], r["nface"], ca.probe_groups(blob), ref_faces=r["index"])
+        faces, pred = mm.run()
+        ok = np.array_equal(faces, r["index"]) and np.array_equal(pred[1:], r["_prediction"][1:])
+        if not ok: bad += 1; print("WRONG: mesh", k, "family", f, "faces", m.nface)
+        for key in ("runs", "leads", "mixes", "mix_rights", "ends", "serial"): tot[key] = tot.get(key, 0) + mm.stats.get(key, 0)
+    print(n, "meshes,", bad, "wrong;", tot)
+    assert not bad
+
+
 if __name__ == "__main__":
     from corto_amd import synth
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        wide(); sys.exit(0)
     check(synth.closed_sphere(24, 12), "closed")
     check(synth.closed_sphere(64, 40), "closed-big")
     check(synth.bumpy_sphere(64, 32, seed=3), "c4")
