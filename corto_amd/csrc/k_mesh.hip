@@ -377,10 +377,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc0 Llmix_%=\n" \
 							"  s_and_b32 %[t1], s90, 0xeeff\n"      /* LEFT RIGHT and two of VERTEX / LEFT, or LEFT LEFT RIGHT and one: the mix step takes ONE RIGHT */ \
 							"  s_cmp_eq_u32 %[t1], 0x0021\n"        /* that has no VERTEX in front of it (after a DELAY the next gate goes L R V V ..) */ \
-							"  s_cbranch_scc1 Lmix_%=\n" \
+							"  s_cbranch_scc1 Lmixr_%=\n" \
 							"  s_and_b32 %[t1], s90, 0xefff\n" \
 							"  s_cmp_eq_u32 %[t1], 0x0211\n" \
-							"  s_cbranch_scc1 Lmix_%=\n" \
+							"  s_cbranch_scc1 Lmixr_%=\n" \
 							"Llgo_%=:\n" \
 							"  s_lshl_b32 %[t0], %[ep], 4\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
@@ -1129,7 +1129,14 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  global_store_dword v59, v36, %[faceb]\n" \
 	"  global_store_short v59, v34, %[faceb] offset:4\n"
 #define TOPO_ASM_MIX(FACE, FSHIFT) \
-	"Lmix_%=:\n" \
+	"Lmix_%=:\n"                                     /* entered on four symbols of VERTEX / LEFT: no RIGHT is looked for (s92 = 64: none; what a step pays */ \
+	"  s_mov_b32 s92, 64\n"                          /* for looking is ~40 instructions and a 64-lane LDS read, and a regular blob's mix steps never meet one) */ \
+	"  s_mov_b64 s[96:97], 0\n" \
+	"  s_mov_b32 s94, -1\n" \
+	"  s_branch Lmixb_%=\n" \
+	"Lmixr_%=:\n"                                    /* entered on L R .. / L L R ..: the step takes its one RIGHT */ \
+	"  s_mov_b32 s92, 0\n" \
+	"Lmixb_%=:\n" \
 	"  s_cmp_gt_u32 %[ep], %[mask]\n"                 /* e.prev in the pool: one symbol at a time */ \
 	"  s_cbranch_scc1 Lmix0_%=\n" \
 	"  s_sub_u32 %[t3], %[end], %[start]\n"           /* kmax = min(63, faces the group and symbols the window hold) */ \
@@ -1156,20 +1163,25 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_lshlrev_b32 v48, 4, v48\n" \
 	"  ds_read_b32 v47, v45 offset:12\n"             /* w[j]: the links of slot ep+j */ \
 	"  ds_read_b32 v51, v48 offset:12\n"             /* w[j-1] */ \
+	"  s_cmp_eq_u32 s92, 64\n" \
+	"  s_cbranch_scc1 Lmixa_%=\n" \
 	"  s_lshl_b32 %[t0], %[en], 4\n"                 /* e.next's record (every lane the same address: a broadcast), for the step's one RIGHT */ \
 	"  v_mov_b32 v52, %[t0]\n" \
-	"  ds_read_b128 v[56:59], v52\n" \
+	"  ds_read_b128 v[36:39], v52\n" \
+	"Lmixa_%=:\n" \
 	"  v_and_b32 v53, 7, v40\n" \
 	"  v_lshlrev_b32 v53, 2, v53\n" \
 	"  s_waitcnt lgkmcnt(0)\n" \
-	"  v_readfirstlane_b32 s93, v57\n"               /* s93: its v1 (the RIGHT's opposite vertex, v1 behind it), s94: its next (e.next behind it), s95: its flags */ \
-	"  v_readfirstlane_b32 s94, v59\n" \
-	"  v_readfirstlane_b32 s95, v58\n" \
 	"  v_lshrrev_b64 v[54:55], v53, v[42:43]\n"      /* v54: the symbols from p on, eight nibbles */ \
 	"  v_and_b32 v56, 15, v54\n"                     /* v56: the lane's symbol */ \
 	"  v_and_b32 v57, 0xffff, v51\n"                 /* rec[ep+j-1].prev */ \
 	"  v_cmp_ne_u32 vcc, 0, v60\n" \
 	"  v_cndmask_b32 v35, 0, v54, vcc\n"             /* (lane 0 may be the head of a regular run: the run step had its chance) */ \
+	"  s_cmp_eq_u32 s92, 64\n" \
+	"  s_cbranch_scc1 Lmixc_%=\n" \
+	"  v_readfirstlane_b32 s93, v37\n"               /* s93: e.next's v1 (the RIGHT's opposite vertex, v1 behind it), s94: its next (e.next behind it), s95: its flags */ \
+	"  v_readfirstlane_b32 s94, v39\n" \
+	"  v_readfirstlane_b32 s95, v38\n" \
 	"  v_cmp_eq_u32 vcc, 2, v56\n"                   /* the step's one RIGHT: the first, and only with no VERTEX in front of it (it closes against e.next */ \
 	"  s_ff1_i32_b64 s92, vcc\n"                     /* as the step finds it: nothing before it has touched that side).  s92: its lane, 64: none; */ \
 	"  v_cmp_eq_u32 vcc, 0, v56\n"                   /* s[96:97]: its exec bit */ \
@@ -1179,6 +1191,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_cselect_b32 s92, s92, 64\n" \
 	"  s_cselect_b32 %[t1], 1, 0\n" \
 	"  s_bfm_b64 s[96:97], %[t1], s92\n" \
+	"Lmixc_%=:\n" \
 	"  v_cmp_gt_u32 vcc, 2, v56\n"                   /* VERTEX or LEFT (or that RIGHT) ... */ \
 	"  s_or_b64 vcc, vcc, s[96:97]\n" \
 	"  s_and_b64 exec, exec, vcc\n" \
@@ -1272,12 +1285,15 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_cndmask_b32 v34, v46, v34, vcc\n"           /* opp_j */ \
 	"  s_lshl_b64 vcc, vcc, 1\n"                     /* lane j: symbol j-1 was a VERTEX */ \
 	"  v_cndmask_b32 v37, v37, v36, vcc\n" \
+	"  s_cmp_eq_u32 s92, 64\n" \
+	"  s_cbranch_scc1 Lmixd_%=\n" \
 	"  v_cmp_eq_u32 vcc, s92, v60\n"                 /* the RIGHT's own opposite vertex ... */ \
 	"  v_cndmask_b32 v34, v34, v62, vcc\n" \
 	"  s_add_u32 %[t1], s92, 1\n"                    /* ... and right behind it v2 is the v1 it found */ \
 	"  v_mov_b32 v63, %[v1]\n" \
 	"  v_cmp_eq_u32 vcc, %[t1], v60\n" \
 	"  v_cndmask_b32 v37, v37, v63, vcc\n" \
+	"Lmixd_%=:\n" \
 	"  v_mov_b32 v58, %[v2]\n" \
 	"  v_cmp_eq_u32 vcc, 0, v60\n" \
 	"  v_cndmask_b32 v37, v37, v58, vcc\n"           /* c_j */ \

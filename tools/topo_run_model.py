@@ -138,7 +138,8 @@ class Model:
                     first4 = [cl[cler + d] for d in range(4)]
                     r4 = first4.index(R) if R in first4 else 4
                     trig_r = use_r and 1 <= r4 <= 2 and all(c_ == L for c_ in first4[:r4]) and all(c_ in (V, L) for c_ in first4[r4 + 1:])   # (L R x x, L L R x: what the LEFT handler tests)
-                    if self.use_mix and ((cler & 7) <= 4 or self.any_align) and (all(c_ in (V, L) for c_ in first4) or trig_r) and ep <= MASK \
+                    NTRIG = int(os.environ.get('MIX_TRIGGER_SYMBOLS', '4'))   # experiment: how many symbols of VERTEX / LEFT the trigger asks for (the window register shows eight)
+                    if self.use_mix and ((cler & 7) <= 4 or self.any_align) and (all(cl[cler + d] in (V, L) for d in range(NTRIG)) or trig_r) and ep <= MASK \
                             and [cl[cler + d] for d in range(4)] not in (([L, V, L, V], [V, V, L, V]) if os.environ.get('RUN_TRIGGER_VISIBLE', '1') == '1' else ([V, L, V, L], [L, V, L, V], [V, V, L, V])):
                         kmax = min(63, (end - start) // 3, self.win_left(cler))
                         budget = min(self.nvert - vc, self.RING - (nq - qpos))
