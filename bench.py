@@ -19,7 +19,7 @@ Timing: barrier + device sync, then W warm-up steps flow straight into the K tim
 between); the clock runs from the completion of the last warm-up step to the completion of the K-th timed step, a few more
 steps are queued behind so that every context is still busy when the clock stops, then everything drains, barrier + sync.
 So `--steps 20` measures the same steady state as `--steps 480`.  value = K batches / that time (max over ranks).
-With K < 100 the K-step region is timed R = ~500/K times back to back (no drain in between) and the MEDIAN region is reported, every
+With K < 100 the K-step region is timed R = ~2000/K times back to back (no drain in between) and the MEDIAN region is reported, every
 region's time in `timed_regions`: completions of sixteen batches in flight come in bursts, and one region of 20 steps lands
 anywhere within -15 / +30 % of the long-run rate (tools/pool_probe.py).
 `python bench.py --gpus N` without a launcher runs the N GPUs from this one process (one pool, shared queue, N x K steps);
@@ -565,7 +565,7 @@ def main():
     # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
     # -15 / +30 % of the long-run rate (tools/pool_probe.py); every region's time is in `timed_regions`.  K >= 100: five regions (one 480-step region that meets a multi-ms stall reads 25 % low).
-    R = 5 if args.steps >= 100 else max(5, -(-500 // args.steps) | 1)      # (an odd number of regions, ~500 steps in all: round 3 - five regions' median still moved +-8 % run to run)
+    R = 5 if args.steps >= 100 else max(5, -(-2000 // args.steps) | 1)     # (an odd number of regions, ~2 000 steps in all = 0.18 s: round 3's five regions' median still moved +-8 % run to run, round 4's 25 +-4 % - 11.0 .. 12.1 Gtri/s on five boxes where the 480-step form read 11.9 .. 12.2)
     # (the W warm-up steps the caller asked for, plus two rounds of the pool's contexts: with twenty batches in flight a pipeline that was empty
     # when the run began is not full after five steps, and the first regions would time its filling)
     ramp = 2 * pool.lanes
@@ -803,7 +803,7 @@ def main():
                        "timed_region": "SURVEY 8d primary: K x [H2D of the batch's .crt bytes from ONE pinned host buffer + plan(host walk)+bind+kernels+sync] per GPU, "
                                        "outputs left in HBM; clock from the "
                                        "completion of the last of W warm-up steps to the completion of the K-th timed step, pipeline full at both ends "
-                                       "(barrier + device sync before the warm-up and after the drain); K < 100: ~500/K such regions back to back, the median one reported (timed_regions); "
+                                       "(barrier + device sync before the warm-up and after the drain); K < 100: ~2000/K such regions back to back, the median one reported (timed_regions); "
                                        "the rate with the compressed inputs already resident in HBM (rounds 1-3's `value`) is `resident_inputs`",
                        "h2d_bytes_per_step": int(stats0.arena_bytes), "pcie_GBps": round(stats0.arena_bytes / (ms_step * 1e-3) / 1e9, 2),
                        "pipeline_depth": depth, "host_threads": nthreads, "launch": mode,

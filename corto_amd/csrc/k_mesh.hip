@@ -502,7 +502,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
       the wave's parked lanes look at 64 queue entries at once, the first live one becomes the current edge, and the dispatch goes on \
       without leaving the block.  pk1 = pool bump pointer | free-list fill << 16, pk2 = DELAY stack fill | its capacity << 16. \
       Layout (records at LDS address 0, ring = pool = mask + 1): free list at (mask+1)*32, DELAY stack at (mask+1)*34. \
-      Anything else (END, SPLIT, an invalid or window-end nibble, no slot left, empty ring, window about to run out) leaves for the C++. */ \
+      Anything else (END, an invalid or window-end nibble, no slot left, empty ring and empty DELAY stack, window about to run out) leaves for the C++. */ \
 							"Lcold_%=:\n" \
 							"  s_cmp_eq_u32 %[c], 4\n" \
 							"  s_cbranch_scc1 Lbnd_%=\n" \
@@ -724,8 +724,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"Lended_%=:\n" \
 							"  s_mov_b32 %[c], 0x200\n"             /* nothing is current: the C++ fetches the next gate (slide, DELAY stack, seed face) */ \
 							"  s_branch Lexit_%=\n" \
-							   /* ---------------- four symbols of VERTEX / LEFT ahead: the mix step (TOPO_MIX_STEP) takes them, unless they are the head of a regular \
-							      run one symbol on (V VLV.., L VLV..: that symbol here, then the run step) or the window register holds fewer than four */ \
+							   /* ---------------- what the next symbols ask for (s90 shows eight of them whatever the alignment: TOPO_ASM_TAIL).  Four of VERTEX / LEFT: the \
+							      mix step (TOPO_ASM_MIX) - unless they are the head of a regular run one symbol on (V VLVLVL V: the run step with that VERTEX as \
+							      its lead lane; L VLV..: the LEFT here, then the run step); VERTEX LEFT VERTEX LEFT: the run step if all eight go on like that, else \
+							      the mix step takes the short run along; L R x x / L L R x: the mix step with its one RIGHT (Lleft above) */ \
 							"Lvlead_%=:\n"                         /* V VLVLVL V: the lone VERTEX in front of a regular run rides along with the run step (TOPO_ASM_RUN's */ \
 							"  s_cmp_eq_u32 s90, 0x01010100\n"    /* lead lane); else it goes one at a time */ \
 							"  s_cbranch_scc1 Lrunv_%=\n" \
@@ -1116,7 +1118,14 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 // slot, lazy for the last; next = the previous VERTEX's slot, e.next for the first), a LEFT lane the deleted flag of slot ep + nL_j.
 // The step ends at the first lane whose symbol is something else, whose LEFT would need a chain slot behind a broken link (slot ep+i is
 // usable while link(ep+i-1).prev == ep+i and ep+i != e.next, as in the run step), whose VERTEX has no vertex id or ring slot left, or
-// from which on a regular run lies ahead (VLVLVLVL: the run step does two symbols a lane).  The state after it is lane k's (a, b, c).
+// from which on a regular run of SIXTEEN symbols lies ahead (the run step does two symbols a lane; a shorter run is cheaper taken along:
+// round 4).  The state after it is lane k's (a, b, c).
+// Round 4: ONE RIGHT, if the step was entered for it (Lmixr: L R x x / L L R x - what follows a DELAY) and no VERTEX stands in front of it.
+// A RIGHT touches the other side of the current edge only: it closes against e.next as the step finds it (t = that record, one broadcast
+// read), and behind it v1 = t.v1, e.next = t.next - so with r = its lane, b_j takes t.v1 for v1 when j > r, c_{r+1} = the old v1, the
+// first VERTEX' record links to t.next, and the chain of slots the LEFTs may close stops in front of t.next as well as in front of
+// e.next: the first VERTEX behind the RIGHT rewrites that slot's prev link, which a lane closing it would have read already (a small
+// closed front comes round to it - tools/topo_run_model.py `wide` found it, the dozen meshes it used to run did not).
 // Two LDS round trips (symbols and links; then a lane's three x, whose addresses depend on nL_j).  Checked against the oracle on the
 // host model (tools/topo_run_model.py) before it was written here.
 #define TOPO_MIX_FACE32 \
@@ -1765,12 +1774,14 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 				for(;;) {
 					if(cler >= slide_at) TOPO_SLIDE();                      // (a chain longer than the window's margin: mid-chain)
 					{
-						// The common steps in hand-scheduled gfx950 ISA: VERTEX, and LEFT / RIGHT against a ring-slot (queued)
-						// neighbour, ~40 instructions per symbol where the compiler's dispatch of the C++ below spends ~68
-						// (scalar copies at every join).  The block PEEKS at the next symbol and leaves with the state
-						// untouched for anything else - cold symbols, a pool-slot neighbour (needs the free list), vertex ids
-						// or ring running out, the group's last face - which the C++ below then handles.  The run step and the mix step (the
-						// whole wave on up to 126 / 63 symbols at once, TOPO_ASM_RUN / TOPO_ASM_MIX above) are sections of the block.
+						// Every symbol a well-formed mesh contains in hand-scheduled gfx950 ISA: VERTEX, LEFT / RIGHT against a queued (ring) or a
+						// surviving (pool) neighbour, SPLIT, BOUNDARY / DELAY with the pop behind them, ~40 instructions per symbol where the
+						// compiler's dispatch of the C++ below spends ~68 (scalar copies at every join), and the wave-wide steps as sections of the
+						// block: runs of (VERTEX LEFT) pairs with a lone VERTEX in front (TOPO_ASM_RUN, up to 127 symbols), any VERTEX / LEFT sequence
+						// with one RIGHT (TOPO_ASM_MIX, 63), runs of chain ends (TOPO_ASM_ENDS).  The block PEEKS at the next symbol and leaves with
+						// the state untouched for the rest - END, an invalid or window-end nibble, vertex ids, ring or pool slots running out, the
+						// group's last face, the window wanting a slide - which the C++ below then handles.  (Round 4's dispatch trace found SPLIT and
+						// the pool neighbours leaving for the C++ at 1 500-2 000 clocks each: DESIGN.md 3.1.)
 						uint32_t t0_, t1_, t2_, t3_, c_;
 						uint32_t budget_ = TOPO_S(min(nvert - min(vc, nvert), MASK + 1u - (nq - qpos)));   // VERTEX steps the block may take: vertex ids and ring slots left
 						{ TOPO_T0();
