@@ -349,6 +349,20 @@ def test_random_mesh_stress_run(ctx):
     assert " mismatching arrays 0 " in tail[-1], "\n".join(l for l in out.stdout.splitlines() if "MISMATCH" in l)[:4000]
 
 
+def test_device_sqrtf_is_the_reference_norm_for_every_float(tmp_path):
+    """k_normal.hip's norm3() takes the f32 square root (17 issue slots) where upstream's Point3::norm() says (float)sqrt((double)s)
+    (34, half of them f64): the same bits for EVERY non-negative float if the device routine is correctly rounded - which
+    tests/cpp/sqrt_equiv.hip checks exhaustively (2^31 patterns, a few milliseconds), built with the library's own flags"""
+    import subprocess
+    from conftest import ROOT
+    from corto_amd import build as cb
+    exe = str(tmp_path / "sqrt_equiv")
+    flags = [f for f in cb.FLAGS if f not in ("-fPIC",)]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(ROOT, "tests", "cpp", "sqrt_equiv.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " mismatches 0 " in out.stdout, out.stdout + out.stderr
+
+
 def test_single_stream_context_decodes_the_same(ctx):
     """crthip_ctx_set_single_stream: everything on one HIP stream (what crthip_pool gives its contexts once their streams would outnumber
     the hardware queues) - same bytes as the two-stream schedule"""
