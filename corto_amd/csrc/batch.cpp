@@ -215,7 +215,8 @@ struct crthip_ctx {
 	hipStream_t stream2 = nullptr;  // attribute streams (Tunstall + bit-unpack) run here while the main stream does topology
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	hipEvent_t ev_done = nullptr;   // recorded behind a decode's last kernel: what sync / done wait for, so that work a caller queues on the stream BEHIND a decode
-	                                // (crthip_pool: the next batch's upload) does not delay the harvest of this one
+	                                // does not delay the harvest of this one
+	uint32_t upload_seq = 0, done_covers_seq = 0;   // arena_pin uploads enqueued so far / how many of them sit IN FRONT of ev_done (harvest may only call those complete)
 	DebugConfig dbg;                // every environment switch, read once when the context is made (debug_config.h)
 	uint32_t normal_fn_max = NORMAL_FN_LDS_MAX;       // largest LDS request for which K-NRM keeps its face normals in LDS (0 for a context that is one of many: crthip_ctx_set_single_stream)
 	uint8_t single_stream = 0;                        // crthip_ctx_set_single_stream: no second HIP stream for the attribute streams
@@ -290,7 +291,7 @@ static int harvest(crthip_ctx *ctx) {
 	crthip_batch *b = ctx->in_flight;
 	if(!b) return CRTHIP_OK;
 	if(hipEventSynchronize(ctx->ev_done) != hipSuccess) { ctx->in_flight = nullptr; return CRTHIP_E_DEVICE; }
-	ctx->arena_upload_pending = false;                                     // (the library's own upload sits in front of the kernels)
+	if(ctx->done_covers_seq == ctx->upload_seq) ctx->arena_upload_pending = false;   // (only an upload that sits in front of the event: one enqueued behind the decode is still on its way)
 	const int32_t *hs = (const int32_t *)ctx->status_host.p;
 	const size_t n = b->blobs.size();
 	for(size_t i = 0; i < n; i++) b->status[i] = b->blobs[i].host_status ? b->blobs[i].host_status : hs[i];
@@ -465,13 +466,14 @@ static int batch_fill(crthip_ctx *ctx, crthip_batch *b, uint32_t nblobs, const u
 		} else {
 		if(ctx->arena_upload_pending) {                                      // (a batch that was created and not decoded yet: its upload has to be through before the image is reused)
 			if(hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
-			ctx->arena_upload_pending = false;
+			ctx->arena_upload_pending = false; ctx->done_covers_seq = ctx->upload_seq;
 		}
 		if(ctx->arena_pin.reserve(off) != CRTHIP_OK) return fail(CRTHIP_E_NOMEM);
 		uint8_t *h = (uint8_t *)ctx->arena_pin.p;
 		for(uint32_t i = 0; i < nblobs; i++) memcpy(h + b->blobs[i].arena_off, blobs[i], lens[i]);
 		if(hipMemcpyAsync(b->own_arena.p, h, off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
 		ctx->arena_upload_pending = true;
+		ctx->upload_seq++;
 		}
 		b->d_arena = (const uint8_t *)b->own_arena.p;
 	}
@@ -916,7 +918,7 @@ int Planner::jobs() {
 			const uint32_t chain0 = unpack_chunks;
 			uint64_t attr_logs = 0;
 			for(const StreamRef &lg : as.logs) attr_logs += lg.size;
-			const bool by_wave = attr_logs <= UNPACK_WAVE_MAX_LOGS && !ctx->dbg.unpack_chunked;   // one wave per stream, no look-back
+			const bool by_wave = attr_logs <= UNPACK_WAVE_MAX_LOGS && as.bits.nwords < (1u << 26) && !ctx->dbg.unpack_chunked;   // one wave per stream, no look-back; its bit cursors are 32-bit (k_stream.hip)
 			const uint32_t attr_first = (uint32_t)pl.unpack.v.size();
 			auto push_unpack = [&](const StreamRef &s, const uint8_t *logs, void *out, bool out_real, uint8_t mode, uint16_t fields, uint16_t stride, uint16_t comp, uint8_t u8) {
 				if(s.size == 0) return;
@@ -1289,6 +1291,7 @@ int Planner::launch() {
 
 	HIP_TRY(hipGetLastError());                                            // (status: written by the kernels straight into the pinned block)
 	HIP_TRY(hipEventRecord(ctx->ev_done, st));
+	ctx->done_covers_seq = ctx->upload_seq;
 
 	return CRTHIP_OK;
 }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 		if((uint32_t)k >= r) break;
 		const bool store = i < J.out_limit;
 		CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + (size_t)i*J.stride;
-		const uint32_t half = d ? (uint32_t)((1ull << d) >> 1) : 0u;
+		const uint32_t half = (1u << (d & 31u)) >> 1;   // upstream's `(1<<diff)>>1` in int (cstream.h:343): 2^(d-1), 0 at d = 0 - and 0 at d = 32, where the compiled reference's shifter takes the count mod 32
 		if(J.fields <= 4 && nwords) {                  // (uniform) every field's words in flight together
 			uint32_t hi[4], lo[4];
 #pragma unroll
@@ -216,7 +216,7 @@ constexpr uint32_t UW_R = 4;                                                // r
 // every window two 64-bit compares, a 64-bit shift and two 64-bit address computations - a third of the kernel's vector instructions, and
 // the pipelined rate is within 2x of the chip's VALU issue rate.
 __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;                                             // (four streams a workgroup, a wave each - 512 workgroups a C4 batch instead of 2 048 - measured level: round 4)
+	if(blockIdx.x >= njobs) return;                                             // (one stream a workgroup of one wave; four streams a workgroup was measured level in round 4)
 	const uint32_t jid = job_ids[blockIdx.x];
 	const UnpackJob J = jobs[jid];
 	const uint32_t lane = threadIdx.x, count = J.count, fields = J.fields;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 	// otherwise clamped loads, and field() masks what bit_field() would not have read
 	auto window = [&](auto INSIDE, uint32_t at, uint32_t &hi, uint32_t &lo) {
 		const uint32_t wi = at >> 5;
-		if constexpr(decltype(INSIDE)::value) hi = words[wi]; else hi = words[min(wi, last_word)];
+		hi = words[min(wi, last_word)];                                         // (a zero-width lane of an exactly full block sits AT nbits: clamp in both modes)
 		lo = words[min(wi + 1u, last_word)];
 	};
 	auto field = [&](auto INSIDE, uint32_t at, uint32_t n, uint32_t hi, uint32_t lo) -> uint32_t {   // = bit_field(words, nwords, at, n); n == 0 -> 0
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 			h = wi < nwords ? hi : 0u; l = (sh + n > 32 && wi + 1 < nwords) ? lo : 0u;
 		}
 		const uint32_t top = sh ? __builtin_amdgcn_alignbit(h, l, 32u - sh) : h;   // the 32 bits from bit `sh` on: a funnel shift, not a 64-bit one (sh = 0: the shift count 32 would wrap to 0 and give l)
-		return (top >> 1) >> (31u - n);                                       // top >> (32 - n) without the shift by 32 at n = 0
+		return (n ? top : 0u) >> ((32u - n) & 31u);                           // top >> (32 - n) with neither the shift by 32 at n = 0 nor the one by -1 at n = 32 (a full word: ADVICE r4)
 	};
 	const bool values = (J.mode & 1u) != 0;
 	const uint32_t stride = J.stride, comp = J.comp, out_limit = J.out_limit;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 			for(uint32_t r = 0; r < UW_R; r++) {
 				const uint32_t i = base + r*64u + lane, dd = d[r];
 				int32_t v = (int32_t)field(INSIDE, at[r], dd, hi[r], lo[r]);
-				const int32_t mid = (int32_t)((1u << dd) >> 1);                  // (dd == 0: v = 0, mid = 0: stays 0)
+				const int32_t mid = (int32_t)(dd ? 1u << (dd - 1u) : 0u);        // (dd == 0: v = 0, mid = 0: stays 0; dd == 32: 2^31, as the chunked kernel and the oracle)
 				v = v < mid ? -v - mid : v;
 				if(i < count && i < out_limit) {
 					if(out_u8) as_global((uint8_t *)J.out)[i*stride + comp] = (uint8_t)v;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 					const uint32_t i = base + (g + k)*64u + lane, dd = d[g + k];
 					const bool store = i < count && i < out_limit;
 					CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + i*stride;
-					const uint32_t half = (1u << dd) >> 1;
+					const uint32_t half = (1u << (dd & 31u)) >> 1;                 // upstream's `(1<<diff)>>1` in int (cstream.h:343): 0 at dd = 32 too (the compiled reference's shift count is mod 32), as k_unpack_extract
 					if(fast) {
 						int32_t v[4];
 #pragma unroll

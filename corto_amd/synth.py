@@ -250,3 +250,285 @@ def point_cloud(nu=578, nv=289, seed=0, color_components=4):
     """Point cloud sampled on the bumpy sphere: nu*nv points, no faces (C3: 578*289 = 167 042)."""
     m = bumpy_sphere(nu, nv - 1, seed, color_components)
     return Mesh(m.position, None, m.normal, m.color, m.uv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Non-lattice connectivity (round 5): what scanned / remeshed / decimated models look like to the CLERS automaton - valence 3..100+,
+# fans, many boundary loops, hundreds of tiny components.  None of these is a quad grid with cut diagonals.
+# ---------------------------------------------------------------------------------------------------------------------------------
+
+def _surface_attrs(pos, seed, color_components):
+    """normals = normalised position (+ a little hash noise), uv = an affine image of x,y, colours = smooth gradients"""
+    p = np.asarray(pos, dtype=np.float64)
+    n = p + 0.05 * (_lcg_fast(seed + 101, p.size).reshape(p.shape) - 0.5)
+    ln = np.sqrt((n * n).sum(-1, keepdims=True))
+    n = n / np.where(ln > 0, ln, 1.0)
+    lo, hi = p.min(0), p.max(0)
+    ext = np.where(hi > lo, hi - lo, 1.0)
+    t = (p - lo) / ext
+    uv = t[:, :2] * 0.999
+    col = np.stack([40 + 170 * t[:, 0], 30 + 190 * t[:, 1], 128 + 100 * n[:, 2], 200 + 40 * n[:, 0]], -1)
+    col = np.clip(np.floor(col), 0, 255).astype(np.uint8)[:, :color_components]
+    return n, uv, col
+
+
+def _canonical_faces(tris):
+    """each triangle rotated so that its smallest vertex id comes first (orientation kept), rows sorted lexicographically:
+    the same array whichever triangulator produced the set"""
+    t = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    k = np.argmin(t, axis=1)
+    r = np.arange(len(t))
+    t = np.stack([t[r, k], t[r, (k + 1) % 3], t[r, (k + 2) % 3]], -1)
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+def _compact(pos, tris):
+    """drop unreferenced vertices, keep the order of the others"""
+    used = np.zeros(len(pos), dtype=bool)
+    used[tris.reshape(-1)] = True
+    remap = np.cumsum(used) - 1
+    return pos[used], remap[tris]
+
+
+def icosphere(level=3, seed=0, color_components=4, noise=0.02):
+    """Subdivided icosahedron: 10*4^level + 2 verts, 20*4^level tris, twelve vertices of valence 5 and the rest 6, no lattice
+    anywhere (level 3: 642 / 1280, level 4: 2562 / 5120).  Closed, genus 0."""
+    g = (1.0 + np.sqrt(5.0)) / 2.0
+    v = np.array([[-1, g, 0], [1, g, 0], [-1, -g, 0], [1, -g, 0], [0, -1, g], [0, 1, g], [0, -1, -g], [0, 1, -g],
+                  [g, 0, -1], [g, 0, 1], [-g, 0, -1], [-g, 0, 1]], dtype=np.float64)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                  [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    for _ in range(level):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        key = np.minimum(e[:, 0], e[:, 1]) * (len(v) + 1) + np.maximum(e[:, 0], e[:, 1])
+        uk, inv = np.unique(key, return_inverse=True)
+        a, b = uk // (len(v) + 1), uk % (len(v) + 1)
+        mid = len(v) + inv.reshape(3, -1).T                     # (nface, 3): midpoints of edges 01, 12, 20
+        v = np.concatenate([v, 0.5 * (v[a] + v[b])])
+        m01, m12, m20 = mid[:, 0], mid[:, 1], mid[:, 2]
+        f = np.concatenate([np.stack([f[:, 0], m01, m20], -1), np.stack([f[:, 1], m12, m01], -1),
+                            np.stack([f[:, 2], m20, m12], -1), np.stack([m01, m12, m20], -1)])
+    v = v / np.sqrt((v * v).sum(-1, keepdims=True))
+    s5, _ = _sincos(5.0 * v[:, 2])
+    _, c7 = _sincos(7.0 * v[:, 0])
+    r = 1.0 + 0.08 * s5 * c7 + noise * (_lcg_fast(seed, len(v)) - 0.5)
+    pos = v * r[:, None]
+    nrm, uv, col = _surface_attrs(pos, seed, color_components)
+    return Mesh(pos, f, nrm, col, uv)
+
+
+def _delaunay_2d(pts):
+    """Delaunay triangles of 2-D points, counter-clockwise, canonical order.  scipy (qhull) when present; else a plain
+    Bowyer-Watson (slow: thousands of points take seconds) - for points in general position both give the same set."""
+    pts = np.asarray(pts, dtype=np.float64)
+    try:
+        from scipy.spatial import Delaunay
+        t = Delaunay(pts).simplices.astype(np.int64)
+    except ImportError:                                          # pragma: no cover  (the image has scipy)
+        t = _bowyer_watson(pts)
+    a, b, c = pts[t[:, 0]], pts[t[:, 1]], pts[t[:, 2]]
+    area2 = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    t = np.where((area2 < 0)[:, None], t[:, [0, 2, 1]], t)
+    return _canonical_faces(t)
+
+
+def _bowyer_watson(pts):
+    n = len(pts)
+    lo, hi = pts.min(0), pts.max(0)
+    c, d = 0.5 * (lo + hi), float((hi - lo).max()) * 20.0 + 1.0
+    P = np.concatenate([pts, [[c[0] - d, c[1] - d], [c[0] + d, c[1] - d], [c[0], c[1] + d]]])
+    tris = {(n, n + 1, n + 2)}
+
+    def circ(t):
+        ax, ay = P[t[0]]; bx, by = P[t[1]]; cx, cy = P[t[2]]
+        dd = 2.0 * (ax * (by - cy) + bx * (cy - ay) + cx * (ay - by))
+        ux = ((ax * ax + ay * ay) * (by - cy) + (bx * bx + by * by) * (cy - ay) + (cx * cx + cy * cy) * (ay - by)) / dd
+        uy = ((ax * ax + ay * ay) * (cx - bx) + (bx * bx + by * by) * (ax - cx) + (cx * cx + cy * cy) * (bx - ax)) / dd
+        return ux, uy, (ax - ux) ** 2 + (ay - uy) ** 2
+    cc = {(n, n + 1, n + 2): circ((n, n + 1, n + 2))}
+    for i in range(n):
+        x, y = P[i]
+        bad = [t for t in tris if (x - cc[t][0]) ** 2 + (y - cc[t][1]) ** 2 < cc[t][2]]
+        edges = {}
+        for t in bad:
+            for e in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                k = (min(e), max(e))
+                edges[k] = None if k in edges else e
+            tris.discard(t); cc.pop(t)
+        for e in edges.values():
+            if e is not None:
+                t = (e[0], e[1], i)
+                tris.add(t); cc[t] = circ(t)
+    return np.array([t for t in tris if max(t) < n], dtype=np.int64).reshape(-1, 3)
+
+
+def delaunay_disc(n=1100, seed=0, holes=6, color_components=4, drop=0.25):
+    """Delaunay triangulation of a jittered point set in a disc, with circular holes punched out: valence 3..10, a boundary ring, one more
+    boundary loop per hole, the odd pinched vertex where two holes nearly touch - connectivity with no lattice structure at all.
+    About n vertices and 1.9 n triangles (n = 2200 -> ~4 100 triangles, the C4 unit's size).  The jitter keeps every pair of points at least
+    a tenth of the grid pitch apart (no zero-area quantised triangle)."""
+    side = int(np.ceil(np.sqrt(n / (0.7854 * (1.0 - drop))))) + 1
+    gx, gy = np.meshgrid(np.arange(side, dtype=np.float64), np.arange(side, dtype=np.float64), indexing="xy")
+    pitch = 2.0 / (side - 1)
+    jit = _lcg_fast(seed * 3 + 1, 2 * side * side).reshape(2, side, side) - 0.5
+    x = -1.0 + (gx + 0.5 * (np.floor(gy) % 2) + 0.8 * jit[0]) * pitch           # staggered rows: no square cells to begin with
+    y = -1.0 + (gy + 0.8 * jit[1]) * pitch
+    keep = (_lcg_fast(seed * 3 + 2, side * side).reshape(side, side) >= drop) & (x * x + y * y < (1.0 - 1.2 * pitch) ** 2)
+    nb = max(12, int(3.2 / pitch))
+    sb, cb = _sincos(np.arange(nb, dtype=np.float64) * (_TWO_PI / nb))
+    pts = np.concatenate([np.stack([x[keep], y[keep]], -1), np.stack([cb, sb], -1)])
+    tris = _delaunay_2d(pts)
+    if holes:
+        h = _lcg_fast(seed * 3 + 3, 3 * holes).reshape(holes, 3)
+        hc = (h[:, :2] - 0.5) * 1.5
+        hr = 0.06 + 0.16 * h[:, 2]
+        cen = pts[tris].mean(1)
+        inside = (((cen[:, None, :] - hc[None]) ** 2).sum(-1) < (hr * hr)[None]).any(1)
+        tris = tris[~inside]
+    s3, _ = _sincos(3.0 * pts[:, 0])
+    _, c2 = _sincos(2.5 * pts[:, 1])
+    z = 0.25 * s3 * c2 + 0.3 * (1.0 - pts[:, 0] ** 2 - pts[:, 1] ** 2)
+    pos, tris = _compact(np.concatenate([pts, z[:, None]], 1), tris)
+    nrm, uv, col = _surface_attrs(pos + [0, 0, 1.0], seed, color_components)
+    return Mesh(pos, tris, nrm, col, uv)
+
+
+def cone_fan(k=96, rings=3, seed=0, color_components=4, closed=True, flip=0.3):
+    """A cone: an apex of valence k (>= 64 asks more of the automaton's chain ends and of K-NRM's incidence lists than any grid), `rings`
+    rings of k vertices under it with randomly flipped diagonals, and (closed) a second valence-k fan at the base."""
+    sa, ca_ = _sincos(np.arange(k, dtype=np.float64) * (_TWO_PI / k))
+    P = [[0.0, 0.0, 1.0]]
+    for r in range(1, rings + 1):
+        rad = r / rings + 0.1 * (_lcg_fast(seed + r, k) - 0.5) / rings
+        P += np.stack([rad * ca_, rad * sa, np.full(k, 1.0 - r / rings) + 0.05 * (_lcg_fast(seed + 50 + r, k) - 0.5)], -1).tolist()
+    ar = np.arange(k)
+    T = [np.stack([np.zeros(k, dtype=np.int64), 1 + ar, 1 + (ar + 1) % k], -1)]
+    for r in range(rings - 1):
+        a, b = 1 + r * k + ar, 1 + r * k + (ar + 1) % k
+        d, c = a + k, b + k
+        f = (_lcg_fast(seed * 31 + r, k) < flip)[:, None]
+        T.append(np.where(f, np.stack([a, d, b], -1), np.stack([a, d, c], -1)))
+        T.append(np.where(f, np.stack([b, d, c], -1), np.stack([a, c, b], -1)))
+    if closed:
+        base = len(P)
+        P.append([0.0, 0.0, -0.3])
+        a, b = 1 + (rings - 1) * k + ar, 1 + (rings - 1) * k + (ar + 1) % k
+        T.append(np.stack([np.full(k, base), b, a], -1))
+    pos = np.array(P, dtype=np.float64)
+    nrm, uv, col = _surface_attrs(pos, seed, color_components)
+    return Mesh(pos, np.concatenate(T), nrm, col, uv)
+
+
+def decimated(mesh: Mesh, keep=0.5, seed=0, max_valence=24):
+    """Random half-edge collapses (link condition: the edge's end points share exactly their two opposite vertices) until `keep` of
+    the vertices are left: valences spread to 3..max_valence the way a decimated scan's do.  Input must be a closed manifold."""
+    faces = [list(map(int, f)) for f in mesh.index]
+    nv = mesh.nvert
+    vf = [set() for _ in range(nv)]
+    for i, f in enumerate(faces):
+        for v in f:
+            vf[v].add(i)
+    alive = np.ones(nv, dtype=bool)
+    dead_face = set()
+
+    def ring(v):
+        s = set()
+        for i in vf[v]:
+            s.update(faces[i])
+        s.discard(v)
+        return s
+    target = max(4, int(nv * keep))
+    left = nv
+    order = np.argsort(_lcg_fast(seed + 17, nv * 8), kind="stable")
+    for t in order:
+        if left <= target:
+            break
+        v = int(t % nv)
+        if not alive[v] or not vf[v]:
+            continue
+        rv = ring(v)
+        cand = sorted(rv)
+        u = cand[int(t // nv) % len(cand)]
+        ru = ring(u)
+        shared = rv & ru
+        if len(shared) != 2 or len(ru) + len(rv) - 4 > max_valence or len(rv) <= 3 or len(ru) <= 3:
+            continue
+        if any(len(ring(s)) <= 3 for s in shared):            # the opposite vertices lose one neighbour each: keep valence >= 3
+            continue
+        for i in list(vf[v]):                                     # v -> u
+            f = faces[i]
+            if u in f:
+                dead_face.add(i)
+                for w in f:
+                    vf[w].discard(i)
+            else:
+                f[f.index(v)] = u
+                vf[u].add(i)
+        vf[v] = set()
+        alive[v] = False
+        left -= 1
+    tris = np.array([f for i, f in enumerate(faces) if i not in dead_face], dtype=np.int64).reshape(-1, 3)
+    pos, tris = _compact(mesh.position.astype(np.float64), tris)
+    sel = alive
+    nrm = None if mesh.normal is None else mesh.normal[sel]
+    col = None if mesh.color is None else mesh.color[sel]
+    uv = None if mesh.uv is None else mesh.uv[sel]
+    assert len(pos) == int(sel.sum())
+    return Mesh(pos, tris, nrm, col, uv)
+
+
+def confetti(ncomp=240, seed=0, color_components=4, max_faces=12):
+    """Hundreds of tiny components of 1..max_faces faces each (open fans, closed fans, strips, tetrahedra, octahedra) scattered over a
+    plane: every component costs the automaton a seed face and its chain ends, and the front never grows past a dozen edges."""
+    side = int(np.ceil(np.sqrt(ncomp)))
+    kind = (_lcg_fast(seed + 1, ncomp) * 5).astype(np.int64)
+    size = 1 + (_lcg_fast(seed + 2, ncomp) * max_faces).astype(np.int64)
+    jit = _lcg_fast(seed + 3, ncomp * 64).reshape(ncomp, 64) - 0.5
+    P, T, off = [], [], 0
+    for c in range(ncomp):
+        cx, cy = float(c % side), float(c // side)
+        f = int(min(size[c], max_faces))
+        k = int(kind[c])
+        if k == 3 and f < 4:
+            k = 0
+        if k == 4 and f < 8:
+            k = 1
+        if k == 2 and f < 3:
+            k = 0
+        if k == 0:                                   # open fan: centre + f+1 rim points over 300 degrees
+            s, co = _sincos(np.arange(f + 1, dtype=np.float64) * (5.2 / max(f, 1)))
+            p = np.concatenate([[[0, 0, 0.1]], np.stack([co, s, np.zeros(f + 1)], -1)])
+            t = np.stack([np.zeros(f, dtype=np.int64), 1 + np.arange(f), 2 + np.arange(f)], -1)
+        elif k == 1:                                 # strip of f triangles
+            i = np.arange(f + 2, dtype=np.float64)
+            p = np.stack([np.floor(i / 2) * (2.0 / max(f // 2 + 1, 1)) - 1.0, (i % 2) * 0.8 - 0.4, 0.05 * (i % 3)], -1)
+            a = np.arange(f)
+            t = np.where((a % 2 == 0)[:, None], np.stack([a, a + 1, a + 2], -1), np.stack([a + 1, a, a + 2], -1))
+        elif k == 2:                                 # closed fan (a disc): hub of valence f
+            s, co = _sincos(np.arange(f, dtype=np.float64) * (_TWO_PI / f))
+            p = np.concatenate([[[0, 0, 0.2]], np.stack([co, s, np.zeros(f)], -1)])
+            a = np.arange(f)
+            t = np.stack([np.zeros(f, dtype=np.int64), 1 + a, 1 + (a + 1) % f], -1)
+        elif k == 3:                                 # tetrahedron (closed, 4 faces)
+            p = np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], dtype=np.float64) * 0.6
+            t = np.array([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]], dtype=np.int64)
+        else:                                        # octahedron (closed, 8 faces)
+            p = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float64) * 0.8
+            t = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], dtype=np.int64)
+        p = p * 0.4 + 0.06 * jit[c, :p.size].reshape(p.shape) + [cx, cy, 0.0]
+        P.append(p); T.append(t + off); off += len(p)
+    pos = np.concatenate(P)
+    nrm, uv, col = _surface_attrs(pos + [0, 0, 5.0], seed, color_components)
+    return Mesh(pos, np.concatenate(T), nrm, col, uv)
+
+
+def full_width_values(mesh: Mesh, seed=0):
+    """Positions and uvs whose quantised values (q = 1) alternate around +-2^30: neighbour differences need all 32 bits of a bit
+    field (upstream's needed() returns 32 for |v| >= 2^30, cstream.h:105-112) - the edge of the bit reader and of `(1<<diff)>>1`."""
+    with np.errstate(over="ignore"):
+        h = _lcg_fast(seed + 5, mesh.nvert * 10).reshape(mesh.nvert, 10)
+    sign = np.where(h[:, :5] < 0.5, -1.0, 1.0)
+    mesh.position = np.ascontiguousarray((sign[:, :3] * (2.0 ** 30 + np.floor(h[:, 5:8] * 2.0 ** 20))).astype(np.float32))
+    if mesh.uv is not None:
+        mesh.uv = np.ascontiguousarray((sign[:, 3:5] * 2.0 ** 18 * (1.0 + np.floor(h[:, 8:10] * 4095.0))).astype(np.float32))
+    return mesh

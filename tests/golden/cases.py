@@ -29,6 +29,15 @@ def cases():
         ("closed_sphere", S.closed_sphere(32, 16, seed=6), dict(normal_prediction=DIFF)),
         ("radius_attr", radius, dict(normal_prediction=BORDER, exif={"mtllib": "a.mtl", "note": "x"})),
         ("entropy_none", S.bumpy_sphere(32, 16, seed=9), dict(normal_prediction=BORDER, entropy=0)),
+        # non-lattice connectivity (round 5): valence 5/6 without a grid, Delaunay with holes, a valence-96 apex, a decimated sphere, confetti
+        ("icosphere", S.icosphere(3, seed=31), dict(normal_prediction=BORDER)),
+        ("delaunay_holes", S.delaunay_disc(1100, seed=32, holes=7), dict(normal_prediction=BORDER)),
+        ("delaunay_shuffled", S.shuffled(S.delaunay_disc(500, seed=33, holes=4, color_components=3), seed=5), dict(normal_prediction=ESTIMATED, position_bits=12)),
+        ("cone_fan", S.cone_fan(96, 3, seed=34), dict(normal_prediction=ESTIMATED)),
+        ("decimated", S.decimated(S.icosphere(3, seed=35), keep=0.45, seed=35), dict(normal_prediction=DIFF)),
+        ("confetti", S.confetti(240, seed=36), dict(normal_prediction=BORDER)),
+        # bit fields of the full 32 bits (|values| >= 2^30), correlated (position) and per component (uv)
+        ("fields32", S.full_width_values(S.bumpy_sphere(9, 7, seed=37), seed=37), dict(normal_prediction=DIFF, position_bits=0, position_q=1.0, uv_bits=0)),
         ("cloud_diff", S.point_cloud(96, 64, seed=7), dict(normal_prediction=DIFF)),
         ("cloud_border", S.point_cloud(40, 20, seed=8), dict(normal_prediction=BORDER)),
     ]

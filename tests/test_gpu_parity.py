@@ -337,16 +337,21 @@ def test_small_closed_meshes_whose_runs_reach_the_current_edge(ctx):
     c.close()
 
 
-def test_random_mesh_stress_run(ctx):
-    """tools/stress_topology.py as a test: eight rounds of 24 random meshes of every synthetic family (sizes, flip rates, hole fractions, random
-    group cuts, shuffles, merges; seed 5: the run that caught round 4's lead-lane bug with everything else green), byte for byte against the
-    oracle, u16 and u32 indices, twice (the second pass with the slots the first one taught the context)"""
+@pytest.mark.parametrize("seed", [5, 11, 23])
+def test_random_mesh_stress_run(ctx, seed):
+    """tools/stress_topology.py as a test: 21 rounds of 24 random meshes (1 008 decodes a seed) of every synthetic family - the lattices
+    (sizes, flip rates, hole fractions, random group cuts, shuffles, merges; seed 5: the run that caught round 4's lead-lane bug with
+    everything else green) and round 5's non-lattice ones (icospheres, Delaunay discs with holes, cones with an apex of valence up to 260,
+    decimated spheres, confetti of 1..12-face components, shuffled merges of them) - byte for byte against the oracle, u16 and u32 indices,
+    twice (the second pass with the slots the first one taught the context)"""
     import subprocess, sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([_sys.executable, os.path.join(root, "tools", "stress_topology.py"), "8", "5"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([_sys.executable, os.path.join(root, "tools", "stress_topology.py"), "21", str(seed)], capture_output=True, text=True, timeout=900)
     tail = [l for l in out.stdout.splitlines() if l.startswith("decodes")]
     assert out.returncode == 0 and tail, out.stdout[-2000:] + out.stderr[-2000:]
     assert " mismatching arrays 0 " in tail[-1], "\n".join(l for l in out.stdout.splitlines() if "MISMATCH" in l)[:4000]
+    assert int(tail[-1].split()[1]) >= 1000, tail[-1]
+    assert "persistent fallback" not in out.stdout, "\n".join(l for l in out.stdout.splitlines() if "persistent" in l)[:4000]
 
 
 def test_device_sqrtf_is_the_reference_norm_for_every_float(tmp_path):

@@ -23,6 +23,13 @@ def corpus():
         out.append(("disc%d" % seed, S.shuffled(S.holey_disc(6 + 6 * seed, seed, hole_frac=0.05 + 0.05 * seed), seed), {}))
         out.append(("torus%d" % seed, S.torus(6 + 5 * seed, 4 + 3 * seed, seed), {}))
         out.append(("closed%d" % seed, S.closed_sphere(5 + 4 * seed, 3 + 3 * seed, seed), {}))
+        # non-lattice connectivity (round 5)
+        out.append(("ico%d" % seed, S.icosphere(seed % 4, seed), {}))
+        out.append(("delaunay%d" % seed, S.delaunay_disc(60 + 350 * seed, seed, holes=2 * seed), {}))
+        out.append(("cone%d" % seed, S.cone_fan(7 + 40 * seed, 1 + seed % 4, seed, closed=bool(seed & 1)), {}))
+        out.append(("decimated%d" % seed, S.decimated(S.icosphere(1 + seed % 3, seed), keep=0.3 + 0.1 * seed, seed=seed), {}))
+        out.append(("confetti%d" % seed, S.shuffled(S.confetti(20 + 60 * seed, seed), seed), {}))
+    out.append(("fields32", S.full_width_values(S.bumpy_sphere(12, 9, 3), 3), dict(position_q=1.0, uv_bits=0)))
     out.append(("merge", S.merge([S.closed_sphere(9, 5, 1), S.closed_sphere(7, 4, 2), S.torus(8, 5, 3), S.holey_disc(9, 4, color_components=4)]), {}))
     return out
 
@@ -32,7 +39,7 @@ def test_meshes_all_normal_modes(pred):
     for name, m, kw in corpus():
         cc = m.color.shape[1]
         for bits in (10, 14, 18):
-            blob = rc.encode(m, position_bits=bits, normal_prediction=pred, **kw)
+            blob = rc.encode(m, position_bits=0 if "position_q" in kw else bits, normal_prediction=pred, **kw)
             r = rc.decode_trace(blob, color_components=cc)
             o = oc.decode(blob, color_components=cc, trace=True)
             assert same(r, o) == [], (name, bits)

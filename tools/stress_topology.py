@@ -17,7 +17,7 @@ fallbacks = []
 for rd in range(rounds):
     meshes = []; kinds = []
     for _ in range(24):
-        k = int(rng.integers(0, 8)); s = int(rng.integers(0, 1 << 30))
+        k = int(rng.integers(0, 15)); s = int(rng.integers(0, 1 << 30))
         if k == 0: m = synth.bumpy_sphere(int(rng.integers(8, 90)), int(rng.integers(4, 45)), seed=s)
         elif k == 1: m = synth.bumpy_sphere_flipped(int(rng.integers(8, 90)), int(rng.integers(4, 45)), seed=s, flip=float(rng.choice([0.01, 0.05, 0.2, 0.5, 0.9, 1.0])))
         elif k == 2: m = synth.holey_disc(int(rng.integers(8, 48)), seed=s, hole_frac=float(rng.uniform(0.02, 0.3)))
@@ -25,7 +25,16 @@ for rd in range(rounds):
         elif k == 4: m = synth.strip(int(rng.integers(10, 500)), seed=s)
         elif k == 5: m = synth.closed_sphere(int(rng.integers(6, 40)), int(rng.integers(4, 20)), seed=s)
         elif k == 6: m = synth.shuffled(synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=s, flip=0.3))
-        else: m = synth.merge([synth.bumpy_sphere(int(rng.integers(6, 24)), int(rng.integers(4, 12)), seed=s), synth.holey_disc(int(rng.integers(8, 20)), seed=s + 1, color_components=4), synth.torus(12, 6, seed=s + 2)])
+        elif k == 7: m = synth.merge([synth.bumpy_sphere(int(rng.integers(6, 24)), int(rng.integers(4, 12)), seed=s), synth.holey_disc(int(rng.integers(8, 20)), seed=s + 1, color_components=4), synth.torus(12, 6, seed=s + 2)])
+        # non-lattice connectivity (round 5): icosphere, Delaunay with holes, high-valence cones, decimated spheres, confetti - plain, shuffled and merged
+        elif k == 8: m = synth.icosphere(int(rng.integers(0, 4)), seed=s)
+        elif k == 9: m = synth.delaunay_disc(int(rng.integers(30, 2400)), seed=s, holes=int(rng.integers(0, 14)), drop=float(rng.uniform(0.0, 0.5)))
+        elif k == 10: m = synth.cone_fan(int(rng.integers(5, 260)), int(rng.integers(1, 6)), seed=s, closed=bool(rng.integers(0, 2)), flip=float(rng.uniform(0, 1)))
+        elif k == 11: m = synth.decimated(synth.icosphere(int(rng.integers(1, 4)), seed=s), keep=float(rng.uniform(0.15, 0.9)), seed=s, max_valence=int(rng.integers(8, 40)))
+        elif k == 12: m = synth.confetti(int(rng.integers(10, 420)), seed=s, max_faces=int(rng.integers(1, 13)))
+        elif k == 13: m = synth.shuffled(synth.delaunay_disc(int(rng.integers(30, 900)), seed=s, holes=int(rng.integers(0, 9))), seed=s, faces=bool(rng.integers(0, 2)), verts=bool(rng.integers(0, 2)))
+        else: m = synth.shuffled(synth.merge([synth.decimated(synth.icosphere(2, seed=s), keep=0.5, seed=s), synth.confetti(int(rng.integers(5, 60)), seed=s + 1), synth.cone_fan(int(rng.integers(64, 130)), 2, seed=s + 2),
+                                              synth.delaunay_disc(int(rng.integers(40, 300)), seed=s + 3, holes=3)]), seed=s)
         if rng.random() < 0.3 and m.nface > 8:           # several groups (each starts from an empty front): random cuts
             cuts = sorted(set(int(c) for c in rng.integers(1, m.nface, int(rng.integers(1, 4)))))
             m.groups = cuts + [m.nface]
@@ -37,11 +46,13 @@ for rd in range(rounds):
     blobs = [ca.aligned_blob(ca.encode(m, position_bits=int(rng.integers(10, 18)), uv_bits=12, normal_bits=10,
                                        normal_prediction=[ca.BORDER, ca.ESTIMATED, ca.DIFF][i % 3])) for i, m in enumerate(meshes)]
     u16 = bool(rd & 1)
+    refs = [oc.decode(blob, index16=u16, color_components=4) for blob in blobs]
     for attempt in range(2):                        # the second pass runs with the slots the first one taught the context
         b = ca.Batch(ctx, blobs); b.allocate_outputs(fill=0, index16=u16, color_components=4); b.decode()
         st = b.sync()
+        assert (np.asarray(st) == 0).all(), ("status", rd, st)
         for i, blob in enumerate(blobs):
-            r = oc.decode(blob, index16=u16, color_components=4)
+            r = refs[i]
             got = b.host_outputs(i)
             for key in KEYS:
                 if key in r and got[key].tobytes() != r[key].tobytes():
