@@ -716,29 +716,37 @@ def main():
         pool_i.close()
         # `realistic`: everything the headline's best case leaves out, at once - irregular connectivity, one dictionary PER STREAM (no two
         # blobs of unrelated meshes share tables), and the compressed blobs uploaded from host memory inside every step (SURVEY 8d's primary region)
+        # Round 5: the meshes of this leg are DELAUNAY discs with holes (synth.delaunay_disc: no lattice anywhere, valence 1-11, a rim and 6-10 more boundary
+        # loops a blob, ~3 900 triangles - the C4 unit's size); rounds 2-4 ran it on grids with flipped diagonals (still `irregular_connectivity` above)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+            rblobs = list(ex.map(lambda sd: ca.encode(synth.delaunay_disc(2310, seed=sd, holes=6 + sd % 5), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER), range(NBLOBS)))
+        pin_r, rviews = ca.pinned_host_arena(rblobs)
         os.environ["CORTO_TUN_SHARE"] = "2"
         pool_r = ca.Pool(devices[:1], threads=nthreads, depth=depth)
         del os.environ["CORTO_TUN_SHARE"]
-        pool_r.run([iblobs], steps=4 * pool_r.lanes, warmup=0, arenas=None)
+        pool_r.run([rblobs], steps=4 * pool_r.lanes, warmup=0, arenas=None)
         r_steps = max(fh_steps // nloc, 200)
-        rep_r, st_r = pool_r.run([iblobs], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
+        rep_r, st_r = pool_r.run([rblobs], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
         assert rep_r.poisoned_lanes == pool_r.lanes
         for lane in range(1, pool_r.lanes, 4):
-            i = 5 * lane + 2
-            ref = oc.decode(iblobs[i])
-            for k, (dt, w) in dts.items():
-                got = pool_r.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
-                assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (realistic)", lane, i, k)
+            for i in (5 * lane + 2, NBLOBS - 1 - lane):
+                ref = oc.decode(ca.aligned_blob(rblobs[i]))
+                for k, (dt, w) in dts.items():
+                    got = pool_r.lane_read(lane, i, k, dt, (ref["nface"] if k == "index" else ref["nvert"]) * w)
+                    assert got.tobytes() == ref[k].tobytes(), ("bit-exact check failed (realistic)", lane, i, k)
         pool_r.set_packed_host_blobs(True)
-        rep_rp, _ = pool_r.run([iviews], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
+        rep_rp, _ = pool_r.run([rviews], steps=r_steps, warmup=2 * pool_r.lanes, arenas=None)
         pool_r.set_packed_host_blobs(False)
         realistic = {"mtri_per_s": round(rep_r.triangles / rep_r.elapsed_s / 1e6, 2), "mverts_per_s": round(rep_r.vertices / rep_r.elapsed_s / 1e6, 2),
                      "ms_per_step": round(rep_r.elapsed_s / r_steps * 1e3, 4), "steps": r_steps,
+                     "triangles_per_step": int(sum(ca.probe(x).nface for x in rblobs)), "vertices_per_step": int(sum(ca.probe(x).nvert for x in rblobs)),
                      "topology_fallbacks": int(rep_r.topology_fallbacks), "failed_blobs": int(rep_r.failed_blobs), **window_stats(st_r, pool_r.lanes),
-                     "h2d_bytes_per_step": int(sum(((len(x) + 15) & ~15) for x in iblobs)),
+                     "h2d_bytes_per_step": int(sum(((len(x) + 15) & ~15) for x in rblobs)),
                      "packed_pinned_mtri_per_s": round(rep_rp.triangles / rep_rp.elapsed_s / 1e6, 2) if not rep_rp.failed_blobs else None,
-                     "note": "one GPU; irregular connectivity (bumpy_sphere_flipped) + $CORTO_TUN_SHARE=2 (one dictionary per stream) + compressed blobs scattered over pageable HOST memory, gathered and uploaded "
-                             "over PCIe inside every step (packed_pinned_mtri_per_s: from one pinned buffer, the region of `value`); outputs poisoned before the last round, bit-exact spot check against the oracle.  The number to expect from unrelated scanned meshes; `value` is the best case"}
+                     "note": "one GPU; 256 Delaunay discs with 6-10 holes each (synth.delaunay_disc(2310, seed, holes): no lattice, valence 1-11, 7-11 boundary loops a blob) + $CORTO_TUN_SHARE=2 (one dictionary "
+                             "per stream) + compressed blobs scattered over pageable HOST memory, gathered and uploaded over PCIe inside every step (packed_pinned_mtri_per_s: from one pinned buffer, the region "
+                             "of `value`); outputs poisoned before the last round, bit-exact spot check against the oracle.  The number to expect from unrelated scanned meshes; `value` is the best case"}
         pool_r.close()
 
     # SURVEY 8e's scaling report when N > 1: per-GPU rate, what ONE of the GPUs does alone on the same box right now (same pool shape, the

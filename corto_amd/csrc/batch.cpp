@@ -876,7 +876,7 @@ int Planner::jobs() {
 				uint32_t ring, pool, symwin;
 				uint32_t scale = ctx->topo_scale, need;
 				for(;;) {                                                                // as much of the context's scale as fits a CU
-					topo_lds_geometry(nface, L.clers.size, 4096, scale, nblobs >= 32 ? 4u : 8u, ring, pool, symwin);
+					topo_lds_geometry(nface, L.clers.size, 4096, scale, nblobs >= 32 ? 4u : 8u, topo_boundary_estimate(nvert, nface), ring, pool, symwin);
 					need = topo_lds_bytes(ring, pool, pool, symwin);                     // every delayed edge is a pool record: same capacity
 #ifdef CORTO_TOPO_STAMPS
 					if(need <= 32768 && L.clers.size < 8190) need = 65536;              // (the dispatch trace: k_mesh.hip TOPO_ASM_STAMP)

@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256) void k_enc_pack(const PackJob *__restrict__ jo
 				if(x != 0) {
 					const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
 					w = 32u - (uint32_t)__clz((int)ax);                     // ilog2(abs) + 1
-					const uint32_t middle = (1u << w) >> 1;
+					// upstream: `int middle = (1<<ret)>>1` (cstream.h:133) - in int, so at ret = 31 (|x| >= 2^30) it is (INT_MIN >> 1) = -2^30, not 2^30, and the
+					// folded value carries a bit above its field, which BitStream::write ORs onto the bit in front of it (enc_put_bits does the same: the
+					// shifts below keep that bit unless the field starts a word, where upstream loses it too) - fixture fields32
+					const uint32_t middle = (uint32_t)((int32_t)(1u << (w & 31u)) >> 1);
 					val = x < 0 ? ax - middle : (uint32_t)x;
 				}
 				nb = w;

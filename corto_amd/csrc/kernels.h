@@ -52,10 +52,16 @@ constexpr uint32_t TOPO_SYMWIN_MAX = 8192;
 // and that it is NOT MORE THAN THE 16 KB of a K-STREAM wave matters more than the size itself: the automaton's workgroups are dispatched
 // while the attribute streams' 2 000 waves fill every CU ten to a CU, and a 16 KB hole opens whenever one of those ends - a 22 KB
 // request waits for two neighbouring ones (0.237 -> 0.200 ms per C4 batch unpipelined, +5 % pipelined).
-inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t slots, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
+// Round 5: the pool keeps every edge of the mesh's own boundary for good, and how many those are is in the header: a manifold mesh has
+// B = 2V - F - 2*chi boundary edges (Euler: V - E + F = chi, 2E = 3F + B), so 2V - F (+ slack for handles and the DELAYed edges in flight)
+// bounds what the pool must hold - 128 for the C4 unit, ~V for a ribbon or for confetti of one-face components, which no multiple of
+// sqrt(nface) covers (tools/stress_topology.py: strips, confetti and holey discs fell back on EVERY decode, whatever the context had learnt).
+inline uint32_t topo_boundary_estimate(uint32_t nvert, uint32_t nface) { const uint64_t v2 = 2ull*nvert; return v2 <= nface ? 0u : v2 - nface > (1u << 20) ? (1u << 20) : (uint32_t)(v2 - nface); }
+inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t slots, uint32_t boundary, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
 	uint32_t want = 256;
 	while((uint64_t)want*want < (uint64_t)slots*slots*nface && want < ring_max) want <<= 1;
 	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }
+	while(want < boundary + boundary/8 + 48 && want < ring_max) want <<= 1;      // (pool = ring in the ISA block: both grow)
 	ring = want; pool = want;
 	const uint32_t all = (nclers + 64 + 31) & ~31u;       // whole 16-byte vectors of nibbles (k_mesh.hip: TOPO_FILL_WINDOW)
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;

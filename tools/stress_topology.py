@@ -60,11 +60,17 @@ for rd in range(rounds):
             total += 1
         fallbacks.append(int(b.stats().topology_fallbacks))
         b.close()
-        if attempt == 1 and fallbacks[-1]:             # who still falls back with the slots learnt: each blob alone, twice
+        if attempt == 1 and fallbacks[-1]:             # who still falls back with the slots learnt: each blob alone on a fresh context, three times (scale 1, 4, 16)
             for i, blob in enumerate(blobs):
                 c1 = ca.Context(0); n = []
-                for _ in range(2):
+                for _ in range(3):
                     b1 = ca.Batch(c1, [blob]); b1.allocate_outputs(fill=0); b1.decode(); b1.sync(); n.append(int(b1.stats().topology_fallbacks)); b1.close()
                 c1.close()
-                if n[1]: print("  persistent fallback: round", rd, "blob", i, kinds[i], "nface", meshes[i].nface, "nvert", meshes[i].nvert, n)
+                if n[2]:
+                    # a front of more than 4 096 + 4 096 records has no LDS form - the HBM front is its path by design: every BOUNDARY edge
+                    # stays in the pool for good, every DELAYed one until it is popped, and the queue of a mesh with handles is ten times a sphere's
+                    cl = oc.decode(blob, trace=True)["_clers"]
+                    nb, nd = int((cl == 4).sum()), int((cl == 5).sum())
+                    big = nb + nd > 3600 or meshes[i].nface > 60000
+                    print("  fallback by capacity:" if big else "  persistent fallback:", "round", rd, "blob", i, "kind", kinds[i], "nface", meshes[i].nface, "nvert", meshes[i].nvert, "BOUNDARY", nb, "DELAY", nd, n)
 print("decodes", total, "mismatching arrays", bad, "fallbacks per batch (first pass, second pass ...)", fallbacks)

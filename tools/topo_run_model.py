@@ -43,6 +43,7 @@ class Model:
             end = ge * 3
             nq = qpos = 0; mbump = self.RING; free = []; delayed = []
             while start < end:
+                self.stats['peak_ring'] = max(self.stats.get('peak_ring', 0), nq - qpos); self.stats['peak_pool'] = max(self.stats.get('peak_pool', 0), mbump - self.RING); self.stats['peak_delayed'] = max(self.stats.get('peak_delayed', 0), len(delayed))
                 # fetch next edge
                 if qpos != nq:
                     t = rec[qpos & MASK]; qpos += 1
@@ -324,13 +325,19 @@ def wide(n=400, seed=7):
     rng = np.random.default_rng(seed)
     bad = 0; tot = {}
     for k in range(n):
-        f = k % 6
+        f = k % 11
         if f == 0: m = synth.closed_sphere(int(rng.integers(6, 40)), int(rng.integers(4, 20)), seed=k)
         elif f == 1: m = synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=k, flip=float(rng.choice([0.05, 0.2, 0.5, 0.9])))
         elif f == 2: m = synth.torus(int(rng.integers(6, 30)), int(rng.integers(4, 14)), seed=k)
         elif f == 3: m = synth.holey_disc(int(rng.integers(8, 30)), seed=k, hole_frac=float(rng.uniform(0.02, 0.3)))
         elif f == 4: m = synth.shuffled(synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=k, flip=0.3))
-        else: m = synth.bumpy_sphere(int(rng.integers(8, 60)), int(rng.integers(4, 30)), seed=k)
+        elif f == 5: m = synth.bumpy_sphere(int(rng.integers(8, 60)), int(rng.integers(4, 30)), seed=k)
+        # non-lattice connectivity (round 5)
+        elif f == 6: m = synth.icosphere(int(rng.integers(0, 4)), seed=k)
+        elif f == 7: m = synth.delaunay_disc(int(rng.integers(30, 1200)), seed=k, holes=int(rng.integers(0, 10)))
+        elif f == 8: m = synth.cone_fan(int(rng.integers(5, 200)), int(rng.integers(1, 5)), seed=k, closed=bool(k & 2), flip=float(rng.uniform(0, 1)))
+        elif f == 9: m = synth.decimated(synth.icosphere(int(rng.integers(1, 4)), seed=k), keep=float(rng.uniform(0.2, 0.9)), seed=k)
+        else: m = synth.shuffled(synth.confetti(int(rng.integers(10, 200)), seed=k), seed=k)
         if k % 2 and m.nface > 24: m.groups = [m.nface // 3, m.nface // 2 + 1, m.nface]
         blob = ca.aligned_blob(ca.encode(m)); r = oc.decode(blob, trace=True)
         mm = Model(r["_clers"], r["nvert"], r["nface"], ca.probe_groups(blob), ref_faces=r["index"])
