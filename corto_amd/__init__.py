@@ -163,6 +163,7 @@ def lib():
         L.crthip_pool_warning.argtypes = [C.c_void_p]
         L.crthip_pool_set_packed_host_blobs.argtypes = [C.c_void_p, C.c_int]
         L.crthip_ctx_set_packed_host_blobs.argtypes = [C.c_void_p, C.c_int]
+        L.crthip_pool_set_outputs_to_host.argtypes = [C.c_void_p, C.c_int]
         L.crthip_pool_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(PoolReport), C.c_void_p]
         L.crthip_pool_lane_item.restype = C.c_int64
         L.crthip_pool_lane_item.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -557,6 +558,11 @@ class Pool:
     def set_packed_host_blobs(self, on: bool = True):
         """items run without device arenas whose blobs are views of ONE pinned host buffer (pinned_host_arena) go up straight from it"""
         _check(lib().crthip_pool_set_packed_host_blobs(self.handle, int(on)))
+
+    def set_outputs_to_host(self, on: bool = True):
+        """every step ends with a D2H copy of its outputs into the lane's pinned host block (SURVEY 8d's secondary region); lane_read then
+        returns what that copy delivered"""
+        _check(lib().crthip_pool_set_outputs_to_host(self.handle, int(on)))
 
     def run(self, items, steps: int, warmup: int = 0, arenas=None):
         """items: list of batches (each a list of aligned uint8 blobs).  arenas: None (every step uploads its blobs) or, per item, a

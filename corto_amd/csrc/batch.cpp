@@ -333,6 +333,15 @@ int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value) {      /
 	hipLaunchKernelGGL(k_fill_block, dim3(2048), dim3(256), 0, ctx->stream, (uint8_t *)dst, (uint64_t)bytes, (uint32_t)(value & 255));
 	return hipGetLastError() == hipSuccess ? CRTHIP_OK : fail(CRTHIP_E_DEVICE);
 }
+// SURVEY 8d's secondary region: a decode's outputs copied to (pinned) host memory behind its kernels, on the context's main stream; what
+// crthip_batch_sync / crthip_batch_done wait for moves behind the copy
+int ctx_copy_to_host_async(crthip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+	if(!bytes) return CRTHIP_OK;
+	if(hipSetDevice(ctx->device) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+	if(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+	if(hipEventRecord(ctx->ev_done, ctx->stream) != hipSuccess) return fail(CRTHIP_E_DEVICE);
+	return CRTHIP_OK;
+}
 int ctx_quiesce(crthip_ctx *ctx) {
 	if(harvest(ctx) != CRTHIP_OK) return fail(CRTHIP_E_DEVICE);
 	ctx->last_decoded = nullptr;                         // the encoder stages reuse the scratch block

@@ -54,5 +54,6 @@ int ctx_device(crthip_ctx *ctx);
 hipStream_t ctx_stream(crthip_ctx *ctx);
 int ctx_quiesce(crthip_ctx *ctx);       // wait for whatever batch is in flight on the context
 int ctx_fill_async(crthip_ctx *ctx, void *dst, size_t bytes, int value);   // k_fill_block on the context's main stream
+int ctx_copy_to_host_async(crthip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);   // D2H behind the decode in flight; sync / done then cover the copy
 
 } // namespace corto_hip

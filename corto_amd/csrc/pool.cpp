@@ -31,6 +31,7 @@ struct Lane {                       // one context = one batch in flight
 	crthip_ctx *ctx = nullptr;
 	crthip_batch *batch = nullptr;
 	void *out = nullptr; size_t out_cap = 0;
+	void *host_out = nullptr; size_t host_cap = 0, out_used = 0;   // outputs_to_host: the pinned mirror of `out` (its first out_used bytes are copied behind every decode)
 	// bindings of the item the batch object is planned for
 	std::vector<crthip_attr_binding> binds;
 	std::vector<void *> index_ptr;
@@ -55,6 +56,7 @@ struct crthip_pool {
 	std::vector<Lane> lanes;        // [device][thread][depth]
 	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
 	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
+	bool to_host = false;           // crthip_pool_set_outputs_to_host: every step ends with a D2H copy of its outputs into the lane's pinned block
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
 	std::mutex m;
@@ -66,7 +68,8 @@ static void destroy_lane(Lane &L) {
 	if(L.batch) crthip_batch_destroy(L.batch);
 	if(L.ctx) crthip_ctx_destroy(L.ctx);
 	if(L.out) (void)hipFree(L.out);
-	L.batch = nullptr; L.ctx = nullptr; L.out = nullptr; L.out_cap = 0;
+	if(L.host_out) (void)hipHostFree(L.host_out);
+	L.batch = nullptr; L.ctx = nullptr; L.out = nullptr; L.out_cap = 0; L.host_out = nullptr; L.host_cap = 0;
 }
 
 extern "C" int crthip_pool_create(uint32_t ndevices, const int *devices, uint32_t threads_per_device, uint32_t depth, crthip_pool **out) {
@@ -139,6 +142,11 @@ extern "C" int64_t crthip_pool_device_cpus(const crthip_pool *p, uint32_t device
 	for(size_t i = 0; i < c.size() && i < cap && cpus; i++) cpus[i] = c[i];
 	return (int64_t)c.size();
 }
+extern "C" int crthip_pool_set_outputs_to_host(crthip_pool *p, int on) {
+	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	p->to_host = on != 0;
+	return CRTHIP_OK;
+}
 extern "C" int crthip_pool_set_packed_host_blobs(crthip_pool *p, int on) {
 	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
 	for(auto &L : p->lanes) { const int err = crthip_ctx_set_packed_host_blobs(L.ctx, on); if(err) return err; }
@@ -193,6 +201,13 @@ static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_
 			L.index_ptr[i] = info.nface ? base + L.index_off[i] : nullptr;
 		}
 		L.status.assign(it.nblobs, 0);
+		L.out_used = off;
+	}
+	if(p->to_host && L.host_cap < L.out_cap) {                 // (first use: 32 MB of pinned memory a lane for a C4 item)
+		if(L.host_out) (void)hipHostFree(L.host_out);
+		L.host_out = nullptr; L.host_cap = 0;
+		if(hipHostMalloc(&L.host_out, L.out_cap, hipHostMallocDefault) != hipSuccess) return ctx_fail(CRTHIP_E_NOMEM, nullptr);
+		L.host_cap = L.out_cap;
 	}
 	L.item = item_id;
 	return crthip_batch_bind_all(L.batch, L.binds.data(), L.index_ptr.data(), L.index_fmt.data());
@@ -229,7 +244,8 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 	std::vector<std::atomic<uint64_t>> home_next(p->ndevices);
 	for(auto &x : home_next) x = 0;
 	std::atomic<uint64_t> stolen{0};
-	const uint64_t poison_from = timed_end > p->lanes.size() ? timed_end - p->lanes.size() : 0;   // the last round of timed steps and the tail behind them
+	// the last round of timed steps and the tail behind them (outputs_to_host: the tail only - poisoning the pinned mirror is 32 MB of memset on the worker thread)
+	const uint64_t poison_from = p->to_host ? timed_end : timed_end > p->lanes.size() ? timed_end - p->lanes.size() : 0;
 	const double t_launch = now_s();
 	stamps[0] = t_launch;
 
@@ -293,10 +309,12 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			L.poisoned = false;
 			if(!err && step >= poison_from && L.out) {
 				err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+				if(!err && p->to_host && L.host_out) memset(L.host_out, POISON, L.out_used);
 				if(!err) L.poisoned = true;
 			}
 			const auto d0 = std::chrono::steady_clock::now();
 			if(!err) err = crthip_batch_decode(L.batch);
+			if(!err && p->to_host) err = corto_hip::ctx_copy_to_host_async(L.ctx, L.host_out, L.out, L.out_used);
 			raise_max(launch_max_ns, ns_since(d0));
 			host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count(); host_steps++;
 			if(!err) { L.busy = true; L.step = step; }
@@ -314,7 +332,9 @@ extern "C" int crthip_pool_run(crthip_pool *p, uint32_t nitems, const crthip_poo
 			}
 			if(L.poisoned || !L.out) continue;
 			err = corto_hip::ctx_fill_async(L.ctx, L.out, L.out_cap, POISON);
+			if(!err && p->to_host && L.host_out) memset(L.host_out, POISON, L.out_used);
 			if(!err) err = crthip_batch_decode(L.batch);
+			if(!err && p->to_host) err = corto_hip::ctx_copy_to_host_async(L.ctx, L.host_out, L.out, L.out_used);
 			if(!err) { L.busy = true; L.poisoned = true; err = finish(L); }
 		}
 		if(err) {
@@ -369,6 +389,8 @@ extern "C" int64_t crthip_pool_lane_read(crthip_pool *p, uint32_t lane, uint32_t
 		if(!src) return ctx_fail(CRTHIP_E_ARGUMENT, "no such attribute");
 	}
 	if(n > cap) n = cap;
+	// outputs_to_host: what the step's own D2H copy left in the lane's pinned block (the tail lies behind the copied range: from the device)
+	if(p->to_host && L.host_out && strcmp(what, "#tail")) { memcpy(host_out, (const uint8_t *)L.host_out + (src - (const uint8_t *)L.out), n); return (int64_t)n; }
 	if(hipSetDevice(L.device) != hipSuccess || hipMemcpy(host_out, src, n, hipMemcpyDeviceToHost) != hipSuccess) return ctx_fail(CRTHIP_E_DEVICE, nullptr);
 	return (int64_t)n;
 }

@@ -35,8 +35,8 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 4   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_*; 3: crthip_pool_report grew, crthip_pool_warning;
-                                  4: integer / DOUBLE output formats of generic attributes, crthip_pool_device_cpus */
+#define CRTHIP_ABI_VERSION 5   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_*; 3: crthip_pool_report grew, crthip_pool_warning;
+                                  4: integer / DOUBLE output formats of generic attributes, crthip_pool_device_cpus; 5: crthip_pool_set_outputs_to_host */
 
 /* VertexAttribute::Format, include/corto/vertex_attribute.h:32 */
 enum { CRTHIP_FMT_UINT32 = 0, CRTHIP_FMT_INT32 = 1, CRTHIP_FMT_UINT16 = 2, CRTHIP_FMT_INT16 = 3,
@@ -210,6 +210,11 @@ const char *crthip_pool_warning(const crthip_pool *pool);
 int64_t crthip_pool_device_cpus(const crthip_pool *pool, uint32_t device_slot, int32_t *cpus, size_t cap);
 /* crthip_ctx_set_packed_host_blobs for every context of the pool (items handed to crthip_pool_run without device arenas). */
 int crthip_pool_set_packed_host_blobs(crthip_pool *pool, int on);
+/* SURVEY 8d's secondary region: every step of crthip_pool_run ends with ONE device-to-host copy of its decoded outputs into a pinned host block
+ * of the lane (queued on the context's stream behind the kernels; a step is complete when the copy is), and crthip_pool_lane_read returns what
+ * that copy delivered.  What a host-side consumer of the outputs sees - the reference's own region, decode() into host buffers
+ * (src/main.cpp:266-300).  Off by default: outputs stay in HBM. */
+int crthip_pool_set_outputs_to_host(crthip_pool *pool, int on);
 
 /* One work item = one batch of blobs (HOST pointers, borrowed for the duration of crthip_pool_run).
  * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step (SURVEY.md 8d's primary

@@ -211,6 +211,29 @@ def test_pool_takes_packed_pinned_items_in_place(c5_blobs):
     pool.close()
 
 
+def test_pool_outputs_to_host_is_the_secondary_region(c5_blobs):
+    """crthip_pool_set_outputs_to_host (SURVEY 8d's secondary region): every step ends with a D2H copy of its outputs into the lane's pinned block,
+    behind its kernels; what the copies delivered is the oracle's bytes (the mirror is poisoned before every lane's last step), and switching it
+    off again leaves the outputs in HBM as before"""
+    items = [c5_blobs[300:340], c5_blobs[900:940]]
+    pool = ca.Pool([0], threads=2, depth=2)
+    pool.set_outputs_to_host(True)
+    dts = {"position": (np.float32, 3), "normal": (np.float32, 3), "color": (np.uint8, 4), "uv": (np.float32, 2), "index": (np.uint32, 3)}
+    for to_host in (True, False, True):
+        pool.set_outputs_to_host(to_host)
+        rep, _ = pool.run(items, steps=24, warmup=4, arenas=None)
+        assert rep.failed_blobs == 0 and rep.poisoned_lanes == pool.lanes
+        for lane in range(pool.lanes):
+            it, _slot = pool.lane_item(lane)
+            for i in (0, 13, 39):
+                ref = oc.decode(items[it][i])
+                for k, (dt, w) in dts.items():
+                    cnt = (ref["nface"] if k == "index" else ref["nvert"]) * w
+                    assert pool.lane_read(lane, i, k, dt, cnt).tobytes() == ref[k].tobytes(), (to_host, lane, i, k)
+            assert (pool.lane_read(lane, 0, "#tail", np.uint8, 256) == 0xA5).all()
+    pool.close()
+
+
 def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
     table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_grouped); $CORTO_TUN_SHARE=0
