@@ -311,10 +311,22 @@ static int harvest(crthip_ctx *ctx) {
 		}
 		ctx->delta_just_narrowed = false;                                   // (narrow and fine, or wide from here on)
 	} else if(!ctx->dbg.delta_wide && ++ctx->delta_calm >= ctx->delta_patience) { ctx->delta_wide = false; ctx->delta_calm = 0; ctx->delta_just_narrowed = true; }
-	// more than one blob in twenty redone on the HBM front (5x slower): four times the edge slots from the next batch on;
+	// more than one blob in twenty redone on the HBM front (5x slower): more edge slots from the next batch on - as many as the redone blobs say they
+	// would have needed (k_topology_lds' redo reports the slots above bit 0 of the flags word; round 4 went up four-fold whatever was missing, and a
+	// batch of Delaunay discs that needed 600 slots of its 512 got 2 048: 72 KB of LDS a blob, two automata a CU, the pipeline at a third of its rate);
 	// a long run without any: try half again, and be more patient the next time that turns out to be too little
 	if(b->stats.topology_fallbacks*20 > n) {
-		if(ctx->topo_scale < 16) ctx->topo_scale *= 4;
+		uint32_t asked = 2;
+		for(size_t i = 0; i < n; i++) if(hs[n + i] & 1) {
+			const auto &h = b->blobs[i].L.h;
+			uint32_t ring, pool, symwin;
+			topo_lds_geometry(h.nface, b->blobs[i].L.clers.size, 4096, 1, n >= 32 ? 4u : 8u, topo_boundary_estimate(h.nvert, h.nface), ring, pool, symwin);
+			const uint32_t need = (uint32_t)hs[n + i] >> 1;
+			uint32_t m = 1;
+			while(ring*m < need && m < 16) m <<= 1;
+			asked = std::max(asked, m);
+		}
+		ctx->topo_scale = std::min(16u, std::max(asked, ctx->topo_scale*2));
 		if(ctx->topo_calm == 0 && ctx->topo_patience < (1u << 20)) ctx->topo_patience *= 2;    // fell back right after scaling down
 		ctx->topo_calm = 0;
 	} else if(b->stats.topology_fallbacks == 0 && ctx->topo_scale > 1 && ++ctx->topo_calm >= ctx->topo_patience) {

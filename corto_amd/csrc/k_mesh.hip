@@ -90,6 +90,9 @@ struct TopoState {
 	uint32_t cler, vertex_count;
 	uint64_t bit;
 	int32_t err;
+	// what the LDS form of this front would have needed (k_topology_lds' redo reports it, batch.cpp learns from it): the longest the queue got
+	// (ring slots), the most pool slots held at once (every BOUNDARY edge for good, every DELAYed one while it sits in the stack), the deepest DELAY stack
+	uint32_t peak_queue = 0, chain_ends = 0, peak_delayed = 0, peak_pool = 0;
 	__device__ uint32_t bits(uint32_t n) {
 		if(bit + n > (uint64_t)J.split_nwords*32) { err = ERR_TOPOLOGY; return 0; }
 		const uint32_t v = bit_field(split, J.split_nwords, bit, n);
@@ -136,6 +139,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 			const uint32_t e = nfront;
 			if(e + 3 > cap) FAIL();
 			F.order_put(norder++, e); F.order_put(norder++, e + 1); F.order_put(norder++, e + 2);
+			if(norder - iorder > S.peak_queue) S.peak_queue = norder - iorder;
 			F.put(e, vi[1], vi[2], vi[0], e + 2, e + 1);
 			F.put(e + 1, vi[2], vi[0], vi[1], e, e + 2);
 			F.put(e + 2, vi[0], vi[1], vi[2], e + 1, e);
@@ -152,7 +156,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 		if(dead) continue;                                             // deleted: no symbol consumed (decoder.cpp:278-279)
 		if(S.cler >= J.nclers) FAIL();
 		const uint32_t c = S.clers[S.cler++];
-		if(c == C_BOUNDARY) continue;
+		if(c == C_BOUNDARY) { S.chain_ends++; if(S.chain_ends + ndelayed > S.peak_pool) S.peak_pool = S.chain_ends + ndelayed; continue; }
 		uint32_t ep, en;
 		F.links(f, ep, en);
 		if(ep >= nfront || en >= nfront) FAIL();
@@ -171,6 +175,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 			F.set_prev(en, ne + 1);
 			F.put(ne, v0, opp, v1, ep, ne + 1);
 			F.order_put(norder++, ne + 1);
+			if(norder - iorder > S.peak_queue) S.peak_queue = norder - iorder;
 			F.put(ne + 1, opp, v1, v0, ne, en);
 			nfront += 2;
 		} else if(c == C_LEFT) {                                       // decoder.cpp:311-317
@@ -194,6 +199,8 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 		} else if(c == C_DELAY) {                                      // decoder.cpp:327-331
 			if(ndelayed >= cap) FAIL();
 			F.delayed_put(ndelayed++, f);
+			if(ndelayed > S.peak_delayed) S.peak_delayed = ndelayed;
+			if(S.chain_ends + ndelayed > S.peak_pool) S.peak_pool = S.chain_ends + ndelayed;
 			new_edge = -1;
 			continue;
 		} else if(c == C_END) {                                        // decoder.cpp:333-339
@@ -211,21 +218,26 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 }
 
 template <class Front, class ClersPtr>
-__device__ void topo_run(const TopoJob &J, ClersPtr clers, Front &F) {
+__device__ uint32_t topo_run(const TopoJob &J, ClersPtr clers, Front &F) {      // returns the slots (ring = pool) the LDS form would have needed
 	TopoState<ClersPtr> S{J, clers, as_global(J.split_words), as_global(J.pred),
 	                      J.faces_u16 ? nullptr : as_global((uint32_t *)J.faces), J.faces_u16 ? as_global((uint16_t *)J.faces) : nullptr, 0, 0, 0, 0};
+	uint32_t need = 0;
 	CRT_GLOBAL const uint32_t *group_end = as_global(J.group_end);
 	uint32_t start = 0;
 	for(uint32_t g = 0; g < J.ngroups && !S.err; g++) {                // decoder.cpp:173-178
 		const uint32_t ge = group_end[g];
 		if(ge > J.nface || ge < start) { S.err = ERR_TOPOLOGY; break; }
+		S.peak_queue = S.chain_ends = S.peak_delayed = S.peak_pool = 0;   // (every group starts from an empty front)
 		topo_group(S, F, start*3, ge*3);
+		const uint32_t n_ = max(max(S.peak_queue + 4u, S.peak_pool + S.peak_pool/16u + 16u), S.peak_delayed + 1u);   // (a chain-end step takes its pool slots before it gives any back)
+		need = n_ > need ? n_ : need;
 		start = ge;
 	}
 	// vertices the stream never made keep the prediction (0, 0, 0), as in the reference's zero-filled vector (src/decoder.cpp:171): the
 	// scratch block is not cleared in front of a batch, so the automaton finishes the array itself (nothing to do for a valid stream)
 	for(uint32_t v = S.vertex_count; v < J.nvert; v++) S.predict(v, 0, 0, 0);
 	if(S.err) *as_global(J.status) = S.err;
+	return need;
 }
 
 // general path: any size, state in HBM scratch
@@ -1886,14 +1898,32 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	return true;
 }
 
+// -DCORTO_TOPO_TIMES (tools/topo_times_probe.py): when and where every workgroup of the launch ran - shader clock at entry and exit, HW_ID, XCC_ID -
+// read back with crthip_debug_topo_times: how many automata the chip really runs at once.  Nothing of it in the product build.
+#ifdef CORTO_TOPO_TIMES
+__device__ uint32_t g_topo_times[8*8192];
+#endif
 __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
+#ifdef CORTO_TOPO_TIMES
+	const uint64_t tt_begin = __builtin_amdgcn_s_memtime();
+#endif
 	const TopoJob J = jobs[job_ids[blockIdx.x]];
 	const bool done = J.faces_u16 ? topo_lds_body<true>(J) : topo_lds_body<false>(J);
+#ifdef CORTO_TOPO_TIMES
+	if(threadIdx.x == 0 && blockIdx.x < 8192) {
+		const uint64_t tt_end = __builtin_amdgcn_s_memtime();
+		uint32_t hw, xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		uint32_t *o = g_topo_times + blockIdx.x*8;
+		o[0] = (uint32_t)tt_begin; o[1] = (uint32_t)(tt_begin >> 32); o[2] = (uint32_t)tt_end; o[3] = (uint32_t)(tt_end >> 32); o[4] = hw; o[5] = xcc; o[6] = done ? 1u : 0u; o[7] = njobs;
+	}
+#endif
 	if(!done) {                                                          // thread 0 only: redo the blob with the front in HBM
-		*as_global(J.flags) = 1;
 		GlobalFront F{(CRT_GLOBAL u32x4 *)as_global(J.front_a), (CRT_GLOBAL u32x2 *)as_global(J.front_b), as_global(J.order), as_global(J.delayed)};
-		topo_run(J, as_global(J.clers), F);
+		const uint32_t need = topo_run(J, as_global(J.clers), F);
+		*as_global(J.flags) = (int32_t)(1u | (need < (1u << 24) ? need : (1u << 24) - 1u) << 1);   // bit 0: redone; above it: the slots it would have needed in LDS
 	}
 }
 
@@ -2032,6 +2062,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__
 
 } // namespace corto_hip
 
+#ifdef CORTO_TOPO_TIMES
+extern "C" int crthip_debug_topo_times(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_topo_times), sizeof(uint32_t)*8*8192); }
+#endif
 #ifdef CORTO_TOPO_STAMPS
 extern "C" int crthip_debug_topo_trace(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_topo_trace), sizeof(uint32_t)*16*8192); }
 extern "C" int crthip_debug_topo_stamps(uint32_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(corto_hip::g_topo_stamps), sizeof(uint32_t)*48*4096); }

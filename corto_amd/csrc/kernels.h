@@ -60,8 +60,8 @@ inline uint32_t topo_boundary_estimate(uint32_t nvert, uint32_t nface) { const u
 inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t slots, uint32_t boundary, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
 	uint32_t want = 256;
 	while((uint64_t)want*want < (uint64_t)slots*slots*nface && want < ring_max) want <<= 1;
-	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }
 	while(want < boundary + boundary/8 + 48 && want < ring_max) want <<= 1;      // (pool = ring in the ISA block: both grow)
+	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }             // what the context has learnt multiplies either estimate
 	ring = want; pool = want;
 	const uint32_t all = (nclers + 64 + 31) & ~31u;       // whole 16-byte vectors of nibbles (k_mesh.hip: TOPO_FILL_WINDOW)
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;

@@ -9,6 +9,9 @@ blobs, _ = bench.load_blobs(0)
 if os.environ.get("KIND") == "irregular":
     from corto_amd import synth
     blobs = [ca.encode(synth.bumpy_sphere_flipped(64, 32, seed=i), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(256)]
+if os.environ.get("KIND") == "delaunay":                   # bench.py's `realistic` blobs
+    from corto_amd import synth
+    blobs = [ca.encode(synth.delaunay_disc(2310, seed=i, holes=6 + i % 5), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER) for i in range(256)]
 arena = ca.upload_arena(blobs, 0)
 arenas = None if os.environ.get("FROM_HOST") in ("1", "2") else [[arena]]      # FROM_HOST=1: every step uploads its blobs from host memory; 2: from ONE pinned buffer, in place
 if os.environ.get("FROM_HOST") == "2":
