@@ -386,6 +386,37 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 	}
 	__syncthreads();
 	// per vertex: ordered accumulation (estimateNormals :40-59) + computeNormals (:281-325)
+	// what a vertex' sum of face normals becomes (its correction: fetched by the caller ahead of the sum)
+	auto finish = [&](uint32_t i, float ex, float ey, float ez, bool flagged, bool has_diff, int32_t pdx, int32_t pdy) {
+		if(flagged) {                                                    // ESTIMATED: every vertex; BORDER: boundary vertices
+			int32_t qx, qy;
+			to_octa(ex, ey, ez, J.unit, qx, qy);
+			asm volatile("" : "+v"(pdx), "+v"(pdy));
+			const int32_t dx = has_diff ? pdx : 0, dy = has_diff ? pdy : 0;
+			int32_t x = (int32_t)((uint32_t)qx + (uint32_t)dx), y = (int32_t)((uint32_t)qy + (uint32_t)dy);
+			if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }
+			float nx, ny, nz;
+			to_sphere(x, y, J.unit, nx, ny, nz);
+			store_normal(J, i, nx, ny, nz);
+		} else if(J.out_i16) {
+			float len = norm3(ex, ey, ez);
+			if(!(len < 0.00001f)) {
+				len = 32767.0f/len;
+				CRT_GLOBAL int16_t *o = (CRT_GLOBAL int16_t *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
+				o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
+			}
+		} else {
+			const float len = norm3(ex, ey, ez);
+			CRT_GLOBAL float *o = (CRT_GLOBAL float *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
+			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
+		}
+	};
+	// Round 5: valences beyond 8 (a Delaunay mesh goes to 11, a decimated one to 20, a cone's apex to hundreds) took a selection loop of deg^2 LDS reads and
+	// data-dependent branches with the whole wave waiting for its one such vertex (Delaunay discs: 0.100 ms a batch against the grid's 0.035; a valence-128
+	// apex: 1.47 ms).  Now: up to 16 incident faces sort in a 63-exchange network in registers (every lane of a wave that holds such a vertex takes it: no
+	// divergence), and a vertex beyond 16 is left to its WAVE afterwards - ranks by counting, the sorted ids back in place, the normals of 64 faces a
+	// round in registers, and the sum taken in id order through v_readlane.
+	const uint32_t HEAVY = 16;
 	for(uint32_t i = tid; i < nv; i += 256) {
 		uint32_t s0 = cur[i ? i - 1u : 0u], fw = fbits[i >> 5], fp = fpre[i >> 5];
 		const uint32_t e0 = cur[i];
@@ -399,7 +430,9 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		int32_t pdx = 0, pdy = 0;
 		if(J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)(has_diff ? rank : 0u); pdx = dp[0]; pdy = dp[1]; }
 		float ex = 0.f, ey = 0.f, ez = 0.f;
-		if(deg <= 8 && deg > 0) {
+		const bool wide = fn_any && __any(deg > 8 && deg <= HEAVY);          // (uniform) somebody in this wave needs the 16-wide network
+		if(fn_any && deg > HEAVY) continue;                                  // the wave's job, below
+		if(deg <= 8 && deg > 0 && !wide) {
 			// the usual vertex: its (at most eight) incident faces sorted by id with a branch-free network and their normals added in that
 			// order.  Equal ids (a face naming the vertex twice) end up adjacent and are added twice, as the reference does.  (The selection
 			// loop below takes deg^2 data-dependent branches; a lone wave pays ~20 clocks for each.)
@@ -466,7 +499,35 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 					}
 				}
 			}
-		} else {
+		} else if(fn_any && deg > 0) {                                       // up to 16 incident faces: the same recipe, twice as wide
+			uint32_t id[16];
+#pragma unroll
+			for(uint32_t k = 0; k < 16; k++) id[k] = (uint32_t)adj[s0 + (k < deg ? k : 0u)];
+			asm volatile("" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]), "+v"(id[5]), "+v"(id[6]), "+v"(id[7]));
+			asm volatile("" : "+v"(id[8]), "+v"(id[9]), "+v"(id[10]), "+v"(id[11]), "+v"(id[12]), "+v"(id[13]), "+v"(id[14]), "+v"(id[15]));
+#pragma unroll
+			for(uint32_t k = 0; k < 16; k++) id[k] = k < deg ? id[k] : 0xFFFFFFFFu;
+#define CRT_CX(p, q) { const uint32_t lo_ = min(id[p], id[q]), hi_ = max(id[p], id[q]); id[p] = lo_; id[q] = hi_; }
+			CRT_CX(0, 1) CRT_CX(2, 3) CRT_CX(0, 2) CRT_CX(1, 3) CRT_CX(1, 2) CRT_CX(4, 5) CRT_CX(6, 7) CRT_CX(4, 6) CRT_CX(5, 7) CRT_CX(5, 6) CRT_CX(0, 4) CRT_CX(2, 6) CRT_CX(2, 4) CRT_CX(1, 5) CRT_CX(3, 7) CRT_CX(3, 5) CRT_CX(1, 2) CRT_CX(3, 4) CRT_CX(5, 6) CRT_CX(8, 9) CRT_CX(10, 11) CRT_CX(8, 10) CRT_CX(9, 11) CRT_CX(9, 10) CRT_CX(12, 13) CRT_CX(14, 15) CRT_CX(12, 14) CRT_CX(13, 15) CRT_CX(13, 14) CRT_CX(8, 12) CRT_CX(10, 14) CRT_CX(10, 12) CRT_CX(9, 13) CRT_CX(11, 15) CRT_CX(11, 13) CRT_CX(9, 10) CRT_CX(11, 12) CRT_CX(13, 14) CRT_CX(0, 8) CRT_CX(4, 12) CRT_CX(4, 8) CRT_CX(2, 10) CRT_CX(6, 14) CRT_CX(6, 10) CRT_CX(2, 4) CRT_CX(6, 8) CRT_CX(10, 12) CRT_CX(1, 9) CRT_CX(5, 13) CRT_CX(5, 9) CRT_CX(3, 11) CRT_CX(7, 15) CRT_CX(7, 11) CRT_CX(3, 5) CRT_CX(7, 9) CRT_CX(11, 13) CRT_CX(1, 2) CRT_CX(3, 4) CRT_CX(5, 6) CRT_CX(7, 8) CRT_CX(9, 10) CRT_CX(11, 12) CRT_CX(13, 14)      // Batcher's odd-even merge sort, 63 exchanges (checked on all 2^16 0/1 inputs)
+#undef CRT_CX
+			const uint32_t id0 = id[0];
+#pragma unroll
+			for(uint32_t h = 0; h < 16; h += 8) {                                // eight faces' normals in flight at a time
+				if(h >= deg) break;
+				float n[8][3];
+				if(fn_lds) {
+#pragma unroll
+					for(uint32_t k = 0; k < 8; k++) { const uint32_t f = h + k < deg ? id[h + k] : id0; n[k][0] = fn[3*f]; n[k][1] = fn[3*f + 1]; n[k][2] = fn[3*f + 2]; }
+				} else {
+#pragma unroll
+					for(uint32_t k = 0; k < 8; k++) { const uint32_t f = h + k < deg ? id[h + k] : id0; CRT_GLOBAL const float *q = fng + 3*(size_t)f; n[k][0] = q[0]; n[k][1] = q[1]; n[k][2] = q[2]; }
+				}
+#pragma unroll
+				for(uint32_t k = 0; k < 8; k++) asm volatile("" : "+v"(n[k][0]), "+v"(n[k][1]), "+v"(n[k][2]));
+#pragma unroll
+				for(uint32_t k = 0; k < 8; k++) { const bool on = h + k < deg; ex = on ? ex + n[k][0] : ex; ey = on ? ey + n[k][1] : ey; ez = on ? ez + n[k][2] : ez; }
+			}
+		} else if(deg > 0) {                                                 // the LDS-lean layout without a face-normal array (a context that was given no scratch for one): the selection loop
 		int32_t last = -1;
 		for(uint32_t done = 0; done < deg;) {
 			uint32_t best = 0xFFFFFFFFu, mult = 0;
@@ -489,27 +550,73 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 			last = (int32_t)best; done += mult;
 		}
 		}
-		if(flagged) {                                                    // ESTIMATED: every vertex; BORDER: boundary vertices
-			int32_t qx, qy;
-			to_octa(ex, ey, ez, J.unit, qx, qy);
-			asm volatile("" : "+v"(pdx), "+v"(pdy));
-			const int32_t dx = has_diff ? pdx : 0, dy = has_diff ? pdy : 0;
-			int32_t x = (int32_t)((uint32_t)qx + (uint32_t)dx), y = (int32_t)((uint32_t)qy + (uint32_t)dy);
-			if(J.out_i16) { x = (int16_t)(uint16_t)(uint32_t)x; y = (int16_t)(uint16_t)(uint32_t)y; }
-			float nx, ny, nz;
-			to_sphere(x, y, J.unit, nx, ny, nz);
-			store_normal(J, i, nx, ny, nz);
-		} else if(J.out_i16) {
-			float len = norm3(ex, ey, ez);
-			if(!(len < 0.00001f)) {
-				len = 32767.0f/len;
-				CRT_GLOBAL int16_t *o = (CRT_GLOBAL int16_t *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
-				o[0] = f2s_x86(ex*len); o[1] = f2s_x86(ey*len); o[2] = f2s_x86(ez*len);
+		finish(i, ex, ey, ez, flagged, has_diff, pdx, pdy);
+	}
+	if(fn_any) {
+		// vertices of more than 16 faces, one at a time by the wave that skipped them above (wave w's lanes hold vertices 256*r + 64*w + lane)
+		const uint32_t lane = tid & 63u;
+		for(uint32_t base = tid & ~63u; base < nv; base += 256) {
+			const uint32_t i = base + lane;
+			uint32_t s0l = i < nv ? (uint32_t)cur[i ? i - 1u : 0u] : 0u;
+			const uint32_t e0l = i < nv ? (uint32_t)cur[i] : 0u;
+			s0l = i ? s0l : 0u;
+			uint64_t hm = __ballot(i < nv && e0l - s0l > HEAVY);
+			while(hm) {                                                          // (uniform)
+				const uint32_t j = (uint32_t)__builtin_ctzll(hm);
+				hm &= hm - 1;
+				const uint32_t v = base + j;
+				const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)s0l, (int)j), deg = (uint32_t)__builtin_amdgcn_readlane((int)e0l, (int)j) - s0;
+				float ex = 0.f, ey = 0.f, ez = 0.f;
+				if(deg <= 512) {
+					uint32_t id[8], rk[8];
+#pragma unroll
+					for(uint32_t k = 0; k < 8; k++) { const uint32_t e = lane + 64u*k; id[k] = e < deg ? (uint32_t)adj[s0 + e] : 0xFFFFFFFFu; rk[k] = 0; }
+					for(uint32_t q = 0; q < deg; q++) {                               // ranks by counting: a broadcast read an element
+						const uint32_t fq = (uint32_t)adj[s0 + q];
+#pragma unroll
+						for(uint32_t k = 0; k < 8; k++) rk[k] += (fq < id[k] || (fq == id[k] && q < lane + 64u*k)) ? 1u : 0u;
+					}
+					// (every lane has read what it needs: the wave runs in lockstep) the sorted ids take the list's place
+#pragma unroll
+					for(uint32_t k = 0; k < 8; k++) if(lane + 64u*k < deg) adj[s0 + rk[k]] = (uint16_t)id[k];
+					for(uint32_t h = 0; h < deg; h += 64) {                           // 64 faces a round: their normals in registers, summed in id order
+						const uint32_t e = h + lane;
+						const uint32_t f = (uint32_t)adj[s0 + (e < deg ? e : 0u)];
+						float nx, ny, nz;
+						if(fn_lds) { nx = fn[3*f]; ny = fn[3*f + 1]; nz = fn[3*f + 2]; }
+						else { CRT_GLOBAL const float *qn = fng + 3*(size_t)f; nx = qn[0]; ny = qn[1]; nz = qn[2]; }
+						const uint32_t cnt = deg - h < 64u ? deg - h : 64u;
+						for(uint32_t q = 0; q < cnt; q++) {
+							ex += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nx), (int)q));
+							ey += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ny), (int)q));
+							ez += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nz), (int)q));
+						}
+					}
+				} else {                                                          // hundreds of faces around one vertex: selection, by every lane alike
+					int32_t last = -1;
+					for(uint32_t done = 0; done < deg;) {
+						uint32_t best = 0xFFFFFFFFu, mult = 0;
+						for(uint32_t k = 0; k < deg; k++) {
+							const uint32_t f = adj[s0 + k];
+							if((int32_t)f > last) { if(f < best) { best = f; mult = 1; } else if(f == best) mult++; }
+						}
+						float nx, ny, nz;
+						if(fn_lds) { nx = fn[3*best]; ny = fn[3*best + 1]; nz = fn[3*best + 2]; }
+						else { nx = fng[3*(size_t)best]; ny = fng[3*(size_t)best + 1]; nz = fng[3*(size_t)best + 2]; }
+						for(uint32_t m = 0; m < mult; m++) { ex += nx; ey += ny; ez += nz; }
+						last = (int32_t)best; done += mult;
+					}
+				}
+				if(lane == 0) {
+					const uint32_t fw = fbits[v >> 5], fp = fpre[v >> 5];
+					const bool flagged = (fw >> (v & 31u)) & 1u;
+					const uint32_t rank = fp + (uint32_t)__popc(fw & ((1u << (v & 31u)) - 1u));
+					const bool has_diff = flagged && rank < J.ndiffs;
+					int32_t pdx = 0, pdy = 0;
+					if(has_diff) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)rank; pdx = dp[0]; pdy = dp[1]; }
+					finish(v, ex, ey, ez, flagged, has_diff, pdx, pdy);
+				}
 			}
-		} else {
-			const float len = norm3(ex, ey, ez);
-			CRT_GLOBAL float *o = (CRT_GLOBAL float *)(as_global((uint8_t *)J.out) + (size_t)i*J.out_stride);
-			o[0] = ex/len; o[1] = ey/len; o[2] = ez/len;
 		}
 	}
 	if(!fn_any) { __syncthreads(); positions_out(); }
