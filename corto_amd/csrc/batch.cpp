@@ -178,6 +178,7 @@ struct Plan {
 	HostArr<FillJob> fill;
 	HostArr<TopoJob> topo; HostArr<uint32_t> aux_u32;     // group_end lists
 	HostArr<uint32_t> topo_lds_ids, topo_big_ids, topo_glob_ids; uint32_t topo_lds = 0, topo_big_lds = 0;   // LDS automata in two size classes, one launch each
+	std::vector<uint32_t> topo_need;                                        // LDS bytes of topo_lds_ids' entries until they are split into the two classes
 	HostArr<UnpackJob> unpack; HostArr<uint32_t> unpack_chunk_job, unpack_wave_ids;   // (unpack_wave_ids: the streams of small bit blocks, one wave each: k_unpack_wave)
 	HostArr<DeltaJob> delta;
 	HostArr<DeltaGroup> delta_groups;                       // blobs whose attributes share one k_delta_lds16 workgroup
@@ -197,7 +198,7 @@ struct Plan {
 	uint64_t total = 0;
 	template <typename A> static void clr(A &a) { a.v.clear(); a.dev_off = 0; }
 	void reset() {                                          // keep every vector's capacity
-		clr(tun); clr(tun_dict); clr(tun_chunk_stream); clr(tun_group_ids); clr(tun_groups); clers_groups = 0; clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids);
+		clr(tun); clr(tun_dict); clr(tun_chunk_stream); clr(tun_group_ids); clr(tun_groups); clers_groups = 0; clr(fill); clr(topo); clr(aux_u32); clr(topo_lds_ids); clr(topo_big_ids); clr(topo_glob_ids); topo_need.clear();
 		clr(unpack); clr(unpack_chunk_job); clr(unpack_wave_ids); clr(delta); clr(delta_groups); clr(cloud); clr(cloud_chunk_job); clr(normal); clr(nv_block_job); clr(nv_block_first);
 		clr(nf_block_job); clr(nf_block_first); clr(normal_fused_ids); clr(dequant); clr(dequant_block_job);
 		topo_lds = topo_big_lds = normal_fused_lds = 0;
@@ -237,7 +238,7 @@ struct crthip_ctx {
 	DeviceBuf host_out;       // decoded outputs of the one blob, back to back
 	PinnedBuf host_pin;       // ... and their landing zone in pinned host memory (one async D2H copy)
 	// feedback on the LDS edge slots of the CLERS automaton: raised after a batch with fallbacks, lowered after a long calm run
-	uint32_t topo_scale = 1, topo_calm = 0, topo_patience = 64;
+	uint32_t topo_scale = 1, topo_pool_q8 = 8, topo_pool_cap = 0, topo_calm = 0, topo_patience = 64;   // K-TOPO's learnt slots: ring x topo_scale (a power of two), pool x topo_pool_q8 / 8 (kernels.h: topo_lds_geometry)
 	// planner state reused from one decode call to the next (batch.cpp: build_and_launch)
 	Plan plan;
 	std::vector<BlobScratch> plan_scratch;
@@ -312,25 +313,30 @@ static int harvest(crthip_ctx *ctx) {
 		ctx->delta_just_narrowed = false;                                   // (narrow and fine, or wide from here on)
 	} else if(!ctx->dbg.delta_wide && ++ctx->delta_calm >= ctx->delta_patience) { ctx->delta_wide = false; ctx->delta_calm = 0; ctx->delta_just_narrowed = true; }
 	// more than one blob in twenty redone on the HBM front (5x slower): more edge slots from the next batch on - as many as the redone blobs say they
-	// would have needed (k_topology_lds' redo reports the slots above bit 0 of the flags word; round 4 went up four-fold whatever was missing, and a
-	// batch of Delaunay discs that needed 600 slots of its 512 got 2 048: 72 KB of LDS a blob, two automata a CU, the pipeline at a third of its rate);
-	// a long run without any: try half again, and be more patient the next time that turns out to be too little
+	// would have needed (k_topology_lds' redo reports ring and pool slots above bit 0 of the flags word; round 4 went up four-fold whatever was
+	// missing, and a batch of Delaunay discs that needed 600 pool slots of its 512 got 2 048 + 2 048: 72 KB of LDS a blob, two automata a CU, the
+	// pipeline at a third of its rate); a long run without any: try less again, and be more patient the next time that turns out to be too little
 	if(b->stats.topology_fallbacks*20 > n) {
-		uint32_t asked = 2;
+		uint32_t ring_m = 1, pool_q8 = 8;
+		const uint32_t cap_before = ctx->topo_pool_cap;
 		for(size_t i = 0; i < n; i++) if(hs[n + i] & 1) {
 			const auto &h = b->blobs[i].L.h;
 			uint32_t ring, pool, symwin;
-			topo_lds_geometry(h.nface, b->blobs[i].L.clers.size, 4096, 1, n >= 32 ? 4u : 8u, topo_boundary_estimate(h.nvert, h.nface), ring, pool, symwin);
-			const uint32_t need = (uint32_t)hs[n + i] >> 1;
+			topo_lds_geometry(h.nface, b->blobs[i].L.clers.size, 4096, 1, 8, n >= 32 ? 4u : 8u, topo_boundary_estimate(h.nvert, h.nface), ring, pool, symwin);
+			const uint32_t need_ring = ((uint32_t)hs[n + i] >> 1) & 0x7FFFu, need_pool = (uint32_t)hs[n + i] >> 16;
 			uint32_t m = 1;
-			while(ring*m < need && m < 16) m <<= 1;
-			asked = std::max(asked, m);
+			while(ring*m < need_ring && m < 16) m <<= 1;
+			ring_m = std::max(ring_m, m);
+			pool_q8 = std::max(pool_q8, std::min(128u, (need_pool*8 + pool - 1)/pool + 1u));      // (an eighth on top)
+			ctx->topo_pool_cap = std::max(ctx->topo_pool_cap, need_pool + need_pool/8);
 		}
-		ctx->topo_scale = std::min(16u, std::max(asked, ctx->topo_scale*2));
+		const bool grew = ring_m > ctx->topo_scale || pool_q8 > ctx->topo_pool_q8 || ctx->topo_pool_cap > cap_before;
+		ctx->topo_scale = std::max(ctx->topo_scale, ring_m); ctx->topo_pool_q8 = std::max(ctx->topo_pool_q8, pool_q8);
+		if(!grew) { ctx->topo_scale = std::min(16u, ctx->topo_scale*2); ctx->topo_pool_q8 = std::min(128u, ctx->topo_pool_q8*2); ctx->topo_pool_cap *= 2; }   // (they fell back with what they asked for: capacity, or a need the redo cannot see)
 		if(ctx->topo_calm == 0 && ctx->topo_patience < (1u << 20)) ctx->topo_patience *= 2;    // fell back right after scaling down
 		ctx->topo_calm = 0;
-	} else if(b->stats.topology_fallbacks == 0 && ctx->topo_scale > 1 && ++ctx->topo_calm >= ctx->topo_patience) {
-		ctx->topo_scale /= 2; ctx->topo_calm = 0;
+	} else if(b->stats.topology_fallbacks == 0 && (ctx->topo_scale > 1 || ctx->topo_pool_q8 > 8) && ++ctx->topo_calm >= ctx->topo_patience) {
+		ctx->topo_scale = std::max(1u, ctx->topo_scale/2); ctx->topo_pool_q8 = std::max(8u, ctx->topo_pool_q8*3/4); ctx->topo_pool_cap = ctx->topo_pool_cap*3/4; ctx->topo_calm = 0;
 	}
 	ctx->in_flight = nullptr;
 	return CRTHIP_OK;
@@ -895,20 +901,19 @@ int Planner::jobs() {
 			{
 				// every mesh takes the LDS path; a lone big mesh may use most of a CU's LDS, a batch keeps its blobs small
 				uint32_t ring, pool, symwin;
-				uint32_t scale = ctx->topo_scale, need;
-				for(;;) {                                                                // as much of the context's scale as fits a CU
-					topo_lds_geometry(nface, L.clers.size, 4096, scale, nblobs >= 32 ? 4u : 8u, topo_boundary_estimate(nvert, nface), ring, pool, symwin);
+				uint32_t scale = ctx->topo_scale, pool_q8 = ctx->topo_pool_q8, need;
+				for(;;) {                                                                // as much of what the context has learnt as fits a CU
+					topo_lds_geometry(nface, L.clers.size, 4096, scale, pool_q8, nblobs >= 32 ? 4u : 8u, topo_boundary_estimate(nvert, nface), ring, pool, symwin, ctx->topo_pool_cap);
 					need = topo_lds_bytes(ring, pool, pool, symwin);                     // every delayed edge is a pool record: same capacity
 #ifdef CORTO_TOPO_STAMPS
 					if(need <= 32768 && L.clers.size < 8190) need = 65536;              // (the dispatch trace: k_mesh.hip TOPO_ASM_STAMP)
 #endif
-					if(need <= TOPO_LDS_MAX || scale == 1) break;
-					scale >>= 1;
+					if(need <= TOPO_LDS_MAX || (scale == 1 && pool_q8 == 8)) break;
+					if(pool_q8 > 8 && (pool > ring || scale == 1)) pool_q8 = std::max(8u, pool_q8/2); else scale >>= 1;
 				}
 				if(need <= TOPO_LDS_MAX) {
 					t.lds_ring = ring; t.lds_pool = pool; t.lds_delayed_cap = pool; t.lds_symwin = symwin;
-					if(need <= 32*1024) { pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_lds = std::max(pl.topo_lds, need); }
-					else { pl.topo_big_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_big_lds = std::max(pl.topo_big_lds, need); }   // (a big mesh does not cost the small ones their occupancy)
+					pl.topo_lds_ids.v.push_back((uint32_t)pl.topo.v.size()); pl.topo_need.push_back(need);     // (split into two launches below)
 				}
 				else pl.topo_glob_ids.v.push_back((uint32_t)pl.topo.v.size());
 			}
@@ -1095,6 +1100,22 @@ void Planner::group() {
 	pl.jobs_begin = cv.take(0);
 	pl.unpack_partial_off = cv.take(unpack_state_words*8, 16);           // (first thing in the uploaded block: zeros)
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
+	// the LDS automata go up in ONE launch whose LDS request is the largest of theirs - unless some ask for much more than the others (a 66K-triangle
+	// mesh among 4K-triangle blobs): those get a launch of their own, so that a big mesh does not cost the small ones their occupancy.  "Much more": beyond
+	// 32 KB AND beyond twice the smallest request (round 5: a batch of Delaunay discs asks for 20-40 KB a blob, and cut at 32 KB it became two launches
+	// one after the other, each as long as its slowest blob - 1.07 ms instead of 0.57)
+	if(!pl.topo_lds_ids.v.empty()) {
+		uint32_t lo = 0xFFFFFFFFu;
+		for(uint32_t nd : pl.topo_need) lo = std::min(lo, nd);
+		const uint32_t cut = std::max(32u*1024u, 2u*lo);
+		std::vector<uint32_t> small_ids;
+		for(size_t k = 0; k < pl.topo_lds_ids.v.size(); k++) {
+			const uint32_t nd = pl.topo_need[k], id = pl.topo_lds_ids.v[k];
+			if(nd <= cut) { small_ids.push_back(id); pl.topo_lds = std::max(pl.topo_lds, nd); }
+			else { pl.topo_big_ids.v.push_back(id); pl.topo_big_lds = std::max(pl.topo_big_lds, nd); }
+		}
+		pl.topo_lds_ids.v.swap(small_ids);
+	}
 	place(pl.tun); place(pl.tun_dict); place(pl.tun_chunk_stream); place(pl.tun_group_ids); place(pl.tun_groups); place(pl.fill); place(pl.topo); place(pl.aux_u32); place(pl.topo_lds_ids); place(pl.topo_big_ids); place(pl.topo_glob_ids); place(pl.unpack); place(pl.unpack_chunk_job); place(pl.unpack_wave_ids);
 	// large attributes first: they are launched with four times the threads of the small ones (k_delta_mesh)
 	std::stable_partition(pl.delta.v.begin(), pl.delta.v.end(), [wide_ = wide](const DeltaJob &d) { return delta_class(d, wide_) == 0; });
@@ -1322,7 +1343,7 @@ void Planner::account() {
 	// stats
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams = ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
 	b->stats.scratch_bytes = pl.total;
-	b->stats.topology_scale = ctx->topo_scale; b->stats.delta_wide = wide ? 1u : 0u;
+	b->stats.topology_scale = std::max(ctx->topo_scale, (ctx->topo_pool_q8 + 7)/8); b->stats.delta_wide = wide ? 1u : 0u;
 	uint64_t ob = 0;
 	for(auto &P : b->blobs) {
 		const BlobLayout &L = P.L;

@@ -218,7 +218,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 }
 
 template <class Front, class ClersPtr>
-__device__ uint32_t topo_run(const TopoJob &J, ClersPtr clers, Front &F) {      // returns the slots (ring = pool) the LDS form would have needed
+__device__ uint32_t topo_run(const TopoJob &J, ClersPtr clers, Front &F) {      // returns the slots the LDS form would have needed: ring | pool << 15
 	TopoState<ClersPtr> S{J, clers, as_global(J.split_words), as_global(J.pred),
 	                      J.faces_u16 ? nullptr : as_global((uint32_t *)J.faces), J.faces_u16 ? as_global((uint16_t *)J.faces) : nullptr, 0, 0, 0, 0};
 	uint32_t need = 0;
@@ -229,8 +229,8 @@ __device__ uint32_t topo_run(const TopoJob &J, ClersPtr clers, Front &F) {      
 		if(ge > J.nface || ge < start) { S.err = ERR_TOPOLOGY; break; }
 		S.peak_queue = S.chain_ends = S.peak_delayed = S.peak_pool = 0;   // (every group starts from an empty front)
 		topo_group(S, F, start*3, ge*3);
-		const uint32_t n_ = max(max(S.peak_queue + 4u, S.peak_pool + S.peak_pool/16u + 16u), S.peak_delayed + 1u);   // (a chain-end step takes its pool slots before it gives any back)
-		need = n_ > need ? n_ : need;
+		const uint32_t nr_ = min(S.peak_queue + 4u, 0x7FFFu), np_ = min(max(S.peak_pool + S.peak_pool/16u + 16u, S.peak_delayed + 1u), 0x7FFFu);   // (a chain-end step takes its pool slots before it gives any back)
+		need = max(need & 0x7FFFu, nr_) | max(need >> 15, np_) << 15;         // ring slots | pool slots << 15
 		start = ge;
 	}
 	// vertices the stream never made keep the prediction (0, 0, 0), as in the reference's zero-filled vector (src/decoder.cpp:171): the
@@ -454,8 +454,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Lleftq_%=\n" \
 							"  s_lshr_b32 %[t0], %[pk1], 16\n" \
 							"  s_lshl_b32 %[t0], %[t0], 1\n" \
-							"  s_add_u32 %[t3], %[mask], 1\n" \
-							"  s_lshl_b32 %[t3], %[t3], 5\n" \
+							"  s_and_b32 %[t3], %[lay], 0xffff\n" \
+							"  s_lshl_b32 %[t3], %[t3], 4\n" \
 							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
 							"  v_mov_b32 v54, %[t0]\n" \
 							"  v_mov_b32 v55, %[ep]\n" \
@@ -481,8 +481,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cbranch_scc1 Lrightq_%=\n" \
 							"  s_lshr_b32 %[t0], %[pk1], 16\n" \
 							"  s_lshl_b32 %[t0], %[t0], 1\n" \
-							"  s_add_u32 %[t3], %[mask], 1\n" \
-							"  s_lshl_b32 %[t3], %[t3], 5\n" \
+							"  s_and_b32 %[t3], %[lay], 0xffff\n" \
+							"  s_lshl_b32 %[t3], %[t3], 4\n" \
 							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
 							"  v_mov_b32 v54, %[t0]\n" \
 							"  v_mov_b32 v55, %[en]\n" \
@@ -499,9 +499,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
    /* ---------------- every eighth symbol: the next word of the window, then the loop test and the dispatch at the top */ \
 							"Lrefill_%=:\n" \
 							"  s_lshr_b32 %[t0], %[cler], 3\n" \
-							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
 							"  s_lshl_b32 %[t0], %[t0], 2\n" \
-							"  s_add_u32 %[t0], %[t0], %[clbase]\n" \
+							"  s_add_u32 %[t0], %[t0], %[clw]\n" \
 							"  v_mov_b32 v55, %[t0]\n" \
 							"  ds_read_b32 v55, v55\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
@@ -513,7 +512,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
       (free list, else the bump pointer), its record, and its neighbours their links to it - then the next gate is fetched from the ring: \
       the wave's parked lanes look at 64 queue entries at once, the first live one becomes the current edge, and the dispatch goes on \
       without leaving the block.  pk1 = pool bump pointer | free-list fill << 16, pk2 = DELAY stack fill | its capacity << 16. \
-      Layout (records at LDS address 0, ring = pool = mask + 1): free list at (mask+1)*32, DELAY stack at (mask+1)*34. \
+      Layout (records at LDS address 0): free list at 16*FL16, DELAY stack at 16*DL16, ring + pool = FL16 slots - the layout word %[lay] = FL16 | DL16 << 16. \
       Anything else (END, an invalid or window-end nibble, no slot left, empty ring and empty DELAY stack, window about to run out) leaves for the C++. */ \
 							"Lcold_%=:\n" \
 							"  s_cmp_eq_u32 %[c], 4\n" \
@@ -531,8 +530,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_eq_u32 %[t0], 0\n" \
 							"  s_cbranch_scc1 Lbump_%=\n" \
 							"  s_sub_u32 %[t0], %[t0], 1\n" \
-							"  s_add_u32 %[t2], %[mask], 1\n" \
-							"  s_lshl_b32 %[t2], %[t2], 5\n" \
+							"  s_and_b32 %[t2], %[lay], 0xffff\n" \
+							"  s_lshl_b32 %[t2], %[t2], 4\n" \
 							"  s_lshl_b32 %[t0], %[t0], 1\n" \
 							"  s_add_u32 %[t0], %[t0], %[t2]\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
@@ -543,8 +542,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_branch Lhave_%=\n" \
 							"Lbump_%=:\n" \
 							"  s_and_b32 %[t1], %[pk1], 0xffff\n" \
-							"  s_add_u32 %[t2], %[mask], 1\n" \
-							"  s_lshl_b32 %[t2], %[t2], 1\n" \
+							"  s_and_b32 %[t2], %[lay], 0xffff\n"         /* ring + pool slots */ \
 							"  s_cmp_ge_u32 %[t1], %[t2]\n"   /* pool exhausted: the C++ flags the blob for the HBM redo */ \
 							"  s_cbranch_scc1 Lexit_%=\n" \
 							"  s_add_u32 %[pk1], %[pk1], 1\n" \
@@ -555,8 +553,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_or_b32 %[t2], %[t2], 0x40000000\n"   /* TOPO_DELAYED; and push the slot */ \
 							"  s_and_b32 %[t0], %[pk2], 0xffff\n" \
 							"  s_lshl_b32 %[t0], %[t0], 1\n" \
-							"  s_add_u32 %[t3], %[mask], 1\n" \
-							"  s_mul_i32 %[t3], %[t3], 34\n" \
+							"  s_lshr_b32 %[t3], %[lay], 16\n" \
+							"  s_lshl_b32 %[t3], %[t3], 4\n" \
 							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
 							"  v_mov_b32 v53, %[t1]\n" \
@@ -584,9 +582,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_and_b32 %[t0], %[cler], 7\n" \
 							"  s_cbranch_scc1 Lpop_%=\n" \
 							"  s_lshr_b32 %[t0], %[cler], 3\n" \
-							"  s_add_u32 %[t0], %[t0], %[wbias]\n" \
 							"  s_lshl_b32 %[t0], %[t0], 2\n" \
-							"  s_add_u32 %[t0], %[t0], %[clbase]\n" \
+							"  s_add_u32 %[t0], %[t0], %[clw]\n" \
 							"  v_mov_b32 v55, %[t0]\n" \
 							"  ds_read_b32 v55, v55\n" \
 							"  s_waitcnt lgkmcnt(0)\n" \
@@ -639,14 +636,15 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_sub_u32 %[pk2], %[pk2], 1\n" \
 							"  s_sub_u32 %[t0], %[t0], 1\n" \
 							"  s_lshl_b32 %[t0], %[t0], 1\n" \
-							"  s_add_u32 %[t3], %[mask], 1\n" \
-							"  s_mul_i32 %[t2], %[t3], 34\n" \
+							"  s_lshr_b32 %[t2], %[lay], 16\n" \
+							"  s_lshl_b32 %[t2], %[t2], 4\n" \
 							"  s_add_u32 %[t0], %[t0], %[t2]\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
 							"  ds_read_u16 v52, v52\n" \
 							"  s_lshr_b32 %[t0], %[pk1], 16\n"      /* free list: where the slot id goes */ \
 							"  s_lshl_b32 %[t0], %[t0], 1\n" \
-							"  s_lshl_b32 %[t3], %[t3], 5\n" \
+							"  s_and_b32 %[t3], %[lay], 0xffff\n" \
+							"  s_lshl_b32 %[t3], %[t3], 4\n" \
 							"  s_add_u32 %[t0], %[t0], %[t3]\n" \
 							"  v_mov_b32 v53, %[t0]\n" \
 							"  s_add_u32 %[pk1], %[pk1], 0x10000\n" \
@@ -678,7 +676,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_cmp_lg_u32 %[budget], 0\n"          /* (the VERTEXes' budget counts ring slots too) */ \
 							"  s_cselect_b32 %[t0], 1, 0\n" \
 							"  s_sub_u32 %[budget], %[budget], %[t0]\n" \
-							"  s_sub_u32 %[t0], %[clbase], 1056\n" \
+							"  s_lshr_b32 %[t0], %[lay], 15\n"          /* cold[] sits behind the DELAY stack: 16*(2*DL16 - FL16) (the layout word: FL16 | DL16 << 16, FL16 < 2^15) */ \
+							"  s_and_b32 %[t1], %[lay], 0xffff\n" \
+							"  s_sub_u32 %[t0], %[t0], %[t1]\n" \
+							"  s_lshl_b32 %[t0], %[t0], 4\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
 							"  ds_read2_b32 v[56:57], v52 offset0:3 offset1:4\n" \
 							"  ds_read2_b32 v[58:59], v52 offset0:5 offset1:6\n" \
@@ -696,9 +697,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  ds_write_b32 v52, v53 offset:12\n"     /* the cursor moves on */ \
 							"  s_lshr_b32 %[t1], %[t0], 5\n" \
 							"  s_lshl_b32 %[t1], %[t1], 2\n" \
-							"  s_add_u32 %[t1], %[t1], %[clbase]\n" \
-							"  s_sub_u32 %[t1], %[t1], 1024\n" \
-							"  v_mov_b32 v54, %[t1]\n" \
+							"  v_add_u32 v54, %[t1], v52\n"               /* (v52: cold[]; the staged words start 32 bytes above it) */ \
+							"  v_add_u32 v54, 32, v54\n" \
 							"  ds_read2_b32 v[56:57], v54 offset1:1\n" \
 							"  s_and_b32 %[t0], %[t0], 31\n" \
 							"  s_sub_u32 %[t2], 64, %[t2]\n" \
@@ -778,8 +778,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							  [nc] "+s"(nc), [ncnext] "+s"(nc_next), [ncv1] "+s"(nc_v1), \
 							  [t0] "=&s"(t0_), [t1] "=&s"(t1_), [t2] "=&s"(t2_), [c] "=&s"(c_), [t3] "=&s"(t3_), [budget] "+s"(budget_), \
 							  [pk1] "+s"(pk1), [pk2] "+s"(pk2), [qpos] "+s"(qpos) \
-							: [mask] "s"(MASK), [end] "s"(end), [wbias] "s"(wbias), [slideat] "s"(slide_at), \
-							  [clbase] "s"((uint32_t)(uintptr_t)cl32), [predb] "s"(predb), [faceb] "s"(faceb) \
+							: [mask] "s"(MASK), [end] "s"(end), [clw] "s"(clw), [slideat] "s"(slide_at), \
+							  [lay] "s"(lay), [predb] "s"(predb), [faceb] "s"(faceb) \
 							: "memory", "scc", "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
 							  "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99" TOPO_ASM_STAMP_CLOBBERS);
 
@@ -974,9 +974,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_lshlrev_b32 v40, 1, v60\n" \
 	"  v_add_u32 v40, %[cler], v40\n"                /* p = cler + 2j: the pair's first symbol */ \
 	"  v_lshrrev_b32 v41, 3, v40\n" \
-	"  v_add_u32 v41, %[wbias], v41\n" \
 	"  v_lshlrev_b32 v41, 2, v41\n" \
-	"  v_add_u32 v41, %[clbase], v41\n" \
+	"  v_add_u32 v41, %[clw], v41\n" \
 	"  v_add_u32 v41, -4, v41\n"                     /* (the word of symbol p is cl32[(p >> 3) + wbias - 1]) */ \
 	"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
 	"  v_add_u32 v44, %[ep], v60\n" \
@@ -1171,9 +1170,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = j */ \
 	"  v_add_u32 v40, %[cler], v60\n"                /* p = cler + j: the lane's symbol */ \
 	"  v_lshrrev_b32 v41, 3, v40\n" \
-	"  v_add_u32 v41, %[wbias], v41\n" \
 	"  v_lshlrev_b32 v41, 2, v41\n" \
-	"  v_add_u32 v41, %[clbase], v41\n" \
+	"  v_add_u32 v41, %[clw], v41\n" \
 	"  v_add_u32 v41, -4, v41\n" \
 	"  ds_read2_b32 v[42:43], v41 offset1:1\n"       /* the word holding symbol p and the next one */ \
 	"  v_add_u32 v44, %[ep], v60\n" \
@@ -1378,8 +1376,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_cbranch_scc1 Lmixr2_%=\n" \
 	"  s_lshr_b32 %[c], %[pk1], 16\n" \
 	"  s_lshl_b32 %[c], %[c], 1\n" \
-	"  s_add_u32 %[t3], %[mask], 1\n" \
-	"  s_lshl_b32 %[t3], %[t3], 5\n" \
+	"  s_and_b32 %[t3], %[lay], 0xffff\n" \
+	"  s_lshl_b32 %[t3], %[t3], 4\n" \
 	"  s_add_u32 %[c], %[c], %[t3]\n" \
 	"  v_mov_b32 v40, %[c]\n" \
 	"  v_mov_b32 v41, s96\n" \
@@ -1430,9 +1428,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_mbcnt_hi_u32_b32 v60, -1, v60\n"            /* v60 = lane */ \
 	"  v_add_u32 v40, %[cler], v60\n"                /* lane j: symbol cler + j */ \
 	"  v_lshrrev_b32 v41, 3, v40\n" \
-	"  v_add_u32 v41, %[wbias], v41\n" \
 	"  v_lshlrev_b32 v41, 2, v41\n" \
-	"  v_add_u32 v41, %[clbase], v41\n" \
+	"  v_add_u32 v41, %[clw], v41\n" \
 	"  v_add_u32 v41, -4, v41\n" \
 	"  ds_read2_b32 v[42:43], v41 offset1:1\n" \
 	"  v_add_u32 v61, %[qpos], v60\n"                /* lane i: queue entry qpos + i */ \
@@ -1463,8 +1460,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_min_u32 %[t0], %[t0], %[t1]\n"              /* k = min(symbols, live gates - 1, pool room, DELAY room) */ \
 	"  s_lshr_b32 %[t1], %[pk1], 16\n"               /* free-list fill */ \
 	"  s_and_b32 %[t3], %[pk1], 0xffff\n"            /* bump pointer */ \
-	"  s_add_u32 %[c], %[mask], 1\n" \
-	"  s_lshl_b32 %[c], %[c], 1\n" \
+	"  s_and_b32 %[c], %[lay], 0xffff\n"             /* ring + pool slots */ \
 	"  s_sub_u32 %[c], %[c], %[t3]\n" \
 	"  s_add_u32 %[c], %[c], %[t1]\n" \
 	"  s_min_u32 %[t0], %[t0], %[c]\n" \
@@ -1488,8 +1484,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_sub_u32 v47, %[t1], v38\n" \
 	"  v_add_u32 v47, -1, v47\n" \
 	"  v_lshlrev_b32 v47, 1, v47\n" \
-	"  s_add_u32 %[c], %[mask], 1\n" \
-	"  s_lshl_b32 %[c], %[c], 5\n" \
+	"  s_and_b32 %[c], %[lay], 0xffff\n" \
+	"  s_lshl_b32 %[c], %[c], 4\n" \
 	"  v_add_u32 v47, %[c], v47\n" \
 	"  s_mov_b64 exec, vcc\n" \
 	"  ds_read_u16 v47, v47\n" \
@@ -1505,8 +1501,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_or_b32 v50, 0xf0000000, v47\n" \
 	"  ds_write_b32 v61, v50\n" \
 	"  s_mov_b64 exec, -1\n" \
-	"  s_add_u32 %[c], %[mask], 1\n" \
-	"  s_lshl_b32 %[c], %[c], 1\n" \
+	"  s_and_b32 %[c], %[lay], 0xffff\n" \
 	"  s_sub_u32 %[c], %[c], 1\n"                    /* (links are slot ids below ring + pool; a lazy 0xffff is clamped) */ \
 	"  v_and_b32 v48, 0xffff, v59\n" \
 	"  v_lshrrev_b32 v49, 16, v59\n" \
@@ -1552,8 +1547,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_lshrrev_b32 v33, 8, v46\n"                  /* a DELAY's place on the stack */ \
 	"  v_add_u32 v33, %[t2], v33\n" \
 	"  v_lshlrev_b32 v33, 1, v33\n" \
-	"  s_add_u32 %[c], %[mask], 1\n" \
-	"  s_mul_i32 %[c], %[c], 34\n" \
+	"  s_lshr_b32 %[c], %[lay], 16\n" \
+	"  s_lshl_b32 %[c], %[c], 4\n" \
 	"  v_add_u32 v33, %[c], v33\n" \
 	"  s_and_b64 exec, exec, vcc\n" \
 	"  ds_write_b16 v33, v47\n" \
@@ -1636,9 +1631,12 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	const uint32_t nspl = J.split_nwords < TOPO_SPLIT_LDS ? J.split_nwords : TOPO_SPLIT_LDS;   // waits ~2 us (the load, and every store in flight before it)
 	CRT_GLOBAL const uint8_t *gcl = as_global(J.clers);
 	const uint32_t nclers = J.nclers, symwords = SYMW/8;
-	// the ISA block addresses records from LDS address 0 and finds the free list and the DELAY stack behind ring + pool records with
-	// pool = ring (topo_lds_geometry): anything else takes the HBM path
-	if((uint32_t)(uintptr_t)rec != 0u || POOL != RING || dcap > 0xFFFFu || RING + POOL > 0xFFFFu) return false;
+	// the ISA block addresses records from LDS address 0 and finds the free list and the DELAY stack through the layout word (round 5: the pool
+	// is sized on its own - rounds 2-4 had pool = ring, and a mesh whose boundary asked for 700 pool slots paid for a ring of 1 024 it used 120 of):
+	// FL16 | DL16 << 16 = where they start, in 16-byte units (FL16 = ring + pool is also the number of slots); cold[] sits one (equally long)
+	// DELAY stack behind DL16: anything else takes the HBM path
+	if((uint32_t)(uintptr_t)rec != 0u || dcap != POOL || (POOL & 7u) || RING + POOL > 0x7FFFu || (RING & MASK)) return false;
+	const uint32_t lay = (RING + POOL) | (RING + POOL + (POOL >> 3)) << 16;
 	// automaton state, alive across window refills (uniform: only lane 0 ever changes it)
 	CRT_GLOBAL const uint32_t *split = as_global(J.split_words);
 	CRT_GLOBAL uint8_t *predb = (CRT_GLOBAL uint8_t *)as_global(J.pred);   // prediction triple of vertex vc at byte 12*vc (vertices are numbered in creation order)
@@ -1688,6 +1686,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	__builtin_amdgcn_s_setprio(3);                                      // the serial chain of the whole batch: ahead of any co-resident kernel's waves
 	uint32_t sw = TOPO_S(cl32[0]), swn = TOPO_S(cl32[1]);   // TOPO_S: a value lane 0 alone computes is uniform by construction; tell the compiler (SGPR)
 	uint32_t wbias = 1, slide_at = SYMW < nclers ? SYMW - 2048u : 0xFFFFFFFFu;   // next symbol word = cl32[(cler >> 3) + wbias]; slide when cler gets here
+	uint32_t clw = (uint32_t)(uintptr_t)cl32 + 4u*wbias;                        // ... at LDS byte address clw + 4*(cler >> 3) (the ISA block's one operand for both)
 	{
 		{
 #define TOPO_BITS(dst, n) do { uint64_t bit_ = (uint64_t)cold[K_BIT_LO] | (uint64_t)cold[K_BIT_HI] << 32; if(bit_ + (n) > bit_end) { err = 1; dst = 0; } \
@@ -1699,7 +1698,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	// slide the symbol window up to the current symbol (whole wave, TOPO_FILL_WINDOW) and reload the two window registers
 #define TOPO_SLIDE() do { winbase = cler & ~31u; TOPO_FILL_WINDOW(winbase); \
 	{ const uint32_t wi_ = (cler - winbase) >> 3; const uint64_t w2_ = ((uint64_t)TOPO_S(cl32[wi_]) | (uint64_t)TOPO_S(cl32[wi_ + 1]) << 32) >> (4*(cler & 7u)); sw = (uint32_t)w2_; swn = (uint32_t)(w2_ >> 32); } \
-	wbias = 1u - (winbase >> 3); slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu; } while(0)
+	wbias = 1u - (winbase >> 3); clw = (uint32_t)(uintptr_t)cl32 + 4u*wbias; slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu; } while(0)
 // (sw, swn) = the 64 bits of the current symbol word and the next one, shifted down to the current symbol: sw always holds EIGHT symbols
 #define TOPO_SYMBOL(c) do { c = sw & 0xFu; sw = sw >> 4 | swn << 28; swn >>= 4; cler++; if((cler & 7u) == 0) swn = TOPO_S(cl32[(cler >> 3) + wbias]); } while(0)
 	// a deleted survivor goes back to the pool, unless it still sits in the DELAY stack (then the pop returns it)
@@ -1923,7 +1922,7 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 	if(!done) {                                                          // thread 0 only: redo the blob with the front in HBM
 		GlobalFront F{(CRT_GLOBAL u32x4 *)as_global(J.front_a), (CRT_GLOBAL u32x2 *)as_global(J.front_b), as_global(J.order), as_global(J.delayed)};
 		const uint32_t need = topo_run(J, as_global(J.clers), F);
-		*as_global(J.flags) = (int32_t)(1u | (need < (1u << 24) ? need : (1u << 24) - 1u) << 1);   // bit 0: redone; above it: the slots it would have needed in LDS
+		*as_global(J.flags) = (int32_t)(1u | need << 1);                    // bit 0: redone; above it: the ring slots (15 bits) and the pool slots (15 bits) it would have needed in LDS
 	}
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_plan.h"
 
 namespace corto_hip {
@@ -44,25 +46,33 @@ inline uint32_t topo_lds_bytes(uint32_t ring, uint32_t pool, uint32_t dcap, uint
 	return (ring + pool)*16 + ((pool + 7) & ~7u)*2 + ((dcap + 7) & ~7u)*2 + symwin/2 + 8 + 32 + TOPO_SPLIT_LDS*4 + 16;
 }
 constexpr uint32_t TOPO_SYMWIN_MAX = 8192;
-// The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the ring gets `slots`*sqrt(nface)
-// rounded up to a power of two (at least 256, at most `ring_max`), the pool as much again (it also holds every edge of the mesh's own
-// boundary for good).  What does not fit - a torus' queue is ten times a sphere's, a ribbon is all boundary - is redone on the HBM front.
-// `scale` (a power of two) multiplies both: the context raises it after a batch whose blobs fell back (batch.cpp).
+// The queue of a sphere-like mesh peaks near 3*sqrt(nface) (189 for 4 096 faces, 1 497 for 256 000): the RING gets `slots`*sqrt(nface) rounded up to a
+// power of two (at least 256, at most `ring_max`) times what the context has learnt (`ring_scale`, a power of two: a torus' queue is ten times a sphere's).
+// The POOL is sized on its own (round 5; rounds 2-4 had pool = ring): it keeps every edge that got a BOUNDARY for good and every DELAYed one while it
+// waits, and how many boundary edges a mesh has is in the header - B = 2V - F - 2*chi for a manifold mesh (Euler: V - E + F = chi, 2E = 3F + B), 128 for
+// the C4 unit, ~V for a ribbon or for confetti of one-face components.  That is a floor (the encoder also writes BOUNDARY where a front meets faces it
+// has been to, and the DELAYed edges come on top: Delaunay discs with holes hold 2-2.5x as many), so the context learns a factor for it too (`pool_q8`,
+// in eighths) from what redone blobs report.  What does not fit is redone on the HBM front.
 // slots = 8 for a few big meshes (LDS is not contended: leave room), 4 for a batch of many blobs: a 4K-triangle blob then takes 12.5 KB,
 // and that it is NOT MORE THAN THE 16 KB of a K-STREAM wave matters more than the size itself: the automaton's workgroups are dispatched
 // while the attribute streams' 2 000 waves fill every CU ten to a CU, and a 16 KB hole opens whenever one of those ends - a 22 KB
 // request waits for two neighbouring ones (0.237 -> 0.200 ms per C4 batch unpipelined, +5 % pipelined).
-// Round 5: the pool keeps every edge of the mesh's own boundary for good, and how many those are is in the header: a manifold mesh has
-// B = 2V - F - 2*chi boundary edges (Euler: V - E + F = chi, 2E = 3F + B), so 2V - F (+ slack for handles and the DELAYed edges in flight)
-// bounds what the pool must hold - 128 for the C4 unit, ~V for a ribbon or for confetti of one-face components, which no multiple of
-// sqrt(nface) covers (tools/stress_topology.py: strips, confetti and holey discs fell back on EVERY decode, whatever the context had learnt).
 inline uint32_t topo_boundary_estimate(uint32_t nvert, uint32_t nface) { const uint64_t v2 = 2ull*nvert; return v2 <= nface ? 0u : v2 - nface > (1u << 20) ? (1u << 20) : (uint32_t)(v2 - nface); }
-inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t scale, uint32_t slots, uint32_t boundary, uint32_t &ring, uint32_t &pool, uint32_t &symwin) {
+// `pool_cap` (0: none): the most pool slots any redone blob has reported (+ an eighth) - a launch's LDS request is its largest blob's, so the factor is
+// not applied beyond what the neediest blob seen so far would have needed
+inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max, uint32_t ring_scale, uint32_t pool_q8, uint32_t slots, uint32_t boundary,
+                              uint32_t &ring, uint32_t &pool, uint32_t &symwin, uint32_t pool_cap = 0) {
 	uint32_t want = 256;
 	while((uint64_t)want*want < (uint64_t)slots*slots*nface && want < ring_max) want <<= 1;
-	while(want < boundary + boundary/8 + 48 && want < ring_max) want <<= 1;      // (pool = ring in the ISA block: both grow)
-	while(scale > 1 && want < ring_max) { want <<= 1; scale >>= 1; }             // what the context has learnt multiplies either estimate
-	ring = want; pool = want;
+	const uint32_t base = want;
+	while(ring_scale > 1 && want < ring_max) { want <<= 1; ring_scale >>= 1; }
+	ring = want;
+	uint64_t p = std::max<uint64_t>(base, (uint64_t)boundary + boundary/8 + 48);
+	const uint64_t p1 = p;
+	p = (p*pool_q8 + 7)/8;
+	if(pool_cap && p > pool_cap) p = std::max<uint64_t>(p1, pool_cap);
+	p = (p + 63) & ~63ull;                                                        // (whole 16-byte vectors of free-list and DELAY-stack halfwords)
+	pool = (uint32_t)std::min<uint64_t>(p, ring_max);
 	const uint32_t all = (nclers + 64 + 31) & ~31u;       // whole 16-byte vectors of nibbles (k_mesh.hip: TOPO_FILL_WINDOW)
 	symwin = all < TOPO_SYMWIN_MAX ? all : TOPO_SYMWIN_MAX;
 }

@@ -1342,7 +1342,7 @@ def test_topology_lds_slot_overflow_redone_on_hbm_front():
     ctx = ca.Context(0)                      # its own context: the feedback is per context
     meshes = [synth.strip(400, seed=3), synth.bumpy_sphere(24, 12, seed=5), synth.torus(100, 50, seed=4), synth.holey_disc(40, seed=2, color_components=4)]
     blobs = [ca.encode(m, normal_prediction=ca.BORDER) for m in meshes]
-    for u16, scale, fallbacks in ((False, 1, 2), (True, 2, 0), (False, 2, 0)):
+    for u16, scale, fallbacks in ((False, 1, 2), (True, None, 0), (False, None, 0)):
         b = run_batch(ctx, blobs, index16=u16)
         for i in range(len(blobs)):
             exp = oc.decode(blobs[i])
@@ -1351,7 +1351,8 @@ def test_topology_lds_slot_overflow_redone_on_hbm_front():
             assert_same(b.host_outputs(i), exp, KEYS, "blob %d u16=%s" % (i, u16))
         # first pass: the torus (queue of 3 800) and the holey disc (each hole adds boundary the header does not show); the ribbon's 800 boundary
         # edges are in the header (2V - F, kernels.h: topo_boundary_estimate) and its pool is planned for them from the start (round 5)
-        assert (b.stats().topology_scale, b.stats().topology_fallbacks) == (scale, fallbacks), (b.stats().topology_scale, b.stats().topology_fallbacks)
+        # (later passes: ring and pool each by the factor the redone blobs reported - the torus' queue four-fold, the disc's pool 2-3 x; `topology_scale` is the larger)
+        assert b.stats().topology_fallbacks == fallbacks and (b.stats().topology_scale == scale if scale else 2 <= b.stats().topology_scale <= 4), (b.stats().topology_scale, b.stats().topology_fallbacks)
         b.close()
     ctx.close()
 
