@@ -123,6 +123,26 @@ def first_iteration(blobs_path_seed=0):
         return {"error": repr(e)[:300]}
 
 
+def gpu_numa_cpus(torch, ndev):
+    """the host CPUs next to each visible GPU (PCI bus id -> sysfs numa_node -> cpulist), [] where sysfs does not say: what crthip_pool pins its
+    threads to, known here BEFORE any pool exists so that the threads per GPU can be sized for the GPUs that share a socket"""
+    out = []
+    for i in range(ndev):
+        cpus = []
+        try:
+            pr = torch.cuda.get_device_properties(i)
+            bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read().strip())
+            if node >= 0:
+                for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus += list(range(int(a), int(b or a) + 1))
+        except Exception:                                       # noqa: BLE001  (no sysfs entry, an older torch: unknown)
+            cpus = []
+        out.append(cpus)
+    return out
+
+
 def window_stats(stamps, lanes, nwin=20):
     """best and median ms per step over up to `nwin` consecutive windows of the timed steps' completion times (a window is at least
     four rounds of the pool's contexts: completions come in bursts of about one per context)"""
@@ -501,11 +521,11 @@ def main():
     # the single-GPU characterisations - reference decoder on the host's cores, Tunstall at roofline scale, the single-object configs, the
     # drop-in class, irregular / realistic batches - belong to the N = 1 line (the task: `cpu_baseline` on rank 0 at N = 1 only); an N > 1
     # run is the scaling measurement and skips them unless asked (--all-legs): the other ranks would only wait at a barrier meanwhile
+    from corto_amd import shard
     n1_only_skipped = False
     if n_gpus > 1 and not args.all_legs:
         args.no_cpu = args.no_tunstall_scaled = args.no_other_configs = True
         n1_only_skipped = True
-    from corto_amd import shard
     # C5 = n_gpus x 256 blobs cut into contiguous work-balanced ranges (one work item each); seeds 256*g .. 256*g+255 for range g
     ranges = shard.balanced_ranges([4096 + 2112] * (NBLOBS * n_gpus), n_gpus)
     z = None
@@ -517,6 +537,14 @@ def main():
         items.append(blobs_g)
     blobs = items[0]
     depth, nthreads = max(1, args.depth), max(1, args.host_threads)
+    # host threads per GPU, sized for the GPUs that share a NUMA node (8 GPUs on two sockets: 4 x threads feeder threads a socket) and for this
+    # process' cpuset - a pool that time-shares its feeder threads measures the host; refused loudly when a GPU cannot get one core
+    numa = gpu_numa_cpus(torch, ndev)
+    phys = sorted(set(range(n_gpus if not share else ndev)) & set(range(ndev))) if world > 1 else sorted(set(devices))
+    plan_t, threads_note = shard.plan_host_threads(nthreads, [numa[d] for d in phys], sorted(os.sched_getaffinity(0)))
+    if min(plan_t) < nthreads:
+        nthreads = min(plan_t)
+        print("bench.py: " + threads_note, file=sys.stderr)
     # compressed inputs resident in HBM before the timed region: item j on ITS pool device (j % N: crthip_pool's home-shard-first policy) -
     # sharding, not replication; a device asked to decode another's item would upload it inside the step
     arenas = [[ca.upload_arena(it, d) if k == j % len(devices) else None for k, d in enumerate(devices)] for j, it in enumerate(items)]
@@ -861,9 +889,7 @@ def main():
             alone = rep_1.triangles / rep_1.elapsed_s / 1e6
             pool_1.close()
         barrier()
-        scaling_block = {"per_gpu_mtri_per_s": per_gpu, "one_gpu_alone_mtri_per_s": round(alone, 2) if alone else None,
-                         "note": "per-GPU rate of the timed steps; one_gpu_alone: GPU 0 with the same pool shape and timed region while the other GPUs idle "
-                                 "(measured behind the main run, the main pool closed); efficiency_vs_1gpu = value / (n_gpus x one_gpu_alone)"}
+        scaling_block = {"per_gpu": per_gpu, "alone": alone}                       # (shard.scaling_report, once `value` is known)
     tris_total = shard.sum_over_ranks(float(rep.triangles), dist, red_dev) / R     # (per K-step region)
     verts_total = shard.sum_over_ranks(float(rep.vertices), dist, red_dev) / R
     tris_h = shard.sum_over_ranks(float(rep_h.triangles), dist, red_dev)
@@ -904,12 +930,12 @@ def main():
                                        "(barrier + device sync before the warm-up and after the drain); K < 100: ~2000/K such regions back to back, the median one reported (timed_regions); "
                                        "the rate with the compressed inputs already resident in HBM (rounds 1-3's `value`) is `resident_inputs`",
                        "h2d_bytes_per_step": int(stats0.arena_bytes), "pcie_GBps": round(stats0.arena_bytes / (ms_step * 1e-3) / 1e9, 2),
-                       "pipeline_depth": depth, "host_threads": nthreads, "launch": mode,
+                       "pipeline_depth": depth, "host_threads": nthreads, "host_threads_note": threads_note or None, "launch": mode,
                        "parallelism": "blob-sharded x%d, no collective; %s; %d native host threads x %d batches in flight per GPU" % (
                            n_gpus, "one process, one work queue over all GPUs" if world == 1 else "one process per GPU, RCCL only for barrier/max", nthreads, depth)},
             "bit_exact": True, "bit_exact_blobs_checked": checked, "topology_fallbacks": int(rep.topology_fallbacks),
             "steps_per_device": steps_per_device, "per_gpu_mtri_per_s": per_gpu, "numa_local_input_buffers": numa_local_inputs,
-            "scaling_report": scaling_block,
+            "scaling_report": None,
             "steady_state": window_stats(stamps, pool_lanes),
             "resident_inputs": {"mtri_per_s": round(tris_res / elapsed_res / 1e6, 2), "mverts_per_s": round(tris_res / elapsed_res / 1e6 * nvert / ntri, 2),
                                 "ms_per_step": round(elapsed_res / args.steps * 1e3, 4), "regions_ms_per_step": [round(e / args.steps * 1e3, 4) for e in regions_res],
@@ -955,9 +981,8 @@ def main():
             "kernels": kernels,
             "hbm_ceiling": hbm_ceiling(torch),
         }
-        if scaling_block and scaling_block["one_gpu_alone_mtri_per_s"]:
-            scaling_block["efficiency_vs_1gpu"] = round(out["value"] / (n_gpus * scaling_block["one_gpu_alone_mtri_per_s"]), 4)
-            scaling_block["host_us_per_step_per_thread"] = out["host_us_per_step_per_thread"]
+        if scaling_block:
+            out["scaling_report"] = shard.scaling_report(out["value"], n_gpus, scaling_block["per_gpu"], scaling_block["alone"], out["host_us_per_step_per_thread"])
         if n1_only_skipped:
             out["n1_only_legs"] = "skipped (cpu_baseline, tunstall_scaled, other_configs, irregular / realistic: see the N = 1 line; --all-legs runs them)"
         if share:
@@ -973,6 +998,7 @@ def main():
             out["vs_cpu_1core"] = round(out["value"] / n_gpus / out["cpu_baseline"]["value"], 2)
             if "facade_per_blob" in out:
                 out["facade_per_blob"]["cpu_reference_us"] = round(4096 / out["cpu_baseline"]["value"], 1)
+        shard.check_bench_line(out, n_gpus)                                   # the contract the driver parses (corto_amd/shard.py; tests/test_sharding_cpu.py runs it on an N = 8 line)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -67,3 +67,58 @@ def test_two_ranks_gloo():
     assert (a0, b0, a1, b1) == (0, 8, 8, 16)                     # 16 equal blobs -> two halves, no overlap
     assert m0 == m1 == max(e0, e1)                               # every rank sees the slowest rank's time
     assert t0 == t1 == 16 * 4096                                 # whole-job work is the sum over ranks
+
+
+def test_host_threads_are_sized_for_the_gpus_that_share_a_socket():
+    """bench.py --gpus 8: five feeder threads a GPU are 40 threads on two sockets - fine on a 2 x 128-core host, too many for a cpuset of 16; the
+    plan gives every GPU of a NUMA node an equal share of that node's usable CPUs (one kept back), and refuses when a GPU could not get one"""
+    node0, node1 = list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))
+    gpus = [node0] * 4 + [node1] * 4
+    t, note = shard.plan_host_threads(5, gpus, range(256))
+    assert t == [5] * 8 and note == ""
+    t, note = shard.plan_host_threads(5, gpus, list(range(0, 8)) + list(range(64, 72)))       # a cpuset of 8 + 8 CPUs: (8 - 1) // 4 = 1 thread a GPU
+    assert t == [1] * 8 and "instead of 5" in note
+    t, _ = shard.plan_host_threads(5, gpus[:1], range(256))
+    assert t == [5]
+    t, _ = shard.plan_host_threads(6, [[]] * 2, range(12))                                     # NUMA unknown: the process' CPUs shared by all GPUs
+    assert t == [5, 5]
+    t, note = shard.plan_host_threads(5, gpus, range(0, 24))                                   # node 1's CPUs are outside the cpuset: its GPUs' threads run unpinned on the same 24 as node 0's
+    assert t == [2] * 8 and "instead of 5" in note
+    with pytest.raises(ValueError, match="not one feeder thread"):
+        shard.plan_host_threads(5, gpus, range(0, 4))
+    with pytest.raises(ValueError):
+        shard.plan_host_threads(0, gpus, range(256))
+
+
+def _canned_line(n_gpus):
+    """a bench line as bench.py assembles it, from the last driver-run record's numbers"""
+    import json
+    rec = json.load(open(os.path.join(ROOT, "BENCH_r04.json")))["parsed"]
+    line = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")}
+    if n_gpus > 1:
+        per_gpu = [line["value"] * (0.93 + 0.01 * g) for g in range(n_gpus)]
+        line.update(n_gpus=n_gpus, value=round(sum(per_gpu), 2), ms_per_step=line["ms_per_step"] / 0.96)
+        del line["cpu_baseline"]
+        line["scaling_report"] = shard.scaling_report(line["value"], n_gpus, per_gpu, rec["value"], 190.0)
+    return line
+
+
+def test_bench_line_contract_at_one_and_eight_gpus():
+    """what the driver parses: shard.check_bench_line (bench.py runs it on every line it prints) on an N = 1 line and on the N = 8 line assembled from
+    eight per-GPU rates - schema, roofline arithmetic, the scaling report's one rate per GPU adding up to `value`, efficiency against the N = 1 rate"""
+    one = _canned_line(1)
+    shard.check_bench_line(one, 1)
+    eight = _canned_line(8)
+    shard.check_bench_line(eight, 8)
+    sr = eight["scaling_report"]
+    assert len(sr["per_gpu_mtri_per_s"]) == 8 and 0.9 < sr["efficiency_vs_1gpu"] < 1.01 and sr["slowest_over_fastest_gpu"] < 1
+    assert abs(sr["efficiency_vs_1gpu"] - eight["value"] / (8 * one["value"])) < 1e-3
+    for breakage in (lambda l: l.pop("roofline"), lambda l: l.update(scaling="strong"), lambda l: l["config"].update(model="x"), lambda l: l.update(n_gpus=4),
+                     lambda l: l["scaling_report"]["per_gpu_mtri_per_s"].pop(), lambda l: l.update(cpu_baseline={}), lambda l: l.update(value=0)):
+        import copy
+        bad = copy.deepcopy(eight)
+        breakage(bad)
+        with pytest.raises(ValueError):
+            shard.check_bench_line(bad, 8)
+    with pytest.raises(ValueError):
+        shard.scaling_report(1.0, 8, [1.0] * 7, 1.0)
