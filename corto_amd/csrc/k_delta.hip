@@ -41,6 +41,7 @@ __device__ __forceinline__ int32_t sx16(uint32_t w) { return (int32_t)(int16_t)(
 // ---- values in LDS: K = 1, 2, 3, 4 int16 components (records of 2, 4, 8, 8 bytes), K = 5: four bytes (colours) ----
 template <int K> struct LdsVal;
 template <> struct LdsVal<1> {
+	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 1; static constexpr bool CHECK = true; typedef uint32_t Raw;
 	CRT_LDS uint16_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -50,6 +51,7 @@ template <> struct LdsVal<1> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsVal<2> {
+	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 2; static constexpr bool CHECK = true; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -58,7 +60,8 @@ template <> struct LdsVal<2> {
 	__device__ __forceinline__ static int32_t wrap(int32_t v) { return sx16((uint32_t)v); }
 	__device__ __forceinline__ void sync() const {}
 };
-template <> struct LdsVal<3> {                                // x | y << 16, z | a << 16: the spare halfword carries the graph's `a`
+template <> struct LdsVal<3> {
+	static constexpr bool CHECK_OR_WIDE = true;                                // x | y << 16, z | a << 16: the spare halfword carries the graph's `a`
 	static constexpr int NC = 3; static constexpr bool CHECK = true; typedef u32x2 Raw;
 	CRT_LDS u32x2 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -70,6 +73,7 @@ template <> struct LdsVal<3> {                                // x | y << 16, z 
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsVal<4> {
+	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 4; static constexpr bool CHECK = true; typedef u32x2 Raw;
 	CRT_LDS u32x2 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -80,7 +84,8 @@ template <> struct LdsVal<4> {
 	__device__ __forceinline__ static int32_t wrap(int32_t v) { return sx16((uint32_t)v); }
 	__device__ __forceinline__ void sync() const {}
 };
-template <> struct LdsVal<5> {                                // bytes, mod 256 (ColorAttr: uchar arithmetic)
+template <> struct LdsVal<5> {
+	static constexpr bool CHECK_OR_WIDE = false;          // (mod-256 fields: the chain loop's 32-bit sums in registers are not what the records read back as)                                // bytes, mod 256 (ColorAttr: uchar arithmetic)
 	static constexpr int NC = 4; static constexpr bool CHECK = false; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -96,6 +101,7 @@ template <> struct LdsVal<5> {                                // bytes, mod 256 
 // (v += v[a]: additions only): a pass adds at most 65 bytes into a field, which cannot carry into its neighbour, so two wave scans do the
 // work of four, and nothing is unpacked (mod 256 is taken when the record is stored)
 template <> struct LdsVal<6> {
+	static constexpr bool CHECK_OR_WIDE = false;          // (mod-256 fields: the chain loop's 32-bit sums in registers are not what the records read back as)
 	static constexpr int NC = 2; static constexpr bool CHECK = false; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -110,6 +116,7 @@ template <> struct LdsVal<6> {
 // base, nothing to check); a three-component record's fourth dword carries the graph's `a`.
 template <int K> struct LdsW;
 template <> struct LdsW<1> {
+	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 1; static constexpr bool CHECK = false; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -119,6 +126,7 @@ template <> struct LdsW<1> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsW<2> {
+	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 2; static constexpr bool CHECK = false; typedef u32x2 Raw;
 	CRT_LDS u32x2 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -127,7 +135,8 @@ template <> struct LdsW<2> {
 	__device__ __forceinline__ static int32_t wrap(int32_t v) { return v; }
 	__device__ __forceinline__ void sync() const {}
 };
-template <> struct LdsW<3> {                                  // x, y, z, a
+template <> struct LdsW<3> {
+	static constexpr bool CHECK_OR_WIDE = true;                                  // x, y, z, a
 	static constexpr int NC = 3; static constexpr bool CHECK = false; typedef u32x4 Raw;
 	CRT_LDS u32x4 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -137,6 +146,7 @@ template <> struct LdsW<3> {                                  // x, y, z, a
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsW<4> {
+	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 4; static constexpr bool CHECK = false; typedef u32x4 Raw;
 	CRT_LDS u32x4 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -150,7 +160,7 @@ template <> struct LdsW<4> {
 // N <= 4, int32 or bytes.  One wave owns the attribute (workgroup-scope accesses: the CU's own cache is coherent for it) and a pass's
 // stores are waited for before the next pass reads.
 template <typename T> struct GlobalVal {
-	static constexpr int NC = 4; static constexpr bool CHECK = false;
+	static constexpr int NC = 4; static constexpr bool CHECK = false; static constexpr bool CHECK_OR_WIDE = false;   // (the HBM redo is called without a hand-over)
 	struct Raw { uint32_t v[4]; };
 	CRT_GLOBAL T *p; uint32_t N;                              // N: components of this run (<= 4)
 	uint32_t stride = 0;                                      // elements from one vertex to the next (0: N); p points at the run's first component
@@ -203,7 +213,7 @@ struct GraphLds {
 // window's are n / (lanes going per pass).  At least two heads a pass and at most fourteen lanes going a pass says walk: random diagonals
 // (three heads, 9-11 going: 292 window passes against 24 + 150) - not rings (one head), grids (25-29 going), or holey discs (five to nine
 // heads but 20 going: 80 passes against 24 + 68).  tests/test_delta16_model_cpu.py has the families this was read off.
-struct WindowHand { uint32_t s; uint64_t donew; };
+struct WindowHand { uint32_t s; uint64_t donew; uint32_t mode; };         // mode (s < nvert): 1 the walk, 2 the round loop
 // PARA: parallelogram prediction (b, c are gathered); else v += v[a] alone - the same loop without the two gathers, their unpacking and
 // their ready tests (a third of a pass's vector instructions, for two of a C4 blob's three attributes: the pipelined rate is within 2x of
 // the chip's VALU issue rate)
@@ -219,9 +229,12 @@ __device__ __forceinline__ uint32_t delta_window_loop(const V &val, const GR &gr
 	uint32_t W, A; typename V::Raw D;
 	{ const uint32_t ic = s + lane < nvert ? s + lane : nvert - 1u; graph.fetch(ic, W, A); W &= wmask; D = val.raw(ic); }
 	uint32_t passes = 0, nheads = 0, ngo = 0;
-	if(hand) { hand->s = nvert; hand->donew = 0; }
+	if(hand) { hand->s = nvert; hand->donew = 0; hand->mode = 0; }
 	while(s < nvert) {
-		if(hand && passes == 24u && nheads >= 32u && ngo <= 224u && nvert - s >= 128u) { hand->s = s; hand->donew = donew; break; }
+		if(hand && passes == 24u && nvert - s >= 128u) {
+			if(PARA && V::CHECK_OR_WIDE && ngo < 288u) { hand->s = s; hand->donew = donew; hand->mode = 2; break; }     // fewer than 18 vertices a pass: the round loop
+			if(nheads >= 32u && ngo <= 224u) { hand->s = s; hand->donew = donew; hand->mode = 1; break; }               // (byte records with parallelogram prediction - no encoder writes them: the walk)
+		}
 		const uint32_t i = s + lane;
 		const bool in = i < nvert;
 		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
@@ -404,6 +417,98 @@ template <class V>
 __device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
                                                   const uint32_t nvert, const bool para, const int32_t (&base)[V::NC], const WindowHand hand) {
 	return para ? delta_walk_loop<true>(val, gw, ga, fbits, G, nvert, base, hand) : delta_walk_loop<false>(val, gw, ga, fbits, G, nvert, base, hand);
+}
+
+// ---- the round loop: parents a vertex or two back, by a scan of 2 x 2 affine maps (round 5) ----
+// The window finishes a run of vertices per pass as long as b and c are DONE: on a grid they lie a ring back and a pass takes 30 vertices.  On
+// anything irregular - flipped diagonals, a Delaunay mesh, a decimated or otherwise irregular closed mesh (fans: c = i - 2 or b = i - 2) - they are the
+// vertices just made, a run is 3.5 to 10 vertices, and the window takes hundreds of passes of ~1 100 clocks (a decimated sphere of 2 049 vertices:
+// 584, 0.31 ms); rounds 3-4 walked many stretches at once instead (one vertex a lane and pass: the DAG's depth in passes, 160-180 for a 4K-triangle
+// blob - and 1 772 for the decimated sphere, which is ONE stretch).  But the dependencies that break the window's runs are almost all of ONE kind: a
+// parent ONE or TWO vertices back (measured on every family: a vertex whose nearest in-flight parent lies further back comes once in ~50).  With
+//     v[i] = pre[i] + ca[i] v[i-1] + cb[i] v[i-2]        pre = d[i] + the parents that are final,  ca, cb in {-1 .. 3} = how often i-1 / i-2 is a parent (+a +b -c)
+// the state (v[i], v[i-1]) is an AFFINE function of (v[i-1], v[i-2]) - T_i = [[ca, cb], [1, 0]], translation (pre, 0) - and affine maps compose
+// associatively: an inclusive scan of the maps over 64 lanes (six steps of a 2 x 2 product and a 2 x 2 . vector + vector a component, mod 2^32)
+// leaves v[i] in lane i.  A round takes the vertices from the lowest unfinished one up to the first whose in-flight parent lies more than two back
+// (that one starts the next round, where its parents are final): 43-52 rounds for a 2K-vertex blob of ANY of those families, ~2 000 clocks each.
+// Exact by the same argument as the other loops (sums in 32-bit registers mod 2^32, the stored int16 checked); the linear parts are shared by an
+// attribute's components.  Chosen by what the window's passes 8-23 looked like (WindowHand.mode): fewer than 18 vertices a pass.
+template <class V>
+__device__ __forceinline__ uint32_t delta_round_loop(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, const uint32_t nvert,
+                                                    const int32_t (&base)[V::NC], const WindowHand hand) {
+	constexpr int NC = V::NC;
+	const uint32_t lane = lane_id();
+	uint32_t bad = 0;
+	uint64_t donew = hand.donew;
+	uint32_t s = hand.s;
+	while(s < nvert) {
+		const uint32_t i = s + lane;
+		const bool in = i < nvert;
+		const uint32_t ic = in ? i : nvert - 1u;
+		const uint32_t W = gw[ic], A = ga.get(ic);
+		const typename V::Raw D = val.raw(ic);
+		const bool done_i = __builtin_amdgcn_inverse_ballot_w64(donew);       // the window finished it out of order: its record IS its value
+		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
+		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (W & GW_NO_BC) == GW_NO_BC;
+		const bool self = !in || done_i || stays;                             // no parents to add
+		const uint32_t pa = ch ? ic - 1u : A;
+		// a parent inside the round (>= s) must be one or two back; the first lane with one further back ends the round
+		const uint32_t da = ic - pa, db = ic - b, dc = ic - c;                   // (parents are below the vertex: distances >= 1)
+		const bool na = !self && pa >= s, nb = !self && b >= s, nc = !self && c >= s;
+		const uint64_t cut = __ballot(!in || (na && da > 2u) || (nb && db > 2u) || (nc && dc > 2u));
+		const uint32_t len = cut ? (uint32_t)__builtin_ctzll(cut) : 64u;          // (lane 0 has no parent inside the round: len >= 1)
+		const typename V::Raw Pw = val.raw(self || na ? 0u : pa), Bw = val.raw(self || nb ? 0u : b), Cw = val.raw(self || nc ? 0u : c);
+		int32_t dv[NC], pv[NC], bv[NC], cv[NC];
+		V::unpack(D, dv); V::unpack(Pw, pv); V::unpack(Bw, bv); V::unpack(Cw, cv);
+		// the lane's map: (x, y) -> (ca x + cb y + pre, x)
+		uint32_t m00 = (na && da == 1u ? 1u : 0u) + (nb && db == 1u ? 1u : 0u) - (nc && dc == 1u ? 1u : 0u);
+		uint32_t m01 = (na && da == 2u ? 1u : 0u) + (nb && db == 2u ? 1u : 0u) - (nc && dc == 2u ? 1u : 0u);
+		uint32_t m10 = 1u, m11 = 0u;
+		uint32_t t0[NC], t1[NC];
+#pragma unroll
+		for(int q = 0; q < NC; q++) {
+			t0[q] = (uint32_t)(done_i ? dv[q] : stays ? dv[q] - base[q] : dv[q] + (na ? 0 : pv[q]) + (nb ? 0 : bv[q]) - (nc ? 0 : cv[q]));
+			t1[q] = 0u;
+		}
+		// inclusive scan of the maps (Kogge-Stone): lane l takes the prefix that ends at lane l - o and puts its own behind it
+#pragma unroll
+		for(uint32_t o = 1; o < 64u; o <<= 1) {
+			const int src = (int)((lane - o) << 2);
+			const bool last = o == 32u;                                            // the linear part is not needed behind the last step
+			uint32_t a00 = 0, a01 = 0, a10 = 0, a11 = 0, u0[NC], u1[NC];
+			if(!last) {
+				a00 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m00); a01 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m01);
+				a10 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m10); a11 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m11);
+			}
+#pragma unroll
+			for(int q = 0; q < NC; q++) { u0[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)t0[q]); u1[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)t1[q]); }
+			if(lane >= o) {
+#pragma unroll
+				for(int q = 0; q < NC; q++) {
+					const uint32_t n0 = m00*u0[q] + m01*u1[q] + t0[q], n1 = m10*u0[q] + m11*u1[q] + t1[q];
+					t0[q] = n0; t1[q] = n1;
+				}
+				if(!last) {
+					const uint32_t n00 = m00*a00 + m01*a10, n01 = m00*a01 + m01*a11, n10 = m10*a00 + m11*a10, n11 = m10*a01 + m11*a11;
+					m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+				}
+			}
+		}
+		if(lane < len && !done_i) {
+			int32_t r[NC];
+#pragma unroll
+			for(int q = 0; q < NC; q++) r[q] = (int32_t)t0[q];
+			if(V::CHECK) {
+#pragma unroll
+				for(int q = 0; q < NC; q++) bad |= (uint32_t)r[q] + 0x8000u;
+			}
+			val.store(i, r, A);
+		}
+		val.sync();
+		s += len;
+		donew = len < 64u ? donew >> len : 0ull;
+	}
+	return bad;
 }
 
 // ---- staging: raw int32 deltas in HBM -> int16 records (checked); results back as the int32 / float the caller wants ----
@@ -602,7 +707,8 @@ __device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob
 	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
 	WindowHand hand;
 	bad |= delta_window_run(val, GraphLds{gw, ga}, nvert, para, base, &hand);
-	if(hand.s < nvert) {
+	if(hand.s < nvert && hand.mode == 2) bad |= delta_round_loop(val, gw, ga, nvert, base, hand);
+	else if(hand.s < nvert) {
 		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
 		bad |= delta_walk_run(val, gw, ga, fbits, starts, nvert, para, base, hand);
 	}
@@ -622,7 +728,8 @@ __device__ __forceinline__ void delta32_run(CRT_LDS uint8_t *rec, const DeltaJob
 	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
 	WindowHand hand;
 	(void)delta_window_run(val, GraphLds{gw, ga}, nvert, para, zero, &hand);
-	if(hand.s < nvert) {
+	if(hand.s < nvert && hand.mode == 2) (void)delta_round_loop(val, gw, ga, nvert, zero, hand);
+	else if(hand.s < nvert) {
 		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
 		(void)delta_walk_run(val, gw, ga, fbits, starts, nvert, para, zero, hand);
 	}
