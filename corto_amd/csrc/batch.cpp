@@ -990,7 +990,7 @@ int Planner::jobs() {
 				if(mesh) {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
-					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = wide;                   // pad[1]: 32-bit records in LDS (k_delta_lds16)
+					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = wide; d.pad2[0] = ctx->dbg.delta_rounds ? 1u : 0u;                   // pad[1]: 32-bit records in LDS (k_delta_lds16)
 					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
 					d.flags = HS(2ull*nblobs + 2ull*i);
 					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2) {

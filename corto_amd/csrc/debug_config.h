@@ -23,6 +23,8 @@ struct DebugConfig {
 	                                // stream (what a launch of fewer than 64 streams takes anyway); 1: two kernels always
 	int delta_wide = 0;             // $CORTO_DELTA_WIDE=1: K-DELTA keeps 32-bit values in LDS from the start (a context otherwise learns it from its first overflowing batch)
 	bool check_pinned = false;      // $CORTO_HIP_CHECK_PINNED=1: a buffer handed over as a packed pinned arena (crthip_ctx_set_packed_host_blobs) is verified to be pinned host memory
+	bool delta_rounds = false;      // $CORTO_DELTA_ROUNDS=1 (test hook): K-DELTA's round loop from vertex 1 for every attribute - int16, 32-bit and byte records, with and
+	                                // without parallelogram prediction - instead of after 24 slow window passes (tests/test_gpu_parity.py runs every fixture through it)
 	bool unpack_chunked = false;    // $CORTO_UNPACK_CHUNKED=1 (test hook): every bit block through the chunked K-BIT with its look-back - the kernel of big meshes -
 	                                // however small (tests/test_gpu_parity.py runs ragged sizes through both)
 };
@@ -34,6 +36,7 @@ inline DebugConfig debug_config_from_env() {
 	c.delta_wide = on("CORTO_DELTA_WIDE");
 	c.check_pinned = on("CORTO_HIP_CHECK_PINNED");
 	c.unpack_chunked = on("CORTO_UNPACK_CHUNKED");
+	c.delta_rounds = on("CORTO_DELTA_ROUNDS");
 	return c;
 }
 

@@ -15,13 +15,14 @@
 //   Colours are bytes with the reference's mod-256 arithmetic: four to a dword, no base, nothing to check.
 // * The graph is 4 bytes a vertex: b | c << 15 | (a == i-1) << 30 | (value stays) << 31, and `a` as a u16 that rides in the spare
 //   halfword of a three-component attribute's 8-byte records when the group has one.
-// * ONE loop instead of scans + walk: an OUT-OF-ORDER WINDOW.  Lane l looks at vertex s + l, s = the lowest vertex not done.  A vertex
+// * TWO loops: an OUT-OF-ORDER WINDOW, and - for what it is slow on - the round loop (a scan of affine maps, below).  Lane l looks at vertex s + l, s = the lowest vertex not done.  A vertex
 //   can go when b, c (and a, unless it continues its predecessor's sum) are done - done = below s, or set in the 64-bit mask of the
 //   window, which is ALL the bookkeeping there is (two SGPRs: nothing above the window is ever done) - and when, if it continues its
 //   predecessor, that predecessor is done or goes in this same pass: a flood fill up the lanes, three scalar instructions.  The lanes
 //   that go form runs; each run is a prefix sum from its head (one DPP scan per component + a bpermute of the head's exclusive sum).
-//   A 4K-triangle grid takes 70 passes (the contiguous blocks of round 2: 110), a holey disc 80 (337), random diagonals 290 (572, or
-//   the walk's 174 cheaper ones) - tests/test_delta16_model_cpu.py restates the loop on the host and checks it against the oracle.
+//   A 4K-triangle grid takes 70 passes (the contiguous blocks of round 2: 110), a holey disc 80 (337), random diagonals 290 - which is why those
+//   leave the window after 24 passes for the round loop (45 rounds of about two passes' cost) - tests/test_delta16_model_cpu.py restates both loops
+//   on the host and checks them against the oracle.
 // * The next window's graph words and raw values are fetched while the current pass gathers and scans.
 #include <hip/hip_runtime.h>
 
@@ -41,7 +42,6 @@ __device__ __forceinline__ int32_t sx16(uint32_t w) { return (int32_t)(int16_t)(
 // ---- values in LDS: K = 1, 2, 3, 4 int16 components (records of 2, 4, 8, 8 bytes), K = 5: four bytes (colours) ----
 template <int K> struct LdsVal;
 template <> struct LdsVal<1> {
-	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 1; static constexpr bool CHECK = true; typedef uint32_t Raw;
 	CRT_LDS uint16_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -51,7 +51,6 @@ template <> struct LdsVal<1> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsVal<2> {
-	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 2; static constexpr bool CHECK = true; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -61,7 +60,6 @@ template <> struct LdsVal<2> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsVal<3> {
-	static constexpr bool CHECK_OR_WIDE = true;                                // x | y << 16, z | a << 16: the spare halfword carries the graph's `a`
 	static constexpr int NC = 3; static constexpr bool CHECK = true; typedef u32x2 Raw;
 	CRT_LDS u32x2 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -73,7 +71,6 @@ template <> struct LdsVal<3> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsVal<4> {
-	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 4; static constexpr bool CHECK = true; typedef u32x2 Raw;
 	CRT_LDS u32x2 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -85,7 +82,6 @@ template <> struct LdsVal<4> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsVal<5> {
-	static constexpr bool CHECK_OR_WIDE = false;          // (mod-256 fields: the chain loop's 32-bit sums in registers are not what the records read back as)                                // bytes, mod 256 (ColorAttr: uchar arithmetic)
 	static constexpr int NC = 4; static constexpr bool CHECK = false; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -101,7 +97,6 @@ template <> struct LdsVal<5> {
 // (v += v[a]: additions only): a pass adds at most 65 bytes into a field, which cannot carry into its neighbour, so two wave scans do the
 // work of four, and nothing is unpacked (mod 256 is taken when the record is stored)
 template <> struct LdsVal<6> {
-	static constexpr bool CHECK_OR_WIDE = false;          // (mod-256 fields: the chain loop's 32-bit sums in registers are not what the records read back as)
 	static constexpr int NC = 2; static constexpr bool CHECK = false; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -116,7 +111,6 @@ template <> struct LdsVal<6> {
 // base, nothing to check); a three-component record's fourth dword carries the graph's `a`.
 template <int K> struct LdsW;
 template <> struct LdsW<1> {
-	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 1; static constexpr bool CHECK = false; typedef uint32_t Raw;
 	CRT_LDS uint32_t *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -126,7 +120,6 @@ template <> struct LdsW<1> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsW<2> {
-	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 2; static constexpr bool CHECK = false; typedef u32x2 Raw;
 	CRT_LDS u32x2 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -136,7 +129,6 @@ template <> struct LdsW<2> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsW<3> {
-	static constexpr bool CHECK_OR_WIDE = true;                                  // x, y, z, a
 	static constexpr int NC = 3; static constexpr bool CHECK = false; typedef u32x4 Raw;
 	CRT_LDS u32x4 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -146,7 +138,6 @@ template <> struct LdsW<3> {
 	__device__ __forceinline__ void sync() const {}
 };
 template <> struct LdsW<4> {
-	static constexpr bool CHECK_OR_WIDE = true;
 	static constexpr int NC = 4; static constexpr bool CHECK = false; typedef u32x4 Raw;
 	CRT_LDS u32x4 *p;
 	__device__ __forceinline__ Raw raw(uint32_t i) const { return p[i]; }
@@ -160,7 +151,7 @@ template <> struct LdsW<4> {
 // N <= 4, int32 or bytes.  One wave owns the attribute (workgroup-scope accesses: the CU's own cache is coherent for it) and a pass's
 // stores are waited for before the next pass reads.
 template <typename T> struct GlobalVal {
-	static constexpr int NC = 4; static constexpr bool CHECK = false; static constexpr bool CHECK_OR_WIDE = false;   // (the HBM redo is called without a hand-over)
+	static constexpr int NC = 4; static constexpr bool CHECK = false;
 	struct Raw { uint32_t v[4]; };
 	CRT_GLOBAL T *p; uint32_t N;                              // N: components of this run (<= 4)
 	uint32_t stride = 0;                                      // elements from one vertex to the next (0: N); p points at the run's first component
@@ -206,14 +197,13 @@ struct GraphLds {
 
 // The window loop.  `base`: what a vertex whose value stays (malformed triple) has to give up to become relative (0 for bytes / HBM).
 // Returns the OR over every stored component of (value + 0x8000): anything at or above bit 16 = a value left int16.
-// `hand`: null, or where to leave (s, window mask) when the loop gives up in favour of the walk below - decided ONCE, at pass 24, from what
-// passes 8 .. 23 looked like: the walk's parallelism is the number of stretches that can advance at the same time, which is what the
-// window sees as HEADS per pass; a pass of either loop costs about the same on the GPU (0.4-0.5 us: the walk's is straight-line but has
-// eleven LDS reads and its bookkeeping), so what counts is passes: the walk's are the DAG's depth (3.5 sqrt(n) on sphere-like meshes), the
-// window's are n / (lanes going per pass).  At least two heads a pass and at most fourteen lanes going a pass says walk: random diagonals
-// (three heads, 9-11 going: 292 window passes against 24 + 150) - not rings (one head), grids (25-29 going), or holey discs (five to nine
-// heads but 20 going: 80 passes against 24 + 68).  tests/test_delta16_model_cpu.py has the families this was read off.
-struct WindowHand { uint32_t s; uint64_t donew; uint32_t mode; };         // mode (s < nvert): 1 the walk, 2 the round loop
+// `hand`: null, or where to leave (s, window mask) when the loop gives up in favour of the round loop below - decided ONCE, at pass 24, from what
+// passes 8 .. 23 looked like: a window pass costs ~1 100 clocks whatever it finishes, a round of the other loop ~2 200 for ~47 vertices, so fewer
+// than 18 vertices a pass says rounds: random diagonals (9-11 a pass), Delaunay meshes, decimated and other irregular closed meshes (3.5), tori
+// (13) - not grids (25-29); a holey disc (20) sits at the threshold.  (Rounds 3-4 handed over to a WALK - one lane per stretch, a vertex a pass,
+// passes = the DAG's depth: 160-180 for a 4K-triangle blob, but 1 772 for a decimated sphere, which is one stretch; the round loop beats it on
+// every family - tests/test_delta16_model_cpu.py - and it is gone.)
+struct WindowHand { uint32_t s; uint64_t donew; };                        // s < nvert: the window handed over to the round loop at vertex s, `donew` = what it had finished out of order from there
 // PARA: parallelogram prediction (b, c are gathered); else v += v[a] alone - the same loop without the two gathers, their unpacking and
 // their ready tests (a third of a pass's vector instructions, for two of a C4 blob's three attributes: the pipelined rate is within 2x of
 // the chip's VALU issue rate)
@@ -228,13 +218,10 @@ __device__ __forceinline__ uint32_t delta_window_loop(const V &val, const GR &gr
 	uint64_t donew = 0;                                                       // bit l: vertex s + l is done (everything below s is; nothing at or above s + 64 can be)
 	uint32_t W, A; typename V::Raw D;
 	{ const uint32_t ic = s + lane < nvert ? s + lane : nvert - 1u; graph.fetch(ic, W, A); W &= wmask; D = val.raw(ic); }
-	uint32_t passes = 0, nheads = 0, ngo = 0;
-	if(hand) { hand->s = nvert; hand->donew = 0; hand->mode = 0; }
+	uint32_t passes = 0, ngo = 0;
+	if(hand) { hand->s = nvert; hand->donew = 0; }
 	while(s < nvert) {
-		if(hand && passes == 24u && nvert - s >= 128u) {
-			if(PARA && V::CHECK_OR_WIDE && ngo < 288u) { hand->s = s; hand->donew = donew; hand->mode = 2; break; }     // fewer than 18 vertices a pass: the round loop
-			if(nheads >= 32u && ngo <= 224u) { hand->s = s; hand->donew = donew; hand->mode = 1; break; }               // (byte records with parallelogram prediction - no encoder writes them: the walk)
-		}
+		if(hand && passes == 24u && nvert - s >= 128u && ngo < 288u) { hand->s = s; hand->donew = donew; break; }   // fewer than 18 vertices a pass: the round loop takes over
 		const uint32_t i = s + lane;
 		const bool in = i < nvert;
 		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
@@ -250,7 +237,7 @@ __device__ __forceinline__ uint32_t delta_window_loop(const V &val, const GR &gr
 		// heads to the ready mask ripples a carry through exactly those
 		const uint64_t G = (((Rm + Sm) ^ Rm) & Rm) | Sm;
 		const bool go = __builtin_amdgcn_inverse_ballot_w64(G), head = __builtin_amdgcn_inverse_ballot_w64(Sm);
-		if(passes >= 8u && passes < 24u) { nheads += (uint32_t)__builtin_popcountll(Sm); ngo += (uint32_t)__builtin_popcountll(G); }
+		if(passes >= 8u && passes < 24u) ngo += (uint32_t)__builtin_popcountll(G);
 		passes++;
 		const uint64_t dn = donew | G;
 		const uint32_t t = ~dn ? (uint32_t)__builtin_ctzll(~dn) : 64u;       // lane 0 always goes: t >= 1
@@ -303,122 +290,6 @@ __device__ __forceinline__ uint32_t delta_window_run(const V &val, const GR &gra
 	return para ? delta_window_loop<true>(val, graph, nvert, base, hand) : delta_window_loop<false>(val, graph, nvert, base, hand);
 }
 
-// ---- the walk: meshes whose fronts break into MANY stretches (runs of vertices that each continue their predecessor's sum) ----
-// The window loop above is a scan machine: it finishes a whole run of such vertices per pass, which is what a mesh of a few long
-// rings wants (a torus: 24 stretches, a closed sphere: one).  A mesh with dozens of stretches alive at once - every open grid, any
-// irregular connectivity - has its parallelism ACROSS stretches instead: fans (c = i-2) and flipped diagonals cut the window's runs
-// to 7 vertices a pass where 40 stretches could each advance by one.  So, when the window's first passes look like that (WindowHand),
-// lane k walks stretches k, k + 64, ... in order from where the window stopped, one vertex a pass, a vertex firing when its parents' fired
-// bits are set; the vertex a lane has just finished stays in its registers (its successor's `a`); vertices the window had finished out of
-// order are stepped over.  Passes = the depth of the DAG (158 for the 4K-triangle
-// grid, 174 with every diagonal random, 106 for a holey disc) at about half a window pass's instructions and ONE LDS round trip each.
-// The lowest unfired vertex is always some lane's current one and its parents are lower, so every pass fires at least one vertex
-// (whatever the triples: malformed ones only cost passes).  One wave's LDS accesses execute in program order: no fences, no polling.
-// Stretches are handed out IN ORDER to whichever lanes are free (a scalar cursor over the start bitmap: the lanes test 64 vertices' start
-// bits, the free lanes take the first so many through 64 words of LDS) - so the lowest unfinished stretch always has a lane, whose current
-// vertex is then the lowest unfired one: progress.  A stretch ends where the next vertex does not continue the sum (its graph word says
-// so, and the word is fetched a pass ahead anyway): no end markers, no search.
-// The pass itself is branch-free up to its one predicated store (the compiler's version of `if(active) { if(ready) { ... if(last) ...`
-// was a dozen exec-masked regions and taken branches per pass, and a binary search whenever any lane's stretch ended - every pass, on a
-// mesh of 500 short stretches).
-struct WalkStarts { CRT_LDS const uint32_t *sbits; CRT_LDS uint32_t *tmp; uint32_t nw; };
-
-template <bool PARA, class V>
-__device__ __forceinline__ uint32_t delta_walk_loop(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
-                                                   const uint32_t nvert, const int32_t (&base)[V::NC], const WindowHand hand) {
-	constexpr int NC = V::NC;
-	const uint32_t lane = lane_id();
-	const uint64_t lane_lt = (1ull << lane) - 1ull;
-	constexpr uint32_t wmask = PARA ? 0xFFFFFFFFu : (GW_CHAINED | GW_STAYS);
-	const uint32_t first = hand.s;                                          // everything below is done, and so are the window's set bits from there
-	for(uint32_t d = lane; d < G.nw; d += 64) {
-		const uint32_t b0 = d*32u;
-		uint32_t w = first >= b0 + 32u ? 0xFFFFFFFFu : first > b0 ? (1u << (first - b0)) - 1u : 0u;
-		if(b0 + 32u > first && b0 < first + 64u) {                             // the window mask's bits that fall into this dword
-			const int32_t sh = (int32_t)b0 - (int32_t)first;                   // bit 0 of the dword is bit `sh` of the mask
-			w |= sh >= 0 ? (uint32_t)(hand.donew >> (uint32_t)sh) : (uint32_t)(hand.donew << (uint32_t)(-sh));
-		}
-		fbits[d] = w;
-	}
-	// lane 0 resumes at `first` (a start, or the middle of the stretch the window was in); everybody else takes starts from first + 1 on
-	uint32_t bad = 0, i = first, cur = first + 1u;
-	bool active = lane == 0, need = lane != 0, at_start = true;
-	uint32_t W, A, F; typename V::Raw D;
-	{ const uint32_t ic = i < nvert ? i : nvert - 1u; W = gw[ic] & wmask; A = ga.get(ic); D = val.raw(ic); F = fbits[ic >> 5]; }
-	int32_t prev[NC];
-#pragma unroll
-	for(int q = 0; q < NC; q++) prev[q] = 0;
-	for(;;) {
-		const uint64_t nm = __ballot(need);
-		if(nm && cur < nvert) {                                                // (uniform) hand out the next starts
-			const uint32_t m = (uint32_t)__builtin_popcountll(nm);
-			const uint32_t v = cur + lane, vc = v < nvert ? v : nvert - 1u;
-			const uint32_t sw = G.sbits[vc >> 5];
-			const bool st = v < nvert && ((sw >> (v & 31u)) & 1u) != 0;
-			const uint64_t sm = __ballot(st);
-			const uint32_t avail = (uint32_t)__builtin_popcountll(sm);
-			const uint32_t srank = (uint32_t)__builtin_popcountll(sm & lane_lt), nrank = (uint32_t)__builtin_popcountll(nm & lane_lt);
-			if(st && srank < m) G.tmp[srank] = v;
-			const uint32_t got = G.tmp[nrank], lastv = G.tmp[m - 1u < 63u ? m - 1u : 63u];   // (one wave: the reads see the writes)
-			const bool gets = need && nrank < avail;
-			cur = avail <= m ? cur + 64u : (uint32_t)__builtin_amdgcn_readfirstlane((int)lastv) + 1u;
-			if(gets) { i = got; active = true; need = false; at_start = true; }
-			const uint32_t ic = i < nvert ? i : nvert - 1u;
-			const uint32_t Wn = gw[ic] & wmask, An = ga.get(ic), Fn = fbits[ic >> 5]; const typename V::Raw Dn = val.raw(ic);
-			if(gets) { W = Wn; A = An; F = Fn; D = Dn; }
-		}
-		const uint64_t am = __ballot(active);
-		if(!am) { if(cur >= nvert || !__ballot(need)) break; continue; }
-		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
-		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (PARA && (W & GW_NO_BC) == GW_NO_BC);
-		const bool own = ch && !at_start;                                      // continues the vertex this lane finished last pass: in `prev`
-		const uint32_t ic = i < nvert ? i : nvert - 1u;
-		const uint32_t ap = stays || own ? 0u : ch ? ic - 1u : A, gb = stays ? 0u : b, gc = stays ? 0u : c;
-		const uint32_t inext = ic + 1u < nvert ? ic + 1u : ic;
-		// the parents' fired bits and values and the next vertex' words: one round trip
-		uint32_t fa = fbits[ap >> 5], fb = 0xFFFFFFFFu, fc = 0xFFFFFFFFu;
-		typename V::Raw Bw, Cw;
-		if constexpr(PARA) { fb = fbits[gb >> 5]; fc = fbits[gc >> 5]; Bw = val.raw(gb); Cw = val.raw(gc); }
-		typename V::Raw Pw = val.raw(ap);
-		uint32_t W2 = gw[inext], A2 = ga.get(inext), F2 = fbits[inext >> 5]; typename V::Raw D2 = val.raw(inext);
-		asm volatile("" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(W2), "+v"(A2), "+v"(F2));
-		const bool mine_done = ((F >> (ic & 31u)) & 1u) != 0;                  // the window finished it out of order: stepped over (only this lane ever fires it otherwise)
-		const uint32_t ready = stays ? 1u : ((fa >> (ap & 31u)) & (PARA ? (fb >> (gb & 31u)) & (fc >> (gc & 31u)) : 1u) & 1u);
-		int32_t dv[NC], bv[NC], cv[NC], pv[NC], r[NC];
-		V::unpack(D, dv); V::unpack(Pw, pv);
-		if constexpr(PARA) { V::unpack(Bw, bv); V::unpack(Cw, cv); }
-#pragma unroll
-		for(int q = 0; q < NC; q++) {
-			if constexpr(PARA) r[q] = dv[q] + (stays ? -base[q] : bv[q] - cv[q] + (own ? prev[q] : pv[q]));
-			else r[q] = dv[q] + (stays ? -base[q] : (own ? prev[q] : pv[q]));
-		}
-		const bool fire = active && (ready != 0 || mine_done), store = fire && !mine_done;
-		if(store) {
-			val.store(ic, r, A);
-			(void)__hip_atomic_fetch_or(fbits + (ic >> 5), 1u << (ic & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_or_b32
-		}
-		uint32_t chk = 0;
-#pragma unroll
-		for(int q = 0; q < NC; q++) { chk |= (uint32_t)r[q] + 0x8000u; prev[q] = store ? V::wrap(r[q]) : prev[q]; }   // (wrap: what the stored record reads back as - packed byte fields must not grow along a stretch)
-		if(V::CHECK) bad |= store ? chk : 0u;
-		// on: the next vertex of my stretch, or - it starts another stretch, or there is none - a new stretch for me
-		const bool ends = ic + 1u >= nvert || (W2 & GW_CHAINED) == 0;
-		const bool on = fire && !ends;
-		at_start = fire ? mine_done : at_start;                                  // (behind a vertex that was stepped over: its value is in LDS, not in `prev`)
-		need = need || (fire && ends);
-		active = active && !(fire && ends);
-		i = on ? inext : i;
-		W = on ? (W2 & wmask) : W; A = on ? A2 : A; F = on ? F2 : F; D = on ? D2 : D;
-		val.sync();
-	}
-	return bad;
-}
-template <class V>
-__device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, CRT_LDS uint32_t *fbits, const WalkStarts &G,
-                                                  const uint32_t nvert, const bool para, const int32_t (&base)[V::NC], const WindowHand hand) {
-	return para ? delta_walk_loop<true>(val, gw, ga, fbits, G, nvert, base, hand) : delta_walk_loop<false>(val, gw, ga, fbits, G, nvert, base, hand);
-}
-
 // ---- the round loop: parents a vertex or two back, by a scan of 2 x 2 affine maps (round 5) ----
 // The window finishes a run of vertices per pass as long as b and c are DONE: on a grid they lie a ring back and a pass takes 30 vertices.  On
 // anything irregular - flipped diagonals, a Delaunay mesh, a decimated or otherwise irregular closed mesh (fans: c = i - 2 or b = i - 2) - they are the
@@ -433,7 +304,8 @@ __device__ __forceinline__ uint32_t delta_walk_run(const V &val, CRT_LDS const u
 // (that one starts the next round, where its parents are final): 43-52 rounds for a 2K-vertex blob of ANY of those families, ~2 000 clocks each.
 // Exact by the same argument as the other loops (sums in 32-bit registers mod 2^32, the stored int16 checked); the linear parts are shared by an
 // attribute's components.  Chosen by what the window's passes 8-23 looked like (WindowHand.mode): fewer than 18 vertices a pass.
-template <class V>
+// (PARA = false: v += v[a] alone - the same loop with b and c left out; byte records: the sums mod 2^32 are stored mod 256.)
+template <bool PARA, class V>
 __device__ __forceinline__ uint32_t delta_round_loop(const V &val, CRT_LDS const uint32_t *gw, const GaRef ga, const uint32_t nvert,
                                                     const int32_t (&base)[V::NC], const WindowHand hand) {
 	constexpr int NC = V::NC;
@@ -449,17 +321,24 @@ __device__ __forceinline__ uint32_t delta_round_loop(const V &val, CRT_LDS const
 		const typename V::Raw D = val.raw(ic);
 		const bool done_i = __builtin_amdgcn_inverse_ballot_w64(donew);       // the window finished it out of order: its record IS its value
 		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
-		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (W & GW_NO_BC) == GW_NO_BC;
+		const bool ch = (W & GW_CHAINED) != 0, stays = (W & GW_STAYS) != 0 || (PARA && (W & GW_NO_BC) == GW_NO_BC);
 		const bool self = !in || done_i || stays;                             // no parents to add
 		const uint32_t pa = ch ? ic - 1u : A;
 		// a parent inside the round (>= s) must be one or two back; the first lane with one further back ends the round
 		const uint32_t da = ic - pa, db = ic - b, dc = ic - c;                   // (parents are below the vertex: distances >= 1)
-		const bool na = !self && pa >= s, nb = !self && b >= s, nc = !self && c >= s;
+		const bool na = !self && pa >= s, nb = PARA && !self && b >= s, nc = PARA && !self && c >= s;
 		const uint64_t cut = __ballot(!in || (na && da > 2u) || (nb && db > 2u) || (nc && dc > 2u));
 		const uint32_t len = cut ? (uint32_t)__builtin_ctzll(cut) : 64u;          // (lane 0 has no parent inside the round: len >= 1)
-		const typename V::Raw Pw = val.raw(self || na ? 0u : pa), Bw = val.raw(self || nb ? 0u : b), Cw = val.raw(self || nc ? 0u : c);
+		const typename V::Raw Pw = val.raw(self || na ? 0u : pa);
 		int32_t dv[NC], pv[NC], bv[NC], cv[NC];
-		V::unpack(D, dv); V::unpack(Pw, pv); V::unpack(Bw, bv); V::unpack(Cw, cv);
+		V::unpack(D, dv); V::unpack(Pw, pv);
+		if constexpr(PARA) {
+			const typename V::Raw Bw = val.raw(self || nb ? 0u : b), Cw = val.raw(self || nc ? 0u : c);
+			V::unpack(Bw, bv); V::unpack(Cw, cv);
+		} else {
+#pragma unroll
+			for(int q = 0; q < NC; q++) bv[q] = cv[q] = 0;
+		}
 		// the lane's map: (x, y) -> (ca x + cb y + pre, x)
 		uint32_t m00 = (na && da == 1u ? 1u : 0u) + (nb && db == 1u ? 1u : 0u) - (nc && dc == 1u ? 1u : 0u);
 		uint32_t m01 = (na && da == 2u ? 1u : 0u) + (nb && db == 2u ? 1u : 0u) - (nc && dc == 2u ? 1u : 0u);
@@ -467,7 +346,7 @@ __device__ __forceinline__ uint32_t delta_round_loop(const V &val, CRT_LDS const
 		uint32_t t0[NC], t1[NC];
 #pragma unroll
 		for(int q = 0; q < NC; q++) {
-			t0[q] = (uint32_t)(done_i ? dv[q] : stays ? dv[q] - base[q] : dv[q] + (na ? 0 : pv[q]) + (nb ? 0 : bv[q]) - (nc ? 0 : cv[q]));
+			t0[q] = (uint32_t)(done_i ? dv[q] : stays ? dv[q] - base[q] : dv[q] + (na ? 0 : pv[q]) + (!PARA || nb ? 0 : bv[q]) - (!PARA || nc ? 0 : cv[q]));
 			t1[q] = 0u;
 		}
 		// inclusive scan of the maps (Kogge-Stone): lane l takes the prefix that ends at lane l - o and puts its own behind it
@@ -695,8 +574,7 @@ __device__ __forceinline__ uint32_t delta16_in(CRT_LDS uint8_t *rec, const Delta
 }
 // returns true if the relative values left int16 (nothing was written back: the caller redoes the attribute in HBM)
 template <int K>
-__device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob &J, CRT_LDS const uint32_t *gw, const GaRef ga, uint32_t bad,
-                                            CRT_LDS uint32_t *fbits, const WalkStarts &starts) {
+__device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob &J, CRT_LDS const uint32_t *gw, const GaRef ga, uint32_t bad) {
 	constexpr int NC = LdsVal<K>::NC;
 	LdsVal<K> val{(decltype(LdsVal<K>::p))rec};
 	CRT_GLOBAL const int32_t *src = as_global((const int32_t *)J.values);
@@ -705,12 +583,11 @@ __device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob
 	for(int q = 0; q < NC; q++) base[q] = src[q];                            // vertex 0 (every lane: one broadcast load each)
 	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert);
 	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
-	WindowHand hand;
-	bad |= delta_window_run(val, GraphLds{gw, ga}, nvert, para, base, &hand);
-	if(hand.s < nvert && hand.mode == 2) bad |= delta_round_loop(val, gw, ga, nvert, base, hand);
-	else if(hand.s < nvert) {
-		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
-		bad |= delta_walk_run(val, gw, ga, fbits, starts, nvert, para, base, hand);
+	WindowHand hand{1u, 0ull};
+	if(!J.pad2[0]) bad |= delta_window_run(val, GraphLds{gw, ga}, nvert, para, base, &hand);
+	if(hand.s < nvert) {
+		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob's window handed over to the round loop)
+		bad |= para ? delta_round_loop<true>(val, gw, ga, nvert, base, hand) : delta_round_loop<false>(val, gw, ga, nvert, base, hand);
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	if(__ballot((bad >> 16) != 0)) return true;
@@ -718,20 +595,18 @@ __device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob
 	return false;
 }
 
-// the same attribute with 32-bit records (the context met values beyond int16): window, walk, copy-out; nothing can overflow
+// the same attribute with 32-bit records (the context met values beyond int16): window, rounds, copy-out; nothing can overflow
 template <int K>
-__device__ __forceinline__ void delta32_run(CRT_LDS uint8_t *rec, const DeltaJob &J, CRT_LDS const uint32_t *gw, const GaRef ga,
-                                            CRT_LDS uint32_t *fbits, const WalkStarts &starts) {
+__device__ __forceinline__ void delta32_run(CRT_LDS uint8_t *rec, const DeltaJob &J, CRT_LDS const uint32_t *gw, const GaRef ga) {
 	LdsW<K> val{(decltype(LdsW<K>::p))rec};
 	const int32_t zero[LdsW<K>::NC] = {};
 	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert);
 	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
-	WindowHand hand;
-	(void)delta_window_run(val, GraphLds{gw, ga}, nvert, para, zero, &hand);
-	if(hand.s < nvert && hand.mode == 2) (void)delta_round_loop(val, gw, ga, nvert, zero, hand);
-	else if(hand.s < nvert) {
-		if(lane_id() == 0) as_global(J.flags)[1] = 1;                          // (statistics: this blob took the walk)
-		(void)delta_walk_run(val, gw, ga, fbits, starts, nvert, para, zero, hand);
+	WindowHand hand{1u, 0ull};
+	if(!J.pad2[0]) (void)delta_window_run(val, GraphLds{gw, ga}, nvert, para, zero, &hand);
+	if(hand.s < nvert) {
+		if(lane_id() == 0) as_global(J.flags)[1] = 1;
+		if(para) (void)delta_round_loop<true>(val, gw, ga, nvert, zero, hand); else (void)delta_round_loop<false>(val, gw, ga, nvert, zero, hand);
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	stage_out32<K>(val, as_global((int32_t *)J.values), J.nvert, J.deq == 1, J.q);
@@ -763,11 +638,6 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 	off += (4u*nvert + 15u) & ~15u;
 	if(!ga_set) { ga_addr = (uint32_t)(uintptr_t)(l8 + off); off += (2u*nvert + 15u) & ~15u; }
 	const GaRef ga{ga_addr, ga_shift};
-	// the walk's bookkeeping: stretch-start bits | per wave: 64 words the free lanes take their starts through, fired bits
-	const uint32_t nw = delta_wave_bit_words(nvert);
-	CRT_LDS uint32_t *sbits = (CRT_LDS uint32_t *)(l8 + off);
-	CRT_LDS uint32_t *wtmp = (CRT_LDS uint32_t *)(l8 + off + delta16_walk_shared(nvert)) + w*(64u + nw);
-	CRT_LDS uint32_t *fbits = wtmp + 64;
 	const uint32_t builder = G.count < 4 ? G.count : 0u;
 	if(w == builder) {
 		// prediction triples -> graph words + a.  Eight rounds of 64 vertices in flight (unconditional loads on clamped indices, pinned).
@@ -785,9 +655,6 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 #pragma unroll
 			for(uint32_t u = 0; u < 8; u++) {
 				const uint32_t i = base + u*64 + lane;
-				const bool start = i < nvert && !(ta[u] < i && ta[u] + 1u == i);   // does not continue its predecessor's sum: a stretch starts here
-				const uint64_t m = __ballot(start);                              // the round's 64 vertices: two dwords of the start bitmap
-				if(lane == 0 && base + u*64 < nvert) { const uint32_t d = (base + u*64) >> 5; sbits[d] = (uint32_t)m; sbits[d + 1] = (uint32_t)(m >> 32); }
 				if(i >= nvert) continue;
 				gw[i] = graph_word(i, ta[u], tb[u], tc[u]);
 				ga.put(i, ta[u] < i ? ta[u] : 0u);
@@ -817,39 +684,39 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 	}
 	__syncthreads();                                                           // the graph is there
 	if(!mine) return;
-	const WalkStarts starts{sbits, wtmp, nw};
 	if(bytes) {
 		const LdsVal<5> val{(CRT_LDS uint32_t *)rec};
-		WindowHand hand;
+		WindowHand hand{1u, 0ull};
 		if(J.parallelogram) {
 			const int32_t zero[4] = {0, 0, 0, 0};
-			(void)delta_window_loop<true>(val, GraphLds{gw, ga}, nvert, zero, &hand);
+			if(!J.pad2[0]) (void)delta_window_loop<true>(val, GraphLds{gw, ga}, nvert, zero, &hand);
 			if(hand.s < nvert) {
 				if(lane == 0) as_global(J.flags)[1] = 1;
-				(void)delta_walk_loop<true>(val, gw, ga, fbits, starts, nvert, zero, hand);
+				(void)delta_round_loop<true>(val, gw, ga, nvert, zero, hand);
 			}
 		} else {                                                               // additions only: two packed registers instead of four components
 			const LdsVal<6> val2{(CRT_LDS uint32_t *)rec};
 			const int32_t zero[2] = {0, 0};
-			(void)delta_window_loop<false>(val2, GraphLds{gw, ga}, nvert, zero, &hand);
-			if(hand.s < nvert) {
+			if(!J.pad2[0]) (void)delta_window_loop<false>(val2, GraphLds{gw, ga}, nvert, zero, &hand);
+			if(hand.s < nvert) {                                                   // (the round loop multiplies: four byte components, not two packed registers)
 				if(lane == 0) as_global(J.flags)[1] = 1;
-				(void)delta_walk_loop<false>(val2, gw, ga, fbits, starts, nvert, zero, hand);
+				const int32_t zero4[4] = {0, 0, 0, 0};
+				(void)delta_round_loop<false>(val, gw, ga, nvert, zero4, hand);
 			}
 		}
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		stage_out_bytes(val, J, J.qc[0], J.qc[1], J.qc[2], J.qc[3]);
 	}
 	else if(wide) {
-		if(N == 1) delta32_run<1>(rec, J, gw, ga, fbits, starts);
-		else if(N == 2) delta32_run<2>(rec, J, gw, ga, fbits, starts);
-		else if(N == 3) delta32_run<3>(rec, J, gw, ga, fbits, starts);
-		else delta32_run<4>(rec, J, gw, ga, fbits, starts);
+		if(N == 1) delta32_run<1>(rec, J, gw, ga);
+		else if(N == 2) delta32_run<2>(rec, J, gw, ga);
+		else if(N == 3) delta32_run<3>(rec, J, gw, ga);
+		else delta32_run<4>(rec, J, gw, ga);
 	}
-	else if(N == 1) redo = delta16_run<1>(rec, J, gw, ga, bad, fbits, starts);
-	else if(N == 2) redo = delta16_run<2>(rec, J, gw, ga, bad, fbits, starts);
-	else if(N == 3) redo = delta16_run<3>(rec, J, gw, ga, bad, fbits, starts);
-	else redo = delta16_run<4>(rec, J, gw, ga, bad, fbits, starts);
+	else if(N == 1) redo = delta16_run<1>(rec, J, gw, ga, bad);
+	else if(N == 2) redo = delta16_run<2>(rec, J, gw, ga, bad);
+	else if(N == 3) redo = delta16_run<3>(rec, J, gw, ga, bad);
+	else redo = delta16_run<4>(rec, J, gw, ga, bad);
 	if(redo) {
 		// the relative values left int16: the raw deltas are still in HBM (nothing was written back) - the same loop on them, 32 bits wide,
 		// and a word for the host: its next batches are planned on the wide kernel (batch.cpp: harvest)

@@ -80,7 +80,6 @@ constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of k_delta_mesh's workgroup for one (blob, attribute) too big for LDS; half of them up to DELTA_SMALL_NVERT vertices
 __global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs);
 constexpr uint32_t DELTA_GROUP_MAX = 4;
-__host__ __device__ inline uint32_t delta_wave_bit_words(uint32_t nvert) { return ((nvert + 63u) >> 6) << 1; }                   // whole 64-vertex rounds
 struct DeltaGroup { uint32_t first, count; };     // DeltaJob entries [first, first + count) of one blob
 // k_delta.hip: one workgroup per blob, one wave per attribute (up to four) + one that builds the prediction graph they share: 16-bit values
 // relative to vertex 0 (bytes for colours), a 4-byte graph word and one out-of-order window loop.  Records: 2 / 4 / 8 / 8 bytes for 1 / 2 / 3 / 4 int16 components, 4 bytes for up to four colour bytes.
@@ -92,10 +91,8 @@ __host__ __device__ inline uint32_t delta_rec(uint32_t N, bool is_u8, bool wide)
 __host__ __device__ inline uint32_t delta_vbytes(uint32_t nvert, uint32_t N, bool is_u8, bool wide) { return (nvert*delta_rec(N, is_u8, wide) + 15u) & ~15u; }
 __host__ __device__ inline bool delta16_eligible(uint32_t nvert, uint32_t N, bool is_u8) { return nvert <= DELTA16_NVERT_MAX && N >= 1 && N <= 4 && (is_u8 || true); }
 // graph: 4 bytes a vertex + (unless a three-component int16 attribute of the group lends its spare halfwords) 2 bytes a vertex of `a`
-// ... + the walk's bookkeeping (k_delta.hip): stretch-start bits, then per wave (four) 64 words and a fired bitmap
-__host__ __device__ inline uint32_t delta16_walk_shared(uint32_t nvert) { return (4u*delta_wave_bit_words(nvert) + 15u) & ~15u; }
 __host__ __device__ inline uint32_t delta16_graph_lds(uint32_t nvert, bool a_embedded) {
-	return ((4u*nvert + 15u) & ~15u) + (a_embedded ? 0u : ((2u*nvert + 15u) & ~15u)) + delta16_walk_shared(nvert) + 4u*4u*(64u + delta_wave_bit_words(nvert)) + 16u;
+	return ((4u*nvert + 15u) & ~15u) + (a_embedded ? 0u : ((2u*nvert + 15u) & ~15u)) + 16u;
 }
 __global__ void k_delta_lds16(const DeltaJob *jobs, const DeltaGroup *groups, uint32_t ngroups);
 

@@ -325,8 +325,9 @@ typedef struct {
 	uint32_t delta_redone;      /* after crthip_batch_sync: blobs with an attribute whose values, relative to vertex 0, left int16 (K-DELTA's LDS
 	                               layout) and were redone on the 32-bit values in HBM (same results, slower); the context plans its next
 	                               batches with 32-bit values in LDS when that happens */
-	uint32_t delta_walked;      /* after crthip_batch_sync: blobs of which K-DELTA finished an attribute with its walk (one lane per stretch of the
-	                               prediction graph) rather than its window of prefix sums: irregular connectivity (k_delta.hip) */
+	uint32_t delta_walked;      /* after crthip_batch_sync: blobs of which K-DELTA finished an attribute with its ROUND LOOP (a scan of affine maps: parents one or
+	                               two vertices back) rather than its window of prefix sums: irregular connectivity (k_delta.hip; the name is rounds 3-4's, when the
+	                               fallback was a walk along the stretches of the prediction graph) */
 	uint32_t delta_wide;        /* 1: this decode was planned with 32-bit values in K-DELTA's LDS (the context had met such blobs, or $CORTO_DELTA_WIDE=1) */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);

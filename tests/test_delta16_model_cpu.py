@@ -65,17 +65,14 @@ def stage_in(raw, u8):
 
 
 def window_run(val, base, W, A, n, NC, u8, hand=True, para=True):
-    """returns (passes, overflow, s, window mask, mode): s < n when the loop handed over (k_delta.hip: WindowHand) - mode 1 to the walk, 2 to the chain loop"""
+    """returns (passes, overflow, s, window mask): s < n when the loop handed over to the round loop (k_delta.hip: WindowHand)"""
     mod = 256 if u8 else (1 << 32)
     ovf = False
     s, donew, passes = 1, 0, 0
-    nheads = ngo = 0
+    ngo = 0
     while s < n:
-        if hand and passes == 24 and n - s >= 128:
-            if para and not u8 and ngo < 288:
-                return passes, ovf, s, donew, 2
-            if nheads >= 32 and ngo <= 224:
-                return passes, ovf, s, donew, 1
+        if hand and passes == 24 and n - s >= 128 and ngo < 288:
+            return passes, ovf, s, donew
         passes += 1
         Rm = Hm = 0
         info = {}
@@ -97,7 +94,6 @@ def window_run(val, base, W, A, n, NC, u8, hand=True, para=True):
         G = ((((Rm + S) & M64) ^ Rm) & Rm) | S                # flood fill from the heads through consecutive ready lanes
         assert G & 1
         if 8 < passes <= 24:                                  # (passes counts from 1 here: the kernel's passes 8 .. 23)
-            nheads += bin(S).count("1")
             ngo += bin(G).count("1")
         acc = None
         for l in range(64):
@@ -129,10 +125,13 @@ def window_run(val, base, W, A, n, NC, u8, hand=True, para=True):
             t += 1
         s += t
         donew >>= t
-    return passes, ovf, n, 0, 0
+    return passes, ovf, n, 0
 
 
-def round_run(val, base, W, A, n, NC, first, donew):
+PARA_OF = [True]          # (set by build_graph's caller: whether b and c count - kernel_model)
+
+
+def round_run(val, base, W, A, n, NC, first, donew, u8=False):
     """k_delta.hip delta_round_loop: a round takes the vertices from `s` up to the first whose parent INSIDE the round lies more than two back; parents
     below the round are read from the records (final), parents one or two back enter through the recurrence v[i] = pre + ca v[i-1] + cb v[i-2], which
     the kernel solves with a scan of 2 x 2 affine maps and this model in order (the same numbers mod 2^32).  Returns (rounds, overflow)."""
@@ -153,11 +152,14 @@ def round_run(val, base, W, A, n, NC, first, donew):
                 maps.append((0, 0, [(val[i][q] - base[q]) & M32 for q in range(NC)], False)); ln += 1
                 continue
             pa = i - 1 if ch else A[i]
-            if any(p >= s and i - p > 2 for p in (pa, b, c)):
+            parents = ((pa, 1), (b, 1), (c, -1))
+            if not PARA_OF[0]:
+                parents = ((pa, 1),)
+            if any(p >= s and i - p > 2 for p, _ in parents):
                 break
             ca = cb = 0
             pre = [val[i][q] for q in range(NC)]
-            for p, sg in ((pa, 1), (b, 1), (c, -1)):
+            for p, sg in parents:
                 if p >= s:
                     if i - p == 1:
                         ca += sg
@@ -174,96 +176,34 @@ def round_run(val, base, W, A, n, NC, first, donew):
             y, x = x, v
             if not was_done:
                 for q in range(NC):
-                    ovf |= not fits16(v[q])
-                    val[s + l][q] = s32(v[q])
+                    if u8:
+                        val[s + l][q] = v[q] & 255
+                    else:
+                        ovf |= not fits16(v[q])
+                        val[s + l][q] = s32(v[q])
         s += ln
         donew = (donew >> ln) if ln < 64 else 0
     return rounds, ovf
 
 
-def walk_run(val, base, W, A, starts, n, NC, u8, first=1, donew=0):
-    """k_delta.hip delta_walk_run: lane 0 resumes at `first`, free lanes take the next stretch starts in order (a cursor over the start
-    bitmap, 64 vertices a round), a stretch ends where the next vertex does not continue the sum"""
-    mod = 256 if u8 else (1 << 32)
-    ovf = False
-    is_start = [False] * n
-    for v in starts:
-        is_start[v] = True
-    chained = [bool((W[i] >> 30) & 1) for i in range(n)]
-    fired = [i < first or (i - first < 64 and (donew >> (i - first)) & 1 == 1) for i in range(n)]
-    lanes = [dict(active=l == 0, need=l != 0, i=first, at_start=True, prev=None) for l in range(64)]
-    cur = first + 1
-    passes = 0
-    while True:
-        needing = [L for L in lanes if L["need"]]
-        if needing and cur < n:
-            avail = [v for v in range(cur, min(cur + 64, n)) if is_start[v]]
-            m = len(needing)
-            for L, v in zip(needing, avail):
-                L.update(active=True, need=False, i=v, at_start=True)
-            cur = cur + 64 if len(avail) <= m else avail[m - 1] + 1
-        if not any(L["active"] for L in lanes):
-            if cur >= n or not any(L["need"] for L in lanes):
-                break
-            continue
-        passes += 1
-        fire = []
-        for L in lanes:                                       # every lane decides on the state before the pass ...
-            if not L["active"]:
-                continue
-            i = L["i"]
-            if fired[i]:                                      # the window finished it out of order: stepped over
-                fire.append((L, None))
-                continue
-            b, c, ch, stays = fields(W[i])
-            own = ch and not L["at_start"]
-            ap = 0 if (stays or own) else (i - 1 if ch else A[i])
-            if stays or (fired[ap] and fired[b] and fired[c]):
-                r = []
-                for q in range(NC):
-                    t = val[i][q]
-                    t += -base[q] if stays else val[b][q] - val[c][q] + (L["prev"][q] if own else val[ap][q])
-                    r.append(t % mod)
-                fire.append((L, r))
-        assert fire
-        for L, r in fire:                                     # ... and the stores land before the next pass reads
-            i = L["i"]
-            if r is not None:
-                for q in range(len(r)):
-                    if u8:
-                        val[i][q] = r[q]
-                    else:
-                        ovf |= not fits16(r[q])
-                        val[i][q] = s32(r[q])
-                fired[i] = True
-                L["prev"] = r
-            L["at_start"] = r is None
-            if i + 1 >= n or not chained[i + 1]:
-                L.update(active=False, need=True)
-            else:
-                L["i"] = i + 1
-    assert all(fired)
-    return passes, ovf
-
-
 def kernel_model(raw, P, para, u8, force=None):
+    """force: None (the kernel's rule), "window" (never hand over), "rounds" (the round loop from vertex 1).  Returns (values, cost in window passes -
+    a round counts as two -, overflow, which loop finished)"""
     n, NC = raw.shape
     W, A, starts = build_graph(P, para)
+    PARA_OF[0] = bool(para)
     val, base, ovf = stage_in(raw, u8)
-    if force == "walk":                                       # (the kernel always starts in the window; the model may start the walk at vertex 1)
-        passes, o2, walked = (*walk_run(val, base, W, A, starts, n, NC, u8), True)
+    if force == "rounds":
+        p2, o2 = round_run(val, base, W, A, n, NC, 1, 0, u8)
+        passes, loop = 2 * p2, "rounds"
     else:
-        passes, o2, s, donew, mode = window_run(val, base, W, A, n, NC, u8, hand=force is None, para=para)
-        walked = s < n and mode == 1
-        if walked:
-            p2, o3 = walk_run(val, base, W, A, starts, n, NC, u8, s, donew)
-            passes, o2 = passes + p2, o2 or o3
-        elif s < n:                                              # the round loop (a round costs about two window passes)
-            p2, o3 = round_run(val, base, W, A, n, NC, s, donew)
-            passes, o2 = passes + 2 * p2, o2 or o3
-            walked = "rounds"
+        passes, o2, s, donew = window_run(val, base, W, A, n, NC, u8, hand=force is None, para=para)
+        loop = False
+        if s < n:
+            p2, o3 = round_run(val, base, W, A, n, NC, s, donew, u8)
+            passes, o2, loop = passes + 2 * p2, o2 or o3, "rounds"
     out = np.array([[val[i][q] if u8 else s32(base[q] + val[i][q]) for q in range(NC)] for i in range(n)], dtype=np.int64)
-    return out, passes, ovf or o2, walked
+    return out, passes, ovf or o2, loop
 
 
 CASES = [("grid", lambda: synth.bumpy_sphere(32, 16, seed=1), dict(position_bits=14, uv_bits=12, normal_prediction=ca.BORDER)),
@@ -296,7 +236,7 @@ def test_model_equals_the_oracle(name, make, kw):
         raw, want = o["_raw_" + nm], o["_delta_" + nm].astype(np.int64)
         u8 = a["codec"] == 3
         para = bool(a["strategy"] & 1) and a["codec"] != 2
-        for force in (None, "window", "walk"):
+        for force in (None, "window", "rounds"):
             got, passes, ovf, walk = kernel_model(raw, P, para, u8, force)
             if u8:
                 got, w = got & 255, want & 255
@@ -308,23 +248,23 @@ def test_model_equals_the_oracle(name, make, kw):
 
 def test_which_loop_a_mesh_gets():
     """the hand-over rule (k_delta.hip: WindowHand) on the families it was read off: whatever the window finishes fewer than 18 vertices a pass of -
-    random diagonals, Delaunay, decimated and other irregular closed meshes, cones - goes to the round loop and finishes in a fraction of the window's
-    cost (a round ~ two window passes), and so does a torus (13 vertices a pass); a grid stays in the window, a holey disc sits at the threshold"""
+    random diagonals, Delaunay, decimated and other irregular closed meshes, cones, tori - goes to the round loop and finishes in a fraction of the
+    window's cost (a round ~ two window passes); a grid stays in the window, a holey disc sits at the threshold"""
     def counts(mesh):
         blob = ca.aligned_blob(ca.encode(mesh, position_bits=14, normal_prediction=ca.BORDER))
         o = oc.decode(blob, trace=True)
         P, raw = o["_prediction"], o["_raw_position"]
         k = kernel_model(raw, P, True, False)
-        return kernel_model(raw, P, True, False, "window")[1], kernel_model(raw, P, True, False, "walk")[1], k[1], k[3]
+        return kernel_model(raw, P, True, False, "window")[1], k[1], k[3]
     for mesh, want in ((synth.decimated(synth.icosphere(3, seed=1), keep=0.8, seed=1), "rounds"), (synth.cone_fan(64, 8, seed=2), "rounds"), (synth.delaunay_disc(1200, seed=3, holes=5), "rounds"),
                        (synth.bumpy_sphere_flipped(48, 24, seed=2), "rounds"), (synth.bumpy_sphere_flipped(64, 32, seed=3, flip=0.1), "rounds"), (synth.holey_disc(40, seed=3), "level"),
                        (synth.bumpy_sphere(64, 32, seed=1), False), (synth.torus(48, 24, seed=4), "rounds")):
-        win, walk, kernel, walked = counts(mesh)
+        win, kernel, loop = counts(mesh)
         if want == "level":                                    # a holey disc sits at the rule's threshold (20 vertices a pass): either loop, about the same cost
-            assert kernel < 1.1 * win, (win, walk, kernel)
+            assert kernel < 1.1 * win, (win, kernel)
             continue
-        assert walked == want, (win, walk, kernel, walked)
-        if want == "rounds":                                   # 24 window passes, then rounds at two passes' cost each: well under both the window and the walk
-            assert kernel < 0.9 * min(win, walk + 24), (win, walk, kernel)
+        assert loop == want, (win, kernel, loop)
+        if want == "rounds":
+            assert kernel < 0.9 * win, (win, kernel)
         else:
-            assert kernel == win, (win, walk, kernel)
+            assert kernel == win, (win, kernel)

@@ -108,7 +108,8 @@ def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
         b.close(); c.close()
 
 
-@pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_UNPACK_CHUNKED": "1"}, {"CORTO_DELTA_WIDE": "1", "CORTO_TUN_SHARE": "2"}],
+@pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_UNPACK_CHUNKED": "1"}, {"CORTO_DELTA_WIDE": "1", "CORTO_TUN_SHARE": "2"}, {"CORTO_DELTA_ROUNDS": "1"},
+                                 {"CORTO_DELTA_ROUNDS": "1", "CORTO_DELTA_WIDE": "1"}],
                          ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
 def test_context_settings_are_bit_exact(monkeypatch, env):
     """csrc/debug_config.h: the settings a context reads select other kernel paths for the same bytes (32-bit records in K-DELTA's LDS -
