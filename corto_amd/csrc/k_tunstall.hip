@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_tun_stream_scan(const TunStream *__rest
 
 // (Rounds 2-3 also carried a SINGLE-PASS form - every decode workgroup adding up its own chunk and finding its offset by decoupled
 // look-back over its predecessors' state words - as a switch: it measured 0.674 ms against 0.57-0.59 for sums + per-stream scan + decode,
-// DESIGN.md 3.2 has the table, and it was removed in round 4.  chain_lookback itself lives on in K-BIT's chunked kernel.)
+// profiles/EXPERIMENTS.md 3.2 has the table, and it was removed in round 4.  chain_lookback itself lives on in K-BIT's chunked kernel.)
 // the decoded bytes leave through non-temporal stores: six bytes are written for every byte read, and as ordinary stores they
 // pushed the chunk's codewords out of the XCD's L2 between the look-back's adding-up pass and the decode pass
 #ifndef TUN_FLUSH_PLAIN
