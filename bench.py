@@ -704,7 +704,7 @@ def main():
     # beside `value`: the same pipelined steps with the compressed inputs ALREADY RESIDENT in HBM (what rounds 1-3 quoted as `value`): no PCIe
     # inside the step.  Same R regions of K steps, median reported.
     # (the side legs run 600 steps whatever K is: a 120-step region of sixteen batches in flight lands anywhere within -40 / +5 % of the
-    # long-run rate - tools/leg_probe.py - and 600 steps of these take 0.1-0.15 s)
+    # long-run rate - round 3, profiles/EXPERIMENTS.md - and 600 steps of these take 0.1-0.15 s)
     fh_steps = 600 * nloc
     pool.set_packed_host_blobs(False)
     pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=arenas)
@@ -719,7 +719,7 @@ def main():
         raise SystemExit("bench.py: resident-input leg: %d failed blobs" % rep_res.failed_blobs)
     # ... and with the blobs scattered over PAGEABLE host memory (256 separate numpy arrays): the worker thread gathers them into a pinned
     # image first (3.7 MB of memcpy per step on the host thread)
-    fhh_steps = 2000 * nloc       # (the from-host legs run longer: round 3 met an occasional 7-8 ms stall - tools/fromhost_gaps.py - that a 60 ms leg cannot average out)
+    fhh_steps = 2000 * nloc       # (the from-host legs run longer: round 3 met an occasional 7-8 ms stall - tools/fromhost_ab.py - that a 60 ms leg cannot average out)
     pool.run(items, steps=4 * pool.lanes * nloc, warmup=0, arenas=None)      # (untimed: every feeder's pinned image of an arena is allocated on first use)
     barrier()
     rep_h, stamps_h = pool.run(items, steps=fhh_steps, warmup=2 * pool.lanes, arenas=None)

@@ -5,7 +5,29 @@ Small blobs only (the trace sits 32 KB up in the blob's LDS).  Development aid."
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
-from topo_cost_fit import families, blobs_of
+
+
+def families():
+    from corto_amd import synth
+    return {
+        "reg": (lambda i: synth.bumpy_sphere(64, 32, seed=i, color_components=4), 64),
+        "reg32": (lambda i: synth.bumpy_sphere(32, 16, seed=i, color_components=4), 32),
+        "reg96": (lambda i: synth.bumpy_sphere(96, 20, seed=i, color_components=4), 32),
+        "f50": (lambda i: synth.bumpy_sphere_flipped(64, 32, seed=i, flip=0.5), 64),
+        "f10": (lambda i: synth.bumpy_sphere_flipped(64, 32, seed=i, flip=0.1), 64),
+        "f25s": (lambda i: synth.bumpy_sphere_flipped(40, 20, seed=i, flip=0.25), 32),
+        "closed": (lambda i: synth.closed_sphere(40 + i % 8, 20 + i % 5, seed=i), 16),
+        "torus": (lambda i: synth.torus(40 + 2*(i % 4), 20 + i % 3, seed=i), 12),
+        "disc": (lambda i: synth.holey_disc(30 + i % 6, seed=i), 12),
+        "strip": (lambda i: synth.strip(300 + 20*(i % 4), seed=i), 8),
+    }
+
+def blobs_of(name):
+    import corto_amd as ca
+    gen, n = families()[name]
+    return [ca.encode(gen(i), position_bits=14, uv_bits=12, normal_bits=10) for i in range(n)]
+
+
 FAMS = ["reg", "f50", "f10", "closed", "strip", "torus"]   # (not the disc: its front outgrows 32 KB once the context has learnt its scale)
 
 def gpu():
