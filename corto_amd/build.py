@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libcorto_hip.so")
 VENEER = os.path.join(LIBDIR, "libcortocodec_hip.so")
 EMVENEER = os.path.join(LIBDIR, "libcorto_em_hip.so")    # upstream's wasm/JS C ABI (include/corto/emcorto.h) over the facade
 CLI = os.path.join(LIBDIR, "corto_hip")                   # the `corto` command line tool on this repo's encoder + GPU decoder (tools/corto_hip_cli.cpp)   # legacy Unity C ABI (include/corto/corto_codec.h) over the facade
-SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_delta.hip", "k_normal.hip", "k_encode.hip", "batch.cpp", "crt_format.cpp", "decoder_facade.cpp", "encoder.cpp", "encode_gpu.cpp", "pool.cpp"]
+SOURCES = ["k_tunstall.hip", "k_stream.hip", "k_mesh.hip", "k_delta.hip", "k_normal.hip", "k_encode.hip", "batch.cpp", "plan_carve.cpp", "plan_jobs.cpp", "plan_group.cpp", "plan_launch.cpp", "crt_format.cpp", "decoder_facade.cpp", "encoder.cpp", "encode_gpu.cpp", "pool.cpp"]
 # every header of csrc/ is a dependency of every object (a stale object behind a changed header decodes with yesterday's kernel)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [
     os.path.join("..", "..", "include", "corto_hip.h"), os.path.join("..", "..", "include", "corto", "decoder.h")]
