@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pipe
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
 # the same pool, un-profiled first: how much the profiler perturbs the operating point is part of the evidence
 PROBE_LONG=${STEPS:-2000} GPU_MAX_HW_QUEUES=20 python tools/pool_probe.py ${SHAPE:-5 4} 2>/dev/null | tail -1 | sed 's/^/un-profiled: /'
-rm -rf $OUT/t; PROBE_LONG=${STEPS:-2000} GPU_MAX_HW_QUEUES=20 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tools/pool_probe.py ${SHAPE:-5 4} > $OUT/log.txt 2>&1
+rm -rf $OUT/t; PROBE_LONG=${STEPS:-2000} GPU_MAX_HW_QUEUES=20 timeout 300 rocprofv3 --output-format csv --kernel-trace -d $OUT/t -o t -- python tools/pool_probe.py ${SHAPE:-5 4} > $OUT/log.txt 2>&1
 grep "ms/step" $OUT/log.txt | sed 's/^/under rocprofv3: /'
 python - <<PY
 import csv, glob, collections

@@ -7,11 +7,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 BENCH="python bench.py --steps 20 --warmup 3 --no-cpu --no-other-configs --sustain 0 --depth 1 --host-threads 1"   # unpipelined: every kernel runs alone, as in bench.py's `kernels` phase
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1
 # PMC passes: counters only (no trace domains), one small group per pass
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o pmc1 -- $BENCH --no-tunstall-scaled > $OUT/bench_pmc1.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $BENCH --steps 5 > $OUT/bench_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $BENCH --steps 5 > $OUT/bench_write.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc1 -o pmc1 -- $BENCH --no-tunstall-scaled > $OUT/bench_pmc1.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $BENCH --steps 5 > $OUT/bench_fetch.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $BENCH --steps 5 > $OUT/bench_write.log 2>&1
 python - <<PY
 import csv, glob, collections, json
 out = {}

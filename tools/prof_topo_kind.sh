@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_topo_kind
 rm -rf $OUT; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $OUT/p -o p -- python tools/kt_probe_irregular.py > $OUT/log.txt 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $OUT/p -o p -- python tools/kt_probe_irregular.py > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob, collections
 for f in sorted(glob.glob("$OUT/p/**/*counter_collection.csv", recursive=True)):

@@ -12,7 +12,7 @@ if [ -z "$SPI_ONLY" ]; then SETS+=("SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LD
       "SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_CMD_FIFO_FULL SQ_INST_CYCLES_SALU"); fi
 for SET in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --output-format csv --pmc $SET -d $OUT/p$i -o p -- python tools/kt_probe_irregular.py > $OUT/log$i.txt 2>&1
+  timeout 300 rocprofv3 --output-format csv --pmc $SET -d $OUT/p$i -o p -- python tools/kt_probe_irregular.py > $OUT/log$i.txt 2>&1
 done
 python - <<PY
 import csv, glob, collections

@@ -2,10 +2,10 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_tun_$1
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/p1 -o p1 -- python tools/tun_scaled.py > $OUT/l1.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE -d $OUT/p2 -o p2 -- python tools/tun_scaled.py > $OUT/l2.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/p3 -o p3 -- python tools/tun_scaled.py > $OUT/l3.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/p4 -o p4 -- python tools/tun_scaled.py > $OUT/l4.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/p1 -o p1 -- python tools/tun_scaled.py > $OUT/l1.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE -d $OUT/p2 -o p2 -- python tools/tun_scaled.py > $OUT/l2.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/p3 -o p3 -- python tools/tun_scaled.py > $OUT/l3.log 2>&1
+timeout 300 timeout 300 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/p4 -o p4 -- python tools/tun_scaled.py > $OUT/l4.log 2>&1
 python - <<PY
 import csv, glob, collections, json
 out = {}
