@@ -138,5 +138,5 @@ def check_bench_line(line: dict, n_gpus: int = None) -> None:
         sr = line.get("scaling_report")
         if not isinstance(sr, dict) or len(sr.get("per_gpu_mtri_per_s", [])) != line["n_gpus"]:
             raise ValueError("bench line: scaling_report needs one rate per GPU")
-        if abs(sum(sr["per_gpu_mtri_per_s"]) / line["value"] - 1.0) > 0.30:      # (per-GPU rates are over all timed regions, `value` is the median region)
-            raise ValueError("bench line: per-GPU rates do not add up to value")
+        if not all(x > 0 for x in sr["per_gpu_mtri_per_s"]):                  # (their sum is over ALL timed regions, `value` the median region: not compared)
+            raise ValueError("bench line: a GPU decoded nothing")
