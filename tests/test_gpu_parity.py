@@ -1371,6 +1371,29 @@ def test_large_and_small_meshes_in_one_batch(ctx):
     assert b.stats().topology_fallbacks == 0
 
 
+def test_wide_context_on_meshes_beyond_the_lds_records(monkeypatch):
+    """ADVICE r4: with 32-bit records (a context that met values beyond int16, or $CORTO_DELTA_WIDE=1) K-DELTA keeps meshes of up to 32 767 vertices in LDS;
+    33K-66K vertices (16-bit ids would still do) and positions quantised to 18 bits take the stretch walk over HBM (k_delta_mesh).  A performance trade-off,
+    not a correctness one: the same bytes as the oracle on both sides of the limit, narrow and wide, rounds forced or not"""
+    from corto_amd import synth
+    meshes = [synth.bumpy_sphere(260, 128, seed=41), synth.bumpy_sphere(250, 130, seed=42), synth.delaunay_disc(2310, seed=43, holes=5),
+              synth.decimated(synth.icosphere(4, seed=44), keep=0.7, seed=44), synth.bumpy_sphere(64, 32, seed=45)]
+    blobs = [ca.encode(m, position_bits=18 if i % 2 == 0 else 14, normal_prediction=(ca.BORDER, ca.ESTIMATED, ca.DIFF)[i % 3]) for i, m in enumerate(meshes)]
+    refs = [oc.decode(bl) for bl in blobs]
+    for env in ({}, {"CORTO_DELTA_WIDE": "1"}, {"CORTO_DELTA_WIDE": "1", "CORTO_DELTA_ROUNDS": "1"}):
+        for k in ("CORTO_DELTA_WIDE", "CORTO_DELTA_ROUNDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ca.Context(0)
+        for _ in range(2):                                   # (the second decode: with what the first taught the context)
+            b = run_batch(c, blobs)
+            for i, r in enumerate(refs):
+                assert_same(b.host_outputs(i), r, KEYS, "blob %d env %s" % (i, env))
+            b.close()
+        c.close()
+
+
 def test_js_veneer_decode(ctx):
     """newDecoder / set* / decode / deleteDecoder (include/corto/emcorto.h = upstream html/js/emscripten/emcorto.cpp:14-89)
     driven the way corto.em.js does: sizes from nvert/nface, u16 index when nvert < 65536, int16 normals on request"""
