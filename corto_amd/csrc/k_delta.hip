@@ -197,8 +197,8 @@ struct GraphLds {
 
 // The window loop.  `base`: what a vertex whose value stays (malformed triple) has to give up to become relative (0 for bytes / HBM).
 // Returns the OR over every stored component of (value + 0x8000): anything at or above bit 16 = a value left int16.
-// `hand`: null, or where to leave (s, window mask) when the loop gives up in favour of the round loop below - decided ONCE, at pass 24, from what
-// passes 8 .. 23 looked like: a window pass costs ~1 100 clocks whatever it finishes, a round of the other loop ~2 200 for ~47 vertices, so fewer
+// `hand`: null, or where to leave (s, window mask) when the loop gives up in favour of the round loop below - decided at pass 24 from what passes
+// 8 .. 23 looked like, and asked again every sixteen passes (a mesh may start as a grid and go on as something else): a window pass costs ~1 100 clocks whatever it finishes, a round of the other loop ~2 200 for ~47 vertices, so fewer
 // than 18 vertices a pass says rounds: random diagonals (9-11 a pass), Delaunay meshes, decimated and other irregular closed meshes (3.5), tori
 // (13) - not grids (25-29); a holey disc (20) sits at the threshold.  (Rounds 3-4 handed over to a WALK - one lane per stretch, a vertex a pass,
 // passes = the DAG's depth: 160-180 for a 4K-triangle blob, but 1 772 for a decimated sphere, which is one stretch; the round loop beats it on
@@ -221,7 +221,10 @@ __device__ __forceinline__ uint32_t delta_window_loop(const V &val, const GR &gr
 	uint32_t passes = 0, ngo = 0;
 	if(hand) { hand->s = nvert; hand->donew = 0; }
 	while(s < nvert) {
-		if(hand && passes == 24u && nvert - s >= 128u && ngo < 288u) { hand->s = s; hand->donew = donew; break; }   // fewer than 18 vertices a pass: the round loop takes over
+		if(hand && passes >= 24u && (passes & 15u) == 8u) {                       // after passes 8-23, 24-39, ...: what did the last sixteen finish?
+			if(nvert - s >= 128u && ngo < 288u) { hand->s = s; hand->donew = donew; break; }   // fewer than 18 vertices a pass: the round loop takes over
+			ngo = 0;                                                               // (a mesh may turn irregular later: the question is asked again every sixteen passes)
+		}
 		const uint32_t i = s + lane;
 		const bool in = i < nvert;
 		const uint32_t b = W & 0x7FFFu, c = (W >> 15) & 0x7FFFu;
@@ -237,7 +240,7 @@ __device__ __forceinline__ uint32_t delta_window_loop(const V &val, const GR &gr
 		// heads to the ready mask ripples a carry through exactly those
 		const uint64_t G = (((Rm + Sm) ^ Rm) & Rm) | Sm;
 		const bool go = __builtin_amdgcn_inverse_ballot_w64(G), head = __builtin_amdgcn_inverse_ballot_w64(Sm);
-		if(passes >= 8u && passes < 24u) ngo += (uint32_t)__builtin_popcountll(G);
+		if(passes >= 8u) ngo += (uint32_t)__builtin_popcountll(G);
 		passes++;
 		const uint64_t dn = donew | G;
 		const uint32_t t = ~dn ? (uint32_t)__builtin_ctzll(~dn) : 64u;       // lane 0 always goes: t >= 1

@@ -592,19 +592,31 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 							ez += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nz), (int)q));
 						}
 					}
-				} else {                                                          // hundreds of faces around one vertex: selection, by every lane alike
-					int32_t last = -1;
-					for(uint32_t done = 0; done < deg;) {
-						uint32_t best = 0xFFFFFFFFu, mult = 0;
-						for(uint32_t k = 0; k < deg; k++) {
-							const uint32_t f = adj[s0 + k];
-							if((int32_t)f > last) { if(f < best) { best = f; mult = 1; } else if(f == best) mult++; }
-						}
+				} else {
+					// more than 512 faces around one vertex (a polygon triangulated as a fan): no sort at all - the faces are walked in id order, 64 at a
+					// time, and the ones that name the vertex add their normal (once per mention, as estimateNormals' three += do): nface / 64 rounds
+					// whatever the valence (rounds 2-4 took a deg^2 selection loop here: seconds for a valence of 20 000)
+					for(uint32_t f0 = 0; f0 < nf; f0 += 64) {
+						const uint32_t f = f0 + lane;
+						uint32_t fa, fb, fc;
+						face(f < nf ? f : nf - 1u, fa, fb, fc);
+						const bool okf = f < nf && fa < nv && fb < nv && fc < nv;       // (what the incidence count took)
+						const uint32_t m = okf ? (fa == v ? 1u : 0u) + (fb == v ? 1u : 0u) + (fc == v ? 1u : 0u) : 0u;
+						uint64_t hit = __ballot(m != 0);
+						if(!hit) continue;
+						const uint32_t fr = m ? f : 0u;
 						float nx, ny, nz;
-						if(fn_lds) { nx = fn[3*best]; ny = fn[3*best + 1]; nz = fn[3*best + 2]; }
-						else { nx = fng[3*(size_t)best]; ny = fng[3*(size_t)best + 1]; nz = fng[3*(size_t)best + 2]; }
-						for(uint32_t m = 0; m < mult; m++) { ex += nx; ey += ny; ez += nz; }
-						last = (int32_t)best; done += mult;
+						if(fn_lds) { nx = fn[3*fr]; ny = fn[3*fr + 1]; nz = fn[3*fr + 2]; }
+						else { CRT_GLOBAL const float *qn = fng + 3*(size_t)fr; nx = qn[0]; ny = qn[1]; nz = qn[2]; }
+						while(hit) {
+							const int q = (int)__builtin_ctzll(hit);
+							hit &= hit - 1;
+							const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, q);
+							const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nx), q));
+							const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ny), q));
+							const float az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nz), q));
+							for(uint32_t t = 0; t < mq; t++) { ex += ax; ey += ay; ez += az; }
+						}
 					}
 				}
 				if(lane == 0) {

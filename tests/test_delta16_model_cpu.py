@@ -71,8 +71,10 @@ def window_run(val, base, W, A, n, NC, u8, hand=True, para=True):
     s, donew, passes = 1, 0, 0
     ngo = 0
     while s < n:
-        if hand and passes == 24 and n - s >= 128 and ngo < 288:
-            return passes, ovf, s, donew
+        if hand and passes >= 24 and passes % 16 == 8:
+            if n - s >= 128 and ngo < 288:
+                return passes, ovf, s, donew
+            ngo = 0
         passes += 1
         Rm = Hm = 0
         info = {}
@@ -93,7 +95,7 @@ def window_run(val, base, W, A, n, NC, u8, hand=True, para=True):
         S = Rm & Hm
         G = ((((Rm + S) & M64) ^ Rm) & Rm) | S                # flood fill from the heads through consecutive ready lanes
         assert G & 1
-        if 8 < passes <= 24:                                  # (passes counts from 1 here: the kernel's passes 8 .. 23)
+        if passes > 8:                                        # (passes counts from 1 here: the kernel's passes 8 ...; reset every sixteen)
             ngo += bin(G).count("1")
         acc = None
         for l in range(64):

@@ -1394,6 +1394,24 @@ def test_wide_context_on_meshes_beyond_the_lds_records(monkeypatch):
         c.close()
 
 
+def test_high_valence_vertices(ctx):
+    """K-NRM adds a vertex' incident face normals in ascending face id (src/normal_attribute.cpp:40-59): <= 8 faces sort in registers, <= 16 in Batcher's
+    network, <= 512 by their wave (ranks by counting), more by walking the faces in order - a cone's apex of valence 9 .. 3 000 takes each of them, with
+    ESTIMATED and BORDER normals (float and int16), and the delta stage's round loop meets its fans"""
+    from corto_amd import synth
+    ks = (9, 12, 16, 17, 33, 64, 65, 128, 300, 512, 513, 700, 3000)
+    meshes = [synth.cone_fan(k, 1 + i % 3, seed=k, closed=bool(i & 1), flip=0.3) for i, k in enumerate(ks)]
+    blobs = [ca.encode(m, normal_prediction=(ca.ESTIMATED, ca.BORDER)[i % 2]) for i, m in enumerate(meshes)]
+    for nf in (oc.FMT_FLOAT, oc.FMT_INT16):
+        b = ca.Batch(ctx, blobs)
+        b.allocate_outputs(fill=0, normal_format=nf)
+        b.decode()
+        assert (b.sync() == 0).all()
+        for i, bl in enumerate(blobs):
+            assert_same(b.host_outputs(i), oc.decode(bl, normal_format=nf), KEYS, "cone of valence %d, normals %s" % (ks[i], "i16" if nf == oc.FMT_INT16 else "f32"))
+        b.close()
+
+
 def test_js_veneer_decode(ctx):
     """newDecoder / set* / decode / deleteDecoder (include/corto/emcorto.h = upstream html/js/emscripten/emcorto.cpp:14-89)
     driven the way corto.em.js does: sizes from nvert/nface, u16 index when nvert < 65536, int16 normals on request"""
