@@ -119,6 +119,8 @@ def main():
     if only is not None:
         if "tunstall_kat" in only:
             tunstall_kat()
+        if "nonlattice_blobs8" in only:
+            nonlattice_blobs()
         return
     # mid-size mesh (C1-class, 34 060 verts / 67 600 tris): blob + digests only
     m = synth.bumpy_sphere(260, 130, seed=34)
@@ -144,7 +146,32 @@ def main():
     np.savez_compressed(os.path.join(OUT, "c4_blobs16.npz"), **d)
     print("c4_blobs16           %d blobs" % 16)
 
+    nonlattice_blobs()
     tunstall_kat()
+
+
+def nonlattice_meshes():
+    """C4-sized blobs with no lattice in them - bench.py's `realistic` blobs (Delaunay discs with holes, seeds 0-3) and a decimated sphere, an icosphere, a
+    cone of fans: (name, mesh, prediction) - shared with the tests, which rebuild them for the repo's own encoder"""
+    out = [("delaunay%d" % sd, synth.delaunay_disc(2310, seed=sd, holes=6 + sd % 5), rc.BORDER) for sd in range(4)]
+    out += [("decimated0", synth.decimated(synth.icosphere(4, seed=0), keep=0.8, seed=0), rc.ESTIMATED), ("decimated1", synth.decimated(synth.icosphere(4, seed=1), keep=0.6, seed=1), rc.BORDER),
+            ("icosphere4", synth.icosphere(4, seed=2), rc.ESTIMATED), ("cone128", synth.cone_fan(128, 16, seed=3), rc.BORDER)]
+    return out
+
+
+def nonlattice_blobs():
+    d = {}
+    names = []
+    for name, m, pred in nonlattice_meshes():
+        blob = rc.encode(m, normal_prediction=pred)
+        ref = rc.decode(blob)
+        d["crt_" + name] = np.asarray(blob).copy()
+        for k in ("position", "normal", "color", "uv", "index"):
+            d["%s_sha256_%s" % (k, name)] = np.frombuffer(sha(ref[k]).encode(), dtype=np.uint8)
+        names.append(name)
+    d["names"] = np.frombuffer(",".join(names).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "nonlattice_blobs8.npz"), **d)
+    print("nonlattice_blobs8    %d blobs" % len(names))
 
 
 if __name__ == "__main__":

@@ -39,6 +39,17 @@ def test_c4_units_and_mid_mesh():
     assert mine.tobytes() == g["crt"].tobytes()
 
 
+def test_nonlattice_c4_sized_blobs():
+    """the repo's encoder writes the reference's bytes for the eight C4-sized non-lattice blobs too (Delaunay discs as bench.py's `realistic` leg makes them)"""
+    z = np.load(os.path.join(GOLDEN, "nonlattice_blobs8.npz"))
+    meshes = {"delaunay%d" % sd: (synth.delaunay_disc(2310, seed=sd, holes=6 + sd % 5), ca.BORDER) for sd in range(4)}
+    meshes.update({"decimated0": (synth.decimated(synth.icosphere(4, seed=0), keep=0.8, seed=0), ca.ESTIMATED), "decimated1": (synth.decimated(synth.icosphere(4, seed=1), keep=0.6, seed=1), ca.BORDER),
+                   "icosphere4": (synth.icosphere(4, seed=2), ca.ESTIMATED), "cone128": (synth.cone_fan(128, 16, seed=3), ca.BORDER)})
+    assert sorted(meshes) == sorted(z["names"].tobytes().decode().split(","))
+    for name, (m, pred) in meshes.items():
+        assert ca.encode(m, normal_prediction=pred).tobytes() == z["crt_" + name].tobytes(), name
+
+
 def test_roundtrip_through_the_oracle_decoder():
     """encode (ours) -> decode (C oracle): positions come back as the quantised inputs, in the encoder's vertex order"""
     from oracle import oracle as oc

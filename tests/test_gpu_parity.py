@@ -1394,6 +1394,26 @@ def test_wide_context_on_meshes_beyond_the_lds_records(monkeypatch):
         c.close()
 
 
+def test_nonlattice_c4_sized_blobs_against_the_reference_digests(ctx):
+    """eight C4-sized blobs with no lattice in them - bench.py's `realistic` Delaunay discs, decimated spheres, an icosphere, a cone of fans - in one batch, twice
+    (the second decode with the edge slots the first taught the context), u32 indices: SHA-256 of every output array = what the compiled REFERENCE decoded
+    (tests/golden/nonlattice_blobs8.npz), not only what the oracle says"""
+    z = np.load(os.path.join(GOLDEN, "nonlattice_blobs8.npz"))
+    names = z["names"].tobytes().decode().split(",")
+    blobs = [aligned(z["crt_" + n]) for n in names]
+    c = ca.Context(0)
+    for attempt in range(2):
+        b = run_batch(c, blobs, color_components=4)
+        for i, n in enumerate(names):
+            got = b.host_outputs(i)
+            for k in ("position", "normal", "color", "uv", "index"):
+                assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() == z["%s_sha256_%s" % (k, n)].tobytes().decode(), (n, k, attempt)
+        if attempt:
+            assert b.stats().topology_fallbacks == 0
+        b.close()
+    c.close()
+
+
 def test_high_valence_vertices(ctx):
     """K-NRM adds a vertex' incident face normals in ascending face id (src/normal_attribute.cpp:40-59): <= 8 faces sort in registers, <= 16 in Batcher's
     network, <= 512 by their wave (ranks by counting), more by walking the faces in order - a cone's apex of valence 9 .. 3 000 takes each of them, with

@@ -127,3 +127,14 @@ def test_generic_attribute_output_formats_match_the_reference():
             _, attr, fmt = key.split(".")
             got = oc.decode_attr_format(blob, attr, int(fmt))
             assert got.tobytes() == z[key].tobytes(), key
+
+
+def test_nonlattice_c4_sized_blobs_against_the_reference_digests():
+    """eight C4-sized blobs with no lattice in them (bench.py's `realistic` Delaunay discs, decimated spheres, an icosphere, a cone of fans): the oracle's
+    outputs against SHA-256 digests of what the compiled reference decoded (tests/golden/make_golden.py: nonlattice_blobs)"""
+    import hashlib
+    z = np.load(os.path.join(GOLDEN, "nonlattice_blobs8.npz"))
+    for name in z["names"].tobytes().decode().split(","):
+        out = oc.decode(aligned(z["crt_" + name]))
+        for k in ("position", "normal", "color", "uv", "index"):
+            assert hashlib.sha256(np.ascontiguousarray(out[k]).tobytes()).hexdigest() == z["%s_sha256_%s" % (k, name)].tobytes().decode(), (name, k)
