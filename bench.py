@@ -538,11 +538,11 @@ def main():
     blobs = items[0]
     depth, nthreads = max(1, args.depth), max(1, args.host_threads)
     # host threads per GPU, sized for the GPUs that share a NUMA node (8 GPUs on two sockets: 4 x threads feeder threads a socket) and for this
-    # process' cpuset - a pool that time-shares its feeder threads measures the host; refused loudly when a GPU cannot get one core
+    # process' cpuset - a pool that time-shares its feeder threads measures the host: said loudly (stderr and `config.host_threads_note`) when a GPU cannot get a core of its own
     numa = gpu_numa_cpus(torch, ndev)
     phys = sorted(set(range(n_gpus if not share else ndev)) & set(range(ndev))) if world > 1 else sorted(set(devices))
     plan_t, threads_note = shard.plan_host_threads(nthreads, [numa[d] for d in phys], sorted(os.sched_getaffinity(0)))
-    if min(plan_t) < nthreads:
+    if min(plan_t) < nthreads or threads_note:
         nthreads = min(plan_t)
         print("bench.py: " + threads_note, file=sys.stderr)
     # compressed inputs resident in HBM before the timed region: item j on ITS pool device (j % N: crthip_pool's home-shard-first policy) -

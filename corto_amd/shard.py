@@ -61,8 +61,9 @@ def sum_over_ranks(value: float, dist=None, device=None) -> float:
 def plan_host_threads(requested: int, gpu_cpus: Sequence[Sequence[int]], affinity: Sequence[int], reserve: int = 1):
     """How many host threads each GPU's decode pool gets (bench.py --host-threads, crthip_pool): every GPU's threads run on the CPUs of ITS
     NUMA node (pool.cpp pins them), so the GPUs of one node share that node's cores.  gpu_cpus[d] = the CPUs next to GPU d ([] = unknown: any
-    CPU of `affinity`), affinity = the CPUs this process may run on (os.sched_getaffinity).  Returns (threads per GPU, note); raises ValueError
-    when some GPU could not even get one core - a scaling run that silently time-shares its feeder threads measures the host, not the GPUs."""
+    CPU of `affinity`), affinity = the CPUs this process may run on (os.sched_getaffinity).  Returns (threads per GPU, note).  When some GPU cannot
+    even get one core the plan is one time-shared thread each and the note begins with OVERSUBSCRIBED HOST (bench.py prints it to stderr and carries
+    it in the JSON line): a scaling run that SILENTLY time-shares its feeder threads would measure the host, not the GPUs."""
     aff = set(int(c) for c in affinity)
     if requested < 1:
         raise ValueError("host threads per GPU must be positive")
@@ -74,12 +75,15 @@ def plan_host_threads(requested: int, gpu_cpus: Sequence[Sequence[int]], affinit
         groups.setdefault(usable, []).append(d)
     per_gpu, notes = [0] * len(gpu_cpus), []
     for cpus, gpus in groups.items():
+        if not cpus:
+            raise ValueError("no usable host CPU for GPUs %s" % gpus)
         room = max(len(cpus) - reserve, 0) // len(gpus)
-        if room < 1:
-            raise ValueError("%d GPU(s) share %d usable host CPU(s) (%s...): not one feeder thread each - widen the cpuset (taskset / cgroup) or run fewer GPUs per process"
-                             % (len(gpus), len(cpus), ",".join(map(str, cpus[:8]))))
+        if room < 1:                                      # fewer cores than GPUs: one thread each, time-shared - measured, but said LOUDLY (stderr and the JSON line)
+            notes.append("OVERSUBSCRIBED HOST: %d GPU(s) share %d usable host CPU(s) (%s...) - one feeder thread each, time-shared: the rate below measures the host; "
+                         "widen the cpuset (taskset / cgroup)" % (len(gpus), len(cpus), ",".join(map(str, cpus[:8]))))
+            room = 1
         t = min(requested, room)
-        if t < requested:
+        if t < requested and room >= 1 and not (notes and notes[-1].startswith("OVERSUBSCRIBED")):
             notes.append("GPUs %s: %d host threads each instead of %d (%d usable CPUs next to them)" % (gpus, t, requested, len(cpus)))
         for d in gpus:
             per_gpu[d] = t
