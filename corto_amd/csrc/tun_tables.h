@@ -108,7 +108,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		const bool rowlane = lane < n;
 		const uint32_t rowc = 0xFFFFu - lane;
 		const uint32_t myP = rowlane ? P[lane] : 0u, sym24 = rowlane ? (uint32_t)sym[lane] << 24 : 0u;
-		uint32_t K = 0, HL = 0xFFFFu, NR = 0, NX = 0xFFFFu, LD = 0;
+		uint32_t K = 0, HL = 0xFFFFu, NR = 0, NX = TUN_ENTRY_CAP - 1, LD = 0;      // (lanes without a row: NX is an address they read every expansion)
 		if(rowlane) {
 			const uint32_t h = head[lane], v = epl[h];
 			K = (v << 16) | rowc; HL = h | (v & 0xFF0000u); NX = h + n;
@@ -118,39 +118,48 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		const uint32_t inc = rowlane ? n : 0u;
 		__builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): no LDS read pending into the loop (its waits would land on the loop's top)
 		const uint32_t width = n <= 4 ? 4u : n <= 16 ? 16u : 64u;                  // lanes that can hold a row
-		auto likeliest = [&](uint32_t key) -> uint32_t {
-			if(width == 64) return wave_max_u32(key);
+		// (the reduction's width is a compile-time constant of each of the three loops below: tested inside the loop it is three branches an expansion)
+		auto likeliest_w = [&](uint32_t key, auto W) -> uint32_t {
+			if(decltype(W)::value == 64) return wave_max_u32(key);
 #define CRT_DPP_MAX(ctrl) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, ctrl, 0xf, 0xf, false); key = o_ > key ? o_ : key; }
 			CRT_DPP_MAX(0xB1) CRT_DPP_MAX(0x4E)                                   // quad_perm [1,0,3,2], [2,3,0,1]
-			if(width == 16) { CRT_DPP_MAX(0x141) CRT_DPP_MAX(0x140) }             // row_half_mirror, row_mirror
+			if(decltype(W)::value == 16) { CRT_DPP_MAX(0x141) CRT_DPP_MAX(0x140) } // row_half_mirror, row_mirror
 #undef CRT_DPP_MAX
 			return (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+		};
+		auto likeliest = [&](uint32_t key) -> uint32_t {
+			return width == 4 ? likeliest_w(key, std::integral_constant<uint32_t, 4>{}) : width == 16 ? likeliest_w(key, std::integral_constant<uint32_t, 16>{})
+			                                                                        : likeliest_w(key, std::integral_constant<uint32_t, 64>{});
 		};
 		bool pend = false;
 		uint32_t whole = nwords + n <= 255 ? (255 - n - nwords)/(n - 1) + 1 : 0;   // expansions that pop their parent
 		nwords += whole*(n - 1); end += whole*n;
-		for(; whole; whole--) {
-			const uint32_t key = likeliest(K);
-			const uint32_t best = 0xFFFFu & ~key;
-			const uint32_t hq = (uint32_t)__builtin_amdgcn_readlane((int)HL, (int)best);
-			const uint32_t parent = hq & 0xFFFFu, len1 = (hq & 0xFF0000u) + 0x10000u;   // the children's length, in place
-			const uint32_t t = __umul24(key >> 16, myP);                          // child probability = t >> 16
-			const uint32_t recv = (t >> 16) | sym24 | len1;
-			epl[E] = recv; eoff[E] = (uint16_t)parent;
-			asm volatile("" ::: "memory");                                        // one wave: LDS executes in program order
-			NR = pend ? LD : NR; pend = false;                                    // (the read issued by the previous pop)
-			const bool is_head = (HL & 0xFFFFu) == E;                             // the row's FIFO was empty: the child is its head
-			K = is_head ? ((t & 0xFFFF0000u) | rowc) : K;
-			HL = is_head ? (E | len1) : HL;
-			NR = NX == E ? recv : NR;                                             // ... held only its head: the child is next
-			if(lane == best) {                                                     // the parent is fully expanded: pop it
-				const uint32_t hnew = parent + n;
-				K = (NR << 16) | rowc; HL = hnew | (NR & 0xFF0000u);
-				NX = hnew + n;
-				LD = epl[NX]; pend = true;                                        // (zero behind the last entry)
+		auto grow = [&](auto W) {
+			for(; whole; whole--) {
+				const uint32_t key = likeliest_w(K, W);
+				const uint32_t best = 0xFFFFu & ~key;
+				const uint32_t hq = (uint32_t)__builtin_amdgcn_readlane((int)HL, (int)best);
+				const uint32_t parent = hq & 0xFFFFu, len1 = (hq & 0xFF0000u) + 0x10000u;   // the children's length, in place
+				const uint32_t t = __umul24(key >> 16, myP);                          // child probability = t >> 16
+				const uint32_t recv = (t >> 16) | sym24 | len1;
+				epl[E] = recv; eoff[E] = (uint16_t)parent;
+				asm volatile("" : "+v"(LD) :: "memory");                              // one wave: LDS executes in program order; the wait for the previous pop's read belongs HERE, behind the reduction
+				NR = pend ? LD : NR; pend = false;                                    // (the read issued by the previous pop)
+				const bool is_head = (HL & 0xFFFFu) == E;                             // the row's FIFO was empty: the child is its head
+				K = is_head ? ((t & 0xFFFF0000u) | rowc) : K;
+				HL = is_head ? (E | len1) : HL;
+				NR = NX == E ? recv : NR;                                             // ... held only its head: the child is next
+				pend = lane == best;                                                   // the parent is fully expanded: its row pops it (selects, not a branch:
+				const uint32_t hnew = parent + n;                                      // every lane reads `its` next-but-one record, the popping lane's is the new one)
+				K = pend ? (NR << 16) | rowc : K; HL = pend ? hnew | (NR & 0xFF0000u) : HL;
+				NX = pend ? hnew + n : NX;
+				LD = epl[NX];                                                          // (zero behind the last entry)
+				E += inc;
 			}
-			E += inc;
-		}
+		};
+		if(width == 4) grow(std::integral_constant<uint32_t, 4>{});
+		else if(width == 16) grow(std::integral_constant<uint32_t, 16>{});
+		else grow(std::integral_constant<uint32_t, 64>{});
 		NR = pend ? LD : NR;
 		if(nwords < 256) {                                                        // the dictionary fills up during the last expansion: its parent stays
 			const uint32_t m = 256 - nwords;
