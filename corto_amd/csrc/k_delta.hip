@@ -352,30 +352,31 @@ __device__ __forceinline__ uint32_t delta_round_loop(const V &val, CRT_LDS const
 			t0[q] = (uint32_t)(done_i ? dv[q] : stays ? dv[q] - base[q] : dv[q] + (na ? 0 : pv[q]) + (!PARA || nb ? 0 : bv[q]) - (!PARA || nc ? 0 : cv[q]));
 			t1[q] = 0u;
 		}
-		// inclusive scan of the maps (Kogge-Stone): lane l takes the prefix that ends at lane l - o and puts its own behind it
-#pragma unroll
-		for(uint32_t o = 1; o < 64u; o <<= 1) {
-			const int src = (int)((lane - o) << 2);
-			const bool last = o == 32u;                                            // the linear part is not needed behind the last step
-			uint32_t a00 = 0, a01 = 0, a10 = 0, a11 = 0, u0[NC], u1[NC];
-			if(!last) {
-				a00 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m00); a01 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m01);
-				a10 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m10); a11 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m11);
-			}
-#pragma unroll
-			for(int q = 0; q < NC; q++) { u0[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)t0[q]); u1[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)t1[q]); }
-			if(lane >= o) {
-#pragma unroll
-				for(int q = 0; q < NC; q++) {
-					const uint32_t n0 = m00*u0[q] + m01*u1[q] + t0[q], n1 = m10*u0[q] + m11*u1[q] + t1[q];
-					t0[q] = n0; t1[q] = n1;
-				}
-				if(!last) {
-					const uint32_t n00 = m00*a00 + m01*a10, n01 = m00*a01 + m01*a11, n10 = m10*a00 + m11*a10, n11 = m10*a01 + m11*a11;
-					m00 = n00; m01 = n01; m10 = n10; m11 = n11;
-				}
-			}
-		}
+		// inclusive scan of the maps: inside every 16-lane row by DPP row shifts (1, 2, 4, 8), then the total of row 0 / row 2 into rows 1 / 3 and the total of
+		// rows 0-1 into rows 2-3 (row_bcast:15, row_bcast:31) - the steps of wave_inclusive_scan_u32 with the maps' composition for the sum.  A lane takes the
+		// prefix that ends in front of its own and puts its own behind it; a lane the step has no source for gets the identity map and stays as it is.
+		// (Round 5 began with ds_bpermute: 56 LDS instructions a round at 16 clocks of issue each and six exposed round trips - tools/micro/issue_latency.hip.)
+#define CRT_MAP_GET(x, ident, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(ident), (int)(x), ctrl, rmask, 0xf, false))
+#define CRT_MAP_STEP(ctrl, rmask, last) { \
+			uint32_t a00 = 1u, a01 = 0u, a10 = 0u, a11 = 1u, u0[NC], u1[NC]; \
+			if(!(last)) { a00 = CRT_MAP_GET(m00, 1u, ctrl, rmask); a01 = CRT_MAP_GET(m01, 0u, ctrl, rmask); a10 = CRT_MAP_GET(m10, 0u, ctrl, rmask); a11 = CRT_MAP_GET(m11, 1u, ctrl, rmask); } \
+			_Pragma("unroll") for(int q = 0; q < NC; q++) { u0[q] = CRT_MAP_GET(t0[q], 0u, ctrl, rmask); u1[q] = CRT_MAP_GET(t1[q], 0u, ctrl, rmask); } \
+			_Pragma("unroll") for(int q = 0; q < NC; q++) { \
+				const uint32_t n0 = m00*u0[q] + m01*u1[q] + t0[q], n1 = m10*u0[q] + m11*u1[q] + t1[q]; \
+				t0[q] = n0; t1[q] = n1; \
+			} \
+			if(!(last)) {                                                          /* (the linear part is not needed behind the last step) */ \
+				const uint32_t n00 = m00*a00 + m01*a10, n01 = m00*a01 + m01*a11, n10 = m10*a00 + m11*a10, n11 = m10*a01 + m11*a11; \
+				m00 = n00; m01 = n01; m10 = n10; m11 = n11; \
+			} }
+		CRT_MAP_STEP(0x111, 0xf, false)      // row_shr:1
+		CRT_MAP_STEP(0x112, 0xf, false)      // row_shr:2
+		CRT_MAP_STEP(0x114, 0xf, false)      // row_shr:4
+		CRT_MAP_STEP(0x118, 0xf, false)      // row_shr:8
+		CRT_MAP_STEP(0x142, 0xa, false)      // row_bcast:15 into rows 1 and 3
+		CRT_MAP_STEP(0x143, 0xc, true)       // row_bcast:31 into rows 2 and 3
+#undef CRT_MAP_STEP
+#undef CRT_MAP_GET
 		if(lane < len && !done_i) {
 			int32_t r[NC];
 #pragma unroll

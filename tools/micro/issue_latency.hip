@@ -37,6 +37,8 @@ template <int mode> __global__ void k(uint64_t *out, uint32_t *sink, int iters) 
 		if(mode == 23) asm volatile(REP16("s_and_saveexec_b64 %1, vcc\n v_add_u32 %0, %0, 1\n s_or_b64 exec, exec, %1\n v_add_u32 %0, %0, 1\n") : "+v"(v0), "=s"(sm) :: "scc", "exec");
 		if(mode == 24) asm volatile(REP16("s_load_dword %1, %2, 0x0\n s_waitcnt lgkmcnt(0)\n s_add_u32 %1, %1, 1\n v_add_u32 %0, %0, 1\n") : "+v"(v0), "+s"(s0) : "s"(out) : "scc", "memory");   // a scalar load round trip (cache hit)
 		if(mode == 25) asm volatile(REP16("global_load_dword %1, %2, off\n s_waitcnt vmcnt(0)\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, 1\n") : "+v"(v0), "+v"(v1) : "v"(gp) : "memory");   // a vector load round trip (L1/L2 hit)
+		if(mode == 26) asm volatile(REP64("v_mul_lo_u32 %0, %0, %1\n") : "+v"(v0) : "v"(v1));
+		if(mode == 27) asm volatile(REP16("v_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n v_add_u32 %0, %0, 1\n") : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
 		if(mode == 11) asm volatile(REP16("v_mul_u32_u24 %0, %0, %1\n v_lshrrev_b32 %0, 16, %0\n v_or3_b32 %0, %0, %1, %2\n v_and_or_b32 %0, %0, %2, %1\n") : "+v"(v0), "+v"(v1), "+v"(v2));  // K-TAB's kind of dependent VALU
 	}
 	const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -70,6 +72,8 @@ int main() {
 		run<13>("v_cmp -> v_cndmask on an SGPR pair ; 2 x v_add", out, sink, per_cu);
 		run<12>("ds_write ; 3 x v_add", out, sink, per_cu);
 		run<14>("s_lshr -> v_mul reading it ; 2 x v_add", out, sink, per_cu);
+		run<26>("v_mul_lo_u32, one chain", out, sink, per_cu);
+		run<27>("3 x v_mov_b32_dpp of one source ; v_add of the source", out, sink, per_cu);
 		run<15>("ds_write_b128 ; 3 x v_add", out, sink, per_cu);
 		run<16>("ds_write_b128 of ONE lane ; 3 x v_add", out, sink, per_cu);
 		run<17>("ds_read_b32 ; wait ; 2 x v_add  (a round trip every four)", out, sink, per_cu);
