@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_unpack_extract(const UnpackJob *__restr
 		if((uint32_t)k >= r) break;
 		const bool store = i < J.out_limit;
 		CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + (size_t)i*J.stride;
-		const uint32_t half = (1u << (d & 31u)) >> 1;   // upstream's `(1<<diff)>>1` in int (cstream.h:343): 2^(d-1), 0 at d = 0 - and 0 at d = 32, where the compiled reference's shifter takes the count mod 32
+		const uint32_t half = (uint32_t)((int32_t)(1u << (d & 31u)) >> 1);   // upstream's `(1<<diff)>>1` in INT (cstream.h:343): 2^(d-1), 0 at d = 0; at d = 32 the compiled reference's shifter takes the count mod 32 (0); at d = 31 its arithmetic shift gives -2^30 (upstream does not round-trip there: the bytes are the contract)
 		if(J.fields <= 4 && nwords) {                  // (uniform) every field's words in flight together
 			uint32_t hi[4], lo[4];
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 					const uint32_t i = base + (g + k)*64u + lane, dd = d[g + k];
 					const bool store = i < count && i < out_limit;
 					CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + i*stride;
-					const uint32_t half = (1u << (dd & 31u)) >> 1;                 // upstream's `(1<<diff)>>1` in int (cstream.h:343): 0 at dd = 32 too (the compiled reference's shift count is mod 32), as k_unpack_extract
+					const uint32_t half = (uint32_t)((int32_t)(1u << (dd & 31u)) >> 1);   // upstream's `(1<<diff)>>1` in INT (cstream.h:343): 0 at dd = 32 (shift count mod 32), -2^30 at dd = 31 (arithmetic shift of INT_MIN), as k_unpack_extract
 					if(fast) {
 						int32_t v[4];
 #pragma unroll

@@ -522,13 +522,70 @@ def confetti(ncomp=240, seed=0, color_components=4, max_faces=12):
     return Mesh(pos, np.concatenate(T), nrm, col, uv)
 
 
-def full_width_values(mesh: Mesh, seed=0):
-    """Positions and uvs whose quantised values (q = 1) alternate around +-2^30: neighbour differences need all 32 bits of a bit
-    field (upstream's needed() returns 32 for |v| >= 2^30, cstream.h:105-112) - the edge of the bit reader and of `(1<<diff)>>1`."""
+def full_width_values(mesh: Mesh, seed=0, magnitude=2.0 ** 30):
+    """Positions and uvs whose quantised values (q = 1) alternate around +-`magnitude`.  2^30: neighbour differences need all 32 bits of a
+    bit field (upstream's needed() returns 32 for |v| >= 2^30, cstream.h:105-112) - the edge of the bit reader and of `(1<<diff)>>1`.
+    2^28.6: differences of 2^29..2^30 need 31 bits, where that int expression is INT_MIN >> 1 = -2^30 (fixture fields31)."""
     with np.errstate(over="ignore"):
         h = _lcg_fast(seed + 5, mesh.nvert * 10).reshape(mesh.nvert, 10)
     sign = np.where(h[:, :5] < 0.5, -1.0, 1.0)
-    mesh.position = np.ascontiguousarray((sign[:, :3] * (2.0 ** 30 + np.floor(h[:, 5:8] * 2.0 ** 20))).astype(np.float32))
+    mesh.position = np.ascontiguousarray((sign[:, :3] * (magnitude + np.floor(h[:, 5:8] * 2.0 ** 20))).astype(np.float32))
     if mesh.uv is not None:
         mesh.uv = np.ascontiguousarray((sign[:, 3:5] * 2.0 ** 18 * (1.0 + np.floor(h[:, 8:10] * 4095.0))).astype(np.float32))
     return mesh
+
+
+def non_manifold(base: Mesh, seed=0, fins=8, dups=6, reversed_dups=6, bowties=3, glue=4, shuffle_faces=True):
+    """`base` with what scanned / merged / badly exported models carry: **fins** (a third face on an edge, to a new vertex or to an
+    existing one), **duplicated** faces, **reversed duplicates** (the same three vertices wound the other way), **bow-tie** vertices
+    (a triangle that touches the surface in one vertex only) and **glued** pairs (two new faces back to back on an existing edge).
+    Upstream's encoder pairs at most two faces on an edge, by the order std::sort leaves them in (src/encoder.cpp:450-504), and
+    writes BOUNDARY where the face across an edge has been visited already ("glue", src/encoder.cpp:633-636) - so the decoder sees
+    chain ends in the middle of a surface, components of one or two faces and vertices re-emitted under new ids."""
+    rng_i = lambda k, n, hi: (_lcg_fast(seed * 131 + k, n) * hi).astype(np.int64)
+    pos = [base.position.astype(np.float64)]
+    nv = base.nvert
+    idx = base.index.astype(np.int64)
+    nf = len(idx)
+    extra = []
+    ext = float((base.position.max(0) - base.position.min(0)).max()) or 1.0
+    newp = []
+
+    def new_vertex(p):
+        newp.append(p)
+        return nv + len(newp) - 1
+    jit = _lcg_fast(seed * 131 + 99, 3 * (fins + bowties * 2 + glue) + 3).reshape(-1, 3) - 0.5
+    j = 0
+    for t, f in enumerate(rng_i(1, fins, nf)):
+        a, b, c = idx[f]
+        if t % 3 == 2:                                  # to an existing vertex (whichever the hash picks: often far away)
+            w = int(rng_i(2 + t, 1, nv)[0])
+            if w in (a, b):
+                continue
+            extra.append([a, b, w])
+        else:
+            p = (pos[0][a] + pos[0][b]) * 0.5 + (0.03 + 0.05 * (t % 4)) * ext * (jit[j] + [0, 0, 0.7]); j += 1
+            extra.append([a, b, new_vertex(p)] if t % 2 else [b, a, new_vertex(p)])
+    for f in rng_i(3, dups, nf):
+        extra.append(list(idx[f]))
+    for f in rng_i(4, reversed_dups, nf):
+        extra.append(list(idx[f][::-1]))
+    for t, v in enumerate(rng_i(5, bowties, nv)):
+        p = pos[0][v] + 0.04 * ext * (jit[j] + [0.6, 0, 0.6]); q = pos[0][v] + 0.04 * ext * (jit[j + 1] + [0, 0.6, 0.6]); j += 2
+        extra.append([int(v), new_vertex(p), new_vertex(q)])
+    for t, f in enumerate(rng_i(6, glue, nf)):
+        a, b, c = idx[f]
+        w = new_vertex((pos[0][a] + pos[0][b]) * 0.5 + 0.05 * ext * (jit[j] + [0, 0, -0.8])); j += 1
+        extra += [[a, b, w], [b, a, w]]
+    extra = np.array([e for e in extra if len(set(int(x) for x in e)) == 3], dtype=np.int64).reshape(-1, 3)
+    P = np.concatenate([pos[0], np.array(newp, dtype=np.float64).reshape(-1, 3)])
+    I = np.concatenate([idx, extra])
+    if shuffle_faces:
+        I = I[np.argsort(_lcg_fast(seed * 131 + 7, len(I)), kind="stable")]
+    cc = 4 if base.color is None else base.color.shape[1]
+    n2, uv2, col2 = _surface_attrs(P, seed, cc)
+    k = len(newp)
+
+    def grown(old, new):
+        return None if old is None else np.concatenate([old, new[len(new) - k:].astype(old.dtype)]) if k else old
+    return Mesh(P, I, grown(base.normal, n2), grown(base.color, col2), grown(base.uv, uv2))

@@ -280,8 +280,10 @@ static uint32_t decode_array(cur_t *c, uint32_t entropy, int32_t *values, uint32
 		for(uint32_t k = 0; k < N; k++) {
 			int32_t v = 0;
 			/* cstream.h:343 `max = (1<<diff)>>1` in int: at diff == 32 the compiled reference (x86-64 and AArch64 shifters take the count
-			   mod 32) gets (1<<0)>>1 = 0, not 2^31 - checked against oracle/_ref in tests/test_oracle_vs_reference.py */
-			if(d) { v = (int32_t)(co_bits(bb.words, bit, d) - ((1u << (d & 31u)) >> 1)); bit += d; }
+			   mod 32) gets (1<<0)>>1 = 0, not 2^31; at diff == 31 it shifts INT_MIN right arithmetically: -2^30 (the encoder added +2^30,
+			   cstream.h:157 - upstream does not round-trip such values; its bytes are the contract) - both checked against oracle/_ref in
+			   tests/test_oracle_vs_reference.py and pinned by the fixtures fields32 / fields31 */
+			if(d) { v = (int32_t)(co_bits(bb.words, bit, d) - (uint32_t)((int32_t)(1u << (d & 31u)) >> 1)); bit += d; }
 			values[(size_t)i*N + k] = v;
 		}
 	}

@@ -12,7 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 MESH_CASES = ["pos_only", "nrm_diff", "nrm_estimated_rgb", "c4_unit", "two_groups", "group_props", "holey_disc",
               "multi_component", "torus", "closed_sphere", "radius_attr", "entropy_none",
-              "icosphere", "delaunay_holes", "delaunay_shuffled", "cone_fan", "decimated", "confetti", "fields32"]
+              "icosphere", "delaunay_holes", "delaunay_shuffled", "cone_fan", "decimated", "confetti", "fields32", "fields31",
+              "nonmanifold_fins", "nonmanifold_glued", "nonmanifold_border"]
 CLOUD_CASES = ["cloud_diff", "cloud_border"]
 ALL_CASES = MESH_CASES + CLOUD_CASES
 

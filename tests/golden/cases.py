@@ -37,7 +37,15 @@ def cases():
         ("decimated", S.decimated(S.icosphere(3, seed=35), keep=0.45, seed=35), dict(normal_prediction=DIFF)),
         ("confetti", S.confetti(240, seed=36), dict(normal_prediction=BORDER)),
         # bit fields of the full 32 bits (|values| >= 2^30), correlated (position) and per component (uv)
+        # 31-bit fields: `(1<<diff)>>1` in int is INT_MIN >> 1 = -2^30 there (cstream.h:343) - upstream's bytes, not a round trip
+        ("fields31", S.full_width_values(S.bumpy_sphere(9, 7, seed=38), seed=38, magnitude=2.0 ** 28.6), dict(normal_prediction=DIFF, position_bits=0, position_q=1.0, uv_bits=0)),
         ("fields32", S.full_width_values(S.bumpy_sphere(9, 7, seed=37), seed=37), dict(normal_prediction=DIFF, position_bits=0, position_q=1.0, uv_bits=0)),
+        # non-manifold input (round 6): fins, duplicated and reversed faces, bow-tie vertices, glued pairs - upstream's encoder pairs two faces an
+        # edge by std::sort's order and writes BOUNDARY for "glue" (src/encoder.cpp:450-504,633-636).  DIFF keeps every normal in contract; the
+        # ESTIMATED one carries vertices whose face normals cancel (0/0 inside the estimate, finite output); BORDER without back-to-back pairs
+        ("nonmanifold_fins", S.non_manifold(S.delaunay_disc(700, seed=41, holes=4), seed=41, fins=12, dups=8, reversed_dups=8, bowties=4, glue=5), dict(normal_prediction=DIFF)),
+        ("nonmanifold_glued", S.non_manifold(S.bumpy_sphere_flipped(28, 14, seed=42), seed=42, fins=9, dups=10, reversed_dups=10, bowties=3, glue=8), dict(normal_prediction=ESTIMATED)),
+        ("nonmanifold_border", S.non_manifold(S.merge([S.icosphere(2, seed=43), S.cone_fan(40, 2, seed=43)]), seed=43, fins=10, dups=6, reversed_dups=6, bowties=5, glue=0, shuffle_faces=False), dict(normal_prediction=BORDER, position_bits=12)),
         ("cloud_diff", S.point_cloud(96, 64, seed=7), dict(normal_prediction=DIFF)),
         ("cloud_border", S.point_cloud(40, 20, seed=8), dict(normal_prediction=BORDER)),
     ]

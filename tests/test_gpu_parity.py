@@ -1497,9 +1497,11 @@ def test_config4_256_distinct_blobs(ctx):
     st = b.stats()
     assert st.total_nface == 256 * 4096 and st.total_nvert == 256 * 2112
     assert st.topology_fallbacks == 0
-    for i in range(0, 256, 5):
-        got = b.host_outputs(i)
-        assert_same(got, oc.decode(blobs[i]), KEYS, "C4 blob %d" % i)
+    import hashlib
+    for i in range(256):                      # every blob, every array, by SHA-256 of the raw bytes against the oracle's
+        got, exp = b.host_outputs(i), oc.decode(blobs[i])
+        for k in KEYS:
+            assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).digest() == hashlib.sha256(np.ascontiguousarray(exp[k]).tobytes()).digest(), "C4 blob %d %s" % (i, k)
     # round trip: the multiset of decoded positions is the multiset of quantised input positions
     got = b.host_outputs(77)
     q = [a["q"] for a in b.infos[77].attrs() if a["name"] == "position"][0]

@@ -29,6 +29,11 @@ def corpus():
         out.append(("cone%d" % seed, S.cone_fan(7 + 40 * seed, 1 + seed % 4, seed, closed=bool(seed & 1)), {}))
         out.append(("decimated%d" % seed, S.decimated(S.icosphere(1 + seed % 3, seed), keep=0.3 + 0.1 * seed, seed=seed), {}))
         out.append(("confetti%d" % seed, S.shuffled(S.confetti(20 + 60 * seed, seed), seed), {}))
+        # non-manifold input (round 6): fins, duplicated / reversed faces, bow-tie vertices, glued pairs (encoder.cpp:450-504,633-636).  Back-to-back pairs
+        # put a 0/0 into the estimated normal of their own vertex: the reference's bytes there (x86 cvttss2si of a NaN) are what the oracle must give too
+        out.append(("nonmanifold%d" % seed, S.non_manifold([S.delaunay_disc(80 + 200 * seed, seed, holes=seed), S.bumpy_sphere_flipped(8 + 5 * seed, 5 + 2 * seed, seed), S.icosphere(1 + seed % 3, seed)][seed % 3],
+                                                           seed=seed, fins=3 + 4 * seed, dups=2 * seed, reversed_dups=1 + 3 * seed, bowties=seed, glue=seed % 4, shuffle_faces=bool(seed & 1)), {}))
+    out.append(("fields31", S.full_width_values(S.bumpy_sphere(12, 9, 4), 4, magnitude=2.0 ** 28.6), dict(position_q=1.0, uv_bits=0)))
     out.append(("fields32", S.full_width_values(S.bumpy_sphere(12, 9, 3), 3), dict(position_q=1.0, uv_bits=0)))
     out.append(("merge", S.merge([S.closed_sphere(9, 5, 1), S.closed_sphere(7, 4, 2), S.torus(8, 5, 3), S.holey_disc(9, 4, color_components=4)]), {}))
     return out

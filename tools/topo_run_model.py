@@ -325,7 +325,7 @@ def wide(n=400, seed=7):
     rng = np.random.default_rng(seed)
     bad = 0; tot = {}
     for k in range(n):
-        f = k % 11
+        f = k % 12
         if f == 0: m = synth.closed_sphere(int(rng.integers(6, 40)), int(rng.integers(4, 20)), seed=k)
         elif f == 1: m = synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=k, flip=float(rng.choice([0.05, 0.2, 0.5, 0.9])))
         elif f == 2: m = synth.torus(int(rng.integers(6, 30)), int(rng.integers(4, 14)), seed=k)
@@ -337,7 +337,10 @@ def wide(n=400, seed=7):
         elif f == 7: m = synth.delaunay_disc(int(rng.integers(30, 1200)), seed=k, holes=int(rng.integers(0, 10)))
         elif f == 8: m = synth.cone_fan(int(rng.integers(5, 200)), int(rng.integers(1, 5)), seed=k, closed=bool(k & 2), flip=float(rng.uniform(0, 1)))
         elif f == 9: m = synth.decimated(synth.icosphere(int(rng.integers(1, 4)), seed=k), keep=float(rng.uniform(0.2, 0.9)), seed=k)
-        else: m = synth.shuffled(synth.confetti(int(rng.integers(10, 200)), seed=k), seed=k)
+        elif f == 10: m = synth.shuffled(synth.confetti(int(rng.integers(10, 200)), seed=k), seed=k)
+        # non-manifold input (round 6): fins, duplicated / reversed faces, bow-ties, glued pairs
+        else: m = synth.non_manifold([synth.delaunay_disc(int(rng.integers(30, 900)), seed=k, holes=3), synth.bumpy_sphere_flipped(int(rng.integers(8, 40)), int(rng.integers(4, 20)), seed=k, flip=0.4), synth.icosphere(int(rng.integers(1, 4)), seed=k)][(k // 12) % 3],
+                                     seed=k, fins=int(rng.integers(0, 30)), dups=int(rng.integers(0, 20)), reversed_dups=int(rng.integers(0, 20)), bowties=int(rng.integers(0, 10)), glue=int(rng.integers(0, 8)), shuffle_faces=bool(k & 4))
         if k % 2 and m.nface > 24: m.groups = [m.nface // 3, m.nface // 2 + 1, m.nface]
         blob = ca.aligned_blob(ca.encode(m)); r = oc.decode(blob, trace=True)
         mm = Model(r["_clers"], r["nvert"], r["nface"], ca.probe_groups(blob), ref_faces=r["index"])
