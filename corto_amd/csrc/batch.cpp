@@ -100,6 +100,7 @@ extern "C" uint64_t crthip_arena_layout(uint32_t nblobs, const uint32_t *lens, u
 // batch object.  EVERY place that is about to reuse the context's stream, scratch or status buffer goes through here, so a
 // decode(A); decode(B); sync(A) sequence still reports A's failures (status used to be read only by crthip_batch_sync(A) and
 // was lost when another call had synchronised first).
+constexpr uint32_t TOPO_SLOTS_MAX = 4096;       // ring and pool slots of the automaton's LDS form (topo_lds_geometry's ring_max)
 int harvest(crthip_ctx *ctx) {
 	crthip_batch *b = ctx->in_flight;
 	if(!b) return CRTHIP_OK;
@@ -138,7 +139,13 @@ int harvest(crthip_ctx *ctx) {
 	if(b->stats.topology_fallbacks*20 > n) {
 		uint32_t ring_m = 1, pool_q8 = 8;
 		const uint32_t cap_before = ctx->topo_pool_cap;
+		uint32_t learnable = 0;
 		for(size_t i = 0; i < n; i++) if(hs[n + i] & 1) {
+			// a redo that ended in an error (an untrusted stream runs its pool dry before it fails) teaches nothing, and a front beyond the LDS
+			// form's 4 096 + 4 096 records is on the HBM path by design: neither may scale every OTHER blob's request up
+			if(b->status[i]) continue;
+			if((((uint32_t)hs[n + i] >> 1) & 0x7FFFu) > TOPO_SLOTS_MAX || ((uint32_t)hs[n + i] >> 16) > TOPO_SLOTS_MAX) continue;
+			learnable++;
 			const auto &h = b->blobs[i].L.h;
 			uint32_t ring, pool, symwin;
 			topo_lds_geometry(h.nface, b->blobs[i].L.clers.size, 4096, 1, 8, n >= 32 ? 4u : 8u, topo_boundary_estimate(h.nvert, h.nface),
@@ -153,8 +160,9 @@ int harvest(crthip_ctx *ctx) {
 		const bool grew = ring_m > ctx->topo_scale || pool_q8 > ctx->topo_pool_q8 || ctx->topo_pool_cap > cap_before;
 		ctx->topo_scale = std::max(ctx->topo_scale, ring_m); ctx->topo_pool_q8 = std::max(ctx->topo_pool_q8, pool_q8);
 		// (they fell back with what they asked for: capacity, or a need the redo cannot see)
-		if(!grew) { ctx->topo_scale = std::min(16u, ctx->topo_scale*2); ctx->topo_pool_q8 = std::min(128u, ctx->topo_pool_q8*2);
+		if(!grew && learnable) { ctx->topo_scale = std::min(16u, ctx->topo_scale*2); ctx->topo_pool_q8 = std::min(128u, ctx->topo_pool_q8*2);
 			ctx->topo_pool_cap *= 2; }
+		ctx->topo_pool_cap = std::min(ctx->topo_pool_cap, TOPO_SLOTS_MAX + TOPO_SLOTS_MAX/8);      // (a uint32 that doubled without a bound wrapped to 0 = "no cap")
 		if(ctx->topo_calm == 0 && ctx->topo_patience < (1u << 20)) ctx->topo_patience *= 2;    // fell back right after scaling down
 		ctx->topo_calm = 0;
 	} else if(b->stats.topology_fallbacks == 0 && (ctx->topo_scale > 1 || ctx->topo_pool_q8 > 8) &&
@@ -385,6 +393,8 @@ extern "C" int crthip_batch_info(const crthip_batch *b, uint32_t i, crthip_blob_
 static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
 	if(!bd.buffer) return CRTHIP_OK;
 	const uint32_t st = bd.stride;
+	if(bd.reserved & ~CRTHIP_BIND_STREAM_VALUES) return CRTHIP_E_ARGUMENT;
+	if((bd.reserved & CRTHIP_BIND_STREAM_VALUES) && a.codec != CRTHIP_CODEC_GENERIC) return CRTHIP_E_FORMAT;   // normals / colours have codecs of their own upstream too
 	if(a.codec == CRTHIP_CODEC_NORMAL) {
 		if(bd.format != CRTHIP_FMT_FLOAT && bd.format != CRTHIP_FMT_INT16) return CRTHIP_E_FORMAT;
 		const uint32_t el = bd.format == CRTHIP_FMT_INT16 ? 2u : 4u;
@@ -401,6 +411,8 @@ static int check_binding(const AttrHeader &a, const crthip_attr_binding &bd) {
 		return CRTHIP_OK;
 	}
 	if(a.N < 1 || bd.format > CRTHIP_FMT_DOUBLE) return CRTHIP_E_FORMAT;
+	// the device half of a caller-supplied codec object: int32 stream values, packed (corto_hip.h: CRTHIP_BIND_STREAM_VALUES)
+	if(bd.reserved & CRTHIP_BIND_STREAM_VALUES) return bd.format == CRTHIP_FMT_INT32 && !st && ((uintptr_t)bd.buffer) % 4 == 0 ? CRTHIP_OK : CRTHIP_E_ARGUMENT;
 	// a packed buffer doubles as the int32 workspace and K-DELTA turns it into floats with dword / 16-byte accesses: a float* that is
 	// not 4-byte aligned (never one a C++ caller's setPositions(float*) could pass) is refused, not decoded into integers
 	if(((uintptr_t)bd.buffer) % (bd.format == CRTHIP_FMT_DOUBLE ? 8 : 4)) return CRTHIP_E_ARGUMENT;
@@ -428,6 +440,7 @@ extern "C" int crthip_batch_bind(crthip_batch *b, uint32_t i, const crthip_attr_
 		const uint32_t packed = a.codec == CRTHIP_CODEC_NORMAL ? (attrs[k].format == CRTHIP_FMT_INT16 ? 6u : 12u)
 		                      : a.codec == CRTHIP_CODEC_COLOR ? P.bind[k].out_components : 4u*a.N;
 		P.bind[k].stride = attrs[k].stride == packed ? 0u : attrs[k].stride;
+		P.bind[k].stream_values = (attrs[k].reserved & CRTHIP_BIND_STREAM_VALUES) != 0;
 	}
 	P.index = index; P.index_u16 = index && index_format == CRTHIP_FMT_UINT16;
 	b->dirty = true;
@@ -535,6 +548,10 @@ extern "C" int crthip_batch_kernel_times(crthip_batch *b, crthip_kernel_times *t
 	return CRTHIP_OK;
 }
 
+extern "C" int64_t crthip_batch_read_prediction(crthip_batch *b, uint32_t i, void *host_out, size_t cap) {
+	return crthip_batch_debug_read(b, i, "prediction", host_out, cap);
+}
+
 extern "C" int64_t crthip_batch_debug_read(crthip_batch *b, uint32_t i, const char *what, void *host_out, size_t cap) {
 	if(!b || i >= b->blobs.size() || !what || !host_out || !b->decoded) return fail(CRTHIP_E_ARGUMENT);
 	crthip_ctx *ctx = b->ctx;
@@ -593,6 +610,7 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 		std::vector<uint32_t> ifmt(m, CRTHIP_FMT_UINT32);
 	struct Piece { uint32_t req, slot; size_t off, bytes; void *host; };
 	std::vector<Piece> pieces;
+	std::vector<std::pair<uint32_t, size_t>> pred_piece;            // (blob of the batch, offset in the output block)
 	size_t total = 0;
 	for(uint32_t k = 0; k < m; k++) {
 		HostDecodeReq &r = reqs[who[k]];
@@ -604,10 +622,10 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 			// attrs == NULL: nothing bound (an index-only decode); host buffers have upstream's packed layouts - a stride is refused, not
 			// ignored
 			crthip_attr_binding d;
-			if(r.attrs) d = r.attrs[a]; else { d.buffer = nullptr; d.format = CRTHIP_FMT_FLOAT; d.out_components = 0; d.stride = 0; }
+			if(r.attrs) d = r.attrs[a]; else { d.buffer = nullptr; d.format = CRTHIP_FMT_FLOAT; d.out_components = 0; d.stride = 0; d.reserved = 0; }
 			if(d.buffer && d.stride) { r.status = fail(CRTHIP_E_ARGUMENT,
 				"crthip_decode_host: host buffers are tightly packed (stride must be 0)"); d.buffer = nullptr; }
-			d.stride = 0; d.reserved = 0;
+			d.stride = 0; d.reserved &= CRTHIP_BIND_STREAM_VALUES;
 			if(d.buffer && r.status == CRTHIP_OK) {
 				const AttrHeader &A = L.h.attrs[a];
 				size_t bytes;
@@ -626,6 +644,11 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 			pieces.push_back(Piece{who[k], CRTHIP_MAX_ATTRS, total, bytes, r.index});
 			dindex[k] = (void *)(uintptr_t)(total + 1); ifmt[k] = r.index_format;
 			total += (bytes + 15) & ~(size_t)15;
+		}
+		if(r.prediction && nface && r.status == CRTHIP_OK) {         // the prediction triples: copied out of the scratch block behind the kernels (below)
+			pieces.push_back(Piece{who[k], CRTHIP_MAX_ATTRS + 1, total, (size_t)nvert*12, r.prediction});
+			pred_piece.push_back({k, total});
+			total += ((size_t)nvert*12 + 15) & ~(size_t)15;
 		}
 	}
 	if(ctx->host_out.reserve(total + 16) != CRTHIP_OK || ctx->host_pin.reserve(total +
@@ -648,6 +671,11 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 		}
 	}
 	if(!err) err = crthip_batch_decode(b);
+	for(auto &pp : pred_piece) {
+		const BlobPlan &P = b->blobs[pp.first];
+		if(!err && P.dbg_pred != ~0ull && hipMemcpyAsync(dbase + pp.second, (const uint8_t *)ctx->scratch.p + P.dbg_pred, (size_t)P.L.h.nvert*12,
+			hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
+	}
 	if(!err && total && hipMemcpyAsync(hbase, dbase, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) err = fail(CRTHIP_E_DEVICE);
 	std::vector<int32_t> st(m, 0);
 	// (waits for the kernels: the event behind them; keeps the context consistent on error)
@@ -659,7 +687,7 @@ int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy
 		HostDecodeReq &r = reqs[p.req];
 		if(r.status != CRTHIP_OK) continue;
 		if(copy_out) memcpy(p.host, hbase + p.off, p.bytes);
-		else if(r.nout < CRTHIP_MAX_ATTRS + 1) { r.out_src[r.nout] = hbase + p.off; r.out_dst[r.nout] = p.host; r.out_bytes[r.nout] =
+		else if(r.nout < CRTHIP_MAX_ATTRS + 2) { r.out_src[r.nout] = hbase + p.off; r.out_dst[r.nout] = p.host; r.out_bytes[r.nout] =
 			p.bytes; r.nout++; }
 	}
 	if(err) return err;

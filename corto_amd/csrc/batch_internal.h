@@ -190,7 +190,7 @@ struct crthip_ctx {
 // in place (include/corto/vertex_attribute.h:184-228), so every format's buffer is nvert*N*4 bytes but DOUBLE's
 static inline size_t generic_work_bytes(uint32_t format) { return format == CRTHIP_FMT_DOUBLE ? 8u : 4u; }
 
-struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; };
+struct Binding { void *buffer = nullptr; uint32_t format = CRTHIP_FMT_FLOAT, out_components = 4, stride = 0; bool stream_values = false; };   // stream_values: CRTHIP_BIND_STREAM_VALUES
 
 struct BlobPlan {
 	BlobLayout L;

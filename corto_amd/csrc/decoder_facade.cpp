@@ -274,9 +274,22 @@ bool Decoder::setAttribute(const char *name, char *buffer, VertexAttribute::Form
 	return true;
 }
 
-bool Decoder::setAttribute(const char *name, char *, VertexAttribute *) {
-	if(data.find(name) == data.end()) return false;
-	throw "Custom attribute codecs cannot run on the device path";
+// src/decoder.cpp:104-114: the object takes the stream's q / strategy / N and the buffer, replaces the attribute, and is the Decoder's from here on.
+// Its codec() tells decode() that the attribute's deltaDecode / postDelta / dequantize are host calls (anything but the three built-in ids;
+// upstream's own convention for such objects is CUSTOM_CODEC).
+bool Decoder::setAttribute(const char *name, char *buffer, VertexAttribute *attr) {
+	auto it = data.find(name);
+	if(it == data.end()) return false;
+	VertexAttribute *found = it->second;
+	if(found->codec_id != VertexAttribute::GENERIC_CODEC) throw "A custom codec object can replace a generic attribute only on the device path";
+	attr->q = found->q;
+	attr->strategy = found->strategy;
+	attr->N = found->N;
+	attr->buffer = buffer;
+	attr->codec_id = VertexAttribute::CUSTOM_CODEC;
+	delete found;
+	it->second = attr;
+	return true;
 }
 
 bool Decoder::setColors(uchar *buffer, int components) {
@@ -309,20 +322,33 @@ void Decoder::decode() {
 		}
 	}
 	Request r;
+	bool custom = false;
+	static_assert(sizeof(Face) == 12, "Face is three uint32");
 	for(auto &it : data) {                                   // std::map order == the C ABI's attribute order (sorted by name)
 		crthip_attr_binding b;
 		b.buffer = it.second->buffer;
 		b.format = (uint32_t)it.second->format;
 		b.out_components = (uint32_t)it.second->out_components;
 		b.stride = 0; b.reserved = 0;
+		if(it.second->codec_id == VertexAttribute::CUSTOM_CODEC && b.buffer) {   // the stream's int32 values; the object's own steps follow below
+			b.format = CRTHIP_FMT_INT32; b.reserved = CRTHIP_BIND_STREAM_VALUES; custom = true;
+		}
 		r.binds.push_back(b);
 	}
+	if(custom && nface) { index.prediction.resize(nvert); r.h.prediction = index.prediction.data(); }
 	r.h.blob = input_; r.h.len = (size_t)len_;
 	r.h.attrs = r.binds.empty() ? nullptr : r.binds.data();
 	r.h.index = index.faces16 ? (void *)index.faces16 : (void *)index.faces32;   // faces16 wins (src/decoder.cpp:246-249)
 	r.h.index_format = index.faces16 ? CRTHIP_FMT_UINT16 : CRTHIP_FMT_UINT32;
 	const int err = combined_decode(r);                       // alone: one blob on a pool context; with other threads decoding: one batch for all
 	if(err) raise(err);
+	if(custom) {
+		// the caller's codec objects, in upstream's order (src/decoder.cpp:186-193 for meshes, :141-146 for clouds: no postDelta there)
+		std::vector<Face> none;
+		for(auto &it : data) if(it.second->codec_id == VertexAttribute::CUSTOM_CODEC) it.second->deltaDecode(nvert, nface ? index.prediction : none);
+		if(nface) for(auto &it : data) if(it.second->codec_id == VertexAttribute::CUSTOM_CODEC) it.second->postDelta(nvert, nface, data, index);
+		for(auto &it : data) if(it.second->codec_id == VertexAttribute::CUSTOM_CODEC) it.second->dequantize(nvert);
+	}
 }
 
 } // namespace crt

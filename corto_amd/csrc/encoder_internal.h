@@ -42,9 +42,10 @@ struct HostDecodeReq {
 	const uint8_t *blob; size_t len;
 	const crthip_attr_binding *attrs;       // info.nattr entries in attribute order, or null: nothing bound
 	void *index; uint32_t index_format;
+	void *prediction;                       // host, nvert*3 uint32 or null: upstream's index.prediction (the context of a caller-supplied codec's deltaDecode)
 	int32_t status;                         // out: CRTHIP_OK or this blob's CRTHIP_E_*
 	uint32_t nout;                          // out (copy_out == false): pieces to copy
-	const uint8_t *out_src[CRTHIP_MAX_ATTRS + 1]; void *out_dst[CRTHIP_MAX_ATTRS + 1]; size_t out_bytes[CRTHIP_MAX_ATTRS + 1];
+	const uint8_t *out_src[CRTHIP_MAX_ATTRS + 2]; void *out_dst[CRTHIP_MAX_ATTRS + 2]; size_t out_bytes[CRTHIP_MAX_ATTRS + 2];
 };
 int decode_host_many(crthip_ctx *ctx, uint32_t n, HostDecodeReq *reqs, bool copy_out);
 

@@ -198,6 +198,9 @@ int Planner::jobs() {
 				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], work, work_real, 1, 1, (uint16_t)a.N, (uint16_t)c,
 					0);
 				values = work; values_real = work_real; para = (a.strategy & CRTHIP_PARALLEL) != 0;
+				// the device half of a caller-supplied codec object (CRTHIP_BIND_STREAM_VALUES): the stream's int32 values stay as they are -
+				// GenericAttr<int>::decode's result (vertex_attribute.h:151-156); deltaDecode / dequantize are the caller's, on the host
+				if(bd.stream_values) continue;
 			}
 			bool dequantised = false;                                // by K-DELTA or by the fused normal kernel: no k_dequant job
 			if(do_delta && nvert > 1) {
@@ -237,8 +240,9 @@ int Planner::jobs() {
 					n.prediction = (uint8_t)pr; n.out_i16 = bd.format == CRTHIP_FMT_INT16;
 					n.status = HS(i);
 					if(pr != 0) {
+						// (a position under a caller-supplied codec holds stream values, not positions: upstream throws there too, normal_attribute.cpp:210-213)
 						const bool pos_ok = pos_k >= 0 && L.h.attrs[pos_k].codec == CRTHIP_CODEC_GENERIC && L.h.attrs[pos_k].N == 3 &&
-							P.bind[pos_k].buffer;
+							P.bind[pos_k].buffer && !P.bind[pos_k].stream_values;
 						if(!pos_ok) { P.host_status = CRTHIP_E_NORMAL_NEEDS_POSITION; continue; }
 						// the integer positions: in the caller's packed buffer, or in scratch
 						const bool pos_scratch = P.bind[pos_k].stride != 0 || P.bind[pos_k].format == CRTHIP_FMT_DOUBLE;

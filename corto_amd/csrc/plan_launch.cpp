@@ -105,7 +105,7 @@ int Planner::launch() {
 	};
 	auto unpack = [&](hipStream_t s) {
 		const uint32_t nuw = (uint32_t)pl.unpack_wave_ids.v.size();
-		if(nuw) { LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_wave, dim3(nuw), dim3(64), 0, s, D(pl.unpack),
+		if(nuw) { LT.begin("unpack_wave", s); hipLaunchKernelGGL(k_unpack_wave, dim3(nuw), dim3(64), 0, s, D(pl.unpack),
 			D(pl.unpack_wave_ids), nuw); LT.end(); }
 		if(!unpack_chunks) return;
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack),
@@ -165,12 +165,15 @@ int Planner::launch() {
 		uint32_t ncls[3] = {0, 0, 0};
 		for(auto &d : pl.delta.v) ncls[delta_class(d, wide)]++;
 		const uint32_t ngroups = (uint32_t)pl.delta_groups.v.size();
-		LT.begin("delta_mesh");
-		if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
-		if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
-		if(ngroups) hipLaunchKernelGGL(k_delta_lds16, dim3(ngroups), dim3(256), pl.delta16_lds, st, D(pl.delta), D(pl.delta_groups),
-			ngroups);
-		LT.end();
+		// (the timer's names are the kernels that run: `delta_mesh` = the walk over HBM, `delta_lds16` = the LDS form, one workgroup a blob)
+		if(ncls[0] || ncls[1]) {
+			LT.begin("delta_mesh");
+			if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
+			if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
+			LT.end();
+		}
+		if(ngroups) { LT.begin("delta_lds16"); hipLaunchKernelGGL(k_delta_lds16, dim3(ngroups), dim3(256), pl.delta16_lds, st, D(pl.delta), D(pl.delta_groups),
+			ngroups); LT.end(); }
 	}
 	if(cloud_chunks) {
 		LT.begin("cloud_sums"); hipLaunchKernelGGL(k_cloud_sums, dim3(cloud_chunks), dim3(256), 0, st, D(pl.cloud), D(pl.cloud_chunk_job),

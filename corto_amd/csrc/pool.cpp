@@ -56,6 +56,7 @@ struct crthip_pool {
 	std::vector<Lane> lanes;        // [device][thread][depth]
 	std::vector<std::vector<int>> cpus;   // per pool device: the host CPUs of the GPU's NUMA node (empty: unknown, threads are not pinned)
 	std::string warning;            // what crthip_pool_create had to say about hardware queues (empty: nothing)
+	bool render = false;            // crthip_pool_set_render_layouts: int16 normals, uint16 index where the blob's vertex ids fit
 	bool to_host = false;           // crthip_pool_set_outputs_to_host: every step ends with a D2H copy of its outputs into the lane's pinned block
 	// state of one run
 	std::atomic<uint64_t> next{0}, completed{0};
@@ -147,6 +148,12 @@ extern "C" int crthip_pool_set_outputs_to_host(crthip_pool *p, int on) {
 	p->to_host = on != 0;
 	return CRTHIP_OK;
 }
+extern "C" int crthip_pool_set_render_layouts(crthip_pool *p, int on) {
+	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
+	p->render = on != 0;
+	for(auto &L : p->lanes) { L.binds.clear(); L.item = -1; }      // the lanes lay their outputs out again
+	return CRTHIP_OK;
+}
 extern "C" int crthip_pool_set_packed_host_blobs(crthip_pool *p, int on) {
 	if(!p) return ctx_fail(CRTHIP_E_ARGUMENT, nullptr);
 	for(auto &L : p->lanes) { const int err = crthip_ctx_set_packed_host_blobs(L.ctx, on); if(err) return err; }
@@ -179,13 +186,14 @@ static int lane_plan(crthip_pool *p, Lane &L, const crthip_pool_item &it, int64_
 				const crthip_attr_info &a = info.attr[k];
 				crthip_attr_binding b; b.buffer = nullptr; b.format = CRTHIP_FMT_FLOAT; b.out_components = 0; b.stride = 0; b.reserved = 0;
 				size_t n;
-				if(a.codec == CRTHIP_CODEC_NORMAL) n = (size_t)info.nvert*12;
+				if(a.codec == CRTHIP_CODEC_NORMAL) { if(p->render) b.format = CRTHIP_FMT_INT16; n = (size_t)info.nvert*(p->render ? 6 : 12); }
 				else if(a.codec == CRTHIP_CODEC_COLOR) { b.format = CRTHIP_FMT_UINT8; b.out_components = 4; n = (size_t)info.nvert*4; }
 				else n = (size_t)info.nvert*a.components*4;
 				L.attr_off.push_back(take(n));
 				L.binds.push_back(b);
 			}
-			if(info.nface) L.index_off[i] = take((size_t)info.nface*12);
+			if(info.nface && p->render && info.nvert < 65536) L.index_fmt[i] = CRTHIP_FMT_UINT16;
+			if(info.nface) L.index_off[i] = take((size_t)info.nface*(L.index_fmt[i] == CRTHIP_FMT_UINT16 ? 6 : 12));
 		}
 		const size_t total = off + 256;
 		if(total > L.out_cap) {
@@ -379,12 +387,12 @@ extern "C" int64_t crthip_pool_lane_read(crthip_pool *p, uint32_t lane, uint32_t
 	if(err) return err;
 	const uint8_t *src = nullptr; size_t n = 0;
 	if(!strcmp(what, "#tail")) { n = L.out_cap < 256 ? L.out_cap : 256; src = (const uint8_t *)L.out + (L.out_cap - n); }   // the block's last bytes: behind every output array
-	else if(!strcmp(what, "index")) { if(!info.nface) return 0; src = (const uint8_t *)L.index_ptr[blob]; n = (size_t)info.nface*12; }
+	else if(!strcmp(what, "index")) { if(!info.nface) return 0; src = (const uint8_t *)L.index_ptr[blob]; n = (size_t)info.nface*(L.index_fmt[blob] == CRTHIP_FMT_UINT16 ? 6 : 12); }
 	else {
 		for(uint32_t k = 0; k < info.nattr; k++) if(!strcmp(info.attr[k].name, what)) {
 			const crthip_attr_info &a = info.attr[k];
 			src = (const uint8_t *)L.binds[L.first_attr[blob] + k].buffer;
-			n = a.codec == CRTHIP_CODEC_NORMAL ? (size_t)info.nvert*12 : a.codec == CRTHIP_CODEC_COLOR ? (size_t)info.nvert*4 : (size_t)info.nvert*a.components*4;
+			n = a.codec == CRTHIP_CODEC_NORMAL ? (size_t)info.nvert*(L.binds[L.first_attr[blob] + k].format == CRTHIP_FMT_INT16 ? 6 : 12) : a.codec == CRTHIP_CODEC_COLOR ? (size_t)info.nvert*4 : (size_t)info.nvert*a.components*4;
 		}
 		if(!src) return ctx_fail(CRTHIP_E_ARGUMENT, "no such attribute");
 	}

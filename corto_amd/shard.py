@@ -78,12 +78,13 @@ def plan_host_threads(requested: int, gpu_cpus: Sequence[Sequence[int]], affinit
         if not cpus:
             raise ValueError("no usable host CPU for GPUs %s" % gpus)
         room = max(len(cpus) - reserve, 0) // len(gpus)
+        oversubscribed = room < 1                         # (per GROUP: an oversubscribed node must not hide a later node's "N threads instead of M" note)
         if room < 1:                                      # fewer cores than GPUs: one thread each, time-shared - measured, but said LOUDLY (stderr and the JSON line)
             notes.append("OVERSUBSCRIBED HOST: %d GPU(s) share %d usable host CPU(s) (%s...) - one feeder thread each, time-shared: the rate below measures the host; "
                          "widen the cpuset (taskset / cgroup)" % (len(gpus), len(cpus), ",".join(map(str, cpus[:8]))))
             room = 1
         t = min(requested, room)
-        if t < requested and room >= 1 and not (notes and notes[-1].startswith("OVERSUBSCRIBED")):
+        if t < requested and not oversubscribed:
             notes.append("GPUs %s: %d host threads each instead of %d (%d usable CPUs next to them)" % (gpus, t, requested, len(cpus)))
         for d in gpus:
             per_gpu[d] = t

@@ -7,8 +7,13 @@
 //
 // Differences, all deliberate and loud:
 //   * there is no CPU path: without a usable HIP device decode() throws;
-//   * VertexAttribute here is a plain descriptor, not upstream's codec base class: custom codec objects
-//     (setAttribute(name, buffer, VertexAttribute*)) cannot run on the device and are rejected;
+//   * VertexAttribute here describes an attribute; the built-in codecs (generic, normal, colour) run on the device.  A caller-supplied
+//     codec OBJECT (setAttribute(name, buffer, VertexAttribute *), src/decoder.cpp:104-114) is host code: the device decodes the
+//     attribute's stream into the buffer as int32 values (what upstream's GenericAttr<int>::decode leaves there,
+//     include/corto/vertex_attribute.h:151-156 - a custom object therefore keeps the generic STREAM coding and overrides what comes
+//     after it), then decode() calls the object's deltaDecode(nvert, index.prediction), postDelta(...) and dequantize(nvert) on the
+//     host, in upstream's order (src/decoder.cpp:186-193).  Other attributes are final by then (upstream: still quantised integers);
+//     ESTIMATED / BORDER normals over a position that has a custom object throw, as upstream's do (src/normal_attribute.cpp:210-213);
 //   * generic attributes take every VertexAttribute::Format through setAttribute(name, buffer, format): FLOAT is the format upstream's own
 //     callers use; the integer formats and DOUBLE leave in the buffer what the compiled reference leaves there (its "*= q" through a pointer
 //     of the output type over the int32 array, vertex_attribute.h:195-228 - buffers of nvert*N*4 bytes, nvert*N*8 for DOUBLE, as upstream);
@@ -33,7 +38,16 @@ typedef unsigned char uchar;
 
 namespace crt {
 
-// upstream include/corto/vertex_attribute.h:30-45 (data members only)
+// upstream include/corto/index_attribute.h:34-38: a vertex' prediction triple (decode order)
+struct Face {
+	uint32_t a, b, c;
+	Face() {}
+	Face(uint32_t v0, uint32_t v1, uint32_t v2): a(v0), b(v1), c(v2) {}
+};
+class IndexAttribute;
+
+// upstream include/corto/vertex_attribute.h:30-66: the data members, and - for caller-supplied codec objects - the decode-side virtuals that
+// are host code (decode(nvert, InStream &) itself is the device's: the generic stream coding)
 class VertexAttribute {
 public:
 	enum Format { UINT32 = 0, INT32, UINT16, INT16, UINT8, INT8, FLOAT, DOUBLE };
@@ -49,7 +63,12 @@ public:
 	int bits = 0;
 	int codec_id = GENERIC_CODEC;
 	int out_components = 4;     // colours only (upstream ColorAttr::out_components)
-	int codec() const { return codec_id; }
+	virtual ~VertexAttribute() {}
+	virtual int codec() { return codec_id; }
+	// the host half of a caller-supplied codec object (vertex_attribute.h:58-65); the defaults do nothing: the built-in codecs' run on the device
+	virtual void deltaDecode(uint32_t /*nvert*/, std::vector<Face> & /*context*/) {}
+	virtual void postDelta(uint32_t /*nvert*/, uint32_t /*nface*/, std::map<std::string, VertexAttribute *> & /*attrs*/, IndexAttribute & /*index*/) {}
+	virtual void dequantize(uint32_t /*nvert*/) {}
 };
 
 // upstream include/corto/index_attribute.h:40-60 (what callers touch)
@@ -62,6 +81,7 @@ class IndexAttribute {
 public:
 	uint32_t *faces32 = nullptr;
 	uint16_t *faces16 = nullptr;
+	std::vector<Face> prediction;   // filled by decode() when an attribute has a caller-supplied codec object (upstream fills it always)
 	std::vector<Group> groups;
 	uint32_t max_front = 0;
 };
@@ -87,7 +107,7 @@ public:
 	bool setColors(uchar *buffer, int components = 4);
 
 	bool setAttribute(const char *name, char *buffer, VertexAttribute::Format format);
-	bool setAttribute(const char *name, char *buffer, VertexAttribute *attr);   // custom codecs: rejected (throws)
+	bool setAttribute(const char *name, char *buffer, VertexAttribute *attr);   // a caller-supplied codec object (owned by the Decoder from here on, as upstream): see the top of this file
 
 	void setIndex(uint32_t *buffer) { index.faces32 = buffer; }
 	void setIndex(uint16_t *buffer) { index.faces16 = buffer; }

@@ -35,8 +35,9 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 5   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_*; 3: crthip_pool_report grew, crthip_pool_warning;
-                                  4: integer / DOUBLE output formats of generic attributes, crthip_pool_device_cpus; 5: crthip_pool_set_outputs_to_host */
+#define CRTHIP_ABI_VERSION 6   /* 2: crthip_attr_binding.stride, crthip_mesh.group_props, crthip_pool_*; 3: crthip_pool_report grew, crthip_pool_warning;
+                                  4: integer / DOUBLE output formats of generic attributes, crthip_pool_device_cpus; 5: crthip_pool_set_outputs_to_host;
+                                  6: crthip_pool_set_render_layouts, crthip_kernel_times names are the kernels' (unpack_wave, delta_lds16) */
 
 /* VertexAttribute::Format, include/corto/vertex_attribute.h:32 */
 enum { CRTHIP_FMT_UINT32 = 0, CRTHIP_FMT_INT32 = 1, CRTHIP_FMT_UINT16 = 2, CRTHIP_FMT_INT16 = 3,
@@ -105,8 +106,16 @@ typedef struct {
 	                                setIndex(uint16_t*) (include/corto/decoder.h:53,61).  Must be a multiple of 4 for FLOAT outputs, of 2
 	                                for INT16 normals, and at least the element's size; with a stride the attribute is decoded in device
 	                                scratch and only its final values touch the buffer (a packed generic buffer doubles as int32 workspace) */
-	uint32_t reserved;           /* 0 */
+	uint32_t reserved;           /* flags: 0, or CRTHIP_BIND_STREAM_VALUES */
 } crthip_attr_binding;
+/* crthip_attr_binding.reserved, generic attributes only (ABI 6): stop behind the stream decode - `buffer` (nvert*N int32, packed, format
+ * CRTHIP_FMT_INT32) receives the values as the stream holds them, i.e. what upstream's GenericAttr<int>::decode leaves in the buffer
+ * (include/corto/vertex_attribute.h:151-156: InStream::decodeArray / decodeValues) BEFORE deltaDecode and dequantize.  This is the device
+ * half of a caller-supplied codec object (Decoder::setAttribute(name, buffer, VertexAttribute *), src/decoder.cpp:104-114): its
+ * deltaDecode / postDelta / dequantize are host code and run on these values (include/corto/decoder.h of this repo).  A position bound this
+ * way cannot feed ESTIMATED / BORDER normals (upstream throws "Position attr has been overloaded" there, src/normal_attribute.cpp:210-213):
+ * the blob fails with CRTHIP_E_NORMAL_NEEDS_POSITION. */
+#define CRTHIP_BIND_STREAM_VALUES 1u
 
 typedef struct crthip_ctx crthip_ctx;       /* one per device; owns streams + scratch pool */
 typedef struct crthip_batch crthip_batch;   /* a planned batch of independent .crt blobs */
@@ -215,6 +224,10 @@ int crthip_pool_set_packed_host_blobs(crthip_pool *pool, int on);
  * that copy delivered.  What a host-side consumer of the outputs sees - the reference's own region, decode() into host buffers
  * (src/main.cpp:266-300).  Off by default: outputs stay in HBM. */
 int crthip_pool_set_outputs_to_host(crthip_pool *pool, int on);
+/* SURVEY 8f3's render layouts for every lane's outputs: normals as int16 (upstream's NormalAttr INT16 output, src/normal_attribute.cpp:203-208,
+ * 317-323) and the index as uint16 where a blob has fewer than 65 536 vertices (Decoder::setIndex(uint16_t *), include/corto/decoder.h:61) - 22 % fewer
+ * output bytes for a C4 blob, which is what the secondary region's D2H copy moves.  crthip_pool_lane_read returns those bytes. */
+int crthip_pool_set_render_layouts(crthip_pool *pool, int on);
 
 /* One work item = one batch of blobs (HOST pointers, borrowed for the duration of crthip_pool_run).
  * device_arena: NULL -> every execution uploads the blobs (pageable or pinned host memory -> HBM) inside the step (SURVEY.md 8d's primary
@@ -343,6 +356,10 @@ typedef struct {
 } crthip_kernel_times;
 int crthip_ctx_set_profiling(crthip_ctx *ctx, int enable);
 int crthip_batch_kernel_times(crthip_batch *b, crthip_kernel_times *t);
+/* The prediction triples of blob i of the last decode (upstream's index.prediction, include/corto/index_attribute.h:34-38,76: one Face
+ * {a, b, c} per vertex in decode order - what VertexAttribute::deltaDecode takes as its context): nvert*3 uint32 copied to HOST memory;
+ * returns the bytes written (0 for a point cloud), < 0 on error.  Valid until the context's next decode. */
+int64_t crthip_batch_read_prediction(crthip_batch *b, uint32_t i, void *host_out, size_t cap);
 
 /* Copy an internal intermediate of blob i to a HOST buffer (tests compare these with the oracle):
  * what = "clers" (u8 symbols), "prediction" (nvert*3 u32). Returns bytes written or <0. */

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# fixtures made from Delaunay meshes carry their triangulations: a test that rebuilds such a mesh gets the one the golden blob was made from
+from corto_amd import synth as _synth  # noqa: E402
+if os.path.exists(os.path.join(GOLDEN, "delaunay_tris.npz")):
+    _synth.load_delaunay_store(os.path.join(GOLDEN, "delaunay_tris.npz"))
+
 MESH_CASES = ["pos_only", "nrm_diff", "nrm_estimated_rgb", "c4_unit", "two_groups", "group_props", "holey_disc",
               "multi_component", "torus", "closed_sphere", "radius_attr", "entropy_none",
               "icosphere", "delaunay_holes", "delaunay_shuffled", "cone_fan", "decimated", "confetti", "fields32", "fields31",

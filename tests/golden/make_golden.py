@@ -117,6 +117,8 @@ def main():
         print("%-20s crt %7d B  nvert %6d nface %6d" % index[-1])
 
     if only is not None:
+        if "delaunay_tris" in only:
+            delaunay_store()
         if "tunstall_kat" in only:
             tunstall_kat()
         if "nonlattice_blobs8" in only:
@@ -148,6 +150,18 @@ def main():
 
     nonlattice_blobs()
     tunstall_kat()
+    delaunay_store()
+
+
+def delaunay_store():
+    """the triangulation of every Delaunay point set a fixture is made from (synth._delaunay_2d looks them up by the points' digest): tests that rebuild
+    those meshes then encode what the reference encoded, whatever triangulator is installed"""
+    synth._DELAUNAY_STORE.clear()
+    synth._DELAUNAY_RECORD = {}
+    cases(); nonlattice_meshes()
+    np.savez_compressed(os.path.join(OUT, "delaunay_tris.npz"), **synth._DELAUNAY_RECORD)
+    print("delaunay_tris        %d point sets" % len(synth._DELAUNAY_RECORD))
+    synth._DELAUNAY_RECORD = None
 
 
 def nonlattice_meshes():

@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(L):
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(L, n), n
-    assert L.crthip_abi_version() == 5
+    assert L.crthip_abi_version() == 6
 
 
 def test_headers_are_plain_c(tmp_path):

@@ -495,6 +495,66 @@ def test_cpp_decoder_dropin(ctx, tmp_path):
     assert out.returncode == 1 and "Not a crt file." in out.stderr
 
 
+def test_cpp_custom_codec_object(ctx, tmp_path):
+    """Decoder::setAttribute(name, buffer, VertexAttribute *) (src/decoder.cpp:104-114): the device decodes the attribute's stream (CRTHIP_BIND_STREAM_VALUES),
+    the caller's object runs deltaDecode / postDelta / dequantize on the host with upstream's prediction triples.  A codec that restates GenericAttr<int>
+    gives the built-in codec's bytes; one with a twist gives its own; estimated normals over a custom position throw as upstream's do"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "facade_custom_codec")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_custom_codec.cpp"),
+                           "-L", os.path.dirname(ca.LIB_PATH), "-lcorto_hip", "-Wl,-rpath," + os.path.dirname(ca.LIB_PATH), "-o", exe])
+    for name, attr in (("nrm_diff", "position"), ("c4_unit", "uv"), ("torus", "uv"), ("radius_attr", "radius"), ("nonmanifold_fins", "position"), ("two_groups", "uv"),
+                       ("cloud_diff", "position"), ("fields32", "uv")):
+        g = load_golden(name)
+        src, dst = str(tmp_path / (name + ".crt")), str(tmp_path / (name + ".bin"))
+        g["crt"].tofile(src)
+        out = subprocess.run([exe, src, attr, dst], capture_output=True, text=True)
+        assert out.returncode == 0, (name, out.stderr)
+        exp = oc.decode(g["crt"])
+        e = exp[attr].reshape(-1)
+        got = np.fromfile(dst, dtype=np.float32)
+        n = e.size
+        assert got[:n].tobytes() == e.tobytes(), (name, "built-in")
+        assert got[n:2 * n].tobytes() == e.tobytes(), (name, "the codec object that restates GenericAttr<int>")
+        assert got[2 * n:3 * n].tobytes() == (np.float32(100.0) - e).astype(np.float32).tobytes(), (name, "the codec object with a twist")
+        if attr != "position":
+            assert got[3 * n:].tobytes() == exp["position"].tobytes(), (name, "positions beside a custom attribute")
+    g = load_golden("c4_unit")                                   # BORDER normals read the integer positions: not there under a custom position codec
+    src = str(tmp_path / "c4.crt"); g["crt"].tofile(src)
+    out = subprocess.run([exe, src, "position", str(tmp_path / "x.bin"), "normals"], capture_output=True, text=True)
+    assert out.returncode == 1 and "Use DIFF normal strategy instead" in out.stderr, (out.returncode, out.stderr)
+    # the C ABI underneath: stream values are int32, packed, generic attributes only
+    b = ca.Batch(ctx, [g["crt"]])
+    outs = b.allocate_outputs()[0]
+    names = [a["name"] for a in b.infos[0].attrs()]
+
+    def binding(name, fmt, flags):
+        bs = [ca.AttrBinding() for _ in names]
+        k = names.index(name)
+        bs[k].buffer = outs[name][0].data_ptr(); bs[k].format = fmt; bs[k].reserved = flags
+        return bs
+    for bs, code in ((binding("normal", ca.FMT_FLOAT, 1), -7),        # CRTHIP_E_FORMAT: normals / colours have codecs of their own
+                     (binding("uv", ca.FMT_FLOAT, 1), -8),            # CRTHIP_E_ARGUMENT: stream values are INT32
+                     (binding("uv", ca.FMT_INT32, 2), -8)):           # unknown flag bits
+        with pytest.raises(ca.CortoError) as ei:
+            b.bind(0, bs)
+        assert ei.value.code == code
+    b.bind(0, binding("uv", ca.FMT_INT32, 1))
+    b.decode(); assert (b.sync() == 0).all()
+    pred = np.zeros((b.infos[0].nvert, 3), dtype=np.uint32)
+    import ctypes as C
+    L = ca.lib()
+    L.crthip_batch_read_prediction.restype = C.c_int64
+    L.crthip_batch_read_prediction.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    assert L.crthip_batch_read_prediction(b.handle, 0, pred.ctypes.data, pred.nbytes) == pred.nbytes
+    tr = oc.decode(g["crt"], trace=True)
+    assert pred.tobytes() == tr["_prediction"].tobytes()
+    import torch
+    assert outs["uv"][0].view(torch.int32).cpu().numpy().tobytes() == tr["_raw_uv"].astype(np.int32).tobytes()      # the stream's values, before delta inversion
+    b.close()
+
+
 @pytest.mark.timeout(300)
 def test_random_corpus_of_mesh_kinds(ctx):
     """the CLERS automaton's ISA paths (runs of (VERTEX LEFT) pairs, BOUNDARY / DELAY / SPLIT, ring and DELAY-stack pops) and the delta
