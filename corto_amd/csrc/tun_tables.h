@@ -7,6 +7,9 @@
 // decode from it).  Otherwise it stays in LDS - word bytes in tun_words(), offsets / lengths in loff / llen - for the same wave to
 // decode from (k_tun_stream below).  Returns (used bytes, longest word).
 struct TunBuilt { uint32_t used, maxlen; };
+#ifndef TUN_BATCH_MAX_N
+#define TUN_BATCH_MAX_N 8u            // alphabets up to this size grow their dictionary in batches of pops (tun_tables_body; 0: never)
+#endif
 // -DCORTO_TUN_STAMPS (CORTO_BUILD_DEFINES=CORTO_TUN_STAMPS python -m corto_amd.build --force; tools/tun_stamp_probe.py): where a stream's
 // time goes - 100 MHz stamps of workgroups 0..4095 at the phase boundaries, read back with crthip_debug_tun_stamps
 #ifdef CORTO_TUN_STAMPS
@@ -105,6 +108,64 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		// from LDS when a head is popped and merged an iteration later - no LDS round trip on the critical path.  Bounds: end <= 510 + n
 		// whatever the probabilities (every expansion adds n entries and n - 1 words), so HL < 640 and NX < 704 < TUN_ENTRY_CAP - 1;
 		// lanes >= n write their (ignored) child to the spare entry TUN_ENTRY_CAP - 1.
+		// ---- batched growth (round 6; host model and proof: tools/tun_batch_model.py).  The expansion order is a merge of the n FIFOs, each
+		// non-increasing when the table is sorted (every stream upstream's encoder writes, tunstall.cpp:108-118: a child is (parent * P[r]) >> 16
+		// and parents come in non-increasing order; the low-entropy seed's columns fall below p0^(count-1) >= whatever is popped first).  So with
+		// M = the likeliest head and c_max = (M * P[0]) >> 16 = the likeliest entry any expansion from now on can make, EVERY unexpanded entry
+		// above c_max is popped before anything that does not exist yet: a whole set of pops is known at once, in the order (probability desc,
+		// row asc, FIFO order), and the k-th of them makes entries end + k*n .. + n - 1.  A 2-symbol alphabet's 252 serial expansions (42 us,
+		// the length of a launch while 200 other waves idle) become ~20 batches, a 4-symbol one's 83 seven to sixteen.
+		// Lane l looks at entry bj = l / n of row br = l % n's FIFO (a window of J = 64 / n entries a row); a row whose whole window is
+		// selected may hold more behind it: nothing at or below its last candidate is taken.  Ranks by comparing keys over the selected
+		// lanes; every popped lane writes its n children.  Anything unusual (all heads zero, an unsorted table) is left to the loop below,
+		// which picks up from head[] / epl[] at any point.
+		if(n <= TUN_BATCH_MAX_N && nwords + n <= 255) {
+			const uint32_t J = 64u/n, br = lane % n, bj = lane/n;
+			const bool slot = bj < J;
+			const uint32_t nextP = lane + 1 < n ? P[lane + 1] : 0u, thisP = lane < n ? P[lane] : 0u;
+			const bool ordered = __ballot(lane + 1 < n && thisP < nextP) == 0;
+			uint32_t left = (255 - n - nwords)/(n - 1) + 1;                          // expansions that pop their parent
+			uint64_t rowmask = 0;                                                    // the window lanes of my row
+			for(uint32_t q = 0; q < n; q++) { const uint64_t m = __ballot(slot && br == q); rowmask = br == q ? m : rowmask; }
+			uint32_t H = head[br];
+			const uint32_t tie = (63u - br) << 6 | (63u - bj), step = bj*n;
+			const uint32_t pmax = P[0];
+			while(ordered && left) {
+				const uint32_t e = H + step;
+				const uint32_t v = slot && e < end ? epl[e] : 0u;
+				const uint32_t prob = v & 0xFFFFu;
+				const uint32_t M = wave_max_u32(prob);
+				if(M == 0) break;                                                    // (every head zero or empty: the loop below has upstream's row-0 rule)
+				const uint32_t cmax = (M*pmax) >> 16;
+				bool sel = prob > cmax;
+				const uint64_t deep = __ballot(sel && bj == J - 1 && e + n < end);
+				if(deep) { const uint32_t T = wave_max_u32((deep >> lane) & 1 ? prob : 0u); sel = sel && prob > T; }
+				const uint64_t smask = __ballot(sel);
+				if(!smask) break;
+				const uint32_t key = prob << 12 | tie;
+				uint32_t rank = 0;
+				for(uint64_t m = smask; m; m &= m - 1) {
+					const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(m));
+					rank += k > key ? 1u : 0u;
+				}
+				const bool pop = sel && rank < left;
+				const uint64_t pmask = __ballot(pop);
+				const uint32_t npop = (uint32_t)__popcll(pmask);
+				if(pop) {
+					const uint32_t cbase = end + rank*n, len1 = (v & 0xFF0000u) + 0x10000u;
+					for(uint32_t q = 0; q < n; q++) {
+						const uint32_t t = (uint32_t)__umul24(prob, (uint32_t)P[q]);        // (HIP declares __umul24 as int: shifted as such, a product >= 2^31 smears its sign over the record)
+						epl[cbase + q] = (t >> 16) | (uint32_t)sym[q] << 24 | len1;
+						eoff[cbase + q] = (uint16_t)e;
+					}
+				}
+				H += (uint32_t)__popcll(pmask & rowmask)*n;
+				end += npop*n; nwords += npop*(n - 1); left -= npop;
+				asm volatile("" ::: "memory");
+			}
+			if(lane < n) head[lane] = (uint16_t)H;
+			__syncthreads();
+		}
 		const bool rowlane = lane < n;
 		const uint32_t rowc = 0xFFFFu - lane;
 		const uint32_t myP = rowlane ? P[lane] : 0u, sym24 = rowlane ? (uint32_t)sym[lane] << 24 : 0u;
