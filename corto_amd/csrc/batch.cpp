@@ -225,6 +225,7 @@ extern "C" int crthip_ctx_create(int device, crthip_ctx **out) {
 	// kernels that may ask for more than 64 KiB of dynamic LDS: raise their limit on this device, once per context
 	// (function attributes are per device; doing it here keeps the launch paths free of shared state between host threads)
 	if(hipFuncSetAttribute((const void *)k_topology_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
+	   hipFuncSetAttribute((const void *)k_topology_lds_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPO_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_delta_lds16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DELTA16_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_normal_blob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NORMAL_LDS_MAX) != hipSuccess ||
 	   hipFuncSetAttribute((const void *)k_enc_tun_parse, hipFuncAttributeMaxDynamicSharedMemorySize,

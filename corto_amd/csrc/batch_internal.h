@@ -81,10 +81,11 @@ struct AttrScratch {
 };
 struct BlobScratch {
 	uint64_t clers = ~0ull, pred = ~0ull, front_a = ~0ull, front_b = ~0ull, order = ~0ull, delayed = ~0ull, faces = ~0ull;
+	uint64_t progress = ~0ull;                              // the automaton's progress word (zeroed): blobs with an attribute too big for K-DELTA's LDS records
 	uint32_t front_cap = 0, aux_groups = 0;
 	std::vector<AttrScratch> attr;
 	size_t nattr = 0;                                       // attr[0..nattr) are this decode's (the vector only grows)
-	void reset() { clers = pred = front_a = front_b = order = delayed = faces = ~0ull; front_cap = 0; aux_groups = 0; nattr = 0; }
+	void reset() { clers = pred = front_a = front_b = order = delayed = faces = progress = ~0ull; front_cap = 0; aux_groups = 0; nattr = 0; }
 	void set_attrs(size_t n) { if(attr.size() < n) attr.resize(n); for(size_t k = nattr; k < n; k++) attr[k].reset();
 		if(n > nattr) nattr = n; }
 };

@@ -25,6 +25,8 @@ struct DebugConfig {
 	bool check_pinned = false;      // $CORTO_HIP_CHECK_PINNED=1: a buffer handed over as a packed pinned arena (crthip_ctx_set_packed_host_blobs) is verified to be pinned host memory
 	bool delta_rounds = false;      // $CORTO_DELTA_ROUNDS=1 (test hook): K-DELTA's round loop from vertex 1 for every attribute - int16, 32-bit and byte records, with and
 	                                // without parallelogram prediction - instead of after 24 slow window passes (tests/test_gpu_parity.py runs every fixture through it)
+	bool delta_walk = false;        // $CORTO_DELTA_WALK=1 (A/B and test hook): attributes too big for K-DELTA's LDS records take rounds 1-5's stretch walk over L2 (k_delta_mesh)
+	                                // instead of the tiles of k_delta_tiles
 	bool unpack_chunked = false;    // $CORTO_UNPACK_CHUNKED=1 (test hook): every bit block through the chunked K-BIT with its look-back - the kernel of big meshes -
 	                                // however small (tests/test_gpu_parity.py runs ragged sizes through both)
 };
@@ -37,6 +39,7 @@ inline DebugConfig debug_config_from_env() {
 	c.check_pinned = on("CORTO_HIP_CHECK_PINNED");
 	c.unpack_chunked = on("CORTO_UNPACK_CHUNKED");
 	c.delta_rounds = on("CORTO_DELTA_ROUNDS");
+	c.delta_walk = on("CORTO_DELTA_WALK");
 	return c;
 }
 

@@ -73,6 +73,12 @@ struct TopoJob {
 	// DELAY stack entries, symbols in the LDS window (a multiple of 8)
 	uint32_t lds_ring, lds_pool, lds_delayed_cap, lds_symwin;
 };
+// TopoJob.pad on the device, bit 1: the automaton keeps a PROGRESS WORD for a consumer that runs BESIDE it (k_delta_tiles on a lone context's second
+// stream) - the number of vertices whose prediction triple has been written and has arrived (published every 4 096 vertices and at every slide of the
+// symbol window), 0xFFFFFFFF when it is done.  The word sits 16 bytes in front of the triples (zeroed by the host before the launch): no pointer of its
+// own - the automaton's ISA block has no scalar register to spare for one (a TopoJob eight bytes longer cost the C4 batch's automata 3 %).
+constexpr uint32_t TOPO_PAD_PROGRESS = 2u;
+constexpr uint32_t TOPO_PROGRESS_BYTES = 16u;
 
 // one log stream to turn into values (include/corto/cstream.h:294-360)
 struct UnpackJob {
@@ -98,7 +104,7 @@ constexpr uint32_t UNPACK_WAVE_MAX_LOGS = 16384;   // bit blocks of at most this
 struct DeltaJob {
 	void *values;                  // int32* or uint8*, stride N
 	const uint32_t *pred;
-	uint8_t *fired;                // nvert zeroed flags in HBM, used only when values + flags do not fit LDS
+	uint8_t *fired;                // k_delta_mesh: nvert zeroed flags in HBM (+ the stretch starts behind them); k_delta_tiles: the automaton's progress word (TopoJob.progress) or null
 	uint32_t nvert, N;
 	uint8_t parallelogram, is_u8, pad[2];   // pad[1]: k_delta_lds16 keeps 32-bit records in LDS (the whole group says the same)
 	// k_delta_lds16 finishes the attribute on its way out of LDS (no k_dequant launch, no second trip through HBM):

@@ -736,4 +736,228 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// k_delta_tiles (round 6) - meshes too big for the LDS records above (tens of thousands to millions of vertices; rounds 1-5: k_delta_mesh, a walk
+// along the stretches of the prediction graph through L2, three round trips a vertex step: 1.5 of config C2's 4.0 ms).
+//
+// One workgroup of SIXTEEN waves per (blob, attribute), walking the vertex sequence in TILES of 1 024: thread t has vertex s + t.  What a vertex
+// reads is final data except for the parents inside its own tile, so a tile is the window loop above with a 1 024-wide window that does not slide:
+//   * the final values of the last DT_RING vertices live in an LDS RING (32-bit components, one array a component: v[x] at ring[q][x mod DT_RING]):
+//     a parent is a gather from LDS, not an L2 round trip; one further back than the ring (a seam, an irregular mesh) is read from HBM when the tile
+//     begins - it was stored tiles ago;
+//   * PASSES inside the tile: a vertex goes when its in-tile parents have gone (a 1 024-bit mask in LDS) - or, if it continues its predecessor
+//     (a = i - 1), when that one goes in the same pass: the window loop's flood fill per wave, with the carry handed from wave to wave (each wave
+//     publishes whether its lane 63 goes without / with a carry-in, every wave folds the sixteen answers); the vertices that go form runs, each a
+//     prefix sum from its head: a wave scan per component, the sum of a run that started in an earlier wave handed on the same way;
+//   * a grid finishes a tile in two or three passes (its parents b, c lie a ring of the traversal back: what does not fit the first pass is the
+//     part of the tile that predicts from the tile's own beginning); the lowest vertex that has not gone always can, so any graph terminates;
+//   * the next tile's triples and raw values are fetched while this one computes; the finished tile goes back to HBM in one coalesced store.
+// Exact as everything else here: sums in 32-bit registers mod 2^32 (bytes: stored mod 256).  A malformed triple (a parent that is not an earlier
+// vertex; vertex 0) leaves the value as it is, as k_delta_mesh does.  vertex_attribute.h:160-176.
+constexpr uint32_t DT_RING = 4096;
+template <int NC, typename T>
+__device__ __forceinline__ void delta_tiles_body(const DeltaJob &J, CRT_LDS uint32_t *ring, CRT_LDS uint64_t *fm, CRT_LDS uint32_t *gpub, CRT_LDS uint32_t *loc63) {
+	constexpr uint32_t NW = DELTA_THREADS/64;
+	const uint32_t nvert = J.nvert, t = threadIdx.x, lane = lane_id(), w = wave_id();
+	const bool para = J.parallelogram != 0;
+	CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
+	CRT_GLOBAL T *vals = as_global((T *)J.values);
+	CRT_LDS const uint32_t *fm32 = (CRT_LDS const uint32_t *)fm;
+	const uint64_t lane_le = (2ull << lane) - 1ull;
+	// The automaton may still be running (a lone context decodes the attribute streams beside it and launches this kernel on that second stream):
+	// it publishes how many vertices have their prediction triple - at every slide of its symbol window, 0xFFFFFFFF when it is done - and a tile
+	// waits for the triples it is about to load.  One thread polls; a wait that outlasts any decode (2 s) is given up rather than hung on.
+	CRT_GLOBAL const uint32_t *progress = as_global((const uint32_t *)J.fired);
+	uint32_t seen = progress ? 0u : 0xFFFFFFFFu;                               // what the word said when it was last looked at (uniform): polled again only when a tile needs more
+	auto wait_for = [&](uint32_t need) {
+		if(seen >= need) return;
+		if(t == 0) {
+			const uint64_t t0 = wall_clock64();
+			uint32_t p;
+			while((p = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+				__builtin_amdgcn_s_sleep(32);
+				if(wall_clock64() - t0 > 200000000ull) { p = 0xFFFFFFFFu; break; }
+			}
+			gpub[DELTA_THREADS/64] = p;
+		}
+		lds_barrier();
+		seen = gpub[DELTA_THREADS/64];
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		lds_barrier();                                                         // (the word is read: the next poll may overwrite it)
+	};
+#ifdef DT_DEBUG
+	if(t == 0) printf("tiles job N %u nvert %u progress %p first %u\n", J.N, nvert, (const void *)J.fired, J.fired ? *(const uint32_t *)J.fired : 7u);
+#endif
+	typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+	auto load_pred = [&](uint32_t j) -> u32x3_t { return *(CRT_GLOBAL const u32x3_t *)(pred + (size_t)(j < nvert ? j : nvert - 1u)*3); };
+	wait_for(nvert < DELTA_THREADS ? nvert : DELTA_THREADS);
+	u32x3_t tri = load_pred(t);
+	uint32_t d[NC];
+#pragma unroll
+	for(int q = 0; q < NC; q++) d[q] = t < nvert ? (uint32_t)vals[(size_t)t*NC + q] : 0u;
+	for(uint32_t s = 0; s < nvert; s += DELTA_THREADS) {
+		const uint32_t i = s + t;
+		const bool in = i < nvert;
+		const uint32_t a = tri.x, b = para ? tri.y : tri.x, c = para ? tri.z : tri.x;
+		uint32_t dv[NC];
+#pragma unroll
+		for(int q = 0; q < NC; q++) dv[q] = d[q];
+		const bool stays = !(a < i && b < i && c < i);                          // (vertex 0; a malformed triple): the value stays
+		const bool a_in = !stays && a >= s, b_in = para && !stays && b >= s, c_in = para && !stays && c >= s;
+		const bool ch = a_in && a + 1u == i;                                    // continues its predecessor's sum (t > 0: the predecessor is in the tile)
+		const uint32_t ra = a - s, rb = b - s, rc = c - s;
+		// parents behind the ring: from HBM, now (stored at least three tiles ago)
+		const uint32_t horizon = s + DELTA_THREADS > DT_RING ? s + DELTA_THREADS - DT_RING : 0u;
+		const bool a_far = !stays && a < horizon, b_far = para && !stays && b < horizon, c_far = para && !stays && c < horizon;
+		// (agent scope: from L2, where the stores of three and more tiles ago have arrived - every wave has since waited for loads it issued
+		// behind them, and this CU's L1 may still hold the raw values those addresses had when they were prefetched.)  Issued BEFORE the next
+		// tile's prefetch: the memory counter retires in order, and waiting for these must not mean waiting for that
+		uint32_t fa[NC], fb[NC], fc[NC];
+#pragma unroll
+		for(int q = 0; q < NC; q++) {
+			fa[q] = a_far ? (uint32_t)__hip_atomic_load(vals + (size_t)a*NC + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			fb[q] = b_far ? (uint32_t)__hip_atomic_load(vals + (size_t)b*NC + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			fc[q] = c_far ? (uint32_t)__hip_atomic_load(vals + (size_t)c*NC + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		}
+		asm volatile("" ::: "memory");
+		// the next tile's triple and raw values, in flight while this one computes
+		if(s + DELTA_THREADS < nvert) {
+			wait_for(s + 2*DELTA_THREADS < nvert ? s + 2*DELTA_THREADS : nvert);
+			const uint32_t j = i + DELTA_THREADS;
+			tri = load_pred(j);
+#pragma unroll
+			for(int q = 0; q < NC; q++) d[q] = j < nvert ? (uint32_t)vals[(size_t)j*NC + q] : 0u;
+		}
+		bool fired = !in;
+#ifdef DT_DEBUG
+		uint32_t npass = 0; const uint64_t dt0 = __builtin_amdgcn_s_memtime();
+#endif
+		{ const uint64_t m = __ballot(!in); if(lane == 0) fm[w] = m; }
+		uint32_t fin[NC];
+#pragma unroll
+		for(int q = 0; q < NC; q++) fin[q] = dv[q];
+		lds_barrier();                                                         // (lgkmcnt only: the next tile's prefetch stays in flight through every barrier of this tile)
+		for(;;) {
+			// ---- who can go: without, and with, the vertex in front of this wave going too ----
+			const uint64_t left = __ballot(!fired);
+			uint64_t Sm = 0, G0 = 0, G1 = 0;
+			bool H = false;
+			if(left) {
+				auto gone = [&](uint32_t x) -> bool { return (fm32[x >> 5] >> (x & 31u)) & 1u; };
+				const bool af = !a_in || gone(ra), bf = !b_in || gone(rb), cf = !c_in || gone(rc);
+				const bool R = !fired && (stays || (bf && cf && (ch || af)));
+				H = stays || !ch || af;                                          // starts a sum of its own
+				const uint64_t Rm = __ballot(R), Cm = __ballot(R && !H && lane == 0);
+				Sm = __ballot(R && H);
+				const uint64_t S1 = Sm | Cm;
+				G0 = (((Rm + Sm) ^ Rm) & Rm) | Sm; G1 = (((Rm + S1) ^ Rm) & Rm) | S1;
+			}
+			// bit 0 / 1: lane 63 goes without / with the vertex in front of this wave going; bit 3: vertices of this wave are left
+			if(lane == 0) gpub[w] = (uint32_t)(G0 >> 63) | (uint32_t)(G1 >> 63) << 1 | (left ? 8u : 0u);
+			lds_barrier();
+			// sixteen answers read by sixteen lanes, folded on the scalar unit
+			const uint32_t gp = lane < NW ? gpub[lane] : 0u;
+			const uint32_t g0m = (uint32_t)__ballot(gp & 1u), g1m = (uint32_t)__ballot(gp & 2u);
+			const bool more = __ballot(gp & 8u) != 0;
+			if(!more) break;                                                    // every vertex of the tile has gone (uniform over the workgroup)
+			uint32_t cinm = 0, cin = 0;                                          // cinm bit k: the vertex in front of wave k goes in this pass
+			for(uint32_t k = 0; k < NW; k++) { cinm |= cin << k; cin = ((cin ? g1m : g0m) >> k) & 1u; }
+			cin = (cinm >> w) & 1u;
+			const uint64_t G = cin ? G1 : G0;
+			const bool go = (G >> lane) & 1ull;
+			const uint64_t hm = Sm & lane_le;                                    // the heads at or below me (none: my run comes in from the wave before)
+			uint32_t r[NC];
+#pragma unroll
+			for(int q = 0; q < NC; q++) r[q] = 0;
+			if(G) {
+				const bool use = go && !stays, head = use && H;
+				uint32_t x[NC];
+#pragma unroll
+				for(int q = 0; q < NC; q++) {
+					uint32_t v = dv[q];
+					if(para) {
+						const uint32_t vb = b_far ? fb[q] : ring[q*DT_RING + ((use ? b : 0u) & (DT_RING - 1u))];
+						const uint32_t vc = c_far ? fc[q] : ring[q*DT_RING + ((use ? c : 0u) & (DT_RING - 1u))];
+						v += use ? vb - vc : 0u;
+					}
+					const uint32_t va = a_far ? fa[q] : ring[q*DT_RING + ((head ? a : 0u) & (DT_RING - 1u))];
+					v += head ? va : 0u;
+					x[q] = go ? v : 0u;
+				}
+				const uint32_t hidx = hm ? 63u - (uint32_t)__builtin_clzll(hm) : 0u;
+#pragma unroll
+				for(int q = 0; q < NC; q++) {
+					const uint32_t incl = wave_inclusive_scan_u32(x[q]);
+					const uint32_t eh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hidx << 2), (int)(incl - x[q]));
+					r[q] = incl - (hm ? eh : 0u);
+				}
+			}
+			// does the run that came in reach this wave's lane 63 (then the next wave's carried sum goes on through this one)?  Only waves whose successor is
+			// carried into publish; the others' words are not read
+			const bool pass_on = ((cinm >> (w + 1 < NW ? w + 1 : w)) & 1u) && w + 1 < NW;
+			if(pass_on && lane == 63) {
+				gpub[NW + 1 + w] = go && !hm ? 1u : 0u;
+#pragma unroll
+				for(int q = 0; q < NC; q++) loc63[w*4 + q] = r[q];
+			}
+			lds_barrier();
+			if(G && cin && (G & 1ull) && !(Sm & 1ull)) {
+				// the sum my first run continues = the final value of the vertex in front of this wave = the lane-63 sums of the waves behind me back to the
+				// first whose lane 63 started afresh
+				const uint32_t o = lane < w && ((cinm >> (lane + 1)) & 1u) ? gpub[NW + 1 + lane] : 0u;
+				const uint64_t closed = __ballot(lane < w && !o) & ((1ull << w) - 1ull);
+				const uint32_t from = closed ? 63u - (uint32_t)__builtin_clzll(closed) : 0u;
+#pragma unroll
+				for(int q = 0; q < NC; q++) {
+					const uint32_t v = lane < w && lane >= from ? loc63[lane*4 + q] : 0u;
+					const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_u32(v), 63);
+					r[q] += go && !hm ? tot : 0u;
+				}
+			}
+			if(go) {
+#pragma unroll
+				for(int q = 0; q < NC; q++) { ring[q*DT_RING + (i & (DT_RING - 1u))] = r[q]; fin[q] = r[q]; }
+				fired = true;
+			}
+			if(lane == 0 && G) fm[w] |= G;
+			lds_barrier();
+#ifdef DT_DEBUG
+			npass++;
+#endif
+		}
+#ifdef DT_DEBUG
+		if(t == 0 && NC == 3 && (s < 4096 || (s & 16383) == 0)) printf("N %u tile %u passes %u clocks %u\n", J.N, s, npass, (uint32_t)(__builtin_amdgcn_s_memtime() - dt0));
+#endif
+		if(in) {
+#pragma unroll
+			for(int q = 0; q < NC; q++) vals[(size_t)i*NC + q] = (T)fin[q];
+		}
+	}
+}
+
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_tiles(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
+	__shared__ uint32_t ring[4*DT_RING];                                       // 64 KB: the last DT_RING vertices' final values, a component an array
+	__shared__ uint64_t fm[DELTA_THREADS/64];                                   // the tile's vertices that have gone
+	__shared__ uint32_t gpub[2*(DELTA_THREADS/64) + 1], loc63[4*DELTA_THREADS/64];  // (gpub[NW]: the progress word as thread 0 last read it; behind it: the waves' open flags)
+	if(blockIdx.x >= njobs) return;
+	const DeltaJob J = jobs[blockIdx.x];
+	if(J.N < 1 || J.N > 4) return;                                              // (more components: k_delta_mesh, launched for those alone)
+	if(J.is_u8) {
+		switch(J.N) {
+		case 1: delta_tiles_body<1, uint8_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		case 2: delta_tiles_body<2, uint8_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		case 3: delta_tiles_body<3, uint8_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		default: delta_tiles_body<4, uint8_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		}
+	} else {
+		switch(J.N) {
+		case 1: delta_tiles_body<1, uint32_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		case 2: delta_tiles_body<2, uint32_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		case 3: delta_tiles_body<3, uint32_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		default: delta_tiles_body<4, uint32_t>(J, (CRT_LDS uint32_t *)ring, (CRT_LDS uint64_t *)fm, (CRT_LDS uint32_t *)gpub, (CRT_LDS uint32_t *)loc63); break;
+		}
+	}
+}
+
 } // namespace corto_hip

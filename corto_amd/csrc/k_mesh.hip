@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64) void k_topology(const TopoJob *__restrict__ job
 	const TopoJob J = jobs[job_ids[blockIdx.x]];
 	GlobalFront F{(CRT_GLOBAL u32x4 *)as_global(J.front_a), (CRT_GLOBAL u32x2 *)as_global(J.front_b), as_global(J.order), as_global(J.delayed)};
 	topo_run(J, as_global(J.clers), F);
+	if(J.pad & TOPO_PAD_PROGRESS) __hip_atomic_store((CRT_GLOBAL uint32_t *)((CRT_GLOBAL uint8_t *)as_global(J.pred) - TOPO_PROGRESS_BYTES), 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LDS path: the front of one blob in LDS, hand-tightened.  A lone wave issues one instruction every ~4 cycles, so this
@@ -1617,8 +1618,13 @@ __device__ uint32_t g_topo_trace[16*8192];
 #define TOPO_T0() do { } while(0)
 #define TOPO_ACC(i) do { } while(0)
 #endif
-template <bool U16>
-__device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false: out of slots, nothing valid written
+template <bool U16, bool PROGRESS_>
+__device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {
+#ifdef TOPO_NO_PARTIAL_PROGRESS
+	constexpr bool PROGRESS = false;
+#else
+	constexpr bool PROGRESS = PROGRESS_;
+#endif       // false: out of slots, nothing valid written
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const uint32_t RING = J.lds_ring, MASK = RING - 1, POOL = J.lds_pool, dcap = J.lds_delayed_cap, SYMW = J.lds_symwin;
 	CRT_LDS u32x4 *rec = (CRT_LDS u32x4 *)as_lds(lds);
@@ -1645,6 +1651,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 	const uint32_t nvert = J.nvert;
 	const uint32_t splitbits = 32 - __clz(nvert | 1u);
 	uint32_t cler = 0, winbase = 0, vc = 0, err = 0;                     // err: 1 = bad stream, 2 = out of slots
+	uint32_t pub = 0;                                                    // vertices published in J.progress
 	uint32_t start = 0;
 	uint32_t nq = 0, qpos = 0;                                           // ring [qpos, nq)
 	const uint64_t bit_end = (uint64_t)J.split_nwords*32;
@@ -1696,7 +1703,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #define TOPO_PRED(a, b, c) do { u32x3 p_; p_.x = (a); p_.y = (b); p_.z = (c); *(CRT_GLOBAL u32x3 *)(predb + vc*12u) = p_; } while(0)   // always right before vc++
 #define TOPO_PUT(e, a, b, c, p, n) do { u32x4 t_; t_.x = (a); t_.y = (b); t_.z = (c); t_.w = (p) | ((n) << 16); rec[e] = t_; } while(0)
 	// slide the symbol window up to the current symbol (whole wave, TOPO_FILL_WINDOW) and reload the two window registers
-#define TOPO_SLIDE() do { winbase = cler & ~31u; TOPO_FILL_WINDOW(winbase); \
+#define TOPO_SLIDE() do { if(PROGRESS) __hip_atomic_store((CRT_GLOBAL uint32_t *)(predb - TOPO_PROGRESS_BYTES), vc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   /* (the window's refill waits for every store in flight anyway) */ \
+	winbase = cler & ~31u; TOPO_FILL_WINDOW(winbase); \
 	{ const uint32_t wi_ = (cler - winbase) >> 3; const uint64_t w2_ = ((uint64_t)TOPO_S(cl32[wi_]) | (uint64_t)TOPO_S(cl32[wi_ + 1]) << 32) >> (4*(cler & 7u)); sw = (uint32_t)w2_; swn = (uint32_t)(w2_ >> 32); } \
 	wbias = 1u - (winbase >> 3); clw = (uint32_t)(uintptr_t)cl32 + 4u*wbias; slide_at = winbase + SYMW < nclers ? winbase + SYMW - 2048u : 0xFFFFFFFFu; } while(0)
 // (sw, swn) = the 64 bits of the current symbol word and the next one, shifted down to the current symbol: sw always holds EIGHT symbols
@@ -1715,6 +1723,9 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 			nq = 0; qpos = 0; pk1 = RING; pk2 = dcap << 16;
 			while(start < end && !err) {
 				if(cler >= slide_at) TOPO_SLIDE();                          // slide the window before it runs low
+				// a consumer running beside the automaton (k_delta_tiles): tell it every 4 096 vertices how far the triples have got (a release: ~1 us for
+				// the stores in flight to arrive - 2 % of a big mesh's automaton; a mesh whose symbols fit the window never slides)
+				if(PROGRESS && vc - pub >= 4096u) { __hip_atomic_store((CRT_GLOBAL uint32_t *)(predb - TOPO_PROGRESS_BYTES), vc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); pub = vc; }
 				TOPO_T0();
 				// ---- cold: fetch the next edge to process: ring, DELAY stack, or a new seed face ----
 				uint32_t f;
@@ -1902,13 +1913,14 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {       // false
 #ifdef CORTO_TOPO_TIMES
 __device__ uint32_t g_topo_times[8*8192];
 #endif
-__global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
+template <bool PROGRESS>
+__device__ __forceinline__ void topo_lds_kernel(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
 	if(blockIdx.x >= njobs) return;
 #ifdef CORTO_TOPO_TIMES
 	const uint64_t tt_begin = __builtin_amdgcn_s_memtime();
 #endif
 	const TopoJob J = jobs[job_ids[blockIdx.x]];
-	const bool done = J.faces_u16 ? topo_lds_body<true>(J) : topo_lds_body<false>(J);
+	const bool done = J.faces_u16 ? topo_lds_body<true, PROGRESS>(J) : topo_lds_body<false, PROGRESS>(J);
 #ifdef CORTO_TOPO_TIMES
 	if(threadIdx.x == 0 && blockIdx.x < 8192) {
 		const uint64_t tt_end = __builtin_amdgcn_s_memtime();
@@ -1924,7 +1936,15 @@ __global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__
 		const uint32_t need = topo_run(J, as_global(J.clers), F);
 		*as_global(J.flags) = (int32_t)(1u | need << 1);                    // bit 0: redone; above it: the ring slots (15 bits) and the pool slots (15 bits) it would have needed in LDS
 	}
+	// every triple is written (the redo rewrites what the LDS attempt had published with the same values: the automaton is deterministic)
+	if(PROGRESS && threadIdx.x == 0) __hip_atomic_store((CRT_GLOBAL uint32_t *)((CRT_GLOBAL uint8_t *)as_global(J.pred) - TOPO_PROGRESS_BYTES), 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Two kernels of the same body.  k_topology_lds: a batch's automata, exactly rounds 1-5's code.  k_topology_lds_big: the launch of the blobs that ask for much
+// more LDS than the rest - big meshes - which ALSO keeps the progress word in front of its triples up to date (device_plan.h: TOPO_PAD_PROGRESS; every mesh
+// has the word, so the kernel needs no test); a kernel of its own because the test, or even a TopoJob eight bytes longer, cost the batch's automata 2-3 %.
+__global__ __launch_bounds__(64) void k_topology_lds(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) { topo_lds_kernel<false>(jobs, job_ids, njobs); }
+__global__ __launch_bounds__(64) void k_topology_lds_big(const TopoJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) { topo_lds_kernel<true>(jobs, job_ids, njobs); }
 
 // ------------------------------------------------------------------------------------------------
 // K-DELTA (mesh): v[i] += v[a] + v[b] - v[c] (or += v[a]) for i = 1..nvert-1 in index order
@@ -2014,9 +2034,10 @@ __device__ void delta_stretch_global(CRT_GLOBAL T *v, CRT_GLOBAL uint8_t *fired,
 	}
 }
 
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs) {
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_mesh(const DeltaJob *__restrict__ jobs, uint32_t njobs, uint32_t wide_n_only) {
 	if(blockIdx.x >= njobs) return;
 	const DeltaJob J = jobs[blockIdx.x];
+	if(wide_n_only && J.N <= 4) return;                                      // (k_delta_tiles' job)
 	const uint32_t THREADS = blockDim.x, nvert = J.nvert, t = threadIdx.x, lane = lane_id(), w = wave_id(), nwaves = THREADS >> 6;
 	CRT_GLOBAL const uint32_t *pred = as_global(J.pred);
 	CRT_GLOBAL uint8_t *fired = as_global(J.fired);                       // zero-filled by the host; the stretch starts live behind it

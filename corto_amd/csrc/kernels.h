@@ -38,6 +38,7 @@ __global__ void k_dequant(const DequantJob *jobs, const uint32_t *block_job, uin
 // k_mesh.hip
 __global__ void k_topology(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
 __global__ void k_topology_lds(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);
+__global__ void k_topology_lds_big(const TopoJob *jobs, const uint32_t *job_ids, uint32_t njobs);   // the same automaton keeping a progress word (k_mesh.hip)
 // dynamic LDS bytes k_topology_lds needs for a front of `cap` edges and `nclers` symbols
 constexpr uint32_t TOPO_SPLIT_LDS = 256;          // words of the split / vertex-id bit block staged in LDS
 // LDS of one blob's CLERS automaton (k_mesh.hip): records of the LIVE front only - a ring for the queued edges, a pool for
@@ -78,7 +79,9 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 }
 constexpr uint32_t TOPO_LDS_MAX = 156*1024;     // of the CU's 160 KiB
 constexpr uint32_t DELTA_THREADS = 1024, DELTA_SMALL_NVERT = 8192;      // threads of k_delta_mesh's workgroup for one (blob, attribute) too big for LDS; half of them up to DELTA_SMALL_NVERT vertices
-__global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs);
+__global__ void k_delta_mesh(const DeltaJob *jobs, uint32_t njobs, uint32_t wide_n_only);       // wide_n_only: the jobs of more than four components alone (the others are k_delta_tiles')
+// k_delta.hip: the same jobs (up to four components) in tiles of DELTA_THREADS vertices out of an LDS ring of recent values (round 6)
+__global__ void k_delta_tiles(const DeltaJob *jobs, uint32_t njobs);
 constexpr uint32_t DELTA_GROUP_MAX = 4;
 struct DeltaGroup { uint32_t first, count; };     // DeltaJob entries [first, first + count) of one blob
 // k_delta.hip: one workgroup per blob, one wave per attribute (up to four) + one that builds the prediction graph they share: 16-bit values

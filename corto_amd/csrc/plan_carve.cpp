@@ -24,9 +24,10 @@ int Planner::carve() {
 	// redone blob does), the host zeroes it before the launch and reads it after the sync - no memset kernel in front of a step
 	// and no copy kernel behind it (each stretched to 50-100 us with eight batches in flight).  Prediction triples are not cleared
 	// either: the automaton writes every vertex it makes and clears the ones it never reached itself (k_mesh.hip).
+	(void)cv.take(256);                                                  // (offset 0 is a null pseudo pointer: the first blob's progress word must not sit there)
 	for(uint32_t i = 0; i < nblobs; i++) {
 		const BlobLayout &L = b->blobs[i].L;
-		if(L.h.nface > 0) bs[i].pred = cv.take((uint64_t)L.h.nvert*12, 16);
+		if(L.h.nface > 0) bs[i].pred = cv.take((uint64_t)L.h.nvert*12 + TOPO_PROGRESS_BYTES, 16) + TOPO_PROGRESS_BYTES;   // (the automaton's progress word in front: device_plan.h)
 	}
 	// zeroed by a memset, present only for big meshes: the counters of the
 	pl.zero_begin = cv.take(0);
@@ -44,9 +45,13 @@ int Planner::carve() {
 			const AttrHeader &a = L.h.attrs[k];
 			DeltaJob probe{};
 			probe.nvert = L.h.nvert; probe.N = a.codec == CRTHIP_CODEC_NORMAL ? 2u : a.N; probe.is_u8 = a.codec == CRTHIP_CODEC_COLOR;
-			// k_delta_mesh: fired flags (zeroed) + the list of stretch starts behind them
-			if(delta_class(probe, wide) <= 1)
-				bs[i].attr[k].fired = cv.take((((uint64_t)L.h.nvert + 15) & ~15ull) + 4ull*L.h.nvert + 16, 16);
+			if(delta_class(probe, wide) <= 1) {
+				// k_delta_tiles: one progress word a blob, kept by the automaton; k_delta_mesh (more than four components, or $CORTO_DELTA_WALK): fired
+				// flags (zeroed) + the list of stretch starts behind them
+				bs[i].progress = bs[i].pred - TOPO_PROGRESS_BYTES;           // (zeroed on its own: Planner::upload)
+				if(ctx->dbg.delta_walk || probe.N > 4)
+					bs[i].attr[k].fired = cv.take((((uint64_t)L.h.nvert + 15) & ~15ull) + 4ull*L.h.nvert + 16, 16);
+			}
 		}
 	}
 	pl.zero_end = cv.take(0);

@@ -63,7 +63,8 @@ void Planner::group() {
 		std::vector<uint32_t> small_ids;
 		for(size_t k = 0; k < pl.topo_lds_ids.v.size(); k++) {
 			const uint32_t nd = pl.topo_need[k], id = pl.topo_lds_ids.v[k];
-			if(nd <= cut) { small_ids.push_back(id); pl.topo_lds = std::max(pl.topo_lds, nd); }
+			// (a blob whose automaton keeps a progress word - an attribute goes through k_delta_tiles - runs in the big launch: k_topology_lds_big is the kernel that does)
+			if(nd <= cut && !(pl.topo.v[id].pad & TOPO_PAD_PROGRESS)) { small_ids.push_back(id); pl.topo_lds = std::max(pl.topo_lds, nd); }
 			else { pl.topo_big_ids.v.push_back(id); pl.topo_big_lds = std::max(pl.topo_big_lds, nd); }
 		}
 		pl.topo_lds_ids.v.swap(small_ids);

@@ -101,6 +101,7 @@ int Planner::jobs() {
 			t.nclers = L.clers.size; t.split_nwords = L.split.nwords; t.ngroups = (uint32_t)L.group_end.size();
 			t.nvert = nvert; t.nface = nface; t.front_cap = S.front_cap; t.faces_u16 = P.index ? P.index_u16 : 0;
 			t.pad = P.index ? 1u : 0u;                                   // pad = 1: faces is a real pointer
+			if(S.progress != ~0ull) t.pad |= TOPO_PAD_PROGRESS;
 			{
 				// every mesh takes the LDS path; a lone big mesh may use most of a CU's LDS, a batch keeps its blobs small
 				uint32_t ring, pool, symwin;
@@ -210,7 +211,8 @@ int Planner::jobs() {
 					// pad[1]: 32-bit records in LDS (k_delta_lds16)
 					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = wide; d.pad2[0] = ctx->dbg.delta_rounds ?
 						1u : 0u;
-					d.fired = A.fired != ~0ull ? SP(A.fired) : nullptr;
+					// (k_delta_mesh's flags, else - k_delta_tiles - the automaton's progress word)
+					d.fired = A.fired != ~0ull ? SP(A.fired) : S.progress != ~0ull ? SP(S.progress) : nullptr;
 					d.flags = HS(2ull*nblobs + 2ull*i);
 					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2) {
 						if(a.codec == CRTHIP_CODEC_COLOR) {

@@ -20,8 +20,8 @@ int Planner::upload() {
 	for(auto &t : pl.topo.v) {
 		t.clers = R(t.clers);
 		t.group_end = (const uint32_t *)(base + pl.aux_u32.dev_off + (uintptr_t)t.group_end);
-		if(!t.pad) t.faces = R(t.faces);
-		t.pad = 0;
+		if(!(t.pad & 1u)) t.faces = R(t.faces);
+		t.pad &= TOPO_PAD_PROGRESS;
 		t.pred = (uint32_t *)R(t.pred); t.front_a = (uint4 *)R(t.front_a); t.front_b = (uint2 *)R(t.front_b);
 		t.order = (uint32_t *)R(t.order); t.delayed = (uint32_t *)R(t.delayed); t.status = (int32_t *)R(t.status); t.flags =
 			(int32_t *)R(t.flags);
@@ -66,6 +66,8 @@ int Planner::launch() {
 	Launch LT{ctx};
 	if(pl.jobs_bytes) HIP_TRY(hipMemcpyAsync(base + pl.jobs_begin, stage, pl.jobs_bytes, hipMemcpyHostToDevice, st));
 	if(pl.zero_end > pl.zero_begin) HIP_TRY(hipMemsetAsync(base + pl.zero_begin, 0, pl.zero_end - pl.zero_begin, st));
+	for(uint32_t i = 0; i < nblobs; i++)                                         // the progress words of big meshes (a handful a batch at most)
+		if(bs[i].progress != ~0ull) HIP_TRY(hipMemsetAsync(base + bs[i].progress, 0, TOPO_PROGRESS_BYTES, st));
 
 	auto D = [&](auto &arr) { return (decltype(arr.v.data()))(base + arr.dev_off); };
 	TunTable *tables = (TunTable *)(base + pl.tables_off);
@@ -111,10 +113,23 @@ int Planner::launch() {
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack),
 			D(pl.unpack_chunk_job), unpack_chunks, unpack_partial); LT.end();
 	};
+	// K-DELTA's jobs by class (sorted that way: 0 / 1 = too big for the LDS records, 2 = the groups of k_delta_lds16)
+	uint32_t ncls[3] = {0, 0, 0};
+	for(auto &d : pl.delta.v) ncls[delta_class(d, wide)]++;
+	bool tiles_launched = false;
+	// the big ones in tiles of 1 024 vertices (k_delta_tiles).  On a lone context this goes to the SECOND stream, behind the attribute streams' bit-unpack
+	// and BESIDE the automaton, whose progress word the tiles wait for: a single big mesh's delta inversion trails its topology instead of following it
+	// (config C2: 1.5 of 4.0 ms).  The automaton is enqueued first on its own stream and waits for nothing of this kernel.
+	auto delta_tiles = [&](hipStream_t s) {
+		const uint32_t nbig = ncls[0] + ncls[1];
+		if(!nbig || ctx->dbg.delta_walk) return;
+		LT.begin("delta_tiles", s); hipLaunchKernelGGL(k_delta_tiles, dim3(nbig), dim3(DELTA_THREADS), 0, s, D(pl.delta), nbig); LT.end();
+		tiles_launched = true;
+	};
 	auto topology = [&]() -> int {
 		if(!pl.topo_lds_ids.v.empty() || !pl.topo_big_ids.v.empty()) {
 			LT.begin("topology_lds");
-			if(!pl.topo_big_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_big_ids.v.size(); hipLaunchKernelGGL(k_topology_lds,
+			if(!pl.topo_big_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_big_ids.v.size(); hipLaunchKernelGGL(k_topology_lds_big,
 				dim3(nj), dim3(64), pl.topo_big_lds, st, D(pl.topo), D(pl.topo_big_ids), nj); }
 			if(!pl.topo_lds_ids.v.empty()) { const uint32_t nj = (uint32_t)pl.topo_lds_ids.v.size(); hipLaunchKernelGGL(k_topology_lds,
 				dim3(nj), dim3(64), pl.topo_lds, st, D(pl.topo), D(pl.topo_lds_ids), nj); }
@@ -142,8 +157,21 @@ int Planner::launch() {
 		if(launch_tun_decode_staged(st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, scanned ? 0u : 1u)) return fail(CRTHIP_E_DEVICE);
 		LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
-		{ int e_ = topology(); if(e_) return e_; }
-		unpack(st);
+		if(!ctx->single_stream && !ctx->dbg.delta_walk && ncls[0] + ncls[1] && !pl.topo.v.empty()) {
+			// a big mesh alone: every stream is decoded; the automaton (one serial chain: 2.2 of C2's 4 ms) goes on on the main stream, the attributes'
+			// bit-unpack and their delta inversion in tiles on the second one, the tiles trailing the automaton's progress word
+			hipStream_t s2 = ctx->stream2;
+			HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+			HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+			{ int e_ = topology(); if(e_) return e_; }
+			unpack(s2);
+			delta_tiles(s2);
+			HIP_TRY(hipEventRecord(ctx->ev_join, s2));
+			HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+		} else {
+			{ int e_ = topology(); if(e_) return e_; }
+			unpack(st);
+		}
 	} else if(!pl.topo.v.empty() && (ntun > clers_tun || nfill > clers_fill || unpack_chunks || !pl.unpack_wave_ids.v.empty()) &&
 		!ctx->single_stream) {
 		// fork: attribute streams on stream2, CLERS + topology on the main stream
@@ -154,6 +182,7 @@ int Planner::launch() {
 		{ int e_ = topology(); if(e_) return e_; }
 		tunstall(s2, clers_tun, ntun, clers_chunks, tun_chunks, clers_fill, nfill);
 		unpack(s2);
+		delta_tiles(s2);
 		HIP_TRY(hipEventRecord(ctx->ev_join, s2));
 		HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
 	} else {
@@ -162,15 +191,22 @@ int Planner::launch() {
 		unpack(st);
 	}
 	if(!pl.delta.v.empty()) {
-		uint32_t ncls[3] = {0, 0, 0};
-		for(auto &d : pl.delta.v) ncls[delta_class(d, wide)]++;
 		const uint32_t ngroups = (uint32_t)pl.delta_groups.v.size();
 		// (the timer's names are the kernels that run: `delta_mesh` = the walk over HBM, `delta_lds16` = the LDS form, one workgroup a blob)
 		if(ncls[0] || ncls[1]) {
-			LT.begin("delta_mesh");
-			if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0]);
-			if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1]);
-			LT.end();
+			// too big for the LDS records: tiles of 1 024 vertices out of an LDS ring (k_delta_tiles, up to four components); rounds 1-5's stretch walk
+			// over L2 for attributes of more components, and for everything under $CORTO_DELTA_WALK=1
+			const uint32_t nbig = ncls[0] + ncls[1];
+			bool many = false;
+			for(uint32_t k = 0; k < nbig; k++) many = many || pl.delta.v[k].N > 4;
+			if(!ctx->dbg.delta_walk && !tiles_launched) delta_tiles(st);
+			if(ctx->dbg.delta_walk || many) {
+				LT.begin("delta_mesh");
+				const uint32_t only = ctx->dbg.delta_walk ? 0u : 1u;
+				if(ncls[0]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[0]), dim3(DELTA_THREADS), 0, st, D(pl.delta), ncls[0], only);
+				if(ncls[1]) hipLaunchKernelGGL(k_delta_mesh, dim3(ncls[1]), dim3(DELTA_THREADS/2), 0, st, D(pl.delta) + ncls[0], ncls[1], only);
+				LT.end();
+			}
 		}
 		if(ngroups) { LT.begin("delta_lds16"); hipLaunchKernelGGL(k_delta_lds16, dim3(ngroups), dim3(256), pl.delta16_lds, st, D(pl.delta), D(pl.delta_groups),
 			ngroups); LT.end(); }

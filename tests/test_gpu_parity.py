@@ -1454,6 +1454,38 @@ def test_wide_context_on_meshes_beyond_the_lds_records(monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"CORTO_DELTA_WALK": "1"}])
+def test_big_meshes_through_the_delta_tiles(monkeypatch, env):
+    """Attributes too big for K-DELTA's LDS records go through k_delta_tiles (tiles of 1 024 vertices out of an LDS ring of the last 4 096 values;
+    $CORTO_DELTA_WALK=1: rounds 1-5's stretch walk over L2): a 45K-vertex mesh with SHUFFLED vertex ids (parents anywhere: behind the ring, inside the
+    tile, one back - every pass pattern), flipped diagonals, a torus, 18-bit positions, rgb colours, several groups - on a lone context (the tiles run on
+    the second stream BESIDE the automaton and wait for its progress word) and on a single-stream one (behind it); plus one of each in ONE batch"""
+    from corto_amd import synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    meshes = [synth.shuffled(synth.bumpy_sphere_flipped(300, 150, seed=5, flip=0.3), seed=9),
+              synth.bumpy_sphere_flipped(260, 140, seed=6, color_components=3),
+              synth.torus(220, 160, seed=7),
+              synth.shuffled(synth.delaunay_disc(40000, seed=8, holes=9), seed=3, faces=False)]
+    meshes[1].groups = [5000, 5001, 40000, meshes[1].nface]
+    kws = [dict(normal_prediction=ca.BORDER), dict(normal_prediction=ca.ESTIMATED, position_bits=18), dict(normal_prediction=ca.DIFF), dict(normal_prediction=ca.BORDER, position_bits=16)]
+    blobs = [ca.encode(m, **kw) for m, kw in zip(meshes, kws)]
+    refs = [oc.decode(x, color_components=4) for x in blobs]
+    for single in (False, True):
+        c = ca.Context(0)
+        if single:
+            c.set_single_stream(True)
+        for i, x in enumerate(blobs):
+            b = run_batch(c, [x], color_components=4)
+            assert_same(b.host_outputs(0), refs[i], KEYS, "big mesh %d single=%s env %s" % (i, single, env))
+            b.close()
+        b = run_batch(c, blobs, color_components=4)
+        for i, r in enumerate(refs):
+            assert_same(b.host_outputs(i), r, KEYS, "big meshes in one batch: %d single=%s env %s" % (i, single, env))
+        b.close()
+        c.close()
+
+
 def test_nonlattice_c4_sized_blobs_against_the_reference_digests(ctx):
     """eight C4-sized blobs with no lattice in them - bench.py's `realistic` Delaunay discs, decimated spheres, an icosphere, a cone of fans - in one batch, twice
     (the second decode with the edge slots the first taught the context), u32 indices: SHA-256 of every output array = what the compiled REFERENCE decoded

@@ -60,7 +60,10 @@ for rd in range(rounds):
             got = b.host_outputs(i)
             for key in KEYS:
                 if key in r and got[key].tobytes() != r[key].tobytes():
-                    bad += 1; print("MISMATCH round", rd, "blob", i, key, "nface", r["nface"])
+                    bad += 1
+                    g_, r_ = got[key].reshape(len(got[key]), -1), r[key].reshape(len(r[key]), -1)
+                    rows = np.flatnonzero((g_.view(np.uint8).reshape(len(g_), -1) != r_.view(np.uint8).reshape(len(r_), -1)).any(1))
+                    print("MISMATCH round", rd, "blob", i, key, "nface", r["nface"], "nvert", r["nvert"], "attempt", attempt, "rows", len(rows), "first", rows[:4].tolist(), "last", rows[-2:].tolist())
             total += 1
         fallbacks.append(int(b.stats().topology_fallbacks))
         b.close()
