@@ -33,6 +33,9 @@ __global__ __launch_bounds__(64) void k_tun_tables(const TunStream *__restrict__
 	const TunStream st = streams[s];
 	extern __shared__ __attribute__((aligned(16))) uint8_t big_words[];        // TUN_TABLE_BYTES when the launch has an alphabet of more than 64 symbols, else nothing
 	tun_tables_body<true>(st, &tables[st.table], nullptr, nullptr, nullptr, big_words);
+#ifdef CORTO_TUN_STAMPS
+	if(threadIdx.x == 0 && blockIdx.x < 4096) { g_tun_stamps[blockIdx.x*8 + 4] = g_tun_stamps[blockIdx.x*8 + 3]; g_tun_stamps[blockIdx.x*8 + 5] = st.nsym; g_tun_stamps[blockIdx.x*8 + 6] = st.probs[1]; g_tun_stamps[blockIdx.x*8 + 7] = st.probs[3]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -116,7 +116,7 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 		// row asc, FIFO order), and the k-th of them makes entries end + k*n .. + n - 1.  A 2-symbol alphabet's 252 serial expansions (42 us,
 		// the length of a launch while 200 other waves idle) become ~20 batches, a 4-symbol one's 83 seven to sixteen.
 		// Lane l looks at entry bj = l / n of row br = l % n's FIFO (a window of J = 64 / n entries a row); a row whose whole window is
-		// selected may hold more behind it: nothing at or below its last candidate is taken.  Ranks by comparing keys over the selected
+		// selected may hold more behind it: nothing later in the order than its last candidate is taken.  Ranks by comparing keys over the selected
 		// lanes; every popped lane writes its n children.  Anything unusual (all heads zero, an unsorted table) is left to the loop below,
 		// which picks up from head[] / epl[] at any point.
 		if(n <= TUN_BATCH_MAX_N && nwords + n <= 255) {
@@ -138,15 +138,42 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 				if(M == 0) break;                                                    // (every head zero or empty: the loop below has upstream's row-0 rule)
 				const uint32_t cmax = (M*pmax) >> 16;
 				bool sel = prob > cmax;
+				const uint32_t key = prob << 12 | tie;
+				// (a row whose whole window is selected may hold more behind it, all of it later in the order than the window's last entry: what is safe is
+				// what comes no later than the earliest such last entry - by KEY, so that a flat table's level of equal probabilities still goes a row at a time)
 				const uint64_t deep = __ballot(sel && bj == J - 1 && e + n < end);
-				if(deep) { const uint32_t T = wave_max_u32((deep >> lane) & 1 ? prob : 0u); sel = sel && prob > T; }
+				if(deep) { const uint32_t cut = wave_max_u32((deep >> lane) & 1 ? key : 0u); sel = sel && key >= cut; }
 				const uint64_t smask = __ballot(sel);
 				if(!smask) break;
-				const uint32_t key = prob << 12 | tie;
-				uint32_t rank = 0;
-				for(uint64_t m = smask; m; m &= m - 1) {
-					const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(m));
-					rank += k > key ? 1u : 0u;
+				// ranks: a row's own entries are in order already (lane = bj*n + br), so the row with the most selected entries takes its ranks from its
+				// position in the row plus ONE compare against each selected entry of the OTHER rows - and each of those gets its exact rank in the same
+				// step (how many selected keys beat it: a ballot and a count).  The loop runs over the other rows' entries only (a two-symbol alphabet's
+				// A-row holds two thirds to three quarters of a batch).
+				const uint32_t mine = (uint32_t)__popcll(smask & rowmask);
+				const uint32_t bigkey = wave_max_u32(slot ? mine << 8 | (255u - br) : 0u);
+				const uint32_t bigrow = 255u - (bigkey & 255u);
+				const uint64_t bigmask = __ballot(slot && br == bigrow);
+				uint32_t rank = (uint32_t)__popcll(smask & rowmask & ((1ull << lane) - 1ull));     // (my place among my row's selected entries)
+				if(n == 2) {
+					// two rows: how many of the OTHER row's selected entries come before me is a binary search down that row (its keys fall with bj): six
+					// cross-lane reads whatever the batch's size - a flat two-symbol table pops 32 a row and batch, and the loop below took a step an entry
+					const uint32_t other = (uint32_t)__popcll(smask & ~rowmask);                       // (lanes 0 .. 63 are all window slots when n = 2)
+					uint32_t lo = 0, hi = other;
+#pragma unroll
+					for(int it = 0; it < 6; it++) {
+						const uint32_t mid = (lo + hi) >> 1;
+						const uint32_t k = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((mid << 1) | (br ^ 1u)) << 2), (int)key);
+						const bool before = lo < hi && k > key;
+						lo = before ? mid + 1 : lo; hi = before || lo >= hi ? hi : mid;
+					}
+					rank += lo;
+				} else
+				for(uint64_t m = smask & ~bigmask; m; m &= m - 1) {
+					const uint32_t i = (uint32_t)__builtin_ctzll(m);
+					const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);
+					rank += br == bigrow && k > key ? 1u : 0u;
+					const uint32_t beat = (uint32_t)__popcll(__ballot(sel && key > k));
+					rank = lane == i ? beat : rank;
 				}
 				const bool pop = sel && rank < left;
 				const uint64_t pmask = __ballot(pop);
@@ -277,13 +304,8 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 	uint32_t row = lane % n;                                              // e % n, carried along (an integer division per entry otherwise)
 	const uint32_t rstep = 64u % n;
 	const uint8_t A = sym[0];
-	for(uint32_t base = 0; base < end; base += 64) {
-		const uint32_t e = base + lane;
-		const bool alive = e < end && !(head[row] > e);
-		row += rstep; row -= row >= n ? n : 0u;
-		const uint64_t mask = __ballot(alive);
-		const uint32_t rank = w + __popcll(mask & ((1ull << lane) - 1ull));
-		const bool take = alive && rank < 256;
+	// one word: its table entry, and - made by an expansion - its bytes, spelled from the back up to its seed word A^(k-1) sym[row]
+	auto emit = [&](bool take, uint32_t e, uint32_t rank) {
 		const uint32_t len_ = take ? (epl[e] >> 16) & 255u : 0u;
 		const bool made = tree && take && e >= seed_end;                  // spelled out here
 		const uint32_t incl = wave_inclusive_scan_u32(made ? len_ : 0u);
@@ -304,6 +326,35 @@ __device__ __forceinline__ TunBuilt tun_tables_body(const TunStream &st, TunTabl
 			put(--j, (uint8_t)(lr >> 24));
 			while(j > off) put(--j, A);
 		}
+	};
+	if(tree) {
+		// the survivors first, compacted (creation order = code order): the ~510 entries hold 256 survivors, and a pass of the spelling loop is as long
+		// as its longest word - four full passes instead of eight half-empty ones.  (pw[] - the low-entropy seed's powers - is free by now.)
+		uint16_t *surv = pw;
+		for(uint32_t base = 0; base < end; base += 64) {
+			const uint32_t e = base + lane;
+			const bool alive = e < end && !(head[row] > e);
+			row += rstep; row -= row >= n ? n : 0u;
+			const uint64_t mask = __ballot(alive);
+			const uint32_t rank = w + __popcll(mask & ((1ull << lane) - 1ull));
+			if(alive && rank < 256) surv[rank] = (uint16_t)e;
+			w += __popcll(mask);
+		}
+		__syncthreads();
+		const uint32_t nw = w < 256 ? w : 256;
+		for(uint32_t base = 0; base < nw; base += 64) {
+			const uint32_t rank = base + lane;
+			const bool take = rank < nw;
+			emit(take, take ? (uint32_t)surv[rank] : 0u, rank);
+		}
+	} else
+	for(uint32_t base = 0; base < end; base += 64) {
+		const uint32_t e = base + lane;
+		const bool alive = e < end && !(head[row] > e);
+		row += rstep; row -= row >= n ? n : 0u;
+		const uint64_t mask = __ballot(alive);
+		const uint32_t rank = w + __popcll(mask & ((1ull << lane) - 1ull));
+		emit(alive && rank < 256, e, rank);
 		w += __popcll(mask);
 	}
 	TUN_STAMP(3);

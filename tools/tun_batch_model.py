@@ -104,17 +104,19 @@ def batched(probs, stats=None):
             break                                    # (all heads zero / empty: the serial loop's row-0 rule)
         cmax = (M * Pmax) >> 16
         sel = [c for c in cand if c[0] > cmax]
-        # a row whose whole window is selected may hold more behind it: nothing at or below its last candidate's probability is safe
-        T = 0
+        # a row whose whole window is selected may hold more behind it - all of it later in the order than the window's last entry: what is safe is what
+        # comes no later than the EARLIEST such last entry (keys: probability desc, row asc, place in the row asc)
+        key = lambda c: (-c[0], c[1], c[2])
+        cut = None
         for r in range(n):
             rows = [c for c in sel if c[1] == r]
             if len(rows) == J and S["head"][r] + J * n < S["end"]:
-                T = max(T, rows[-1][0])
-        if T:
-            sel = [c for c in sel if c[0] > T]
+                cut = key(rows[-1]) if cut is None else min(cut, key(rows[-1]))
+        if cut is not None:
+            sel = [c for c in sel if key(c) <= cut]
         if not sel:
             break
-        sel.sort(key=lambda c: (-c[0], c[1], c[2]))
+        sel.sort(key=key)
         sel = sel[:min(J, whole)]
         base = S["end"]
         for k, (p, r, j, e) in enumerate(sel):
