@@ -235,6 +235,30 @@ def test_pool_outputs_to_host_is_the_secondary_region(c5_blobs):
     pool.close()
 
 
+def test_pool_render_layouts(c5_blobs):
+    """crthip_pool_set_render_layouts (SURVEY 8f3): every lane's normals as int16 (upstream's INT16 output) and its index as uint16 (Decoder::setIndex(uint16_t *)),
+    with and without the D2H mirror; a blob of 65 536+ vertices keeps its uint32 index; switching the layouts off again gives the float / uint32 bytes"""
+    from corto_amd import synth
+    big = ca.aligned_blob(ca.encode(synth.bumpy_sphere(300, 230, seed=3), normal_prediction=ca.BORDER))      # 69 300 vertices: no uint16 index
+    items = [c5_blobs[100:124] + [big]]
+    pool = ca.Pool([0], threads=2, depth=2)
+    for render, to_host in ((True, False), (True, True), (False, True)):
+        pool.set_render_layouts(render); pool.set_outputs_to_host(to_host)
+        rep, _ = pool.run(items, steps=12, warmup=2, arenas=None)
+        assert rep.failed_blobs == 0 and rep.poisoned_lanes == pool.lanes
+        for lane in range(pool.lanes):
+            for i in (0, 11, 24):
+                nv = ca.probe(items[0][i]).nvert
+                u16 = render and nv < 65536
+                ref = oc.decode(items[0][i], normal_format=oc.FMT_INT16 if render else oc.FMT_FLOAT, index16=u16)
+                dts = {"position": (np.float32, 3), "normal": (np.int16 if render else np.float32, 3), "color": (np.uint8, 4), "uv": (np.float32, 2),
+                       "index": (np.uint16 if u16 else np.uint32, 3)}
+                for k, (dt, w) in dts.items():
+                    cnt = (ref["nface"] if k == "index" else ref["nvert"]) * w
+                    assert pool.lane_read(lane, i, k, dt, cnt).tobytes() == ref[k].tobytes(), (render, to_host, lane, i, k)
+    pool.close()
+
+
 def test_streams_with_the_same_table_share_one_dictionary(monkeypatch):
     """a Tunstall dictionary is a function of the probability table alone (src/tunstall.cpp:125-256), so a batch builds each DISTINCT
     table once and every stream that carries it decodes from that dictionary (k_tun_tables + k_tun_stream_grouped); $CORTO_TUN_SHARE=0

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the summaries of tools/gpu_final.sh <tag> from gpurun_out/ (scratch) into profiles/ (tracked): tools/collect_profiles.sh <tag>
-TAG=${1:-r05}; cd /root/repo || exit 1
+TAG=${1:-r06}; cd /root/repo || exit 1
 cp gpurun_out/prof_$TAG/kernel_stats.csv profiles/${TAG}_rocprofv3_kernel_stats.csv
 cp gpurun_out/prof_$TAG/pmc_per_dispatch.json profiles/${TAG}_pmc_per_dispatch.json
 cp gpurun_out/prof_tun_$TAG/pmc_per_dispatch.json profiles/${TAG}_tunstall_scaled_pmc_per_dispatch.json
