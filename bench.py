@@ -649,6 +649,11 @@ def main():
     # whatever W is: every context used (scratch pools are allocated on first use) and the GPU at its working clocks before the clock starts
     prewarm_steps = int(os.environ.get("BENCH_PREWARM_STEPS", "0")) or 8 * pool.lanes
     pool.run(host_items, steps=prewarm_steps * nloc, warmup=0, arenas=None)
+    # ... and for at least 0.3 s (round 6: on a box that had just been idle - or profiled - the first ~100 steps behind 8 rounds of the contexts still ran at
+    # 0.10-0.21 ms: clocks and the host's page / NUMA state, not the pipeline's depth)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < float(os.environ.get("BENCH_PREWARM_SECONDS", "0.3")):
+        pool.run(host_items, steps=16 * pool.lanes * nloc, warmup=0, arenas=None)
     barrier()
     # A K-step region is timed R times back to back (no drain in between) and the MEDIAN region is the one reported: with sixteen batches
     # in flight completions come in bursts, and a single region of K = 20 steps (1.25 rounds of the contexts) lands anywhere within
