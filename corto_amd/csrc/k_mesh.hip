@@ -156,7 +156,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 		if(dead) continue;                                             // deleted: no symbol consumed (decoder.cpp:278-279)
 		if(S.cler >= J.nclers) FAIL();
 		const uint32_t c = S.clers[S.cler++];
-		if(c == C_BOUNDARY) { S.chain_ends++; if(S.chain_ends + ndelayed > S.peak_pool) S.peak_pool = S.chain_ends + ndelayed; continue; }
+		if(c == C_BOUNDARY) { S.chain_ends++; continue; }              // (the LDS form keeps no record of it: the sink, below)
 		uint32_t ep, en;
 		F.links(f, ep, en);
 		if(ep >= nfront || en >= nfront) FAIL();
@@ -200,7 +200,7 @@ __device__ void topo_group(TopoState<ClersPtr> &S, Front &F, uint32_t start, uin
 			if(ndelayed >= cap) FAIL();
 			F.delayed_put(ndelayed++, f);
 			if(ndelayed > S.peak_delayed) S.peak_delayed = ndelayed;
-			if(S.chain_ends + ndelayed > S.peak_pool) S.peak_pool = S.chain_ends + ndelayed;
+			if(ndelayed + 1 > S.peak_pool) S.peak_pool = ndelayed + 1;     // (the LDS form's pool: the DELAYed edges while they wait + the sink)
 			new_edge = -1;
 			continue;
 		} else if(c == C_END) {                                        // decoder.cpp:333-339
@@ -516,8 +516,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
       Layout (records at LDS address 0): free list at 16*FL16, DELAY stack at 16*DL16, ring + pool = FL16 slots - the layout word %[lay] = FL16 | DL16 << 16. \
       Anything else (END, an invalid or window-end nibble, no slot left, empty ring and empty DELAY stack, window about to run out) leaves for the C++. */ \
 							"Lcold_%=:\n" \
-							"  s_cmp_eq_u32 %[c], 4\n" \
-							"  s_cbranch_scc1 Lbnd_%=\n" \
+							"  s_cmp_eq_u32 %[c], 4\n"          /* BOUNDARY: the sink takes it (round 6: Lsink below) - no slot, no record: the two links, then the pop */ \
+							"  s_cbranch_scc1 Lsink_%=\n" \
 							"  s_cmp_eq_u32 %[c], 6\n" \
 							"  s_cbranch_scc1 Lsplit_%=\n" \
 							"  s_cmp_eq_u32 %[c], 5\n" \
@@ -526,8 +526,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_lshr_b32 %[t2], %[pk2], 16\n" \
 							"  s_cmp_ge_u32 %[t0], %[t2]\n" \
 							"  s_cbranch_scc1 Lexit_%=\n" \
-							"Lbnd_%=:\n" \
-							"  s_lshr_b32 %[t0], %[pk1], 16\n"   /* free-list fill */ \
+							"  s_lshr_b32 %[t0], %[pk1], 16\n"   /* (DELAY) free-list fill */ \
 							"  s_cmp_eq_u32 %[t0], 0\n" \
 							"  s_cbranch_scc1 Lbump_%=\n" \
 							"  s_sub_u32 %[t0], %[t0], 1\n" \
@@ -571,6 +570,7 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_lshl_b32 %[t0], %[t1], 4\n" \
 							"  v_mov_b32 v54, %[t0]\n" \
 							"  ds_write_b128 v54, v[48:51]\n" \
+							"Llinks_%=:\n" \
 							"  v_mov_b32 v53, %[t1]\n" \
 							"  s_lshl_b32 %[t0], %[ep], 4\n" \
 							"  v_mov_b32 v52, %[t0]\n" \
@@ -629,6 +629,9 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 							"  s_lshr_b32 %[en], %[t0], 16\n" \
 							"  s_mov_b32 %[nc], -1\n" \
 							"  s_branch Ltop_%=\n" \
+							"Lsink_%=:\n" \
+							"  s_add_u32 %[t1], %[mask], 1\n"      /* pool slot RING: every BOUNDARY edge (k_mesh.hip: THE SINK) */ \
+							"  s_branch Llinks_%=\n" \
    /* the ring is empty: the youngest postponed gate (decoder.cpp:266-270); its pool slot goes back to the free list */ \
 							"Ldpop_%=:\n" \
 							"  s_and_b32 %[t0], %[pk2], 0xffff\n" \
@@ -1481,8 +1484,10 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_lshl_or_b32 v45, v45, 8, v44\n" \
 	"  v_lshlrev_b32 v46, 2, v38\n" \
 	"  ds_bpermute_b32 v46, v46, v45\n"              /* v46: the symbol that ends the lane's gate (lane rank's) */ \
-	"  v_cmp_gt_u32 vcc, %[t1], v38\n"               /* rank < free-list fill: slot freel[fill - 1 - rank] */ \
-	"  v_sub_u32 v47, %[t1], v38\n" \
+	"  s_waitcnt lgkmcnt(0)\n" \
+	"  v_lshrrev_b32 v62, 8, v46\n"                  /* round 6: only a DELAY takes a pool slot (a BOUNDARY edge goes to the sink): its place among the step's DELAYs */ \
+	"  v_cmp_gt_u32 vcc, %[t1], v62\n"               /* place < free-list fill: slot freel[fill - 1 - place] */ \
+	"  v_sub_u32 v47, %[t1], v62\n" \
 	"  v_add_u32 v47, -1, v47\n" \
 	"  v_lshlrev_b32 v47, 1, v47\n" \
 	"  s_and_b32 %[c], %[lay], 0xffff\n" \
@@ -1491,10 +1496,15 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_mov_b64 exec, vcc\n" \
 	"  ds_read_u16 v47, v47\n" \
 	"  s_mov_b64 exec, -1\n" \
-	"  v_add_u32 v48, %[t3], v38\n"                  /* else bump + rank - fill */ \
+	"  v_add_u32 v48, %[t3], v62\n"                  /* else bump + place - fill */ \
 	"  v_subrev_u32 v48, %[t1], v48\n" \
 	"  s_waitcnt lgkmcnt(0)\n" \
-	"  v_cndmask_b32 v47, v48, v47, vcc\n"           /* v47: the lane's pool slot */ \
+	"  v_cndmask_b32 v47, v48, v47, vcc\n"           /* a DELAY's pool slot ... */ \
+	"  v_and_b32 v48, 15, v46\n" \
+	"  v_cmp_eq_u32 vcc, 5, v48\n" \
+	"  s_add_u32 %[c], %[mask], 1\n" \
+	"  v_mov_b32 v48, %[c]\n" \
+	"  v_cndmask_b32 v47, v48, v47, vcc\n"           /* v47: ... or the sink */ \
 	"  v_cmp_ne_u32 vcc, 0, v39\n" \
 	"  s_mov_b64 exec, vcc\n"                        /* live lanes ... */ \
 	"  v_cmp_gt_u32 vcc, %[t0], v38\n" \
@@ -1544,14 +1554,14 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  v_cndmask_b32 v58, v58, v33, vcc\n" \
 	"  v_lshl_or_b32 v59, v53, 16, v52\n" \
 	"  v_lshlrev_b32 v32, 4, v47\n" \
-	"  ds_write_b128 v32, v[56:59]\n" \
 	"  v_lshrrev_b32 v33, 8, v46\n"                  /* a DELAY's place on the stack */ \
 	"  v_add_u32 v33, %[t2], v33\n" \
 	"  v_lshlrev_b32 v33, 1, v33\n" \
 	"  s_lshr_b32 %[c], %[lay], 16\n" \
 	"  s_lshl_b32 %[c], %[c], 4\n" \
 	"  v_add_u32 v33, %[c], v33\n" \
-	"  s_and_b64 exec, exec, vcc\n" \
+	"  s_and_b64 exec, exec, vcc\n"                  /* the DELAYs: their records in the pool (a BOUNDARY edge leaves none), their slots on the stack */ \
+	"  ds_write_b128 v32, v[56:59]\n" \
 	"  ds_write_b16 v33, v47\n" \
 	"  s_mov_b64 exec, -1\n" \
 	"  v_cmp_ne_u32 vcc, 0, v39\n"                   /* the neighbours that stay where they are: their links */ \
@@ -1586,8 +1596,8 @@ constexpr uint32_t TOPO_DEAD = 0x80000000u, TOPO_DELAYED = 0x40000000u, TOPO_VMA
 	"  s_lshr_b32 %[c], %[c], 8\n" \
 	"  s_add_u32 %[pk2], %[pk2], %[c]\n" \
 	"  s_lshr_b32 %[t1], %[pk1], 16\n" \
-	"  s_min_u32 %[t1], %[t1], %[t0]\n"              /* slots taken from the free list; the rest from the bump pointer */ \
-	"  s_sub_u32 %[c], %[t0], %[t1]\n" \
+	"  s_min_u32 %[t1], %[t1], %[c]\n"               /* the DELAYs' slots: taken from the free list; the rest from the bump pointer */ \
+	"  s_sub_u32 %[c], %[c], %[t1]\n" \
 	"  s_add_u32 %[pk1], %[pk1], %[c]\n" \
 	"  s_lshl_b32 %[t1], %[t1], 16\n" \
 	"  s_sub_u32 %[pk1], %[pk1], %[t1]\n" \
@@ -1683,7 +1693,7 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {
 	{ const uint64_t lim = (uint64_t)nspl*32u; cold[K_BIT_LIMIT] = (uint32_t)(lim < bit_end ? lim : bit_end); }
 	// pool bump pointer | free-list fill << 16, DELAY stack fill | its capacity << 16: touched at every chain end, kept in registers and
 	// packed in pairs - the ISA block carries them, and an asm statement takes 30 operands at most
-	uint32_t pk1 = RING, pk2 = dcap << 16;
+	uint32_t pk1 = RING + 1u, pk2 = dcap << 16;                          // (pool slot RING is the sink of the BOUNDARY edges: below)
 #define TOPO_NFREE() (pk1 >> 16)
 #define TOPO_MBUMP() (pk1 & 0xFFFFu)
 #define TOPO_NDEL() (pk2 & 0xFFFFu)
@@ -1720,7 +1730,13 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {
 			const uint32_t ge = TOPO_S(group_end[g]);
 			if(ge > J.nface || ge*3 < start) { err = 1; break; }
 			const uint32_t end = ge*3;
-			nq = 0; qpos = 0; pk1 = RING; pk2 = dcap << 16;
+			nq = 0; qpos = 0; pk1 = RING + 1u; pk2 = dcap << 16;
+			// THE SINK (round 6).  A BOUNDARY edge's record is never read again: decoder.cpp:311-339 read front[e.prev] / front[e.next] only to close against them, and
+			// nothing closes against an edge that has no face behind it (tools/topo_run_model.py asserts it on every family, non-manifold glue included).  Only its slot id
+			// lives on, in its neighbours' links - which they only ever overwrite.  So every BOUNDARY edge is ONE pool slot, this one: no slot taken, no record written,
+			// two link writes - and the pool holds the DELAYed edges alone (a C4 blob: 65 slots instead of 222, a Delaunay disc: 194 of 469).  Its record exists for
+			// malformed streams only: links in range, flagged DELAYED so that a LEFT / RIGHT against it never puts it on the free list.
+			{ u32x4 t_; t_.x = 0; t_.y = 0; t_.z = TOPO_DELAYED; t_.w = RING | RING << 16; rec[RING] = t_; }
 			while(start < end && !err) {
 				if(cler >= slide_at) TOPO_SLIDE();                          // slide the window before it runs low
 				// a consumer running beside the automaton (k_delta_tiles): tell it every 4 096 vertices how far the triples have got (a release: ~1 us for
@@ -1844,8 +1860,8 @@ __device__ __forceinline__ bool topo_lds_body(const TopoJob &J) {
 						nc = 0xFFFFFFFFu;
 						v2 = v1; v1 = opp; en = nn;                        // new edge (v0, opp, old v1, ep, nn): next, lazily
 					} else {                                               // ---- cold symbols end the chain ----
-						if(c == C_BOUNDARY) {
-							TOPO_MATERIALISE(0u);
+						if(c == C_BOUNDARY) {                              // (the sink: above)
+							rec16[ep*8 + 7] = (uint16_t)RING; rec16[en*8 + 6] = (uint16_t)RING;
 						} else if(c == C_SPLIT) {
 							if(nq - qpos > MASK) { err = 2; break; }
 							uint32_t opp; TOPO_BITS(opp, splitbits);

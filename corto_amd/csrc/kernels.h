@@ -68,7 +68,11 @@ inline void topo_lds_geometry(uint32_t nface, uint32_t nclers, uint32_t ring_max
 	const uint32_t base = want;
 	while(ring_scale > 1 && want < ring_max) { want <<= 1; ring_scale >>= 1; }
 	ring = want;
-	uint64_t p = std::max<uint64_t>(base, (uint64_t)boundary + boundary/8 + 48);
+	// round 6: the BOUNDARY edges share ONE slot (the sink, k_mesh.hip), so the pool holds the DELAYed edges while they wait + that slot: 65 for a C4 blob
+	// (222 with a record per BOUNDARY edge), 131 with flipped diagonals, 194 for a Delaunay disc with holes (469), 511 for a holey disc (1 325) - half the
+	// ring's base to begin with, times what the context learns from the blobs that outgrow it.  (`boundary`: rounds 4-5's floor from the header, unused now.)
+	(void)boundary;
+	uint64_t p = std::max<uint64_t>(64, base/2);
 	const uint64_t p1 = p;
 	p = (p*pool_q8 + 7)/8;
 	if(pool_cap && p > pool_cap) p = std::max<uint64_t>(p1, pool_cap);

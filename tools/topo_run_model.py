@@ -23,6 +23,7 @@ class Model:
         self.use_runs = use_runs
         self.use_mix = use_mix
         self.use_ends = use_ends
+        self.use_sink = os.environ.get('TOPO_SINK', '1') == '1'
         self.any_align = os.environ.get('MIX_ANY_ALIGN', '1') == '1'   # the kernel's window register holds eight symbols whatever the alignment (round 4; 0: what rounds 2-3 did - four certain symbols only with cler & 7 <= 4)
         self.ref_faces = ref_faces        # SPLIT operands are taken from the oracle's faces (the model does not read the bit stream)
         self.group_end = group_end
@@ -41,7 +42,14 @@ class Model:
         cler = 0; vc = 0; start = 0
         for ge in self.group_end:
             end = ge * 3
-            nq = qpos = 0; mbump = self.RING; free = []; delayed = []
+            # round 6: a BOUNDARY edge's record is never read again (nothing closes against an edge without a face behind it: decoder.cpp:311-339 read
+            # front[e.prev] / front[e.next] only to close against them) - only its SLOT ID lives on, in its neighbours' links, and they only ever WRITE
+            # their own ids into it.  So every BOUNDARY edge is the same slot, the SINK (the pool's first): no slot, no record, two link writes.
+            SINK = self.RING if self.use_sink else None
+            nq = qpos = 0; mbump = self.RING + (1 if self.use_sink else 0); free = []; delayed = []
+            def readable(slot):
+                assert slot != SINK, "a BOUNDARY edge's record is read"
+                return rec[slot]
             while start < end:
                 self.stats['peak_ring'] = max(self.stats.get('peak_ring', 0), nq - qpos); self.stats['peak_pool'] = max(self.stats.get('peak_pool', 0), mbump - self.RING); self.stats['peak_delayed'] = max(self.stats.get('peak_delayed', 0), len(delayed))
                 # fetch next edge
@@ -51,7 +59,7 @@ class Model:
                     self.stats['pops'] += 1; self.events.append((cler, 'pop', 1))
                     cur = list(t)
                 elif delayed:
-                    f = delayed.pop(); t = rec[f]; free.append(f)
+                    f = delayed.pop(); t = readable(f); free.append(f)
                     if t[3]: continue
                     self.stats['dpops'] += 1; self.events.append((cler, 'dpop', 1))
                     cur = list(t)
@@ -174,7 +182,7 @@ class Model:
                             w = [rec[(ep + i) & MASK][4] for i in range(64)]
                             TV, TL = nV[k], nL[k]
                             hasR = rpos < k                  # the RIGHT closes against e.next as it is when the step begins (nothing in front of it touches that side)
-                            tR = list(rec[en]) if hasR else None
+                            tR = list(readable(en)) if hasR else None
                             v1b = tR[1] if hasR else v1       # v1 and e.next behind the RIGHT
                             enb = tR[5] if hasR else en
                             nV = [sum(isV[:min(j, k)]) for j in range(64)]      # masks cut at k (lane k reads the state after the step)
@@ -231,16 +239,18 @@ class Model:
                                 nonlocal mbump
                                 if free: return free.pop()
                                 f = mbump; mbump += 1; return f
-                            f0 = alloc()
-                            rec[f0] = [v0, v1, v2, 0, ep, en]; rec[ep][5] = f0; rec[en][4] = f0
+                            sunk = lambda m: SINK is not None and cl[cler + m] == B          # (a BOUNDARY edge goes to the sink: no slot, no record)
+                            f0 = SINK if sunk(0) else alloc()
+                            if not sunk(0): rec[f0] = [v0, v1, v2, 0, ep, en]
+                            rec[ep][5] = f0; rec[en][4] = f0
                             if cl[cler] == D: delayed.append(f0)
                             G = [((qpos + i) & MASK, list(rec[(qpos + i) & MASK])) for i in live[:k]]      # read AFTER edge 0's link writes
-                            fs = [alloc() for m in range(1, k)]                                               # edge m -> fs[m - 1]
+                            fs = [SINK if sunk(m) else alloc() for m in range(1, k)]                         # edge m -> fs[m - 1]
                             fwd = {G[m - 1][0]: fs[m - 1] for m in range(1, k)}
                             for m in range(1, k):
                                 slot, t = G[m - 1]; f = fs[m - 1]
                                 pv, nx = fwd.get(t[4], t[4]), fwd.get(t[5], t[5])
-                                rec[f] = [t[0], t[1], t[2], 0, pv, nx]
+                                if not sunk(m): rec[f] = [t[0], t[1], t[2], 0, pv, nx]
                                 if t[4] not in fwd: rec[pv][5] = f
                                 if t[5] not in fwd: rec[nx][4] = f
                                 if cl[cler + m] == D: delayed.append(f)
@@ -267,12 +277,12 @@ class Model:
                         rec[s] = [opp, v1, v0, 0, LAZY, en]
                         v2 = v1; v1 = opp; en = s
                     elif c == L:
-                        t = rec[ep]; pp, opp = t[4], t[0]; t[3] = 1
+                        t = readable(ep); pp, opp = t[4], t[0]; t[3] = 1
                         if ep > MASK and ep not in delayed: free.append(ep)
                         self.faces += [v1, v0, opp]; start += 3
                         v2 = v0; v0 = opp; ep = pp
                     elif c == R:
-                        t = rec[en]; nn, opp = t[5], t[1]; t[3] = 1
+                        t = readable(en); nn, opp = t[5], t[1]; t[3] = 1
                         if en > MASK and en not in delayed: free.append(en)
                         self.faces += [v1, v0, opp]; start += 3
                         v2 = v1; v1 = opp; en = nn
@@ -283,10 +293,11 @@ class Model:
                             else: f = mbump; mbump += 1
                             rec[f] = [v0, v1, v2, 0, ep, en]; rec[ep][5] = f; rec[en][4] = f
                             return f
-                        if c == B: materialise()
+                        if c == B and SINK is not None: rec[ep][5] = SINK; rec[en][4] = SINK
+                        elif c == B: materialise()
                         elif c == D: delayed.append(materialise())
                         elif c == E:
-                            tp, tn = rec[ep], rec[en]
+                            tp, tn = readable(ep), readable(en)
                             pp, nn, opp = tp[4], tn[5], tp[0]
                             tp[3] = 1; tn[3] = 1
                             if ep > MASK and ep not in delayed: free.append(ep)
