@@ -78,6 +78,6 @@ for rd in range(rounds):
                     # stays in the pool for good, every DELAYed one until it is popped, and the queue of a mesh with handles is ten times a sphere's
                     cl = oc.decode(blob, trace=True)["_clers"]
                     nb, nd = int((cl == 4).sum()), int((cl == 5).sum())
-                    big = nb + nd > 3600 or meshes[i].nface > 60000
+                    big = nd > 3600 or meshes[i].nface > 60000                    # (round 6: the BOUNDARY edges share one slot - the DELAYed ones alone need the pool)
                     print("  fallback by capacity:" if big else "  persistent fallback:", "round", rd, "blob", i, "kind", kinds[i], "nface", meshes[i].nface, "nvert", meshes[i].nvert, "BOUNDARY", nb, "DELAY", nd, n)
 print("decodes", total, "mismatching arrays", bad, "fallbacks per batch (first pass, second pass ...)", fallbacks)
