@@ -394,16 +394,18 @@ def other_configs(ctx, ca):
             pass
     # where a single mesh stops losing to one CPU core: the same decode on grids of growing size
     sweep = []
-    for nu, nv in ((64, 32), (128, 64), (256, 125), (384, 190)):
+    # (round 6: + the 33-66K-vertex meshes with 16-bit positions, which rounds 1-5 sent through the stretch walk over L2: 30K vertices is the LDS records' size,
+    # 50K the first beyond them - `ns_per_vertex` should fall, not jump, from one to the other)
+    for nu, nv, pbits in ((64, 32, 14), (128, 64, 14), (240, 124, 16), (256, 125, 14), (320, 160, 16), (384, 190, 14)):
         mesh = synth.bumpy_sphere(nu, nv, seed=1)
-        blob = ca.encode(mesh, position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
+        blob = ca.encode(mesh, position_bits=pbits, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
         b = ca.Batch(ctx, [blob]); b.allocate_outputs()
         b.decode(); b.sync()
         t0 = time.perf_counter()
         for _ in range(5):
             b.decode(); b.sync()
         dt = (time.perf_counter() - t0) / 5
-        row = {"triangles": int(mesh.nface), "gpu_ms": round(dt * 1e3, 3)}
+        row = {"triangles": int(mesh.nface), "vertices": int(mesh.nvert), "position_bits": pbits, "gpu_ms": round(dt * 1e3, 3), "ns_per_vertex": round(dt * 1e9 / mesh.nvert, 1)}
         b.close()
         try:
             from oracle import refcodec as rc
