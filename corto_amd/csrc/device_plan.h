@@ -115,7 +115,7 @@ struct DeltaJob {
 	void *out;                     // colour destination
 	uint32_t out_components, out_stride;
 	int32_t *flags;                // k_delta_lds16: set to 1 when the attribute's values relative to vertex 0 left int16 and were redone in HBM
-	uint32_t pad2[2];              // pad2[0]: the round loop from vertex 1 (test hook: $CORTO_DELTA_ROUNDS)
+	uint32_t pad2[2];              // pad2[0]: the round loop from vertex 1 (test hook: $CORTO_DELTA_ROUNDS); pad2[1]: words from the blob's status word to `flags` (k_delta_tiles)
 };
 
 // point-cloud running sum, one job per (blob, attribute) (vertex_attribute.h:177-181, normal_attribute.cpp:202-207)

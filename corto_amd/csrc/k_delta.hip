@@ -777,7 +777,10 @@ __device__ __forceinline__ void delta_tiles_body(const DeltaJob &J, CRT_LDS uint
 			uint32_t p;
 			while((p = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < need) {
 				__builtin_amdgcn_s_sleep(32);
-				if(wall_clock64() - t0 > 200000000ull) { p = 0xFFFFFFFFu; break; }
+				if(wall_clock64() - t0 > 200000000ull) {                           // (cannot happen: the automaton is enqueued first and waits for nothing of this kernel;
+					as_global(J.flags)[-(int32_t)J.pad2[1]] = -9;                    //  if it ever does, the blob says CRTHIP_E_DEVICE instead of carrying wrong values)
+					p = 0xFFFFFFFFu; break;
+				}
 			}
 			gpub[DELTA_THREADS/64] = p;
 		}

@@ -214,6 +214,7 @@ int Planner::jobs() {
 					// (k_delta_mesh's flags, else - k_delta_tiles - the automaton's progress word)
 					d.fired = A.fired != ~0ull ? SP(A.fired) : S.progress != ~0ull ? SP(S.progress) : nullptr;
 					d.flags = HS(2ull*nblobs + 2ull*i);
+					d.pad2[1] = 2u*nblobs + i;                              // (words from the blob's status to its flags: k_delta_tiles reports a progress word that never came)
 					if(a.codec != CRTHIP_CODEC_NORMAL && delta_class(d, wide) >= 2) {
 						if(a.codec == CRTHIP_CODEC_COLOR) {
 							d.deq = 2; d.out = bd.buffer; d.out_components = bd.out_components; d.out_stride = bd.stride;

@@ -120,9 +120,14 @@ int Planner::launch() {
 	// the big ones in tiles of 1 024 vertices (k_delta_tiles).  On a lone context this goes to the SECOND stream, behind the attribute streams' bit-unpack
 	// and BESIDE the automaton, whose progress word the tiles wait for: a single big mesh's delta inversion trails its topology instead of following it
 	// (config C2: 1.5 of 4.0 ms).  The automaton is enqueued first on its own stream and waits for nothing of this kernel.
+	// BESIDE the automaton only a handful of workgroups: they hold 66 KB of LDS each while they wait, and a batch of hundreds of big meshes' tiles, resident
+	// first, could keep the automata (up to 156 KB a workgroup) from ever finding a CU - the tiles would wait for a progress word nobody can write.  Up to 48
+	// (sixteen big meshes' three attributes) leave most of the chip free; more run behind the automaton as on a pool context.
+	constexpr uint32_t TILES_BESIDE_MAX = 48;
 	auto delta_tiles = [&](hipStream_t s) {
 		const uint32_t nbig = ncls[0] + ncls[1];
 		if(!nbig || ctx->dbg.delta_walk) return;
+		if(s != st && nbig > TILES_BESIDE_MAX) return;
 		LT.begin("delta_tiles", s); hipLaunchKernelGGL(k_delta_tiles, dim3(nbig), dim3(DELTA_THREADS), 0, s, D(pl.delta), nbig); LT.end();
 		tiles_launched = true;
 	};
@@ -157,7 +162,7 @@ int Planner::launch() {
 		if(launch_tun_decode_staged(st, D(pl.tun), D(pl.tun_chunk_stream), tun_chunks, tables, tun_partial, scanned ? 0u : 1u)) return fail(CRTHIP_E_DEVICE);
 		LT.end();
 		if(nfill) { LT.begin("fill"); hipLaunchKernelGGL(k_fill, dim3(nfill), dim3(256), 0, st, D(pl.fill), nfill); LT.end(); }
-		if(!ctx->single_stream && !ctx->dbg.delta_walk && ncls[0] + ncls[1] && !pl.topo.v.empty()) {
+		if(!ctx->single_stream && !ctx->dbg.delta_walk && ncls[0] + ncls[1] && ncls[0] + ncls[1] <= TILES_BESIDE_MAX && !pl.topo.v.empty()) {
 			// a big mesh alone: every stream is decoded; the automaton (one serial chain: 2.2 of C2's 4 ms) goes on on the main stream, the attributes'
 			// bit-unpack and their delta inversion in tiles on the second one, the tiles trailing the automaton's progress word
 			hipStream_t s2 = ctx->stream2;

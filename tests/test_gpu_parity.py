@@ -1507,6 +1507,14 @@ def test_big_meshes_through_the_delta_tiles(monkeypatch, env):
         for i, r in enumerate(refs):
             assert_same(b.host_outputs(i), r, KEYS, "big meshes in one batch: %d single=%s env %s" % (i, single, env))
         b.close()
+        if not env:
+            # eighteen big meshes at once: more tile workgroups (54) than may wait BESIDE the automata (48: they hold 66 KB of LDS each and the automata of
+            # big meshes ask for up to 156 KB) - these run behind them, and sixteen (48) beside them
+            for n in (18, 16):
+                b = run_batch(c, [blobs[1], blobs[2]] * (n // 2), color_components=4)
+                for i in range(n):
+                    assert_same(b.host_outputs(i), refs[1 + (i & 1)], KEYS, "%d big meshes in one batch: %d single=%s" % (n, i, single))
+                b.close()
         c.close()
 
 
