@@ -47,6 +47,7 @@ void Planner::group() {
 
 	// job arrays region
 	pl.jobs_begin = cv.take(0);
+	unpack_state_words = (uint64_t)unpack_chunks + 1;                    // (plan_carve's count was every bound stream's; the bit blocks that go a wave a stream keep no state)
 	pl.unpack_partial_off = cv.take(unpack_state_words*8, 16);           // (first thing in the uploaded block: zeros)
 	auto place = [&](auto &arr) { arr.dev_off = cv.take(arr.v.size()*sizeof(arr.v[0]) + 16, 16); };
 	// the LDS automata go up in ONE launch whose LDS request is the largest of theirs - unless some ask for much more than the others (a

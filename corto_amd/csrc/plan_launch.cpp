@@ -277,6 +277,7 @@ void Planner::account() {
 	b->stats.tunstall_in = stat_tin; b->stats.tunstall_out = stat_tout; b->stats.tunstall_tables = stat_tt; b->stats.tunstall_streams =
 		ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
 	b->stats.scratch_bytes = pl.total;
+	b->stats.descriptor_bytes = (uint32_t)pl.jobs_bytes;
 	b->stats.topology_scale = std::max(ctx->topo_scale, (ctx->topo_pool_q8 + 7)/8); b->stats.delta_wide = wide ? 1u : 0u;
 	uint64_t ob = 0;
 	for(auto &P : b->blobs) {

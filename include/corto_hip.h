@@ -342,6 +342,7 @@ typedef struct {
 	                               two vertices back) rather than its window of prefix sums: irregular connectivity (k_delta.hip; the name is rounds 3-4's, when the
 	                               fallback was a walk along the stretches of the prediction graph) */
 	uint32_t delta_wide;        /* 1: this decode was planned with 32-bit values in K-DELTA's LDS (the context had met such blobs, or $CORTO_DELTA_WIDE=1) */
+	uint32_t descriptor_bytes;  /* the job descriptors of the last decode: one host -> HBM copy beside the blobs' own bytes (it shares their PCIe link) */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 
