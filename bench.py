@@ -984,7 +984,10 @@ def main():
             "first_iteration": first_iter, "first_iteration_ms": (first_iter or {}).get("first_iteration_ms"),
             "pcie": ({"bytes_per_step": int(stats0.arena_bytes), "GBps": round(stats0.arena_bytes / (ms_step * 1e-3) / 1e9, 2), "measured_ceiling_GBps": pcie_caps["h2d_GBps"],
                       "frac": round(stats0.arena_bytes / (ms_step * 1e-3) / 1e9 / pcie_caps["h2d_GBps"], 4), "ceilings": pcie_caps,
-                      "note": "the H2D copy inside every timed step (one DMA copy of the batch's compressed bytes) against what back-to-back copies of that size reach on this box"}
+                      "descriptor_bytes_per_step": int(stats0.descriptor_bytes),
+                      "GBps_with_descriptors": round((stats0.arena_bytes + stats0.descriptor_bytes) / (ms_step * 1e-3) / 1e9, 2),
+                      "note": "the H2D copy inside every timed step (one DMA copy of the batch's compressed bytes) against what back-to-back copies of that size reach on this box; the job descriptors "
+                              "are a second, smaller copy on the same link (profiles/r06_what_was_measured.txt: sending a third of them moved nothing - a step from the host is the link AND the GPU, both nearly full)"}
                      if pcie_caps else None),
             "sustained": sustained,
             "poisoned_lanes": int(rep.poisoned_lanes), "pool_warning": pool_warning or None,
