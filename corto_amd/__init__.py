@@ -58,7 +58,7 @@ class BatchStats(C.Structure):
                 ("total_nvert", C.c_uint64), ("total_nface", C.c_uint64), ("scratch_bytes", C.c_uint64),
                 ("clers_symbols", C.c_uint64), ("split_bytes", C.c_uint64), ("topology_fallbacks", C.c_uint64),
                 ("host_plan_us", C.c_float), ("host_stage_us", C.c_float), ("host_launch_us", C.c_float), ("host_create_us", C.c_float),
-                ("topology_scale", C.c_uint32), ("tunstall_dictionaries", C.c_uint32), ("delta_redone", C.c_uint32), ("delta_walked", C.c_uint32), ("delta_wide", C.c_uint32), ("descriptor_bytes", C.c_uint32)]
+                ("topology_scale", C.c_uint32), ("tunstall_dictionaries", C.c_uint32), ("delta_redone", C.c_uint32), ("delta_walked", C.c_uint32), ("delta_wide", C.c_uint32), ("descriptor_bytes", C.c_uint32), ("int16_streams", C.c_uint32)]
 
 
 class MeshDesc(C.Structure):

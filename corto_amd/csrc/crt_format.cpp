@@ -83,6 +83,7 @@ StreamRef byte_block(Cursor &c, uint32_t entropy, int &err) {
 		s.payload_off = (uint32_t)c.pos;
 		c.skip(s.size);
 		s.mode = s.size ? STREAM_RAW : STREAM_EMPTY;
+		if(!s.size) s.max_sym = 0;
 		return s;
 	}
 	if(entropy != CRTHIP_ENTROPY_TUNSTALL) { err = CRTHIP_E_ENTROPY; return s; }
@@ -90,6 +91,7 @@ StreamRef byte_block(Cursor &c, uint32_t entropy, int &err) {
 	s.probs_off = (uint32_t)c.pos;
 	if(c.need((size_t)s.nsym * 2) && s.nsym >= 1) s.fill = c.p[c.pos];
 	if(c.need((size_t)s.nsym * 2) && s.nsym >= 2 && s.nsym <= 16) memcpy(s.probs16, c.p + c.pos, (size_t)s.nsym * 2);
+	if(c.need((size_t)s.nsym * 2) && s.nsym >= 1) { uint8_t m = 0; for(uint32_t k = 0; k < s.nsym; k++) m = std::max(m, c.p[c.pos + 2*(size_t)k]); s.max_sym = m; }
 	c.skip((size_t)s.nsym * 2);
 	s.size = c.u32();
 	s.csize = c.u32();

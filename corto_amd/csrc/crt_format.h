@@ -46,6 +46,8 @@ struct StreamRef {
 	uint32_t payload_off = 0;   // blob offset of payload (codewords, or raw bytes)
 	uint32_t fill = 0;          // STREAM_FILL: the single symbol
 	uint8_t probs16[32] = {0};  // Tunstall, nsym <= 16: the pairs themselves (streams of a batch with the same table share one dictionary, batch.cpp)
+	uint8_t max_sym = 255;      // the largest symbol the stream can decode to (Tunstall: of its table; a fill: the symbol; raw bytes: unknown = 255): a log stream whose
+	                            // widths are all <= 16 bits unpacks to values that fit int16 (plan_jobs.cpp)
 };
 
 struct BitsRef { uint32_t words_off = 0, nwords = 0; };   // words_off is 4-aligned relative to blob start

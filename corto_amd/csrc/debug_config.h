@@ -27,6 +27,8 @@ struct DebugConfig {
 	                                // without parallelogram prediction - instead of after 24 slow window passes (tests/test_gpu_parity.py runs every fixture through it)
 	bool delta_walk = false;        // $CORTO_DELTA_WALK=1 (A/B and test hook): attributes too big for K-DELTA's LDS records take rounds 1-5's stretch walk over L2 (k_delta_mesh)
 	                                // instead of the tiles of k_delta_tiles
+	bool values_i32 = false;        // $CORTO_VALUES_I32=1 (A/B and test hook): K-BIT always hands 32-bit values on (otherwise int16 where an attribute's tables prove every
+	                                // width <= 16 bits and the consumer is k_delta_lds16 / k_normal_blob: plan_jobs.cpp)
 	bool unpack_chunked = false;    // $CORTO_UNPACK_CHUNKED=1 (test hook): every bit block through the chunked K-BIT with its look-back - the kernel of big meshes -
 	                                // however small (tests/test_gpu_parity.py runs ragged sizes through both)
 };
@@ -40,6 +42,7 @@ inline DebugConfig debug_config_from_env() {
 	c.unpack_chunked = on("CORTO_UNPACK_CHUNKED");
 	c.delta_rounds = on("CORTO_DELTA_ROUNDS");
 	c.delta_walk = on("CORTO_DELTA_WALK");
+	c.values_i32 = on("CORTO_VALUES_I32");
 	return c;
 }
 

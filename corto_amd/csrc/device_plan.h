@@ -94,7 +94,7 @@ struct UnpackJob {
 	uint16_t stride;               // output elements per vertex
 	uint16_t comp;                 // VALUES: component
 	uint8_t mode;                  // 0 ARRAY, 1 VALUES
-	uint8_t out_u8;
+	uint8_t out_u8;                // 1: bytes (colours); 2: int16 (k_unpack_wave only: a stream whose table holds no width above 16 bits, read by k_delta_lds16 / k_normal_blob)
 };
 
 constexpr uint32_t UNPACK_WAVE_MAX_LOGS = 16384;   // bit blocks of at most this many logs (all streams together): one wave per stream (k_unpack_wave); else chunks of 1 024 with look-back
@@ -106,7 +106,8 @@ struct DeltaJob {
 	const uint32_t *pred;
 	uint8_t *fired;                // k_delta_mesh: nvert zeroed flags in HBM (+ the stretch starts behind them); k_delta_tiles: the automaton's progress word (TopoJob.progress) or null
 	uint32_t nvert, N;
-	uint8_t parallelogram, is_u8, pad[2];   // pad[1]: k_delta_lds16 keeps 32-bit records in LDS (the whole group says the same)
+	uint8_t parallelogram, is_u8, pad[2];   // pad[1]: k_delta_lds16 keeps 32-bit records in LDS (the whole group says the same); pad[0] (device): `values` holds the raw
+	                               // deltas as int16 (K-BIT's UnpackJob.out_u8 == 2), packed at the front of the buffer the results go to
 	// k_delta_lds16 finishes the attribute on its way out of LDS (no k_dequant launch, no second trip through HBM):
 	uint32_t deq;                  // 0: write the integers back; 1: generic, packed: (float)v*q in place (vertex_attribute.h:190-193);
 	                               // 2: colour: YCC -> RGB x qc into `out` (color_attribute.cpp:76-95)
@@ -141,7 +142,7 @@ struct NormalJob {
 	uint32_t pos_stride;           // bytes from one vertex to the next in pos_out (12 = packed, in place when pos_out == position)
 	void *pos_out;                 // null: leave the positions alone
 	float pos_q;
-	uint32_t pad;
+	uint32_t diffs_i16;            // k_normal_blob: `diffs` holds int16 pairs (K-BIT's UnpackJob.out_u8 == 2)
 	float *fn_scratch;             // k_normal_blob without its face normals in LDS: 3 floats per face in HBM scratch (null: recompute them per incident vertex)
 };
 

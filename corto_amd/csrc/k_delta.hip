@@ -395,8 +395,8 @@ __device__ __forceinline__ uint32_t delta_round_loop(const V &val, CRT_LDS const
 }
 
 // ---- staging: raw int32 deltas in HBM -> int16 records (checked); results back as the int32 / float the caller wants ----
-template <int K>
-__device__ __forceinline__ uint32_t stage_in16(const LdsVal<K> &val, CRT_GLOBAL const int32_t *src, uint32_t nvert, bool ga_here) {
+template <int K, typename S>                                                // S: int32_t, or int16_t when K-BIT wrote halfwords (DeltaJob.pad[0])
+__device__ __forceinline__ uint32_t stage_in16(const LdsVal<K> &val, CRT_GLOBAL const S *src, uint32_t nvert, bool ga_here) {
 	constexpr int NC = LdsVal<K>::NC;
 	uint32_t bad = 0;
 	constexpr uint32_t U = NC <= 2 ? 16u : 8u;                              // vertices per lane and round: every load of a round in flight together
@@ -574,7 +574,8 @@ __device__ __forceinline__ void stage_out_bytes(const LdsVal<5> &val, const Delt
 template <int K>
 __device__ __forceinline__ uint32_t delta16_in(CRT_LDS uint8_t *rec, const DeltaJob &J, bool ga_here) {
 	LdsVal<K> val{(decltype(LdsVal<K>::p))rec};
-	return stage_in16<K>(val, as_global((const int32_t *)J.values), J.nvert, ga_here);
+	if(J.pad[0]) return stage_in16<K, int16_t>(val, as_global((const int16_t *)J.values), J.nvert, ga_here);
+	return stage_in16<K, int32_t>(val, as_global((const int32_t *)J.values), J.nvert, ga_here);
 }
 // returns true if the relative values left int16 (nothing was written back: the caller redoes the attribute in HBM)
 template <int K>
@@ -584,7 +585,7 @@ __device__ __forceinline__ bool delta16_run(CRT_LDS uint8_t *rec, const DeltaJob
 	CRT_GLOBAL const int32_t *src = as_global((const int32_t *)J.values);
 	int32_t base[NC];
 #pragma unroll
-	for(int q = 0; q < NC; q++) base[q] = src[q];                            // vertex 0 (every lane: one broadcast load each)
+	for(int q = 0; q < NC; q++) base[q] = J.pad[0] ? (int32_t)((CRT_GLOBAL const int16_t *)src)[q] : src[q];   // vertex 0 (every lane: one broadcast load each)
 	const uint32_t nvert = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.nvert);
 	const bool para = __builtin_amdgcn_readfirstlane((int)J.parallelogram) != 0;
 	WindowHand hand{1u, 0ull};
@@ -725,6 +726,20 @@ __global__ __launch_bounds__(256) void k_delta_lds16(const DeltaJob *__restrict_
 		// the relative values left int16: the raw deltas are still in HBM (nothing was written back) - the same loop on them, 32 bits wide,
 		// and a word for the host: its next batches are planned on the wide kernel (batch.cpp: harvest)
 		if(lane == 0) *as_global(J.flags) = 1;
+		if(J.pad[0]) {
+			// (the raw deltas came as halfwords at the front of the buffer: widened in place from the top down - a chunk's 64 values are read before
+			// they are written, and what a chunk writes lies above everything still unread)
+			CRT_GLOBAL int32_t *v32 = as_global((int32_t *)J.values);
+			CRT_GLOBAL const int16_t *v16 = (CRT_GLOBAL const int16_t *)v32;
+			const uint32_t n = nvert*N;
+			for(uint32_t top = (n + 63u) & ~63u; top > 0; top -= 64) {
+				const uint32_t k = top - 64 + lane;
+				const int32_t x = k < n ? (int32_t)v16[k] : 0;
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if(k < n) __hip_atomic_store(v32 + k, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // (as GlobalVal's own stores: the loop below reads them back)
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
 		const int32_t zero[4] = {0, 0, 0, 0};
 		const GlobalVal<int32_t> gval{as_global((int32_t *)J.values), N};
 		(void)delta_window_run(gval, GraphLds{gw, ga}, nvert, J.parallelogram != 0, zero);

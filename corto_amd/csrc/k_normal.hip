@@ -238,6 +238,12 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		if(f16) { a = f16[3*(size_t)f]; b = f16[3*(size_t)f + 1]; c = f16[3*(size_t)f + 2]; }
 		else { a = f32[3*(size_t)f]; b = f32[3*(size_t)f + 1]; c = f32[3*(size_t)f + 2]; }
 	};
+	// the correction of diff-stream slot `rank`: two int32, or (K-BIT wrote halfwords: every width of the stream <= 16 bits) two int16 in one dword
+	const bool diffs_i16 = J.diffs_i16 != 0;
+	auto diff_at = [&](uint32_t rank, int32_t &dx, int32_t &dy) {
+		if(diffs_i16) { const uint32_t w = ((CRT_GLOBAL const uint32_t *)as_global(J.diffs))[rank]; dx = (int32_t)(int16_t)(w & 0xFFFFu); dy = (int32_t)(int16_t)(w >> 16); }
+		else { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)rank; dx = dp[0]; dy = dp[1]; }
+	};
 	for(uint32_t i = tid; i < nv; i += 256) bnd[i] = 0;
 	for(uint32_t i = tid; i < ncur/2; i += 256) cur32[i] = 0;
 	__syncthreads();
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 		const uint32_t rank = fp + (uint32_t)__popc(fw & ((1u << (i & 31u)) - 1u));
 		const bool has_diff = flagged && rank < J.ndiffs;
 		int32_t pdx = 0, pdy = 0;
-		if(J.ndiffs) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)(has_diff ? rank : 0u); pdx = dp[0]; pdy = dp[1]; }
+		if(J.ndiffs) diff_at(has_diff ? rank : 0u, pdx, pdy);
 		float ex = 0.f, ey = 0.f, ez = 0.f;
 		const bool wide = fn_any && __any(deg > 8 && deg <= HEAVY);          // (uniform) somebody in this wave needs the 16-wide network
 		if(fn_any && deg > HEAVY) continue;                                  // the wave's job, below
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(256) void k_normal_blob(const NormalJob *__restrict
 					const uint32_t rank = fp + (uint32_t)__popc(fw & ((1u << (v & 31u)) - 1u));
 					const bool has_diff = flagged && rank < J.ndiffs;
 					int32_t pdx = 0, pdy = 0;
-					if(has_diff) { CRT_GLOBAL const int32_t *dp = as_global(J.diffs) + 2*(size_t)rank; pdx = dp[0]; pdy = dp[1]; }
+					if(has_diff) diff_at(rank, pdx, pdy);
 					finish(v, ex, ey, ez, flagged, has_diff, pdx, pdy);
 				}
 			}

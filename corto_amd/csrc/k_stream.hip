@@ -216,8 +216,12 @@ constexpr uint32_t UW_R = 4;                                                // r
 // every window two 64-bit compares, a 64-bit shift and two 64-bit address computations - a third of the kernel's vector instructions, and
 // the pipelined rate is within 2x of the chip's VALU issue rate.
 __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict__ jobs, const uint32_t *__restrict__ job_ids, uint32_t njobs) {
-	if(blockIdx.x >= njobs) return;                                             // (one stream a workgroup of one wave; four streams a workgroup was measured level in round 4)
-	const uint32_t jid = job_ids[blockIdx.x];
+	// (one stream a workgroup of one wave; four streams a workgroup was measured level in round 4)
+	// XCD-aware slots (kernels_common.h): the streams of one attribute are consecutive jobs - the four colour components write the bytes of the SAME lines
+	// (out[4*i + comp]), and every stream re-adds the logs of the ones in front of it: through one L2, a C4 launch's WRITE_SIZE 23.5 -> 13.1 MB, FETCH_SIZE 5.8 -> 3.5
+	const uint32_t slot = xcd_slot(blockIdx.x, njobs);
+	if(slot >= njobs) return;
+	const uint32_t jid = job_ids[slot];
 	const UnpackJob J = jobs[jid];
 	const uint32_t lane = threadIdx.x, count = J.count, fields = J.fields;
 	CRT_GLOBAL const uint8_t *logs = as_global(J.logs);
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 	};
 	const bool values = (J.mode & 1u) != 0;
 	const uint32_t stride = J.stride, comp = J.comp, out_limit = J.out_limit;
-	const bool out_u8 = J.out_u8 != 0;
+	const bool out_u8 = J.out_u8 == 1, out_i16 = J.out_u8 == 2;              // (2: every width of the stream is <= 16 bits - its table says so, plan_jobs.cpp - and K-DELTA / K-NRM read int16)
 	for(uint32_t base = 0; base < count; base += UW_R*64u) {
 		// this block's widths and bit offsets (a scan per round, the cursor a scalar), then the next block's logs go out before the windows
 		uint32_t d[UW_R], at[UW_R];
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 				v = v < mid ? -v - mid : v;
 				if(i < count && i < out_limit) {
 					if(out_u8) as_global((uint8_t *)J.out)[i*stride + comp] = (uint8_t)v;
+					else if(out_i16) as_global((int16_t *)J.out)[i*stride + comp] = (int16_t)v;
 					else as_global((int32_t *)J.out)[i*stride + comp] = v;
 				}
 			}
@@ -326,11 +331,21 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 					const uint32_t i = base + (g + k)*64u + lane, dd = d[g + k];
 					const bool store = i < count && i < out_limit;
 					CRT_GLOBAL int32_t *out = as_global((int32_t *)J.out) + i*stride;
+					CRT_GLOBAL int16_t *out16 = as_global((int16_t *)J.out) + i*stride;
 					const uint32_t half = (uint32_t)((int32_t)(1u << (dd & 31u)) >> 1);   // upstream's `(1<<diff)>>1` in INT (cstream.h:343): 0 at dd = 32 (shift count mod 32), -2^30 at dd = 31 (arithmetic shift of INT_MIN), as k_unpack_extract
 					if(fast) {
 						int32_t v[4];
 #pragma unroll
 						for(uint32_t f = 0; f < 4; f++) v[f] = (int32_t)(field(INSIDE, at[g + k] + (f < fields ? f : 0u)*dd, dd, hi[k][f], lo[k][f]) - half);
+						if(store && out_i16) {                                       // halfwords: the vertex' record is 2-byte aligned (4 when it has two or four fields)
+							typedef int16_t i16x2_t __attribute__((ext_vector_type(2)));
+							typedef int16_t i16x4_t __attribute__((ext_vector_type(4)));
+							typedef i16x2_t __attribute__((aligned(4))) i16x2u; typedef i16x4_t __attribute__((aligned(4))) i16x4u;
+							if(fields == 3) { out16[0] = (int16_t)v[0]; out16[1] = (int16_t)v[1]; out16[2] = (int16_t)v[2]; }
+							else if(fields == 2) *(CRT_GLOBAL i16x2u *)out16 = i16x2_t{(int16_t)v[0], (int16_t)v[1]};
+							else if(fields == 4) *(CRT_GLOBAL i16x4u *)out16 = i16x4_t{(int16_t)v[0], (int16_t)v[1], (int16_t)v[2], (int16_t)v[3]};
+							else out16[0] = (int16_t)v[0];
+						} else
 						if(store) {                                                  // one vector store a vertex (the caller's ints are 4-byte aligned)
 							typedef int32_t i32x2_t __attribute__((ext_vector_type(2)));
 							typedef int32_t i32x3_t __attribute__((ext_vector_type(3)));
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(64) void k_unpack_wave(const UnpackJob *__restrict_
 						for(uint32_t f = 0; f < fields; f++) {
 							const int32_t v = dd ? (int32_t)(bit_field(words, nwords, (uint64_t)oo, dd) - half) : 0;
 							oo += dd;
-							if(store) out[f] = v;
+							if(store) { if(out_i16) out16[f] = (int16_t)v; else out[f] = v; }
 						}
 					}
 				}

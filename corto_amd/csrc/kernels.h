@@ -22,6 +22,8 @@ __global__ void k_tun_decode(const TunStream *streams, const uint32_t *chunk_str
 __host__ __device__ inline uint32_t tun_width(uint32_t cpl, uint32_t maxlen) { return cpl < 8 || maxlen > 8 ? 4u : maxlen > 4 ? 2u : 1u; }
 int launch_tun_decode_staged(hipStream_t stream, const TunStream *streams, const uint32_t *chunk_stream, uint32_t nchunks, const TunTable *tables,
                              uint64_t *chunk_out, uint32_t sums_only);    // words <= 4 bytes, <= 8 bytes, longer: three bodies of one kernel
+// blocks of a launch whose kernel takes its job by xcd_slot() (kernels_common.h: every XCD a contiguous eighth of the jobs)
+inline uint32_t xcd_grid(uint32_t n) { return 8u*((n + 7u) >> 3); }
 __global__ void k_fill(const FillJob *jobs, uint32_t njobs);
 __global__ void k_fill_block(uint8_t *dst, uint64_t bytes, uint32_t value);
 

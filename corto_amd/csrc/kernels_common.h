@@ -42,6 +42,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // inclusive +scan of a u32 across the 64 lanes of a wave with DPP row shifts / row broadcasts (gfx9): six v_add_u32 with a
 // DPP modifier.  The generic __shfl_up version below goes through ds_bpermute (an LDS-pipe round trip per step) and was half
 // of the Tunstall decode kernel's time.
+// XCD-aware job slots.  Block b runs on XCD b % 8 (observed - MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility" - and a matter
+// of speed only: any placement gives the same bytes).  A grid of xcd_grid(n) blocks (kernels.h) gives every XCD a CONTIGUOUS eighth of the n jobs: K-BIT's consecutive
+// jobs are the streams of one attribute, which write neighbouring bytes (the four colour components fill the same lines) and re-read one another's logs - through one
+// L2 instead of four.  (The same eighth of the BLOBS on one XCD in every kernel of a step - K-TOPO, K-DELTA, K-NRM - was measured too: FETCH_SIZE unchanged, nothing
+// survives in an L2 from one kernel to the next; not kept.)
+__device__ __forceinline__ uint32_t xcd_slot(uint32_t block, uint32_t n) { return (block & 7u)*((n + 7u) >> 3) + (block >> 3); }   // >= n: no job (the last eighth's tail)
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
 #define CRT_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false);
 	CRT_DPP_ADD(0x111, 0xf)     // row_shr:1

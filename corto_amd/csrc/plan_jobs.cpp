@@ -171,13 +171,29 @@ int Planner::jobs() {
 				}
 				pl.unpack.v.push_back(u);
 			};
+			// K-BIT hands its values on as int16 where that is PROVEN to hold them: the attribute's log streams are Tunstall-coded and no width in their tables
+			// exceeds 16 bits (decodeArray: v in [-2^(d-1), 2^(d-1)); decodeValues folds the sign the other way: |v| < 2^d, 15 bits), the consumer reads
+			// halfwords (k_delta_lds16 on 16-bit records, k_normal_blob), and the stream goes a wave a stream.  Half the bytes of that round trip through HBM
+			auto widths_fit = [&](const StreamRef &s, uint32_t bits) { return s.mode != STREAM_RAW && s.max_sym <= bits; };
+			bool hand_i16 = false;
+			if(mesh && by_wave && !wide && !ctx->dbg.values_i32 && nvert > 1) {
+				if(a.codec == CRTHIP_CODEC_NORMAL) hand_i16 = as.normal_prediction != 0 && normal_fused(nvert, nface) && widths_fit(as.logs[0], 16);
+				else if(a.codec != CRTHIP_CODEC_COLOR && !bd.stream_values) {
+					DeltaJob probe{};
+					probe.nvert = nvert; probe.N = a.N;
+					hand_i16 = delta_class(probe, wide) >= 2;
+					if(a.strategy & CRTHIP_CORRELATED) hand_i16 = hand_i16 && widths_fit(as.logs[0], 16);
+					else for(uint32_t c = 0; c < a.N && hand_i16; c++) hand_i16 = widths_fit(as.logs[c], 15);
+				}
+			}
+			const uint8_t val_fmt = hand_i16 ? 2 : 0;
 			std::vector<const uint8_t *> &logs = ctx->plan_logs;
 			logs.assign(as.logs.size(), nullptr);
 			for(size_t j = 0; j < as.logs.size(); j++) logs[j] = add_stream(as.logs[j], A.sym[j], bo);
 
 			void *values = nullptr; bool values_real = false; uint8_t is_u8 = 0; uint32_t N = a.N; bool para = false; bool do_delta = true;
 			if(a.codec == CRTHIP_CODEC_NORMAL) {
-				push_unpack(as.logs[0], logs[0], SP(A.diffs), false, 0, 2, 2, 0, 0);
+				push_unpack(as.logs[0], logs[0], SP(A.diffs), false, 0, 2, 2, 0, val_fmt);
 				// a (malformed) stream with fewer diffs than vertices: upstream's vector is zero-filled behind them
 				// (normal_attribute.cpp:180-184)
 				// (only DIFF reads all nvert entries; the other predictions stop at ndiffs)
@@ -195,9 +211,9 @@ int Planner::jobs() {
 				const bool in_scratch = bd.stride || bd.format == CRTHIP_FMT_DOUBLE;
 				void *work = in_scratch ? (void *)SP(A.vals) : bd.buffer;
 				const bool work_real = !in_scratch;
-				if(a.strategy & CRTHIP_CORRELATED) push_unpack(as.logs[0], logs[0], work, work_real, 0, (uint16_t)a.N, (uint16_t)a.N, 0, 0);
+				if(a.strategy & CRTHIP_CORRELATED) push_unpack(as.logs[0], logs[0], work, work_real, 0, (uint16_t)a.N, (uint16_t)a.N, 0, val_fmt);
 				else for(uint32_t c = 0; c < a.N; c++) push_unpack(as.logs[c], logs[c], work, work_real, 1, 1, (uint16_t)a.N, (uint16_t)c,
-					0);
+					val_fmt);
 				values = work; values_real = work_real; para = (a.strategy & CRTHIP_PARALLEL) != 0;
 				// the device half of a caller-supplied codec object (CRTHIP_BIND_STREAM_VALUES): the stream's int32 values stay as they are -
 				// GenericAttr<int>::decode's result (vertex_attribute.h:151-156); deltaDecode / dequantize are the caller's, on the host
@@ -209,8 +225,8 @@ int Planner::jobs() {
 					DeltaJob d{};
 					d.values = values; d.pred = (const uint32_t *)SP(S.pred); d.nvert = nvert; d.N = N;
 					// pad[1]: 32-bit records in LDS (k_delta_lds16)
-					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = values_real; d.pad[1] = wide; d.pad2[0] = ctx->dbg.delta_rounds ?
-						1u : 0u;
+					d.parallelogram = para; d.is_u8 = is_u8; d.pad[0] = (uint8_t)((values_real ? 1 : 0) | (hand_i16 ? 2 : 0)); d.pad[1] = wide; d.pad2[0] = ctx->dbg.delta_rounds ?
+						1u : 0u;                                                // (pad[0] bit 0: `values` is a real pointer - host only; bit 1: int16 raw deltas - what the device sees)
 					// (k_delta_mesh's flags, else - k_delta_tiles - the automaton's progress word)
 					d.fired = A.fired != ~0ull ? SP(A.fired) : S.progress != ~0ull ? SP(S.progress) : nullptr;
 					d.flags = HS(2ull*nblobs + 2ull*i);
@@ -254,7 +270,7 @@ int Planner::jobs() {
 						// bit7: faces is a real pointer, bit6: position is a scratch offset (both cleared at fixup)
 						n.faces_u16 = (uint8_t)((P.index ? P.index_u16 : 0) | (P.index ? 0x80 : 0) | (pos_scratch ? 0x40 : 0));
 						if(normal_fused(nvert, nface)) {
-							n.fused = 1;
+							n.fused = 1; n.diffs_i16 = hand_i16;
 							n.fn_scratch = A.facen != ~0ull ? (float *)SP(A.facen) : nullptr;
 							if(pos_by_normal) { n.pos_out = P.bind[pos_k].buffer; n.pos_stride = P.bind[pos_k].stride ?
 								P.bind[pos_k].stride : 12u; n.pos_q = L.h.attrs[pos_k].q; }

@@ -31,7 +31,7 @@ int Planner::upload() {
 		if(!(u.out_u8 & 0x80)) u.out = R(u.out);
 		u.out_u8 &= 0x7F;
 	}
-	for(auto &d : pl.delta.v) { if(!d.pad[0]) d.values = R(d.values); d.pad[0] = 0; d.pred = (const uint32_t *)R(d.pred);
+	for(auto &d : pl.delta.v) { if(!(d.pad[0] & 1)) d.values = R(d.values); d.pad[0] >>= 1; d.pred = (const uint32_t *)R(d.pred);
 		if(d.fired) d.fired = R(d.fired); d.flags = (int32_t *)R(d.flags); }
 	for(auto &c : pl.cloud.v) { if(!c.pad[0]) c.values = R(c.values); c.pad[0] = 0; }
 	for(auto &n : pl.normal.v) {
@@ -107,7 +107,7 @@ int Planner::launch() {
 	};
 	auto unpack = [&](hipStream_t s) {
 		const uint32_t nuw = (uint32_t)pl.unpack_wave_ids.v.size();
-		if(nuw) { LT.begin("unpack_wave", s); hipLaunchKernelGGL(k_unpack_wave, dim3(nuw), dim3(64), 0, s, D(pl.unpack),
+		if(nuw) { LT.begin("unpack_wave", s); hipLaunchKernelGGL(k_unpack_wave, dim3(xcd_grid(nuw)), dim3(64), 0, s, D(pl.unpack),
 			D(pl.unpack_wave_ids), nuw); LT.end(); }
 		if(!unpack_chunks) return;
 		LT.begin("unpack_extract", s); hipLaunchKernelGGL(k_unpack_extract, dim3(unpack_chunks), dim3(256), 0, s, D(pl.unpack),
@@ -278,6 +278,8 @@ void Planner::account() {
 		ntun; b->stats.tunstall_dictionaries = (uint32_t)stat_dicts;
 	b->stats.scratch_bytes = pl.total;
 	b->stats.descriptor_bytes = (uint32_t)pl.jobs_bytes;
+	b->stats.int16_streams = 0;
+	for(const UnpackJob &u : pl.unpack.v) b->stats.int16_streams += u.out_u8 == 2;
 	b->stats.topology_scale = std::max(ctx->topo_scale, (ctx->topo_pool_q8 + 7)/8); b->stats.delta_wide = wide ? 1u : 0u;
 	uint64_t ob = 0;
 	for(auto &P : b->blobs) {

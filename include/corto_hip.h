@@ -343,6 +343,8 @@ typedef struct {
 	                               fallback was a walk along the stretches of the prediction graph) */
 	uint32_t delta_wide;        /* 1: this decode was planned with 32-bit values in K-DELTA's LDS (the context had met such blobs, or $CORTO_DELTA_WIDE=1) */
 	uint32_t descriptor_bytes;  /* the job descriptors of the last decode: one host -> HBM copy beside the blobs' own bytes (it shares their PCIe link) */
+	uint32_t int16_streams;     /* log streams of the last decode whose values K-BIT handed on as int16 instead of int32: the stream's probability table holds no
+	                               width above 16 bits (15 for per-component streams), and the reader is the LDS-resident K-DELTA / K-NRM ($CORTO_VALUES_I32=1: none) */
 } crthip_batch_stats;
 int crthip_batch_get_stats(const crthip_batch *b, crthip_batch_stats *s);
 

@@ -109,11 +109,12 @@ def test_bit_unpack_one_wave_per_stream_and_chunked(monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"CORTO_DELTA_WIDE": "1"}, {"CORTO_UNPACK_CHUNKED": "1"}, {"CORTO_DELTA_WIDE": "1", "CORTO_TUN_SHARE": "2"}, {"CORTO_DELTA_ROUNDS": "1"},
-                                 {"CORTO_DELTA_ROUNDS": "1", "CORTO_DELTA_WIDE": "1"}],
+                                 {"CORTO_DELTA_ROUNDS": "1", "CORTO_DELTA_WIDE": "1"}, {"CORTO_VALUES_I32": "1"}],
                          ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
 def test_context_settings_are_bit_exact(monkeypatch, env):
     """csrc/debug_config.h: the settings a context reads select other kernel paths for the same bytes (32-bit records in K-DELTA's LDS -
-    what a context learns from values beyond int16 -, the chunked K-BIT, one dictionary per stream) - every fixture and the 16 C4 blobs
+    what a context learns from values beyond int16 -, the chunked K-BIT, one dictionary per stream, K-BIT handing 32-bit values on where it would
+    hand int16 ones) - every fixture and the 16 C4 blobs
     through each, on a two-stream and on a single-stream context.  (The experiment switches of rounds 2-3 were removed with their kernels.)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -1812,3 +1813,42 @@ def test_delta_values_beyond_int16_are_redone_and_the_context_learns():
     b2 = run_batch(ca.Context(0), blobs[:1] + blobs[2:3], color_components=4)
     assert b2.stats().delta_wide == 0 and b2.stats().delta_redone == 0
     b2.close(); c.close()
+
+
+def test_bit_unpack_hands_int16_values_on_where_the_tables_prove_them(monkeypatch):
+    """K-BIT (k_unpack_wave) writes an attribute's raw deltas as int16 when the probability table of its log stream holds no width above 16 bits (decodeArray,
+    cstream.h:337-357: v in [-2^(d-1), 2^(d-1)); the per-component decodeValues folds the sign the other way: 15) and the reader is k_delta_lds16 / k_normal_blob
+    (plan_jobs.cpp; crthip_batch_stats.int16_streams) - half the bytes of that trip through HBM.  A finely tessellated sphere at 18 bits has small deltas and a large
+    extent: int16 in, relative values beyond int16 - K-DELTA widens the halfwords in place and redoes the attribute on 32-bit values.  Streams with wider
+    fields (the 31-bit fixture) and the wide plan of a context that has learnt stay 32-bit.  Same bytes as the oracle and as $CORTO_VALUES_I32=1."""
+    from corto_amd import synth
+    fine = ca.encode(synth.bumpy_sphere(120, 60, seed=3), position_bits=18, uv_bits=12, normal_bits=10, normal_prediction=ca.BORDER)
+    c4 = ca.encode(synth.bumpy_sphere(64, 32, seed=1), position_bits=14, uv_bits=12, normal_bits=10, normal_prediction=ca.ESTIMATED)
+    f31 = load_golden("fields31")["crt"]
+    blobs = [fine, c4, f31]
+    refs = [oc.decode(b_, color_components=4) for b_ in blobs]
+    c = ca.Context(0)
+    b = run_batch(c, blobs[:1], color_components=4)
+    st = b.stats()
+    assert st.int16_streams >= 2 and st.delta_redone == 1 and st.delta_wide == 0, (st.int16_streams, st.delta_redone)      # positions + uv + normal corrections as halfwords; the positions redone
+    assert_same(b.host_outputs(0), refs[0], KEYS, "fine sphere, 18 bits: int16 deltas widened in place")
+    b.close()
+    b = run_batch(c, blobs, color_components=4)                             # the context has learnt: 32-bit records, 32-bit values (the corrections of the normals stay halfwords)
+    assert b.stats().delta_wide == 1
+    for i, r in enumerate(refs):
+        assert_same(b.host_outputs(i), r, KEYS, "blob %d, wide plan" % i)
+    b.close(); c.close()
+    c = ca.Context(0)
+    b = run_batch(c, blobs[1:], color_components=4)
+    n16 = b.stats().int16_streams
+    assert n16 >= 3                                                          # the C4-like blob's positions, uv and corrections; not the 31-bit fields
+    for i, r in enumerate(refs[1:]):
+        assert_same(b.host_outputs(i), r, KEYS, "blob %d, narrow plan" % (i + 1))
+    b.close(); c.close()
+    monkeypatch.setenv("CORTO_VALUES_I32", "1")
+    c = ca.Context(0)
+    b = run_batch(c, blobs, color_components=4)
+    assert b.stats().int16_streams == 0
+    for i, r in enumerate(refs):
+        assert_same(b.host_outputs(i), r, KEYS, "blob %d, 32-bit values" % i)
+    b.close(); c.close()
